@@ -1,0 +1,285 @@
+"""TEST INFRASTRUCTURE ONLY.  Generates tests/golden/*.npz by running the UNMODIFIED
+reference (NVIDIA-Merlin/Transformers4Rec at /root/reference, imported through
+oracle/ref_standins.py) on CPU fp32 with fixed seeds.
+
+    python oracle/make_golden.py            # (re)writes tests/golden/*.npz
+
+The fixtures pin the oracle (oracle/t4r_oracle.py) and, through it and directly, the HIP
+path.  /root/reference is absent on the GPU box, so only the .npz files travel.
+
+Conventions inside each .npz
+  in/<feature>            model inputs  [B,L]
+  p/<state_dict key>      every parameter/buffer of the reference model (state_dict names;
+                          aliases of one tensor stored once; *_eval/*_infer cases reuse the
+                          parameters of the matching *_train file)
+  draw/bern, draw/j1, draw/j2, draw/neg   recorded torch.bernoulli / torch.multinomial draws
+  out/mask_schema, out/masked_targets, out/inputs_embeds, out/hidden,
+  out/predictions, out/labels, out/loss
+  g/<state_dict key>      d loss / d param   (training cases)
+  meta/*                  scalars (n_head, d_model, eps, ...)
+Weights are re-drawn N(0, 0.1) (biases N(0,0.1), LN weight 1+N(0,0.1)) so that indexing
+mistakes are visible far above fp32 rounding; dropout=0.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_standins as rs  # noqa: E402
+from ref_standins import ColumnSchema, Schema, Tags, _IntDomain, _ValueCount  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+class DrawRecorder:
+    """Records torch.bernoulli / torch.multinomial results while the reference runs."""
+
+    def __init__(self):
+        self.bern, self.multi = [], []
+
+    def __enter__(self):
+        self._b, self._m = torch.bernoulli, torch.multinomial
+
+        def bern(*a, **k):
+            r = self._b(*a, **k)
+            self.bern.append(r.clone())
+            return r
+
+        def multi(*a, **k):
+            r = self._m(*a, **k)
+            self.multi.append(r.clone())
+            return r
+
+        torch.bernoulli, torch.multinomial = bern, multi
+        return self
+
+    def __exit__(self, *exc):
+        torch.bernoulli, torch.multinomial = self._b, self._m
+
+
+def make_schema(V, L, cats=(), conts=()):
+    cols = [ColumnSchema("item_id", tags=[Tags.CATEGORICAL, Tags.ITEM_ID, Tags.LIST, Tags.ITEM],
+                         int_domain=_IntDomain(0, V), value_count=_ValueCount(1, L))]
+    for name, card in cats:
+        cols.append(ColumnSchema(name, tags=[Tags.CATEGORICAL, Tags.LIST],
+                                 int_domain=_IntDomain(0, card), value_count=_ValueCount(1, L)))
+    for name in conts:
+        cols.append(ColumnSchema(name, tags=[Tags.CONTINUOUS, Tags.LIST],
+                                 value_count=_ValueCount(1, L)))
+    return Schema(cols)
+
+
+def synth_inputs(B, L, V, cats, conts, seed, min_len=1):
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(min_len, L + 1, (B,), generator=g)
+    lens[0] = L  # a full-length session
+    lens[1] = max(min_len, 2)
+    m = torch.arange(L)[None] < lens[:, None]
+    x = {"item_id": torch.randint(1, V + 1, (B, L), generator=g) * m}
+    for name, card in cats:
+        x[name] = torch.randint(1, card + 1, (B, L), generator=g) * m
+    for name in conts:
+        x[name] = torch.rand((B, L), generator=g) * m
+    return x
+
+
+def reinit(model, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "layer_norm" in n and n.endswith("weight"):
+                p.copy_(1 + 0.1 * torch.randn(p.shape, generator=g))
+            else:
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+
+
+def build(tr, V, L, d_model, n_head, n_layer, cats=(), conts=(), masking="mlm",
+          aggregation="concat", d_output=None, embedding_dims=None, emb_default=None,
+          weight_tying=True, sampled_softmax=False, max_n_samples=100, seed=0):
+    schema = make_schema(V, L, cats, conts)
+    kw = dict(max_sequence_length=L, masking=masking, aggregation=aggregation)
+    if d_output:
+        kw["d_output"] = d_output
+    if conts:
+        kw["continuous_soft_embeddings"] = True
+    if embedding_dims:
+        kw["embedding_dims"] = embedding_dims
+    if emb_default:
+        kw["embedding_dim_default"] = emb_default
+    torch.manual_seed(seed)
+    inputs = tr.TabularSequenceFeatures.from_schema(schema, **kw)
+    cfg = tr.XLNetConfig.build(d_model=d_model, n_head=n_head, n_layer=n_layer,
+                               total_seq_length=L, dropout=0.0)
+    task = tr.NextItemPredictionTask(weight_tying=weight_tying, sampled_softmax=sampled_softmax,
+                                     max_n_samples=max_n_samples)
+    model = cfg.to_torch_model(inputs, task)
+    reinit(model, seed + 1)
+    return model
+
+
+def run(model, x, training, testing, want_grads, with_params=True):
+    cap = {}
+    body = model.heads[0].body
+    h0 = body[0].register_forward_hook(lambda m, i, o: cap.__setitem__("inputs_embeds", o.detach().clone()))
+    h1 = body[1].register_forward_hook(lambda m, i, o: cap.__setitem__("hidden", o.detach().clone()))
+    model.zero_grad(set_to_none=True)
+    with DrawRecorder() as rec:
+        out = model({k: v.clone() for k, v in x.items()}, training=training, testing=testing)
+    h0.remove()
+    h1.remove()
+    d = {}
+    for k, v in x.items():
+        d["in/" + k] = v.numpy()
+    seen = set()
+    for k, v in model.state_dict().items():
+        # the same tensor is registered under several names; keep the first
+        if not with_params or v.data_ptr() in seen:
+            continue
+        seen.add(v.data_ptr())
+        d["p/" + k] = v.detach().numpy().copy()
+    masking = body[0].masking
+    d["out/mask_schema"] = masking.mask_schema.numpy()
+    d["out/masked_targets"] = masking.masked_targets.numpy()
+    d["out/inputs_embeds"] = cap["inputs_embeds"].numpy()
+    d["out/hidden"] = cap["hidden"].numpy()
+    if isinstance(out, dict):
+        d["out/predictions"] = out["predictions"].detach().numpy()
+        d["out/labels"] = out["labels"].numpy()
+        d["out/loss"] = out["loss"].detach().numpy()
+        if want_grads:
+            out["loss"].backward()
+            sd_params = dict(model.named_parameters())
+            for k, p in sd_params.items():
+                if p.grad is not None:
+                    d["g/" + k] = p.grad.numpy().copy()
+    else:
+        d["out/predictions"] = out.detach().numpy()
+    if rec.bern:
+        d["draw/bern"] = rec.bern[0].numpy()
+    mlm = masking.__class__.__name__ == "MaskedLanguageModeling"
+    multi = list(rec.multi)
+    if mlm and training:
+        d["draw/j1"] = multi[0].reshape(-1).numpy()
+        d["draw/j2"] = multi[1].reshape(-1).numpy()
+        multi = multi[2:]
+    if multi:  # sampled softmax: the sampler's multinomial (2n tries)
+        d["draw/neg_tries"] = multi[0].numpy()
+    return d
+
+
+def save(name, d, **meta):
+    for k, v in meta.items():
+        d["meta/" + k] = np.asarray(v)
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **d)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB, loss={d.get('out/loss')}")
+
+
+def main():
+    tr = rs.import_reference()
+    torch.set_num_threads(4)
+    L = 20
+
+    # A: item-id only, MLM train, tied full softmax   (C1/C2 structure, small dims)
+    V, d, nh, nl, B = 300, 32, 2, 2, 12
+    mA = build(tr, V, L, d, nh, nl, emb_default=d, seed=10)
+    xA = synth_inputs(B, L, V, (), (), seed=11)
+    save("xlnet_mlm_item_train", run(mA, xA, True, False, True), n_head=nh, d_model=d,
+         n_layer=nl, eps=0.03, L=L, V=V + 1)
+    # B: same model, eval (last item) and inference (L+1) paths
+    save("xlnet_mlm_item_eval", run(mA, xA, False, True, False, with_params=False), n_head=nh, d_model=d,
+         n_layer=nl, eps=0.03, L=L, V=V + 1)
+    save("xlnet_mlm_item_infer", run(mA, xA, False, False, False, with_params=False), n_head=nh, d_model=d,
+         n_layer=nl, eps=0.03, L=L, V=V + 1)
+
+    # C: multi-feature concat + soft embeddings + ReLU projection + task_block (item dim 16 != d)
+    cats, conts = (("category", 40), ("brand", 9)), ("price", "age")
+    mC = build(tr, V, L, d, nh, nl, cats=cats, conts=conts, d_output=d,
+               embedding_dims={"item_id": 16, "category": 24, "brand": 8}, seed=20)
+    xC = synth_inputs(B, L, V, cats, conts, seed=21)
+    save("xlnet_mlm_multi_train", run(mC, xC, True, False, True), n_head=nh, d_model=d,
+         n_layer=nl, eps=0.03, L=L, V=V + 1)
+
+    # D: CLM (XLNet-bi + CLM, as the reference's own fixtures), untied output layer
+    mD = build(tr, V, L, d, nh, nl, masking="clm", emb_default=d, weight_tying=False, seed=30)
+    xD = synth_inputs(B, L, V, (), (), seed=31, min_len=2)
+    save("xlnet_clm_item_train", run(mD, xD, True, False, True), n_head=nh, d_model=d,
+         n_layer=nl, eps=0.03, L=L, V=V + 1)
+    save("xlnet_clm_item_eval", run(mD, xD, False, True, False, with_params=False), n_head=nh, d_model=d,
+         n_layer=nl, eps=0.03, L=L, V=V + 1)
+    save("xlnet_clm_item_infer", run(mD, xD, False, False, False, with_params=False), n_head=nh, d_model=d,
+         n_layer=nl, eps=0.03, L=L, V=V + 1)
+
+    # E: element-wise-sum aggregation + sampled softmax (tied)
+    catsE = (("category", 40),)
+    mE = build(tr, V, L, d, nh, 1, cats=catsE, aggregation="element-wise-sum", emb_default=d,
+               sampled_softmax=True, max_n_samples=20, seed=40)
+    xE = synth_inputs(B, L, V, catsE, (), seed=41)
+    save("xlnet_mlm_sum_sampled_train", run(mE, xE, True, False, True), n_head=nh, d_model=d,
+         n_layer=1, eps=0.03, L=L, V=V + 1, max_n_samples=20)
+
+    # F: masking-only integer fixture, many rows (lengths 1..L incl. full rows)
+    Bm = 96
+    msk = tr.masking.MaskedLanguageModeling(hidden_size=4, mlm_probability=0.3)
+    xF = synth_inputs(Bm, L, 5000, (), (), seed=51)["item_id"]
+    dF = {"in/item_id": xF.numpy()}
+    with DrawRecorder() as rec:
+        info = msk._compute_masked_targets(xF, training=True)
+    dF["draw/bern"] = rec.bern[0].numpy()
+    dF["draw/j1"] = rec.multi[0].reshape(-1).numpy()
+    dF["draw/j2"] = rec.multi[1].reshape(-1).numpy()
+    dF["out/mask_schema"], dF["out/masked_targets"] = info.schema.numpy(), info.targets.numpy()
+    for tag, kw in (("eval_last", dict(testing=True)), ("infer", dict())):
+        info = msk._compute_masked_targets(xF, training=False, **kw)
+        dF[f"out/{tag}_schema"], dF[f"out/{tag}_targets"] = info.schema.numpy(), info.targets.numpy()
+    msk_all = tr.masking.MaskedLanguageModeling(hidden_size=4, eval_on_last_item_seq_only=False)
+    info = msk_all._compute_masked_targets(xF, training=False, testing=True)
+    dF["out/eval_all_schema"], dF["out/eval_all_targets"] = info.schema.numpy(), info.targets.numpy()
+    xF2 = synth_inputs(Bm, L, 5000, (), (), seed=52, min_len=2)["item_id"]
+    dF["in/item_id_clm"] = xF2.numpy()
+    for tag, ckw, fkw in (
+        ("clm_train", {}, dict(training=True)),
+        ("clm_train_last", dict(train_on_last_item_seq_only=True), dict(training=True)),
+        ("clm_eval_last", {}, dict(testing=True)),
+        ("clm_eval_all", dict(eval_on_last_item_seq_only=False), dict(testing=True)),
+        ("clm_infer", {}, {}),
+    ):
+        c = tr.masking.CausalLanguageModeling(hidden_size=4, **ckw)
+        info = c._compute_masked_targets(xF2, **fkw)
+        dF[f"out/{tag}_schema"], dF[f"out/{tag}_targets"] = info.schema.numpy(), info.targets.numpy()
+    save("masking_int", dF, mlm_probability=0.3, L=L)
+
+    # G: ragged -> padded through the reference's pad_inputs (random ragged batch)
+    from transformers4rec.torch.utils.padding import pad_batch, pad_inputs
+
+    g = torch.Generator().manual_seed(60)
+    lens = torch.randint(0, 31, (40,), generator=g)
+    offs = torch.cat([torch.zeros(1, dtype=torch.int64), lens.cumsum(0)])
+    vals = torch.randint(1, 1000, (int(offs[-1]),), generator=g)
+    fvals = torch.rand(int(offs[-1]), generator=g)
+    dG = {"in/values": vals.numpy(), "in/fvalues": fvals.numpy(), "in/offsets": offs.numpy()}
+    for msl in (None, 20, 64):
+        o = pad_inputs({"a__values": vals, "a__offsets": offs, "f__values": fvals,
+                        "f__offsets": offs}, msl)
+        dG[f"out/pad_inputs_{msl}_a"] = o["a"].numpy()
+        dG[f"out/pad_inputs_{msl}_f"] = o["f"].numpy()
+    o = pad_batch({"a__values": vals, "a__offsets": offs}, {"a": 7})
+    dG["out/pad_batch_7"] = o["a"].numpy()
+    o = pad_batch({"a__values": vals, "a__offsets": offs}, {"a": 45})
+    dG["out/pad_batch_45"] = o["a"].numpy()
+    save("padding", dG)
+
+    # H: log-uniform sampler distributions
+    from transformers4rec.torch.model.prediction_task import LogUniformSampler
+
+    s = LogUniformSampler(max_n_samples=20, max_id=301, min_id=1)
+    save("log_uniform", {"out/dist": s.dist.numpy(), "out/unique_dist": s.unique_sampling_dist.numpy()},
+         max_id=301, min_id=1, n_sample=40)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,205 @@
+"""Pins the oracle (oracle/t4r_oracle.py) against fixtures produced by the unmodified
+reference (oracle/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+import golden_utils as gu
+import t4r_oracle as O
+
+TOL = dict(rtol=2e-5, atol=2e-5)
+
+
+def _inputs(d):
+    return {k[3:]: gu.t(v) for k, v in d.items() if k.startswith("in/")}
+
+
+def _cfg(d, **kw):
+    c = dict(n_head=int(d["meta/n_head"]), eps=float(d["meta/eps"]), item="item_id")
+    c.update(kw)
+    return c
+
+
+def _replay_mlm(d):
+    ids = gu.t(d["in/item_id"])
+    j2 = gu.t(d["draw/j2"])
+    return O.mlm_targets_train(ids, gu.t(d["draw/bern"]), gu.t(d["draw/j1"]), lambda m: j2)
+
+
+# ----------------------------------------------------------------------------- integer paths
+def test_masking_int_bit_exact():
+    d = gu.load("masking_int")
+    ids = gu.t(d["in/item_id"])
+    j2 = gu.t(d["draw/j2"])
+    m, lab = O.mlm_targets_train(ids, gu.t(d["draw/bern"]), gu.t(d["draw/j1"]), lambda _: j2)
+    assert torch.equal(m, gu.t(d["out/mask_schema"]))
+    assert torch.equal(lab, gu.t(d["out/masked_targets"]))
+    m, lab = O.mlm_targets_eval(ids, True)
+    assert torch.equal(m, gu.t(d["out/eval_last_schema"])) and torch.equal(lab, gu.t(d["out/eval_last_targets"]))
+    m, lab = O.mlm_targets_eval(ids, False)
+    assert torch.equal(m, gu.t(d["out/eval_all_schema"])) and torch.equal(lab, gu.t(d["out/eval_all_targets"]))
+    m, lab = O.mlm_targets_inference(ids)
+    assert torch.equal(m, gu.t(d["out/infer_schema"])) and torch.equal(lab, gu.t(d["out/infer_targets"]))
+    ids2 = gu.t(d["in/item_id_clm"])
+    for tag, kw in (
+        ("clm_train", dict(training=True, testing=False)),
+        ("clm_train_last", dict(training=True, testing=False, train_on_last_item_seq_only=True)),
+        ("clm_eval_last", dict(training=False, testing=True)),
+        ("clm_eval_all", dict(training=False, testing=True, eval_on_last_item_seq_only=False)),
+        ("clm_infer", dict(training=False, testing=False)),
+    ):
+        m, lab = O.clm_targets(ids2, **kw)
+        assert torch.equal(m, gu.t(d[f"out/{tag}_schema"])), tag
+        assert torch.equal(lab, gu.t(d[f"out/{tag}_targets"])), tag
+
+
+def test_padding_golden():
+    d = gu.load("padding")
+    vals, fvals, offs = gu.t(d["in/values"]), gu.t(d["in/fvalues"]), gu.t(d["in/offsets"])
+    for msl in (None, 20, 64):
+        L = O.pad_inputs_length([offs], msl)
+        assert torch.equal(O.pad_ragged(vals, offs, L), gu.t(d[f"out/pad_inputs_{msl}_a"]))
+        assert torch.equal(O.pad_ragged(fvals, offs, L), gu.t(d[f"out/pad_inputs_{msl}_f"]))
+    assert torch.equal(O.pad_ragged(vals, offs, 7), gu.t(d["out/pad_batch_7"]))
+    assert torch.equal(O.pad_ragged(vals, offs, 45), gu.t(d["out/pad_batch_45"]))
+
+
+def test_padding_reference_known_answers():
+    """The reference's own known-answer vectors, tests/unit/utils/test_padding.py:33-151."""
+    def vo(data):
+        vals = [x for row in data for x in row]
+        offs = np.cumsum([0] + [len(r) for r in data])
+        return torch.tensor(vals, dtype=torch.int64), torch.tensor(offs, dtype=torch.int64)
+
+    v, o = vo([[1, 2], [], [3, 4, 5]])
+    assert O.pad_ragged(v, o, 7).tolist() == [[1, 2, 0, 0, 0, 0, 0], [0] * 7, [3, 4, 5, 0, 0, 0, 0]]
+    v, o = vo([[1, 2], [], [3, 4, 5, 4, 7]])
+    assert O.pad_ragged(v, o, 3).tolist() == [[1, 2, 0], [0, 0, 0], [3, 4, 5]]
+    v, o = vo([[1, 2, 3, 4, 5], [6, 7, 8]])
+    assert O.pad_ragged(v, o, O.pad_inputs_length([o])).tolist() == [[1, 2, 3, 4, 5], [6, 7, 8, 0, 0]]
+    v, o = vo([[1, 2, 3, 4, 5], [6, 7, 8, 9]])
+    assert O.pad_ragged(v, o, O.pad_inputs_length([o], 3)).tolist() == [[1, 2, 3], [6, 7, 8]]
+
+
+def test_log_uniform_golden():
+    d = gu.load("log_uniform")
+    dist = O.log_uniform_dist(int(d["meta/max_id"]), int(d["meta/min_id"]))
+    assert torch.equal(dist, gu.t(d["out/dist"]))
+    assert torch.equal(O.unique_sampling_dist(dist, int(d["meta/n_sample"])), gu.t(d["out/unique_dist"]))
+
+
+# ----------------------------------------------------------------------------- float paths
+@pytest.mark.parametrize("name,masking,agg", [
+    ("xlnet_mlm_item_train", "mlm", "concat"),
+    ("xlnet_mlm_multi_train", "mlm", "concat"),
+    ("xlnet_clm_item_train", "clm", "concat"),
+])
+def test_train_forward_backward_golden(name, masking, agg):
+    d = gu.load(name)
+    x = _inputs(d)
+    ids = x["item_id"]
+    if masking == "mlm":
+        m, lab = _replay_mlm(d)
+    else:
+        m, lab = O.clm_targets(ids, True, False)
+    assert torch.equal(m, gu.t(d["out/mask_schema"])) and torch.equal(lab, gu.t(d["out/masked_targets"]))
+    p = gu.oracle_params(d, requires_grad=True)
+    out = O.session_forward(p, _cfg(d, masking=masking, aggregation=agg), x, m, lab, True, False)
+    torch.testing.assert_close(out["inputs_embeds"], gu.t(d["out/inputs_embeds"]), **TOL)
+    torch.testing.assert_close(out["hidden"], gu.t(d["out/hidden"]), **TOL)
+    assert torch.equal(out["labels"], gu.t(d["out/labels"]))
+    torch.testing.assert_close(out["logits"], gu.t(d["out/predictions"]), **TOL)
+    torch.testing.assert_close(out["loss"], gu.t(d["out/loss"]), **TOL)
+    out["loss"].backward()
+    g = gu.section(d, "g/")
+    item = p["tables"]["item_id"]
+    torch.testing.assert_close(item.grad, g[gu.CAT + "item_id.weight"], **TOL)
+    torch.testing.assert_close(p["masked_item_embedding"].grad,
+                               g["heads.0.body.0._masking.masked_item_embedding"], **TOL)
+    for i, lp in enumerate(p["layers"]):
+        b = gu.XL + f"{i}."
+        for ok, rk in (("q", "rel_attn.q"), ("k", "rel_attn.k"), ("v", "rel_attn.v"),
+                       ("o", "rel_attn.o"), ("r", "rel_attn.r"), ("r_w_bias", "rel_attn.r_w_bias"),
+                       ("r_r_bias", "rel_attn.r_r_bias"), ("ln_w", "rel_attn.layer_norm.weight"),
+                       ("ln_b", "rel_attn.layer_norm.bias"), ("w1", "ff.layer_1.weight"),
+                       ("b1", "ff.layer_1.bias"), ("w2", "ff.layer_2.weight"),
+                       ("b2", "ff.layer_2.bias"), ("ff_ln_w", "ff.layer_norm.weight"),
+                       ("ff_ln_b", "ff.layer_norm.bias")):
+            torch.testing.assert_close(lp[ok].grad, g[b + rk], **TOL, msg=f"layer {i} {ok}")
+    if p["proj"] is not None:
+        torch.testing.assert_close(p["proj"][0].grad, g["heads.0.body.0.projection_module.0.0.weight"], **TOL)
+    for f, tup in p["soft"].items():
+        b = gu.CONT + "embedding_tables." + f
+        torch.testing.assert_close(tup[0].grad, g[b + ".projection_layer.weight"], **TOL)
+        torch.testing.assert_close(tup[2].grad, g[b + ".embedding_table.weight"], **TOL)
+        torch.testing.assert_close(tup[3].grad, g[gu.CONT + f"post.feature_layer_norm.{f}.weight"], **TOL)
+    if p["output_layer"] is not None:
+        torch.testing.assert_close(p["output_layer"].grad, g[gu.TASK + "pre.module.output_layer"], **TOL)
+    if p["task_proj"] is not None:
+        torch.testing.assert_close(p["task_proj"][0].grad, g[gu.TASK + "task_block.0.0.weight"], **TOL)
+
+
+@pytest.mark.parametrize("name,params_from,masking", [
+    ("xlnet_mlm_item_eval", "xlnet_mlm_item_train", "mlm"),
+    ("xlnet_clm_item_eval", "xlnet_clm_item_train", "clm"),
+])
+def test_eval_golden(name, params_from, masking):
+    d = gu.load(name, params_from)
+    x = _inputs(d)
+    ids = x["item_id"]
+    m, lab = O.mlm_targets_eval(ids) if masking == "mlm" else O.clm_targets(ids, False, True)
+    assert torch.equal(m, gu.t(d["out/mask_schema"])) and torch.equal(lab, gu.t(d["out/masked_targets"]))
+    p = gu.oracle_params(d)
+    out = O.session_forward(p, _cfg(d, masking=masking), x, m, lab, False, True)
+    torch.testing.assert_close(out["hidden"], gu.t(d["out/hidden"]), **TOL)
+    torch.testing.assert_close(out["logits"], gu.t(d["out/predictions"]), **TOL)
+    torch.testing.assert_close(out["loss"], gu.t(d["out/loss"]), **TOL)
+    assert out["logits"].shape[0] == ids.shape[0]  # one label per session (reference test_model.py:392-407)
+
+
+@pytest.mark.parametrize("name,params_from,masking", [
+    ("xlnet_mlm_item_infer", "xlnet_mlm_item_train", "mlm"),
+    ("xlnet_clm_item_infer", "xlnet_clm_item_train", "clm"),
+])
+def test_inference_golden(name, params_from, masking):
+    d = gu.load(name, params_from)
+    x = _inputs(d)
+    ids = x["item_id"]
+    p = gu.oracle_params(d)
+    emb = O.embedding_lookup(ids, p["tables"]["item_id"])
+    if masking == "mlm":
+        m, lab = O.mlm_targets_inference(ids)
+        xin = O.apply_mask_mlm(emb, m, p["masked_item_embedding"], False, False)
+    else:
+        m, lab = O.clm_targets(ids, False, False)
+        xin = O.apply_mask_clm(emb, m, p["masked_item_embedding"], False, False)
+    assert torch.equal(m, gu.t(d["out/mask_schema"]))
+    torch.testing.assert_close(xin, gu.t(d["out/inputs_embeds"]), **TOL)
+    h = O.xlnet_model(xin, p["layers"], int(d["meta/n_head"]), float(d["meta/eps"]))
+    torch.testing.assert_close(h, gu.t(d["out/hidden"]), **TOL)
+    rows = O.inference_rows(h, ids, masking == "mlm")
+    W = p["tables"]["item_id"] if p["output_layer"] is None else p["output_layer"]
+    torch.testing.assert_close(O.head_logits(rows, W), gu.t(d["out/predictions"]), **TOL)
+
+
+def test_sampled_softmax_golden():
+    d = gu.load("xlnet_mlm_sum_sampled_train")
+    x = _inputs(d)
+    m, lab = _replay_mlm(d)
+    p = gu.oracle_params(d, requires_grad=True)
+    feats = {k: O.embedding_lookup(x[k], tab) for k, tab in p["tables"].items()}
+    xin = O.apply_mask_mlm(O.elementwise_sum(feats), m, p["masked_item_embedding"], True, False)
+    torch.testing.assert_close(xin, gu.t(d["out/inputs_embeds"]), **TOL)
+    h = O.xlnet_model(xin, p["layers"], int(d["meta/n_head"]), float(d["meta/eps"]))
+    xr, y = O.remove_pad_rows(h, lab)
+    n = int(d["meta/max_n_samples"])
+    neg = gu.t(d["draw/neg_tries"]).unique()[:n]  # prediction_task.py:843-845
+    dist = gu.section(d, "p/")[gu.TASK + "pre.module.sampler.unique_sampling_dist"]
+    torch.testing.assert_close(dist, O.unique_sampling_dist(O.log_uniform_dist(int(d["meta/V"]), 1), 2 * n))
+    logits = O.sampled_logits(xr, y, p["tables"]["item_id"], neg, dist)
+    torch.testing.assert_close(logits, gu.t(d["out/predictions"]), **TOL)
+    loss = O.cross_entropy(logits, torch.zeros_like(y))
+    torch.testing.assert_close(loss, gu.t(d["out/loss"]), **TOL)
+    loss.backward()
+    g = gu.section(d, "g/")
+    torch.testing.assert_close(p["tables"]["item_id"].grad, g[gu.CAT + "item_id.weight"], **TOL)

@@ -1,0 +1,197 @@
+/* t4r_hip.h -- C ABI of libt4r_hip.so: the MI355X (gfx950) implementation of the
+ * Transformers4Rec session-sequence hot path
+ *     tr.TabularSequenceFeatures -> tr.TransformerBlock (XLNet) -> tr.NextItemPredictionTask
+ *
+ * The reference (NVIDIA-Merlin/Transformers4Rec) is pure Python over ATen / HuggingFace: it has
+ * NO native FFI for this path.  Each entry point below therefore replaces an ATen/HF *op chain*
+ * of the reference; the chain it replaces is cited as  <reference file>:<lines>  (paths relative
+ * to the reference repository root; "HF" = transformers/models/xlnet/modeling_xlnet.py, the
+ * third-party dependency pinned by requirements/base_external.txt:1).  The Python binding a
+ * maintainer adds is a ctypes stub: see INTEGRATION.md and transformers4rec_amd/_lib.py.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless marked "host"; tensors are dense row-major;
+ *     float = fp32, long = int64 (torch.int64), unsigned char = torch.bool / uint8, int = int32
+ *   - `stream` is a hipStream_t (0 = null stream); all work is enqueued, nothing synchronises
+ *   - return 0 on success; -1 on an argument error, a hipError_t value on a launch error;
+ *     t4r_last_error() gives the message (thread-local)
+ *   - no global mutable state besides the error string and lazily-set kernel attributes;
+ *     callable from any host thread with the right device current
+ *   - "accumulated" outputs are read-modify-write (parameter gradients); everything else is
+ *     overwritten
+ */
+#ifndef T4R_HIP_H
+#define T4R_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int t4r_abi_version(void);
+const char* t4r_last_error(void);
+
+/* ----------------------------------------------------------------------------------------
+ * a1  ragged -> padded
+ * replaces: transformers4rec/torch/utils/padding.py:48-68 (_pad_ragged_tensor: repeat_interleave,
+ *           sparse_coo_tensor().to_dense(), F.pad) and :126-164 (pad_inputs length rule)
+ * out[r, c] = values[offsets[r] + c] if c < min(len_r, L) else 0.   elem_size 4 (fp32) | 8 (int64)
+ * t4r_ragged_max_len writes max_r(len_r) to *out_max (device int) for the
+ * min(max_sequence_length, batch max) rule. */
+int t4r_ragged_max_len(void* stream, const long* offsets, int rows, int* out_max);
+int t4r_ragged_to_padded(void* stream, const void* values, const long* offsets, void* out, int rows,
+                         int L, int elem_size);
+
+/* ----------------------------------------------------------------------------------------
+ * a2,a3,a5,a7,a8,a13  multi-feature embedding gather + aggregation (+ fused masking epilogue)
+ * replaces: features/embedding.py:226-249 (per-feature nn.Embedding lookup),
+ *           tabular/aggregation.py:35-47 (concat in sorted-name order: the host passes `col`),
+ *           :140-157 (element-wise-sum), :162-193 (element-wise-sum-item-multi),
+ *           masking.py:473-498 / :302-337 (apply_mask_to_inputs) when mask_mode != 0.
+ * kind[f] 0: table lookup, input[f] = int64 ids [B*L_in], table[f] = [rows[f], dim[f]]
+ *         1: dense rows, input[f] = fp32 [B*L_in, dim[f]] (soft embeddings, continuous pass-through)
+ * agg 0 concat (col[f] = first output column) | 1 sum | 2 item * sum(others) (item_feat = index)
+ * mask_mode 0 none | 1 MLM (out = mask ? memb : x) | 2 CLM train/eval (mask ? (l==L-1 ? 0 : x) : memb)
+ *           | 3 CLM inference (mask ? x : memb).  L_out = L_in + 1 is the MLM-inference grid
+ *           (position L duplicates L-1 before masking).
+ * host arrays: kind, input, table, dim, col, rows (length n_feat <= 16).
+ * *err_flag (device int, may be NULL) is set to 1 if an id is outside [0, rows). */
+int t4r_seq_features_fwd(void* stream, int n_feat, const int* kind, const void* const* input,
+                         const float* const* table, const int* dim, const int* col, const long* rows,
+                         int agg, int item_feat, int B, int L_in, int L_out, int W, int mask_mode,
+                         const unsigned char* mask, const float* masked_emb, float* out,
+                         int* err_flag);
+/* backward of one table lookup: d_table[id, :] += dout[tok, col:col+dim] for id != padding_idx
+ * (nn.Embedding(padding_idx=0), features/sequence.py:75-81).  d_table accumulated. */
+int t4r_embedding_bwd(void* stream, const float* dout, const long* ids, float* d_table, long ntok,
+                      int W, int col, int dim, long rows, int padding_idx);
+/* masking as its own pass (after the projection MLP), in place on x [B*L, H]; and its backward:
+ * d_memb[H] += sum of dy over replaced tokens (accumulated), dy zeroed there (in place). */
+int t4r_apply_mask_fwd(void* stream, float* x, const unsigned char* mask, const float* masked_emb,
+                       int B, int L, int H, int mode);
+int t4r_apply_mask_bwd(void* stream, float* dy, const unsigned char* mask, float* d_masked_emb, int B,
+                       int L, int H, int mode);
+int t4r_mul(void* stream, const float* a, const float* b, float* out, long n);
+
+/* a4  SoftEmbedding (+ per-feature LayerNorm)
+ * replaces: features/embedding.py:551-556 (Linear(1,K) -> softmax -> weighted sum of E[K,D]) and
+ *           :306-309 / tabular/transformations.py:128-132 (LayerNorm, eps 1e-5).  ln_w NULL = no LN.
+ * K <= 32, D <= 32.  Backward accumulates all parameter gradients. */
+int t4r_soft_embedding_fwd(void* stream, const float* x, const float* proj_w, const float* proj_b,
+                           const float* table, const float* ln_w, const float* ln_b, float* out,
+                           long ntok, int K, int D, float eps);
+int t4r_soft_embedding_bwd(void* stream, const float* dout, const float* x, const float* proj_w,
+                           const float* proj_b, const float* table, const float* ln_w,
+                           float* d_proj_w, float* d_proj_b, float* d_table, float* d_ln_w,
+                           float* d_ln_b, long ntok, int W, int col, int K, int D, float eps);
+
+/* ----------------------------------------------------------------------------------------
+ * a11,a12  masking schema + labels (integer, bit-exact)
+ * replaces: masking.py:376-470 (MLM), :274-300 (CLM), :182-213 (predict_all)
+ * mode 0 MLM train | 1 MLM eval last item | 2 MLM eval all | 3 MLM inference ([B, L+1] outputs)
+ *      4 CLM train/eval all | 5 CLM last item only | 6 CLM inference
+ * MLM train draws: bern [B,L] uint8, j1 [B], j2 [B] = the recorded torch.bernoulli /
+ * torch.multinomial results (parity replay); pass NULL for device Philox draws (seed, offset).
+ * row_count[B] (may be NULL) receives the number of labels per session. */
+int t4r_mask_targets(void* stream, const long* item_ids, int B, int L, int mode, long padding_idx,
+                     const unsigned char* bern, const long* j1, const long* j2,
+                     float mlm_probability, unsigned long long seed, unsigned long long offset,
+                     unsigned char* mask_schema, long* masked_targets, int* row_count);
+/* a17  ordered compaction of label positions
+ * replaces: model/prediction_task.py:436-443 + remove_pad_3d :472-479 (masked_select, row-major)
+ * row_offset[B], *n_labels, label_pos[>= n_labels] (token index b*L+l), labels_compact[>= n_labels] */
+int t4r_compact_labels(void* stream, const long* masked_targets, const int* row_count, int B, int L,
+                       long padding_idx, int* row_offset, int* n_labels, int* label_pos,
+                       long* labels_compact);
+int t4r_gather_rows(void* stream, const float* x, const int* pos, float* out, int n, int D);
+int t4r_scatter_rows_add(void* stream, const float* dout, const int* pos, float* dx, int n, int D);
+/* a21  inference row selection (prediction_task.py:453-461): pos[b] = b*Lgrid + last_item(b) */
+int t4r_last_positions(void* stream, const long* item_ids, int B, int L, int Lgrid, int is_mlm,
+                       long padding_idx, int* pos);
+
+/* ----------------------------------------------------------------------------------------
+ * dense contractions on the fp32 matrix cores (v_mfma_f32_32x32x2_f32)
+ * replaces: every Linear / einsum / mm of the path: block/mlp.py:133-135, HF :253-259,:145,:297-305,
+ *           model/prediction_task.py:664 (+ torch.div by temperature via alpha) and their autograd.
+ * C[M,N] = alpha * op(A) * op(B) (+ epilogue).  transA=0: A is [M,lda] ; 1: A is [K,lda].
+ * transB=0: B is [K,ldb] ; 1: B is [N,ldb].  epilogue 0 none | 1 +bias | 2 gelu(+bias), pre-act
+ * to aux | 3 relu(+bias).  splitk 1: plain; >1 or -1 (auto): fp32 atomics into C (C zeroed first
+ * unless accumulate).  accumulate: C += result.  batch: strided batches. */
+int t4r_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, float alpha,
+                 const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+                 const float* bias, int epilogue, float* aux, long ldaux, int splitk, int accumulate,
+                 int batch, long strideA, long strideB, long strideC);
+
+/* residual + LayerNorm:  y = LN(a + b) (b may be NULL).
+ * replaces: HF :142-152, :297-305 (post-LN), tabular/transformations.py:128-132.
+ * backward recomputes x = a + b; dgamma/dbeta accumulated; dx overwritten (or += if accumulate_dx). */
+int t4r_add_layernorm_fwd(void* stream, const float* a, const float* b, const float* gamma,
+                          const float* beta, float* y, float* mean, float* rstd, int rows, int D,
+                          float eps);
+int t4r_add_layernorm_bwd(void* stream, const float* a, const float* b, const float* gamma,
+                          const float* mean, const float* rstd, const float* dy, float* dx,
+                          float* dgamma, float* dbeta, int rows, int D, int accumulate_dx);
+/* activation backward + bias gradient: mode 0 GELU(erf) on saved pre-activation, 1 ReLU on saved output */
+int t4r_act_bwd_bias(void* stream, const float* dact, const float* pre, float* dpre, float* dbias,
+                     long rows, int N, int mode);
+int t4r_colsum(void* stream, const float* x, float* out, long rows, int N, long ld);
+
+/* ----------------------------------------------------------------------------------------
+ * a15  XLNet relative attention core and the whole layer
+ * replaces: HF XLNetRelativeAttention.rel_attn_core :95-140 (+ rel_shift_bnij :81-93),
+ *           XLNetLayer.forward :308-353 as configured by config/transformer.py:432-482.
+ * q,k,v,out [B*L, n_head*d_head]; k_r [2L, D] = pos_emb @ r; lse [B,n,L]; L <= 64.
+ * backward: d_r_w_bias / d_r_r_bias accumulated, the rest overwritten. */
+int t4r_xlnet_attn_fwd(void* stream, const float* q, const float* k, const float* v, const float* k_r,
+                       const float* r_w_bias, const float* r_r_bias, float* out, float* lse, int B,
+                       int L, int n_head, int d_head);
+long t4r_xlnet_attn_bwd_ws_floats(int B, int L, int D, int n_head);
+int t4r_xlnet_attn_bwd(void* stream, const float* q, const float* k, const float* v, const float* k_r,
+                       const float* r_w_bias, const float* r_r_bias, const float* out,
+                       const float* lse, const float* dout, float* dq, float* dk, float* dv,
+                       float* dk_r, float* d_r_w_bias, float* d_r_r_bias, float* workspace, int B,
+                       int L, int n_head, int d_head);
+/* params / grads: host arrays of 15 device pointers in the order
+ *   q, k, v, o, r [D,n,dh] ; r_w_bias, r_r_bias [n,dh] ; rel_attn.layer_norm.{weight,bias} ;
+ *   ff.layer_1.{weight [4D,D], bias} ; ff.layer_2.{weight [D,4D], bias} ; ff.layer_norm.{weight,bias}
+ * (state_dict names of SURVEY 8(b)).  pos_emb [2L, D] = HF relative_positional_encoding :940-976.
+ * ws: t4r_xlnet_layer_ws_floats() floats saved by fwd for bwd; bws: scratch for bwd. */
+long t4r_xlnet_layer_ws_floats(int B, int L, int D, int n_head);
+long t4r_xlnet_layer_bwd_ws_floats(int B, int L, int D, int n_head);
+int t4r_xlnet_layer_fwd(void* stream, const float* h, const float* pos_emb, const float* const* params,
+                        float* ws, float* h_out, int B, int L, int D, int n_head, float ln_eps);
+int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* pos_emb, const float* const* params,
+                        float* const* grads, const float* ws, float* bws, const float* dh_out,
+                        float* dh_in, int B, int L, int D, int n_head, float ln_eps);
+
+/* ----------------------------------------------------------------------------------------
+ * a18-a21  next-item head
+ * replaces: model/prediction_task.py:347,446 (CrossEntropyLoss, mean), torch/losses.py:4-20 (label
+ *           smoothing), :673-696 (sampled softmax logits), :466-470 (torch.topk).
+ * logits [N, ld] (ld >= V, leading dimension); loss_rows/lse [N]; *loss_mean = mean(loss_rows).
+ * bwd: dlogits = (*grad_out / N) * (softmax - target), pad columns V..ld-1 written 0. */
+int t4r_softmax_ce_fwd(void* stream, const float* logits, const long* labels, float* loss_rows,
+                       float* lse, float* loss_mean, int N, int V, long ld, float label_smoothing);
+int t4r_softmax_ce_bwd(void* stream, const float* logits, const long* labels, const float* lse,
+                       const float* grad_out, float* dlogits, int N, int V, long ld,
+                       float label_smoothing);
+int t4r_sampled_logits_fwd(void* stream, const float* x, const long* labels, const float* W,
+                           const long* neg_samples, const float* sampling_dist, float* out, int N,
+                           int D, int n_neg, float temperature);
+int t4r_sampled_logits_bwd(void* stream, const float* dlogits, const float* x, const long* labels,
+                           const float* W, const long* neg_samples, float* dx, float* dW, int N, int D,
+                           int n_neg, float temperature);
+int t4r_topk(void* stream, const float* scores, int N, int V, long ld, int k, float* out_val,
+             long* out_idx);
+
+/* ----------------------------------------------------------------------------------------
+ * optimizer: fused Adam over a flat parameter buffer (torch.optim.Adam semantics, the optimizer
+ * of the reference's Model.fit, torch/model/base.py:669-718).  grad is multiplied by grad_scale
+ * first (1/world_size after the RCCL sum); zero_grad clears grad in the same pass. */
+int t4r_adam_step(void* stream, float* param, float* grad, float* exp_avg, float* exp_avg_sq, long n,
+                  int step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  float grad_scale, int zero_grad);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* T4R_HIP_H */

@@ -1,0 +1,490 @@
+"""Kernel-level parity: every C-ABI entry point (through transformers4rec_amd.ops, which only
+marshals pointers) against the CPU oracle / plain torch fp32 on the same seeded inputs.
+Integer outputs bit-exact; fp32 outputs to 1e-5-class tolerances (O(0.1-1) weights)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_utils as gu
+import t4r_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from transformers4rec_amd import ops as _ops
+
+    return _ops
+
+
+def cu(t):
+    return t.to(DEV).contiguous()
+
+
+def close(a, b, rtol=2e-5, atol=2e-5, msg=None):
+    torch.testing.assert_close(a.cpu(), b.cpu(), rtol=rtol, atol=atol, msg=msg)
+
+
+# ------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (77, 130, 33), (300, 64, 512), (33, 1001, 128),
+                                   (1, 5, 3), (257, 384, 128)])
+def test_gemm_layouts(ops, ta, tb, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + ta * 2 + tb)
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    B = torch.randn((N, K) if tb else (K, N), generator=g)
+    ref = (A.t() if ta else A).double() @ (B.t() if tb else B).double()
+    out = ops.gemm(cu(A), cu(B), bool(ta), bool(tb), alpha=0.5)
+    close(out, (0.5 * ref).float(), rtol=1e-5, atol=1e-4)
+
+
+def test_gemm_asymmetric_identity(ops):
+    """A = I with an asymmetric B catches a transposed C write (guide rule 16)."""
+    n = 96
+    B = torch.arange(n * n, dtype=torch.float32).reshape(n, n) / 100.0
+    out = ops.gemm(cu(torch.eye(n)), cu(B))
+    assert torch.equal(out.cpu(), B)
+
+
+def test_gemm_epilogues_splitk_accumulate(ops):
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 200, 192, 96
+    A, W, bias = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    pre = A @ W.t() + bias
+    aux = torch.empty((M, N), device=DEV)
+    out = ops.gemm(cu(A), cu(W), False, True, bias=cu(bias), epilogue=ops.EPI_BIAS_GELU, aux=aux)
+    close(aux, pre, atol=1e-4)
+    close(out, torch.nn.functional.gelu(pre), atol=1e-4)
+    out = ops.gemm(cu(A), cu(W), False, True, bias=cu(bias), epilogue=ops.EPI_BIAS_RELU)
+    close(out, torch.relu(pre), atol=1e-4)
+    out = ops.gemm(cu(A), cu(W), False, True, bias=cu(bias), epilogue=ops.EPI_BIAS)
+    close(out, pre, atol=1e-4)
+    # split-K (atomics): overwrite and accumulate flavours, long K
+    K2 = 5000
+    A2, B2 = torch.randn(K2, 70, generator=g), torch.randn(K2, 90, generator=g)
+    ref = (A2.t().double() @ B2.double()).float()
+    out = ops.gemm(cu(A2), cu(B2), True, False, splitk=-1)
+    close(out, ref, rtol=1e-4, atol=2e-3)
+    acc = cu(torch.ones(70, 90))
+    ops.gemm(cu(A2), cu(B2), True, False, splitk=-1, accumulate=True, out=acc)
+    close(acc, ref + 1, rtol=1e-4, atol=2e-3)
+    acc = cu(torch.ones(70, 90))
+    ops.gemm(cu(A2), cu(B2), True, False, splitk=1, accumulate=True, out=acc)
+    close(acc, ref + 1, rtol=1e-4, atol=2e-3)
+    # padded leading dimension of C and unaligned K (logits-like: N odd)
+    X, Wv = torch.randn(37, 64, generator=g), torch.randn(1001, 64, generator=g)
+    out = ops.gemm(cu(X), cu(Wv), False, True, alpha=1 / 0.7, ldc=ops.pad_ld(1001))
+    assert out.stride(0) == 1004
+    close(out, (X @ Wv.t()) / 0.7, atol=1e-4)
+    # K not a multiple of 4 with a k-contiguous operand and padded lda (head dX shape)
+    dl = torch.zeros(37, 1004)
+    dl[:, :1001] = torch.randn(37, 1001, generator=g)
+    dx = ops.gemm(cu(dl)[:, :1001], cu(Wv), False, False, splitk=-1)
+    close(dx, dl[:, :1001] @ Wv, rtol=1e-4, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------ LN / act / adam
+@pytest.mark.parametrize("rows,D", [(50, 128), (33, 64), (20, 8), (7, 512), (9, 336), (4, 32)])
+def test_add_layernorm_fwd_bwd(ops, rows, D):
+    g = torch.Generator().manual_seed(rows + D)
+    a, b = torch.randn(rows, D, generator=g), torch.randn(rows, D, generator=g)
+    gam, bet = 1 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    dy = torch.randn(rows, D, generator=g)
+    a_, b_, g_, be_ = (t.clone().requires_grad_() for t in (a, b, gam, bet))
+    ref = O.layer_norm(a_ + b_, g_, be_, 0.03)
+    ref.backward(dy)
+    y, mean, rstd = ops.add_layernorm_fwd(cu(a), cu(b), cu(gam), cu(bet), 0.03)
+    close(y, ref.detach())
+    dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    dx = ops.add_layernorm_bwd(cu(a), cu(b), cu(gam), mean, rstd, cu(dy), dg, db)
+    close(dx, a_.grad, atol=5e-5)
+    close(dg, g_.grad, atol=1e-4)
+    close(db, be_.grad, atol=1e-4)
+    y2, _, _ = ops.add_layernorm_fwd(cu(a), None, cu(gam), cu(bet), 1e-5)
+    close(y2, O.layer_norm(a, gam, bet, 1e-5))
+
+
+def test_act_bwd_bias_and_colsum(ops):
+    g = torch.Generator().manual_seed(3)
+    pre = torch.randn(100, 96, generator=g).requires_grad_()
+    dact = torch.randn(100, 96, generator=g)
+    torch.nn.functional.gelu(pre).backward(dact)
+    db = torch.zeros(96, device=DEV)
+    out = ops.act_bwd_bias(cu(dact), cu(pre.detach()), db, 0, out=torch.empty(100, 96, device=DEV))
+    close(out, pre.grad, atol=1e-5)
+    close(db, pre.grad.sum(0), atol=1e-4)
+    relu_out = torch.relu(pre.detach())
+    out = ops.act_bwd_bias(cu(dact), cu(relu_out), None, 1, out=torch.empty(100, 96, device=DEV))
+    close(out, dact * (relu_out > 0))
+    acc = torch.zeros(96, device=DEV)
+    ops.colsum_(cu(dact), acc)
+    close(acc, dact.sum(0), atol=1e-4)
+
+
+def test_adam_matches_torch(ops):
+    g = torch.Generator().manual_seed(0)
+    n = 4099
+    p0, grads = torch.randn(n, generator=g), [torch.randn(n, generator=g) for _ in range(3)]
+    p_ref = p0.clone().requires_grad_()
+    opt = torch.optim.Adam([p_ref], lr=1e-2, weight_decay=0.01)
+    p, m, v = cu(p0.clone()), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step, gr in enumerate(grads, 1):
+        p_ref.grad = gr.clone()
+        opt.step()
+        gd = cu(2.0 * gr)
+        ops.adam_step_(p, gd, m, v, step, lr=1e-2, weight_decay=0.01, grad_scale=0.5)
+        assert float(gd.abs().max()) == 0.0  # zero_grad fused
+        close(p, p_ref.detach(), rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------ masking (bit exact)
+def test_mask_targets_golden_bit_exact(ops):
+    d = gu.load("masking_int")
+    ids = cu(gu.t(d["in/item_id"]))
+    m, lab, cnt = ops.mask_targets(ids, ops.MLM_TRAIN, bern=cu(gu.t(d["draw/bern"])).to(torch.uint8),
+                                   j1=cu(gu.t(d["draw/j1"])), j2=cu(gu.t(d["draw/j2"])))
+    assert torch.equal(m.cpu(), gu.t(d["out/mask_schema"]))
+    assert torch.equal(lab.cpu(), gu.t(d["out/masked_targets"]))
+    assert torch.equal(cnt.cpu().long(), (gu.t(d["out/masked_targets"]) != 0).sum(1))
+    for mode, tag in ((ops.MLM_EVAL_LAST, "eval_last"), (ops.MLM_EVAL_ALL, "eval_all"), (ops.MLM_INFER, "infer")):
+        m, lab, _ = ops.mask_targets(ids, mode)
+        assert torch.equal(m.cpu(), gu.t(d[f"out/{tag}_schema"])), tag
+        assert torch.equal(lab.cpu(), gu.t(d[f"out/{tag}_targets"])), tag
+    ids2 = cu(gu.t(d["in/item_id_clm"]))
+    for mode, tag in ((ops.CLM_TRAIN, "clm_train"), (ops.CLM_LAST, "clm_train_last"),
+                      (ops.CLM_LAST, "clm_eval_last"), (ops.CLM_TRAIN, "clm_eval_all"),
+                      (ops.CLM_INFER, "clm_infer")):
+        m, lab, _ = ops.mask_targets(ids2, mode)
+        assert torch.equal(m.cpu(), gu.t(d[f"out/{tag}_schema"])), tag
+        assert torch.equal(lab.cpu(), gu.t(d[f"out/{tag}_targets"])), tag
+
+
+@pytest.mark.parametrize("L", [1, 2, 20, 63, 64, 65, 100, 200])
+def test_mask_targets_vs_oracle_random(ops, L):
+    g = torch.Generator().manual_seed(L)
+    B = 70
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    lens[0] = L
+    ids = torch.randint(1, 999, (B, L), generator=g) * (torch.arange(L)[None] < lens[:, None])
+    bern = torch.rand(B, L, generator=g) < 0.5
+    j1 = (torch.rand(B, generator=g) * lens).long()
+    m0 = bern & (ids != 0)
+    j2 = torch.zeros(B, dtype=torch.int64)
+    ref_m, ref_l = O.mlm_targets_train(ids, bern, j1, lambda mm: mm.float().argmax(1))
+    # feed the same j2 the lambda produced
+    tmp = torch.where(m0, ids, torch.zeros_like(ids)); tmp[torch.arange(B), j1] = ids[torch.arange(B), j1]
+    j2 = (tmp != 0).float().argmax(1)
+    m, lab, _ = ops.mask_targets(cu(ids), ops.MLM_TRAIN, bern=cu(bern).to(torch.uint8), j1=cu(j1), j2=cu(j2))
+    assert torch.equal(m.cpu(), ref_m) and torch.equal(lab.cpu(), ref_l)
+    for mode, fn in ((ops.MLM_EVAL_LAST, lambda: O.mlm_targets_eval(ids, True)),
+                     (ops.MLM_EVAL_ALL, lambda: O.mlm_targets_eval(ids, False)),
+                     (ops.MLM_INFER, lambda: O.mlm_targets_inference(ids)),
+                     (ops.CLM_TRAIN, lambda: O.clm_targets(ids, True, False)),
+                     (ops.CLM_LAST, lambda: O.clm_targets(ids, False, True)),
+                     (ops.CLM_INFER, lambda: O.clm_targets(ids, False, False))):
+        if L == 1 and mode == ops.CLM_LAST:
+            continue  # reference indexes labels[-1] on an all-pad label row; same wrap, covered at L>=2
+        rm, rl = fn()
+        m, lab, _ = ops.mask_targets(cu(ids), mode)
+        assert torch.equal(m.cpu(), rm), mode
+        assert torch.equal(lab.cpu(), rl), mode
+
+
+def test_mask_targets_device_rng_invariants(ops):
+    """Reference invariants (tests/unit/torch/test_masking.py:117-150) on the Philox path."""
+    g = torch.Generator().manual_seed(1)
+    B, L = 4096, 20
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    ids = cu(torch.randint(1, 999, (B, L), generator=g) * (torch.arange(L)[None] < lens[:, None]))
+    m, lab, cnt = ops.mask_targets(ids, ops.MLM_TRAIN, p=0.15, seed=123, offset=0)
+    m2, lab2, _ = ops.mask_targets(ids, ops.MLM_TRAIN, p=0.15, seed=123, offset=0)
+    assert torch.equal(m, m2) and torch.equal(lab, lab2)  # deterministic in (seed, offset)
+    m3, _, _ = ops.mask_targets(ids, ops.MLM_TRAIN, p=0.15, seed=124, offset=0)
+    assert not torch.equal(m, m3)
+    nonpad = ids != 0
+    n_lab, n_np = m.sum(1), nonpad.sum(1)
+    assert bool((m & ~nonpad).sum() == 0)
+    assert bool(torch.equal(lab, torch.where(m, ids, torch.zeros_like(ids))))
+    assert bool(((n_lab >= 1) | (n_np == 1)).all())          # >= 1 label unless a 1-item session
+    assert bool(((n_lab < n_np) | (n_np == 0)).all())         # never all items masked
+    assert torch.equal(cnt.long(), n_lab)
+    frac = float(m.sum()) / float(nonpad.sum())
+    assert 0.15 < frac < 0.30                                 # p=0.15 plus the forced label
+
+
+def test_compact_gather_scatter(ops):
+    g = torch.Generator().manual_seed(2)
+    B, L, D = 1500, 20, 64
+    labels = torch.randint(0, 50, (B, L), generator=g) * (torch.rand(B, L, generator=g) < 0.2)
+    x = torch.randn(B, L, D, generator=g)
+    ref_x, ref_y = O.remove_pad_rows(x, labels)
+    lab_d = cu(labels)
+    cnt = (lab_d != 0).sum(1).to(torch.int32)
+    n, pos, lab = ops.compact_labels(lab_d, cnt)
+    N = int(n.item())
+    assert N == ref_y.numel()
+    assert torch.equal(lab[:N].cpu(), ref_y)
+    out = ops.gather_rows(cu(x).view(B * L, D), pos, N)
+    assert torch.equal(out.cpu(), ref_x)
+    dx = torch.zeros(B * L, D, device=DEV)
+    ops.scatter_rows_add_(out, pos, dx)
+    ref_dx = torch.zeros(B * L, D)
+    ref_dx[(labels.flatten() != 0)] = ref_x
+    assert torch.equal(dx.cpu(), ref_dx)
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    ids = torch.where(torch.arange(L)[None] < lens[:, None], 5, 0)
+    pos_mlm = ops.last_positions(cu(ids), L + 1, True)
+    assert torch.equal(pos_mlm.cpu().long(), torch.arange(B) * (L + 1) + lens)
+    pos_clm = ops.last_positions(cu(ids), L, False)
+    assert torch.equal(pos_clm.cpu().long(), torch.arange(B) * L + lens - 1)
+
+
+def test_ragged_to_padded_golden(ops):
+    d = gu.load("padding")
+    vals, fvals, offs = cu(gu.t(d["in/values"])), cu(gu.t(d["in/fvalues"])), cu(gu.t(d["in/offsets"]))
+    mx = int(ops.ragged_max_len(offs).item())
+    assert mx == int((gu.t(d["in/offsets"])[1:] - gu.t(d["in/offsets"])[:-1]).max())
+    for msl in (None, 20, 64):
+        L = mx if msl is None else min(msl, mx)
+        assert torch.equal(ops.ragged_to_padded(vals, offs, L).cpu(), gu.t(d[f"out/pad_inputs_{msl}_a"]))
+        assert torch.equal(ops.ragged_to_padded(fvals, offs, L).cpu(), gu.t(d[f"out/pad_inputs_{msl}_f"]))
+    assert torch.equal(ops.ragged_to_padded(vals, offs, 7).cpu(), gu.t(d["out/pad_batch_7"]))
+    assert torch.equal(ops.ragged_to_padded(vals, offs, 45).cpu(), gu.t(d["out/pad_batch_45"]))
+    # reference known answers (tests/unit/utils/test_padding.py:33-80): empty row + truncation
+    v = cu(torch.tensor([1, 2, 3, 4, 5, 4, 7]))
+    o = cu(torch.tensor([0, 2, 2, 7]))
+    assert ops.ragged_to_padded(v, o, 3).cpu().tolist() == [[1, 2, 0], [0, 0, 0], [3, 4, 5]]
+
+
+# ------------------------------------------------------------------------------------ input block
+def _feat_setup(g, B, L, dims, cards):
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    m = torch.arange(L)[None] < lens[:, None]
+    ids = [torch.randint(1, c, (B, L), generator=g) * m for c in cards]
+    tabs = [torch.randn(c, d, generator=g) for c, d in zip(cards, dims)]
+    return ids, tabs
+
+
+@pytest.mark.parametrize("dims", [(128,), (64, 24, 8), (16, 12, 6), (32, 32, 32)])
+def test_seq_features_concat_and_mask_modes(ops, dims):
+    g = torch.Generator().manual_seed(sum(dims))
+    B, L = 37, 20
+    cards = [500, 40, 9][: len(dims)]
+    ids, tabs = _feat_setup(g, B, L, dims, cards)
+    cols = np.cumsum([0] + list(dims))
+    W = int(cols[-1])
+    feats = [dict(kind=0, input=cu(i), table=cu(t), dim=d, col=int(c), rows=t.shape[0])
+             for i, t, d, c in zip(ids, tabs, dims, cols)]
+    ref = torch.cat([O.embedding_lookup(i, t) for i, t in zip(ids, tabs)], -1)
+    out = ops.seq_features_fwd(feats, "concat", B, L, L, W)
+    assert torch.equal(out.cpu(), ref)
+    memb = torch.randn(W, generator=g)
+    mask = torch.rand(B, L, generator=g) < 0.3
+    out = ops.seq_features_fwd(feats, "concat", B, L, L, W, mask_mode=ops.MASK_MLM, mask=cu(mask), masked_emb=cu(memb))
+    assert torch.equal(out.cpu(), O.apply_mask_mlm(ref, mask, memb, True, False))
+    out = ops.seq_features_fwd(feats, "concat", B, L, L, W, mask_mode=ops.MASK_CLM, mask=cu(mask), masked_emb=cu(memb))
+    assert torch.equal(out.cpu(), O.apply_mask_clm(ref, mask, memb, True, False))
+    out = ops.seq_features_fwd(feats, "concat", B, L, L, W, mask_mode=ops.MASK_CLM_INFER, mask=cu(mask), masked_emb=cu(memb))
+    assert torch.equal(out.cpu(), O.apply_mask_clm(ref, mask, memb, False, False))
+    mask1 = torch.rand(B, L + 1, generator=g) < 0.3
+    out = ops.seq_features_fwd(feats, "concat", B, L, L + 1, W, mask_mode=ops.MASK_MLM, mask=cu(mask1), masked_emb=cu(memb))
+    assert torch.equal(out.cpu(), O.apply_mask_mlm(ref, mask1, memb, False, False))
+    # separate-pass masking
+    x = cu(ref.clone())
+    ops.apply_mask_fwd_(x, cu(mask), cu(memb), ops.MASK_MLM)
+    assert torch.equal(x.cpu(), O.apply_mask_mlm(ref, mask, memb, True, False))
+    x = cu(ref.clone())
+    ops.apply_mask_fwd_(x, cu(mask), cu(memb), ops.MASK_CLM)
+    assert torch.equal(x.cpu(), O.apply_mask_clm(ref, mask, memb, True, False))
+    # backward of masking + gather against autograd
+    for mode, fn in ((ops.MASK_MLM, O.apply_mask_mlm), (ops.MASK_CLM, O.apply_mask_clm)):
+        tabs_r = [t.clone().requires_grad_() for t in tabs]
+        memb_r = memb.clone().requires_grad_()
+        y = fn(torch.cat([O.embedding_lookup(i, t) for i, t in zip(ids, tabs_r)], -1), mask, memb_r, True, False)
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy)
+        dyd = cu(dy.clone())
+        dm = torch.zeros(W, device=DEV)
+        ops.apply_mask_bwd_(dyd, cu(mask), dm, mode)
+        close(dm, memb_r.grad, atol=1e-4)
+        for i, t, tr, d, c in zip(ids, tabs, tabs_r, dims, cols):
+            dt = torch.zeros(t.shape, device=DEV)
+            ops.embedding_bwd(dyd, cu(i), dt, int(c), d)
+            close(dt, tr.grad, atol=1e-4)
+
+
+def test_seq_features_sum_and_item_multi(ops):
+    g = torch.Generator().manual_seed(9)
+    B, L, D = 21, 20, 32
+    ids, tabs = _feat_setup(g, B, L, (D, D, D), (300, 40, 7))
+    feats = [dict(kind=0, input=cu(i), table=cu(t), dim=D, col=0, rows=t.shape[0]) for i, t in zip(ids, tabs)]
+    embs = {f"f{k}": O.embedding_lookup(i, t) for k, (i, t) in enumerate(zip(ids, tabs))}
+    out = ops.seq_features_fwd(feats, "element-wise-sum", B, L, L, D)
+    close(out, O.elementwise_sum(embs), atol=1e-6)
+    out = ops.seq_features_fwd(feats, "element-wise-sum-item-multi", B, L, L, D, item_feat=0)
+    close(out, O.elementwise_sum_item_multi(embs, "f0"), atol=1e-6)
+    # dense (kind 1) feature rows mixed in a concat
+    dense = torch.randn(B, L, 8, generator=g)
+    feats2 = [dict(kind=0, input=cu(ids[0]), table=cu(tabs[0]), dim=D, col=8, rows=300),
+              dict(kind=1, input=cu(dense), table=None, dim=8, col=0)]
+    out = ops.seq_features_fwd(feats2, "concat", B, L, L, D + 8)
+    assert torch.equal(out.cpu(), torch.cat([dense, embs["f0"]], -1))
+    err = torch.zeros(1, device=DEV, dtype=torch.int32)
+    bad = cu(ids[0].clone()); bad[0, 0] = 10 ** 6
+    ops.seq_features_fwd([dict(kind=0, input=bad, table=cu(tabs[0]), dim=D, col=0, rows=300)], "concat",
+                         B, L, L, D, err_flag=err)
+    assert int(err.item()) == 1
+
+
+@pytest.mark.parametrize("K,D,ln", [(10, 8, True), (10, 8, False), (20, 16, True)])
+def test_soft_embedding_fwd_bwd(ops, K, D, ln):
+    g = torch.Generator().manual_seed(K + D)
+    B, L = 33, 20
+    x = torch.rand(B, L, generator=g)
+    pw, pb, tab = (torch.randn(K, 1, generator=g), torch.randn(K, generator=g), torch.randn(K, D, generator=g))
+    lw, lb = 1 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    ps = [t.clone().requires_grad_() for t in (pw, pb, tab, lw, lb)]
+    ref = O.soft_embedding(x, ps[0], ps[1], ps[2])
+    if ln:
+        ref = O.layer_norm(ref, ps[3], ps[4], 1e-5)
+    dy = torch.randn(B, L, D + 4, generator=g)
+    ref.backward(dy[..., 4:])
+    out = ops.soft_embedding_fwd(cu(x), cu(pw), cu(pb), cu(tab), cu(lw) if ln else None, cu(lb) if ln else None)
+    close(out, ref.detach(), atol=1e-5)
+    gr = [torch.zeros(t.shape, device=DEV) for t in (pw, pb, tab, lw, lb)]
+    ops.soft_embedding_bwd(cu(dy), cu(x), cu(pw), cu(pb), cu(tab), cu(lw) if ln else None, gr[0], gr[1], gr[2],
+                           gr[3] if ln else None, gr[4] if ln else None, col=4)
+    for got, p in zip(gr[: (5 if ln else 3)], ps):
+        close(got, p.grad, rtol=1e-4, atol=2e-4)
+
+
+# ------------------------------------------------------------------------------------ attention / layer
+def _layer_params(g, D, n, scale=0.1):
+    dh = D // n
+    r = lambda *s: scale * torch.randn(*s, generator=g)
+    return dict(q=r(D, n, dh), k=r(D, n, dh), v=r(D, n, dh), o=r(D, n, dh), r=r(D, n, dh),
+                r_w_bias=r(n, dh), r_r_bias=r(n, dh), ln_w=1 + r(D), ln_b=r(D),
+                w1=r(4 * D, D), b1=r(4 * D), w2=r(D, 4 * D), b2=r(D), ff_ln_w=1 + r(D), ff_ln_b=r(D))
+
+
+ORDER = ("q", "k", "v", "o", "r", "r_w_bias", "r_r_bias", "ln_w", "ln_b", "w1", "b1", "w2", "b2",
+         "ff_ln_w", "ff_ln_b")
+
+
+@pytest.mark.parametrize("B,L,D,n", [(5, 20, 64, 4), (3, 21, 32, 2), (2, 7, 128, 4), (4, 33, 64, 8), (2, 64, 32, 4)])
+def test_xlnet_attention_core(ops, B, L, D, n):
+    g = torch.Generator().manual_seed(B * L + D)
+    dh = D // n
+    q, k, v = (torch.randn(B, L, n, dh, generator=g).requires_grad_() for _ in range(3))
+    kr = torch.randn(2 * L, n, dh, generator=g).requires_grad_()
+    rw, rr = (0.5 * torch.randn(n, dh, generator=g)).requires_grad_(), (0.5 * torch.randn(n, dh, generator=g)).requires_grad_()
+    ac = torch.einsum("bind,bjnd->bnij", q + rw, k)
+    bd_full = torch.einsum("bind,pnd->bnip", q + rr, kr)
+    idx = torch.arange(L)[None, :] + L - torch.arange(L)[:, None]
+    bd = torch.gather(bd_full, 3, idx[None, None].expand(B, n, L, L))
+    prob = torch.softmax((ac + bd) / dh ** 0.5, 3)
+    ref = torch.einsum("bnij,bjnd->bind", prob, v)
+    dout = torch.randn(B, L, n, dh, generator=g)
+    ref.backward(dout)
+    f2 = lambda t: cu(t.detach().reshape(-1, D))
+    out, lse = ops.xlnet_attn_fwd(f2(q), f2(k), f2(v), f2(kr), cu(rw.detach().reshape(-1)), cu(rr.detach().reshape(-1)), B, L, n)
+    close(out, ref.detach().reshape(-1, D), atol=2e-5)
+    drw, drr = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    dq, dk, dv, dkr = ops.xlnet_attn_bwd(f2(q), f2(k), f2(v), f2(kr), cu(rw.detach().reshape(-1)),
+                                         cu(rr.detach().reshape(-1)), out, lse, f2(dout), drw, drr, B, L, n)
+    close(dq, q.grad.reshape(-1, D), atol=1e-4)
+    close(dk, k.grad.reshape(-1, D), atol=1e-4)
+    close(dv, v.grad.reshape(-1, D), atol=1e-4)
+    close(dkr, kr.grad.reshape(-1, D), atol=2e-4)
+    close(drw, rw.grad.reshape(-1), atol=3e-4)
+    close(drr, rr.grad.reshape(-1), atol=3e-4)
+
+
+@pytest.mark.parametrize("B,L,D,n", [(6, 20, 64, 4), (3, 21, 32, 2), (9, 20, 128, 4)])
+def test_xlnet_layer_fwd_bwd(ops, B, L, D, n):
+    g = torch.Generator().manual_seed(B + L + D)
+    p = _layer_params(g, D, n)
+    pr = {k: v.clone().requires_grad_() for k, v in p.items()}
+    h = torch.randn(B, L, D, generator=g)
+    hr = h.clone().requires_grad_()
+    ref = O.xlnet_layer(hr, pr, n, 0.03)
+    dout = torch.randn(B, L, D, generator=g)
+    ref.backward(dout)
+    pos = cu(O.xlnet_pos_emb(L, D))
+    params = [cu(p[k]) for k in ORDER]
+    out, ws = ops.xlnet_layer_fwd(cu(h).view(B * L, D), pos, params, B, L, n, 0.03)
+    close(out, ref.detach().reshape(B * L, D), atol=3e-5)
+    grads = [torch.zeros_like(t) for t in params]
+    dh = ops.xlnet_layer_bwd(cu(h).view(B * L, D), pos, params, grads, ws, cu(dout).view(B * L, D), B, L, n, 0.03)
+    close(dh, hr.grad.reshape(B * L, D), rtol=1e-4, atol=2e-4)
+    for k, gt in zip(ORDER, grads):
+        close(gt.reshape(-1), pr[k].grad.reshape(-1), rtol=1e-4, atol=5e-4, msg=lambda m, k=k: f"{k}: {m}")
+
+
+def test_xlnet_layer_golden_hidden(ops):
+    """reference fixture: inputs_embeds -> hidden through both layers."""
+    d = gu.load("xlnet_mlm_item_train")
+    p = gu.oracle_params(d)
+    x = gu.t(d["out/inputs_embeds"])
+    B, L, D = x.shape
+    n = int(d["meta/n_head"])
+    pos = cu(O.xlnet_pos_emb(L, D))
+    h = cu(x).view(B * L, D)
+    for lp in p["layers"]:
+        params = [cu(lp[k]) for k in ORDER]
+        h, _ = ops.xlnet_layer_fwd(h, pos, params, B, L, n, float(d["meta/eps"]))
+    close(h.view(B, L, D), gu.t(d["out/hidden"]), atol=3e-5)
+
+
+# ------------------------------------------------------------------------------------ head
+@pytest.mark.parametrize("N,V,eps", [(37, 1001, 0.0), (5, 100001, 0.0), (16, 517, 0.1), (1, 33, 0.0)])
+def test_softmax_ce_fwd_bwd(ops, N, V, eps):
+    g = torch.Generator().manual_seed(N + V)
+    ld = ops.pad_ld(V)
+    logits = 3 * torch.randn(N, V, generator=g)
+    y = torch.randint(0, V, (N,), generator=g)
+    lr = logits.clone().requires_grad_()
+    ref = torch.nn.functional.cross_entropy(lr, y, label_smoothing=eps)
+    (ref * 1.7).backward()
+    buf = torch.zeros(N, ld, device=DEV)
+    buf[:, :V] = cu(logits)
+    loss, rows, lse = ops.softmax_ce_fwd(buf[:, :V], cu(y), V, eps)
+    close(loss, ref.detach(), atol=1e-5)
+    dl = ops.softmax_ce_bwd(buf[:, :V], cu(y), lse, torch.tensor(1.7, device=DEV), V, eps)
+    close(dl[:, :V], lr.grad, rtol=1e-4, atol=1e-7)
+    assert float(dl[:, V:].abs().sum()) == 0.0
+
+
+def test_sampled_logits_golden(ops):
+    d = gu.load("xlnet_mlm_sum_sampled_train")
+    p = gu.oracle_params(d, requires_grad=True)
+    n = int(d["meta/max_n_samples"])
+    neg = gu.t(d["draw/neg_tries"]).unique()[:n]
+    dist = gu.section(d, "p/")[gu.TASK + "pre.module.sampler.unique_sampling_dist"]
+    j2 = gu.t(d["draw/j2"])
+    _, lab = O.mlm_targets_train(gu.t(d["in/item_id"]), gu.t(d["draw/bern"]), gu.t(d["draw/j1"]), lambda m: j2)
+    xr, y = O.remove_pad_rows(gu.t(d["out/hidden"]), lab)
+    W = p["tables"]["item_id"]
+    xr_ = xr.clone().requires_grad_()
+    ref = O.sampled_logits(xr_, y, W, neg, dist)
+    close(ref.detach(), gu.t(d["out/predictions"]), atol=1e-4)
+    out = ops.sampled_logits_fwd(cu(xr), cu(y), cu(W.detach()), cu(neg), cu(dist))
+    close(out, ref.detach(), atol=1e-4)
+    dl = torch.randn(ref.shape, generator=torch.Generator().manual_seed(0))
+    ref.backward(dl)
+    dW = torch.zeros(W.shape, device=DEV)
+    dx = ops.sampled_logits_bwd(cu(dl), cu(xr), cu(y), cu(W.detach()), cu(neg), dW)
+    close(dx, xr_.grad, atol=1e-4)
+    close(dW, W.grad, atol=1e-4)
+
+
+@pytest.mark.parametrize("N,V,k", [(9, 1000, 20), (3, 100001, 20), (4, 50, 10), (2, 64, 64)])
+def test_topk(ops, N, V, k):
+    g = torch.Generator().manual_seed(V)
+    s = torch.randn(N, V, generator=g)
+    ref_v, ref_i = torch.topk(s, k, dim=-1)
+    v, i = ops.topk(cu(s), k)
+    assert torch.equal(v.cpu(), ref_v)
+    assert torch.equal(i.cpu(), ref_i)

@@ -1,0 +1,113 @@
+"""ctypes binding of libt4r_hip.so (C ABI declared in include/t4r_hip.h).
+
+There is NO fallback: if the shared library is missing or a call fails the product path
+raises.  Build with `python -m transformers4rec_amd.build` (or __graft_entry__.build()).
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libt4r_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "t4r_hip.h")
+
+_P, _I, _L, _F, _Q = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_ulonglong
+_C = {"p": _P, "i": _I, "l": _L, "f": _F, "Q": _Q}
+
+# name -> (restype, argtype codes).  Must match include/t4r_hip.h (tests/test_abi.py checks the
+# symbol list against the header).
+_SIGS = {
+    "t4r_abi_version": ("i", ""),
+    "t4r_last_error": ("s", ""),
+    "t4r_ragged_max_len": ("i", "ppip"),
+    "t4r_ragged_to_padded": ("i", "ppppiii"),
+    "t4r_seq_features_fwd": ("i", "pippppppiiiiiiipppp"),
+    "t4r_embedding_bwd": ("i", "pppp" + "liiili"),
+    "t4r_apply_mask_fwd": ("i", "ppppiiii"),
+    "t4r_apply_mask_bwd": ("i", "ppppiiii"),
+    "t4r_mul": ("i", "ppppl"),
+    "t4r_soft_embedding_fwd": ("i", "pppppppp" + "liif"),
+    "t4r_soft_embedding_bwd": ("i", "pppppppppppp" + "liiiif"),
+    "t4r_mask_targets": ("i", "ppiiil" + "ppp" + "fQQ" + "ppp"),
+    "t4r_compact_labels": ("i", "pppiil" + "pppp"),
+    "t4r_gather_rows": ("i", "ppppii"),
+    "t4r_scatter_rows_add": ("i", "ppppii"),
+    "t4r_last_positions": ("i", "ppiiiilp"),
+    "t4r_gemm_f32": ("i", "piiiiif" + "plplpl" + "pipl" + "iii" + "lll"),
+    "t4r_add_layernorm_fwd": ("i", "pppppppp" + "iif"),
+    "t4r_add_layernorm_bwd": ("i", "pppppppppp" + "iii"),
+    "t4r_act_bwd_bias": ("i", "ppppp" + "lii"),
+    "t4r_colsum": ("i", "ppp" + "lil"),
+    "t4r_xlnet_attn_fwd": ("i", "ppppppppp" + "iiii"),
+    "t4r_xlnet_attn_bwd_ws_floats": ("l", "iiii"),
+    "t4r_xlnet_attn_bwd": ("i", "p" * 17 + "iiii"),
+    "t4r_xlnet_layer_ws_floats": ("l", "iiii"),
+    "t4r_xlnet_layer_bwd_ws_floats": ("l", "iiii"),
+    "t4r_xlnet_layer_fwd": ("i", "pppppp" + "iiiif"),
+    "t4r_xlnet_layer_bwd": ("i", "ppppppppp" + "iiiif"),
+    "t4r_softmax_ce_fwd": ("i", "pppppp" + "iilf"),
+    "t4r_softmax_ce_bwd": ("i", "pppppp" + "iilf"),
+    "t4r_sampled_logits_fwd": ("i", "ppppppp" + "iiif"),
+    "t4r_sampled_logits_bwd": ("i", "pppppppp" + "iiif"),
+    "t4r_topk": ("i", "pp" + "iili" + "pp"),
+    "t4r_adam_step": ("i", "ppppp" + "li" + "ffffff" + "i"),
+}
+
+_lib = None
+
+
+class T4RHipError(RuntimeError):
+    pass
+
+
+def header_symbols():
+    """Function names declared in include/t4r_hip.h."""
+    with open(HEADER_PATH) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(t4r_\w+)\s*\(", text)))
+
+
+def load():
+    """Loads the library and sets ctypes prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise T4RHipError(
+            f"{LIB_PATH} not found: the HIP extension is not built "
+            "(run `python -m transformers4rec_amd.build`). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (ret, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = ctypes.c_char_p if ret == "s" else _C[ret]
+        fn.argtypes = [_C[a] for a in args]
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().t4r_last_error()
+        raise T4RHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def call(name, *args):
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        check(rc, name)
+
+
+def ptr_array(ptrs):
+    """host array of device pointers (const T* const*)"""
+    arr = (ctypes.c_void_p * len(ptrs))(*ptrs)
+    return ctypes.cast(arr, ctypes.c_void_p), arr
+
+
+def int_array(vals):
+    arr = (ctypes.c_int * len(vals))(*vals)
+    return ctypes.cast(arr, ctypes.c_void_p), arr
+
+
+def long_array(vals):
+    arr = (ctypes.c_long * len(vals))(*vals)
+    return ctypes.cast(arr, ctypes.c_void_p), arr

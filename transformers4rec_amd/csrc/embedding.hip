@@ -1,0 +1,557 @@
+// Input block of the session-sequence path: multi-feature embedding gather + aggregation,
+// SoftEmbedding (+ per-feature LayerNorm), optional masking epilogue, and the ragged->padded
+// conversion in front of it.  HBM-bound integer/copy work: one fused launch for all tables,
+// 16-byte row accesses, several token rows in flight per wave.
+//
+// Reference behaviour restated (paths relative to the reference repo):
+//   SequenceEmbeddingFeatures / EmbeddingFeatures.forward   transformers4rec/torch/features/embedding.py:226-249
+//       (row 0 of a table is a normal, randomly initialised row -- features/sequence.py:75-81;
+//        padding_idx=0 only blocks the *gradient* of row 0)
+//   SoftEmbedding.forward                                   features/embedding.py:551-556
+//   SoftEmbeddingFeatures post LayerNorm (eps 1e-5)         features/embedding.py:306-309
+//   ConcatFeatures (sorted feature names -> column offsets chosen by the host)
+//                                                           torch/tabular/aggregation.py:35-47
+//   ElementwiseSum / ElementwiseSumItemMulti                torch/tabular/aggregation.py:140-193
+//   MaskSequence.apply_mask_to_inputs (MLM / CLM variants)  torch/masking.py:302-337,473-498
+//   _pad_ragged_tensor / pad_inputs                         torch/utils/padding.py:48-68,126-164
+#include "t4r_common.h"
+
+#define T4R_MAX_FEATS 16
+#define T4R_SOFT_MAXK 32
+#define T4R_SOFT_MAXD 32
+
+enum { AGG_CONCAT = 0, AGG_SUM = 1, AGG_SUM_ITEM_MULTI = 2 };
+enum { MASK_NONE = 0, MASK_MLM = 1, MASK_CLM = 2, MASK_CLM_INFER = 3 };
+
+struct SeqFeatParams {
+    int n_feat;
+    int kind[T4R_MAX_FEATS];          // 0 categorical table lookup, 1 dense rows (precomputed)
+    const void* input[T4R_MAX_FEATS]; // kind 0: int64 ids [B*L_in] ; kind 1: float [B*L_in, dim]
+    const float* table[T4R_MAX_FEATS];
+    int dim[T4R_MAX_FEATS];
+    int col[T4R_MAX_FEATS];           // output column offset (concat) / 0 (sum)
+    long rows[T4R_MAX_FEATS];         // table rows (bounds check)
+    int agg, item_feat;               // item_feat: index of the item-id feature (item-multi)
+    int B, L_in, L_out, W;            // W = output row width
+    // masking epilogue (only legal when no projection follows, i.e. W == hidden)
+    int mask_mode;
+    const unsigned char* mask;        // [B*L_out]
+    const float* masked_emb;          // [W]
+    float* out;                       // [B*L_out, W]
+    int* err;                         // set to 1 on an out-of-range id
+};
+
+// One token row per GROUP lanes (GROUP = power of two <= 64); each lane produces 4 consecutive
+// output columns per step.  "Dense" features (soft embeddings computed by
+// t4r_soft_embedding_fwd, continuous pass-through) are copied from their [tokens, dim] rows.
+template <int GROUP>
+__global__ __launch_bounds__(256) void seq_features_fwd_kernel(SeqFeatParams p) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gl = threadIdx.x & (GROUP - 1);
+    const long tok = (long)tid / GROUP;                 // output token index b*L_out + l
+    const long ntok = (long)p.B * p.L_out;
+    if (tok >= ntok) return;
+    const int b = (int)(tok / p.L_out), l = (int)(tok % p.L_out);
+    const int ls = min(l, p.L_in - 1);                  // MLM inference: position L duplicates L-1
+    const long ts = (long)b * p.L_in + ls;
+
+    int mode = p.mask_mode;
+    bool m = false;
+    if (mode != MASK_NONE) m = p.mask[tok] != 0;
+    float* orow = p.out + tok * p.W;
+
+    for (int c0 = gl * 4; c0 < p.W; c0 += GROUP * 4) {
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        // masking decides whether the embedding is needed at all
+        bool use_emb = true, zero = false;
+        if (mode == MASK_MLM) use_emb = !m;
+        else if (mode == MASK_CLM) { use_emb = m; zero = (l == p.L_out - 1); }
+        else if (mode == MASK_CLM_INFER) use_emb = m;
+        if (use_emb && !zero) {
+            float other[4] = {0.f, 0.f, 0.f, 0.f};
+            float item[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int f = 0; f < p.n_feat; ++f) {
+                int lc0;  // first column inside feature f handled by this lane, or skip
+                if (p.agg == AGG_CONCAT) {
+                    if (c0 + 4 <= p.col[f] || c0 >= p.col[f] + p.dim[f]) continue;
+                    lc0 = c0 - p.col[f];
+                } else {
+                    lc0 = c0;
+                }
+                float fv[4] = {0.f, 0.f, 0.f, 0.f};
+                const float* row;
+                if (p.kind[f] == 0) {
+                    long id = reinterpret_cast<const long*>(p.input[f])[ts];
+                    if (id < 0 || id >= p.rows[f]) { if (p.err) *p.err = 1; id = 0; }
+                    row = p.table[f] + id * p.dim[f];
+                } else {
+                    row = reinterpret_cast<const float*>(p.input[f]) + ts * p.dim[f];
+                }
+                if (lc0 >= 0 && lc0 + 4 <= p.dim[f] && (p.dim[f] & 3) == 0) {
+                    const float4 t = *reinterpret_cast<const float4*>(row + lc0);
+                    fv[0] = t.x; fv[1] = t.y; fv[2] = t.z; fv[3] = t.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = lc0 + e;
+                        if (c >= 0 && c < p.dim[f]) fv[e] = row[c];
+                    }
+                }
+                if (p.agg == AGG_CONCAT) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = lc0 + e;
+                        if (c >= 0 && c < p.dim[f]) v[e] = fv[e];
+                    }
+                } else if (p.agg == AGG_SUM) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += fv[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (f == p.item_feat) item[e] = fv[e]; else other[e] += fv[e];
+                    }
+                }
+            }
+            if (p.agg == AGG_SUM_ITEM_MULTI) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = item[e] * other[e];
+            }
+        } else if (!use_emb) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c0 + e < p.W) v[e] = p.masked_emb[c0 + e];
+        }
+        if (c0 + 4 <= p.W && (p.W & 3) == 0) {
+            *reinterpret_cast<float4*>(orow + c0) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c0 + e < p.W) orow[c0 + e] = v[e];
+        }
+    }
+}
+
+static int pick_group(int W) {
+    int units = (W + 3) / 4, g = 1;
+    while (g < units && g < 64) g <<= 1;
+    return g < 8 ? 8 : g;
+}
+
+extern "C" int t4r_seq_features_fwd(
+    void* stream, int n_feat, const int* kind, const void* const* input, const float* const* table,
+    const int* dim, const int* col, const long* rows, int agg, int item_feat, int B, int L_in,
+    int L_out, int W, int mask_mode, const unsigned char* mask, const float* masked_emb, float* out,
+    int* err_flag) {
+    T4R_CHECK_ARG(n_feat >= 1 && n_feat <= T4R_MAX_FEATS, "seq_features: 1..16 features");
+    T4R_CHECK_ARG(B >= 0 && L_in >= 1 && L_out >= L_in && W >= 1, "seq_features: bad shape");
+    T4R_CHECK_ARG(mask_mode == MASK_NONE || (mask && masked_emb), "seq_features: mask inputs missing");
+    if (B == 0) return 0;
+    SeqFeatParams p;
+    p.n_feat = n_feat;
+    for (int f = 0; f < n_feat; ++f) {
+        p.kind[f] = kind[f]; p.input[f] = input[f]; p.table[f] = table[f]; p.dim[f] = dim[f];
+        p.col[f] = col ? col[f] : 0; p.rows[f] = rows ? rows[f] : 0;
+        T4R_CHECK_ARG(input[f] && (kind[f] == 1 || table[f]), "seq_features: null feature pointer");
+        if (agg != AGG_CONCAT) T4R_CHECK_ARG(dim[f] == W, "seq_features: element-wise needs equal dims");
+    }
+    p.agg = agg; p.item_feat = item_feat;
+    p.B = B; p.L_in = L_in; p.L_out = L_out; p.W = W;
+    p.mask_mode = mask_mode; p.mask = mask; p.masked_emb = masked_emb; p.out = out; p.err = err_flag;
+    const int g = pick_group(W);
+    const long threads = (long)B * L_out * g;
+    dim3 grid((unsigned)((threads + 255) / 256));
+    hipStream_t st = (hipStream_t)stream;
+    switch (g) {
+        case 8: hipLaunchKernelGGL(seq_features_fwd_kernel<8>, grid, dim3(256), 0, st, p); break;
+        case 16: hipLaunchKernelGGL(seq_features_fwd_kernel<16>, grid, dim3(256), 0, st, p); break;
+        case 32: hipLaunchKernelGGL(seq_features_fwd_kernel<32>, grid, dim3(256), 0, st, p); break;
+        default: hipLaunchKernelGGL(seq_features_fwd_kernel<64>, grid, dim3(256), 0, st, p); break;
+    }
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// apply mask as its own pass (used after the projection MLP):  in place on x [B*L_out, H]
+//   MLM: x = mask ? memb : x ;  CLM: x = mask ? (l==L-1 ? 0 : x) : memb ;  CLM infer: mask ? x : memb
+// For MLM inference (L_out = L_in + 1) the caller gathers with L_out first.
+__global__ __launch_bounds__(256) void apply_mask_kernel(float* __restrict__ x,
+                                                          const unsigned char* __restrict__ mask,
+                                                          const float* __restrict__ memb, long ntok,
+                                                          int L, int H, int mode) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int hq = (H + 3) / 4;
+    const long tok = i / hq;
+    if (tok >= ntok) return;
+    const int c0 = (int)(i % hq) * 4;
+    const bool m = mask[tok] != 0;
+    const int l = (int)(tok % L);
+    bool keep, zero = false;
+    if (mode == MASK_MLM) keep = !m;
+    else if (mode == MASK_CLM) { keep = m; zero = (l == L - 1); }
+    else keep = m;
+    if (keep && !zero) return;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (c0 + e < H) x[tok * H + c0 + e] = keep ? 0.f : memb[c0 + e];
+}
+
+extern "C" int t4r_apply_mask_fwd(void* stream, float* x, const unsigned char* mask,
+                                  const float* masked_emb, int B, int L, int H, int mode) {
+    const long ntok = (long)B * L;
+    if (ntok == 0 || mode == MASK_NONE) return 0;
+    const long n = ntok * ((H + 3) / 4);
+    hipLaunchKernelGGL(apply_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, mask, masked_emb, ntok, L, H, mode);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+// backward of apply mask: d_memb[H] += sum over replaced tokens of dy ; dy <- 0 at replaced /
+// zeroed tokens (in place), so that the upstream backward sees d x.
+__global__ __launch_bounds__(256) void apply_mask_bwd_kernel(float* __restrict__ dy,
+                                                              const unsigned char* __restrict__ mask,
+                                                              float* __restrict__ d_memb, long ntok,
+                                                              int L, int H, int mode, int tok_per_block) {
+    const long t0 = (long)blockIdx.x * tok_per_block;
+    const long t1 = min(ntok, t0 + tok_per_block);
+    for (int c = threadIdx.x; c < H; c += 256) {
+        float acc = 0.f;
+        for (long t = t0; t < t1; ++t) {
+            const bool m = mask[t] != 0;
+            const int l = (int)(t % L);
+            bool keep, zero = false;
+            if (mode == MASK_MLM) keep = !m;
+            else if (mode == MASK_CLM) { keep = m; zero = (l == L - 1); }
+            else keep = m;
+            if (!keep) { acc += dy[t * H + c]; dy[t * H + c] = 0.f; }
+            else if (zero) dy[t * H + c] = 0.f;
+        }
+        if (acc != 0.f) atomicAdd(d_memb + c, acc);
+    }
+}
+
+extern "C" int t4r_apply_mask_bwd(void* stream, float* dy, const unsigned char* mask, float* d_memb,
+                                  int B, int L, int H, int mode) {
+    const long ntok = (long)B * L;
+    if (ntok == 0 || mode == MASK_NONE) return 0;
+    const int tpb = 32;
+    hipLaunchKernelGGL(apply_mask_bwd_kernel, dim3((unsigned)((ntok + tpb - 1) / tpb)), dim3(256), 0,
+                       (hipStream_t)stream, dy, mask, d_memb, ntok, L, H, mode, tpb);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// backward of the gather: for categorical feature f, d_table[id, :] += d_out[tok, col:col+dim]
+// for id != padding_idx (nn.Embedding(padding_idx=0): row 0 gets no lookup gradient).
+// For element-wise-sum aggregation every feature receives d_out itself.
+// MLM inference duplication is forward-only, so L_in == L_out here.
+// Small tables (rows*dim*4 <= 48 KiB) are accumulated in LDS per block first: a 10-row table
+// hit by 20k tokens would otherwise serialise ~2k atomics per address.
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restrict__ dout,
+                                                             const long* __restrict__ ids,
+                                                             float* __restrict__ dtable, long ntok,
+                                                             int W, int col, int dim, long rows,
+                                                             int padding_idx, int tok_per_block,
+                                                             int use_lds) {
+    extern __shared__ float lds[];
+    const long t0 = (long)blockIdx.x * tok_per_block;
+    const long t1 = min(ntok, t0 + tok_per_block);
+    if (use_lds) {
+        const int n = (int)(rows * dim);
+        for (int i = threadIdx.x; i < n; i += 256) lds[i] = 0.f;
+        __syncthreads();
+        for (long t = t0; t < t1; ++t) {
+            const long id = ids[t];
+            if (id == padding_idx || id < 0 || id >= rows) continue;
+            for (int c = threadIdx.x; c < dim; c += 256)
+                atomicAdd(&lds[id * dim + c], dout[t * W + col + c]);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 256)
+            if (lds[i] != 0.f) atomicAdd(dtable + i, lds[i]);
+    } else {
+        const int dq = dim;  // one lane per column, tokens striped over waves
+        for (long t = t0 + (threadIdx.x / 64); t < t1; t += 4) {
+            const long id = ids[t];
+            if (id == padding_idx || id < 0 || id >= rows) continue;
+            for (int c = threadIdx.x & 63; c < dq; c += 64)
+                atomicAdd(dtable + id * dim + c, dout[t * W + col + c]);
+        }
+    }
+}
+
+extern "C" int t4r_embedding_bwd(void* stream, const float* dout, const long* ids, float* dtable,
+                                 long ntok, int W, int col, int dim, long rows, int padding_idx) {
+    if (ntok == 0) return 0;
+    const int use_lds = rows * dim * 4 <= 48 * 1024;
+    const int tpb = use_lds ? 256 : 32;
+    const size_t smem = use_lds ? (size_t)rows * dim * 4 : 0;
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)((ntok + tpb - 1) / tpb)), dim3(256), smem,
+                       (hipStream_t)stream, dout, ids, dtable, ntok, W, col, dim, rows, padding_idx,
+                       tpb, use_lds);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+// item-multi aggregation backward helper: out = item * other  =>
+//   d_item = d_out * other ; d_other = d_out * item.  The host recomputes `other`/`item` rows
+// with t4r_seq_features_fwd (AGG_SUM over the respective feature subsets) and multiplies here.
+__global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ a,
+                                                   const float* __restrict__ b,
+                                                   float* __restrict__ out, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] * b[i];
+}
+extern "C" int t4r_mul(void* stream, const float* a, const float* b, float* out, long n) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, a, b, out, n);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// SoftEmbedding (+ per-feature LayerNorm) forward for one continuous feature:
+//   s_k = x*pw_k + pb_k ; w = softmax(s) ; e = sum_k w_k T[k,:] ; y = LN(e)*g + b  (g null: y = e)
+// One thread per token, K/D bounded by template maxima so everything stays in registers.
+template <int KMAX, int DMAX>
+__global__ __launch_bounds__(256) void soft_embedding_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ pw, const float* __restrict__ pb,
+    const float* __restrict__ table, const float* __restrict__ lnw, const float* __restrict__ lnb,
+    float* __restrict__ out, long ntok, int K, int D, float eps) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntok) return;
+    const float xv = x[t];
+    float w[KMAX], e[DMAX];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) { w[k] = k < K ? xv * pw[k] + pb[k] : -INFINITY; mx = fmaxf(mx, w[k]); }
+    float den = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) { w[k] = k < K ? expf(w[k] - mx) : 0.f; den += w[k]; }
+    const float inv = 1.f / den;
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) {
+        float a = 0.f;
+        if (d < D) {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k < K) a += (w[k] * inv) * table[k * D + d];
+        }
+        e[d] = a;
+    }
+    if (lnw) {
+        float mu = 0.f;
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) mu += e[d];
+        mu /= D;
+        float var = 0.f;
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) if (d < D) var += (e[d] - mu) * (e[d] - mu);
+        const float rs = rsqrtf(var / D + eps);
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) if (d < D) e[d] = (e[d] - mu) * rs * lnw[d] + lnb[d];
+    }
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) if (d < D) out[t * D + d] = e[d];
+}
+
+extern "C" int t4r_soft_embedding_fwd(void* stream, const float* x, const float* proj_w,
+                                      const float* proj_b, const float* table, const float* ln_w,
+                                      const float* ln_b, float* out, long ntok, int K, int D,
+                                      float eps) {
+    if (ntok == 0) return 0;
+    T4R_CHECK_ARG(K >= 1 && K <= T4R_SOFT_MAXK && D >= 1 && D <= T4R_SOFT_MAXD,
+                  "soft_embedding_fwd: K<=32, dim<=32");
+    dim3 grid((unsigned)((ntok + 255) / 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (K <= 16 && D <= 8)
+        hipLaunchKernelGGL((soft_embedding_fwd_kernel<16, 8>), grid, block, 0, st, x, proj_w, proj_b,
+                           table, ln_w, ln_b, out, ntok, K, D, eps);
+    else
+        hipLaunchKernelGGL((soft_embedding_fwd_kernel<32, 32>), grid, block, 0, st, x, proj_w, proj_b,
+                           table, ln_w, ln_b, out, ntok, K, D, eps);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+// SoftEmbedding + LayerNorm backward.  dy = d out [tok, W] (columns col..col+D):
+//   d g, d b, d T, d pw, d pb   (x has no gradient).  One thread per token; block partials are
+// reduced with LDS atomics, then one global atomic per parameter per block.
+template <int KMAX, int DMAX>
+__global__ __launch_bounds__(256) void soft_embedding_bwd_kernel(
+    const float* __restrict__ dout, const float* __restrict__ x, const float* __restrict__ pw,
+    const float* __restrict__ pb, const float* __restrict__ table, const float* __restrict__ lnw,
+    float* __restrict__ d_pw, float* __restrict__ d_pb, float* __restrict__ d_table,
+    float* __restrict__ d_lnw, float* __restrict__ d_lnb, long ntok, int W, int col, int K, int D,
+    float eps) {
+    __shared__ float red[KMAX * DMAX + 2 * KMAX + 2 * DMAX];
+    const int nred = K * D + 2 * K + 2 * D;
+    for (int i = threadIdx.x; i < nred; i += 256) red[i] = 0.f;
+    __syncthreads();
+    float* r_tab = red;             // [K*D]
+    float* r_pw = red + K * D;      // [K]
+    float* r_pb = r_pw + K;         // [K]
+    float* r_g = r_pb + K;          // [D]
+    float* r_b = r_g + D;           // [D]
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < ntok) {
+        const float xv = x[t];
+        float w[KMAX], e[DMAX], de[DMAX];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) { w[k] = k < K ? xv * pw[k] + pb[k] : -INFINITY; mx = fmaxf(mx, w[k]); }
+        float den = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) { w[k] = k < K ? expf(w[k] - mx) : 0.f; den += w[k]; }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) w[k] /= den;
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) {
+            float a = 0.f;
+            if (d < D) {
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) if (k < K) a += w[k] * table[k * D + d];
+            }
+            e[d] = a;
+        }
+        const float* dy = dout + t * W + col;
+        if (lnw) {
+            float mu = 0.f;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) mu += e[d];
+            mu /= D;
+            float var = 0.f;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) if (d < D) var += (e[d] - mu) * (e[d] - mu);
+            const float rs = rsqrtf(var / D + eps);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) if (d < D) {
+                const float xh = (e[d] - mu) * rs;
+                const float g = dy[d] * lnw[d];
+                s1 += g; s2 += g * xh;
+                atomicAdd(&r_g[d], dy[d] * xh);
+                atomicAdd(&r_b[d], dy[d]);
+            }
+            s1 /= D; s2 /= D;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) {
+                const float xh = (e[d] - mu) * rs;
+                de[d] = d < D ? rs * (dy[d] * lnw[d] - s1 - xh * s2) : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) de[d] = d < D ? dy[d] : 0.f;
+        }
+        // e = sum_k w_k T_k :  dT_k += w_k de ; dw_k = de . T_k ; ds = w * (dw - sum_j w_j dw_j)
+        float dw[KMAX];
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            float a = 0.f;
+            if (k < K) {
+#pragma unroll
+                for (int d = 0; d < DMAX; ++d) if (d < D) {
+                    a += de[d] * table[k * D + d];
+                    atomicAdd(&r_tab[k * D + d], w[k] * de[d]);
+                }
+            }
+            dw[k] = a;
+            dot += w[k] * a;
+        }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) if (k < K) {
+            const float ds = w[k] * (dw[k] - dot);
+            atomicAdd(&r_pw[k], ds * xv);
+            atomicAdd(&r_pb[k], ds);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * D; i += 256) atomicAdd(d_table + i, r_tab[i]);
+    for (int i = threadIdx.x; i < K; i += 256) {
+        atomicAdd(d_pw + i, r_pw[i]);
+        atomicAdd(d_pb + i, r_pb[i]);
+    }
+    if (lnw)
+        for (int i = threadIdx.x; i < D; i += 256) {
+            atomicAdd(d_lnw + i, r_g[i]);
+            atomicAdd(d_lnb + i, r_b[i]);
+        }
+}
+
+extern "C" int t4r_soft_embedding_bwd(void* stream, const float* dout, const float* x,
+                                      const float* proj_w, const float* proj_b, const float* table,
+                                      const float* ln_w, float* d_proj_w, float* d_proj_b,
+                                      float* d_table, float* d_ln_w, float* d_ln_b, long ntok, int W,
+                                      int col, int K, int D, float eps) {
+    if (ntok == 0) return 0;
+    T4R_CHECK_ARG(K >= 1 && K <= T4R_SOFT_MAXK && D >= 1 && D <= T4R_SOFT_MAXD,
+                  "soft_embedding_bwd: K<=32, dim<=32");
+    dim3 grid((unsigned)((ntok + 255) / 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (K <= 16 && D <= 8)
+        hipLaunchKernelGGL((soft_embedding_bwd_kernel<16, 8>), grid, block, 0, st, dout, x, proj_w,
+                           proj_b, table, ln_w, d_proj_w, d_proj_b, d_table, d_ln_w, d_ln_b, ntok, W,
+                           col, K, D, eps);
+    else
+        hipLaunchKernelGGL((soft_embedding_bwd_kernel<32, 32>), grid, block, 0, st, dout, x, proj_w,
+                           proj_b, table, ln_w, d_proj_w, d_proj_b, d_table, d_ln_w, d_ln_b, ntok, W,
+                           col, K, D, eps);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// ragged -> padded  (pad_inputs / _pad_ragged_tensor): out[r, c] = values[offsets[r] + c] for
+// c < min(len_r, L), else 0.  One wave per row; elem_size 4 or 8 bytes (float / int64).
+template <typename T>
+__global__ __launch_bounds__(256) void ragged_to_padded_kernel(const T* __restrict__ values,
+                                                                const long* __restrict__ offsets,
+                                                                T* __restrict__ out, int rows, int L) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long o0 = offsets[row], o1 = offsets[row + 1];
+    const long len = o1 - o0;
+    for (int c = threadIdx.x & 63; c < L; c += 64)
+        out[(long)row * L + c] = c < len ? values[o0 + c] : (T)0;
+}
+
+// row-length maximum (pad_inputs: min(max_sequence_length, batch max)); result in *out_max
+__global__ void max_row_len_kernel(const long* __restrict__ offsets, int rows, int* out_max) {
+    int m = 0;
+    for (int r = threadIdx.x; r < rows; r += blockDim.x) m = max(m, (int)(offsets[r + 1] - offsets[r]));
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+    __shared__ int sm[16];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = max(m, sm[i]);
+        *out_max = m;
+    }
+}
+
+extern "C" int t4r_ragged_max_len(void* stream, const long* offsets, int rows, int* out_max) {
+    T4R_CHECK_ARG(rows >= 1, "ragged_max_len: rows >= 1");
+    hipLaunchKernelGGL(max_row_len_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, offsets, rows, out_max);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int t4r_ragged_to_padded(void* stream, const void* values, const long* offsets, void* out,
+                                    int rows, int L, int elem_size) {
+    if (rows == 0 || L == 0) return 0;
+    T4R_CHECK_ARG(elem_size == 4 || elem_size == 8, "ragged_to_padded: elem_size 4 or 8");
+    dim3 grid((rows + 3) / 4), block(256);
+    if (elem_size == 8)
+        hipLaunchKernelGGL(ragged_to_padded_kernel<long>, grid, block, 0, (hipStream_t)stream,
+                           (const long*)values, offsets, (long*)out, rows, L);
+    else
+        hipLaunchKernelGGL(ragged_to_padded_kernel<float>, grid, block, 0, (hipStream_t)stream,
+                           (const float*)values, offsets, (float*)out, rows, L);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}

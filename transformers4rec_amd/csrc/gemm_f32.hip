@@ -1,0 +1,311 @@
+// fp32 GEMM on the CDNA4 matrix cores:  C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] (+ epilogue)
+//
+// Used for every dense contraction of the session-sequence hot path (exact-fp32 parity with
+// the reference's CPU path, which computes in fp32):
+//   XLNet q/k/v/o/r projections   (HF modeling_xlnet.py:253-259,145)   einsum("ibh,hnd->ibnd")
+//   XLNet feed-forward            (HF modeling_xlnet.py:297-305)
+//   projection MLP / task block   (transformers4rec/torch/block/mlp.py:133-135)
+//   next-item logits X @ W^T      (transformers4rec/torch/model/prediction_task.py:664)
+// and all of their dgrad / wgrad contractions.
+//
+// Design (gfx950): v_mfma_f32_32x32x2_f32 (exact f32, 64 FLOP/clk/SIMD, 157 TF chip peak).
+// 256-thread workgroup = 4 waves as 2(M) x 2(N); block tile BM x BN x BK, wave tile
+// (BM/2) x (BN/2) = WMxWN MFMA tiles of 32x32.  Both operands are staged through LDS in a
+// k-major image  S[k][m]  (m contiguous) so that an MFMA A/B fragment (lane l -> row l&31,
+// k-slot l>>5) is one conflict-free ds_read_b32 per lane.  Operands that are k-contiguous in
+// HBM are transposed on the way into LDS (row pitch == 2 mod 32 keeps the 4 scattered
+// ds_write_b32 of one float4 conflict free); m-contiguous operands are copied with 16-byte
+// LDS stores.  Global loads for tile t+1 are issued before the MFMAs of tile t (register
+// prefetch, 2 LDS buffers, one barrier per k-tile).
+// Split-K (gridDim.z) accumulates with hardware fp32 atomics into a zeroed / accumulating C:
+// this is how every weight gradient (K = tokens) and the head's dX (K = vocabulary) get
+// enough workgroups to fill 256 CUs.
+#include "t4r_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_RELU = 3 };
+
+struct GemmParams {
+    int M, N, K;
+    const float* A; long lda;   // TA=0: A[M][lda] (k contiguous)   TA=1: A[K][lda] (m contiguous)
+    const float* B; long ldb;   // TB=0: B[K][ldb] (n contiguous)   TB=1: B[N][ldb] (k contiguous)
+    float* C; long ldc;
+    const float* bias;          // [N] or null
+    float* aux; long ldaux;     // EPI_BIAS_GELU: pre-activation (x + bias) written here
+    float alpha;
+    int epilogue;
+    int splitk;                 // >1: atomic accumulate alpha*partial into C (epilogue must be NONE)
+    int accumulate;             // splitk==1 only: C += result instead of C = result
+    long sA, sB, sC;            // batch strides in elements (gridDim.z = batch * splitk)
+    int vecA, vecB;             // 16-byte vector loads legal for this operand
+};
+
+// Load one float4 worth of an operand with guards.  `valid` = number of in-range elements
+// (<=0: none).  vec: 16-byte load legal.
+__device__ __forceinline__ float4 ld4_guard(const float* p, int valid, bool vec) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid >= 4 && vec) {
+        v = *reinterpret_cast<const float4*>(p);
+    } else if (valid > 0) {
+        v.x = p[0];
+        if (valid > 1) v.y = p[1];
+        if (valid > 2) v.z = p[2];
+        if (valid > 3) v.w = p[3];
+    }
+    return v;
+}
+
+template <int BM, int BN, int BK, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
+    constexpr int WM = BM / 64, WN = BN / 64;          // MFMA tiles per wave per dim
+    constexpr int LDA_S = BM + (TA ? 4 : 2);           // LDS row pitch (floats)
+    constexpr int LDB_S = BN + (TB ? 2 : 4);
+    constexpr int NA4 = BM * BK / 4 / 256;             // float4 per thread per tile
+    constexpr int NB4 = BN * BK / 4 / 256;
+    static_assert(NA4 >= 1 && NB4 >= 1, "tile too small");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                                   // [2][BK][LDA_S]
+    float* Bs = smem + 2 * BK * LDA_S;                  // [2][BK][LDB_S]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int batch = blockIdx.z / p.splitk, ks = blockIdx.z % p.splitk;
+
+    // split-K range (multiples of BK)
+    const int kt_total = (p.K + BK - 1) / BK;
+    const int kt_per = (kt_total + p.splitk - 1) / p.splitk;
+    const int kt_begin = ks * kt_per;
+    const int kt_end = min(kt_total, kt_begin + kt_per);
+    if (kt_begin >= kt_end) return;
+
+    const float* A = p.A + batch * p.sA;
+    const float* B = p.B + batch * p.sB;
+    float* C = p.C + batch * p.sC;
+    const bool vecA = p.vecA, vecB = p.vecB;
+
+    float4 ra[NA4], rb[NB4];
+
+    auto load_tiles = [&](int kt) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int r = 0; r < NA4; ++r) {
+            const int idx = tid + r * 256;
+            if (TA) {  // A[K][lda], m contiguous: tile row = k, 4 consecutive m
+                const int k = idx / (BM / 4), m4 = (idx % (BM / 4)) * 4;
+                const int gk = k0 + k, gm = m0 + m4;
+                ra[r] = ld4_guard(A + (long)gk * p.lda + gm, gk < p.K ? p.M - gm : 0, vecA);
+            } else {   // A[M][lda], k contiguous: tile row = m, 4 consecutive k
+                const int m = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
+                const int gm = m0 + m, gk = k0 + k4;
+                ra[r] = ld4_guard(A + (long)gm * p.lda + gk, gm < p.M ? p.K - gk : 0, vecA);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NB4; ++r) {
+            const int idx = tid + r * 256;
+            if (!TB) {  // B[K][ldb], n contiguous
+                const int k = idx / (BN / 4), n4 = (idx % (BN / 4)) * 4;
+                const int gk = k0 + k, gn = n0 + n4;
+                rb[r] = ld4_guard(B + (long)gk * p.ldb + gn, gk < p.K ? p.N - gn : 0, vecB);
+            } else {    // B[N][ldb], k contiguous
+                const int n = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
+                const int gn = n0 + n, gk = k0 + k4;
+                rb[r] = ld4_guard(B + (long)gn * p.ldb + gk, gn < p.N ? p.K - gk : 0, vecB);
+            }
+        }
+    };
+
+    auto store_tiles = [&](int buf) {
+        float* as = As + buf * BK * LDA_S;
+        float* bs = Bs + buf * BK * LDB_S;
+#pragma unroll
+        for (int r = 0; r < NA4; ++r) {
+            const int idx = tid + r * 256;
+            if (TA) {
+                const int k = idx / (BM / 4), m4 = (idx % (BM / 4)) * 4;
+                *reinterpret_cast<float4*>(as + k * LDA_S + m4) = ra[r];
+            } else {
+                const int m = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
+                as[(k4 + 0) * LDA_S + m] = ra[r].x;
+                as[(k4 + 1) * LDA_S + m] = ra[r].y;
+                as[(k4 + 2) * LDA_S + m] = ra[r].z;
+                as[(k4 + 3) * LDA_S + m] = ra[r].w;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NB4; ++r) {
+            const int idx = tid + r * 256;
+            if (!TB) {
+                const int k = idx / (BN / 4), n4 = (idx % (BN / 4)) * 4;
+                *reinterpret_cast<float4*>(bs + k * LDB_S + n4) = rb[r];
+            } else {
+                const int n = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
+                bs[(k4 + 0) * LDB_S + n] = rb[r].x;
+                bs[(k4 + 1) * LDB_S + n] = rb[r].y;
+                bs[(k4 + 2) * LDB_S + n] = rb[r].z;
+                bs[(k4 + 3) * LDB_S + n] = rb[r].w;
+            }
+        }
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_tiles(kt_begin);
+    store_tiles(0);
+    __syncthreads();
+
+    const int arow = wm * (BM / 2) + (lane & 31);
+    const int bcol = wn * (BN / 2) + (lane & 31);
+    const int khalf = lane >> 5;
+
+    int buf = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const bool more = kt + 1 < kt_end;
+        if (more) load_tiles(kt + 1);
+        const float* as = As + buf * BK * LDA_S;
+        const float* bs = Bs + buf * BK * LDB_S;
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            const int k = 2 * kk + khalf;
+            float a[WM], b[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) a[i] = as[k * LDA_S + arow + i * 32];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) b[j] = bs[k * LDB_S + bcol + j * 32];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_tiles(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const float alpha = p.alpha;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+            if (col >= p.N) continue;
+            float bv = 0.f;
+            if (p.epilogue != EPI_NONE && p.bias) bv = p.bias[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (row >= p.M) continue;
+                float v = alpha * acc[i][j][r];
+                float* cp = C + (long)row * p.ldc + col;
+                if (p.splitk > 1) {
+                    atomicAdd(cp, v);
+                } else {
+                    if (p.epilogue == EPI_BIAS) {
+                        v += bv;
+                    } else if (p.epilogue == EPI_BIAS_GELU) {
+                        v += bv;
+                        if (p.aux) p.aux[(long)row * p.ldaux + col] = v;
+                        v = gelu_erf(v);
+                    } else if (p.epilogue == EPI_BIAS_RELU) {
+                        v = fmaxf(v + bv, 0.f);
+                    }
+                    if (p.accumulate) v += *cp;
+                    *cp = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int BK, bool TA, bool TB>
+static int launch_cfg(const GemmParams& p, int batch, hipStream_t stream) {
+    constexpr int LDA_S = BM + (TA ? 4 : 2), LDB_S = BN + (TB ? 2 : 4);
+    constexpr size_t smem = (size_t)2 * BK * (LDA_S + LDB_S) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_f32_kernel<BM, BN, BK, TA, TB>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+    }
+    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, batch * p.splitk);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, TA, TB>), grid, dim3(256), smem, stream, p);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+template <bool TA, bool TB>
+static int launch_layout(GemmParams& p, int batch, int splitk_req, hipStream_t stream) {
+    // tile choice: prefer 128x128; drop to 64-wide tiles when the grid would not fill 256 CUs
+    auto nblk = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * batch; };
+    int bm = 128, bn = 128;
+    if (p.N <= 64) bn = 64;
+    if (p.M <= 64) bm = 64;
+    if (nblk(bm, bn) < 384 && bm == 128) bm = 64;
+    if (nblk(bm, bn) < 384 && bn == 128) bn = 64;
+    constexpr int BK = 32;
+    int splitk = splitk_req;
+    if (splitk_req == 0) {  // auto: only when the caller allows atomics (accumulating outputs)
+        splitk = 1;
+    } else if (splitk_req < 0) {
+        const long blocks = nblk(bm, bn);
+        const int kt = (p.K + BK - 1) / BK;
+        splitk = (int)min((long)kt, max(1L, 1024 / max(1L, blocks)));
+        splitk = min(splitk, 256);
+    }
+    p.splitk = max(1, splitk);
+    if (p.splitk > 1) {
+        if (p.epilogue != EPI_NONE) { t4r_set_error("gemm: split-K needs epilogue NONE"); return -1; }
+        if (!p.accumulate) {  // atomics accumulate: start from zero unless the caller accumulates
+            for (int b = 0; b < batch; ++b)
+                (void)hipMemset2DAsync(p.C + b * p.sC, p.ldc * sizeof(float), 0, p.N * sizeof(float), p.M, stream);
+        }
+    }
+    if (bm == 128 && bn == 128) return launch_cfg<128, 128, BK, TA, TB>(p, batch, stream);
+    if (bm == 64 && bn == 128) return launch_cfg<64, 128, BK, TA, TB>(p, batch, stream);
+    if (bm == 128 && bn == 64) return launch_cfg<128, 64, BK, TA, TB>(p, batch, stream);
+    return launch_cfg<64, 64, BK, TA, TB>(p, batch, stream);
+}
+
+// Internal C++ entry used by the composite (layer / head) launchers.
+int t4r_gemm_launch(hipStream_t stream, int transA, int transB, int M, int N, int K, float alpha,
+                    const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+                    const float* bias, int epilogue, float* aux, long ldaux, int splitk,
+                    int accumulate, int batch, long sA, long sB, long sC) {
+    if (M <= 0 || N <= 0) return 0;
+    T4R_CHECK_ARG(K > 0 && A && B && C && batch >= 1, "gemm: bad arguments");
+    GemmParams p;
+    p.M = M; p.N = N; p.K = K;
+    p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;
+    p.bias = bias; p.aux = aux; p.ldaux = ldaux; p.alpha = alpha; p.epilogue = epilogue;
+    p.accumulate = accumulate; p.sA = sA; p.sB = sB; p.sC = sC;
+    p.vecA = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0) && (sA % 4 == 0);
+    p.vecB = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0) && (sB % 4 == 0);
+    p.splitk = 1;
+    if (transA) {
+        if (transB) return launch_layout<true, true>(p, batch, splitk, stream);
+        return launch_layout<true, false>(p, batch, splitk, stream);
+    }
+    if (transB) return launch_layout<false, true>(p, batch, splitk, stream);
+    return launch_layout<false, false>(p, batch, splitk, stream);
+}
+
+extern "C" int t4r_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, float alpha,
+                            const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+                            const float* bias, int epilogue, float* aux, long ldaux, int splitk,
+                            int accumulate, int batch, long strideA, long strideB, long strideC) {
+    return t4r_gemm_launch((hipStream_t)stream, transA, transB, M, N, K, alpha, A, lda, B, ldb, C,
+                           ldc, bias, epilogue, aux, ldaux, splitk, accumulate, batch, strideA,
+                           strideB, strideC);
+}

@@ -1,0 +1,305 @@
+// Next-item head: softmax cross-entropy over the item vocabulary (forward + backward) on the
+// materialised logits [N, V] (the reference returns them as "predictions"), the mean
+// reduction, the sampled-softmax logit assembly, and top-k for the inference/eval path.
+//
+// Reference behaviour restated (transformers4rec/torch/model/prediction_task.py):
+//   logits = X @ W^T ; torch.div(logits, T)      :664-669   (GEMM, alpha = 1/T: gemm_f32.hip)
+//   loss = torch.nn.CrossEntropyLoss()(logits,y) :347,446   mean over the N label rows
+//   label smoothing variant                      transformers4rec/torch/losses.py:4-20
+//   sampled softmax logits                       :673-696
+//   top-k at inference                           :466-470
+// HBM-bound: the [N, V] matrix is read exactly once per pass with 16-byte loads; one
+// workgroup per row, online (max, sum-exp) per thread then a workgroup reduction.
+#include "t4r_common.h"
+
+__device__ __forceinline__ void online_merge(float& m, float& s, float m2, float s2) {
+    const float mn = fmaxf(m, m2);
+    if (mn == -INFINITY) { m = mn; s = 0.f; return; }
+    s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
+    m = mn;
+}
+
+// loss_row[i] = lse_i - (1-eps)*logit[i,y_i] - eps/V * sum_j logit[i,j]   (eps = label smoothing)
+__global__ __launch_bounds__(256) void softmax_ce_fwd_kernel(const float* __restrict__ logits,
+                                                              const long* __restrict__ labels,
+                                                              float* __restrict__ loss_row,
+                                                              float* __restrict__ lse_out, int N,
+                                                              int V, long ld, float smoothing) {
+    const int row = blockIdx.x;
+    const float* x = logits + (long)row * ld;
+    float m = -INFINITY, s = 0.f, tot = 0.f;
+    const bool vec = (ld % 4 == 0) && ((uintptr_t)logits % 16 == 0);
+    if (vec) {
+        const int v4 = V / 4;
+        for (int i = threadIdx.x; i < v4; i += 256) {
+            const float4 t = *reinterpret_cast<const float4*>(x + 4 * i);
+            const float mx = fmaxf(fmaxf(t.x, t.y), fmaxf(t.z, t.w));
+            const float mn = fmaxf(m, mx);
+            s = s * __expf(m - mn) + __expf(t.x - mn) + __expf(t.y - mn) + __expf(t.z - mn) + __expf(t.w - mn);
+            m = mn;
+            tot += t.x + t.y + t.z + t.w;
+        }
+        for (int i = v4 * 4 + threadIdx.x; i < V; i += 256) {
+            const float t = x[i];
+            const float mn = fmaxf(m, t);
+            s = s * __expf(m - mn) + __expf(t - mn);
+            m = mn;
+            tot += t;
+        }
+    } else {
+        for (int i = threadIdx.x; i < V; i += 256) {
+            const float t = x[i];
+            const float mn = fmaxf(m, t);
+            s = s * __expf(m - mn) + __expf(t - mn);
+            m = mn;
+            tot += t;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+        online_merge(m, s, m2, s2);
+        tot += __shfl_xor(tot, o, 64);
+    }
+    __shared__ float sm[4], ss[4], st[4];
+    if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = m; ss[threadIdx.x >> 6] = s; st[threadIdx.x >> 6] = tot; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) { online_merge(m, s, sm[w], ss[w]); tot += st[w]; }
+        const float lse = m + __logf(s);
+        const long y = labels[row];
+        float loss = lse - x[y];
+        if (smoothing > 0.f) loss = (1.f - smoothing) * loss + smoothing * (lse - tot / V);
+        loss_row[row] = loss;
+        lse_out[row] = lse;
+    }
+}
+
+// deterministic mean of n floats (single workgroup)
+__global__ __launch_bounds__(1024) void mean_kernel(const float* __restrict__ x, int n,
+                                                     float* __restrict__ out) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) s += x[i];
+    s = wave_sum(s);
+    __shared__ float sm[16];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += sm[w];
+        *out = n > 0 ? t / n : 0.f;
+    }
+}
+
+extern "C" int t4r_softmax_ce_fwd(void* stream, const float* logits, const long* labels,
+                                  float* loss_rows, float* lse, float* loss_mean, int N, int V, long ld,
+                                  float label_smoothing) {
+    hipStream_t st = (hipStream_t)stream;
+    if (N > 0) {
+        hipLaunchKernelGGL(softmax_ce_fwd_kernel, dim3(N), dim3(256), 0, st, logits, labels, loss_rows,
+                           lse, N, V, ld, label_smoothing);
+    }
+    if (loss_mean) hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, st, loss_rows, N, loss_mean);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+// dlogits[i,j] = gscale * (softmax_ij - (1-eps)*[j==y_i] - eps/V),  gscale = *gout / N (mean)
+// columns V..ld-1 (padding of the leading dimension) are written as 0.
+__global__ __launch_bounds__(256) void softmax_ce_bwd_kernel(const float* __restrict__ logits,
+                                                              const long* __restrict__ labels,
+                                                              const float* __restrict__ lse,
+                                                              const float* __restrict__ gout,
+                                                              float* __restrict__ dlogits, int N,
+                                                              int V, long ld, float smoothing) {
+    const int row = blockIdx.y;
+    const float* x = logits + (long)row * ld;
+    float* dx = dlogits + (long)row * ld;
+    const float g = (gout ? *gout : 1.f) / N;
+    const float l = lse[row];
+    const int y = (int)labels[row];
+    const float sub = smoothing / V;
+    const bool vec = (ld % 4 == 0) && ((uintptr_t)logits % 16 == 0) && ((uintptr_t)dlogits % 16 == 0);
+    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= ld) return;
+    if (vec && i0 + 4 <= V) {
+        float4 t = *reinterpret_cast<const float4*>(x + i0);
+        t.x = g * (__expf(t.x - l) - sub); t.y = g * (__expf(t.y - l) - sub);
+        t.z = g * (__expf(t.z - l) - sub); t.w = g * (__expf(t.w - l) - sub);
+        const float hit = g * (1.f - smoothing);
+        if (y == i0) t.x -= hit; else if (y == i0 + 1) t.y -= hit;
+        else if (y == i0 + 2) t.z -= hit; else if (y == i0 + 3) t.w -= hit;
+        *reinterpret_cast<float4*>(dx + i0) = t;
+    } else {
+        for (int e = 0; e < 4; ++e) {
+            const int i = i0 + e;
+            if (i >= ld) break;
+            float v = 0.f;
+            if (i < V) {
+                v = g * (__expf(x[i] - l) - sub);
+                if (i == y) v -= g * (1.f - smoothing);
+            }
+            dx[i] = v;
+        }
+    }
+}
+
+extern "C" int t4r_softmax_ce_bwd(void* stream, const float* logits, const long* labels,
+                                  const float* lse, const float* grad_out, float* dlogits, int N, int V,
+                                  long ld, float label_smoothing) {
+    if (N == 0) return 0;
+    dim3 grid((unsigned)((ld + 1023) / 1024), N);
+    hipLaunchKernelGGL(softmax_ce_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, logits, labels,
+                       lse, grad_out, dlogits, N, V, ld, label_smoothing);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// sampled softmax (prediction_task.py:673-696): logits[N, 1+S]
+//   col 0   : sum(x * W[y]) - log(q[y] + 1e-16)
+//   col 1+s : x . W[neg_s]  - log(q[neg_s] + 1e-16), or finfo(fp16).min/100 on accidental hits
+// then / T.  One wave per (row): the S+1 dot products of length D.
+__global__ __launch_bounds__(256) void sampled_logits_kernel(
+    const float* __restrict__ x, const long* __restrict__ y, const float* __restrict__ W,
+    const long* __restrict__ neg, const float* __restrict__ qdist, float* __restrict__ out, int N,
+    int D, int S, float inv_t) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const float* xr = x + (long)row * D;
+    const long yi = y[row];
+    for (int c = 0; c <= S; ++c) {
+        const long id = c == 0 ? yi : neg[c - 1];
+        const float* wr = W + id * D;
+        float s = 0.f;
+        for (int d = lane; d < D; d += 64) s += xr[d] * wr[d];
+        s = wave_sum(s);
+        if (lane == 0) {
+            float v = s - __logf(qdist[id] + 1e-16f);
+            if (c > 0 && id == yi) v = -65504.0f / 100.0f;
+            out[(long)row * (S + 1) + c] = v * inv_t;
+        }
+    }
+}
+
+extern "C" int t4r_sampled_logits_fwd(void* stream, const float* x, const long* labels, const float* W,
+                                      const long* neg_samples, const float* sampling_dist, float* out,
+                                      int N, int D, int n_neg, float temperature) {
+    if (N == 0) return 0;
+    const float inv_t = temperature != 0.f ? 1.f / temperature : 1.f;
+    hipLaunchKernelGGL(sampled_logits_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x,
+                       labels, W, neg_samples, sampling_dist, out, N, D, n_neg, inv_t);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+// backward of sampled logits:  dx[row] = sum_c g[row,c]/T * W[id_c] ; dW[id_c] += g[row,c]/T * x[row]
+// (accidental hits carry no gradient: their value is a constant)
+__global__ __launch_bounds__(256) void sampled_logits_bwd_kernel(
+    const float* __restrict__ g, const float* __restrict__ x, const long* __restrict__ y,
+    const float* __restrict__ W, const long* __restrict__ neg, float* __restrict__ dx,
+    float* __restrict__ dW, int N, int D, int S, float inv_t) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const long yi = y[row];
+    const float* xr = x + (long)row * D;
+    for (int d = lane; d < D; d += 64) {
+        float acc = 0.f;
+        const float xv = xr[d];
+        for (int c = 0; c <= S; ++c) {
+            const long id = c == 0 ? yi : neg[c - 1];
+            if (c > 0 && id == yi) continue;
+            const float gv = g[(long)row * (S + 1) + c] * inv_t;
+            acc += gv * W[id * D + d];
+            atomicAdd(dW + id * D + d, gv * xv);
+        }
+        dx[(long)row * D + d] = acc;
+    }
+}
+
+extern "C" int t4r_sampled_logits_bwd(void* stream, const float* dlogits, const float* x,
+                                      const long* labels, const float* W, const long* neg_samples,
+                                      float* dx, float* dW, int N, int D, int n_neg, float temperature) {
+    if (N == 0) return 0;
+    const float inv_t = temperature != 0.f ? 1.f / temperature : 1.f;
+    hipLaunchKernelGGL(sampled_logits_bwd_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       dlogits, x, labels, W, neg_samples, dx, dW, N, D, n_neg, inv_t);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// top-k per row (k <= 64) for inference (prediction_task.py:466-470) and Recall/NDCG@k:
+// one workgroup per row; every thread keeps a sorted local top-k over its strided slice in
+// LDS, then a tournament merge.  Ties resolve to the lower index.
+#define TOPK_MAX 64
+__global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ scores, int V, long ld,
+                                                    int k, float* __restrict__ out_val,
+                                                    long* __restrict__ out_idx) {
+    extern __shared__ float sh[];
+    float* cv = sh;                         // [256][k]
+    int* ci = (int*)(sh + 256 * k);         // [256][k]
+    const int row = blockIdx.x;
+    const float* x = scores + (long)row * ld;
+    float* myv = cv + threadIdx.x * k;
+    int* myi = ci + threadIdx.x * k;
+    for (int j = 0; j < k; ++j) { myv[j] = -INFINITY; myi[j] = 0x7fffffff; }
+    for (int i = threadIdx.x; i < V; i += 256) {
+        const float v = x[i];
+        if (v > myv[k - 1] || (v == myv[k - 1] && i < myi[k - 1])) {
+            int j = k - 1;
+            while (j > 0 && (myv[j - 1] < v || (myv[j - 1] == v && myi[j - 1] > i))) {
+                myv[j] = myv[j - 1]; myi[j] = myi[j - 1]; --j;
+            }
+            myv[j] = v; myi[j] = i;
+        }
+    }
+    __syncthreads();
+    // k rounds: pick the best head among the 256 sorted lists
+    __shared__ int head[256];
+    __shared__ float bv[4];
+    __shared__ int bi[4], bt[4];
+    head[threadIdx.x] = 0;
+    __syncthreads();
+    for (int r = 0; r < k; ++r) {
+        const int hd = head[threadIdx.x];
+        float v = hd < k ? myv[hd] : -INFINITY;
+        int idx = hd < k ? myi[hd] : 0x7fffffff;
+        int t = threadIdx.x;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float v2 = __shfl_xor(v, o, 64);
+            const int i2 = __shfl_xor(idx, o, 64);
+            const int t2 = __shfl_xor(t, o, 64);
+            if (v2 > v || (v2 == v && i2 < idx)) { v = v2; idx = i2; t = t2; }
+        }
+        if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = v; bi[threadIdx.x >> 6] = idx; bt[threadIdx.x >> 6] = t; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (bv[w] > v || (bv[w] == v && bi[w] < idx)) { v = bv[w]; idx = bi[w]; t = bt[w]; }
+            out_val[(long)row * k + r] = v;
+            out_idx[(long)row * k + r] = idx;
+            head[t] += 1;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int t4r_topk(void* stream, const float* scores, int N, int V, long ld, int k, float* out_val,
+                        long* out_idx) {
+    if (N == 0) return 0;
+    T4R_CHECK_ARG(k >= 1 && k <= TOPK_MAX && k <= V, "topk: 1 <= k <= min(64, V)");
+    const size_t smem = (size_t)256 * k * 8;
+    static size_t attr = 0;
+    if (smem > attr) {
+        (void)hipFuncSetAttribute((const void*)topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr = smem;
+    }
+    hipLaunchKernelGGL(topk_kernel, dim3(N), dim3(256), smem, (hipStream_t)stream, scores, V, ld, k,
+                       out_val, out_idx);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,77 @@
+// Shared device/host helpers for the t4r_hip kernels (gfx950 / CDNA4 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define T4R_WAVE 64
+
+extern "C" void t4r_set_error(const char* msg);
+
+#define T4R_CHECK_ARG(cond, msg)          \
+    do {                                  \
+        if (!(cond)) {                    \
+            t4r_set_error(msg);           \
+            return -1;                    \
+        }                                 \
+    } while (0)
+
+#define T4R_LAUNCH_CHECK()                                  \
+    do {                                                    \
+        hipError_t e__ = hipGetLastError();                 \
+        if (e__ != hipSuccess) {                            \
+            t4r_set_error(hipGetErrorString(e__));          \
+            return (int)e__;                                \
+        }                                                   \
+    } while (0)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// exact (erf) GELU, as torch.nn.functional.gelu(approximate="none") / HF ACT2FN["gelu"]
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// Philox4x32-10 counter RNG (device-side draws for MLM masking / dropout).
+struct Philox {
+    uint32_t k0, k1;
+    __device__ __forceinline__ Philox(uint64_t seed) : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)) {}
+    __device__ __forceinline__ uint4 operator()(uint64_t ctr_lo, uint64_t ctr_hi) const {
+        uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32);
+        uint32_t c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
+        uint32_t a = k0, b = k1;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+            const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+            const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ a;
+            const uint32_t n1 = (uint32_t)p1;
+            const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ b;
+            const uint32_t n3 = (uint32_t)p0;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            a += 0x9E3779B9u; b += 0xBB67AE85u;
+        }
+        return make_uint4(c0, c1, c2, c3);
+    }
+};
+__device__ __forceinline__ float u32_to_unit(uint32_t x) {  // [0,1)
+    return (float)(x >> 8) * (1.0f / 16777216.0f);
+}

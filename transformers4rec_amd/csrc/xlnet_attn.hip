@@ -1,0 +1,388 @@
+// XLNet relative-position bidirectional attention core, forward and backward (gfx950).
+//
+// Restates HF transformers modeling_xlnet.py (third-party dependency of the reference,
+// reached through transformers4rec/torch/block/transformer.py:179-199):
+//   rel_attn_core   :95-140    ac = (q + r_w_bias).k ; bd = rel_shift((q + r_r_bias).k_r)
+//                              prob = softmax((ac + bd) * 1/sqrt(d_head)) ; out = prob.v
+//   rel_shift_bnij  :81-93     for klen == qlen == L:  bd[i, j] = raw[i, j + L - i]
+// with the reference's configuration (config/transformer.py:432-482): attn_type "bi", no
+// attention mask (padding positions attend and are attended -- SURVEY fact 3), no segment
+// term, dropout handled outside.
+//
+// MI355X design: the sequences are tiny (L ~ 20, d_head 16-32) so this is not MFMA work: one
+// workgroup per session, one wave per head, lane i owns query row i.  K, V and the
+// batch-independent positional keys k_r [2L, D] (computed ONCE per layer by a GEMM, not per
+// batch row as the reference does) sit in LDS with a +4 float row pad (conflict-free 16-byte
+// reads for the lane-dependent k_r row j+L-i; k_j / v_j rows are wave-uniform broadcasts).
+// Forward is a single online-softmax pass and saves only the row log-sum-exp; backward
+// recomputes the probabilities (no [B,n,L,L] tensor ever goes to HBM).
+#include "t4r_common.h"
+
+#define ATT_PAD 4
+
+template <int DH>
+__global__ __launch_bounds__(512) void xlnet_attn_fwd_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    const float* __restrict__ kr,      // [2L, D]
+    const float* __restrict__ r_w_bias, const float* __restrict__ r_r_bias,  // [D]
+    float* __restrict__ out,           // [B*L, D]
+    float* __restrict__ lse,           // [B, n, L]
+    int B, int L, int n_head, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int D = n_head * DH;
+    const int LD = D + ATT_PAD;
+    float* Ks = smem;                 // [L][LD]
+    float* Vs = Ks + L * LD;          // [L][LD]
+    float* KRs = Vs + L * LD;         // [2L][LD]
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int dq = D / 4;
+    for (int i = tid; i < L * dq; i += nthr) {
+        const int r = i / dq, c = (i % dq) * 4;
+        *reinterpret_cast<float4*>(Ks + r * LD + c) =
+            *reinterpret_cast<const float4*>(k + ((long)b * L + r) * D + c);
+        *reinterpret_cast<float4*>(Vs + r * LD + c) =
+            *reinterpret_cast<const float4*>(v + ((long)b * L + r) * D + c);
+    }
+    for (int i = tid; i < 2 * L * dq; i += nthr) {
+        const int r = i / dq, c = (i % dq) * 4;
+        *reinterpret_cast<float4*>(KRs + r * LD + c) = *reinterpret_cast<const float4*>(kr + (long)r * D + c);
+    }
+    __syncthreads();
+    const int lane = tid & 63;
+    {
+        const int h = blockIdx.y * 8 + (tid >> 6);   // one head per wave, <= 8 heads per block
+        const int i = lane;
+        if (i >= L || h >= n_head) return;
+        const int hc = h * DH;
+        float qw[DH], qr[DH], o[DH];
+        const float* qrow = q + ((long)b * L + i) * D + hc;
+#pragma unroll
+        for (int d = 0; d < DH; d += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(qrow + d);
+            const float4 bw = *reinterpret_cast<const float4*>(r_w_bias + hc + d);
+            const float4 br = *reinterpret_cast<const float4*>(r_r_bias + hc + d);
+            qw[d] = t.x + bw.x; qw[d + 1] = t.y + bw.y; qw[d + 2] = t.z + bw.z; qw[d + 3] = t.w + bw.w;
+            qr[d] = t.x + br.x; qr[d + 1] = t.y + br.y; qr[d + 2] = t.z + br.z; qr[d + 3] = t.w + br.w;
+        }
+#pragma unroll
+        for (int d = 0; d < DH; ++d) o[d] = 0.f;
+        float m = -INFINITY, l = 0.f;
+        for (int j = 0; j < L; ++j) {
+            const float* kj = Ks + j * LD + hc;
+            const float* krp = KRs + (j + L - i) * LD + hc;
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < DH; d += 4) {
+                const float4 a = *reinterpret_cast<const float4*>(kj + d);
+                const float4 c = *reinterpret_cast<const float4*>(krp + d);
+                s += qw[d] * a.x + qw[d + 1] * a.y + qw[d + 2] * a.z + qw[d + 3] * a.w;
+                s += qr[d] * c.x + qr[d + 1] * c.y + qr[d + 2] * c.z + qr[d + 3] * c.w;
+            }
+            s *= scale;
+            const float mn = fmaxf(m, s);
+            const float alpha = __expf(m - mn);
+            const float pj = __expf(s - mn);
+            l = l * alpha + pj;
+            const float* vj = Vs + j * LD + hc;
+#pragma unroll
+            for (int d = 0; d < DH; d += 4) {
+                const float4 a = *reinterpret_cast<const float4*>(vj + d);
+                o[d] = o[d] * alpha + pj * a.x;
+                o[d + 1] = o[d + 1] * alpha + pj * a.y;
+                o[d + 2] = o[d + 2] * alpha + pj * a.z;
+                o[d + 3] = o[d + 3] * alpha + pj * a.w;
+            }
+            m = mn;
+        }
+        const float inv = 1.f / l;
+        float* orow = out + ((long)b * L + i) * D + hc;
+#pragma unroll
+        for (int d = 0; d < DH; d += 4)
+            *reinterpret_cast<float4*>(orow + d) =
+                make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
+        lse[((long)b * n_head + h) * L + i] = m + __logf(l);
+    }
+}
+
+// Backward.  Grid-stride over sessions; per block partial sums of the batch-reduced
+// gradients (d k_r, d r_w_bias, d r_r_bias) go to a workspace and are summed by
+// xlnet_attn_bwd_reduce_kernel (deterministic, no atomics).
+template <int DH>
+__global__ __launch_bounds__(512) void xlnet_attn_bwd_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    const float* __restrict__ kr, const float* __restrict__ r_w_bias,
+    const float* __restrict__ r_r_bias, const float* __restrict__ out,
+    const float* __restrict__ lse, const float* __restrict__ dout,
+    float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
+    float* __restrict__ part,          // [grid][2L*D + 2*D]
+    int B, int L, int n_head, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int D = n_head * DH;
+    const int LD = D + ATT_PAD;
+    const int LS = L + 1;
+    float* Ks = smem;                        // [L][LD]
+    float* Vs = Ks + L * LD;                 // [L][LD]
+    float* Qs = Vs + L * LD;                 // [L][LD]
+    float* dOs = Qs + L * LD;                // [L][LD]
+    float* KRs = dOs + L * LD;               // [2L][LD]
+    float* dKR = KRs + 2 * L * LD;           // [2L][LD]   block accumulator
+    float* dSs = dKR + 2 * L * LD;           // [n][L][LS]
+    float* Ps = dSs + n_head * L * LS;       // [n][L][LS]
+    float* dRW = Ps + n_head * L * LS;       // [D]  block accumulators of d r_w_bias / d r_r_bias
+    float* dRR = dRW + D;                    // [D]
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63;
+    const int h = blockIdx.y * 8 + (tid >> 6);       // one head per wave, <= 8 heads per block
+    const bool hvalid = h < n_head;
+    const int dq4 = D / 4;
+    for (int i = tid; i < 2 * L * dq4; i += nthr) {
+        const int r = i / dq4, c = (i % dq4) * 4;
+        *reinterpret_cast<float4*>(KRs + r * LD + c) = *reinterpret_cast<const float4*>(kr + (long)r * D + c);
+        *reinterpret_cast<float4*>(dKR + r * LD + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int i = tid; i < 2 * D; i += nthr) dRW[i] = 0.f;
+
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();  // previous session's phases done before the tiles are overwritten
+        for (int i = tid; i < L * dq4; i += nthr) {
+            const int r = i / dq4, c = (i % dq4) * 4;
+            const long g = ((long)b * L + r) * D + c;
+            *reinterpret_cast<float4*>(Ks + r * LD + c) = *reinterpret_cast<const float4*>(k + g);
+            *reinterpret_cast<float4*>(Vs + r * LD + c) = *reinterpret_cast<const float4*>(v + g);
+            *reinterpret_cast<float4*>(Qs + r * LD + c) = *reinterpret_cast<const float4*>(q + g);
+            *reinterpret_cast<float4*>(dOs + r * LD + c) = *reinterpret_cast<const float4*>(dout + g);
+        }
+        __syncthreads();
+        // ---- phase 1: lane = query row i
+        if (hvalid) {
+            const int i = lane;
+            const int hc = h * DH;
+            float ga[DH], gb[DH];
+#pragma unroll
+            for (int d = 0; d < DH; ++d) ga[d] = gb[d] = 0.f;
+            if (lane < L) {
+            float qw[DH], qr[DH], go[DH];
+            const float* orow = out + ((long)b * L + i) * D + hc;
+            float Di = 0.f;
+#pragma unroll
+            for (int d = 0; d < DH; ++d) {
+                const float qv = Qs[i * LD + hc + d];
+                qw[d] = qv + r_w_bias[hc + d];
+                qr[d] = qv + r_r_bias[hc + d];
+                go[d] = dOs[i * LD + hc + d];
+                Di += go[d] * orow[d];
+            }
+            const float lse_i = lse[((long)b * n_head + h) * L + i];
+            float* dsrow = dSs + (h * L + i) * LS;
+            float* prow = Ps + (h * L + i) * LS;
+            for (int j = 0; j < L; ++j) {
+                const float* kj = Ks + j * LD + hc;
+                const float* krp = KRs + (j + L - i) * LD + hc;
+                const float* vj = Vs + j * LD + hc;
+                float s = 0.f, dp = 0.f;
+#pragma unroll
+                for (int d = 0; d < DH; d += 4) {
+                    const float4 a = *reinterpret_cast<const float4*>(kj + d);
+                    const float4 c = *reinterpret_cast<const float4*>(krp + d);
+                    const float4 e = *reinterpret_cast<const float4*>(vj + d);
+                    s += qw[d] * a.x + qw[d + 1] * a.y + qw[d + 2] * a.z + qw[d + 3] * a.w;
+                    s += qr[d] * c.x + qr[d + 1] * c.y + qr[d + 2] * c.z + qr[d + 3] * c.w;
+                    dp += go[d] * e.x + go[d + 1] * e.y + go[d + 2] * e.z + go[d + 3] * e.w;
+                }
+                const float p = __expf(s * scale - lse_i);
+                const float ds = p * (dp - Di) * scale;
+                prow[j] = p;
+                dsrow[j] = ds;
+#pragma unroll
+                for (int d = 0; d < DH; d += 4) {
+                    const float4 a = *reinterpret_cast<const float4*>(kj + d);
+                    const float4 c = *reinterpret_cast<const float4*>(krp + d);
+                    ga[d] += ds * a.x; ga[d + 1] += ds * a.y; ga[d + 2] += ds * a.z; ga[d + 3] += ds * a.w;
+                    gb[d] += ds * c.x; gb[d + 1] += ds * c.y; gb[d + 2] += ds * c.z; gb[d + 3] += ds * c.w;
+                }
+            }
+            float* dqrow = dq + ((long)b * L + i) * D + hc;
+#pragma unroll
+            for (int d = 0; d < DH; d += 4)
+                *reinterpret_cast<float4*>(dqrow + d) = make_float4(
+                    ga[d] + gb[d], ga[d + 1] + gb[d + 1], ga[d + 2] + gb[d + 2], ga[d + 3] + gb[d + 3]);
+            }
+            // d r_w_bias[h] += sum_i ga_i ; d r_r_bias[h] += sum_i gb_i  (this wave owns head h)
+#pragma unroll
+            for (int d = 0; d < DH; ++d) {
+                const float sw = wave_sum(ga[d]);
+                const float sr = wave_sum(gb[d]);
+                if (lane == 0) { dRW[hc + d] += sw; dRR[hc + d] += sr; }
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: lane = key row j :  dk_j = sum_i dS_ij (q_i + r_w) ; dv_j = sum_i P_ij dO_i
+        if (hvalid && lane < L) {
+            const int j = lane;
+            const int hc = h * DH;
+            float gk[DH], gv[DH];
+#pragma unroll
+            for (int d = 0; d < DH; ++d) gk[d] = gv[d] = 0.f;
+            for (int i = 0; i < L; ++i) {
+                const float ds = dSs[(h * L + i) * LS + j];
+                const float p = Ps[(h * L + i) * LS + j];
+                const float* qi = Qs + i * LD + hc;
+                const float* gi = dOs + i * LD + hc;
+#pragma unroll
+                for (int d = 0; d < DH; d += 4) {
+                    const float4 a = *reinterpret_cast<const float4*>(qi + d);
+                    const float4 bw = *reinterpret_cast<const float4*>(r_w_bias + hc + d);
+                    const float4 e = *reinterpret_cast<const float4*>(gi + d);
+                    gk[d] += ds * (a.x + bw.x); gk[d + 1] += ds * (a.y + bw.y);
+                    gk[d + 2] += ds * (a.z + bw.z); gk[d + 3] += ds * (a.w + bw.w);
+                    gv[d] += p * e.x; gv[d + 1] += p * e.y; gv[d + 2] += p * e.z; gv[d + 3] += p * e.w;
+                }
+            }
+            float* dkrow = dk + ((long)b * L + j) * D + hc;
+            float* dvrow = dv + ((long)b * L + j) * D + hc;
+#pragma unroll
+            for (int d = 0; d < DH; d += 4) {
+                *reinterpret_cast<float4*>(dkrow + d) = make_float4(gk[d], gk[d + 1], gk[d + 2], gk[d + 3]);
+                *reinterpret_cast<float4*>(dvrow + d) = make_float4(gv[d], gv[d + 1], gv[d + 2], gv[d + 3]);
+            }
+        }
+        // ---- phase 3: d k_r[p] += sum_i dS[i, p - L + i] (q_i + r_r)   (p = j + L - i)
+        if (hvalid) {
+            const int hc = h * DH;
+            for (int p = lane; p < 2 * L; p += 64) {
+                float g[DH];
+#pragma unroll
+                for (int d = 0; d < DH; ++d) g[d] = 0.f;
+                for (int i = 0; i < L; ++i) {
+                    const int j = p - L + i;
+                    if (j < 0 || j >= L) continue;
+                    const float ds = dSs[(h * L + i) * LS + j];
+                    const float* qi = Qs + i * LD + hc;
+#pragma unroll
+                    for (int d = 0; d < DH; ++d) g[d] += ds * (qi[d] + r_r_bias[hc + d]);
+                }
+                float* acc = dKR + p * LD + hc;
+#pragma unroll
+                for (int d = 0; d < DH; ++d) acc[d] += g[d];
+            }
+        }
+    }
+    __syncthreads();
+    // block partials -> workspace
+    float* mypart = part + ((long)blockIdx.y * gridDim.x + blockIdx.x) * (2 * L * D + 2 * D);
+    for (int i = tid; i < 2 * L * D; i += nthr) mypart[i] = dKR[(i / D) * LD + (i % D)];
+    for (int i = tid; i < 2 * D; i += nthr) mypart[2 * L * D + i] = dRW[i];
+}
+
+// sums the per-block partials: dkr[2L*D] = sum_blocks ; d_rw[D] += ; d_rr[D] +=
+__global__ __launch_bounds__(256) void xlnet_attn_bwd_reduce_kernel(const float* __restrict__ part,
+                                                                     int nblocks, int n_kr, int D,
+                                                                     float* __restrict__ dkr,
+                                                                     float* __restrict__ d_rw,
+                                                                     float* __restrict__ d_rr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = n_kr + 2 * D;
+    if (i >= total) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += part[(long)b * total + i];
+    if (i < n_kr) dkr[i] = s;
+    else if (i < n_kr + D) d_rw[i - n_kr] += s;
+    else d_rr[i - n_kr - D] += s;
+}
+
+static size_t attn_fwd_smem(int L, int D) { return (size_t)(4 * L) * (D + ATT_PAD) * sizeof(float); }
+static size_t attn_bwd_smem(int L, int D, int n) {
+    return ((size_t)(8 * L) * (D + ATT_PAD) + (size_t)2 * n * L * (L + 1) + 2 * D) * sizeof(float);
+}
+
+extern "C" int t4r_xlnet_attn_bwd_blocks(int B) { return B < 512 ? B : 512; }
+extern "C" long t4r_xlnet_attn_bwd_ws_floats(int B, int L, int D, int n_head) {
+    return (long)t4r_xlnet_attn_bwd_blocks(B) * ((n_head + 7) / 8) * (2L * L * D + 2L * D);
+}
+
+template <int DH>
+static int attn_fwd_launch(hipStream_t st, const float* q, const float* k, const float* v,
+                           const float* kr, const float* rw, const float* rr, float* out, float* lse,
+                           int B, int L, int n_head, float scale) {
+    const int D = n_head * DH;
+    const size_t smem = attn_fwd_smem(L, D);
+    static size_t attr = 0;
+    if (smem > attr) {
+        (void)hipFuncSetAttribute((const void*)xlnet_attn_fwd_kernel<DH>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr = smem;
+    }
+    const int waves = n_head < 8 ? n_head : 8;
+    hipLaunchKernelGGL(xlnet_attn_fwd_kernel<DH>, dim3(B, (n_head + 7) / 8), dim3(64 * waves), smem, st, q, k, v, kr, rw,
+                       rr, out, lse, B, L, n_head, scale);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int t4r_xlnet_attn_fwd(void* stream, const float* q, const float* k, const float* v,
+                                  const float* k_r, const float* r_w_bias, const float* r_r_bias,
+                                  float* out, float* lse, int B, int L, int n_head, int d_head) {
+    if (B == 0) return 0;
+    T4R_CHECK_ARG(L >= 1 && L <= 64, "xlnet_attn: L must be in [1, 64]");
+    const int D = n_head * d_head;
+    T4R_CHECK_ARG(attn_fwd_smem(L, D) <= 160 * 1024, "xlnet_attn: L*d_model too large for LDS");
+    const float scale = 1.0f / sqrtf((float)d_head);
+    hipStream_t st = (hipStream_t)stream;
+    switch (d_head) {
+        case 8: return attn_fwd_launch<8>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, B, L, n_head, scale);
+        case 16: return attn_fwd_launch<16>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, B, L, n_head, scale);
+        case 32: return attn_fwd_launch<32>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, B, L, n_head, scale);
+        case 64: return attn_fwd_launch<64>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, B, L, n_head, scale);
+    }
+    t4r_set_error("xlnet_attn: d_head must be 8, 16, 32 or 64");
+    return -1;
+}
+
+template <int DH>
+static int attn_bwd_launch(hipStream_t st, const float* q, const float* k, const float* v,
+                           const float* kr, const float* rw, const float* rr, const float* out,
+                           const float* lse, const float* dout, float* dq, float* dk, float* dv,
+                           float* part, float* dkr, float* d_rw, float* d_rr, int B, int L, int n_head,
+                           float scale) {
+    const int D = n_head * DH;
+    const size_t smem = attn_bwd_smem(L, D, n_head);
+    static size_t attr = 0;
+    if (smem > attr) {
+        (void)hipFuncSetAttribute((const void*)xlnet_attn_bwd_kernel<DH>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr = smem;
+    }
+    const int waves = n_head < 8 ? n_head : 8;
+    const int hg = (n_head + 7) / 8;
+    const int nblocks = t4r_xlnet_attn_bwd_blocks(B);
+    hipLaunchKernelGGL(xlnet_attn_bwd_kernel<DH>, dim3(nblocks, hg), dim3(64 * waves), smem, st, q, k, v, kr,
+                       rw, rr, out, lse, dout, dq, dk, dv, part, B, L, n_head, scale);
+    const int total = 2 * L * D + 2 * D;
+    hipLaunchKernelGGL(xlnet_attn_bwd_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, part,
+                       nblocks * hg, 2 * L * D, D, dkr, d_rw, d_rr);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+// d_rw / d_rr are ACCUMULATED into (parameter gradients); dq/dk/dv/dk_r are overwritten.
+extern "C" int t4r_xlnet_attn_bwd(void* stream, const float* q, const float* k, const float* v,
+                                  const float* k_r, const float* r_w_bias, const float* r_r_bias,
+                                  const float* out, const float* lse, const float* dout, float* dq,
+                                  float* dk, float* dv, float* dk_r, float* d_r_w_bias,
+                                  float* d_r_r_bias, float* workspace, int B, int L, int n_head,
+                                  int d_head) {
+    if (B == 0) return 0;
+    T4R_CHECK_ARG(L >= 1 && L <= 64, "xlnet_attn: L must be in [1, 64]");
+    const int D = n_head * d_head;
+    T4R_CHECK_ARG(attn_bwd_smem(L, D, n_head) <= 160 * 1024, "xlnet_attn_bwd: L*d_model too large for LDS");
+    const float scale = 1.0f / sqrtf((float)d_head);
+    hipStream_t st = (hipStream_t)stream;
+    switch (d_head) {
+        case 8: return attn_bwd_launch<8>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, dout, dq, dk, dv, workspace, dk_r, d_r_w_bias, d_r_r_bias, B, L, n_head, scale);
+        case 16: return attn_bwd_launch<16>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, dout, dq, dk, dv, workspace, dk_r, d_r_w_bias, d_r_r_bias, B, L, n_head, scale);
+        case 32: return attn_bwd_launch<32>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, dout, dq, dk, dv, workspace, dk_r, d_r_w_bias, d_r_r_bias, B, L, n_head, scale);
+    }
+    t4r_set_error("xlnet_attn_bwd: d_head must be 8, 16 or 32");
+    return -1;
+}

@@ -1,0 +1,203 @@
+// One XLNet layer (relative attention + feed-forward, both post-LN), forward and backward, as
+// a fixed chain of launches on one HIP stream.  Restates HF modeling_xlnet.py
+//   XLNetRelativeAttention.forward (g=None branch) :245-282   + post_attention :142-152
+//   XLNetFeedForward.forward                        :297-305
+//   XLNetLayer.forward                              :308-353
+// with the hyper-parameters fixed by XLNetConfig.build (transformers4rec/config/transformer.py:
+// 432-482): d_inner = 4 d_model, gelu(erf), layer_norm_eps as passed (0.03), attn_type "bi",
+// no masks, no mems.  Dropout = identity here (eval / p = 0).
+//
+// Layout (all fp32, row-major, token t = b*L + l):
+//   h [T,D] -> q,k,v = h @ {q,k,v}[D, n*dh]           (one batched MFMA GEMM when q,k,v are adjacent)
+//   k_r = pos_emb[2L,D] @ r[D, n*dh]                  (once per layer, NOT per batch row)
+//   attn_vec [T,D] = rel-attention(q,k,v,k_r)         (xlnet_attn.hip)
+//   h1 = LN(attn_vec @ o^T + h) ; h2 = LN(W2 gelu(W1 h1 + b1) + b2 + h1)
+// Saved-for-backward activations live in one caller-provided workspace (offsets below).
+#include "t4r_common.h"
+
+int t4r_gemm_launch(hipStream_t stream, int transA, int transB, int M, int N, int K, float alpha,
+                    const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+                    const float* bias, int epilogue, float* aux, long ldaux, int splitk,
+                    int accumulate, int batch, long sA, long sB, long sC);
+extern "C" {
+int t4r_add_layernorm_fwd(void*, const float*, const float*, const float*, const float*, float*,
+                          float*, float*, int, int, float);
+int t4r_add_layernorm_bwd(void*, const float*, const float*, const float*, const float*,
+                          const float*, const float*, float*, float*, float*, int, int, int);
+int t4r_act_bwd_bias(void*, const float*, const float*, float*, float*, long, int, int);
+int t4r_colsum(void*, const float*, float*, long, int, long);
+int t4r_xlnet_attn_fwd(void*, const float*, const float*, const float*, const float*, const float*,
+                       const float*, float*, float*, int, int, int, int);
+int t4r_xlnet_attn_bwd(void*, const float*, const float*, const float*, const float*, const float*,
+                       const float*, const float*, const float*, const float*, float*, float*, float*,
+                       float*, float*, float*, float*, int, int, int, int);
+long t4r_xlnet_attn_bwd_ws_floats(int, int, int, int);
+}
+
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_RELU = 3 };
+
+// parameter order of the `params` / `grads` pointer arrays
+enum { P_Q = 0, P_K, P_V, P_O, P_R, P_RWB, P_RRB, P_LN1W, P_LN1B, P_W1, P_B1, P_W2, P_B2, P_LN2W,
+       P_LN2B, P_COUNT };
+
+struct LayerWs {
+    float *qkv, *kr, *av, *lse, *ao, *mean1, *rstd1, *h1, *ffpre, *ffact, *ffout, *mean2, *rstd2;
+    long total;
+};
+
+static long align4(long x) { return (x + 3) & ~3L; }
+
+static LayerWs carve(float* base, int B, int L, int D, int n) {
+    const long T = (long)B * L;
+    LayerWs w;
+    long o = 0;
+    auto take = [&](long nfl) { float* p = base ? base + o : nullptr; o += align4(nfl); return p; };
+    w.qkv = take(3 * T * D);
+    w.kr = take(2L * L * D);
+    w.av = take(T * D);
+    w.lse = take((long)B * n * L);
+    w.ao = take(T * D);
+    w.mean1 = take(T);
+    w.rstd1 = take(T);
+    w.h1 = take(T * D);
+    w.ffpre = take(T * 4 * D);
+    w.ffact = take(T * 4 * D);
+    w.ffout = take(T * D);
+    w.mean2 = take(T);
+    w.rstd2 = take(T);
+    w.total = o;
+    return w;
+}
+
+extern "C" long t4r_xlnet_layer_ws_floats(int B, int L, int D, int n_head) {
+    return carve(nullptr, B, L, D, n_head).total;
+}
+// backward scratch: dqkv [3,T,D] + dav [T,D] + dx [T,D] + dff [T,4D] + dkr [2L,D] + attention partials
+extern "C" long t4r_xlnet_layer_bwd_ws_floats(int B, int L, int D, int n_head) {
+    const long T = (long)B * L;
+    return align4(3 * T * D) + align4(T * D) + align4(T * D) + align4(T * 4 * D) + align4(2L * L * D) +
+           align4(t4r_xlnet_attn_bwd_ws_floats(B, L, D, n_head));
+}
+
+#define RUN(call)                \
+    do {                         \
+        int rc__ = (call);       \
+        if (rc__ != 0) return rc__; \
+    } while (0)
+
+extern "C" int t4r_xlnet_layer_fwd(void* stream, const float* h, const float* pos_emb,
+                                   const float* const* params, float* ws, float* h_out, int B, int L,
+                                   int D, int n_head, float ln_eps) {
+    if (B == 0) return 0;
+    T4R_CHECK_ARG(D % n_head == 0 && D % 4 == 0, "xlnet_layer: d_model must divide by n_head and 4");
+    hipStream_t st = (hipStream_t)stream;
+    const int T = B * L, dh = D / n_head;
+    LayerWs w = carve(ws, B, L, D, n_head);
+    const float* q_w = params[P_Q];
+    const float* k_w = params[P_K];
+    const float* v_w = params[P_V];
+    const long TD = (long)T * D, DD = (long)D * D;
+    if (k_w == q_w + DD && v_w == q_w + 2 * DD) {
+        RUN(t4r_gemm_launch(st, 0, 0, T, D, D, 1.f, h, D, q_w, D, w.qkv, D, nullptr, EPI_NONE, nullptr, 0,
+                            1, 0, 3, 0, DD, TD));
+    } else {
+        const float* ws3[3] = {q_w, k_w, v_w};
+        for (int z = 0; z < 3; ++z)
+            RUN(t4r_gemm_launch(st, 0, 0, T, D, D, 1.f, h, D, ws3[z], D, w.qkv + z * TD, D, nullptr,
+                                EPI_NONE, nullptr, 0, 1, 0, 1, 0, 0, 0));
+    }
+    RUN(t4r_gemm_launch(st, 0, 0, 2 * L, D, D, 1.f, pos_emb, D, params[P_R], D, w.kr, D, nullptr,
+                        EPI_NONE, nullptr, 0, 1, 0, 1, 0, 0, 0));
+    RUN(t4r_xlnet_attn_fwd(stream, w.qkv, w.qkv + TD, w.qkv + 2 * TD, w.kr, params[P_RWB],
+                           params[P_RRB], w.av, w.lse, B, L, n_head, dh));
+    // attn_out[t, h] = sum_{nd} av[t, nd] * o[h, nd]
+    RUN(t4r_gemm_launch(st, 0, 1, T, D, D, 1.f, w.av, D, params[P_O], D, w.ao, D, nullptr, EPI_NONE,
+                        nullptr, 0, 1, 0, 1, 0, 0, 0));
+    RUN(t4r_add_layernorm_fwd(stream, w.ao, h, params[P_LN1W], params[P_LN1B], w.h1, w.mean1, w.rstd1,
+                              T, D, ln_eps));
+    RUN(t4r_gemm_launch(st, 0, 1, T, 4 * D, D, 1.f, w.h1, D, params[P_W1], D, w.ffact, 4 * D,
+                        params[P_B1], EPI_BIAS_GELU, w.ffpre, 4 * D, 1, 0, 1, 0, 0, 0));
+    RUN(t4r_gemm_launch(st, 0, 1, T, D, 4 * D, 1.f, w.ffact, 4 * D, params[P_W2], 4 * D, w.ffout, D,
+                        params[P_B2], EPI_BIAS, nullptr, 0, 1, 0, 1, 0, 0, 0));
+    RUN(t4r_add_layernorm_fwd(stream, w.ffout, w.h1, params[P_LN2W], params[P_LN2B], h_out, w.mean2,
+                              w.rstd2, T, D, ln_eps));
+    return 0;
+}
+
+// grads[] are ACCUMULATED into (zero them / let the optimizer zero them between steps).
+// dh_in [T,D] is overwritten with d loss / d h.
+extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* pos_emb,
+                                   const float* const* params, float* const* grads, const float* ws,
+                                   float* bws, const float* dh_out, float* dh_in, int B, int L, int D,
+                                   int n_head, float ln_eps) {
+    if (B == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int T = B * L, dh = D / n_head;
+    const long TD = (long)T * D, DD = (long)D * D;
+    LayerWs w = carve(const_cast<float*>(ws), B, L, D, n_head);
+    long o = 0;
+    auto take = [&](long nfl) { float* p = bws + o; o += align4(nfl); return p; };
+    float* dqkv = take(3 * TD);
+    float* dav = take(TD);
+    float* dx = take(TD);
+    float* dff = take(4 * TD);
+    float* dkr = take(2L * L * D);
+    float* attn_ws = take(t4r_xlnet_attn_bwd_ws_floats(B, L, D, n_head));
+
+    // LN2: dy = dh_out, x = ffout + h1  ->  dx (= d ffout = residual part of d h1)
+    RUN(t4r_add_layernorm_bwd(stream, w.ffout, w.h1, params[P_LN2W], w.mean2, w.rstd2, dh_out, dx,
+                              grads[P_LN2W], grads[P_LN2B], T, D, 0));
+    // FF2: ffout = ffact @ w2^T + b2
+    RUN(t4r_gemm_launch(st, 0, 0, T, 4 * D, D, 1.f, dx, D, params[P_W2], 4 * D, dff, 4 * D, nullptr,
+                        EPI_NONE, nullptr, 0, 1, 0, 1, 0, 0, 0));
+    RUN(t4r_gemm_launch(st, 1, 0, D, 4 * D, T, 1.f, dx, D, w.ffact, 4 * D, grads[P_W2], 4 * D, nullptr,
+                        EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0));
+    RUN(t4r_colsum(stream, dx, grads[P_B2], T, D, D));
+    // GELU + bias1
+    RUN(t4r_act_bwd_bias(stream, dff, w.ffpre, dff, grads[P_B1], T, 4 * D, 0));
+    // FF1: ffpre = h1 @ w1^T + b1 ;  d h1 = dx (residual) + dff @ w1
+    RUN(t4r_gemm_launch(st, 0, 0, T, D, 4 * D, 1.f, dff, 4 * D, params[P_W1], D, dx, D, nullptr,
+                        EPI_NONE, nullptr, 0, 1, 1, 1, 0, 0, 0));
+    RUN(t4r_gemm_launch(st, 1, 0, 4 * D, D, T, 1.f, dff, 4 * D, w.h1, D, grads[P_W1], D, nullptr,
+                        EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0));
+    // LN1: dy = d h1 (dx), x = ao + h  ->  dh_in (= d ao = residual part of d h)
+    RUN(t4r_add_layernorm_bwd(stream, w.ao, h, params[P_LN1W], w.mean1, w.rstd1, dx, dh_in,
+                              grads[P_LN1W], grads[P_LN1B], T, D, 0));
+    // O projection: ao = av @ o^T
+    RUN(t4r_gemm_launch(st, 0, 0, T, D, D, 1.f, dh_in, D, params[P_O], D, dav, D, nullptr, EPI_NONE,
+                        nullptr, 0, 1, 0, 1, 0, 0, 0));
+    RUN(t4r_gemm_launch(st, 1, 0, D, D, T, 1.f, dh_in, D, w.av, D, grads[P_O], D, nullptr, EPI_NONE,
+                        nullptr, 0, -1, 1, 1, 0, 0, 0));
+    // attention core
+    RUN(t4r_xlnet_attn_bwd(stream, w.qkv, w.qkv + TD, w.qkv + 2 * TD, w.kr, params[P_RWB],
+                           params[P_RRB], w.av, w.lse, dav, dqkv, dqkv + TD, dqkv + 2 * TD, dkr,
+                           grads[P_RWB], grads[P_RRB], attn_ws, B, L, n_head, dh));
+    // k_r = pos_emb @ r  ->  d r += pos_emb^T @ d k_r
+    RUN(t4r_gemm_launch(st, 1, 0, D, D, 2 * L, 1.f, pos_emb, D, dkr, D, grads[P_R], D, nullptr,
+                        EPI_NONE, nullptr, 0, 1, 1, 1, 0, 0, 0));
+    // q,k,v = h @ w  ->  d h += d{q,k,v} @ w^T ; d w += h^T @ d{q,k,v}
+    const float* wz[3] = {params[P_Q], params[P_K], params[P_V]};
+    float* gz[3] = {grads[P_Q], grads[P_K], grads[P_V]};
+    for (int z = 0; z < 3; ++z)
+        RUN(t4r_gemm_launch(st, 0, 1, T, D, D, 1.f, dqkv + z * TD, D, wz[z], D, dh_in, D, nullptr,
+                            EPI_NONE, nullptr, 0, 1, 1, 1, 0, 0, 0));
+    if (gz[1] == gz[0] + DD && gz[2] == gz[0] + 2 * DD) {
+        RUN(t4r_gemm_launch(st, 1, 0, D, D, T, 1.f, h, D, dqkv, D, gz[0], D, nullptr, EPI_NONE, nullptr,
+                            0, -1, 1, 3, 0, TD, DD));
+    } else {
+        for (int z = 0; z < 3; ++z)
+            RUN(t4r_gemm_launch(st, 1, 0, D, D, T, 1.f, h, D, dqkv + z * TD, D, gz[z], D, nullptr,
+                                EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0));
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+#include <string.h>
+static thread_local char g_err[512] = "";
+extern "C" void t4r_set_error(const char* msg) {
+    strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1);
+    g_err[sizeof(g_err) - 1] = 0;
+}
+extern "C" const char* t4r_last_error(void) { return g_err; }
+extern "C" int t4r_abi_version(void) { return 1; }

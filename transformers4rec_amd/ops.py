@@ -1,0 +1,339 @@
+"""Thin functional layer over the C ABI (include/t4r_hip.h): tensor checks, output allocation
+with the torch caching allocator, launch on torch's current HIP stream.  No arithmetic happens
+here and nothing falls back to torch ops: a missing library raises (see _lib.load).
+"""
+import torch
+
+from . import _lib
+from ._lib import call, int_array, long_array, ptr_array
+
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU = 0, 1, 2, 3
+AGG = {"concat": 0, "element-wise-sum": 1, "element-wise-sum-item-multi": 2}
+MASK_NONE, MASK_MLM, MASK_CLM, MASK_CLM_INFER = 0, 1, 2, 3
+MLM_TRAIN, MLM_EVAL_LAST, MLM_EVAL_ALL, MLM_INFER, CLM_TRAIN, CLM_LAST, CLM_INFER = range(7)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, dtype=None, name="tensor"):
+    if not t.is_cuda:
+        raise _lib.T4RHipError(f"{name} must live on the GPU (got {t.device}); there is no CPU path")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t.data_ptr()
+
+
+def _p(t, dtype=None, name="tensor"):
+    return None if t is None else _chk(t, dtype, name)
+
+
+def pad_ld(V):
+    """leading dimension used for [N, V] logits: rows stay 16-byte aligned"""
+    return (V + 3) // 4 * 4
+
+
+# ------------------------------------------------------------------------------------ GEMM
+def gemm(a, b, trans_a=False, trans_b=False, alpha=1.0, bias=None, epilogue=EPI_NONE, out=None,
+         aux=None, splitk=1, accumulate=False, ldc=None):
+    """out[M,N] = alpha * op(a) @ op(b) (+epilogue).  a, b 2-D row-major fp32."""
+    M = a.shape[1] if trans_a else a.shape[0]
+    K = a.shape[0] if trans_a else a.shape[1]
+    N = b.shape[0] if trans_b else b.shape[1]
+    Kb = b.shape[1] if trans_b else b.shape[0]
+    if K != Kb:
+        raise ValueError(f"gemm: inner dims differ ({K} vs {Kb})")
+    lda, ldb = a.stride(0), b.stride(0)
+    if a.stride(1) != 1 or b.stride(1) != 1:
+        raise ValueError("gemm: operands must be row-major with unit inner stride")
+    if out is None:
+        ldc = N if ldc is None else ldc
+        buf = torch.empty((M, ldc), device=a.device, dtype=torch.float32)
+        out = buf[:, :N]
+    ldc = out.stride(0)
+    call("t4r_gemm_f32", _stream(), int(trans_a), int(trans_b), M, N, K, float(alpha),
+         a.data_ptr(), lda, b.data_ptr(), ldb, out.data_ptr(), ldc,
+         _p(bias, torch.float32, "bias"), int(epilogue),
+         None if aux is None else aux.data_ptr(), 0 if aux is None else aux.stride(0),
+         int(splitk), int(accumulate), 1, 0, 0, 0)
+    return out
+
+
+# ------------------------------------------------------------------------------------ LN / act
+def add_layernorm_fwd(a, b, gamma, beta, eps):
+    rows, D = a.shape[0], a.shape[1]
+    y = torch.empty_like(a)
+    mean = torch.empty(rows, device=a.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    call("t4r_add_layernorm_fwd", _stream(), _chk(a, torch.float32), _p(b, torch.float32),
+         _chk(gamma), _chk(beta), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, D, float(eps))
+    return y, mean, rstd
+
+
+def add_layernorm_bwd(a, b, gamma, mean, rstd, dy, dgamma, dbeta, dx=None, accumulate_dx=False):
+    rows, D = a.shape
+    if dx is None:
+        dx = torch.empty_like(a)
+    call("t4r_add_layernorm_bwd", _stream(), _chk(a), _p(b), _chk(gamma), _chk(mean), _chk(rstd),
+         _chk(dy), dx.data_ptr(), _p(dgamma), _p(dbeta), rows, D, int(accumulate_dx))
+    return dx
+
+
+def act_bwd_bias(dact, pre, dbias, mode, out=None):
+    rows, N = dact.shape
+    out = dact if out is None else out
+    call("t4r_act_bwd_bias", _stream(), _chk(dact), _chk(pre), out.data_ptr(), _p(dbias), rows, N, mode)
+    return out
+
+
+def colsum_(x, out):
+    call("t4r_colsum", _stream(), _chk(x), _chk(out), x.shape[0], x.shape[1], x.stride(0))
+    return out
+
+
+# ------------------------------------------------------------------------------------ input block
+def ragged_to_padded(values, offsets, L):
+    rows = offsets.numel() - 1
+    out = torch.empty((rows, L), device=values.device, dtype=values.dtype)
+    if values.dtype not in (torch.int64, torch.float32):
+        raise TypeError("ragged_to_padded: int64 or float32 values")
+    call("t4r_ragged_to_padded", _stream(), _chk(values), _chk(offsets, torch.int64), out.data_ptr(),
+         rows, L, values.element_size())
+    return out
+
+
+def ragged_max_len(offsets):
+    out = torch.empty(1, device=offsets.device, dtype=torch.int32)
+    call("t4r_ragged_max_len", _stream(), _chk(offsets, torch.int64), offsets.numel() - 1, out.data_ptr())
+    return out
+
+
+def seq_features_fwd(feats, agg, B, L_in, L_out, W, item_feat=-1, mask_mode=MASK_NONE, mask=None,
+                     masked_emb=None, err_flag=None):
+    """feats: list of dicts(kind, input, table, dim, col, rows).  Returns out [B, L_out, W]."""
+    n = len(feats)
+    dev = feats[0]["input"].device
+    out = torch.empty((B, L_out, W), device=dev, dtype=torch.float32)
+    kinds, _k = int_array([f["kind"] for f in feats])
+    inputs, _i = ptr_array([_chk(f["input"]) for f in feats])
+    tables, _t = ptr_array([0 if f.get("table") is None else _chk(f["table"], torch.float32) for f in feats])
+    dims, _d = int_array([f["dim"] for f in feats])
+    cols, _c = int_array([f.get("col", 0) for f in feats])
+    rows, _r = long_array([f.get("rows", 0) for f in feats])
+    call("t4r_seq_features_fwd", _stream(), n, kinds, inputs, tables, dims, cols, rows, AGG[agg] if
+         isinstance(agg, str) else agg, item_feat, B, L_in, L_out, W, mask_mode,
+         _p(mask), _p(masked_emb), out.data_ptr(), _p(err_flag))
+    return out
+
+
+def embedding_bwd(dout, ids, d_table, col, dim, padding_idx=0):
+    ntok = ids.numel()
+    W = dout.shape[-1]
+    call("t4r_embedding_bwd", _stream(), _chk(dout, torch.float32), _chk(ids, torch.int64),
+         _chk(d_table, torch.float32), ntok, W, col, dim, d_table.shape[0], padding_idx)
+
+
+def apply_mask_fwd_(x, mask, memb, mode):
+    B, L, H = x.shape
+    call("t4r_apply_mask_fwd", _stream(), _chk(x), _chk(mask), _chk(memb), B, L, H, mode)
+    return x
+
+
+def apply_mask_bwd_(dy, mask, d_memb, mode):
+    B, L, H = dy.shape
+    call("t4r_apply_mask_bwd", _stream(), _chk(dy), _chk(mask), _chk(d_memb), B, L, H, mode)
+    return dy
+
+
+def mul(a, b):
+    out = torch.empty_like(a)
+    call("t4r_mul", _stream(), _chk(a), _chk(b), out.data_ptr(), a.numel())
+    return out
+
+
+def soft_embedding_fwd(x, proj_w, proj_b, table, ln_w, ln_b, eps=1e-5):
+    K, D = table.shape
+    out = torch.empty(x.shape + (D,), device=x.device, dtype=torch.float32)
+    call("t4r_soft_embedding_fwd", _stream(), _chk(x, torch.float32), _chk(proj_w), _chk(proj_b),
+         _chk(table), _p(ln_w), _p(ln_b), out.data_ptr(), x.numel(), K, D, float(eps))
+    return out
+
+
+def soft_embedding_bwd(dout, x, proj_w, proj_b, table, ln_w, d_proj_w, d_proj_b, d_table, d_ln_w,
+                       d_ln_b, col, eps=1e-5):
+    K, D = table.shape
+    W = dout.shape[-1]
+    call("t4r_soft_embedding_bwd", _stream(), _chk(dout), _chk(x), _chk(proj_w), _chk(proj_b),
+         _chk(table), _p(ln_w), _chk(d_proj_w), _chk(d_proj_b), _chk(d_table), _p(d_ln_w), _p(d_ln_b),
+         x.numel(), W, col, K, D, float(eps))
+
+
+# ------------------------------------------------------------------------------------ masking
+def mask_targets(item_ids, mode, padding_idx=0, bern=None, j1=None, j2=None, p=0.15, seed=0,
+                 offset=0, want_counts=True):
+    B, L = item_ids.shape
+    Lout = L + 1 if mode == MLM_INFER else L
+    dev = item_ids.device
+    mask = torch.empty((B, Lout), device=dev, dtype=torch.bool)
+    labels = torch.empty((B, Lout), device=dev, dtype=torch.int64)
+    counts = torch.empty(B, device=dev, dtype=torch.int32) if want_counts else None
+    if bern is not None:
+        bern = bern.to(torch.uint8) if bern.dtype != torch.uint8 else bern
+    call("t4r_mask_targets", _stream(), _chk(item_ids, torch.int64), B, L, mode, padding_idx,
+         _p(bern), _p(j1, torch.int64), _p(j2, torch.int64), float(p), int(seed), int(offset),
+         mask.data_ptr(), labels.data_ptr(), _p(counts))
+    return mask, labels, counts
+
+
+def compact_labels(labels, counts, padding_idx=0):
+    """-> (n_labels [1] int32 device, label_pos [B*L] int32, labels_compact [B*L] int64)"""
+    B, L = labels.shape
+    dev = labels.device
+    row_off = torch.empty(B, device=dev, dtype=torch.int32)
+    n = torch.empty(1, device=dev, dtype=torch.int32)
+    pos = torch.empty(B * L, device=dev, dtype=torch.int32)
+    lab = torch.empty(B * L, device=dev, dtype=torch.int64)
+    call("t4r_compact_labels", _stream(), _chk(labels, torch.int64), _chk(counts, torch.int32), B, L,
+         padding_idx, row_off.data_ptr(), n.data_ptr(), pos.data_ptr(), lab.data_ptr())
+    return n, pos, lab
+
+
+def gather_rows(x2d, pos, n):
+    D = x2d.shape[1]
+    out = torch.empty((n, D), device=x2d.device, dtype=torch.float32)
+    call("t4r_gather_rows", _stream(), _chk(x2d, torch.float32), _chk(pos, torch.int32), out.data_ptr(), n, D)
+    return out
+
+
+def scatter_rows_add_(dout, pos, dx2d):
+    n, D = dout.shape
+    call("t4r_scatter_rows_add", _stream(), _chk(dout), _chk(pos, torch.int32), _chk(dx2d), n, D)
+    return dx2d
+
+
+def last_positions(item_ids, Lgrid, is_mlm, padding_idx=0):
+    B, L = item_ids.shape
+    pos = torch.empty(B, device=item_ids.device, dtype=torch.int32)
+    call("t4r_last_positions", _stream(), _chk(item_ids, torch.int64), B, L, Lgrid, int(is_mlm),
+         padding_idx, pos.data_ptr())
+    return pos
+
+
+# ------------------------------------------------------------------------------------ attention / layer
+def xlnet_attn_fwd(q, k, v, k_r, r_w_bias, r_r_bias, B, L, n_head):
+    D = q.shape[-1]
+    out = torch.empty((B * L, D), device=q.device, dtype=torch.float32)
+    lse = torch.empty((B, n_head, L), device=q.device, dtype=torch.float32)
+    call("t4r_xlnet_attn_fwd", _stream(), _chk(q), _chk(k), _chk(v), _chk(k_r), _chk(r_w_bias),
+         _chk(r_r_bias), out.data_ptr(), lse.data_ptr(), B, L, n_head, D // n_head)
+    return out, lse
+
+
+def xlnet_attn_bwd(q, k, v, k_r, r_w_bias, r_r_bias, out, lse, dout, d_rw, d_rr, B, L, n_head):
+    D = q.shape[-1]
+    dev = q.device
+    dq, dk, dv = (torch.empty((B * L, D), device=dev, dtype=torch.float32) for _ in range(3))
+    dkr = torch.empty((2 * L, D), device=dev, dtype=torch.float32)
+    nws = _lib.load().t4r_xlnet_attn_bwd_ws_floats(B, L, D, n_head)
+    ws = torch.empty(nws, device=dev, dtype=torch.float32)
+    call("t4r_xlnet_attn_bwd", _stream(), _chk(q), _chk(k), _chk(v), _chk(k_r), _chk(r_w_bias),
+         _chk(r_r_bias), _chk(out), _chk(lse), _chk(dout), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+         dkr.data_ptr(), _chk(d_rw), _chk(d_rr), ws.data_ptr(), B, L, n_head, D // n_head)
+    return dq, dk, dv, dkr
+
+
+XLNET_PARAM_ORDER = ("q", "k", "v", "o", "r", "r_w_bias", "r_r_bias", "ln1_w", "ln1_b", "w1", "b1",
+                     "w2", "b2", "ln2_w", "ln2_b")
+
+
+def xlnet_layer_ws_floats(B, L, D, n_head):
+    return _lib.load().t4r_xlnet_layer_ws_floats(B, L, D, n_head)
+
+
+def xlnet_layer_bwd_ws_floats(B, L, D, n_head):
+    return _lib.load().t4r_xlnet_layer_bwd_ws_floats(B, L, D, n_head)
+
+
+def xlnet_layer_fwd(h, pos_emb, params, B, L, n_head, eps, ws=None):
+    """h [B*L, D]; params: sequence of 15 tensors in XLNET_PARAM_ORDER.  -> (h_out, ws)"""
+    D = h.shape[-1]
+    if ws is None:
+        ws = torch.empty(xlnet_layer_ws_floats(B, L, D, n_head), device=h.device, dtype=torch.float32)
+    out = torch.empty_like(h)
+    parr, _keep = ptr_array([_chk(p, torch.float32, "xlnet param") for p in params])
+    call("t4r_xlnet_layer_fwd", _stream(), _chk(h, torch.float32), _chk(pos_emb, torch.float32), parr,
+         ws.data_ptr(), out.data_ptr(), B, L, D, n_head, float(eps))
+    return out, ws
+
+
+def xlnet_layer_bwd(h, pos_emb, params, grads, ws, dh_out, B, L, n_head, eps, bws=None):
+    D = h.shape[-1]
+    if bws is None:
+        bws = torch.empty(xlnet_layer_bwd_ws_floats(B, L, D, n_head), device=h.device, dtype=torch.float32)
+    dh_in = torch.empty_like(h)
+    parr, _k1 = ptr_array([_chk(p, torch.float32) for p in params])
+    garr, _k2 = ptr_array([_chk(g, torch.float32) for g in grads])
+    call("t4r_xlnet_layer_bwd", _stream(), _chk(h), _chk(pos_emb), parr, garr, _chk(ws),
+         bws.data_ptr(), _chk(dh_out), dh_in.data_ptr(), B, L, D, n_head, float(eps))
+    return dh_in
+
+
+# ------------------------------------------------------------------------------------ head
+def softmax_ce_fwd(logits, labels, V, label_smoothing=0.0):
+    """logits [N, ld] view or buffer whose row stride is the leading dimension."""
+    N = logits.shape[0]
+    ld = logits.stride(0) if N > 1 else max(logits.shape[1], V)
+    dev = logits.device
+    loss_rows = torch.empty(N, device=dev, dtype=torch.float32)
+    lse = torch.empty(N, device=dev, dtype=torch.float32)
+    loss = torch.empty((), device=dev, dtype=torch.float32)
+    call("t4r_softmax_ce_fwd", _stream(), logits.data_ptr(), _chk(labels, torch.int64),
+         loss_rows.data_ptr(), lse.data_ptr(), loss.data_ptr(), N, V, ld, float(label_smoothing))
+    return loss, loss_rows, lse
+
+
+def softmax_ce_bwd(logits, labels, lse, grad_out, V, label_smoothing=0.0):
+    N = logits.shape[0]
+    ld = logits.stride(0) if N > 1 else max(logits.shape[1], V)
+    buf = torch.empty((N, ld), device=logits.device, dtype=torch.float32)
+    call("t4r_softmax_ce_bwd", _stream(), logits.data_ptr(), _chk(labels, torch.int64), _chk(lse),
+         _p(grad_out), buf.data_ptr(), N, V, ld, float(label_smoothing))
+    return buf
+
+
+def sampled_logits_fwd(x, labels, W, neg, dist, temperature=1.0):
+    N, D = x.shape
+    S = neg.numel()
+    out = torch.empty((N, S + 1), device=x.device, dtype=torch.float32)
+    call("t4r_sampled_logits_fwd", _stream(), _chk(x), _chk(labels, torch.int64), _chk(W),
+         _chk(neg, torch.int64), _chk(dist, torch.float32), out.data_ptr(), N, D, S, float(temperature))
+    return out
+
+
+def sampled_logits_bwd(dlogits, x, labels, W, neg, dW, temperature=1.0):
+    N, D = x.shape
+    dx = torch.empty_like(x)
+    call("t4r_sampled_logits_bwd", _stream(), _chk(dlogits), _chk(x), _chk(labels, torch.int64),
+         _chk(W), _chk(neg, torch.int64), dx.data_ptr(), _chk(dW), N, D, neg.numel(), float(temperature))
+    return dx
+
+
+def topk(scores, k, V=None):
+    N = scores.shape[0]
+    V = scores.shape[1] if V is None else V
+    ld = scores.stride(0) if N > 1 else scores.shape[1]
+    vals = torch.empty((N, k), device=scores.device, dtype=torch.float32)
+    idx = torch.empty((N, k), device=scores.device, dtype=torch.int64)
+    call("t4r_topk", _stream(), scores.data_ptr(), N, V, ld, k, vals.data_ptr(), idx.data_ptr())
+    return vals, idx
+
+
+# ------------------------------------------------------------------------------------ optimizer
+def adam_step_(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+               weight_decay=0.0, grad_scale=1.0, zero_grad=True):
+    call("t4r_adam_step", _stream(), _chk(param, torch.float32), _chk(grad, torch.float32),
+         _chk(exp_avg), _chk(exp_avg_sq), param.numel(), int(step), float(lr), float(betas[0]),
+         float(betas[1]), float(eps), float(weight_decay), float(grad_scale), int(zero_grad))

@@ -373,7 +373,7 @@ ORDER = ("q", "k", "v", "o", "r", "r_w_bias", "r_r_bias", "ln_w", "ln_b", "w1", 
          "ff_ln_w", "ff_ln_b")
 
 
-@pytest.mark.parametrize("B,L,D,n", [(5, 20, 64, 4), (3, 21, 32, 2), (2, 7, 128, 4), (4, 33, 64, 8), (2, 64, 32, 4)])
+@pytest.mark.parametrize("B,L,D,n", [(5, 20, 64, 4), (3, 21, 32, 2), (2, 7, 128, 4), (4, 33, 64, 8), (2, 64, 32, 2)])
 def test_xlnet_attention_core(ops, B, L, D, n):
     g = torch.Generator().manual_seed(B * L + D)
     dh = D // n

@@ -5,3 +5,13 @@ Hand-written HIP kernels behind a C ABI (include/t4r_hip.h, lib/libt4r_hip.so); 
 the host-side mirror of the reference's module interface.  No CPU fallback exists.
 """
 __version__ = "0.1.0"
+
+from .schema import ColumnSchema, IntDomain, Schema, Tags, ValueCount, random_data_from_schema, session_schema  # noqa: E402,F401
+from .masking import CausalLanguageModeling, MaskedLanguageModeling, MaskSequence  # noqa: E402,F401
+from .features import (  # noqa: E402,F401
+    SequenceEmbeddingFeatures, SoftEmbedding, SoftEmbeddingFeatures, TabularSequenceFeatures)
+from .transformer import TransformerBlock, XLNetConfig, XLNetModel  # noqa: E402,F401
+from .prediction_task import LogUniformSampler, NextItemPredictionTask  # noqa: E402,F401
+from .model import Head, Model  # noqa: E402,F401
+from .optim import FlatParams, FusedAdam, flatten_model  # noqa: E402,F401
+from .distributed import GradReducer, shard_batch  # noqa: E402,F401

@@ -1,0 +1,346 @@
+"""Input block: host-side mirror of the reference's
+  SequenceEmbeddingFeatures / EmbeddingFeatures   transformers4rec/torch/features/{sequence.py:43-94, embedding.py:51-276}
+  SoftEmbeddingFeatures / SoftEmbedding           features/embedding.py:280-410, 517-556
+  TabularSequenceFeatures                         features/sequence.py:97-296
+with the same constructor arguments for the hot path, attribute contract (`masking`,
+`item_id`, `item_embedding_table`, `categorical_module.item_seq`, `to_merge[...]`,
+`projection_module`) and state_dict names.  All arithmetic runs in
+csrc/embedding.hip / gemm_f32.hip through one fused autograd function.
+"""
+import math
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from .masking import MaskSequence, _grad_buf, parse_masking
+from .schema import Tags, categorical_cardinalities
+
+
+class EmbeddingTable(nn.Module):
+    """nn.Embedding-shaped parameter holder (`weight`, num_embeddings, embedding_dim, padding_idx)."""
+
+    def __init__(self, num_embeddings, embedding_dim, padding_idx=None, std=0.05):
+        super().__init__()
+        self.num_embeddings, self.embedding_dim, self.padding_idx = num_embeddings, embedding_dim, padding_idx
+        self.weight = nn.Parameter(torch.empty(num_embeddings, embedding_dim))
+        # TableConfig default initializer normal_(0, 0.05) runs AFTER nn.Embedding's padding row
+        # zero-fill (features/sequence.py:75-81; embedding.py:460-464): row 0 is random, not zero.
+        nn.init.normal_(self.weight, mean=0.0, std=std)
+
+    def extra_repr(self):
+        return f"{self.num_embeddings}, {self.embedding_dim}, padding_idx={self.padding_idx}"
+
+
+class _Linear(nn.Module):
+    """torch.nn.Linear-shaped parameter holder with the same default init."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if bias:
+            bound = 1 / math.sqrt(in_features) if in_features > 0 else 0
+            nn.init.uniform_(self.bias, -bound, bound)
+
+
+class _LayerNormParams(nn.Module):
+    def __init__(self, dim, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+
+class SoftEmbedding(nn.Module):
+    """reference features/embedding.py:517-556: `embedding_table` [K, D] + `projection_layer` Linear(1, K)"""
+
+    def __init__(self, num_embeddings, embeddings_dim):
+        super().__init__()
+        self.embedding_table = EmbeddingTable(num_embeddings, embeddings_dim)
+        self.projection_layer = _Linear(1, num_embeddings)
+
+
+class SequenceEmbeddingFeatures(nn.Module):
+    """Categorical sequence features; holds `embedding_tables` and the stateful `item_seq`."""
+
+    def __init__(self, table_sizes: Dict[str, tuple], item_id: Optional[str] = None, padding_idx: int = 0):
+        super().__init__()
+        self.item_id = item_id
+        self.padding_idx = padding_idx
+        self.embedding_tables = nn.ModuleDict(
+            {n: EmbeddingTable(v, d, padding_idx=padding_idx) for n, (v, d) in table_sizes.items()})
+        self.item_seq = None
+
+    @property
+    def item_embedding_table(self):
+        assert self.item_id is not None
+        return self.embedding_tables[self.item_id]
+
+    def item_ids(self, inputs):
+        return inputs[self.item_id]
+
+
+class _FeaturePost(nn.Module):
+    def __init__(self, dims: Dict[str, int]):
+        super().__init__()
+        self.feature_layer_norm = nn.ModuleDict({n: _LayerNormParams(d) for n, d in dims.items()})
+
+
+class SoftEmbeddingFeatures(nn.Module):
+    """Continuous features through SoftEmbedding (+ per-feature LayerNorm in `post`)."""
+
+    def __init__(self, table_sizes: Dict[str, tuple], layer_norm: bool = True):
+        super().__init__()
+        self.embedding_tables = nn.ModuleDict({n: SoftEmbedding(k, d) for n, (k, d) in table_sizes.items()})
+        self.post = _FeaturePost({n: d for n, (k, d) in table_sizes.items()}) if layer_norm else None
+
+
+class _SeqFeaturesFn(torch.autograd.Function):
+    """gather (+soft embeddings) -> aggregate -> [ReLU projection] -> masking, one autograd node.
+    Parameter gradients are accumulated straight into `.grad` (flat-buffer friendly)."""
+
+    @staticmethod
+    def forward(ctx, anchor, mod, inputs, training, testing):
+        cat, cont = mod.categorical_module, mod.continuous_module
+        names = mod._feature_order
+        item_ids = inputs[cat.item_id].contiguous()
+        B, L = item_ids.shape
+        masking = mod._masking
+        mask_mode, mask, L_out = ops.MASK_NONE, None, L
+        if masking is not None:
+            masking.compute_masked_targets(item_ids, training=training, testing=testing)
+            mask = masking.mask_schema
+            mask_mode = masking.apply_mode(training, testing)
+            L_out = mask.shape[1]
+        feats, soft_saved = [], {}
+        for name in names:
+            col, dim = mod._cols[name], mod._dims[name]
+            if name in cat.embedding_tables:
+                tab = cat.embedding_tables[name].weight
+                feats.append(dict(kind=0, input=inputs[name].contiguous(), table=tab.detach(), dim=dim,
+                                  col=col, rows=tab.shape[0]))
+            else:
+                se = cont.embedding_tables[name]
+                ln = cont.post.feature_layer_norm[name] if cont.post is not None else None
+                x = inputs[name].contiguous().float()
+                rows = ops.soft_embedding_fwd(
+                    x, se.projection_layer.weight.detach(), se.projection_layer.bias.detach(),
+                    se.embedding_table.weight.detach(), None if ln is None else ln.weight.detach(),
+                    None if ln is None else ln.bias.detach(), 1e-5 if ln is None else ln.eps)
+                soft_saved[name] = x
+                feats.append(dict(kind=1, input=rows, table=None, dim=dim, col=col))
+        W = mod._agg_width
+        proj = mod.projection_module
+        fuse_mask = masking is not None and proj is None
+        memb = masking.masked_item_embedding if masking is not None else None
+        item_feat = names.index(cat.item_id) if cat.item_id in names else -1
+        agg_out = ops.seq_features_fwd(
+            feats, mod._aggregation, B, L, L_out, W, item_feat=item_feat,
+            mask_mode=mask_mode if fuse_mask else ops.MASK_NONE, mask=mask if fuse_mask else None,
+            masked_emb=memb.detach() if fuse_mask else None, err_flag=mod._err_flag(item_ids.device))
+        out = agg_out
+        if proj is not None:
+            lin = proj[0][0]
+            out = ops.gemm(agg_out.view(B * L_out, W), lin.weight.detach(), False, True,
+                           bias=lin.bias.detach(), epilogue=ops.EPI_BIAS_RELU).view(B, L_out, -1)
+            if masking is not None:
+                ops.apply_mask_fwd_(out, mask, memb.detach(), mask_mode)
+        ctx.mod, ctx.inputs, ctx.soft_saved = mod, inputs, soft_saved
+        ctx.mask_mode, ctx.mask, ctx.dims = mask_mode, mask, (B, L, L_out, W)
+        ctx.agg_out = agg_out if proj is not None else None
+        ctx.proj_out = out if proj is not None else None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        mod = ctx.mod
+        cat, cont = mod.categorical_module, mod.continuous_module
+        B, L, L_out, W = ctx.dims
+        if L_out != L:
+            raise RuntimeError("the MLM inference grid (L+1) is forward-only")
+        masking, proj = mod._masking, mod.projection_module
+        d = dy.contiguous().clone()
+        if masking is not None:
+            ops.apply_mask_bwd_(d, ctx.mask, _grad_buf(masking.masked_item_embedding), ctx.mask_mode)
+        if proj is not None:
+            lin = proj[0][0]
+            H = d.shape[-1]
+            d2 = d.view(B * L, H)
+            ops.act_bwd_bias(d2, ctx.proj_out.view(B * L, H), None if lin.bias is None else _grad_buf(lin.bias), 1)
+            ops.gemm(d2, ctx.agg_out.view(B * L, W), True, False, splitk=-1, accumulate=True,
+                     out=_grad_buf(lin.weight))
+            d = ops.gemm(d2, lin.weight.detach(), False, False).view(B, L, W)
+        names = mod._feature_order
+        agg = mod._aggregation
+        if agg == "element-wise-sum-item-multi":
+            item = cat.item_id
+            f_item = [dict(kind=0, input=ctx.inputs[item].contiguous(), table=cat.embedding_tables[item].weight.detach(),
+                           dim=W, col=0, rows=cat.embedding_tables[item].weight.shape[0])]
+            f_other = [dict(kind=0, input=ctx.inputs[n].contiguous(), table=cat.embedding_tables[n].weight.detach(),
+                            dim=W, col=0, rows=cat.embedding_tables[n].weight.shape[0])
+                       for n in names if n != item]
+            e_item = ops.seq_features_fwd(f_item, "element-wise-sum", B, L, L, W)
+            e_other = ops.seq_features_fwd(f_other, "element-wise-sum", B, L, L, W)
+            d_item, d_other = ops.mul(d, e_other), ops.mul(d, e_item)
+        for name in names:
+            col, dim = mod._cols[name], mod._dims[name]
+            if name in cat.embedding_tables:
+                tab = cat.embedding_tables[name].weight
+                if not tab.requires_grad:
+                    continue
+                src = d
+                if agg == "element-wise-sum-item-multi":
+                    src = d_item if name == cat.item_id else d_other
+                ops.embedding_bwd(src, ctx.inputs[name].contiguous(), _grad_buf(tab), col, dim, cat.padding_idx)
+            else:
+                se = cont.embedding_tables[name]
+                ln = cont.post.feature_layer_norm[name] if cont.post is not None else None
+                ops.soft_embedding_bwd(
+                    d, ctx.soft_saved[name], se.projection_layer.weight.detach(),
+                    se.projection_layer.bias.detach(), se.embedding_table.weight.detach(),
+                    None if ln is None else ln.weight.detach(), _grad_buf(se.projection_layer.weight),
+                    _grad_buf(se.projection_layer.bias), _grad_buf(se.embedding_table.weight),
+                    None if ln is None else _grad_buf(ln.weight), None if ln is None else _grad_buf(ln.bias),
+                    col, 1e-5 if ln is None else ln.eps)
+        return None, None, None, None, None
+
+
+class TabularSequenceFeatures(nn.Module):
+    """Drop-in for tr.TabularSequenceFeatures on the hot path (features/sequence.py:97-296).
+
+    forward(inputs: Dict[str, Tensor[B, L]], training=False, testing=False) -> Tensor[B, L(+1), H]
+    """
+
+    def __init__(self, categorical_module: SequenceEmbeddingFeatures,
+                 continuous_module: Optional[SoftEmbeddingFeatures] = None, aggregation: str = "concat",
+                 projection_dim: Optional[int] = None, masking: Optional[MaskSequence] = None,
+                 schema=None, max_sequence_length: Optional[int] = None):
+        super().__init__()
+        if aggregation not in ops.AGG:
+            raise ValueError(f"aggregation must be one of {sorted(ops.AGG)}")
+        self.schema = schema
+        self.max_sequence_length = max_sequence_length
+        mods = {}
+        if continuous_module is not None:
+            mods["continuous_module"] = continuous_module
+        mods["categorical_module"] = categorical_module
+        self.to_merge = nn.ModuleDict(mods)
+        self._aggregation = aggregation
+        dims = {n: t.embedding_dim for n, t in categorical_module.embedding_tables.items()}
+        if continuous_module is not None:
+            dims.update({n: s.embedding_table.embedding_dim for n, s in continuous_module.embedding_tables.items()})
+        # ConcatFeatures order = sorted(feature names) (tabular/aggregation.py:43)
+        self._feature_order = sorted(dims)
+        self._dims = dims
+        if aggregation == "concat":
+            off, cols = 0, {}
+            for n in self._feature_order:
+                cols[n] = off
+                off += dims[n]
+            self._cols, self._agg_width = cols, off
+        else:
+            if len(set(dims.values())) != 1:
+                raise ValueError(f"All features must have the same dimension for element-wise aggregation: {dims}")
+            self._cols, self._agg_width = {n: 0 for n in dims}, next(iter(dims.values()))
+        self.projection_module = None
+        if projection_dim:
+            # MLPBlock([d_output]) -> SequentialBlock(DenseBlock(Linear, ReLU)) (block/mlp.py:68-143)
+            self.projection_module = nn.Sequential(nn.Sequential(_Linear(self._agg_width, projection_dim)))
+        self._masking = None
+        self.set_masking(masking)
+        self._err = None
+
+    # ------------------------------------------------------------------ reference attribute contract
+    @property
+    def categorical_module(self):
+        return self.to_merge["categorical_module"]
+
+    @property
+    def continuous_module(self):
+        return self.to_merge["continuous_module"] if "continuous_module" in self.to_merge else None
+
+    @property
+    def masking(self):
+        return self._masking
+
+    def set_masking(self, value):
+        self._masking = value
+
+    @property
+    def item_id(self):
+        return self.categorical_module.item_id
+
+    @property
+    def item_embedding_table(self):
+        return self.categorical_module.item_embedding_table
+
+    @property
+    def aggregation(self):
+        return self._aggregation
+
+    def output_size(self, input_size=None):
+        H = self.projection_module[0][0].out_features if self.projection_module is not None else self._agg_width
+        return torch.Size([-1, self.max_sequence_length or -1, H])
+
+    forward_output_size = output_size
+
+    def _err_flag(self, device):
+        if self._err is None or self._err.device != device:
+            self._err = torch.zeros(1, dtype=torch.int32, device=device)
+        return self._err
+
+    def check_ids(self):
+        """Raises if any lookup id was out of range since the last check (device flag, syncs)."""
+        if self._err is not None and int(self._err.item()) != 0:
+            self._err.zero_()
+            raise IndexError("embedding lookup id out of range")
+
+    # ------------------------------------------------------------------ construction
+    @classmethod
+    def from_schema(cls, schema, continuous_tags=(Tags.CONTINUOUS,), categorical_tags=(Tags.CATEGORICAL,),
+                    aggregation=None, max_sequence_length=None, continuous_soft_embeddings=False,
+                    d_output=None, masking=None, embedding_dims=None, embedding_dim_default=64,
+                    soft_embedding_cardinalities=None, soft_embedding_cardinality_default=10,
+                    soft_embedding_dims=None, soft_embedding_dim_default=8, layer_norm=True,
+                    projection=None, continuous_projection=None, **kwargs):
+        """Same keyword surface as the reference (features/sequence.py:140-229,
+        features/embedding.py:103-221, :313-410) for the arguments the hot path uses."""
+        if projection is not None or continuous_projection is not None:
+            raise NotImplementedError("only d_output (ReLU MLP) projection is on the hot path")
+        cat_schema = schema.select_by_tag(list(categorical_tags))
+        cards = categorical_cardinalities(cat_schema)
+        if not cards:
+            raise ValueError("a categorical_module including an item_id column is required")
+        item_cols = schema.select_by_tag(Tags.ITEM_ID).column_names
+        item_id = item_cols[0] if item_cols else None
+        embedding_dims = embedding_dims or {}
+        tables = {n: (v, embedding_dims.get(n, embedding_dim_default)) for n, v in cards.items()}
+        cat = SequenceEmbeddingFeatures(tables, item_id=item_id)
+        cont = None
+        cont_names = [c for c in schema.select_by_tag(list(continuous_tags)).column_names if c not in cards]
+        if cont_names:
+            if not continuous_soft_embeddings:
+                raise NotImplementedError("continuous features need continuous_soft_embeddings=True on this path")
+            sc, sd = soft_embedding_cardinalities or {}, soft_embedding_dims or {}
+            cont = SoftEmbeddingFeatures(
+                {n: (sc.get(n, soft_embedding_cardinality_default), sd.get(n, soft_embedding_dim_default))
+                 for n in cont_names}, layer_norm=layer_norm)
+        if (masking or d_output) and not aggregation:
+            aggregation = "concat"
+        out = cls(cat, cont, aggregation or "concat", d_output, None, schema, max_sequence_length)
+        hidden = out.output_size()[-1]
+        if masking is not None and item_id is None:
+            raise ValueError("For masking a categorical_module is required including an item_id.")
+        out.set_masking(parse_masking(masking, hidden, **kwargs))
+        return out
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, inputs, training=False, testing=False, **kwargs):
+        cat = self.categorical_module
+        if cat.item_id:
+            cat.item_seq = cat.item_ids(inputs)  # stateful, as the reference (embedding.py:242-245)
+        return _SeqFeaturesFn.apply(cat.item_embedding_table.weight, self, inputs, training, testing)

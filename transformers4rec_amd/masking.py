@@ -1,0 +1,181 @@
+"""Masking modules: host-side mirror of transformers4rec/torch/masking.py for the hot path
+(MaskSequence :61-243, CausalLanguageModeling :247-337, MaskedLanguageModeling :342-498).
+Same constructor arguments, attributes (`mask_schema`, `masked_targets`, `padding_idx`,
+`masked_item_embedding`) and state_dict names; the integer work runs in
+csrc/masking.hip, the embedding replacement in csrc/embedding.hip.
+PLM / RTD are out of scope.
+"""
+from collections import namedtuple
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import ops
+
+MaskingInfo = namedtuple("MaskingInfo", ["schema", "targets"])
+
+
+def _grad_buf(p):
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    return p.grad
+
+
+class _ApplyMaskFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, memb, mask, mode):
+        out = x.detach().clone()
+        ops.apply_mask_fwd_(out, mask, memb.detach(), mode)
+        ctx.mode = mode
+        ctx.memb = memb
+        ctx.save_for_backward(mask)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dx = dy.contiguous().clone()
+        ops.apply_mask_bwd_(dx, mask, _grad_buf(ctx.memb), ctx.mode)
+        return dx, None, None, None
+
+
+class MaskSequence(nn.Module):
+    """Base class (reference masking.py:61-243)."""
+
+    def __init__(self, hidden_size: int, padding_idx: int = 0,
+                 eval_on_last_item_seq_only: bool = True, **kwargs):
+        super().__init__()
+        self.padding_idx = padding_idx
+        self.hidden_size = hidden_size
+        self.eval_on_last_item_seq_only = eval_on_last_item_seq_only
+        self.mask_schema: Optional[torch.Tensor] = None
+        self.masked_targets: Optional[torch.Tensor] = None
+        # trainable vector that replaces masked interactions; N(0, 0.001) (masking.py:102-108)
+        self.masked_item_embedding = nn.Parameter(torch.empty(hidden_size))
+        nn.init.normal_(self.masked_item_embedding, mean=0, std=0.001)
+        # device-RNG state for the training draws (Philox counter) and the parity hook
+        self.seed = 0
+        self._rng_offset = 0
+        self._draws = None
+        # label compaction cache for the prediction head (filled by compute_masked_targets)
+        self._row_count = None
+        self._compact = None
+
+    # ---- parity hook: replay recorded torch.bernoulli / torch.multinomial draws once
+    def set_draws(self, bern=None, j1=None, j2=None):
+        self._draws = (bern, j1, j2)
+
+    def _mode(self, training, testing):
+        raise NotImplementedError
+
+    def apply_mode(self, training, testing):
+        raise NotImplementedError
+
+    def compute_masked_targets(self, item_ids, training=False, testing=False) -> MaskingInfo:
+        assert item_ids.ndim == 2, "`item_ids` must have 2 dimensions."
+        mode = self._mode(training, testing)
+        bern = j1 = j2 = None
+        if self._draws is not None and mode == ops.MLM_TRAIN:
+            bern, j1, j2 = self._draws
+            self._draws = None
+        mask, labels, counts = ops.mask_targets(
+            item_ids.contiguous(), mode, self.padding_idx, bern, j1, j2,
+            getattr(self, "mlm_probability", 0.0), self.seed, self._rng_offset)
+        if mode == ops.MLM_TRAIN:
+            self._rng_offset += item_ids.numel()
+        self.mask_schema, self.masked_targets = mask, labels
+        self._row_count, self._compact = counts, None
+        return MaskingInfo(mask, labels)
+
+    def compact_labels(self):
+        """(n_labels [1] i32, label_pos [B*L] i32, labels [B*L] i64) in remove_pad_3d order."""
+        if self._compact is None:
+            self._compact = ops.compact_labels(self.masked_targets, self._row_count, self.padding_idx)
+        return self._compact
+
+    def apply_mask_to_inputs(self, inputs, schema, training=False, testing=False):
+        raise NotImplementedError
+
+    def forward(self, inputs, item_ids, training=False, testing=False):
+        self.compute_masked_targets(item_ids=item_ids, training=training, testing=testing)
+        if self.mask_schema is None:
+            raise ValueError("`mask_schema must be set.`")
+        return self.apply_mask_to_inputs(inputs, self.mask_schema, training=training, testing=testing)
+
+    def forward_output_size(self, input_size):
+        return input_size
+
+    def transformer_required_arguments(self):
+        return {}
+
+    def transformer_optional_arguments(self):
+        return {}
+
+    @property
+    def transformer_arguments(self):
+        return {**self.transformer_required_arguments(), **self.transformer_optional_arguments()}
+
+
+class CausalLanguageModeling(MaskSequence):
+    """reference masking.py:247-337"""
+
+    def __init__(self, hidden_size, padding_idx=0, eval_on_last_item_seq_only=True,
+                 train_on_last_item_seq_only=False, **kwargs):
+        super().__init__(hidden_size, padding_idx, eval_on_last_item_seq_only)
+        self.train_on_last_item_seq_only = train_on_last_item_seq_only
+
+    def _mode(self, training, testing):
+        if not training and not testing:
+            return ops.CLM_INFER
+        last = (self.eval_on_last_item_seq_only and not training) or (
+            self.train_on_last_item_seq_only and training)
+        return ops.CLM_LAST if last else ops.CLM_TRAIN
+
+    def apply_mode(self, training, testing):
+        return ops.MASK_CLM_INFER if (not training and not testing) else ops.MASK_CLM
+
+    def apply_mask_to_inputs(self, inputs, mask_schema, training=False, testing=False):
+        return _ApplyMaskFn.apply(inputs.contiguous(), self.masked_item_embedding, mask_schema,
+                                  self.apply_mode(training, testing))
+
+
+class MaskedLanguageModeling(MaskSequence):
+    """reference masking.py:342-498"""
+
+    def __init__(self, hidden_size, padding_idx=0, eval_on_last_item_seq_only=True,
+                 mlm_probability=0.15, **kwargs):
+        super().__init__(hidden_size, padding_idx, eval_on_last_item_seq_only)
+        self.mlm_probability = mlm_probability
+
+    def _mode(self, training, testing):
+        if training:
+            return ops.MLM_TRAIN
+        if testing:
+            return ops.MLM_EVAL_LAST if self.eval_on_last_item_seq_only else ops.MLM_EVAL_ALL
+        return ops.MLM_INFER
+
+    def apply_mode(self, training, testing):
+        return ops.MASK_MLM
+
+    def apply_mask_to_inputs(self, inputs, mask_schema, training=False, testing=False):
+        if not testing and not training:
+            # inference: extend with a [MASK] slot (masking.py:489-492)
+            inputs = torch.cat([inputs, inputs[:, -1:, :]], dim=1)
+        return _ApplyMaskFn.apply(inputs.contiguous(), self.masked_item_embedding, mask_schema,
+                                  ops.MASK_MLM)
+
+
+masking_registry = {
+    "clm": CausalLanguageModeling, "causal": CausalLanguageModeling,
+    "mlm": MaskedLanguageModeling, "masked": MaskedLanguageModeling,
+}
+
+
+def parse_masking(masking, hidden_size, **kwargs):
+    """masking_registry.parse(masking)(hidden_size=..., **kwargs) (features/sequence.py:221-224)"""
+    if masking is None or isinstance(masking, MaskSequence):
+        return masking
+    if masking not in masking_registry:
+        raise KeyError(f"{masking} never registered with registry masking (supported: clm, causal, mlm, masked)")
+    return masking_registry[masking](hidden_size=hidden_size, **kwargs)

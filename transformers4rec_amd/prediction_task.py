@@ -1,0 +1,267 @@
+"""NextItemPredictionTask: host-side mirror of transformers4rec/torch/model/prediction_task.py
+  NextItemPredictionTask   :306-479   (constructor, build, forward train/eval/inference)
+  _NextItemPredictionTask  :589-696   (tied / untied projection, temperature, sampled softmax)
+  LogUniformSampler        :702-861
+with the same arguments, output dict {"loss","labels","predictions"}, attribute contract and
+state_dict names.  Arithmetic: csrc/masking.hip (row compaction), gemm_f32.hip
+(X @ W^T and its two backward contractions), head.hip (softmax-CE, sampled logits, top-k).
+"""
+import math
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from .features import _Linear
+from .masking import MaskedLanguageModeling, _grad_buf
+
+
+class LogUniformSampler(nn.Module):
+    """reference prediction_task.py:702-861 (buffers `dist`, `unique_sampling_dist`)."""
+
+    def __init__(self, max_n_samples: int, max_id: int, min_id: int = 0, unique_sampling: bool = True,
+                 n_samples_multiplier_before_unique: int = 2):
+        super().__init__()
+        if max_id <= 0:
+            raise ValueError("max_id must be a positive integer.")
+        if max_n_samples <= 0:
+            raise ValueError("n_sample must be a positive integer.")
+        self.max_id, self.unique_sampling, self.max_n_samples = max_id, unique_sampling, max_n_samples
+        self.n_sample = int(max_n_samples * n_samples_multiplier_before_unique) if unique_sampling else max_n_samples
+        with torch.no_grad():
+            log_indices = torch.arange(1.0, max_id - min_id + 2.0, 1.0).log_()
+            dist = (log_indices[1:] - log_indices[:-1]) / log_indices[-1]
+            if min_id > 0:
+                dist = torch.cat([torch.zeros([min_id], dtype=dist.dtype), dist], dim=0)
+            self.register_buffer("dist", dist)
+            self.register_buffer("unique_sampling_dist", (-(-dist.double().log1p_() * self.n_sample).expm1_()).float())
+
+    def sample(self, labels: torch.Tensor):
+        if not torch.is_tensor(labels):
+            raise TypeError("Labels must be a torch.Tensor.")
+        if labels.dtype != torch.long:
+            raise ValueError("Labels must be a tensor of dtype long.")
+        if labels.size(0) == 0:
+            raise ValueError("Labels must not be an empty tensor.")
+        with torch.no_grad():
+            # negatives shared by the batch: multinomial with replacement, unique (sorted), truncated
+            neg = torch.multinomial(self.dist, self.n_sample, replacement=True).unique()[: self.max_n_samples]
+            return neg.to(labels.device)
+
+    @property
+    def correction_dist(self):
+        return self.unique_sampling_dist if self.unique_sampling else self.dist
+
+
+class _NextItemPredictionModule(nn.Module):
+    """Parameter holder named like the reference's `pre.module` (_NextItemPredictionTask)."""
+
+    def __init__(self, input_dim, target_dim, weight_tying, item_embedding_table, softmax_temperature,
+                 sampled_softmax, max_n_samples, min_id):
+        super().__init__()
+        self.target_dim, self.weight_tying = target_dim, weight_tying
+        self.item_embedding_table = item_embedding_table
+        self.softmax_temperature = softmax_temperature
+        self.sampled_softmax = sampled_softmax
+        if not weight_tying:
+            self.output_layer = nn.Parameter(torch.empty(target_dim, input_dim))
+            nn.init.kaiming_uniform_(self.output_layer, a=math.sqrt(5))
+        if sampled_softmax:
+            self.sampler = LogUniformSampler(max_n_samples=max_n_samples, max_id=target_dim, min_id=min_id,
+                                             unique_sampling=True)
+
+    @property
+    def output_weights(self):
+        return self.item_embedding_table.weight if self.weight_tying else self.output_layer
+
+
+class _Pre(nn.Module):
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+
+class _NextItemHeadFn(torch.autograd.Function):
+    """rows at label positions -> [task Linear] -> logits (full or sampled) -> mean CE."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, task, pos, labels, N, neg):
+        B, L, D = x.shape
+        mod = task.pre.module
+        W = mod.output_weights
+        T = float(mod.softmax_temperature) if mod.softmax_temperature else 1.0
+        x2 = x.contiguous().view(B * L, D)
+        xr = ops.gather_rows(x2, pos, N)
+        lin = task.task_block[0][0] if task.task_block is not None else None
+        xp = xr
+        if lin is not None:
+            xp = ops.gemm(xr, lin.weight.detach(), False, True, bias=lin.bias.detach(), epilogue=ops.EPI_BIAS)
+        V = W.shape[0]
+        if neg is None:
+            logits = ops.gemm(xp, W.detach(), False, True, alpha=1.0 / T, ldc=ops.pad_ld(V))
+            tgt, width = labels, V
+        else:
+            logits = ops.sampled_logits_fwd(xp, labels, W.detach(), neg, mod.sampler.correction_dist, T)
+            tgt, width = torch.zeros_like(labels), logits.shape[1]
+        smooth = float(getattr(task.loss, "label_smoothing", 0.0) or 0.0)
+        loss, _rows, lse = ops.softmax_ce_fwd(logits, tgt, width, smooth)
+        ctx.task, ctx.neg, ctx.meta = task, neg, (B, L, D, N, V, T, width, smooth)
+        ctx.save_for_backward(pos, labels, tgt, xr, xp, logits, lse)
+        ctx.mark_non_differentiable(logits)
+        return loss, logits
+
+    @staticmethod
+    def backward(ctx, dloss, _dlogits_unused):
+        pos, labels, tgt, xr, xp, logits, lse = ctx.saved_tensors
+        task = ctx.task
+        B, L, D, N, V, T, width, smooth = ctx.meta
+        mod = task.pre.module
+        W = mod.output_weights
+        dl = ops.softmax_ce_bwd(logits, tgt, lse, dloss.contiguous(), width, smooth)
+        if ctx.neg is None:
+            dlv = dl[:, :V]
+            dxp = ops.gemm(dlv, W.detach(), False, False, alpha=1.0 / T, splitk=-1)
+            if W.requires_grad:
+                ops.gemm(dlv, xp, True, False, alpha=1.0 / T, accumulate=True, out=_grad_buf(W))
+        else:
+            dxp = ops.sampled_logits_bwd(dl, xp, labels, W.detach(), ctx.neg, _grad_buf(W), T)
+        lin = task.task_block[0][0] if task.task_block is not None else None
+        dxr = dxp
+        if lin is not None:
+            ops.gemm(dxp, xr, True, False, splitk=-1, accumulate=True, out=_grad_buf(lin.weight))
+            ops.colsum_(dxp, _grad_buf(lin.bias))
+            dxr = ops.gemm(dxp, lin.weight.detach(), False, False)
+        dx = torch.zeros((B * L, D), device=dxr.device, dtype=torch.float32)
+        ops.scatter_rows_add_(dxr, pos, dx)
+        return dx.view(B, L, D), None, None, None, None, None, None
+
+
+class NextItemPredictionTask(nn.Module):
+    """Drop-in for tr.NextItemPredictionTask on the hot path."""
+
+    def __init__(self, loss: nn.Module = None, metrics=None, task_block=None, task_name: str = "next-item",
+                 weight_tying: bool = False, softmax_temperature: float = 1, padding_idx: int = 0,
+                 target_dim: int = None, sampled_softmax: Optional[bool] = False,
+                 max_n_samples: Optional[int] = 100, top_ks=(10, 20)):
+        super().__init__()
+        loss = loss if loss is not None else nn.CrossEntropyLoss()
+        if not isinstance(loss, nn.CrossEntropyLoss):
+            raise NotImplementedError("the HIP head fuses torch.nn.CrossEntropyLoss (optionally label-smoothed)")
+        if task_block is not None:
+            raise NotImplementedError("custom task_block is off the hot path (auto projection is supported)")
+        self.loss = loss
+        self.task_name = task_name
+        self.softmax_temperature = softmax_temperature
+        self.weight_tying = weight_tying
+        self.padding_idx = padding_idx
+        self.target_dim = target_dim
+        self.sampled_softmax = sampled_softmax
+        self.max_n_samples = max_n_samples
+        self.top_ks = tuple(top_ks)
+        self.task_block = None
+        self.item_embedding_table = None
+        self.masking = None
+        self.embeddings = None
+        self.pre = None
+        self._metric_sums = None
+
+    def build(self, body=None, input_size=None, device=None, inputs=None, task_block=None, pre=None):
+        """Called by the Head/Model (prediction_task.py:369-417)."""
+        if input_size is None or len(input_size) != 3:
+            raise ValueError(f"NextItemPredictionTask needs a 3-dim vector as input, found:{input_size}")
+        if inputs is None:
+            inputs = body.inputs
+        if not getattr(inputs, "item_id", None):
+            raise ValueError("For Item Prediction task a categorical_module including an item_id column is required.")
+        self.embeddings = inputs.categorical_module
+        if not self.target_dim:
+            self.target_dim = self.embeddings.item_embedding_table.num_embeddings
+        item_table = None
+        in_dim = input_size[-1]
+        if self.weight_tying:
+            item_table = self.embeddings.item_embedding_table
+            self.item_embedding_table = item_table
+            item_dim = item_table.weight.shape[1]
+            if in_dim != item_dim:
+                # MLPBlock([item_dim], activation=None)  (prediction_task.py:390-397)
+                self.task_block = nn.Sequential(nn.Sequential(_Linear(in_dim, item_dim)))
+                in_dim = item_dim
+        self.masking = inputs.masking
+        if not self.masking:
+            raise ValueError("The input block should contain a masking schema for training and evaluation")
+        self.padding_idx = self.masking.padding_idx
+        self.pre = _Pre(_NextItemPredictionModule(
+            in_dim, self.target_dim, self.weight_tying, item_table, self.softmax_temperature,
+            self.sampled_softmax, self.max_n_samples, self.padding_idx + 1))
+        if device is not None:
+            self.to(device)
+        return self
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, inputs, targets=None, training=False, testing=False, top_k=None, **kwargs):
+        if isinstance(inputs, (tuple, list)):
+            inputs = inputs[0]
+        x = inputs.float()
+        mod = self.pre.module
+        if training or testing:
+            n, pos, lab = self.masking.compact_labels()
+            N = int(n.item())  # host sync: the logits tensor the API returns is [N, V]
+            labels = lab[:N]
+            if N == 0:
+                raise ValueError("no label positions in this batch")
+            neg = mod.sampler.sample(labels) if (self.sampled_softmax and training) else None
+            loss, logits = _NextItemHeadFn.apply(x, mod.output_weights, self, pos, labels, N, neg)
+            if neg is None:
+                preds = logits[:, : mod.output_weights.shape[0]]
+                y = labels
+            else:
+                preds, y = logits, torch.zeros_like(labels)
+            return {"loss": loss, "labels": y, "predictions": preds}
+        # inference: hidden state at the last item (prediction_task.py:452-470)
+        item_seq = self.embeddings.item_seq
+        B, Lg, D = x.shape
+        pos = ops.last_positions(item_seq.contiguous(), Lg, isinstance(self.masking, MaskedLanguageModeling),
+                                 self.padding_idx)
+        xr = ops.gather_rows(x.contiguous().view(B * Lg, D), pos, B)
+        if self.task_block is not None:
+            lin = self.task_block[0][0]
+            xr = ops.gemm(xr, lin.weight.detach(), False, True, bias=lin.bias.detach(), epilogue=ops.EPI_BIAS)
+        W = mod.output_weights.detach()
+        T = float(mod.softmax_temperature) if mod.softmax_temperature else 1.0
+        V = W.shape[0]
+        scores = ops.gemm(xr, W, False, True, alpha=1.0 / T, ldc=ops.pad_ld(V))
+        if top_k is None:
+            return scores
+        return ops.topk(scores, top_k, V)
+
+    # ------------------------------------------------------------------ ranking metrics (N1)
+    def calculate_metrics(self, predictions, targets):
+        """Recall@k / NDCG@k with one relevant item per row (ranking_metric.py:107-147,242-280;
+        labels_onehot=True) from a fused top-k -- no [N, V] one-hot."""
+        kmax = max(self.top_ks)
+        _, idx = ops.topk(predictions, kmax, predictions.shape[1])
+        hit = idx == targets.unsqueeze(-1)
+        out = {}
+        ranks = torch.arange(kmax, device=idx.device, dtype=torch.float32)
+        gain = 1.0 / torch.log2(ranks + 2.0)
+        for k in self.top_ks:
+            out[f"recall_at_{k}"] = hit[:, :k].any(-1).float()
+            out[f"ndcg_at_{k}"] = (hit[:, :k].float() * gain[:k]).sum(-1)
+        if self._metric_sums is None:
+            self._metric_sums = {k: [0.0, 0] for k in out}
+        for k, v in out.items():
+            self._metric_sums[k][0] += float(v.sum())
+            self._metric_sums[k][1] += v.numel()
+        return out
+
+    def compute_metrics(self, mode=None):
+        if not self._metric_sums:
+            return {}
+        return {f"{self.task_name}/{k}": s / max(n, 1) for k, (s, n) in self._metric_sums.items()}
+
+    def reset_metrics(self):
+        self._metric_sums = None
+
+    def metric_name(self, name):
+        return f"{self.task_name}/{name}"

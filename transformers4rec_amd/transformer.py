@@ -1,0 +1,233 @@
+"""TransformerBlock + XLNet configuration: host-side mirror of
+  transformers4rec/torch/block/transformer.py:76-206   (TransformerBlock)
+  transformers4rec/config/transformer.py:423-482        (XLNetConfig.build)
+and of the parameter layout of HF `XLNetModel` (third-party dependency of the reference;
+modeling_xlnet.py:245-353, 979-1205) so that reference checkpoints load unchanged
+(state_dict names `transformer.layer.<i>.rel_attn.{q,k,v,o,r,r_r_bias,r_s_bias,r_w_bias,
+seg_embed,layer_norm.*}`, `...ff.{layer_norm,layer_1,layer_2}.*`, `transformer.mask_emb`,
+`transformer.word_embedding.weight`).  The arithmetic is csrc/xlnet_layer.hip.
+
+Reference semantics kept on purpose: NO padding attention mask; the
+relative positional keys are computed once per layer, not per batch row.
+"""
+from dataclasses import dataclass, field
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from .masking import MaskedLanguageModeling, CausalLanguageModeling, MaskSequence, _grad_buf
+
+
+@dataclass
+class XLNetConfig:
+    """Fields XLNetConfig.build sets on the HF config (config/transformer.py:432-482)."""
+    d_model: int = 128
+    n_head: int = 4
+    n_layer: int = 4
+    d_inner: int = 512
+    attn_type: str = "bi"
+    ff_activation: str = "gelu"
+    initializer_range: float = 0.01
+    layer_norm_eps: float = 0.03
+    dropout: float = 0.3
+    pad_token_id: int = 0
+    vocab_size: int = 1
+    mem_len: int = 1
+    total_seq_length: Optional[int] = None
+    model_type: str = field(default="xlnet", repr=False)
+
+    @classmethod
+    def build(cls, d_model, n_head, n_layer, total_seq_length=None, attn_type="bi", hidden_act="gelu",
+              initializer_range=0.01, layer_norm_eps=0.03, dropout=0.3, pad_token=0,
+              log_attention_weights=False, mem_len=1, **kwargs):
+        if attn_type != "bi":
+            raise NotImplementedError("only attn_type='bi' (the reference default) is on the hot path")
+        if hidden_act != "gelu":
+            raise NotImplementedError("only hidden_act='gelu' (erf) is on the hot path")
+        if d_model % n_head:
+            raise ValueError(f"The hidden size ({d_model}) is not a multiple of the number of attention heads ({n_head}")
+        return cls(d_model=d_model, n_head=n_head, n_layer=n_layer, d_inner=4 * d_model,
+                   attn_type=attn_type, ff_activation=hidden_act, initializer_range=initializer_range,
+                   layer_norm_eps=layer_norm_eps, dropout=dropout, pad_token_id=pad_token,
+                   mem_len=mem_len, total_seq_length=total_seq_length)
+
+    @property
+    def hidden_size(self):
+        return self.d_model
+
+    @property
+    def d_head(self):
+        return self.d_model // self.n_head
+
+    def to_huggingface_torch_model(self):
+        return XLNetModel(self)
+
+    def to_torch_model(self, input_features, *prediction_task, task_blocks=None, task_weights=None,
+                       loss_reduction="mean", **kwargs):
+        """config/transformer.py:71-131: SequentialBlock(inputs, TransformerBlock) -> Head -> Model."""
+        from .model import Model
+
+        if len(prediction_task) != 1:
+            raise NotImplementedError("one NextItemPredictionTask per model on the hot path")
+        block = TransformerBlock(self, masking=input_features.masking)
+        return Model(input_features, block, prediction_task[0])
+
+
+class _LN(nn.Module):
+    def __init__(self, dim, eps):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+
+class _Lin(nn.Module):
+    def __init__(self, fin, fout, std):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(fout, fin).normal_(0, std))
+        self.bias = nn.Parameter(torch.zeros(fout))
+
+
+class XLNetRelativeAttentionParams(nn.Module):
+    def __init__(self, cfg: XLNetConfig):
+        super().__init__()
+        D, n, dh, s = cfg.d_model, cfg.n_head, cfg.d_head, cfg.initializer_range
+        mk = lambda *shape: nn.Parameter(torch.empty(*shape).normal_(0, s))
+        self.q, self.k, self.v, self.o, self.r = mk(D, n, dh), mk(D, n, dh), mk(D, n, dh), mk(D, n, dh), mk(D, n, dh)
+        self.r_r_bias, self.r_s_bias, self.r_w_bias = mk(n, dh), mk(n, dh), mk(n, dh)
+        self.seg_embed = mk(2, n, dh)      # unused without token_type_ids (as in the reference run)
+        self.layer_norm = _LN(D, cfg.layer_norm_eps)
+
+
+class XLNetFeedForwardParams(nn.Module):
+    def __init__(self, cfg: XLNetConfig):
+        super().__init__()
+        self.layer_norm = _LN(cfg.d_model, cfg.layer_norm_eps)
+        self.layer_1 = _Lin(cfg.d_model, cfg.d_inner, cfg.initializer_range)
+        self.layer_2 = _Lin(cfg.d_inner, cfg.d_model, cfg.initializer_range)
+
+
+class XLNetLayer(nn.Module):
+    def __init__(self, cfg: XLNetConfig):
+        super().__init__()
+        self.rel_attn = XLNetRelativeAttentionParams(cfg)
+        self.ff = XLNetFeedForwardParams(cfg)
+
+    def ordered_params(self):
+        a, f = self.rel_attn, self.ff
+        return [a.q, a.k, a.v, a.o, a.r, a.r_w_bias, a.r_r_bias, a.layer_norm.weight, a.layer_norm.bias,
+                f.layer_1.weight, f.layer_1.bias, f.layer_2.weight, f.layer_2.bias, f.layer_norm.weight,
+                f.layer_norm.bias]
+
+
+def relative_positional_encoding(L, D):
+    """HF modeling_xlnet.py:940-976 for attn_type='bi', bi_data=False, clamp_len=-1, klen==qlen:
+    pos_seq = arange(L, -L, -1) ; [sin(pos*inv_freq) | cos(pos*inv_freq)]  -> [2L, D]"""
+    freq_seq = torch.arange(0, D, 2.0, dtype=torch.int64).float()
+    inv_freq = 1 / torch.pow(10000, (freq_seq / D))
+    pos_seq = torch.arange(L, -L, -1.0, dtype=torch.int64).float()
+    sinusoid = torch.einsum("i,d->id", pos_seq, inv_freq)
+    return torch.cat([torch.sin(sinusoid), torch.cos(sinusoid)], dim=-1)
+
+
+class _XLNetLayerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, anchor, layer, pos_emb, n_head, eps):
+        B, L, D = h.shape
+        h2 = h.contiguous().view(B * L, D)
+        params = [p.detach() for p in layer.ordered_params()]
+        out, ws = ops.xlnet_layer_fwd(h2, pos_emb, params, B, L, n_head, eps)
+        ctx.layer, ctx.pos_emb, ctx.cfg = layer, pos_emb, (B, L, D, n_head, eps)
+        ctx.save_for_backward(h2, ws)
+        return out.view(B, L, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        h2, ws = ctx.saved_tensors
+        B, L, D, n_head, eps = ctx.cfg
+        plist = ctx.layer.ordered_params()
+        grads = [_grad_buf(p) for p in plist]
+        dh = ops.xlnet_layer_bwd(h2, ctx.pos_emb, [p.detach() for p in plist], grads, ws,
+                                 dout.contiguous().view(B * L, D), B, L, n_head, eps)
+        return dh.view(B, L, D), None, None, None, None, None
+
+
+class _WordEmbedding(nn.Module):
+    def __init__(self, vocab, dim, std):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(vocab, dim).normal_(0, std))
+
+
+class XLNetModel(nn.Module):
+    """Parameter container with HF XLNetModel's layout; forward(inputs_embeds) -> (hidden,)"""
+
+    def __init__(self, config: XLNetConfig):
+        super().__init__()
+        self.config = config
+        self.word_embedding = _WordEmbedding(config.vocab_size, config.d_model, config.initializer_range)
+        self.mask_emb = nn.Parameter(torch.empty(1, 1, config.d_model).normal_(0, config.initializer_range))
+        self.layer = nn.ModuleList([XLNetLayer(config) for _ in range(config.n_layer)])
+        self._pos_cache = {}
+
+    config_class = XLNetConfig
+
+    def pos_emb(self, L, device):
+        key = (L, str(device))
+        if key not in self._pos_cache:
+            self._pos_cache[key] = relative_positional_encoding(L, self.config.d_model).to(device).contiguous()
+        return self._pos_cache[key]
+
+    def forward(self, inputs_embeds=None, **kwargs):
+        cfg = self.config
+        if self.training and cfg.dropout > 0:
+            raise NotImplementedError(
+                "XLNet dropout > 0 in training mode is not implemented on the HIP path yet; "
+                "build the config with dropout=0.0 (SURVEY H3)")
+        B, L, D = inputs_embeds.shape
+        if D != cfg.d_model:
+            raise ValueError(f"inputs_embeds last dim {D} != d_model {cfg.d_model}")
+        pos = self.pos_emb(L, inputs_embeds.device)
+        h = inputs_embeds
+        for layer in self.layer:
+            h = _XLNetLayerFn.apply(h, layer.rel_attn.q, layer, pos, cfg.n_head, cfg.layer_norm_eps)
+        return (h,)
+
+
+class TransformerBlock(nn.Module):
+    """Drop-in for tr.TransformerBlock (block/transformer.py:76-206) with the XLNet body on HIP."""
+
+    SUPPORTED_MASKING = (MaskedLanguageModeling, CausalLanguageModeling)
+
+    def __init__(self, transformer, masking: Optional[MaskSequence] = None, prepare_module=None):
+        super().__init__()
+        if isinstance(transformer, XLNetConfig):
+            self.transformer = transformer.to_huggingface_torch_model()
+        elif isinstance(transformer, XLNetModel):
+            self.transformer = transformer
+        else:
+            raise TypeError("TransformerBlock on the HIP path takes an XLNetConfig or XLNetModel")
+        if masking is not None and not isinstance(masking, self.SUPPORTED_MASKING):
+            raise ValueError(f"{masking.__class__.__name__} is not supported by: the XLNetConfig architecture")
+        self.masking = masking
+        self.prepare_module = None
+
+    @classmethod
+    def from_registry(cls, transformer: str, d_model: int, n_head: int, n_layer: int, total_seq_length: int,
+                      masking: Optional[MaskSequence] = None):
+        if transformer != "xlnet":
+            raise KeyError(f"{transformer} never registered with the HIP transformer registry (supported: xlnet)")
+        return cls(XLNetConfig.build(d_model=d_model, n_head=n_head, n_layer=n_layer,
+                                     total_seq_length=total_seq_length), masking)
+
+    def forward(self, inputs_embeds, **kwargs):
+        # the reference passes inputs_embeds only for XLNet + MLM/CLM (block/transformer.py:183-199)
+        return self.transformer(inputs_embeds=inputs_embeds)[0]
+
+    def _get_name(self):
+        return "TansformerBlock"
+
+    def forward_output_size(self, input_size):
+        assert len(input_size) == 3
+        return torch.Size([input_size[0], input_size[1], self.transformer.config.hidden_size])

@@ -129,11 +129,15 @@ int t4r_add_layernorm_fwd(void* stream, const float* a, const float* b, const fl
                           float eps);
 int t4r_add_layernorm_bwd(void* stream, const float* a, const float* b, const float* gamma,
                           const float* mean, const float* rstd, const float* dy, float* dx,
-                          float* dgamma, float* dbeta, int rows, int D, int accumulate_dx);
-/* activation backward + bias gradient: mode 0 GELU(erf) on saved pre-activation, 1 ReLU on saved output */
+                          float* dgamma, float* dbeta, float* ws, int rows, int D, int accumulate_dx);
+/* Batch-reduced gradients are summed in two deterministic stages through a caller workspace of
+ * t4r_colreduce_ws_floats(rows, ncols) floats (ncols = 2*D for LayerNorm backward, N otherwise). */
+long t4r_colreduce_ws_floats(long rows, int ncols);
+/* activation backward + bias gradient: mode 0 GELU(erf) on saved pre-activation, 1 ReLU on saved
+ * output; dbias (accumulated) may be NULL (then ws may be NULL).  N % 4 == 0. */
 int t4r_act_bwd_bias(void* stream, const float* dact, const float* pre, float* dpre, float* dbias,
-                     long rows, int N, int mode);
-int t4r_colsum(void* stream, const float* x, float* out, long rows, int N, long ld);
+                     float* ws, long rows, int N, int mode);
+int t4r_colsum(void* stream, const float* x, float* out, float* ws, long rows, int N, long ld);
 
 /* ----------------------------------------------------------------------------------------
  * a15  XLNet relative attention core and the whole layer

@@ -35,9 +35,10 @@ _SIGS = {
     "t4r_last_positions": ("i", "ppiiiilp"),
     "t4r_gemm_f32": ("i", "piiiiif" + "plplpl" + "pipl" + "iii" + "lll"),
     "t4r_add_layernorm_fwd": ("i", "pppppppp" + "iif"),
-    "t4r_add_layernorm_bwd": ("i", "pppppppppp" + "iii"),
-    "t4r_act_bwd_bias": ("i", "ppppp" + "lii"),
-    "t4r_colsum": ("i", "ppp" + "lil"),
+    "t4r_add_layernorm_bwd": ("i", "ppppppppppp" + "iii"),
+    "t4r_colreduce_ws_floats": ("l", "li"),
+    "t4r_act_bwd_bias": ("i", "pppppp" + "lii"),
+    "t4r_colsum": ("i", "pppp" + "lil"),
     "t4r_xlnet_attn_fwd": ("i", "ppppppppp" + "iiii"),
     "t4r_xlnet_attn_bwd_ws_floats": ("l", "iiii"),
     "t4r_xlnet_attn_bwd": ("i", "p" * 17 + "iiii"),

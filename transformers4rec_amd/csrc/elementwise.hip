@@ -115,19 +115,69 @@ extern "C" int t4r_add_layernorm_fwd(void* stream, const float* a, const float* 
     return 0;
 }
 
+// ---------------------------------------------------------------- deterministic column reductions
+// Every batch-reduced gradient (LayerNorm gamma/beta, biases, attention biases / k_r) is produced
+// in two stages: each workgroup writes its partial sums to a workspace row, then this kernel
+// sums the rows.  No atomics: 20k token rows hitting a few hundred addresses serialise in L2
+// (measured: 254 us for a LayerNorm backward whose data pass takes ~10 us).
+//   out_s[i] (+)= sum_b part[b*n + off_s + i]   for up to three output segments s.
+struct ReduceSeg { float* out; int len; int accumulate; };
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part,
+                                                               int nblocks, int n, ReduceSeg s0,
+                                                               ReduceSeg s1, ReduceSeg s2) {
+    __shared__ float sm[4][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + c;
+    float acc = 0.f;
+    if (i < n) {
+        int b = g;
+        for (; b + 12 < nblocks; b += 16)
+            acc += part[(long)b * n + i] + part[(long)(b + 4) * n + i] + part[(long)(b + 8) * n + i] +
+                   part[(long)(b + 12) * n + i];
+        for (; b < nblocks; b += 4) acc += part[(long)b * n + i];
+    }
+    sm[g][c] = acc;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        const float v = sm[0][c] + sm[1][c] + sm[2][c] + sm[3][c];
+        int j = i;
+        ReduceSeg seg = s0;
+        if (j >= s0.len) { j -= s0.len; seg = s1; if (j >= s1.len) { j -= s1.len; seg = s2; } }
+        if (seg.out) seg.out[j] = seg.accumulate ? seg.out[j] + v : v;
+    }
+}
+
+int t4r_reduce_partials_launch(hipStream_t st, const float* part, int nblocks, float* o0, int n0, int a0,
+                               float* o1, int n1, int a1, float* o2, int n2, int a2) {
+    const int n = n0 + n1 + n2;
+    if (n <= 0 || nblocks <= 0) return 0;
+    ReduceSeg s0{o0, n0, a0}, s1{o1, n1, a1}, s2{o2, n2, a2};
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 63) / 64), dim3(256), 0, st, part, nblocks, n,
+                       s0, s1, s2);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+#define T4R_COLRED_ROWS 64
+// workspace floats needed by the column-reducing kernels below for `rows` rows and `ncols`
+// reduced columns in total (LayerNorm backward: 2*D ; act_bwd_bias / colsum: N)
+extern "C" long t4r_colreduce_ws_floats(long rows, int ncols) {
+    return ((rows + T4R_COLRED_ROWS - 1) / T4R_COLRED_ROWS) * (long)ncols;
+}
+
 // ---------------------------------------------------------------- residual + LayerNorm bwd
 // x = a + b (recomputed), xhat = (x - mean) * rstd
 // dx = rstd * (g - mean_D(g) - xhat * mean_D(g * xhat)),  g = dy * gamma
-// dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy     (atomics, one per column per wave)
-// Each wave walks rows_per_wave rows keeping its column partials in registers.
+// dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy   (two-stage, see above)
+// One workgroup = 4 waves x 16 rows; column partials stay in registers, are combined across the
+// 4 waves through LDS and written to part[block][0:D | D:2D].
 template <int VEC, int NC>
 __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(
     const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ dy,
-    float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int D,
-    int rows_per_wave, int accumulate_dx) {
-    const int lane = threadIdx.x & 63;
-    const int wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    float* __restrict__ dx, float* __restrict__ part, int rows, int D, int accumulate_dx) {
+    extern __shared__ float sm[];   // [4][2*D]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     FV<VEC> pg[NC], pb[NC], gam[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -136,9 +186,9 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(
         for (int e = 0; e < VEC; ++e) pg[c].v[e] = pb[c].v[e] = gam[c].v[e] = 0.f;
         if (c0 < D) gam[c] = *reinterpret_cast<const FV<VEC>*>(gamma + c0);
     }
-    const int r0 = wave_global * rows_per_wave;
-    const int r1 = min(rows, r0 + rows_per_wave);
-    for (int row = r0; row < r1; ++row) {
+    const int r0 = blockIdx.x * T4R_COLRED_ROWS;
+    const int r1 = min(rows, r0 + T4R_COLRED_ROWS);
+    for (int row = r0 + wave; row < r1; row += 4) {
         const float* ar = a + (long)row * D;
         const float* br = b ? b + (long)row * D : nullptr;
         const float* dyr = dy + (long)row * D;
@@ -187,94 +237,126 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(
             }
         }
     }
-    if (r0 >= r1) return;
+    float* mine = sm + wave * 2 * D;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int c0 = (c * 64 + lane) * VEC;
         if (c0 < D) {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                if (dgamma) atomicAdd(dgamma + c0 + e, pg[c].v[e]);
-                if (dbeta) atomicAdd(dbeta + c0 + e, pb[c].v[e]);
-            }
+            for (int e = 0; e < VEC; ++e) { mine[c0 + e] = pg[c].v[e]; mine[D + c0 + e] = pb[c].v[e]; }
         }
     }
+    __syncthreads();
+    float* prow = part + (long)blockIdx.x * 2 * D;
+    for (int i = threadIdx.x; i < 2 * D; i += 256)
+        prow[i] = sm[i] + sm[2 * D + i] + sm[4 * D + i] + sm[6 * D + i];
 }
 
+// ws: t4r_colreduce_ws_floats(rows, 2*D) floats
 extern "C" int t4r_add_layernorm_bwd(void* stream, const float* a, const float* b,
                                      const float* gamma, const float* mean, const float* rstd,
                                      const float* dy, float* dx, float* dgamma, float* dbeta,
-                                     int rows, int D, int accumulate_dx) {
+                                     float* ws, int rows, int D, int accumulate_dx) {
     if (rows <= 0) return 0;
     int vec, nc;
     T4R_CHECK_ARG(D > 0 && ln_pick(D, &vec, &nc), "layernorm: D out of range");
+    T4R_CHECK_ARG(ws != nullptr, "layernorm_bwd: workspace required");
     hipStream_t st = (hipStream_t)stream;
-    const int wpb = 4;
-    int rpw = (rows + 2048 * wpb - 1) / (2048 * wpb);  // ~2048 blocks at most
-    if (rpw < 4) rpw = 4;
-    const int waves = (rows + rpw - 1) / rpw;
-    dim3 grid((waves + wpb - 1) / wpb), block(64 * wpb);
-    LN_DISPATCH(add_layernorm_bwd_kernel, a, b, gamma, mean, rstd, dy, dx, dgamma, dbeta, rows, D,
-                rpw, accumulate_dx);
+    const int nblocks = (rows + T4R_COLRED_ROWS - 1) / T4R_COLRED_ROWS;
+    dim3 grid(nblocks), block(256);
+    const size_t smem = (size_t)8 * D * sizeof(float);
+#undef LN_DISPATCH_SMEM
+#define LN_BWD(V, N) hipLaunchKernelGGL((add_layernorm_bwd_kernel<V, N>), grid, block, smem, st, a, b, gamma, mean, rstd, dy, dx, ws, rows, D, accumulate_dx)
+    if (vec == 4 && nc == 1) LN_BWD(4, 1);
+    else if (vec == 4 && nc == 2) LN_BWD(4, 2);
+    else if (vec == 4 && nc == 4) LN_BWD(4, 4);
+    else if (vec == 4 && nc == 8) LN_BWD(4, 8);
+    else if (vec == 2 && nc == 1) LN_BWD(2, 1);
+    else if (vec == 2) LN_BWD(2, 8);
+    else if (nc == 1) LN_BWD(1, 1);
+    else if (nc == 2) LN_BWD(1, 2);
+    else LN_BWD(1, 8);
+#undef LN_BWD
     T4R_LAUNCH_CHECK();
-    return 0;
+    return t4r_reduce_partials_launch(st, ws, nblocks, dgamma, D, 1, dbeta, D, 1, nullptr, 0, 0);
 }
 
 // ---------------------------------------------------------------- activation backward + bias grad
 // mode 0: GELU(erf):  dpre = dact * gelu'(pre)      (pre = saved pre-activation)
 // mode 1: ReLU     :  dpre = dact * (out > 0)       (pre = saved OUTPUT of relu)
-// dbias[N] += column sums of dpre.  Block = 256 threads handles a [rows_per_block, N] slab;
-// thread t owns columns t, t+256, ... so the column partial stays in a register.
+// mode 2: plain column sum of dact (no dpre)
+// dbias[N] += column sums (two-stage).  A workgroup owns 64 rows; threads are laid out as
+// (row group g, float4 column cq) so that every global access is a 16-byte coalesced access.
 __global__ __launch_bounds__(256) void act_bwd_bias_kernel(
     const float* __restrict__ dact, const float* __restrict__ pre, float* __restrict__ dpre,
-    float* __restrict__ dbias, long rows, int N, int rows_per_block, int mode) {
-    const long r0 = (long)blockIdx.x * rows_per_block;
-    const long r1 = min(rows, r0 + rows_per_block);
-    for (int c = threadIdx.x; c < N; c += 256) {
-        float acc = 0.f;
-        for (long r = r0; r < r1; ++r) {
-            const long i = r * N + c;
-            const float p = pre[i];
-            float g = dact[i];
-            g *= (mode == 0) ? gelu_erf_grad(p) : (p > 0.f ? 1.f : 0.f);
-            dpre[i] = g;
-            acc += g;
+    float* __restrict__ part, long rows, int N, long ld, int mode, int cqp) {
+    __shared__ float4 sm[256];
+    const int NQ = N >> 2;
+    const int ng = 256 / cqp;
+    const int tc = threadIdx.x % cqp, g = threadIdx.x / cqp;
+    const long r0 = (long)blockIdx.x * T4R_COLRED_ROWS;
+    const long r1 = min(rows, r0 + T4R_COLRED_ROWS);
+    for (int cq0 = 0; cq0 < NQ; cq0 += cqp) {
+        const int cq = cq0 + tc;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cq < NQ) {
+            for (long r = r0 + g; r < r1; r += ng) {
+                const long i = r * ld + 4 * cq;
+                float4 d = *reinterpret_cast<const float4*>(dact + i);
+                if (mode != 2) {
+                    const float4 p = *reinterpret_cast<const float4*>(pre + i);
+                    if (mode == 0) {
+                        d.x *= gelu_erf_grad(p.x); d.y *= gelu_erf_grad(p.y);
+                        d.z *= gelu_erf_grad(p.z); d.w *= gelu_erf_grad(p.w);
+                    } else {
+                        d.x = p.x > 0.f ? d.x : 0.f; d.y = p.y > 0.f ? d.y : 0.f;
+                        d.z = p.z > 0.f ? d.z : 0.f; d.w = p.w > 0.f ? d.w : 0.f;
+                    }
+                    *reinterpret_cast<float4*>(dpre + i) = d;
+                }
+                acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
+            }
         }
-        if (dbias) atomicAdd(dbias + c, acc);
+        if (part) {
+            sm[threadIdx.x] = acc;
+            __syncthreads();
+            if (g == 0 && cq < NQ) {
+                for (int k = 1; k < ng; ++k) {
+                    const float4 o = sm[k * cqp + tc];
+                    acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+                }
+                *reinterpret_cast<float4*>(part + (long)blockIdx.x * N + 4 * cq) = acc;
+            }
+            __syncthreads();
+        }
     }
 }
 
+static int colred_launch(hipStream_t st, const float* dact, const float* pre, float* dpre, float* dbias,
+                         float* ws, long rows, int N, long ld, int mode) {
+    if (rows <= 0) return 0;
+    T4R_CHECK_ARG(N % 4 == 0 && ld % 4 == 0, "act_bwd_bias/colsum: N and ld must be multiples of 4");
+    T4R_CHECK_ARG(!dbias || ws, "act_bwd_bias/colsum: workspace required");
+    int cqp = 1;
+    while (cqp * 2 <= (N >> 2) && cqp < 256) cqp <<= 1;
+    const int nblocks = (int)((rows + T4R_COLRED_ROWS - 1) / T4R_COLRED_ROWS);
+    hipLaunchKernelGGL(act_bwd_bias_kernel, dim3(nblocks), dim3(256), 0, st, dact, pre, dpre,
+                       dbias ? ws : nullptr, rows, N, ld, mode, cqp);
+    T4R_LAUNCH_CHECK();
+    if (dbias) return t4r_reduce_partials_launch(st, ws, nblocks, dbias, N, 1, nullptr, 0, 0, nullptr, 0, 0);
+    return 0;
+}
+
+// ws: t4r_colreduce_ws_floats(rows, N) floats (only needed when dbias != NULL)
 extern "C" int t4r_act_bwd_bias(void* stream, const float* dact, const float* pre, float* dpre,
-                                float* dbias, long rows, int N, int mode) {
-    if (rows <= 0) return 0;
-    const int rpb = 16;
-    dim3 grid((unsigned)((rows + rpb - 1) / rpb));
-    hipLaunchKernelGGL(act_bwd_bias_kernel, grid, dim3(256), 0, (hipStream_t)stream, dact, pre, dpre,
-                       dbias, rows, N, rpb, mode);
-    T4R_LAUNCH_CHECK();
-    return 0;
+                                float* dbias, float* ws, long rows, int N, int mode) {
+    T4R_CHECK_ARG(mode == 0 || mode == 1, "act_bwd_bias: mode 0 (gelu) or 1 (relu)");
+    return colred_launch((hipStream_t)stream, dact, pre, dpre, dbias, ws, rows, N, N, mode);
 }
 
-// column sums: out[N] += sum_rows x[rows, N]   (bias gradients)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x,
-                                                      float* __restrict__ out, long rows, int N,
-                                                      long ld, int rows_per_block) {
-    const long r0 = (long)blockIdx.x * rows_per_block;
-    const long r1 = min(rows, r0 + rows_per_block);
-    for (int c = threadIdx.x; c < N; c += 256) {
-        float acc = 0.f;
-        for (long r = r0; r < r1; ++r) acc += x[r * ld + c];
-        atomicAdd(out + c, acc);
-    }
-}
-
-extern "C" int t4r_colsum(void* stream, const float* x, float* out, long rows, int N, long ld) {
-    if (rows <= 0) return 0;
-    const int rpb = 32;
-    dim3 grid((unsigned)((rows + rpb - 1) / rpb));
-    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, out, rows, N, ld, rpb);
-    T4R_LAUNCH_CHECK();
-    return 0;
+// out[N] += sum_rows x[rows, N]   (bias gradients).  ws: t4r_colreduce_ws_floats(rows, N)
+extern "C" int t4r_colsum(void* stream, const float* x, float* out, float* ws, long rows, int N, long ld) {
+    return colred_launch((hipStream_t)stream, x, nullptr, nullptr, out, ws, rows, N, ld, 2);
 }
 
 // ---------------------------------------------------------------- fused Adam over a flat buffer

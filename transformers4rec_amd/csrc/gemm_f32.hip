@@ -21,6 +21,7 @@
 // this is how every weight gradient (K = tokens) and the head's dX (K = vocabulary) get
 // enough workgroups to fill 256 CUs.
 #include "t4r_common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -249,12 +250,17 @@ template <bool TA, bool TB>
 static int launch_layout(GemmParams& p, int batch, int splitk_req, hipStream_t stream) {
     // tile choice: prefer 128x128; drop to 64-wide tiles when the grid would not fill 256 CUs
     auto nblk = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * batch; };
-    int bm = 128, bn = 128;
-    if (p.N <= 64) bn = 64;
-    if (p.M <= 64) bm = 64;
-    if (nblk(bm, bn) < 384 && bm == 128) bm = 64;
-    if (nblk(bm, bn) < 384 && bn == 128) bn = 64;
-    constexpr int BK = 32;
+    // Measured on MI355X (tools/gemm_bench.py, profiles/r01_b_gemm_tile_sweep.txt): on every shape
+    // of this path the 64x64x16 tile (8 waves/SIMD resident) beats the 128-wide tiles -- the
+    // kernel is latency- not LDS-bound, so more workgroups in flight win (head dW 47 -> 79 TF/s).
+    int bm = 64, bn = 64;
+    static int tile_sel = -1;
+    if (tile_sel < 0) { const char* e = getenv("T4R_GEMM_TILE"); tile_sel = e ? atoi(e) : 0; }
+    if (tile_sel == 1) { bm = 64; bn = 128; } else if (tile_sel == 2) { bm = 128; bn = 64; }
+    else if (tile_sel == 3) { bm = 64; bn = 64; } else if (tile_sel == 4) { bm = 128; bn = 128; }
+    static int bk_sel = -1;
+    if (bk_sel < 0) { const char* e = getenv("T4R_GEMM_BK"); bk_sel = e ? atoi(e) : 16; }
+    const int BK = bk_sel;
     int splitk = splitk_req;
     if (splitk_req == 0) {  // auto: only when the caller allows atomics (accumulating outputs)
         splitk = 1;
@@ -272,10 +278,16 @@ static int launch_layout(GemmParams& p, int batch, int splitk_req, hipStream_t s
                 (void)hipMemset2DAsync(p.C + b * p.sC, p.ldc * sizeof(float), 0, p.N * sizeof(float), p.M, stream);
         }
     }
-    if (bm == 128 && bn == 128) return launch_cfg<128, 128, BK, TA, TB>(p, batch, stream);
-    if (bm == 64 && bn == 128) return launch_cfg<64, 128, BK, TA, TB>(p, batch, stream);
-    if (bm == 128 && bn == 64) return launch_cfg<128, 64, BK, TA, TB>(p, batch, stream);
-    return launch_cfg<64, 64, BK, TA, TB>(p, batch, stream);
+    if (BK == 16) {
+        if (bm == 128 && bn == 128) return launch_cfg<128, 128, 16, TA, TB>(p, batch, stream);
+        if (bm == 64 && bn == 128) return launch_cfg<64, 128, 16, TA, TB>(p, batch, stream);
+        if (bm == 128 && bn == 64) return launch_cfg<128, 64, 16, TA, TB>(p, batch, stream);
+        return launch_cfg<64, 64, 16, TA, TB>(p, batch, stream);
+    }
+    if (bm == 128 && bn == 128) return launch_cfg<128, 128, 32, TA, TB>(p, batch, stream);
+    if (bm == 64 && bn == 128) return launch_cfg<64, 128, 32, TA, TB>(p, batch, stream);
+    if (bm == 128 && bn == 64) return launch_cfg<128, 64, 32, TA, TB>(p, batch, stream);
+    return launch_cfg<64, 64, 32, TA, TB>(p, batch, stream);
 }
 
 // Internal C++ entry used by the composite (layer / head) launchers.

@@ -275,21 +275,8 @@ __global__ __launch_bounds__(512) void xlnet_attn_bwd_kernel(
     for (int i = tid; i < 2 * D; i += nthr) mypart[2 * L * D + i] = dRW[i];
 }
 
-// sums the per-block partials: dkr[2L*D] = sum_blocks ; d_rw[D] += ; d_rr[D] +=
-__global__ __launch_bounds__(256) void xlnet_attn_bwd_reduce_kernel(const float* __restrict__ part,
-                                                                     int nblocks, int n_kr, int D,
-                                                                     float* __restrict__ dkr,
-                                                                     float* __restrict__ d_rw,
-                                                                     float* __restrict__ d_rr) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int total = n_kr + 2 * D;
-    if (i >= total) return;
-    float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += part[(long)b * total + i];
-    if (i < n_kr) dkr[i] = s;
-    else if (i < n_kr + D) d_rw[i - n_kr] += s;
-    else d_rr[i - n_kr - D] += s;
-}
+int t4r_reduce_partials_launch(hipStream_t st, const float* part, int nblocks, float* o0, int n0, int a0,
+                               float* o1, int n1, int a1, float* o2, int n2, int a2);
 
 static size_t attn_fwd_smem(int L, int D) { return (size_t)(4 * L) * (D + ATT_PAD) * sizeof(float); }
 static size_t attn_bwd_smem(int L, int D, int n) {
@@ -358,11 +345,9 @@ static int attn_bwd_launch(hipStream_t st, const float* q, const float* k, const
     const int nblocks = t4r_xlnet_attn_bwd_blocks(B);
     hipLaunchKernelGGL(xlnet_attn_bwd_kernel<DH>, dim3(nblocks, hg), dim3(64 * waves), smem, st, q, k, v, kr,
                        rw, rr, out, lse, dout, dq, dk, dv, part, B, L, n_head, scale);
-    const int total = 2 * L * D + 2 * D;
-    hipLaunchKernelGGL(xlnet_attn_bwd_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, part,
-                       nblocks * hg, 2 * L * D, D, dkr, d_rw, d_rr);
     T4R_LAUNCH_CHECK();
-    return 0;
+    // d k_r overwritten, bias gradients accumulated
+    return t4r_reduce_partials_launch(st, part, nblocks * hg, dkr, 2 * L * D, 0, d_rw, D, 1, d_rr, D, 1);
 }
 
 // d_rw / d_rr are ACCUMULATED into (parameter gradients); dq/dk/dv/dk_r are overwritten.

@@ -23,9 +23,10 @@ extern "C" {
 int t4r_add_layernorm_fwd(void*, const float*, const float*, const float*, const float*, float*,
                           float*, float*, int, int, float);
 int t4r_add_layernorm_bwd(void*, const float*, const float*, const float*, const float*,
-                          const float*, const float*, float*, float*, float*, int, int, int);
-int t4r_act_bwd_bias(void*, const float*, const float*, float*, float*, long, int, int);
-int t4r_colsum(void*, const float*, float*, long, int, long);
+                          const float*, const float*, float*, float*, float*, float*, int, int, int);
+int t4r_act_bwd_bias(void*, const float*, const float*, float*, float*, float*, long, int, int);
+int t4r_colsum(void*, const float*, float*, float*, long, int, long);
+long t4r_colreduce_ws_floats(long, int);
 int t4r_xlnet_attn_fwd(void*, const float*, const float*, const float*, const float*, const float*,
                        const float*, float*, float*, int, int, int, int);
 int t4r_xlnet_attn_bwd(void*, const float*, const float*, const float*, const float*, const float*,
@@ -76,7 +77,7 @@ extern "C" long t4r_xlnet_layer_ws_floats(int B, int L, int D, int n_head) {
 extern "C" long t4r_xlnet_layer_bwd_ws_floats(int B, int L, int D, int n_head) {
     const long T = (long)B * L;
     return align4(3 * T * D) + align4(T * D) + align4(T * D) + align4(T * 4 * D) + align4(2L * L * D) +
-           align4(t4r_xlnet_attn_bwd_ws_floats(B, L, D, n_head));
+           align4(t4r_xlnet_attn_bwd_ws_floats(B, L, D, n_head)) + align4(t4r_colreduce_ws_floats(T, 4 * D));
 }
 
 #define RUN(call)                \
@@ -143,18 +144,19 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
     float* dff = take(4 * TD);
     float* dkr = take(2L * L * D);
     float* attn_ws = take(t4r_xlnet_attn_bwd_ws_floats(B, L, D, n_head));
+    float* red_ws = take(t4r_colreduce_ws_floats(T, 4 * D));
 
     // LN2: dy = dh_out, x = ffout + h1  ->  dx (= d ffout = residual part of d h1)
     RUN(t4r_add_layernorm_bwd(stream, w.ffout, w.h1, params[P_LN2W], w.mean2, w.rstd2, dh_out, dx,
-                              grads[P_LN2W], grads[P_LN2B], T, D, 0));
+                              grads[P_LN2W], grads[P_LN2B], red_ws, T, D, 0));
     // FF2: ffout = ffact @ w2^T + b2
     RUN(t4r_gemm_launch(st, 0, 0, T, 4 * D, D, 1.f, dx, D, params[P_W2], 4 * D, dff, 4 * D, nullptr,
                         EPI_NONE, nullptr, 0, 1, 0, 1, 0, 0, 0));
     RUN(t4r_gemm_launch(st, 1, 0, D, 4 * D, T, 1.f, dx, D, w.ffact, 4 * D, grads[P_W2], 4 * D, nullptr,
                         EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0));
-    RUN(t4r_colsum(stream, dx, grads[P_B2], T, D, D));
+    RUN(t4r_colsum(stream, dx, grads[P_B2], red_ws, T, D, D));
     // GELU + bias1
-    RUN(t4r_act_bwd_bias(stream, dff, w.ffpre, dff, grads[P_B1], T, 4 * D, 0));
+    RUN(t4r_act_bwd_bias(stream, dff, w.ffpre, dff, grads[P_B1], red_ws, T, 4 * D, 0));
     // FF1: ffpre = h1 @ w1^T + b1 ;  d h1 = dx (residual) + dff @ w1
     RUN(t4r_gemm_launch(st, 0, 0, T, D, 4 * D, 1.f, dff, 4 * D, params[P_W1], D, dx, D, nullptr,
                         EPI_NONE, nullptr, 0, 1, 1, 1, 0, 0, 0));
@@ -162,7 +164,7 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
                         EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0));
     // LN1: dy = d h1 (dx), x = ao + h  ->  dh_in (= d ao = residual part of d h)
     RUN(t4r_add_layernorm_bwd(stream, w.ao, h, params[P_LN1W], w.mean1, w.rstd1, dx, dh_in,
-                              grads[P_LN1W], grads[P_LN1B], T, D, 0));
+                              grads[P_LN1W], grads[P_LN1B], red_ws, T, D, 0));
     // O projection: ao = av @ o^T
     RUN(t4r_gemm_launch(st, 0, 0, T, D, D, 1.f, dh_in, D, params[P_O], D, dav, D, nullptr, EPI_NONE,
                         nullptr, 0, 1, 0, 1, 0, 0, 0));

@@ -77,20 +77,27 @@ def add_layernorm_bwd(a, b, gamma, mean, rstd, dy, dgamma, dbeta, dx=None, accum
     rows, D = a.shape
     if dx is None:
         dx = torch.empty_like(a)
+    ws = _colred_ws(rows, 2 * D, a.device)
     call("t4r_add_layernorm_bwd", _stream(), _chk(a), _p(b), _chk(gamma), _chk(mean), _chk(rstd),
-         _chk(dy), dx.data_ptr(), _p(dgamma), _p(dbeta), rows, D, int(accumulate_dx))
+         _chk(dy), dx.data_ptr(), _p(dgamma), _p(dbeta), ws.data_ptr(), rows, D, int(accumulate_dx))
     return dx
+
+
+def _colred_ws(rows, ncols, device):
+    return torch.empty(_lib.load().t4r_colreduce_ws_floats(rows, ncols), device=device, dtype=torch.float32)
 
 
 def act_bwd_bias(dact, pre, dbias, mode, out=None):
     rows, N = dact.shape
     out = dact if out is None else out
-    call("t4r_act_bwd_bias", _stream(), _chk(dact), _chk(pre), out.data_ptr(), _p(dbias), rows, N, mode)
+    ws = None if dbias is None else _colred_ws(rows, N, dact.device)
+    call("t4r_act_bwd_bias", _stream(), _chk(dact), _chk(pre), out.data_ptr(), _p(dbias), _p(ws), rows, N, mode)
     return out
 
 
 def colsum_(x, out):
-    call("t4r_colsum", _stream(), _chk(x), _chk(out), x.shape[0], x.shape[1], x.stride(0))
+    ws = _colred_ws(x.shape[0], x.shape[1], x.device)
+    call("t4r_colsum", _stream(), _chk(x), _chk(out), ws.data_ptr(), x.shape[0], x.shape[1], x.stride(0))
     return out
 
 

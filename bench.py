@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--dropout", type=float, default=0.0)
+    ap.add_argument("--dropout", type=float, default=0.3)  # XLNetConfig.build default (config/transformer.py:442)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

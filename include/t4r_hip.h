@@ -124,48 +124,70 @@ int t4r_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, floa
 /* residual + LayerNorm:  y = LN(a + b) (b may be NULL).
  * replaces: HF :142-152, :297-305 (post-LN), tabular/transformations.py:128-132.
  * backward recomputes x = a + b; dgamma/dbeta accumulated; dx overwritten (or += if accumulate_dx). */
+/* Dropout (torch.nn.Dropout semantics) is fused where the reference applies it.  A keep decision is
+ * a pure function of (seed, ctr_hi, element index): Philox4x32-10(key = seed, counter =
+ * (index >> 2, ctr_hi)), component index & 3; kept values are scaled by 1/(1-p).  Nothing is stored:
+ * backward kernels recompute the mask.  ctr_hi = t4r_dropout_ctr_hi(step offset, layer, site).
+ * t4r_dropout: out = x[i % n_src] * mask(i)/(1-p) for i < n (n_src < n broadcasts x, e.g. pos_emb over
+ * the batch); mask_out (uint8) optionally exports the keep mask; out may be NULL. */
+unsigned long long t4r_dropout_ctr_hi(unsigned long long offset, int layer, int site);
+int t4r_dropout(void* stream, const float* x, float* out, unsigned char* mask_out, long n, long n_src,
+                float p, unsigned long long seed, unsigned long long ctr_hi);
+/* y = LN(dropout(a) + b); mask index row*D + col.  drop_p = 0 disables. */
 int t4r_add_layernorm_fwd(void* stream, const float* a, const float* b, const float* gamma,
                           const float* beta, float* y, float* mean, float* rstd, int rows, int D,
-                          float eps);
+                          float eps, float drop_p, unsigned long long seed, unsigned long long ctr_hi);
+/* dx = d loss / d b ; dxa = d loss / d a (= dx * mask/(1-p); may be NULL when drop_p == 0) */
 int t4r_add_layernorm_bwd(void* stream, const float* a, const float* b, const float* gamma,
-                          const float* mean, const float* rstd, const float* dy, float* dx,
-                          float* dgamma, float* dbeta, float* ws, int rows, int D, int accumulate_dx);
+                          const float* mean, const float* rstd, const float* dy, float* dx, float* dxa,
+                          float* dgamma, float* dbeta, float* ws, int rows, int D, int accumulate_dx,
+                          float drop_p, unsigned long long seed, unsigned long long ctr_hi);
 /* Batch-reduced gradients are summed in two deterministic stages through a caller workspace of
  * t4r_colreduce_ws_floats(rows, ncols) floats (ncols = 2*D for LayerNorm backward, N otherwise). */
 long t4r_colreduce_ws_floats(long rows, int ncols);
 /* activation backward + bias gradient: mode 0 GELU(erf) on saved pre-activation, 1 ReLU on saved
  * output; dbias (accumulated) may be NULL (then ws may be NULL).  N % 4 == 0. */
 int t4r_act_bwd_bias(void* stream, const float* dact, const float* pre, float* dpre, float* dbias,
-                     float* ws, long rows, int N, int mode);
+                     float* ws, long rows, int N, int mode, float drop_p, unsigned long long seed,
+                     unsigned long long ctr_hi);
 int t4r_colsum(void* stream, const float* x, float* out, float* ws, long rows, int N, long ld);
 
 /* ----------------------------------------------------------------------------------------
  * a15  XLNet relative attention core and the whole layer
  * replaces: HF XLNetRelativeAttention.rel_attn_core :95-140 (+ rel_shift_bnij :81-93),
  *           XLNetLayer.forward :308-353 as configured by config/transformer.py:432-482.
- * q,k,v,out [B*L, n_head*d_head]; k_r [2L, D] = pos_emb @ r; lse [B,n,L]; L <= 64.
- * backward: d_r_w_bias / d_r_r_bias accumulated, the rest overwritten. */
+ * q,k,v,out [B*L, n_head*d_head]; k_r [2L, D] = pos_emb @ r (kr_per_batch: [B,2L,D], one set per
+ * session, used when pos_emb dropout is on); lse [B,n,L]; L <= 64.  drop_p: attention-probability
+ * dropout (HF :132), mask index ((b*n+h)*L+i)*L+j.
+ * backward: d_r_w_bias / d_r_r_bias accumulated, the rest overwritten (dk_r has k_r's shape). */
 int t4r_xlnet_attn_fwd(void* stream, const float* q, const float* k, const float* v, const float* k_r,
                        const float* r_w_bias, const float* r_r_bias, float* out, float* lse, int B,
-                       int L, int n_head, int d_head);
+                       int L, int n_head, int d_head, int kr_per_batch, float drop_p,
+                       unsigned long long seed, unsigned long long ctr_hi);
 long t4r_xlnet_attn_bwd_ws_floats(int B, int L, int D, int n_head);
 int t4r_xlnet_attn_bwd(void* stream, const float* q, const float* k, const float* v, const float* k_r,
                        const float* r_w_bias, const float* r_r_bias, const float* out,
                        const float* lse, const float* dout, float* dq, float* dk, float* dv,
                        float* dk_r, float* d_r_w_bias, float* d_r_r_bias, float* workspace, int B,
-                       int L, int n_head, int d_head);
+                       int L, int n_head, int d_head, int kr_per_batch, float drop_p,
+                       unsigned long long seed, unsigned long long ctr_hi);
 /* params / grads: host arrays of 15 device pointers in the order
  *   q, k, v, o, r [D,n,dh] ; r_w_bias, r_r_bias [n,dh] ; rel_attn.layer_norm.{weight,bias} ;
  *   ff.layer_1.{weight [4D,D], bias} ; ff.layer_2.{weight [D,4D], bias} ; ff.layer_norm.{weight,bias}
  * (state_dict names of SURVEY 8(b)).  pos_emb [2L, D] = HF relative_positional_encoding :940-976.
- * ws: t4r_xlnet_layer_ws_floats() floats saved by fwd for bwd; bws: scratch for bwd. */
-long t4r_xlnet_layer_ws_floats(int B, int L, int D, int n_head);
-long t4r_xlnet_layer_bwd_ws_floats(int B, int L, int D, int n_head);
+ * ws: t4r_xlnet_layer_ws_floats() floats saved by fwd for bwd; bws: scratch for bwd.
+ * drop_p > 0 enables the reference's training-mode dropouts of the layer (HF :132,:147,:301,:303 and
+ * the per-session pos_emb dropout :1143) with masks keyed by (seed, offset = step counter, layer_idx);
+ * the workspace queries take dropout = (drop_p > 0). */
+long t4r_xlnet_layer_ws_floats(int B, int L, int D, int n_head, int dropout);
+long t4r_xlnet_layer_bwd_ws_floats(int B, int L, int D, int n_head, int dropout);
 int t4r_xlnet_layer_fwd(void* stream, const float* h, const float* pos_emb, const float* const* params,
-                        float* ws, float* h_out, int B, int L, int D, int n_head, float ln_eps);
+                        float* ws, float* h_out, int B, int L, int D, int n_head, float ln_eps,
+                        float drop_p, unsigned long long seed, unsigned long long offset, int layer_idx);
 int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* pos_emb, const float* const* params,
                         float* const* grads, const float* ws, float* bws, const float* dh_out,
-                        float* dh_in, int B, int L, int D, int n_head, float ln_eps);
+                        float* dh_in, int B, int L, int D, int n_head, float ln_eps, float drop_p,
+                        unsigned long long seed, unsigned long long offset, int layer_idx);
 
 /* ----------------------------------------------------------------------------------------
  * a18-a21  next-item head

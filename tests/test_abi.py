@@ -26,17 +26,19 @@ def test_no_torch_types_in_the_abi():
 
 def test_workspace_size_queries_are_pure():
     lib = _lib.load()
-    n = lib.t4r_xlnet_layer_ws_floats(1024, 20, 128, 4)
+    n = lib.t4r_xlnet_layer_ws_floats(1024, 20, 128, 4, 0)
     T = 1024 * 20
     assert n >= T * 128 * (3 + 1 + 1 + 1 + 4 + 4 + 1)
-    assert lib.t4r_xlnet_layer_bwd_ws_floats(8, 20, 64, 4) > 0
+    assert lib.t4r_xlnet_layer_ws_floats(1024, 20, 128, 4, 1) == n + (1024 - 1) * 2 * 20 * 128
+    assert lib.t4r_xlnet_layer_bwd_ws_floats(8, 20, 64, 4, 0) > 0
+    assert lib.t4r_dropout_ctr_hi(3, 2, 4) == (3 << 16) | (2 << 8) | 4
     assert lib.t4r_xlnet_attn_bwd_ws_floats(8, 20, 64, 4) == 8 * (2 * 20 * 64 + 2 * 64)
 
 
 def test_argument_errors_are_reported_not_crashes():
     lib = _lib.load()
     # d_head 7 is unsupported: must come back as rc != 0 with a message, before any launch
-    rc = lib.t4r_xlnet_attn_fwd(None, None, None, None, None, None, None, None, None, 1, 20, 4, 7)
+    rc = lib.t4r_xlnet_attn_fwd(None, None, None, None, None, None, None, None, None, 1, 20, 4, 7, 0, 0.0, 0, 0)
     assert rc != 0 and b"d_head" in lib.t4r_last_error()
     rc = lib.t4r_mask_targets(None, None, 4, 0, 0, 0, None, None, None, 0.15, 0, 0, None, None, None)
     assert rc != 0 and b"L must be" in lib.t4r_last_error()

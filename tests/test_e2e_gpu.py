@@ -240,3 +240,41 @@ def test_three_adam_steps_match_oracle():
     ra = model.transformer_block.transformer.layer[0].rel_attn
     assert ra.k.data_ptr() == ra.q.data_ptr() + 4 * ra.q.numel()
     assert ra.v.data_ptr() == ra.k.data_ptr() + 4 * ra.k.numel()
+
+
+def test_training_mode_dropout_end_to_end():
+    """dropout 0.3 (the reference default) active only in module.train(); deterministic in
+    (seed, step); eval mode identical to dropout 0."""
+    import transformers4rec_amd as tr
+
+    torch.manual_seed(0)
+    B, L, V, D = 64, 20, 3000, 64
+    schema = tr.session_schema(V - 1, L)
+    inputs = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=L, masking="mlm", embedding_dim_default=D)
+    cfg = tr.XLNetConfig.build(D, 4, 2, total_seq_length=L)        # dropout=0.3 default
+    assert cfg.dropout == 0.3
+    model = cfg.to_torch_model(inputs, tr.NextItemPredictionTask(weight_tying=True)).to(DEV)
+    x = {"item_id": tr.random_data_from_schema(schema, B, L, seed=5)["item_id"].to(DEV)}
+    xl = model.transformer_block.transformer
+
+    def run(train):
+        model.train(train)
+        model.input_features.masking._rng_offset = 0
+        xl._drop_offset = 0
+        model.zero_grad(set_to_none=True)
+        out = model(x, training=True)
+        out["loss"].backward()
+        return out["loss"].detach().clone(), model.input_features.item_embedding_table.weight.grad.clone()
+
+    l1, g1 = run(True)
+    l2, g2 = run(True)
+    assert torch.equal(l1, l2) and torch.allclose(g1, g2, rtol=1e-4, atol=1e-6)   # same (seed, step) -> same masks (atomics reorder only)
+    l0, g0 = run(False)
+    assert not torch.equal(l0, l1) and torch.isfinite(l1) and torch.isfinite(g1).all()
+    xl._drop_offset = 0
+    model.train(True)
+    model.input_features.masking._rng_offset = 0
+    la = model(x, training=True)["loss"]
+    lb = model(x, training=True)["loss"]      # next step: new masks
+    assert not torch.equal(la, lb)
+    assert abs(float(l1) - float(l0)) < 0.5

@@ -488,3 +488,127 @@ def test_topk(ops, N, V, k):
     v, i = ops.topk(cu(s), k)
     assert torch.equal(v.cpu(), ref_v)
     assert torch.equal(i.cpu(), ref_i)
+
+
+# ------------------------------------------------------------------------------------ dropout
+def _mask(ops, shape, p, seed, ctr):
+    n = int(np.prod(shape))
+    _, m = ops.dropout(torch.ones(1, device=DEV), p, seed, ctr, n_total=n, want_mask=True)
+    return m.view(shape).float().cpu()
+
+
+def test_dropout_mask_properties(ops):
+    n, p = 1 << 20, 0.3
+    x = torch.randn(n, device=DEV)
+    out, m = ops.dropout(x, p, 7, ops.dropout_ctr_hi(1, 0, 3), want_mask=True)
+    keep = m.float().mean().item()
+    assert abs(keep - 0.7) < 3e-3
+    close(out, x * m / 0.7, atol=1e-6)
+    out2 = ops.dropout(x, p, 7, ops.dropout_ctr_hi(1, 0, 3))
+    assert torch.equal(out, out2)                                   # pure function of (seed, ctr, idx)
+    for other in ((8, ops.dropout_ctr_hi(1, 0, 3)), (7, ops.dropout_ctr_hi(2, 0, 3)),
+                  (7, ops.dropout_ctr_hi(1, 1, 3)), (7, ops.dropout_ctr_hi(1, 0, 4))):
+        _, m2 = ops.dropout(x, p, other[0], other[1], want_mask=True)
+        agree = (m2 == m).float().mean().item()
+        assert 0.55 < agree < 0.61                                  # independent masks: 0.7^2 + 0.3^2 = 0.58
+    # broadcast source (pos_emb over the batch): every replica gets its own mask
+    src = torch.randn(640, device=DEV)
+    out, m = ops.dropout(src, p, 1, 5, n_total=640 * 50, want_mask=True)
+    close(out.view(50, 640), src[None] * m.view(50, 640) / 0.7, atol=1e-6)
+    assert not torch.equal(m.view(50, 640)[0], m.view(50, 640)[1])
+    assert torch.equal(ops.dropout(x, 0.0, 1, 1), x)
+
+
+@pytest.mark.parametrize("rows,D", [(50, 128), (33, 64), (7, 512)])
+def test_add_layernorm_dropout_fwd_bwd(ops, rows, D):
+    g = torch.Generator().manual_seed(rows * D)
+    p, seed, ctr = 0.3, 11, ops.dropout_ctr_hi(5, 2, ops.SITE_ATTN_OUT)
+    a, b = torch.randn(rows, D, generator=g), torch.randn(rows, D, generator=g)
+    gam, bet = 1 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    dy = torch.randn(rows, D, generator=g)
+    m = _mask(ops, (rows, D), p, seed, ctr)
+    a_, b_, g_, be_ = (t.clone().requires_grad_() for t in (a, b, gam, bet))
+    ref = O.layer_norm(a_ * m / (1 - p) + b_, g_, be_, 0.03)
+    ref.backward(dy)
+    y, mean, rstd = ops.add_layernorm_fwd(cu(a), cu(b), cu(gam), cu(bet), 0.03, drop=(p, seed, ctr))
+    close(y, ref.detach())
+    dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    dx, dxa = ops.add_layernorm_bwd(cu(a), cu(b), cu(gam), mean, rstd, cu(dy), dg, db, drop=(p, seed, ctr))
+    close(dx, b_.grad, atol=5e-5)
+    close(dxa, a_.grad, atol=5e-5)
+    close(dg, g_.grad, atol=1e-4)
+
+
+def test_act_bwd_dropout(ops):
+    g = torch.Generator().manual_seed(4)
+    rows, N, p, seed, ctr = 70, 256, 0.3, 3, ops.dropout_ctr_hi(9, 1, ops.SITE_FF_ACT)
+    pre = torch.randn(rows, N, generator=g).requires_grad_()
+    dact = torch.randn(rows, N, generator=g)
+    m = _mask(ops, (rows, N), p, seed, ctr)
+    (torch.nn.functional.gelu(pre) * m / (1 - p)).backward(dact)
+    db = torch.zeros(N, device=DEV)
+    out = ops.act_bwd_bias(cu(dact), cu(pre.detach()), db, 0, out=torch.empty(rows, N, device=DEV), drop=(p, seed, ctr))
+    close(out, pre.grad, atol=1e-5)
+    close(db, pre.grad.sum(0), atol=1e-4)
+
+
+@pytest.mark.parametrize("B,L,D,n", [(5, 20, 64, 4), (3, 21, 128, 4), (4, 9, 32, 2)])
+def test_xlnet_attention_dropout_per_session_kr(ops, B, L, D, n):
+    g = torch.Generator().manual_seed(B + L + D)
+    dh = D // n
+    p, seed, ctr = 0.3, 21, ops.dropout_ctr_hi(2, 1, ops.SITE_PROB)
+    q, k, v = (torch.randn(B, L, n, dh, generator=g).requires_grad_() for _ in range(3))
+    kr = torch.randn(B, 2 * L, n, dh, generator=g).requires_grad_()
+    rw, rr = (0.5 * torch.randn(n, dh, generator=g)).requires_grad_(), (0.5 * torch.randn(n, dh, generator=g)).requires_grad_()
+    m = _mask(ops, (B, n, L, L), p, seed, ctr)
+    ac = torch.einsum("bind,bjnd->bnij", q + rw, k)
+    bd_full = torch.einsum("bind,bpnd->bnip", q + rr, kr)
+    idx = torch.arange(L)[None, :] + L - torch.arange(L)[:, None]
+    bd = torch.gather(bd_full, 3, idx[None, None].expand(B, n, L, L))
+    prob = torch.softmax((ac + bd) / dh ** 0.5, 3) * m / (1 - p)
+    ref = torch.einsum("bnij,bjnd->bind", prob, v)
+    dout = torch.randn(B, L, n, dh, generator=g)
+    ref.backward(dout)
+    f2 = lambda t: cu(t.detach().reshape(-1, D))
+    rwd, rrd = cu(rw.detach().reshape(-1)), cu(rr.detach().reshape(-1))
+    out, lse = ops.xlnet_attn_fwd(f2(q), f2(k), f2(v), f2(kr), rwd, rrd, B, L, n, drop=(p, seed, ctr))
+    close(out, ref.detach().reshape(-1, D), atol=3e-5)
+    drw, drr = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    dq, dk, dv, dkr = ops.xlnet_attn_bwd(f2(q), f2(k), f2(v), f2(kr), rwd, rrd, out, lse, f2(dout), drw, drr,
+                                         B, L, n, drop=(p, seed, ctr))
+    close(dq, q.grad.reshape(-1, D), atol=2e-4)
+    close(dk, k.grad.reshape(-1, D), atol=2e-4)
+    close(dv, v.grad.reshape(-1, D), atol=2e-4)
+    close(dkr, kr.grad.reshape(-1, D), atol=2e-4)
+    close(drw, rw.grad.reshape(-1), atol=5e-4)
+    close(drr, rr.grad.reshape(-1), atol=5e-4)
+
+
+@pytest.mark.parametrize("B,L,D,n", [(6, 20, 64, 4), (9, 20, 128, 4)])
+def test_xlnet_layer_dropout_fwd_bwd(ops, B, L, D, n):
+    """whole layer in training mode vs the oracle fed with the SAME masks (extracted per site)."""
+    g = torch.Generator().manual_seed(B * 3 + D)
+    p_drop, seed, offset, layer = 0.3, 99, 7, 2
+    prm = _layer_params(g, D, n)
+    pr = {k: v.clone().requires_grad_() for k, v in prm.items()}
+    h = torch.randn(B, L, D, generator=g)
+    hr = h.clone().requires_grad_()
+    C = lambda site: ops.dropout_ctr_hi(offset, layer, site)
+    masks = dict(pos=_mask(ops, (B, 2 * L, D), p_drop, seed, C(ops.SITE_POS)),
+                 prob=_mask(ops, (B, n, L, L), p_drop, seed, C(ops.SITE_PROB)),
+                 attn_out=_mask(ops, (B, L, D), p_drop, seed, C(ops.SITE_ATTN_OUT)),
+                 ff_act=_mask(ops, (B, L, 4 * D), p_drop, seed, C(ops.SITE_FF_ACT)),
+                 ff_out=_mask(ops, (B, L, D), p_drop, seed, C(ops.SITE_FF_OUT)))
+    ref = O.xlnet_layer_dropout(hr, pr, n, 0.03, masks, p_drop)
+    dout = torch.randn(B, L, D, generator=g)
+    ref.backward(dout)
+    pos = cu(O.xlnet_pos_emb(L, D))
+    params = [cu(prm[k]) for k in ORDER]
+    kw = dict(drop_p=p_drop, seed=seed, offset=offset, layer_idx=layer)
+    out, ws = ops.xlnet_layer_fwd(cu(h).view(B * L, D), pos, params, B, L, n, 0.03, **kw)
+    close(out, ref.detach().reshape(B * L, D), atol=5e-5)
+    grads = [torch.zeros_like(t) for t in params]
+    dh = ops.xlnet_layer_bwd(cu(h).view(B * L, D), pos, params, grads, ws, cu(dout).view(B * L, D), B, L, n, 0.03, **kw)
+    close(dh, hr.grad.reshape(B * L, D), rtol=1e-4, atol=3e-4)
+    for k, gt in zip(ORDER, grads):
+        close(gt.reshape(-1), pr[k].grad.reshape(-1), rtol=1e-4, atol=8e-4, msg=lambda mm, k=k: f"{k}: {mm}")

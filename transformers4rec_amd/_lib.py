@@ -34,18 +34,20 @@ _SIGS = {
     "t4r_scatter_rows_add": ("i", "ppppii"),
     "t4r_last_positions": ("i", "ppiiiilp"),
     "t4r_gemm_f32": ("i", "piiiiif" + "plplpl" + "pipl" + "iii" + "lll"),
-    "t4r_add_layernorm_fwd": ("i", "pppppppp" + "iif"),
-    "t4r_add_layernorm_bwd": ("i", "ppppppppppp" + "iii"),
+    "t4r_dropout_ctr_hi": ("Q", "Qii"),
+    "t4r_dropout": ("i", "pppp" + "llfQQ"),
+    "t4r_add_layernorm_fwd": ("i", "pppppppp" + "iif" + "fQQ"),
+    "t4r_add_layernorm_bwd": ("i", "pppppppppppp" + "iii" + "fQQ"),
     "t4r_colreduce_ws_floats": ("l", "li"),
-    "t4r_act_bwd_bias": ("i", "pppppp" + "lii"),
+    "t4r_act_bwd_bias": ("i", "pppppp" + "lii" + "fQQ"),
     "t4r_colsum": ("i", "pppp" + "lil"),
-    "t4r_xlnet_attn_fwd": ("i", "ppppppppp" + "iiii"),
+    "t4r_xlnet_attn_fwd": ("i", "ppppppppp" + "iiii" + "ifQQ"),
     "t4r_xlnet_attn_bwd_ws_floats": ("l", "iiii"),
-    "t4r_xlnet_attn_bwd": ("i", "p" * 17 + "iiii"),
-    "t4r_xlnet_layer_ws_floats": ("l", "iiii"),
-    "t4r_xlnet_layer_bwd_ws_floats": ("l", "iiii"),
-    "t4r_xlnet_layer_fwd": ("i", "pppppp" + "iiiif"),
-    "t4r_xlnet_layer_bwd": ("i", "ppppppppp" + "iiiif"),
+    "t4r_xlnet_attn_bwd": ("i", "p" * 17 + "iiii" + "ifQQ"),
+    "t4r_xlnet_layer_ws_floats": ("l", "iiiii"),
+    "t4r_xlnet_layer_bwd_ws_floats": ("l", "iiiii"),
+    "t4r_xlnet_layer_fwd": ("i", "pppppp" + "iiiif" + "fQQi"),
+    "t4r_xlnet_layer_bwd": ("i", "ppppppppp" + "iiiif" + "fQQi"),
     "t4r_softmax_ce_fwd": ("i", "pppppp" + "iilf"),
     "t4r_softmax_ce_bwd": ("i", "pppppp" + "iilf"),
     "t4r_sampled_logits_fwd": ("i", "ppppppp" + "iiif"),

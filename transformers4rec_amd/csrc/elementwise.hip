@@ -21,7 +21,7 @@ template <int VEC, int NC>
 __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(
     const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ y, float* __restrict__ mean,
-    float* __restrict__ rstd, int rows, int D, float eps) {
+    float* __restrict__ rstd, int rows, int D, float eps, DropCfg drop) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -34,6 +34,10 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(
         const int c0 = (c * 64 + lane) * VEC;
         if (c0 < D) {
             v[c] = *reinterpret_cast<const FV<VEC>*>(ar + c0);
+            if (drop.p > 0.f) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[c].v[e] *= drop_scale(drop, (unsigned long long)row * D + c0 + e);
+            }
             if (br) {
                 const FV<VEC> t = *reinterpret_cast<const FV<VEC>*>(br + c0);
 #pragma unroll
@@ -103,14 +107,17 @@ static bool ln_pick(int D, int* vec, int* nc) {
 
 extern "C" int t4r_add_layernorm_fwd(void* stream, const float* a, const float* b,
                                      const float* gamma, const float* beta, float* y, float* mean,
-                                     float* rstd, int rows, int D, float eps) {
+                                     float* rstd, int rows, int D, float eps, float drop_p,
+                                     unsigned long long seed, unsigned long long ctr_hi) {
     if (rows <= 0) return 0;
     int vec, nc;
     T4R_CHECK_ARG(D > 0 && ln_pick(D, &vec, &nc), "layernorm: D out of range");
+    T4R_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "layernorm: dropout p in [0, 1)");
     hipStream_t st = (hipStream_t)stream;
     const int wpb = 4;
     dim3 grid((rows + wpb - 1) / wpb), block(64 * wpb);
-    LN_DISPATCH(add_layernorm_fwd_kernel, a, b, gamma, beta, y, mean, rstd, rows, D, eps);
+    const DropCfg drop = make_drop(drop_p, seed, ctr_hi);
+    LN_DISPATCH(add_layernorm_fwd_kernel, a, b, gamma, beta, y, mean, rstd, rows, D, eps, drop);
     T4R_LAUNCH_CHECK();
     return 0;
 }
@@ -175,7 +182,8 @@ template <int VEC, int NC>
 __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(
     const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ dy,
-    float* __restrict__ dx, float* __restrict__ part, int rows, int D, int accumulate_dx) {
+    float* __restrict__ dx, float* __restrict__ dxa, float* __restrict__ part, int rows, int D,
+    int accumulate_dx, DropCfg drop) {
     extern __shared__ float sm[];   // [4][2*D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     FV<VEC> pg[NC], pb[NC], gam[NC];
@@ -193,13 +201,20 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(
         const float* br = b ? b + (long)row * D : nullptr;
         const float* dyr = dy + (long)row * D;
         const float mu = mean[row], rs = rstd[row];
-        FV<VEC> xh[NC], g[NC];
+        FV<VEC> xh[NC], g[NC], ds[NC];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int c0 = (c * 64 + lane) * VEC;
             if (c0 < D) {
                 FV<VEC> x = *reinterpret_cast<const FV<VEC>*>(ar + c0);
+                if (drop.p > 0.f) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        ds[c].v[e] = drop_scale(drop, (unsigned long long)row * D + c0 + e);
+                        x.v[e] *= ds[c].v[e];
+                    }
+                }
                 if (br) {
                     const FV<VEC> t = *reinterpret_cast<const FV<VEC>*>(br + c0);
 #pragma unroll
@@ -234,6 +249,15 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(
                     o.v[e] = accumulate_dx ? o.v[e] + v : v;
                 }
                 *reinterpret_cast<FV<VEC>*>(dxr + c0) = o;
+                if (dxa) {   // gradient of the dropped operand `a`
+                    FV<VEC> oa;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const float v = rs * (g[c].v[e] - s1 - xh[c].v[e] * s2);
+                        oa.v[e] = drop.p > 0.f ? v * ds[c].v[e] : v;
+                    }
+                    *reinterpret_cast<FV<VEC>*>(dxa + (long)row * D + c0) = oa;
+                }
             }
         }
     }
@@ -252,11 +276,13 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(
         prow[i] = sm[i] + sm[2 * D + i] + sm[4 * D + i] + sm[6 * D + i];
 }
 
-// ws: t4r_colreduce_ws_floats(rows, 2*D) floats
+// ws: t4r_colreduce_ws_floats(rows, 2*D) floats.  With dropout (x = drop(a) + b): dx = d loss/d b
+// (the residual operand) and dxa = d loss/d a = dx * mask/(1-p); dxa may be NULL when p == 0.
 extern "C" int t4r_add_layernorm_bwd(void* stream, const float* a, const float* b,
                                      const float* gamma, const float* mean, const float* rstd,
-                                     const float* dy, float* dx, float* dgamma, float* dbeta,
-                                     float* ws, int rows, int D, int accumulate_dx) {
+                                     const float* dy, float* dx, float* dxa, float* dgamma,
+                                     float* dbeta, float* ws, int rows, int D, int accumulate_dx,
+                                     float drop_p, unsigned long long seed, unsigned long long ctr_hi) {
     if (rows <= 0) return 0;
     int vec, nc;
     T4R_CHECK_ARG(D > 0 && ln_pick(D, &vec, &nc), "layernorm: D out of range");
@@ -265,8 +291,9 @@ extern "C" int t4r_add_layernorm_bwd(void* stream, const float* a, const float* 
     const int nblocks = (rows + T4R_COLRED_ROWS - 1) / T4R_COLRED_ROWS;
     dim3 grid(nblocks), block(256);
     const size_t smem = (size_t)8 * D * sizeof(float);
-#undef LN_DISPATCH_SMEM
-#define LN_BWD(V, N) hipLaunchKernelGGL((add_layernorm_bwd_kernel<V, N>), grid, block, smem, st, a, b, gamma, mean, rstd, dy, dx, ws, rows, D, accumulate_dx)
+    T4R_CHECK_ARG(drop_p == 0.f || dxa, "layernorm_bwd: dxa required with dropout");
+    const DropCfg drop = make_drop(drop_p, seed, ctr_hi);
+#define LN_BWD(V, N) hipLaunchKernelGGL((add_layernorm_bwd_kernel<V, N>), grid, block, smem, st, a, b, gamma, mean, rstd, dy, dx, dxa, ws, rows, D, accumulate_dx, drop)
     if (vec == 4 && nc == 1) LN_BWD(4, 1);
     else if (vec == 4 && nc == 2) LN_BWD(4, 2);
     else if (vec == 4 && nc == 4) LN_BWD(4, 4);
@@ -289,7 +316,7 @@ extern "C" int t4r_add_layernorm_bwd(void* stream, const float* a, const float* 
 // (row group g, float4 column cq) so that every global access is a 16-byte coalesced access.
 __global__ __launch_bounds__(256) void act_bwd_bias_kernel(
     const float* __restrict__ dact, const float* __restrict__ pre, float* __restrict__ dpre,
-    float* __restrict__ part, long rows, int N, long ld, int mode, int cqp) {
+    float* __restrict__ part, long rows, int N, long ld, int mode, int cqp, DropCfg drop) {
     __shared__ float4 sm[256];
     const int NQ = N >> 2;
     const int ng = 256 / cqp;
@@ -303,6 +330,10 @@ __global__ __launch_bounds__(256) void act_bwd_bias_kernel(
             for (long r = r0 + g; r < r1; r += ng) {
                 const long i = r * ld + 4 * cq;
                 float4 d = *reinterpret_cast<const float4*>(dact + i);
+                if (drop.p > 0.f) {   // act_out = drop(act(pre)): d act = d out * mask/(1-p)
+                    const float4 m = drop_scale4(drop, (unsigned long long)r * N + 4 * cq);
+                    d.x *= m.x; d.y *= m.y; d.z *= m.z; d.w *= m.w;
+                }
                 if (mode != 2) {
                     const float4 p = *reinterpret_cast<const float4*>(pre + i);
                     if (mode == 0) {
@@ -333,7 +364,7 @@ __global__ __launch_bounds__(256) void act_bwd_bias_kernel(
 }
 
 static int colred_launch(hipStream_t st, const float* dact, const float* pre, float* dpre, float* dbias,
-                         float* ws, long rows, int N, long ld, int mode) {
+                         float* ws, long rows, int N, long ld, int mode, DropCfg drop) {
     if (rows <= 0) return 0;
     T4R_CHECK_ARG(N % 4 == 0 && ld % 4 == 0, "act_bwd_bias/colsum: N and ld must be multiples of 4");
     T4R_CHECK_ARG(!dbias || ws, "act_bwd_bias/colsum: workspace required");
@@ -341,7 +372,7 @@ static int colred_launch(hipStream_t st, const float* dact, const float* pre, fl
     while (cqp * 2 <= (N >> 2) && cqp < 256) cqp <<= 1;
     const int nblocks = (int)((rows + T4R_COLRED_ROWS - 1) / T4R_COLRED_ROWS);
     hipLaunchKernelGGL(act_bwd_bias_kernel, dim3(nblocks), dim3(256), 0, st, dact, pre, dpre,
-                       dbias ? ws : nullptr, rows, N, ld, mode, cqp);
+                       dbias ? ws : nullptr, rows, N, ld, mode, cqp, drop);
     T4R_LAUNCH_CHECK();
     if (dbias) return t4r_reduce_partials_launch(st, ws, nblocks, dbias, N, 1, nullptr, 0, 0, nullptr, 0, 0);
     return 0;
@@ -349,14 +380,47 @@ static int colred_launch(hipStream_t st, const float* dact, const float* pre, fl
 
 // ws: t4r_colreduce_ws_floats(rows, N) floats (only needed when dbias != NULL)
 extern "C" int t4r_act_bwd_bias(void* stream, const float* dact, const float* pre, float* dpre,
-                                float* dbias, float* ws, long rows, int N, int mode) {
+                                float* dbias, float* ws, long rows, int N, int mode, float drop_p,
+                                unsigned long long seed, unsigned long long ctr_hi) {
     T4R_CHECK_ARG(mode == 0 || mode == 1, "act_bwd_bias: mode 0 (gelu) or 1 (relu)");
-    return colred_launch((hipStream_t)stream, dact, pre, dpre, dbias, ws, rows, N, N, mode);
+    return colred_launch((hipStream_t)stream, dact, pre, dpre, dbias, ws, rows, N, N, mode,
+                         make_drop(drop_p, seed, ctr_hi));
 }
 
 // out[N] += sum_rows x[rows, N]   (bias gradients).  ws: t4r_colreduce_ws_floats(rows, N)
 extern "C" int t4r_colsum(void* stream, const float* x, float* out, float* ws, long rows, int N, long ld) {
-    return colred_launch((hipStream_t)stream, x, nullptr, nullptr, out, ws, rows, N, ld, 2);
+    return colred_launch((hipStream_t)stream, x, nullptr, nullptr, out, ws, rows, N, ld, 2, make_drop(0.f, 0, 0));
+}
+
+// ---------------------------------------------------------------- element-wise dropout
+// out = x * mask/(1-p)   (HF XLNetModel: dropout on inputs_embeds :1116, pos_emb :1143, final :1177).
+// The same kernel is its own backward (apply to the incoming gradient).  `rep`: x is broadcast
+// `rep` times (pos_emb [2L,D] -> [B,2L,D]: one independent mask per batch row, as the reference's
+// batch-expanded pos_emb gets).  mask_out (uint8, may be NULL) exports the keep mask for tests.
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                       unsigned char* __restrict__ mask_out, long n,
+                                                       long n_src, DropCfg drop) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float4 m = drop_scale4(drop, (unsigned long long)i);
+    const float mm[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (i + e < n) {
+            if (out) out[i + e] = x[(i + e) % n_src] * mm[e];
+            if (mask_out) mask_out[i + e] = mm[e] != 0.f;
+        }
+    }
+}
+
+extern "C" int t4r_dropout(void* stream, const float* x, float* out, unsigned char* mask_out, long n,
+                           long n_src, float p, unsigned long long seed, unsigned long long ctr_hi) {
+    if (n <= 0) return 0;
+    T4R_CHECK_ARG(p >= 0.f && p < 1.f && n_src > 0, "dropout: p in [0,1), n_src > 0");
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, out, mask_out, n, n_src, make_drop(p, seed, ctr_hi));
+    T4R_LAUNCH_CHECK();
+    return 0;
 }
 
 // ---------------------------------------------------------------- fused Adam over a flat buffer

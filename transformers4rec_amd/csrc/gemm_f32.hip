@@ -40,6 +40,7 @@ struct GemmParams {
     int accumulate;             // splitk==1 only: C += result instead of C = result
     long sA, sB, sC;            // batch strides in elements (gridDim.z = batch * splitk)
     int vecA, vecB;             // 16-byte vector loads legal for this operand
+    DropCfg drop;               // EPI_BIAS_GELU only: C = dropout(gelu(x + bias)), mask index row*N + col
 };
 
 // Load one float4 worth of an operand with guards.  `valid` = number of in-range elements
@@ -219,6 +220,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                         v += bv;
                         if (p.aux) p.aux[(long)row * p.ldaux + col] = v;
                         v = gelu_erf(v);
+                        if (p.drop.p > 0.f) v *= drop_scale(p.drop, (unsigned long long)row * p.N + col);
                     } else if (p.epilogue == EPI_BIAS_RELU) {
                         v = fmaxf(v + bv, 0.f);
                     }
@@ -294,7 +296,7 @@ static int launch_layout(GemmParams& p, int batch, int splitk_req, hipStream_t s
 int t4r_gemm_launch(hipStream_t stream, int transA, int transB, int M, int N, int K, float alpha,
                     const float* A, long lda, const float* B, long ldb, float* C, long ldc,
                     const float* bias, int epilogue, float* aux, long ldaux, int splitk,
-                    int accumulate, int batch, long sA, long sB, long sC) {
+                    int accumulate, int batch, long sA, long sB, long sC, const DropCfg* drop) {
     if (M <= 0 || N <= 0) return 0;
     T4R_CHECK_ARG(K > 0 && A && B && C && batch >= 1, "gemm: bad arguments");
     GemmParams p;
@@ -305,6 +307,7 @@ int t4r_gemm_launch(hipStream_t stream, int transA, int transB, int M, int N, in
     p.vecA = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0) && (sA % 4 == 0);
     p.vecB = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0) && (sB % 4 == 0);
     p.splitk = 1;
+    p.drop = drop ? *drop : make_drop(0.f, 0, 0);
     if (transA) {
         if (transB) return launch_layout<true, true>(p, batch, splitk, stream);
         return launch_layout<true, false>(p, batch, splitk, stream);
@@ -319,5 +322,5 @@ extern "C" int t4r_gemm_f32(void* stream, int transA, int transB, int M, int N, 
                             int accumulate, int batch, long strideA, long strideB, long strideC) {
     return t4r_gemm_launch((hipStream_t)stream, transA, transB, M, N, K, alpha, A, lda, B, ldb, C,
                            ldc, bias, epilogue, aux, ldaux, splitk, accumulate, batch, strideA,
-                           strideB, strideC);
+                           strideB, strideC, nullptr);
 }

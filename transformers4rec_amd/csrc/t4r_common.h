@@ -75,3 +75,35 @@ struct Philox {
 __device__ __forceinline__ float u32_to_unit(uint32_t x) {  // [0,1)
     return (float)(x >> 8) * (1.0f / 16777216.0f);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Dropout masks (torch.nn.Dropout semantics: keep with prob 1-p, scale kept values by 1/(1-p)).
+// The keep decision of element `idx` at a dropout site is a pure function of
+// (seed, ctr_hi, idx):  component (idx & 3) of Philox4x32-10(key = seed, counter = (idx >> 2, ctr_hi)).
+// Forward and backward kernels recompute it; nothing is stored.  ctr_hi encodes
+// (step offset << 16) | (layer << 8) | site, see xlnet_layer.hip.
+struct DropCfg {
+    float p;          // 0 => disabled
+    float inv_keep;   // 1 / (1 - p)
+    unsigned long long seed;
+    unsigned long long ctr_hi;
+};
+__device__ __forceinline__ float drop_scale(const DropCfg& d, unsigned long long idx) {
+    const Philox rng(d.seed);
+    const uint4 r = rng(idx >> 2, d.ctr_hi);
+    const unsigned k = (unsigned)(idx & 3);
+    const uint32_t v = k == 0 ? r.x : (k == 1 ? r.y : (k == 2 ? r.z : r.w));
+    return u32_to_unit(v) >= d.p ? d.inv_keep : 0.f;
+}
+// four consecutive elements starting at a multiple of 4
+__device__ __forceinline__ float4 drop_scale4(const DropCfg& d, unsigned long long idx4) {
+    const Philox rng(d.seed);
+    const uint4 r = rng(idx4 >> 2, d.ctr_hi);
+    return make_float4(u32_to_unit(r.x) >= d.p ? d.inv_keep : 0.f, u32_to_unit(r.y) >= d.p ? d.inv_keep : 0.f,
+                       u32_to_unit(r.z) >= d.p ? d.inv_keep : 0.f, u32_to_unit(r.w) >= d.p ? d.inv_keep : 0.f);
+}
+static inline DropCfg make_drop(float p, unsigned long long seed, unsigned long long ctr_hi) {
+    DropCfg d;
+    d.p = p; d.inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f; d.seed = seed; d.ctr_hi = ctr_hi;
+    return d;
+}

@@ -19,15 +19,18 @@
 #include "t4r_common.h"
 
 #define ATT_PAD 4
+// heads (= waves) per workgroup: 4 for d_head >= 32 so the compiler may use up to 512 VGPRs
+// (one head per wave, lane = row: q+r_w, q+r_r, two gradient accumulators of d_head floats each)
+template <int DH> struct HeadsPerBlock { static constexpr int v = DH >= 32 ? 4 : 8; };
 
 template <int DH>
-__global__ __launch_bounds__(512) void xlnet_attn_fwd_kernel(
+__global__ __launch_bounds__(64 * HeadsPerBlock<DH>::v) void xlnet_attn_fwd_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const float* __restrict__ kr,      // [2L, D]
     const float* __restrict__ r_w_bias, const float* __restrict__ r_r_bias,  // [D]
     float* __restrict__ out,           // [B*L, D]
     float* __restrict__ lse,           // [B, n, L]
-    int B, int L, int n_head, float scale) {
+    int B, int L, int n_head, float scale, long kr_bstride, DropCfg drop) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int D = n_head * DH;
     const int LD = D + ATT_PAD;
@@ -35,6 +38,7 @@ __global__ __launch_bounds__(512) void xlnet_attn_fwd_kernel(
     float* Vs = Ks + L * LD;          // [L][LD]
     float* KRs = Vs + L * LD;         // [2L][LD]
     const int b = blockIdx.x;
+    kr += (long)b * kr_bstride;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int dq = D / 4;
     for (int i = tid; i < L * dq; i += nthr) {
@@ -51,7 +55,7 @@ __global__ __launch_bounds__(512) void xlnet_attn_fwd_kernel(
     __syncthreads();
     const int lane = tid & 63;
     {
-        const int h = blockIdx.y * 8 + (tid >> 6);   // one head per wave, <= 8 heads per block
+        const int h = blockIdx.y * HeadsPerBlock<DH>::v + (tid >> 6);   // one head per wave
         const int i = lane;
         if (i >= L || h >= n_head) return;
         const int hc = h * DH;
@@ -84,14 +88,17 @@ __global__ __launch_bounds__(512) void xlnet_attn_fwd_kernel(
             const float alpha = __expf(m - mn);
             const float pj = __expf(s - mn);
             l = l * alpha + pj;
+            // attention-probability dropout (HF rel_attn_core :132): the normaliser keeps all terms
+            float pd = pj;
+            if (drop.p > 0.f) pd *= drop_scale(drop, ((unsigned long long)(b * n_head + h) * L + i) * L + j);
             const float* vj = Vs + j * LD + hc;
 #pragma unroll
             for (int d = 0; d < DH; d += 4) {
                 const float4 a = *reinterpret_cast<const float4*>(vj + d);
-                o[d] = o[d] * alpha + pj * a.x;
-                o[d + 1] = o[d + 1] * alpha + pj * a.y;
-                o[d + 2] = o[d + 2] * alpha + pj * a.z;
-                o[d + 3] = o[d + 3] * alpha + pj * a.w;
+                o[d] = o[d] * alpha + pd * a.x;
+                o[d + 1] = o[d + 1] * alpha + pd * a.y;
+                o[d + 2] = o[d + 2] * alpha + pd * a.z;
+                o[d + 3] = o[d + 3] * alpha + pd * a.w;
             }
             m = mn;
         }
@@ -109,14 +116,15 @@ __global__ __launch_bounds__(512) void xlnet_attn_fwd_kernel(
 // gradients (d k_r, d r_w_bias, d r_r_bias) go to a workspace and are summed by
 // xlnet_attn_bwd_reduce_kernel (deterministic, no atomics).
 template <int DH>
-__global__ __launch_bounds__(512) void xlnet_attn_bwd_kernel(
+__global__ __launch_bounds__(64 * HeadsPerBlock<DH>::v) void xlnet_attn_bwd_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const float* __restrict__ kr, const float* __restrict__ r_w_bias,
     const float* __restrict__ r_r_bias, const float* __restrict__ out,
     const float* __restrict__ lse, const float* __restrict__ dout,
     float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
     float* __restrict__ part,          // [grid][2L*D + 2*D]
-    int B, int L, int n_head, float scale) {
+    float* __restrict__ dkr_b,         // per-batch d k_r [B][2L][D] (kr_bstride > 0) or null
+    int B, int L, int n_head, float scale, long kr_bstride, DropCfg drop) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int D = n_head * DH;
     const int LD = D + ATT_PAD;
@@ -133,7 +141,7 @@ __global__ __launch_bounds__(512) void xlnet_attn_bwd_kernel(
     float* dRR = dRW + D;                    // [D]
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63;
-    const int h = blockIdx.y * 8 + (tid >> 6);       // one head per wave, <= 8 heads per block
+    const int h = blockIdx.y * HeadsPerBlock<DH>::v + (tid >> 6);       // one head per wave
     const bool hvalid = h < n_head;
     const int dq4 = D / 4;
     for (int i = tid; i < 2 * L * dq4; i += nthr) {
@@ -145,6 +153,13 @@ __global__ __launch_bounds__(512) void xlnet_attn_bwd_kernel(
 
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         __syncthreads();  // previous session's phases done before the tiles are overwritten
+        if (kr_bstride > 0) {   // per-session positional keys (pos_emb dropout): reload
+            for (int i = tid; i < 2 * L * dq4; i += nthr) {
+                const int r = i / dq4, c = (i % dq4) * 4;
+                *reinterpret_cast<float4*>(KRs + r * LD + c) =
+                    *reinterpret_cast<const float4*>(kr + (long)b * kr_bstride + (long)r * D + c);
+            }
+        }
         for (int i = tid; i < L * dq4; i += nthr) {
             const int r = i / dq4, c = (i % dq4) * 4;
             const long g = ((long)b * L + r) * D + c;
@@ -161,8 +176,16 @@ __global__ __launch_bounds__(512) void xlnet_attn_bwd_kernel(
             float ga[DH], gb[DH];
 #pragma unroll
             for (int d = 0; d < DH; ++d) ga[d] = gb[d] = 0.f;
+            if (lane < L && drop.p > 0.f) {
+                // keep-scales first (low register pressure here), parked in this row's P slot
+                float* prow0 = Ps + (h * L + lane) * LS;
+#pragma unroll 1
+                for (int j = 0; j < L; ++j)
+                    prow0[j] = drop_scale(drop, ((unsigned long long)(b * n_head + h) * L + lane) * L + j);
+            }
             if (lane < L) {
-            float qw[DH], qr[DH], go[DH];
+            float qw[DH], qr[DH];
+            const float* go = dOs + i * LD + hc;   // d out row stays in LDS (register budget)
             const float* orow = out + ((long)b * L + i) * D + hc;
             float Di = 0.f;
 #pragma unroll
@@ -170,12 +193,12 @@ __global__ __launch_bounds__(512) void xlnet_attn_bwd_kernel(
                 const float qv = Qs[i * LD + hc + d];
                 qw[d] = qv + r_w_bias[hc + d];
                 qr[d] = qv + r_r_bias[hc + d];
-                go[d] = dOs[i * LD + hc + d];
                 Di += go[d] * orow[d];
             }
             const float lse_i = lse[((long)b * n_head + h) * L + i];
             float* dsrow = dSs + (h * L + i) * LS;
             float* prow = Ps + (h * L + i) * LS;
+#pragma unroll 1
             for (int j = 0; j < L; ++j) {
                 const float* kj = Ks + j * LD + hc;
                 const float* krp = KRs + (j + L - i) * LD + hc;
@@ -186,13 +209,15 @@ __global__ __launch_bounds__(512) void xlnet_attn_bwd_kernel(
                     const float4 a = *reinterpret_cast<const float4*>(kj + d);
                     const float4 c = *reinterpret_cast<const float4*>(krp + d);
                     const float4 e = *reinterpret_cast<const float4*>(vj + d);
+                    const float4 gq = *reinterpret_cast<const float4*>(go + d);
                     s += qw[d] * a.x + qw[d + 1] * a.y + qw[d + 2] * a.z + qw[d + 3] * a.w;
                     s += qr[d] * c.x + qr[d + 1] * c.y + qr[d + 2] * c.z + qr[d + 3] * c.w;
-                    dp += go[d] * e.x + go[d + 1] * e.y + go[d + 2] * e.z + go[d + 3] * e.w;
+                    dp += gq.x * e.x + gq.y * e.y + gq.z * e.z + gq.w * e.w;
                 }
                 const float p = __expf(s * scale - lse_i);
-                const float ds = p * (dp - Di) * scale;
-                prow[j] = p;
+                const float msk = drop.p > 0.f ? prow[j] : 1.f;
+                const float ds = p * (dp * msk - Di) * scale;
+                prow[j] = p * msk;    // dropped probability: what multiplied v in the forward
                 dsrow[j] = ds;
 #pragma unroll
                 for (int d = 0; d < DH; d += 4) {
@@ -262,9 +287,15 @@ __global__ __launch_bounds__(512) void xlnet_attn_bwd_kernel(
 #pragma unroll
                     for (int d = 0; d < DH; ++d) g[d] += ds * (qi[d] + r_r_bias[hc + d]);
                 }
-                float* acc = dKR + p * LD + hc;
+                if (dkr_b) {
+                    float* dst = dkr_b + ((long)b * 2 * L + p) * D + hc;
 #pragma unroll
-                for (int d = 0; d < DH; ++d) acc[d] += g[d];
+                    for (int d = 0; d < DH; ++d) dst[d] = g[d];
+                } else {
+                    float* acc = dKR + p * LD + hc;
+#pragma unroll
+                    for (int d = 0; d < DH; ++d) acc[d] += g[d];
+                }
             }
         }
     }
@@ -285,13 +316,14 @@ static size_t attn_bwd_smem(int L, int D, int n) {
 
 extern "C" int t4r_xlnet_attn_bwd_blocks(int B) { return B < 512 ? B : 512; }
 extern "C" long t4r_xlnet_attn_bwd_ws_floats(int B, int L, int D, int n_head) {
-    return (long)t4r_xlnet_attn_bwd_blocks(B) * ((n_head + 7) / 8) * (2L * L * D + 2L * D);
+    const int hpb = (D / n_head) >= 32 ? 4 : 8;
+    return (long)t4r_xlnet_attn_bwd_blocks(B) * ((n_head + hpb - 1) / hpb) * (2L * L * D + 2L * D);
 }
 
 template <int DH>
 static int attn_fwd_launch(hipStream_t st, const float* q, const float* k, const float* v,
                            const float* kr, const float* rw, const float* rr, float* out, float* lse,
-                           int B, int L, int n_head, float scale) {
+                           int B, int L, int n_head, float scale, long kr_bstride, DropCfg drop) {
     const int D = n_head * DH;
     const size_t smem = attn_fwd_smem(L, D);
     static size_t attr = 0;
@@ -300,27 +332,34 @@ static int attn_fwd_launch(hipStream_t st, const float* q, const float* k, const
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr = smem;
     }
-    const int waves = n_head < 8 ? n_head : 8;
-    hipLaunchKernelGGL(xlnet_attn_fwd_kernel<DH>, dim3(B, (n_head + 7) / 8), dim3(64 * waves), smem, st, q, k, v, kr, rw,
-                       rr, out, lse, B, L, n_head, scale);
+    constexpr int HPB = HeadsPerBlock<DH>::v;
+    const int waves = n_head < HPB ? n_head : HPB;
+    hipLaunchKernelGGL(xlnet_attn_fwd_kernel<DH>, dim3(B, (n_head + HPB - 1) / HPB), dim3(64 * waves), smem, st, q, k, v, kr, rw,
+                       rr, out, lse, B, L, n_head, scale, kr_bstride, drop);
     T4R_LAUNCH_CHECK();
     return 0;
 }
 
+// kr_per_batch: k_r is [B, 2L, D] (one set of positional keys per session: pos_emb dropout) instead
+// of [2L, D].  drop_p: attention-probability dropout (mask index ((b*n+h)*L+i)*L+j).
 extern "C" int t4r_xlnet_attn_fwd(void* stream, const float* q, const float* k, const float* v,
                                   const float* k_r, const float* r_w_bias, const float* r_r_bias,
-                                  float* out, float* lse, int B, int L, int n_head, int d_head) {
+                                  float* out, float* lse, int B, int L, int n_head, int d_head,
+                                  int kr_per_batch, float drop_p, unsigned long long seed,
+                                  unsigned long long ctr_hi) {
     if (B == 0) return 0;
     T4R_CHECK_ARG(L >= 1 && L <= 64, "xlnet_attn: L must be in [1, 64]");
     const int D = n_head * d_head;
     T4R_CHECK_ARG(attn_fwd_smem(L, D) <= 160 * 1024, "xlnet_attn: L*d_model too large for LDS");
     const float scale = 1.0f / sqrtf((float)d_head);
     hipStream_t st = (hipStream_t)stream;
+    const long bs = kr_per_batch ? 2L * L * D : 0;
+    const DropCfg dc = make_drop(drop_p, seed, ctr_hi);
     switch (d_head) {
-        case 8: return attn_fwd_launch<8>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, B, L, n_head, scale);
-        case 16: return attn_fwd_launch<16>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, B, L, n_head, scale);
-        case 32: return attn_fwd_launch<32>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, B, L, n_head, scale);
-        case 64: return attn_fwd_launch<64>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, B, L, n_head, scale);
+        case 8: return attn_fwd_launch<8>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, B, L, n_head, scale, bs, dc);
+        case 16: return attn_fwd_launch<16>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, B, L, n_head, scale, bs, dc);
+        case 32: return attn_fwd_launch<32>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, B, L, n_head, scale, bs, dc);
+        case 64: return attn_fwd_launch<64>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, B, L, n_head, scale, bs, dc);
     }
     t4r_set_error("xlnet_attn: d_head must be 8, 16, 32 or 64");
     return -1;
@@ -331,7 +370,7 @@ static int attn_bwd_launch(hipStream_t st, const float* q, const float* k, const
                            const float* kr, const float* rw, const float* rr, const float* out,
                            const float* lse, const float* dout, float* dq, float* dk, float* dv,
                            float* part, float* dkr, float* d_rw, float* d_rr, int B, int L, int n_head,
-                           float scale) {
+                           float scale, long kr_bstride, DropCfg drop) {
     const int D = n_head * DH;
     const size_t smem = attn_bwd_smem(L, D, n_head);
     static size_t attr = 0;
@@ -340,14 +379,17 @@ static int attn_bwd_launch(hipStream_t st, const float* q, const float* k, const
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr = smem;
     }
-    const int waves = n_head < 8 ? n_head : 8;
-    const int hg = (n_head + 7) / 8;
+    constexpr int HPB = HeadsPerBlock<DH>::v;
+    const int waves = n_head < HPB ? n_head : HPB;
+    const int hg = (n_head + HPB - 1) / HPB;
     const int nblocks = t4r_xlnet_attn_bwd_blocks(B);
     hipLaunchKernelGGL(xlnet_attn_bwd_kernel<DH>, dim3(nblocks, hg), dim3(64 * waves), smem, st, q, k, v, kr,
-                       rw, rr, out, lse, dout, dq, dk, dv, part, B, L, n_head, scale);
+                       rw, rr, out, lse, dout, dq, dk, dv, part, kr_bstride > 0 ? dkr : nullptr, B, L, n_head,
+                       scale, kr_bstride, drop);
     T4R_LAUNCH_CHECK();
-    // d k_r overwritten, bias gradients accumulated
-    return t4r_reduce_partials_launch(st, part, nblocks * hg, dkr, 2 * L * D, 0, d_rw, D, 1, d_rr, D, 1);
+    // d k_r overwritten (shared k_r: summed over sessions here), bias gradients accumulated
+    return t4r_reduce_partials_launch(st, part, nblocks * hg, kr_bstride > 0 ? nullptr : dkr, 2 * L * D, 0,
+                                      d_rw, D, 1, d_rr, D, 1);
 }
 
 // d_rw / d_rr are ACCUMULATED into (parameter gradients); dq/dk/dv/dk_r are overwritten.
@@ -356,17 +398,20 @@ extern "C" int t4r_xlnet_attn_bwd(void* stream, const float* q, const float* k, 
                                   const float* out, const float* lse, const float* dout, float* dq,
                                   float* dk, float* dv, float* dk_r, float* d_r_w_bias,
                                   float* d_r_r_bias, float* workspace, int B, int L, int n_head,
-                                  int d_head) {
+                                  int d_head, int kr_per_batch, float drop_p, unsigned long long seed,
+                                  unsigned long long ctr_hi) {
     if (B == 0) return 0;
     T4R_CHECK_ARG(L >= 1 && L <= 64, "xlnet_attn: L must be in [1, 64]");
     const int D = n_head * d_head;
     T4R_CHECK_ARG(attn_bwd_smem(L, D, n_head) <= 160 * 1024, "xlnet_attn_bwd: L*d_model too large for LDS");
     const float scale = 1.0f / sqrtf((float)d_head);
     hipStream_t st = (hipStream_t)stream;
+    const long bs = kr_per_batch ? 2L * L * D : 0;
+    const DropCfg dc = make_drop(drop_p, seed, ctr_hi);
     switch (d_head) {
-        case 8: return attn_bwd_launch<8>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, dout, dq, dk, dv, workspace, dk_r, d_r_w_bias, d_r_r_bias, B, L, n_head, scale);
-        case 16: return attn_bwd_launch<16>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, dout, dq, dk, dv, workspace, dk_r, d_r_w_bias, d_r_r_bias, B, L, n_head, scale);
-        case 32: return attn_bwd_launch<32>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, dout, dq, dk, dv, workspace, dk_r, d_r_w_bias, d_r_r_bias, B, L, n_head, scale);
+        case 8: return attn_bwd_launch<8>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, dout, dq, dk, dv, workspace, dk_r, d_r_w_bias, d_r_r_bias, B, L, n_head, scale, bs, dc);
+        case 16: return attn_bwd_launch<16>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, dout, dq, dk, dv, workspace, dk_r, d_r_w_bias, d_r_r_bias, B, L, n_head, scale, bs, dc);
+        case 32: return attn_bwd_launch<32>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, dout, dq, dk, dv, workspace, dk_r, d_r_w_bias, d_r_r_bias, B, L, n_head, scale, bs, dc);
     }
     t4r_set_error("xlnet_attn_bwd: d_head must be 8, 16 or 32");
     return -1;

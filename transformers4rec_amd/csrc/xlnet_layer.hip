@@ -18,21 +18,39 @@
 int t4r_gemm_launch(hipStream_t stream, int transA, int transB, int M, int N, int K, float alpha,
                     const float* A, long lda, const float* B, long ldb, float* C, long ldc,
                     const float* bias, int epilogue, float* aux, long ldaux, int splitk,
-                    int accumulate, int batch, long sA, long sB, long sC);
+                    int accumulate, int batch, long sA, long sB, long sC, const DropCfg* drop);
 extern "C" {
 int t4r_add_layernorm_fwd(void*, const float*, const float*, const float*, const float*, float*,
-                          float*, float*, int, int, float);
+                          float*, float*, int, int, float, float, unsigned long long, unsigned long long);
 int t4r_add_layernorm_bwd(void*, const float*, const float*, const float*, const float*,
-                          const float*, const float*, float*, float*, float*, float*, int, int, int);
-int t4r_act_bwd_bias(void*, const float*, const float*, float*, float*, float*, long, int, int);
+                          const float*, const float*, float*, float*, float*, float*, float*, int, int,
+                          int, float, unsigned long long, unsigned long long);
+int t4r_act_bwd_bias(void*, const float*, const float*, float*, float*, float*, long, int, int, float,
+                     unsigned long long, unsigned long long);
 int t4r_colsum(void*, const float*, float*, float*, long, int, long);
 long t4r_colreduce_ws_floats(long, int);
+int t4r_dropout(void*, const float*, float*, unsigned char*, long, long, float, unsigned long long,
+                unsigned long long);
 int t4r_xlnet_attn_fwd(void*, const float*, const float*, const float*, const float*, const float*,
-                       const float*, float*, float*, int, int, int, int);
+                       const float*, float*, float*, int, int, int, int, int, float, unsigned long long,
+                       unsigned long long);
 int t4r_xlnet_attn_bwd(void*, const float*, const float*, const float*, const float*, const float*,
                        const float*, const float*, const float*, const float*, float*, float*, float*,
-                       float*, float*, float*, float*, int, int, int, int);
+                       float*, float*, float*, float*, int, int, int, int, int, float,
+                       unsigned long long, unsigned long long);
 long t4r_xlnet_attn_bwd_ws_floats(int, int, int, int);
+}
+
+// dropout sites of one layer (HF modeling_xlnet.py): pos_emb :1143 (model level, but the mask is per
+// batch row so k_r becomes per-session), attention probabilities :132, attention output :147,
+// FF activation :301, FF output :303.  ctr_hi = (offset << 16) | (layer << 8) | site.
+enum { SITE_INPUT = 0, SITE_POS = 1, SITE_PROB = 2, SITE_ATTN_OUT = 3, SITE_FF_ACT = 4, SITE_FF_OUT = 5,
+       SITE_FINAL = 6 };
+static unsigned long long ctr_hi(unsigned long long offset, int layer, int site) {
+    return (offset << 16) | ((unsigned long long)(layer & 0xff) << 8) | (unsigned long long)site;
+}
+extern "C" unsigned long long t4r_dropout_ctr_hi(unsigned long long offset, int layer, int site) {
+    return ctr_hi(offset, layer, site);
 }
 
 enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_RELU = 3 };
@@ -48,13 +66,13 @@ struct LayerWs {
 
 static long align4(long x) { return (x + 3) & ~3L; }
 
-static LayerWs carve(float* base, int B, int L, int D, int n) {
+static LayerWs carve(float* base, int B, int L, int D, int n, int per_batch_kr) {
     const long T = (long)B * L;
     LayerWs w;
     long o = 0;
     auto take = [&](long nfl) { float* p = base ? base + o : nullptr; o += align4(nfl); return p; };
     w.qkv = take(3 * T * D);
-    w.kr = take(2L * L * D);
+    w.kr = take((per_batch_kr ? (long)B : 1L) * 2L * L * D);
     w.av = take(T * D);
     w.lse = take((long)B * n * L);
     w.ao = take(T * D);
@@ -70,14 +88,17 @@ static LayerWs carve(float* base, int B, int L, int D, int n) {
     return w;
 }
 
-extern "C" long t4r_xlnet_layer_ws_floats(int B, int L, int D, int n_head) {
-    return carve(nullptr, B, L, D, n_head).total;
+// dropout != 0: positional keys are per session (k_r [B,2L,D])
+extern "C" long t4r_xlnet_layer_ws_floats(int B, int L, int D, int n_head, int dropout) {
+    return carve(nullptr, B, L, D, n_head, dropout).total;
 }
 // backward scratch: dqkv [3,T,D] + dav [T,D] + dx [T,D] + dff [T,4D] + dkr [2L,D] + attention partials
-extern "C" long t4r_xlnet_layer_bwd_ws_floats(int B, int L, int D, int n_head) {
+extern "C" long t4r_xlnet_layer_bwd_ws_floats(int B, int L, int D, int n_head, int dropout) {
     const long T = (long)B * L;
-    return align4(3 * T * D) + align4(T * D) + align4(T * D) + align4(T * 4 * D) + align4(2L * L * D) +
-           align4(t4r_xlnet_attn_bwd_ws_floats(B, L, D, n_head)) + align4(t4r_colreduce_ws_floats(T, 4 * D));
+    const long nkr = (dropout ? (long)B : 1L) * 2L * L * D;
+    return align4(3 * T * D) + align4(T * D) + align4(T * D) + align4(T * 4 * D) + align4(nkr) +
+           align4(t4r_xlnet_attn_bwd_ws_floats(B, L, D, n_head)) + align4(t4r_colreduce_ws_floats(T, 4 * D)) +
+           (dropout ? align4(T * D) + align4(nkr) : 0);
 }
 
 #define RUN(call)                \
@@ -88,40 +109,56 @@ extern "C" long t4r_xlnet_layer_bwd_ws_floats(int B, int L, int D, int n_head) {
 
 extern "C" int t4r_xlnet_layer_fwd(void* stream, const float* h, const float* pos_emb,
                                    const float* const* params, float* ws, float* h_out, int B, int L,
-                                   int D, int n_head, float ln_eps) {
+                                   int D, int n_head, float ln_eps, float drop_p,
+                                   unsigned long long seed, unsigned long long offset, int layer_idx) {
     if (B == 0) return 0;
     T4R_CHECK_ARG(D % n_head == 0 && D % 4 == 0, "xlnet_layer: d_model must divide by n_head and 4");
+    T4R_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "xlnet_layer: dropout p in [0, 1)");
     hipStream_t st = (hipStream_t)stream;
     const int T = B * L, dh = D / n_head;
-    LayerWs w = carve(ws, B, L, D, n_head);
+    const int drop = drop_p > 0.f;
+    LayerWs w = carve(ws, B, L, D, n_head, drop);
     const float* q_w = params[P_Q];
     const float* k_w = params[P_K];
     const float* v_w = params[P_V];
     const long TD = (long)T * D, DD = (long)D * D;
+    auto C = [&](int site) { return ctr_hi(offset, layer_idx, site); };
     if (k_w == q_w + DD && v_w == q_w + 2 * DD) {
         RUN(t4r_gemm_launch(st, 0, 0, T, D, D, 1.f, h, D, q_w, D, w.qkv, D, nullptr, EPI_NONE, nullptr, 0,
-                            1, 0, 3, 0, DD, TD));
+                            1, 0, 3, 0, DD, TD, nullptr));
     } else {
         const float* ws3[3] = {q_w, k_w, v_w};
         for (int z = 0; z < 3; ++z)
             RUN(t4r_gemm_launch(st, 0, 0, T, D, D, 1.f, h, D, ws3[z], D, w.qkv + z * TD, D, nullptr,
-                                EPI_NONE, nullptr, 0, 1, 0, 1, 0, 0, 0));
+                                EPI_NONE, nullptr, 0, 1, 0, 1, 0, 0, 0, nullptr));
     }
-    RUN(t4r_gemm_launch(st, 0, 0, 2 * L, D, D, 1.f, pos_emb, D, params[P_R], D, w.kr, D, nullptr,
-                        EPI_NONE, nullptr, 0, 1, 0, 1, 0, 0, 0));
+    if (drop) {
+        // dropout(pos_emb expanded over the batch) @ r : per-session positional keys (HF :1142-1143
+        // drops the batch-expanded pos_emb, so every session gets its own mask).  The dropped copy
+        // [B*2L, D] is staged in the ffpre region (T*4D floats), which FF1 only overwrites later.
+        float* pe_b = w.ffpre;
+        RUN(t4r_dropout(stream, pos_emb, pe_b, nullptr, (long)B * 2 * L * D, 2L * L * D, drop_p, seed,
+                        C(SITE_POS)));
+        RUN(t4r_gemm_launch(st, 0, 0, B * 2 * L, D, D, 1.f, pe_b, D, params[P_R], D, w.kr, D, nullptr,
+                            EPI_NONE, nullptr, 0, 1, 0, 1, 0, 0, 0, nullptr));
+    } else {
+        RUN(t4r_gemm_launch(st, 0, 0, 2 * L, D, D, 1.f, pos_emb, D, params[P_R], D, w.kr, D, nullptr,
+                            EPI_NONE, nullptr, 0, 1, 0, 1, 0, 0, 0, nullptr));
+    }
     RUN(t4r_xlnet_attn_fwd(stream, w.qkv, w.qkv + TD, w.qkv + 2 * TD, w.kr, params[P_RWB],
-                           params[P_RRB], w.av, w.lse, B, L, n_head, dh));
+                           params[P_RRB], w.av, w.lse, B, L, n_head, dh, drop, drop_p, seed, C(SITE_PROB)));
     // attn_out[t, h] = sum_{nd} av[t, nd] * o[h, nd]
     RUN(t4r_gemm_launch(st, 0, 1, T, D, D, 1.f, w.av, D, params[P_O], D, w.ao, D, nullptr, EPI_NONE,
-                        nullptr, 0, 1, 0, 1, 0, 0, 0));
+                        nullptr, 0, 1, 0, 1, 0, 0, 0, nullptr));
     RUN(t4r_add_layernorm_fwd(stream, w.ao, h, params[P_LN1W], params[P_LN1B], w.h1, w.mean1, w.rstd1,
-                              T, D, ln_eps));
+                              T, D, ln_eps, drop_p, seed, C(SITE_ATTN_OUT)));
+    const DropCfg dff = make_drop(drop_p, seed, C(SITE_FF_ACT));
     RUN(t4r_gemm_launch(st, 0, 1, T, 4 * D, D, 1.f, w.h1, D, params[P_W1], D, w.ffact, 4 * D,
-                        params[P_B1], EPI_BIAS_GELU, w.ffpre, 4 * D, 1, 0, 1, 0, 0, 0));
+                        params[P_B1], EPI_BIAS_GELU, w.ffpre, 4 * D, 1, 0, 1, 0, 0, 0, &dff));
     RUN(t4r_gemm_launch(st, 0, 1, T, D, 4 * D, 1.f, w.ffact, 4 * D, params[P_W2], 4 * D, w.ffout, D,
-                        params[P_B2], EPI_BIAS, nullptr, 0, 1, 0, 1, 0, 0, 0));
+                        params[P_B2], EPI_BIAS, nullptr, 0, 1, 0, 1, 0, 0, 0, nullptr));
     RUN(t4r_add_layernorm_fwd(stream, w.ffout, w.h1, params[P_LN2W], params[P_LN2B], h_out, w.mean2,
-                              w.rstd2, T, D, ln_eps));
+                              w.rstd2, T, D, ln_eps, drop_p, seed, C(SITE_FF_OUT)));
     return 0;
 }
 
@@ -130,66 +167,82 @@ extern "C" int t4r_xlnet_layer_fwd(void* stream, const float* h, const float* po
 extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* pos_emb,
                                    const float* const* params, float* const* grads, const float* ws,
                                    float* bws, const float* dh_out, float* dh_in, int B, int L, int D,
-                                   int n_head, float ln_eps) {
+                                   int n_head, float ln_eps, float drop_p, unsigned long long seed,
+                                   unsigned long long offset, int layer_idx) {
     if (B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const int T = B * L, dh = D / n_head;
     const long TD = (long)T * D, DD = (long)D * D;
-    LayerWs w = carve(const_cast<float*>(ws), B, L, D, n_head);
+    const int drop = drop_p > 0.f;
+    const long nkr = (drop ? (long)B : 1L) * 2L * L * D;
+    LayerWs w = carve(const_cast<float*>(ws), B, L, D, n_head, drop);
+    auto C = [&](int site) { return ctr_hi(offset, layer_idx, site); };
     long o = 0;
     auto take = [&](long nfl) { float* p = bws + o; o += align4(nfl); return p; };
     float* dqkv = take(3 * TD);
     float* dav = take(TD);
     float* dx = take(TD);
     float* dff = take(4 * TD);
-    float* dkr = take(2L * L * D);
+    float* dkr = take(nkr);
     float* attn_ws = take(t4r_xlnet_attn_bwd_ws_floats(B, L, D, n_head));
     float* red_ws = take(t4r_colreduce_ws_floats(T, 4 * D));
+    float* dxa = drop ? take(TD) : nullptr;     // gradient of a dropped LayerNorm operand
+    float* pe_b = drop ? take(nkr) : nullptr;   // regenerated dropout(pos_emb) per session
 
-    // LN2: dy = dh_out, x = ffout + h1  ->  dx (= d ffout = residual part of d h1)
-    RUN(t4r_add_layernorm_bwd(stream, w.ffout, w.h1, params[P_LN2W], w.mean2, w.rstd2, dh_out, dx,
-                              grads[P_LN2W], grads[P_LN2B], red_ws, T, D, 0));
+    // LN2: y = LN(drop(ffout) + h1): dx = d h1 (residual part), d ffout = dxa (or dx when p = 0)
+    RUN(t4r_add_layernorm_bwd(stream, w.ffout, w.h1, params[P_LN2W], w.mean2, w.rstd2, dh_out, dx, dxa,
+                              grads[P_LN2W], grads[P_LN2B], red_ws, T, D, 0, drop_p, seed, C(SITE_FF_OUT)));
+    const float* dffout = drop ? dxa : dx;
     // FF2: ffout = ffact @ w2^T + b2
-    RUN(t4r_gemm_launch(st, 0, 0, T, 4 * D, D, 1.f, dx, D, params[P_W2], 4 * D, dff, 4 * D, nullptr,
-                        EPI_NONE, nullptr, 0, 1, 0, 1, 0, 0, 0));
-    RUN(t4r_gemm_launch(st, 1, 0, D, 4 * D, T, 1.f, dx, D, w.ffact, 4 * D, grads[P_W2], 4 * D, nullptr,
-                        EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0));
-    RUN(t4r_colsum(stream, dx, grads[P_B2], red_ws, T, D, D));
-    // GELU + bias1
-    RUN(t4r_act_bwd_bias(stream, dff, w.ffpre, dff, grads[P_B1], red_ws, T, 4 * D, 0));
+    RUN(t4r_gemm_launch(st, 0, 0, T, 4 * D, D, 1.f, dffout, D, params[P_W2], 4 * D, dff, 4 * D, nullptr,
+                        EPI_NONE, nullptr, 0, 1, 0, 1, 0, 0, 0, nullptr));
+    RUN(t4r_gemm_launch(st, 1, 0, D, 4 * D, T, 1.f, dffout, D, w.ffact, 4 * D, grads[P_W2], 4 * D, nullptr,
+                        EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
+    RUN(t4r_colsum(stream, dffout, grads[P_B2], red_ws, T, D, D));
+    // ffact = drop(gelu(ffpre)) ; GELU' + bias1
+    RUN(t4r_act_bwd_bias(stream, dff, w.ffpre, dff, grads[P_B1], red_ws, T, 4 * D, 0, drop_p, seed,
+                         C(SITE_FF_ACT)));
     // FF1: ffpre = h1 @ w1^T + b1 ;  d h1 = dx (residual) + dff @ w1
     RUN(t4r_gemm_launch(st, 0, 0, T, D, 4 * D, 1.f, dff, 4 * D, params[P_W1], D, dx, D, nullptr,
-                        EPI_NONE, nullptr, 0, 1, 1, 1, 0, 0, 0));
+                        EPI_NONE, nullptr, 0, 1, 1, 1, 0, 0, 0, nullptr));
     RUN(t4r_gemm_launch(st, 1, 0, 4 * D, D, T, 1.f, dff, 4 * D, w.h1, D, grads[P_W1], D, nullptr,
-                        EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0));
-    // LN1: dy = d h1 (dx), x = ao + h  ->  dh_in (= d ao = residual part of d h)
-    RUN(t4r_add_layernorm_bwd(stream, w.ao, h, params[P_LN1W], w.mean1, w.rstd1, dx, dh_in,
-                              grads[P_LN1W], grads[P_LN1B], red_ws, T, D, 0));
+                        EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
+    // LN1: h1 = LN(drop(ao) + h): dh_in = d h (residual part), d ao = dxa (or dh_in when p = 0)
+    RUN(t4r_add_layernorm_bwd(stream, w.ao, h, params[P_LN1W], w.mean1, w.rstd1, dx, dh_in, dxa,
+                              grads[P_LN1W], grads[P_LN1B], red_ws, T, D, 0, drop_p, seed, C(SITE_ATTN_OUT)));
+    const float* dao = drop ? dxa : dh_in;
     // O projection: ao = av @ o^T
-    RUN(t4r_gemm_launch(st, 0, 0, T, D, D, 1.f, dh_in, D, params[P_O], D, dav, D, nullptr, EPI_NONE,
-                        nullptr, 0, 1, 0, 1, 0, 0, 0));
-    RUN(t4r_gemm_launch(st, 1, 0, D, D, T, 1.f, dh_in, D, w.av, D, grads[P_O], D, nullptr, EPI_NONE,
-                        nullptr, 0, -1, 1, 1, 0, 0, 0));
+    RUN(t4r_gemm_launch(st, 0, 0, T, D, D, 1.f, dao, D, params[P_O], D, dav, D, nullptr, EPI_NONE,
+                        nullptr, 0, 1, 0, 1, 0, 0, 0, nullptr));
+    RUN(t4r_gemm_launch(st, 1, 0, D, D, T, 1.f, dao, D, w.av, D, grads[P_O], D, nullptr, EPI_NONE,
+                        nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
     // attention core
     RUN(t4r_xlnet_attn_bwd(stream, w.qkv, w.qkv + TD, w.qkv + 2 * TD, w.kr, params[P_RWB],
                            params[P_RRB], w.av, w.lse, dav, dqkv, dqkv + TD, dqkv + 2 * TD, dkr,
-                           grads[P_RWB], grads[P_RRB], attn_ws, B, L, n_head, dh));
-    // k_r = pos_emb @ r  ->  d r += pos_emb^T @ d k_r
-    RUN(t4r_gemm_launch(st, 1, 0, D, D, 2 * L, 1.f, pos_emb, D, dkr, D, grads[P_R], D, nullptr,
-                        EPI_NONE, nullptr, 0, 1, 1, 1, 0, 0, 0));
+                           grads[P_RWB], grads[P_RRB], attn_ws, B, L, n_head, dh, drop, drop_p, seed,
+                           C(SITE_PROB)));
+    // k_r = pos_emb(_b) @ r  ->  d r += pos_emb(_b)^T @ d k_r
+    if (drop) {
+        RUN(t4r_dropout(stream, pos_emb, pe_b, nullptr, nkr, 2L * L * D, drop_p, seed, C(SITE_POS)));
+        RUN(t4r_gemm_launch(st, 1, 0, D, D, B * 2 * L, 1.f, pe_b, D, dkr, D, grads[P_R], D, nullptr,
+                            EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
+    } else {
+        RUN(t4r_gemm_launch(st, 1, 0, D, D, 2 * L, 1.f, pos_emb, D, dkr, D, grads[P_R], D, nullptr,
+                            EPI_NONE, nullptr, 0, 1, 1, 1, 0, 0, 0, nullptr));
+    }
     // q,k,v = h @ w  ->  d h += d{q,k,v} @ w^T ; d w += h^T @ d{q,k,v}
     const float* wz[3] = {params[P_Q], params[P_K], params[P_V]};
     float* gz[3] = {grads[P_Q], grads[P_K], grads[P_V]};
     for (int z = 0; z < 3; ++z)
         RUN(t4r_gemm_launch(st, 0, 1, T, D, D, 1.f, dqkv + z * TD, D, wz[z], D, dh_in, D, nullptr,
-                            EPI_NONE, nullptr, 0, 1, 1, 1, 0, 0, 0));
+                            EPI_NONE, nullptr, 0, 1, 1, 1, 0, 0, 0, nullptr));
     if (gz[1] == gz[0] + DD && gz[2] == gz[0] + 2 * DD) {
         RUN(t4r_gemm_launch(st, 1, 0, D, D, T, 1.f, h, D, dqkv, D, gz[0], D, nullptr, EPI_NONE, nullptr,
-                            0, -1, 1, 3, 0, TD, DD));
+                            0, -1, 1, 3, 0, TD, DD, nullptr));
     } else {
         for (int z = 0; z < 3; ++z)
             RUN(t4r_gemm_launch(st, 1, 0, D, D, T, 1.f, h, D, dqkv + z * TD, D, gz[z], D, nullptr,
-                                EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0));
+                                EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
     }
     return 0;
 }

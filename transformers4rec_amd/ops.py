@@ -63,35 +63,61 @@ def gemm(a, b, trans_a=False, trans_b=False, alpha=1.0, bias=None, epilogue=EPI_
 
 
 # ------------------------------------------------------------------------------------ LN / act
-def add_layernorm_fwd(a, b, gamma, beta, eps):
+SITE_INPUT, SITE_POS, SITE_PROB, SITE_ATTN_OUT, SITE_FF_ACT, SITE_FF_OUT, SITE_FINAL = range(7)
+NO_DROP = (0.0, 0, 0)
+
+
+def dropout_ctr_hi(offset, layer, site):
+    return _lib.load().t4r_dropout_ctr_hi(int(offset), int(layer), int(site))
+
+
+def dropout(x, p, seed, ctr_hi, n_total=None, want_mask=False, out=None):
+    """out[i] = x[i % x.numel()] * keep(i)/(1-p), i < n_total (default x.numel())."""
+    n_src = x.numel()
+    n = n_src if n_total is None else n_total
+    if out is None:
+        out = torch.empty(n, device=x.device, dtype=torch.float32)
+    mask = torch.empty(n, device=x.device, dtype=torch.uint8) if want_mask else None
+    call("t4r_dropout", _stream(), _chk(x, torch.float32), out.data_ptr(), _p(mask), n, n_src, float(p),
+         int(seed), int(ctr_hi))
+    return (out, mask) if want_mask else out
+
+
+def add_layernorm_fwd(a, b, gamma, beta, eps, drop=NO_DROP):
     rows, D = a.shape[0], a.shape[1]
     y = torch.empty_like(a)
     mean = torch.empty(rows, device=a.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)
     call("t4r_add_layernorm_fwd", _stream(), _chk(a, torch.float32), _p(b, torch.float32),
-         _chk(gamma), _chk(beta), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, D, float(eps))
+         _chk(gamma), _chk(beta), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, D, float(eps),
+         float(drop[0]), int(drop[1]), int(drop[2]))
     return y, mean, rstd
 
 
-def add_layernorm_bwd(a, b, gamma, mean, rstd, dy, dgamma, dbeta, dx=None, accumulate_dx=False):
+def add_layernorm_bwd(a, b, gamma, mean, rstd, dy, dgamma, dbeta, dx=None, accumulate_dx=False,
+                      drop=NO_DROP):
+    """-> dx (gradient of b), or (dx, dxa) with dropout (dxa = gradient of the dropped operand a)."""
     rows, D = a.shape
     if dx is None:
         dx = torch.empty_like(a)
+    dxa = torch.empty_like(a) if drop[0] > 0 else None
     ws = _colred_ws(rows, 2 * D, a.device)
     call("t4r_add_layernorm_bwd", _stream(), _chk(a), _p(b), _chk(gamma), _chk(mean), _chk(rstd),
-         _chk(dy), dx.data_ptr(), _p(dgamma), _p(dbeta), ws.data_ptr(), rows, D, int(accumulate_dx))
-    return dx
+         _chk(dy), dx.data_ptr(), _p(dxa), _p(dgamma), _p(dbeta), ws.data_ptr(), rows, D,
+         int(accumulate_dx), float(drop[0]), int(drop[1]), int(drop[2]))
+    return dx if dxa is None else (dx, dxa)
 
 
 def _colred_ws(rows, ncols, device):
     return torch.empty(_lib.load().t4r_colreduce_ws_floats(rows, ncols), device=device, dtype=torch.float32)
 
 
-def act_bwd_bias(dact, pre, dbias, mode, out=None):
+def act_bwd_bias(dact, pre, dbias, mode, out=None, drop=NO_DROP):
     rows, N = dact.shape
     out = dact if out is None else out
     ws = None if dbias is None else _colred_ws(rows, N, dact.device)
-    call("t4r_act_bwd_bias", _stream(), _chk(dact), _chk(pre), out.data_ptr(), _p(dbias), _p(ws), rows, N, mode)
+    call("t4r_act_bwd_bias", _stream(), _chk(dact), _chk(pre), out.data_ptr(), _p(dbias), _p(ws), rows, N,
+         mode, float(drop[0]), int(drop[1]), int(drop[2]))
     return out
 
 
@@ -230,25 +256,31 @@ def last_positions(item_ids, Lgrid, is_mlm, padding_idx=0):
 
 
 # ------------------------------------------------------------------------------------ attention / layer
-def xlnet_attn_fwd(q, k, v, k_r, r_w_bias, r_r_bias, B, L, n_head):
+def xlnet_attn_fwd(q, k, v, k_r, r_w_bias, r_r_bias, B, L, n_head, drop=NO_DROP):
+    """k_r [2L, D] (shared) or [B*2L, D] (per session)."""
     D = q.shape[-1]
+    per_b = int(k_r.shape[0] == B * 2 * L and B > 1)
     out = torch.empty((B * L, D), device=q.device, dtype=torch.float32)
     lse = torch.empty((B, n_head, L), device=q.device, dtype=torch.float32)
     call("t4r_xlnet_attn_fwd", _stream(), _chk(q), _chk(k), _chk(v), _chk(k_r), _chk(r_w_bias),
-         _chk(r_r_bias), out.data_ptr(), lse.data_ptr(), B, L, n_head, D // n_head)
+         _chk(r_r_bias), out.data_ptr(), lse.data_ptr(), B, L, n_head, D // n_head, per_b,
+         float(drop[0]), int(drop[1]), int(drop[2]))
     return out, lse
 
 
-def xlnet_attn_bwd(q, k, v, k_r, r_w_bias, r_r_bias, out, lse, dout, d_rw, d_rr, B, L, n_head):
+def xlnet_attn_bwd(q, k, v, k_r, r_w_bias, r_r_bias, out, lse, dout, d_rw, d_rr, B, L, n_head,
+                   drop=NO_DROP):
     D = q.shape[-1]
     dev = q.device
+    per_b = int(k_r.shape[0] == B * 2 * L and B > 1)
     dq, dk, dv = (torch.empty((B * L, D), device=dev, dtype=torch.float32) for _ in range(3))
-    dkr = torch.empty((2 * L, D), device=dev, dtype=torch.float32)
+    dkr = torch.empty_like(k_r)
     nws = _lib.load().t4r_xlnet_attn_bwd_ws_floats(B, L, D, n_head)
     ws = torch.empty(nws, device=dev, dtype=torch.float32)
     call("t4r_xlnet_attn_bwd", _stream(), _chk(q), _chk(k), _chk(v), _chk(k_r), _chk(r_w_bias),
          _chk(r_r_bias), _chk(out), _chk(lse), _chk(dout), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
-         dkr.data_ptr(), _chk(d_rw), _chk(d_rr), ws.data_ptr(), B, L, n_head, D // n_head)
+         dkr.data_ptr(), _chk(d_rw), _chk(d_rr), ws.data_ptr(), B, L, n_head, D // n_head, per_b,
+         float(drop[0]), int(drop[1]), int(drop[2]))
     return dq, dk, dv, dkr
 
 
@@ -256,35 +288,41 @@ XLNET_PARAM_ORDER = ("q", "k", "v", "o", "r", "r_w_bias", "r_r_bias", "ln1_w", "
                      "w2", "b2", "ln2_w", "ln2_b")
 
 
-def xlnet_layer_ws_floats(B, L, D, n_head):
-    return _lib.load().t4r_xlnet_layer_ws_floats(B, L, D, n_head)
+def xlnet_layer_ws_floats(B, L, D, n_head, dropout=False):
+    return _lib.load().t4r_xlnet_layer_ws_floats(B, L, D, n_head, int(bool(dropout)))
 
 
-def xlnet_layer_bwd_ws_floats(B, L, D, n_head):
-    return _lib.load().t4r_xlnet_layer_bwd_ws_floats(B, L, D, n_head)
+def xlnet_layer_bwd_ws_floats(B, L, D, n_head, dropout=False):
+    return _lib.load().t4r_xlnet_layer_bwd_ws_floats(B, L, D, n_head, int(bool(dropout)))
 
 
-def xlnet_layer_fwd(h, pos_emb, params, B, L, n_head, eps, ws=None):
+def xlnet_layer_fwd(h, pos_emb, params, B, L, n_head, eps, ws=None, drop_p=0.0, seed=0, offset=0,
+                    layer_idx=0):
     """h [B*L, D]; params: sequence of 15 tensors in XLNET_PARAM_ORDER.  -> (h_out, ws)"""
     D = h.shape[-1]
     if ws is None:
-        ws = torch.empty(xlnet_layer_ws_floats(B, L, D, n_head), device=h.device, dtype=torch.float32)
+        ws = torch.empty(xlnet_layer_ws_floats(B, L, D, n_head, drop_p > 0), device=h.device,
+                         dtype=torch.float32)
     out = torch.empty_like(h)
     parr, _keep = ptr_array([_chk(p, torch.float32, "xlnet param") for p in params])
     call("t4r_xlnet_layer_fwd", _stream(), _chk(h, torch.float32), _chk(pos_emb, torch.float32), parr,
-         ws.data_ptr(), out.data_ptr(), B, L, D, n_head, float(eps))
+         ws.data_ptr(), out.data_ptr(), B, L, D, n_head, float(eps), float(drop_p), int(seed),
+         int(offset), int(layer_idx))
     return out, ws
 
 
-def xlnet_layer_bwd(h, pos_emb, params, grads, ws, dh_out, B, L, n_head, eps, bws=None):
+def xlnet_layer_bwd(h, pos_emb, params, grads, ws, dh_out, B, L, n_head, eps, bws=None, drop_p=0.0,
+                    seed=0, offset=0, layer_idx=0):
     D = h.shape[-1]
     if bws is None:
-        bws = torch.empty(xlnet_layer_bwd_ws_floats(B, L, D, n_head), device=h.device, dtype=torch.float32)
+        bws = torch.empty(xlnet_layer_bwd_ws_floats(B, L, D, n_head, drop_p > 0), device=h.device,
+                          dtype=torch.float32)
     dh_in = torch.empty_like(h)
     parr, _k1 = ptr_array([_chk(p, torch.float32) for p in params])
     garr, _k2 = ptr_array([_chk(g, torch.float32) for g in grads])
     call("t4r_xlnet_layer_bwd", _stream(), _chk(h), _chk(pos_emb), parr, garr, _chk(ws),
-         bws.data_ptr(), _chk(dh_out), dh_in.data_ptr(), B, L, D, n_head, float(eps))
+         bws.data_ptr(), _chk(dh_out), dh_in.data_ptr(), B, L, D, n_head, float(eps), float(drop_p),
+         int(seed), int(offset), int(layer_idx))
     return dh_in
 
 

@@ -134,12 +134,14 @@ def relative_positional_encoding(L, D):
 
 class _XLNetLayerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, h, anchor, layer, pos_emb, n_head, eps):
+    def forward(ctx, h, anchor, layer, pos_emb, n_head, eps, drop):
         B, L, D = h.shape
         h2 = h.contiguous().view(B * L, D)
         params = [p.detach() for p in layer.ordered_params()]
-        out, ws = ops.xlnet_layer_fwd(h2, pos_emb, params, B, L, n_head, eps)
-        ctx.layer, ctx.pos_emb, ctx.cfg = layer, pos_emb, (B, L, D, n_head, eps)
+        p, seed, offset, idx = drop
+        out, ws = ops.xlnet_layer_fwd(h2, pos_emb, params, B, L, n_head, eps, drop_p=p, seed=seed,
+                                      offset=offset, layer_idx=idx)
+        ctx.layer, ctx.pos_emb, ctx.cfg, ctx.drop = layer, pos_emb, (B, L, D, n_head, eps), drop
         ctx.save_for_backward(h2, ws)
         return out.view(B, L, D)
 
@@ -147,11 +149,28 @@ class _XLNetLayerFn(torch.autograd.Function):
     def backward(ctx, dout):
         h2, ws = ctx.saved_tensors
         B, L, D, n_head, eps = ctx.cfg
+        p, seed, offset, idx = ctx.drop
         plist = ctx.layer.ordered_params()
-        grads = [_grad_buf(p) for p in plist]
-        dh = ops.xlnet_layer_bwd(h2, ctx.pos_emb, [p.detach() for p in plist], grads, ws,
-                                 dout.contiguous().view(B * L, D), B, L, n_head, eps)
-        return dh.view(B, L, D), None, None, None, None, None
+        grads = [_grad_buf(q) for q in plist]
+        dh = ops.xlnet_layer_bwd(h2, ctx.pos_emb, [q.detach() for q in plist], grads, ws,
+                                 dout.contiguous().view(B * L, D), B, L, n_head, eps, drop_p=p, seed=seed,
+                                 offset=offset, layer_idx=idx)
+        return dh.view(B, L, D), None, None, None, None, None, None
+
+
+class _DropoutFn(torch.autograd.Function):
+    """element-wise dropout with a recomputed Philox mask (model-level sites of HF XLNetModel:
+    inputs_embeds :1116, final output :1177)"""
+
+    @staticmethod
+    def forward(ctx, x, p, seed, ctr_hi):
+        ctx.cfg = (p, seed, ctr_hi)
+        return ops.dropout(x.contiguous().view(-1), p, seed, ctr_hi).view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, ctr_hi = ctx.cfg
+        return ops.dropout(dy.contiguous().view(-1), p, seed, ctr_hi).view(dy.shape), None, None, None
 
 
 class _WordEmbedding(nn.Module):
@@ -170,6 +189,8 @@ class XLNetModel(nn.Module):
         self.mask_emb = nn.Parameter(torch.empty(1, 1, config.d_model).normal_(0, config.initializer_range))
         self.layer = nn.ModuleList([XLNetLayer(config) for _ in range(config.n_layer)])
         self._pos_cache = {}
+        self.seed = 0             # Philox key of the dropout masks
+        self._drop_offset = 0     # advanced once per training forward
 
     config_class = XLNetConfig
 
@@ -181,17 +202,24 @@ class XLNetModel(nn.Module):
 
     def forward(self, inputs_embeds=None, **kwargs):
         cfg = self.config
-        if self.training and cfg.dropout > 0:
-            raise NotImplementedError(
-                "XLNet dropout > 0 in training mode is not implemented on the HIP path yet; "
-                "build the config with dropout=0.0 (SURVEY H3)")
         B, L, D = inputs_embeds.shape
         if D != cfg.d_model:
             raise ValueError(f"inputs_embeds last dim {D} != d_model {cfg.d_model}")
         pos = self.pos_emb(L, inputs_embeds.device)
+        # dropout is active iff the module is in training mode, as in HF (nn.Dropout)
+        p = float(cfg.dropout) if self.training else 0.0
+        offset = 0
+        if p > 0:
+            self._drop_offset += 1
+            offset = self._drop_offset
         h = inputs_embeds
-        for layer in self.layer:
-            h = _XLNetLayerFn.apply(h, layer.rel_attn.q, layer, pos, cfg.n_head, cfg.layer_norm_eps)
+        if p > 0:
+            h = _DropoutFn.apply(h, p, self.seed, ops.dropout_ctr_hi(offset, 255, ops.SITE_INPUT))
+        for i, layer in enumerate(self.layer):
+            h = _XLNetLayerFn.apply(h, layer.rel_attn.q, layer, pos, cfg.n_head, cfg.layer_norm_eps,
+                                    (p, self.seed, offset, i))
+        if p > 0:
+            h = _DropoutFn.apply(h, p, self.seed, ops.dropout_ctr_hi(offset, 255, ops.SITE_FINAL))
         return (h,)
 
 

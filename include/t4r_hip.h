@@ -121,6 +121,16 @@ int t4r_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, floa
                  const float* bias, int epilogue, float* aux, long ldaux, int splitk, int accumulate,
                  int batch, long strideA, long strideB, long strideC);
 
+/* Head backward with CrossEntropyLoss' backward fused into the A operand (the [N, V] gradient is
+ * never written): dlogits = (*grad_out / n_rows) * (softmax(logits) - target), from logits/lse/labels.
+ *   transA = 0: C[n_rows, N] (+)= alpha * dlogits @ B[V, N]       (d X)
+ *   transA = 1: C[V, N]     (+)= alpha * dlogits^T @ B[n_rows, N] (d W)
+ * replaces: the autograd of model/prediction_task.py:446 (CrossEntropyLoss) and :664 (X @ W^T). */
+int t4r_gemm_softmax_grad_f32(void* stream, int transA, int n_rows, int V, int N, float alpha,
+                              const float* logits, long ld_logits, const float* lse, const long* labels,
+                              const float* grad_out, float label_smoothing, const float* B, long ldb,
+                              float* C, long ldc, int splitk, int accumulate);
+
 /* residual + LayerNorm:  y = LN(a + b) (b may be NULL).
  * replaces: HF :142-152, :297-305 (post-LN), tabular/transformations.py:128-132.
  * backward recomputes x = a + b; dgamma/dbeta accumulated; dx overwritten (or += if accumulate_dx). */

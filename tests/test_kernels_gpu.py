@@ -612,3 +612,27 @@ def test_xlnet_layer_dropout_fwd_bwd(ops, B, L, D, n):
     close(dh, hr.grad.reshape(B * L, D), rtol=1e-4, atol=3e-4)
     for k, gt in zip(ORDER, grads):
         close(gt.reshape(-1), pr[k].grad.reshape(-1), rtol=1e-4, atol=8e-4, msg=lambda mm, k=k: f"{k}: {mm}")
+
+
+@pytest.mark.parametrize("N,V,D,eps", [(37, 1001, 64, 0.0), (130, 5003, 128, 0.1)])
+def test_gemm_softmax_grad_fused(ops, N, V, D, eps):
+    """dX / dW of the head with the CE backward fused into the A operand == autograd."""
+    g = torch.Generator().manual_seed(N + V)
+    x = torch.randn(N, D, generator=g).requires_grad_()
+    W = (0.3 * torch.randn(V, D, generator=g)).requires_grad_()
+    y = torch.randint(0, V, (N,), generator=g)
+    T = 0.7
+    logits = (x @ W.t()) / T
+    loss = torch.nn.functional.cross_entropy(logits, y, label_smoothing=eps)
+    (loss * 1.3).backward()
+    ld = ops.pad_ld(V)
+    buf = torch.zeros(N, ld, device=DEV)
+    buf[:, :V] = cu(logits.detach())
+    lg = buf[:, :V]
+    _, _, lse = ops.softmax_ce_fwd(lg, cu(y), V, eps)
+    gout = torch.tensor(1.3, device=DEV)
+    dx = ops.gemm_softmax_grad(lg, lse, cu(y), gout, V, cu(W.detach()), False, alpha=1 / T, label_smoothing=eps, splitk=-1)
+    close(dx, x.grad, rtol=1e-4, atol=1e-6)
+    dW = torch.ones(V, D, device=DEV)
+    ops.gemm_softmax_grad(lg, lse, cu(y), gout, V, cu(x.detach()), True, alpha=1 / T, label_smoothing=eps, out=dW, accumulate=True)
+    close(dW - 1, W.grad, rtol=1e-4, atol=2e-6)

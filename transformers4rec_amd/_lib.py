@@ -36,6 +36,7 @@ _SIGS = {
     "t4r_gemm_f32": ("i", "piiiiif" + "plplpl" + "pipl" + "iii" + "lll"),
     "t4r_dropout_ctr_hi": ("Q", "Qii"),
     "t4r_dropout": ("i", "pppp" + "llfQQ"),
+    "t4r_gemm_softmax_grad_f32": ("i", "piiiif" + "plpppf" + "plpl" + "ii"),
     "t4r_add_layernorm_fwd": ("i", "pppppppp" + "iif" + "fQQ"),
     "t4r_add_layernorm_bwd": ("i", "pppppppppppp" + "iii" + "fQQ"),
     "t4r_colreduce_ws_floats": ("l", "li"),

@@ -41,7 +41,35 @@ struct GemmParams {
     long sA, sB, sC;            // batch strides in elements (gridDim.z = batch * splitk)
     int vecA, vecB;             // 16-byte vector loads legal for this operand
     DropCfg drop;               // EPI_BIAS_GELU only: C = dropout(gelu(x + bias)), mask index row*N + col
+    // A-operand transform: A holds LOGITS [rows, V]; the GEMM consumes the softmax-CE gradient
+    //   a = (*gout / n_rows) * (exp(x - lse[row]) - (1-eps)*[col == y[row]] - eps/V)
+    // computed on the fly while staging the tile (fuses CrossEntropyLoss backward into the
+    // head's dX / dW contractions: the [N, V] gradient never goes to HBM).
+    const float* sg_lse;        // null => plain A
+    const long* sg_labels;
+    const float* sg_gout;       // device scalar (d loss), may be null (=1)
+    int sg_rows, sg_V;
+    float sg_smooth;
 };
+
+// applies the softmax-gradient transform to the `valid` leading elements of v (row fixed,
+// columns col0..col0+3)
+__device__ __forceinline__ float4 softmax_grad4(float4 v, int valid, float l, int y, int col0, float g,
+                                                 const GemmParams& p) {
+    if (valid <= 0) return v;
+    const float sub = p.sg_smooth / p.sg_V;
+    const float hit = g * (1.f - p.sg_smooth);
+    float* e = &v.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < valid) {
+            float t = g * (__expf(e[i] - l) - sub);
+            if (col0 + i == y) t -= hit;
+            e[i] = t;
+        }
+    }
+    return v;
+}
 
 // Load one float4 worth of an operand with guards.  `valid` = number of in-range elements
 // (<=0: none).  vec: 16-byte load legal.
@@ -90,6 +118,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     const bool vecA = p.vecA, vecB = p.vecB;
 
     float4 ra[NA4], rb[NB4];
+    // softmax-gradient A operand: per-row lse / label are prefetched with the tile, the transform
+    // itself runs in store_tiles (after the MFMAs), so the global loads still overlap compute
+    float sgl[NA4];
+    int sgy[NA4];
+    const float sg_g = p.sg_lse ? (p.sg_gout ? *p.sg_gout : 1.f) / p.sg_rows : 0.f;
 
     auto load_tiles = [&](int kt) {
         const int k0 = kt * BK;
@@ -99,11 +132,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             if (TA) {  // A[K][lda], m contiguous: tile row = k, 4 consecutive m
                 const int k = idx / (BM / 4), m4 = (idx % (BM / 4)) * 4;
                 const int gk = k0 + k, gm = m0 + m4;
-                ra[r] = ld4_guard(A + (long)gk * p.lda + gm, gk < p.K ? p.M - gm : 0, vecA);
+                const int valid = gk < p.K ? p.M - gm : 0;
+                ra[r] = ld4_guard(A + (long)gk * p.lda + gm, valid, vecA);
+                if (p.sg_lse && valid > 0) { sgl[r] = p.sg_lse[gk]; sgy[r] = (int)p.sg_labels[gk]; }  // rows = k
             } else {   // A[M][lda], k contiguous: tile row = m, 4 consecutive k
                 const int m = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
                 const int gm = m0 + m, gk = k0 + k4;
-                ra[r] = ld4_guard(A + (long)gm * p.lda + gk, gm < p.M ? p.K - gk : 0, vecA);
+                const int valid = gm < p.M ? p.K - gk : 0;
+                ra[r] = ld4_guard(A + (long)gm * p.lda + gk, valid, vecA);
+                if (p.sg_lse && valid > 0) { sgl[r] = p.sg_lse[gm]; sgy[r] = (int)p.sg_labels[gm]; }  // rows = m
             }
         }
 #pragma unroll
@@ -121,7 +158,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         }
     };
 
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, int kt) {
         float* as = As + buf * BK * LDA_S;
         float* bs = Bs + buf * BK * LDB_S;
 #pragma unroll
@@ -129,9 +166,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             const int idx = tid + r * 256;
             if (TA) {
                 const int k = idx / (BM / 4), m4 = (idx % (BM / 4)) * 4;
+                if (p.sg_lse) {
+                    const int gk = kt * BK + k, gm = m0 + m4;
+                    ra[r] = softmax_grad4(ra[r], gk < p.K ? p.M - gm : 0, sgl[r], sgy[r], gm, sg_g, p);
+                }
                 *reinterpret_cast<float4*>(as + k * LDA_S + m4) = ra[r];
             } else {
                 const int m = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
+                if (p.sg_lse) {
+                    const int gm = m0 + m, gk = kt * BK + k4;
+                    ra[r] = softmax_grad4(ra[r], gm < p.M ? p.K - gk : 0, sgl[r], sgy[r], gk, sg_g, p);
+                }
                 as[(k4 + 0) * LDA_S + m] = ra[r].x;
                 as[(k4 + 1) * LDA_S + m] = ra[r].y;
                 as[(k4 + 2) * LDA_S + m] = ra[r].z;
@@ -163,7 +208,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     load_tiles(kt_begin);
-    store_tiles(0);
+    store_tiles(0, kt_begin);
     __syncthreads();
 
     const int arow = wm * (BM / 2) + (lane & 31);
@@ -190,7 +235,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 for (int j = 0; j < WN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (more) store_tiles(buf ^ 1);
+        if (more) store_tiles(buf ^ 1, kt + 1);
         __syncthreads();
         buf ^= 1;
     }
@@ -292,6 +337,9 @@ static int launch_layout(GemmParams& p, int batch, int splitk_req, hipStream_t s
     return launch_cfg<64, 64, 32, TA, TB>(p, batch, stream);
 }
 
+struct SoftmaxGradA { const float* lse; const long* labels; const float* gout; int rows, V; float smooth; };
+static thread_local const SoftmaxGradA* g_sg = nullptr;   // set only by t4r_gemm_softmax_grad_f32
+
 // Internal C++ entry used by the composite (layer / head) launchers.
 int t4r_gemm_launch(hipStream_t stream, int transA, int transB, int M, int N, int K, float alpha,
                     const float* A, long lda, const float* B, long ldb, float* C, long ldc,
@@ -308,6 +356,11 @@ int t4r_gemm_launch(hipStream_t stream, int transA, int transB, int M, int N, in
     p.vecB = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0) && (sB % 4 == 0);
     p.splitk = 1;
     p.drop = drop ? *drop : make_drop(0.f, 0, 0);
+    p.sg_lse = nullptr; p.sg_labels = nullptr; p.sg_gout = nullptr; p.sg_rows = 1; p.sg_V = 1; p.sg_smooth = 0.f;
+    if (g_sg) {
+        p.sg_lse = g_sg->lse; p.sg_labels = g_sg->labels; p.sg_gout = g_sg->gout;
+        p.sg_rows = g_sg->rows; p.sg_V = g_sg->V; p.sg_smooth = g_sg->smooth;
+    }
     if (transA) {
         if (transB) return launch_layout<true, true>(p, batch, splitk, stream);
         return launch_layout<true, false>(p, batch, splitk, stream);
@@ -323,4 +376,26 @@ extern "C" int t4r_gemm_f32(void* stream, int transA, int transB, int M, int N, 
     return t4r_gemm_launch((hipStream_t)stream, transA, transB, M, N, K, alpha, A, lda, B, ldb, C,
                            ldc, bias, epilogue, aux, ldaux, splitk, accumulate, batch, strideA,
                            strideB, strideC, nullptr);
+}
+
+// Head backward contractions with CrossEntropyLoss' backward fused into the A operand:
+//   transA = 0:  C[N_rows, N] (+)= alpha * dlogits[N_rows, V] @ B[V, N]          (d X = dlogits @ W)
+//   transA = 1:  C[V, N]     (+)= alpha * dlogits[N_rows, V]^T @ B[N_rows, N]    (d W = dlogits^T @ X)
+// where dlogits = (*grad_out / N_rows) * (softmax(logits) - target) is formed from `logits`,
+// `lse` and `labels` while the tile is staged.  Replaces model/prediction_task.py:446 (loss
+// backward through CrossEntropyLoss) + the autograd of :664.
+extern "C" int t4r_gemm_softmax_grad_f32(void* stream, int transA, int n_rows, int V, int N, float alpha,
+                                         const float* logits, long ld_logits, const float* lse,
+                                         const long* labels, const float* grad_out, float label_smoothing,
+                                         const float* B, long ldb, float* C, long ldc, int splitk,
+                                         int accumulate) {
+    T4R_CHECK_ARG(lse && labels && logits, "gemm_softmax_grad: null operand");
+    SoftmaxGradA sg{lse, labels, grad_out, n_rows, V, label_smoothing};
+    g_sg = &sg;
+    const int M = transA ? V : n_rows, K = transA ? n_rows : V;
+    const int rc = t4r_gemm_launch((hipStream_t)stream, transA, 0, M, N, K, alpha, logits, ld_logits, B, ldb,
+                                   C, ldc, nullptr, EPI_NONE, nullptr, 0, splitk, accumulate, 1, 0, 0, 0,
+                                   nullptr);
+    g_sg = nullptr;
+    return rc;
 }

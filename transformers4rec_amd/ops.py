@@ -62,6 +62,21 @@ def gemm(a, b, trans_a=False, trans_b=False, alpha=1.0, bias=None, epilogue=EPI_
     return out
 
 
+def gemm_softmax_grad(logits, lse, labels, grad_out, V, b, trans_a, alpha=1.0, label_smoothing=0.0,
+                      out=None, splitk=1, accumulate=False):
+    """trans_a=False: out[N_rows, N] = alpha * dlogits @ b[V, N] ; True: out[V, N] = alpha * dlogits^T @ b[N_rows, N]
+    with dlogits = softmax-CE gradient formed on the fly from (logits, lse, labels, grad_out)."""
+    n_rows = logits.shape[0]
+    N = b.shape[1]
+    ld = logits.stride(0) if n_rows > 1 else max(logits.shape[1], V)
+    if out is None:
+        out = torch.empty((V if trans_a else n_rows, N), device=logits.device, dtype=torch.float32)
+    call("t4r_gemm_softmax_grad_f32", _stream(), int(trans_a), n_rows, V, N, float(alpha), logits.data_ptr(), ld,
+         _chk(lse, torch.float32), _chk(labels, torch.int64), _p(grad_out), float(label_smoothing),
+         b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), int(splitk), int(accumulate))
+    return out
+
+
 # ------------------------------------------------------------------------------------ LN / act
 SITE_INPUT, SITE_POS, SITE_PROB, SITE_ATTN_OUT, SITE_FF_ACT, SITE_FF_OUT, SITE_FINAL = range(7)
 NO_DROP = (0.0, 0, 0)

@@ -118,13 +118,17 @@ class _NextItemHeadFn(torch.autograd.Function):
         B, L, D, N, V, T, width, smooth = ctx.meta
         mod = task.pre.module
         W = mod.output_weights
-        dl = ops.softmax_ce_bwd(logits, tgt, lse, dloss.contiguous(), width, smooth)
         if ctx.neg is None:
-            dlv = dl[:, :V]
-            dxp = ops.gemm(dlv, W.detach(), False, False, alpha=1.0 / T, splitk=-1)
+            # CrossEntropyLoss backward is fused into the A operand of both contractions:
+            # the [N_m, V] gradient is never materialised
+            g = dloss.contiguous()
+            dxp = ops.gemm_softmax_grad(logits, lse, tgt, g, V, W.detach(), False, alpha=1.0 / T,
+                                        label_smoothing=smooth, splitk=-1)
             if W.requires_grad:
-                ops.gemm(dlv, xp, True, False, alpha=1.0 / T, accumulate=True, out=_grad_buf(W))
+                ops.gemm_softmax_grad(logits, lse, tgt, g, V, xp, True, alpha=1.0 / T, label_smoothing=smooth,
+                                      out=_grad_buf(W), accumulate=True)
         else:
+            dl = ops.softmax_ce_bwd(logits, tgt, lse, dloss.contiguous(), width, smooth)
             dxp = ops.sampled_logits_bwd(dl, xp, labels, W.detach(), ctx.neg, _grad_buf(W), T)
         lin = task.task_block[0][0] if task.task_block is not None else None
         dxr = dxp

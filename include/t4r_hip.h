@@ -114,12 +114,15 @@ int t4r_last_positions(void* stream, const long* item_ids, int B, int L, int Lgr
  *           model/prediction_task.py:664 (+ torch.div by temperature via alpha) and their autograd.
  * C[M,N] = alpha * op(A) * op(B) (+ epilogue).  transA=0: A is [M,lda] ; 1: A is [K,lda].
  * transB=0: B is [K,ldb] ; 1: B is [N,ldb].  epilogue 0 none | 1 +bias | 2 gelu(+bias), pre-act
- * to aux | 3 relu(+bias).  splitk 1: plain; >1 or -1 (auto): fp32 atomics into C (C zeroed first
- * unless accumulate).  accumulate: C += result.  batch: strided batches. */
+ * to aux | 3 relu(+bias) | 4 dropout(x + bias) + residual (residual read from aux).
+ * splitk 1: plain; >1 or -1 (auto): fp32 atomics into C (C zeroed first unless accumulate).
+ * accumulate: C += result.  batch: strided batches.  drop_p > 0: dropout on the output of
+ * epilogue 2 / the pre-residual value of epilogue 4, mask index row*N + col. */
 int t4r_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, float alpha,
                  const float* A, long lda, const float* B, long ldb, float* C, long ldc,
                  const float* bias, int epilogue, float* aux, long ldaux, int splitk, int accumulate,
-                 int batch, long strideA, long strideB, long strideC);
+                 int batch, long strideA, long strideB, long strideC, float drop_p,
+                 unsigned long long seed, unsigned long long ctr_hi);
 
 /* Head backward with CrossEntropyLoss' backward fused into the A operand (the [N, V] gradient is
  * never written): dlogits = (*grad_out / n_rows) * (softmax(logits) - target), from logits/lse/labels.
@@ -181,6 +184,24 @@ int t4r_xlnet_attn_bwd(void* stream, const float* q, const float* k, const float
                        float* dk_r, float* d_r_w_bias, float* d_r_r_bias, float* workspace, int B,
                        int L, int n_head, int d_head, int kr_per_batch, float drop_p,
                        unsigned long long seed, unsigned long long ctr_hi);
+/* a16  scaled-dot-product attention core of the GPT-2 (causal) and BERT blocks
+ * replaces: HF gpt2/modeling_gpt2.py eager_attention_forward :54-72 ; HF bert BertSelfAttention.
+ * q,k,v rows of `ld` floats (3*D for GPT-2's fused c_attn output), head h at columns h*d_head..;
+ * out/dout rows of ld_out; lse [B,n,L]; L <= 128; d_head 16|32|64.  No padding mask (reference
+ * semantics).  drop_p: attention-probability dropout, mask index ((b*n+h)*L+i)*L+j. */
+int t4r_mha_fwd(void* stream, const float* q, const float* k, const float* v, long ld, float* out,
+                long ld_out, float* lse, int B, int L, int n_head, int d_head, int causal, float drop_p,
+                unsigned long long seed, unsigned long long ctr_hi);
+int t4r_mha_bwd(void* stream, const float* q, const float* k, const float* v, long ld, const float* out,
+                const float* dout, long ld_out, const float* lse, float* dq, float* dk, float* dv, long ld_d,
+                int B, int L, int n_head, int d_head, int causal, float drop_p, unsigned long long seed,
+                unsigned long long ctr_hi);
+/* learned position (+ token-type row 0) embeddings: out[t] = x[t] + pos[t % L] (+ token_type);
+ * backward accumulates d_pos[l] += sum_b dy[b,l]  (HF gpt2 :576-577 wpe ; HF bert embeddings) */
+int t4r_add_pos_fwd(void* stream, const float* x, const float* pos, const float* token_type, float* out,
+                    int B, int L, int D);
+int t4r_add_pos_bwd(void* stream, const float* dy, float* d_pos, int B, int L, int D);
+
 /* params / grads: host arrays of 15 device pointers in the order
  *   q, k, v, o, r [D,n,dh] ; r_w_bias, r_r_bias [n,dh] ; rel_attn.layer_norm.{weight,bias} ;
  *   ff.layer_1.{weight [4D,D], bias} ; ff.layer_2.{weight [D,4D], bias} ; ff.layer_norm.{weight,bias}

@@ -98,7 +98,7 @@ def reinit(model, seed):
 
 def build(tr, V, L, d_model, n_head, n_layer, cats=(), conts=(), masking="mlm",
           aggregation="concat", d_output=None, embedding_dims=None, emb_default=None,
-          weight_tying=True, sampled_softmax=False, max_n_samples=100, seed=0):
+          weight_tying=True, sampled_softmax=False, max_n_samples=100, seed=0, arch="xlnet"):
     schema = make_schema(V, L, cats, conts)
     kw = dict(max_sequence_length=L, masking=masking, aggregation=aggregation)
     if d_output:
@@ -111,8 +111,17 @@ def build(tr, V, L, d_model, n_head, n_layer, cats=(), conts=(), masking="mlm",
         kw["embedding_dim_default"] = emb_default
     torch.manual_seed(seed)
     inputs = tr.TabularSequenceFeatures.from_schema(schema, **kw)
-    cfg = tr.XLNetConfig.build(d_model=d_model, n_head=n_head, n_layer=n_layer,
-                               total_seq_length=L, dropout=0.0)
+    if arch == "xlnet":
+        cfg = tr.XLNetConfig.build(d_model=d_model, n_head=n_head, n_layer=n_layer,
+                                   total_seq_length=L, dropout=0.0)
+    elif arch == "gpt2":
+        cfg = tr.GPT2Config.build(d_model=d_model, n_head=n_head, n_layer=n_layer,
+                                  total_seq_length=L, dropout=0.0)
+    else:  # BertConfig.build ignores its `dropout` argument (HF defaults 0.1 stay): zero them explicitly
+        from transformers4rec.config import transformer as tconf
+
+        cfg = tconf.BertConfig.build(d_model=d_model, n_head=n_head, n_layer=n_layer, total_seq_length=L,
+                                  hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
     task = tr.NextItemPredictionTask(weight_tying=weight_tying, sampled_softmax=sampled_softmax,
                                      max_n_samples=max_n_samples)
     model = cfg.to_torch_model(inputs, task)
@@ -221,6 +230,21 @@ def main():
     xE = synth_inputs(B, L, V, catsE, (), seed=41)
     save("xlnet_mlm_sum_sampled_train", run(mE, xE, True, False, True), n_head=nh, d_model=d,
          n_layer=1, eps=0.03, L=L, V=V + 1, max_n_samples=20)
+
+    # I: GPT-2 (causal LM) and BERT (masked LM) blocks through the reference's TransformerBlock
+    mG = build(tr, V, L, d, nh, nl, masking="clm", emb_default=d, seed=70, arch="gpt2")
+    xG = synth_inputs(B, L, V, (), (), seed=71, min_len=2)
+    save("gpt2_clm_item_train", run(mG, xG, True, False, True), n_head=nh, d_model=d, n_layer=nl,
+         eps=1e-5, L=L, V=V + 1)
+    save("gpt2_clm_item_infer", run(mG, xG, False, False, False, with_params=False), n_head=nh, d_model=d,
+         n_layer=nl, eps=1e-5, L=L, V=V + 1)
+    # (one layer: BertConfig.build leaves intermediate_size at HF's 3072, so layers are large)
+    mB = build(tr, V, L, d, nh, 1, emb_default=d, seed=80, arch="bert")
+    xB = synth_inputs(B, L, V, (), (), seed=81)
+    save("bert_mlm_item_train", run(mB, xB, True, False, True), n_head=nh, d_model=d, n_layer=1,
+         eps=0.03, L=L, V=V + 1)
+    save("bert_mlm_item_infer", run(mB, xB, False, False, False, with_params=False), n_head=nh, d_model=d,
+         n_layer=1, eps=0.03, L=L, V=V + 1)
 
     # F: masking-only integer fixture, many rows (lengths 1..L incl. full rows)
     Bm = 96

@@ -25,7 +25,7 @@ def close(a, b, **kw):
 
 
 def build_model(d, cats=(), conts=(), masking="mlm", aggregation="concat", d_output=None,
-                embedding_dims=None, emb_default=None, weight_tying=True, sampled=False, max_n=100):
+                embedding_dims=None, emb_default=None, weight_tying=True, sampled=False, max_n=100, arch="xlnet"):
     import transformers4rec_amd as tr
 
     L, V = int(d["meta/L"]), int(d["meta/V"])
@@ -40,8 +40,14 @@ def build_model(d, cats=(), conts=(), masking="mlm", aggregation="concat", d_out
     if emb_default:
         kw["embedding_dim_default"] = emb_default
     inputs = tr.TabularSequenceFeatures.from_schema(schema, **kw)
-    cfg = tr.XLNetConfig.build(d_model=int(d["meta/d_model"]), n_head=int(d["meta/n_head"]),
-                               n_layer=int(d["meta/n_layer"]), total_seq_length=L, dropout=0.0)
+    kw_cfg = dict(d_model=int(d["meta/d_model"]), n_head=int(d["meta/n_head"]), n_layer=int(d["meta/n_layer"]),
+                  total_seq_length=L)
+    if arch == "xlnet":
+        cfg = tr.XLNetConfig.build(dropout=0.0, **kw_cfg)
+    elif arch == "gpt2":
+        cfg = tr.GPT2Config.build(dropout=0.0, **kw_cfg)
+    else:
+        cfg = tr.BertConfig.build(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **kw_cfg)
     task = tr.NextItemPredictionTask(weight_tying=weight_tying, sampled_softmax=sampled, max_n_samples=max_n)
     return cfg.to_torch_model(inputs, task)
 
@@ -58,7 +64,7 @@ def load_reference_state(model, d):
             assert own[k].shape == v.shape, (k, own[k].shape, v.shape)
             own[k].copy_(v)
             loaded_ptrs.add(own[k].data_ptr())
-    never_used = ("r_s_bias", "seg_embed", "mask_emb", "word_embedding")  # HF params XLNet never touches here
+    never_used = ("r_s_bias", "seg_embed", "mask_emb", "word_embedding", "wte")  # HF params never touched on this path
     for n, p in model.named_parameters():
         assert p.data_ptr() in loaded_ptrs or any(s in n for s in never_used), f"{n} not covered by the reference state_dict"
 
@@ -84,6 +90,8 @@ def run_train_case(name, **build_kw):
     ("xlnet_mlm_multi_train", dict(cats=(("category", 40), ("brand", 9)), conts=("price", "age"), d_output=32,
                                    embedding_dims={"item_id": 16, "category": 24, "brand": 8})),
     ("xlnet_clm_item_train", dict(masking="clm", emb_default=32, weight_tying=False)),
+    ("gpt2_clm_item_train", dict(masking="clm", emb_default=32, arch="gpt2")),
+    ("bert_mlm_item_train", dict(emb_default=32, arch="bert")),
 ])
 def test_train_step_matches_reference(name, kw):
     d, model, x, cap, hooks = run_train_case(name, **kw)
@@ -159,6 +167,8 @@ def test_eval_matches_reference(name, params_from, kw):
 @pytest.mark.parametrize("name,params_from,kw", [
     ("xlnet_mlm_item_infer", "xlnet_mlm_item_train", dict(emb_default=32)),
     ("xlnet_clm_item_infer", "xlnet_clm_item_train", dict(masking="clm", emb_default=32, weight_tying=False)),
+    ("gpt2_clm_item_infer", "gpt2_clm_item_train", dict(masking="clm", emb_default=32, arch="gpt2")),
+    ("bert_mlm_item_infer", "bert_mlm_item_train", dict(emb_default=32, arch="bert")),
 ])
 def test_inference_matches_reference(name, params_from, kw):
     d = gu.load(name, params_from)
@@ -278,3 +288,33 @@ def test_training_mode_dropout_end_to_end():
     lb = model(x, training=True)["loss"]      # next step: new masks
     assert not torch.equal(la, lb)
     assert abs(float(l1) - float(l0)) < 0.5
+
+
+@pytest.mark.parametrize("arch", ["gpt2", "bert"])
+def test_gpt2_bert_training_mode_dropout_and_masking_rules(arch):
+    import transformers4rec_amd as tr
+
+    torch.manual_seed(0)
+    B, L, V, D = 32, 20, 2000, 64
+    schema = tr.session_schema(V - 1, L)
+    masking = "clm" if arch == "gpt2" else "mlm"
+    inputs = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=L, masking=masking, embedding_dim_default=D)
+    cfg = (tr.GPT2Config if arch == "gpt2" else tr.BertConfig).build(D, 4, 2, total_seq_length=L)
+    model = cfg.to_torch_model(inputs, tr.NextItemPredictionTask(weight_tying=True)).to(DEV)
+    x = {"item_id": tr.random_data_from_schema(schema, B, L, seed=5)["item_id"].to(DEV)}
+    model.train()
+    out = model(x, training=True)
+    out["loss"].backward()
+    assert torch.isfinite(out["loss"])
+    g = model.input_features.item_embedding_table.weight.grad
+    assert torch.isfinite(g).all() and float(g.abs().sum()) > 0
+    model.eval()
+    with torch.no_grad():
+        a = model(x, testing=True)["loss"]
+        b = model(x, testing=True)["loss"]
+    assert torch.equal(a, b)
+    # reference rule (tests/unit/torch/block/test_transformer.py:168-194): MLM rejected on GPT-2, CLM on BERT
+    wrong = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=L, masking="mlm" if arch == "gpt2" else "clm",
+                                                   embedding_dim_default=D)
+    with pytest.raises(ValueError, match="is not supported by"):
+        tr.TransformerBlock(cfg, masking=wrong.masking)

@@ -636,3 +636,56 @@ def test_gemm_softmax_grad_fused(ops, N, V, D, eps):
     dW = torch.ones(V, D, device=DEV)
     ops.gemm_softmax_grad(lg, lse, cu(y), gout, V, cu(x.detach()), True, alpha=1 / T, label_smoothing=eps, out=dW, accumulate=True)
     close(dW - 1, W.grad, rtol=1e-4, atol=2e-6)
+
+
+# ------------------------------------------------------------------------------------ GPT-2 / BERT attention core
+@pytest.mark.parametrize("B,L,D,n,causal,p", [(4, 20, 64, 4, True, 0.0), (3, 50, 128, 2, True, 0.0), (2, 100, 128, 2, False, 0.0),
+                                              (3, 33, 64, 4, False, 0.1), (2, 21, 32, 2, True, 0.3), (2, 128, 32, 1, True, 0.0)])
+def test_mha_fwd_bwd(ops, B, L, D, n, causal, p):
+    g = torch.Generator().manual_seed(B + L + D + int(causal))
+    dh = D // n
+    seed, ctr = 5, ops.dropout_ctr_hi(3, 1, ops.SITE_PROB)
+    qkv = torch.randn(B * L, 3 * D, generator=g)
+    qkv_r = qkv.clone().requires_grad_()
+    q, k, v = (qkv_r[:, i * D:(i + 1) * D].view(B, L, n, dh).transpose(1, 2) for i in range(3))
+    s = q @ k.transpose(-1, -2) / dh ** 0.5
+    if causal:
+        s = s.masked_fill(~torch.tril(torch.ones(L, L, dtype=torch.bool)), float("-inf"))
+    prob = torch.softmax(s, -1)
+    if p > 0:
+        prob = prob * _mask(ops, (B, n, L, L), p, seed, ctr) / (1 - p)
+    ref = (prob @ v).transpose(1, 2).reshape(B * L, D)
+    dout = torch.randn(B * L, D, generator=g)
+    ref.backward(dout)
+    dq = cu(qkv)
+    drop = (p, seed, ctr) if p > 0 else ops.NO_DROP
+    out, lse = ops.mha_fwd(dq[:, :D], dq[:, D:2 * D], dq[:, 2 * D:], B, L, n, causal, drop)
+    close(out, ref.detach(), atol=3e-5)
+    dqkv = ops.mha_bwd(dq[:, :D], dq[:, D:2 * D], dq[:, 2 * D:], out, lse, cu(dout), B, L, n, causal, drop, fused_out=True)
+    close(dqkv, qkv_r.grad, rtol=1e-4, atol=2e-4)
+    # separate (non-fused) operands
+    a, b_, c = (cu(qkv[:, i * D:(i + 1) * D]) for i in range(3))
+    out2, lse2 = ops.mha_fwd(a, b_, c, B, L, n, causal, drop)
+    assert torch.equal(out2, out)
+    g1, g2, g3 = ops.mha_bwd(a, b_, c, out2, lse2, cu(dout), B, L, n, causal, drop)
+    close(torch.cat([g1, g2, g3], 1), qkv_r.grad, rtol=1e-4, atol=2e-4)
+
+
+def test_gemm_resid_dropout_epilogue_and_pos_emb(ops):
+    g = torch.Generator().manual_seed(12)
+    M, N, K, p, seed, ctr = 150, 96, 64, 0.3, 2, ops.dropout_ctr_hi(1, 0, ops.SITE_FF_OUT)
+    A, W, bias, R = (torch.randn(M, K, generator=g), torch.randn(K, N, generator=g), torch.randn(N, generator=g),
+                     torch.randn(M, N, generator=g))
+    m = _mask(ops, (M, N), p, seed, ctr)
+    out = ops.gemm(cu(A), cu(W), bias=cu(bias), epilogue=ops.EPI_BIAS_RESID, aux=cu(R), drop=(p, seed, ctr))
+    close(out, (A @ W + bias) * m / (1 - p) + R, atol=1e-4)
+    out = ops.gemm(cu(A), cu(W), bias=cu(bias), epilogue=ops.EPI_BIAS_RESID, aux=cu(R))
+    close(out, A @ W + bias + R, atol=1e-4)
+    B, L, D = 37, 20, 64
+    x, pos, tt = torch.randn(B, L, D, generator=g), torch.randn(L + 2, D, generator=g), torch.randn(2, D, generator=g)
+    out = ops.add_pos_fwd(cu(x), cu(pos[:L]), cu(tt[0]))
+    close(out, x + pos[:L] + tt[0], atol=1e-6)
+    dpos = torch.zeros(L, D, device=DEV)
+    dy = torch.randn(B, L, D, generator=g)
+    ops.add_pos_bwd_(cu(dy), dpos)
+    close(dpos, dy.sum(0), atol=1e-4)

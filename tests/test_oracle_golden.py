@@ -203,3 +203,23 @@ def test_sampled_softmax_golden():
     loss.backward()
     g = gu.section(d, "g/")
     torch.testing.assert_close(p["tables"]["item_id"].grad, g[gu.CAT + "item_id.weight"], **TOL)
+
+
+@pytest.mark.parametrize("name,arch", [("gpt2_clm_item_train", "gpt2"), ("bert_mlm_item_train", "bert")])
+def test_gpt2_bert_block_golden(name, arch):
+    """inputs_embeds -> hidden of the reference's TransformerBlock(GPT2Config / BertConfig) fixtures."""
+    d = gu.load(name)
+    sd = gu.section(d, "p/")
+    pre = "heads.0.body.1.transformer."
+    x = gu.t(d["out/inputs_embeds"])
+    n = int(d["meta/n_head"])
+    if arch == "gpt2":
+        h = O.gpt2_model(x, O.gpt2_params_from_state(sd, pre), n, float(d["meta/eps"]))
+    else:
+        h = O.bert_model(x, O.bert_params_from_state(sd, pre), n, float(d["meta/eps"]))
+    torch.testing.assert_close(h, gu.t(d["out/hidden"]), **TOL)
+    # head on top (tied full softmax) reproduces the fixture's logits and loss
+    xr, y = O.remove_pad_rows(h, gu.t(d["out/masked_targets"]))
+    logits = O.head_logits(xr, sd[gu.CAT + "item_id.weight"])
+    torch.testing.assert_close(logits, gu.t(d["out/predictions"]), **TOL)
+    torch.testing.assert_close(O.cross_entropy(logits, y), gu.t(d["out/loss"]), **TOL)

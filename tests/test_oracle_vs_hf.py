@@ -37,3 +37,44 @@ def test_rel_shift_identity():
     idx = torch.arange(L)[None, :] + L - torch.arange(L)[:, None]
     got = torch.gather(x, 3, idx[None, None].expand(2, 3, L, L))
     assert torch.equal(ref, got)
+
+
+def _rand_init(m, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            ln = ("ln_" in n or "LayerNorm" in n or "layer_norm" in n) and n.endswith("weight")
+            p.copy_(1 + 0.1 * torch.randn(p.shape, generator=g) if ln else 0.1 * torch.randn(p.shape, generator=g))
+
+
+@pytest.mark.parametrize("B,L,D,n,layers", [(3, 20, 64, 4, 2), (2, 50, 32, 2, 1)])
+def test_gpt2_restatement_matches_hf(B, L, D, n, layers):
+    """config exactly as GPT2Config.build passes it (layer_norm_eps is ignored by HF -> 1e-5)."""
+    cfg = transformers.GPT2Config(n_embd=D, n_inner=4 * D, n_layer=layers, n_head=n, activation_function="gelu",
+                                  initializer_range=0.01, layer_norm_eps=0.03, resid_pdrop=0.0, embd_pdrop=0.0,
+                                  attn_pdrop=0.0, n_positions=L, n_ctx=L, vocab_size=1)
+    assert cfg.layer_norm_epsilon == 1e-5
+    m = transformers.GPT2Model(cfg).eval()
+    _rand_init(m, 0)
+    x = torch.randn(B, L, D)
+    with torch.no_grad():
+        ref = m(inputs_embeds=x)[0]
+        got = O.gpt2_model(x, O.gpt2_params_from_state(m.state_dict()), n, 1e-5)
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("B,L,D,n,layers", [(3, 20, 64, 4, 2), (2, 33, 32, 2, 1)])
+def test_bert_restatement_matches_hf(B, L, D, n, layers):
+    """config as BertConfig.build passes it: intermediate_size stays HF's 3072."""
+    cfg = transformers.BertConfig(hidden_size=D, num_hidden_layers=layers, num_attention_heads=n, hidden_act="gelu",
+                                  initializer_range=0.01, layer_norm_eps=0.03, pad_token_id=0,
+                                  max_position_embeddings=L + 2, vocab_size=1,
+                                  hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    assert cfg.intermediate_size == 3072
+    m = transformers.BertModel(cfg).eval()
+    _rand_init(m, 1)
+    x = torch.randn(B, L, D)
+    with torch.no_grad():
+        ref = m(inputs_embeds=x)[0]
+        got = O.bert_model(x, O.bert_params_from_state(m.state_dict()), n, 0.03)
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=2e-5)

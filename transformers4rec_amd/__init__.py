@@ -11,6 +11,7 @@ from .masking import CausalLanguageModeling, MaskedLanguageModeling, MaskSequenc
 from .features import (  # noqa: E402,F401
     SequenceEmbeddingFeatures, SoftEmbedding, SoftEmbeddingFeatures, TabularSequenceFeatures)
 from .transformer import TransformerBlock, XLNetConfig, XLNetModel  # noqa: E402,F401
+from .transformer_hf import BertConfig, BertModel, GPT2Config, GPT2Model  # noqa: E402,F401
 from .prediction_task import LogUniformSampler, NextItemPredictionTask  # noqa: E402,F401
 from .model import Head, Model  # noqa: E402,F401
 from .optim import FlatParams, FusedAdam, flatten_model  # noqa: E402,F401

@@ -423,6 +423,56 @@ extern "C" int t4r_dropout(void* stream, const float* x, float* out, unsigned ch
     return 0;
 }
 
+// ---------------------------------------------------------------- learned position (+ token type) embeddings
+// out[t, :] = x[t, :] + pos[t % L, :] (+ tt[:])      GPT-2: inputs_embeds + wpe (HF gpt2 :576-577)
+//                                                     BERT : + position + token_type(0) (HF bert embeddings)
+__global__ __launch_bounds__(256) void add_pos_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pos,
+                                                           const float* __restrict__ tt, float* __restrict__ out,
+                                                           long ntok, int L, int D) {
+    const int dq = D >> 2;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ntok * dq) return;
+    const long t = i / dq;
+    const int c = (int)(i % dq) * 4;
+    const int l = (int)(t % L);
+    float4 v = *reinterpret_cast<const float4*>(x + t * D + c);
+    const float4 p = *reinterpret_cast<const float4*>(pos + (long)l * D + c);
+    v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    if (tt) {
+        const float4 q = *reinterpret_cast<const float4*>(tt + c);
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+    }
+    *reinterpret_cast<float4*>(out + t * D + c) = v;
+}
+// d pos[l, :] += sum_b dy[b, l, :]   (16 batch chunks, one atomic per (chunk, l, column))
+__global__ __launch_bounds__(256) void add_pos_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dpos,
+                                                           int B, int L, int D) {
+    const int l = blockIdx.x, chunk = blockIdx.y, nchunk = gridDim.y;
+    for (int c = threadIdx.x; c < D; c += 256) {
+        float acc = 0.f;
+        for (int b = chunk; b < B; b += nchunk) acc += dy[((long)b * L + l) * D + c];
+        atomicAdd(dpos + (long)l * D + c, acc);
+    }
+}
+extern "C" int t4r_add_pos_fwd(void* stream, const float* x, const float* pos, const float* token_type,
+                               float* out, int B, int L, int D) {
+    const long ntok = (long)B * L;
+    if (ntok == 0) return 0;
+    T4R_CHECK_ARG(D % 4 == 0, "add_pos: D must be a multiple of 4");
+    const long n = ntok * (D / 4);
+    hipLaunchKernelGGL(add_pos_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       pos, token_type, out, ntok, L, D);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int t4r_add_pos_bwd(void* stream, const float* dy, float* d_pos, int B, int L, int D) {
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(add_pos_bwd_kernel, dim3(L, B < 16 ? B : 16), dim3(256), 0, (hipStream_t)stream, dy, d_pos, B,
+                       L, D);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---------------------------------------------------------------- fused Adam over a flat buffer
 // torch.optim.Adam (amsgrad=False, maximize=False): with step t (1-based)
 //   g = grad (+ wd * p) ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2

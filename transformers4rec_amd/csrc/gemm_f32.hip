@@ -25,7 +25,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_RELU = 3 };
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_RELU = 3, EPI_BIAS_RESID = 4 };
 
 struct GemmParams {
     int M, N, K;
@@ -268,6 +268,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                         if (p.drop.p > 0.f) v *= drop_scale(p.drop, (unsigned long long)row * p.N + col);
                     } else if (p.epilogue == EPI_BIAS_RELU) {
                         v = fmaxf(v + bv, 0.f);
+                    } else if (p.epilogue == EPI_BIAS_RESID) {
+                        // C = dropout(x + bias) + residual   (GPT-2: hidden + resid_dropout(c_proj(...)))
+                        v += bv;
+                        if (p.drop.p > 0.f) v *= drop_scale(p.drop, (unsigned long long)row * p.N + col);
+                        v += p.aux[(long)row * p.ldaux + col];
                     }
                     if (p.accumulate) v += *cp;
                     *cp = v;
@@ -372,10 +377,13 @@ int t4r_gemm_launch(hipStream_t stream, int transA, int transB, int M, int N, in
 extern "C" int t4r_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, float alpha,
                             const float* A, long lda, const float* B, long ldb, float* C, long ldc,
                             const float* bias, int epilogue, float* aux, long ldaux, int splitk,
-                            int accumulate, int batch, long strideA, long strideB, long strideC) {
+                            int accumulate, int batch, long strideA, long strideB, long strideC,
+                            float drop_p, unsigned long long seed, unsigned long long ctr_hi) {
+    T4R_CHECK_ARG(epilogue != EPI_BIAS_RESID || aux, "gemm: EPI_BIAS_RESID needs the residual in aux");
+    const DropCfg dc = make_drop(drop_p, seed, ctr_hi);
     return t4r_gemm_launch((hipStream_t)stream, transA, transB, M, N, K, alpha, A, lda, B, ldb, C,
                            ldc, bias, epilogue, aux, ldaux, splitk, accumulate, batch, strideA,
-                           strideB, strideC, nullptr);
+                           strideB, strideC, drop_p > 0.f ? &dc : nullptr);
 }
 
 // Head backward contractions with CrossEntropyLoss' backward fused into the A operand:

@@ -134,8 +134,8 @@ __global__ __launch_bounds__(64 * HeadsPerBlock<DH>::v) void xlnet_attn_bwd_kern
     float* Qs = Vs + L * LD;                 // [L][LD]
     float* dOs = Qs + L * LD;                // [L][LD]
     float* KRs = dOs + L * LD;               // [2L][LD]
-    float* dKR = KRs + 2 * L * LD;           // [2L][LD]   block accumulator
-    float* dSs = dKR + 2 * L * LD;           // [n][L][LS]
+    float* dKR = KRs + 2 * L * LD;           // [2L][LD]   block accumulator (shared k_r only)
+    float* dSs = dKR + (kr_bstride > 0 ? 0 : 2 * L * LD);   // [n][L][LS]
     float* Ps = dSs + n_head * L * LS;       // [n][L][LS]
     float* dRW = Ps + n_head * L * LS;       // [D]  block accumulators of d r_w_bias / d r_r_bias
     float* dRR = dRW + D;                    // [D]
@@ -144,10 +144,12 @@ __global__ __launch_bounds__(64 * HeadsPerBlock<DH>::v) void xlnet_attn_bwd_kern
     const int h = blockIdx.y * HeadsPerBlock<DH>::v + (tid >> 6);       // one head per wave
     const bool hvalid = h < n_head;
     const int dq4 = D / 4;
-    for (int i = tid; i < 2 * L * dq4; i += nthr) {
-        const int r = i / dq4, c = (i % dq4) * 4;
-        *reinterpret_cast<float4*>(KRs + r * LD + c) = *reinterpret_cast<const float4*>(kr + (long)r * D + c);
-        *reinterpret_cast<float4*>(dKR + r * LD + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kr_bstride == 0) {
+        for (int i = tid; i < 2 * L * dq4; i += nthr) {
+            const int r = i / dq4, c = (i % dq4) * 4;
+            *reinterpret_cast<float4*>(KRs + r * LD + c) = *reinterpret_cast<const float4*>(kr + (long)r * D + c);
+            *reinterpret_cast<float4*>(dKR + r * LD + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
     for (int i = tid; i < 2 * D; i += nthr) dRW[i] = 0.f;
 
@@ -302,7 +304,8 @@ __global__ __launch_bounds__(64 * HeadsPerBlock<DH>::v) void xlnet_attn_bwd_kern
     __syncthreads();
     // block partials -> workspace
     float* mypart = part + ((long)blockIdx.y * gridDim.x + blockIdx.x) * (2 * L * D + 2 * D);
-    for (int i = tid; i < 2 * L * D; i += nthr) mypart[i] = dKR[(i / D) * LD + (i % D)];
+    if (kr_bstride == 0)
+        for (int i = tid; i < 2 * L * D; i += nthr) mypart[i] = dKR[(i / D) * LD + (i % D)];
     for (int i = tid; i < 2 * D; i += nthr) mypart[2 * L * D + i] = dRW[i];
 }
 
@@ -310,11 +313,11 @@ int t4r_reduce_partials_launch(hipStream_t st, const float* part, int nblocks, f
                                float* o1, int n1, int a1, float* o2, int n2, int a2);
 
 static size_t attn_fwd_smem(int L, int D) { return (size_t)(4 * L) * (D + ATT_PAD) * sizeof(float); }
-static size_t attn_bwd_smem(int L, int D, int n) {
-    return ((size_t)(8 * L) * (D + ATT_PAD) + (size_t)2 * n * L * (L + 1) + 2 * D) * sizeof(float);
+static size_t attn_bwd_smem(int L, int D, int n, int per_batch_kr = 0) {
+    return ((size_t)((per_batch_kr ? 6 : 8) * L) * (D + ATT_PAD) + (size_t)2 * n * L * (L + 1) + 2 * D) * sizeof(float);
 }
 
-extern "C" int t4r_xlnet_attn_bwd_blocks(int B) { return B < 512 ? B : 512; }
+extern "C" int t4r_xlnet_attn_bwd_blocks(int B) { return B < 1024 ? B : 1024; }
 extern "C" long t4r_xlnet_attn_bwd_ws_floats(int B, int L, int D, int n_head) {
     const int hpb = (D / n_head) >= 32 ? 4 : 8;
     return (long)t4r_xlnet_attn_bwd_blocks(B) * ((n_head + hpb - 1) / hpb) * (2L * L * D + 2L * D);
@@ -372,7 +375,7 @@ static int attn_bwd_launch(hipStream_t st, const float* q, const float* k, const
                            float* part, float* dkr, float* d_rw, float* d_rr, int B, int L, int n_head,
                            float scale, long kr_bstride, DropCfg drop) {
     const int D = n_head * DH;
-    const size_t smem = attn_bwd_smem(L, D, n_head);
+    const size_t smem = attn_bwd_smem(L, D, n_head, kr_bstride > 0);
     static size_t attr = 0;
     if (smem > attr) {
         (void)hipFuncSetAttribute((const void*)xlnet_attn_bwd_kernel<DH>,

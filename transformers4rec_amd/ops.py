@@ -7,7 +7,7 @@ import torch
 from . import _lib
 from ._lib import call, int_array, long_array, ptr_array
 
-EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU = 0, 1, 2, 3
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_BIAS_RESID = 0, 1, 2, 3, 4
 AGG = {"concat": 0, "element-wise-sum": 1, "element-wise-sum-item-multi": 2}
 MASK_NONE, MASK_MLM, MASK_CLM, MASK_CLM_INFER = 0, 1, 2, 3
 MLM_TRAIN, MLM_EVAL_LAST, MLM_EVAL_ALL, MLM_INFER, CLM_TRAIN, CLM_LAST, CLM_INFER = range(7)
@@ -38,7 +38,7 @@ def pad_ld(V):
 
 # ------------------------------------------------------------------------------------ GEMM
 def gemm(a, b, trans_a=False, trans_b=False, alpha=1.0, bias=None, epilogue=EPI_NONE, out=None,
-         aux=None, splitk=1, accumulate=False, ldc=None):
+         aux=None, splitk=1, accumulate=False, ldc=None, drop=(0.0, 0, 0)):
     """out[M,N] = alpha * op(a) @ op(b) (+epilogue).  a, b 2-D row-major fp32."""
     M = a.shape[1] if trans_a else a.shape[0]
     K = a.shape[0] if trans_a else a.shape[1]
@@ -58,7 +58,7 @@ def gemm(a, b, trans_a=False, trans_b=False, alpha=1.0, bias=None, epilogue=EPI_
          a.data_ptr(), lda, b.data_ptr(), ldb, out.data_ptr(), ldc,
          _p(bias, torch.float32, "bias"), int(epilogue),
          None if aux is None else aux.data_ptr(), 0 if aux is None else aux.stride(0),
-         int(splitk), int(accumulate), 1, 0, 0, 0)
+         int(splitk), int(accumulate), 1, 0, 0, 0, float(drop[0]), int(drop[1]), int(drop[2]))
     return out
 
 
@@ -297,6 +297,47 @@ def xlnet_attn_bwd(q, k, v, k_r, r_w_bias, r_r_bias, out, lse, dout, d_rw, d_rr,
          dkr.data_ptr(), _chk(d_rw), _chk(d_rr), ws.data_ptr(), B, L, n_head, D // n_head, per_b,
          float(drop[0]), int(drop[1]), int(drop[2]))
     return dq, dk, dv, dkr
+
+
+def mha_fwd(q, k, v, B, L, n_head, causal, drop=NO_DROP):
+    """q,k,v: [B*L, D] views that may be column slices of one [B*L, 3D] buffer (row stride = ld)."""
+    D = q.shape[1]
+    ld = q.stride(0)
+    assert k.stride(0) == ld and v.stride(0) == ld and q.stride(1) == 1
+    out = torch.empty((B * L, D), device=q.device, dtype=torch.float32)
+    lse = torch.empty((B, n_head, L), device=q.device, dtype=torch.float32)
+    call("t4r_mha_fwd", _stream(), q.data_ptr(), k.data_ptr(), v.data_ptr(), ld, out.data_ptr(), D,
+         lse.data_ptr(), B, L, n_head, D // n_head, int(causal), float(drop[0]), int(drop[1]), int(drop[2]))
+    return out, lse
+
+
+def mha_bwd(q, k, v, out, lse, dout, B, L, n_head, causal, drop=NO_DROP, fused_out=False):
+    """-> dq, dk, dv.  fused_out: one [B*L, 3D] buffer (column blocks q|k|v), returned as the single tensor."""
+    D = q.shape[1]
+    ld = q.stride(0)
+    dev = q.device
+    if fused_out:
+        buf = torch.empty((B * L, 3 * D), device=dev, dtype=torch.float32)
+        dq, dk, dv, ldd = buf[:, :D], buf[:, D:2 * D], buf[:, 2 * D:], 3 * D
+    else:
+        dq, dk, dv = (torch.empty((B * L, D), device=dev, dtype=torch.float32) for _ in range(3))
+        buf, ldd = None, D
+    call("t4r_mha_bwd", _stream(), q.data_ptr(), k.data_ptr(), v.data_ptr(), ld, _chk(out), _chk(dout), D,
+         _chk(lse), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ldd, B, L, n_head, D // n_head, int(causal),
+         float(drop[0]), int(drop[1]), int(drop[2]))
+    return buf if fused_out else (dq, dk, dv)
+
+
+def add_pos_fwd(x, pos, token_type=None):
+    B, L, D = x.shape
+    out = torch.empty_like(x)
+    call("t4r_add_pos_fwd", _stream(), _chk(x, torch.float32), _chk(pos), _p(token_type), out.data_ptr(), B, L, D)
+    return out
+
+
+def add_pos_bwd_(dy, d_pos):
+    B, L, D = dy.shape
+    call("t4r_add_pos_bwd", _stream(), _chk(dy), _chk(d_pos), B, L, D)
 
 
 XLNET_PARAM_ORDER = ("q", "k", "v", "o", "r", "r_w_bias", "r_r_bias", "ln1_w", "ln1_b", "w1", "b1",

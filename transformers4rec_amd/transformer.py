@@ -226,28 +226,35 @@ class XLNetModel(nn.Module):
 class TransformerBlock(nn.Module):
     """Drop-in for tr.TransformerBlock (block/transformer.py:76-206) with the XLNet body on HIP."""
 
-    SUPPORTED_MASKING = (MaskedLanguageModeling, CausalLanguageModeling)
-
     def __init__(self, transformer, masking: Optional[MaskSequence] = None, prepare_module=None):
         super().__init__()
-        if isinstance(transformer, XLNetConfig):
+        from .transformer_hf import BertConfig, BertModel, GPT2Config, GPT2Model
+
+        if isinstance(transformer, (XLNetConfig, GPT2Config, BertConfig)):
             self.transformer = transformer.to_huggingface_torch_model()
-        elif isinstance(transformer, XLNetModel):
+        elif isinstance(transformer, (XLNetModel, GPT2Model, BertModel)):
             self.transformer = transformer
         else:
-            raise TypeError("TransformerBlock on the HIP path takes an XLNetConfig or XLNetModel")
-        if masking is not None and not isinstance(masking, self.SUPPORTED_MASKING):
-            raise ValueError(f"{masking.__class__.__name__} is not supported by: the XLNetConfig architecture")
+            raise TypeError("TransformerBlock on the HIP path takes an XLNet / GPT-2 / BERT config or model")
+        # MappingTransformerMasking (torch/utils/torch_utils.py:441-473)
+        allowed = {XLNetModel: (MaskedLanguageModeling, CausalLanguageModeling),
+                   GPT2Model: (CausalLanguageModeling,), BertModel: (MaskedLanguageModeling,)}[type(self.transformer)]
+        if masking is not None and not isinstance(masking, allowed):
+            raise ValueError(f"{masking.__class__.__name__} is not supported by: "
+                             f"the {self.transformer.config_class.__name__} architecture")
         self.masking = masking
         self.prepare_module = None
 
     @classmethod
     def from_registry(cls, transformer: str, d_model: int, n_head: int, n_layer: int, total_seq_length: int,
                       masking: Optional[MaskSequence] = None):
-        if transformer != "xlnet":
-            raise KeyError(f"{transformer} never registered with the HIP transformer registry (supported: xlnet)")
-        return cls(XLNetConfig.build(d_model=d_model, n_head=n_head, n_layer=n_layer,
-                                     total_seq_length=total_seq_length), masking)
+        from .transformer_hf import BertConfig, GPT2Config
+
+        reg = {"xlnet": XLNetConfig, "gtp2": GPT2Config, "gpt2": GPT2Config, "bert": BertConfig}
+        if transformer not in reg:
+            raise KeyError(f"{transformer} never registered with the HIP transformer registry (supported: {sorted(reg)})")
+        return cls(reg[transformer].build(d_model=d_model, n_head=n_head, n_layer=n_layer,
+                                          total_seq_length=total_seq_length), masking)
 
     def forward(self, inputs_embeds, **kwargs):
         # the reference passes inputs_embeds only for XLNet + MLM/CLM (block/transformer.py:183-199)

@@ -318,3 +318,55 @@ def test_gpt2_bert_training_mode_dropout_and_masking_rules(arch):
                                                    embedding_dim_default=D)
     with pytest.raises(ValueError, match="is not supported by"):
         tr.TransformerBlock(cfg, masking=wrong.masking)
+
+
+@pytest.mark.parametrize("multi", [False, True])
+def test_full_size_step_vs_oracle(multi):
+    """BASELINE.json configs[1] (item-id only) and configs[2] (multi-feature) at FULL size: one
+    training step (dropout 0) on the HIP path vs the CPU oracle on the same device-drawn mask."""
+    import transformers4rec_amd as tr
+
+    torch.manual_seed(0)
+    torch.set_num_threads(32)
+    B, L, V, D = 1024, 20, 100_000, 128
+    cats = (("category", 1000), ("brand", 100), ("kind", 10)) if multi else ()
+    conts = ("price", "age") if multi else ()
+    schema = tr.session_schema(V, L, cats, conts)
+    kw = dict(max_sequence_length=L, masking="mlm")
+    if multi:
+        kw.update(continuous_soft_embeddings=True, d_output=D, embedding_dims={"item_id": D}, embedding_dim_default=64)
+    else:
+        kw.update(embedding_dim_default=D)
+    inputs = tr.TabularSequenceFeatures.from_schema(schema, **kw)
+    cfg = tr.XLNetConfig.build(D, 4, 4, total_seq_length=L, dropout=0.0)
+    model = cfg.to_torch_model(inputs, tr.NextItemPredictionTask(weight_tying=True))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(DEV)
+    data = tr.random_data_from_schema(schema, B, L, seed=11)
+    out = model({k: v.to(DEV) for k, v in data.items()}, training=True)
+    out["loss"].backward()
+    m = model.input_features.masking
+    mask, labels = m.mask_schema.cpu(), m.masked_targets.cpu()
+    # reference invariants of the device-drawn mask at full size (test_masking.py:117-150)
+    ids = data["item_id"]
+    assert bool((mask.sum(1) >= 1).all()) and bool((mask.sum(1) < (ids != 0).sum(1)).all())
+    assert torch.equal(labels, torch.where(mask, ids, torch.zeros_like(ids)))
+    p = gu.oracle_params({"p/" + k: v.numpy() for k, v in sd.items()}, requires_grad=True)
+    ref = O.session_forward(p, dict(n_head=4, eps=0.03, item="item_id", masking="mlm"), data, mask, labels, True, False)
+    ref["loss"].backward()
+    assert abs(float(out["loss"].detach()) - float(ref["loss"])) < 1e-4
+    assert abs(float(ref["loss"]) - np.log(V + 1)) < 0.2                 # ~ln(V) at init
+    assert torch.equal(out["labels"].cpu(), ref["labels"])
+    assert float((out["predictions"].detach().cpu() - ref["logits"].detach()).abs().max()) < 1e-4
+    g_hip = model.input_features.item_embedding_table.weight.grad.cpu()
+    g_ref = p["tables"]["item_id"].grad
+    close(g_hip, g_ref, rtol=1e-3, atol=2e-7)
+    # checksum: softmax-CE rows sum to zero => the head's contribution to sum_v dW[v,:] vanishes;
+    # what remains is the lookup scatter, identical on both sides
+    close(g_hip.sum(0), g_ref.sum(0), rtol=1e-3, atol=1e-6)
+    lw = model.transformer_block.transformer.layer[0].ff.layer_1.weight.grad.cpu()
+    close(lw, p["layers"][0]["w1"].grad, rtol=2e-3, atol=2e-7)
+    if multi:
+        close(model.input_features.projection_module[0][0].weight.grad, p["proj"][0].grad, rtol=2e-3, atol=2e-7)
+        close(model.input_features.continuous_module.embedding_tables["price"].embedding_table.weight.grad,
+              p["soft"]["price"][2].grad, rtol=2e-3, atol=2e-6)

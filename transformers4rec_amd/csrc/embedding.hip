@@ -158,6 +158,8 @@ extern "C" int t4r_seq_features_fwd(
     p.agg = agg; p.item_feat = item_feat;
     p.B = B; p.L_in = L_in; p.L_out = L_out; p.W = W;
     p.mask_mode = mask_mode; p.mask = mask; p.masked_emb = masked_emb; p.out = out; p.err = err_flag;
+    // (a single-table fast path with 2-4 row reads in flight per lane was measured: 10.8-13.2 us vs
+    //  8.7 us for this kernel at C2 -- at 21 MB the launch ramp dominates, occupancy beats ILP)
     const int g = pick_group(W);
     const long threads = (long)B * L_out * g;
     dim3 grid((unsigned)((threads + 255) / 256));

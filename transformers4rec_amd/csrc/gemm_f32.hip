@@ -199,6 +199,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         }
     };
 
+    // (a second, independent accumulator chain per tile was measured: no gain -- the 64-cycle
+    //  dependent-accumulator latency equals the issue interval of v_mfma_f32_32x32x2_f32)
     f32x16 acc[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -221,6 +223,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         if (more) load_tiles(kt + 1);
         const float* as = As + buf * BK * LDA_S;
         const float* bs = Bs + buf * BK * LDB_S;
+        // (fetching all fragments of the k-tile before the MFMAs was measured: slower in the full
+        //  step -- one more VGPR bank costs a resident wave; the simple per-step form stays)
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             const int k = 2 * kk + khalf;

@@ -49,6 +49,8 @@ int t4r_ragged_to_padded(void* stream, const void* values, const long* offsets, 
  *           masking.py:473-498 / :302-337 (apply_mask_to_inputs) when mask_mode != 0.
  * kind[f] 0: table lookup, input[f] = int64 ids [B*L_in], table[f] = [rows[f], dim[f]]
  *         1: dense rows, input[f] = fp32 [B*L_in, dim[f]] (soft embeddings, continuous pass-through)
+ *         2: per-session table lookup (a3), input[f] = int64 ids [B], the row is broadcast over the
+ *            sequence (features/embedding.py:229-240 2-D branch + tabular/base.py:53-63)
  * agg 0 concat (col[f] = first output column) | 1 sum | 2 item * sum(others) (item_feat = index)
  * mask_mode 0 none | 1 MLM (out = mask ? memb : x) | 2 CLM train/eval (mask ? (l==L-1 ? 0 : x) : memb)
  *           | 3 CLM inference (mask ? x : memb).  L_out = L_in + 1 is the MLM-inference grid
@@ -61,9 +63,10 @@ int t4r_seq_features_fwd(void* stream, int n_feat, const int* kind, const void* 
                          const unsigned char* mask, const float* masked_emb, float* out,
                          int* err_flag);
 /* backward of one table lookup: d_table[id, :] += dout[tok, col:col+dim] for id != padding_idx
- * (nn.Embedding(padding_idx=0), features/sequence.py:75-81).  d_table accumulated. */
+ * (nn.Embedding(padding_idx=0), features/sequence.py:75-81).  d_table accumulated.
+ * ids_div = 1 (ids [B*L]) or L (per-session ids [B]: id index = tok / L). */
 int t4r_embedding_bwd(void* stream, const float* dout, const long* ids, float* d_table, long ntok,
-                      int W, int col, int dim, long rows, int padding_idx);
+                      int W, int col, int dim, long rows, int padding_idx, int ids_div);
 /* masking as its own pass (after the projection MLP), in place on x [B*L, H]; and its backward:
  * d_memb[H] += sum of dy over replaced tokens (accumulated), dy zeroed there (in place). */
 int t4r_apply_mask_fwd(void* stream, float* x, const unsigned char* mask, const float* masked_emb,

@@ -246,6 +246,23 @@ def main():
     save("bert_mlm_item_infer", run(mB, xB, False, False, False, with_params=False), n_head=nh, d_model=d,
          n_layer=1, eps=0.03, L=L, V=V + 1)
 
+    # J: a per-session (non-list) categorical context feature: [B] ids -> nn.Embedding -> [B, D],
+    #    broadcast over L by ConcatFeatures._expand_non_sequential_features (tabular/base.py:53-63)
+    colsJ = [ColumnSchema("item_id", tags=[Tags.CATEGORICAL, Tags.ITEM_ID, Tags.LIST, Tags.ITEM],
+                          int_domain=_IntDomain(0, V), value_count=_ValueCount(1, L)),
+             ColumnSchema("country", tags=[Tags.CATEGORICAL], int_domain=_IntDomain(0, 17))]
+    torch.manual_seed(90)
+    inJ = tr.TabularSequenceFeatures.from_schema(Schema(colsJ), max_sequence_length=L, masking="mlm",
+                                                 aggregation="concat", d_output=d,
+                                                 embedding_dims={"item_id": 24, "country": 8})
+    cfgJ = tr.XLNetConfig.build(d_model=d, n_head=nh, n_layer=1, total_seq_length=L, dropout=0.0)
+    mJ = cfgJ.to_torch_model(inJ, tr.NextItemPredictionTask(weight_tying=True))
+    reinit(mJ, 91)
+    xJ = synth_inputs(B, L, V, (), (), seed=92)
+    xJ["country"] = torch.randint(1, 18, (B,), generator=torch.Generator().manual_seed(93))
+    save("xlnet_mlm_context_train", run(mJ, xJ, True, False, True), n_head=nh, d_model=d, n_layer=1,
+         eps=0.03, L=L, V=V + 1)
+
     # F: masking-only integer fixture, many rows (lengths 1..L incl. full rows)
     Bm = 96
     msk = tr.masking.MaskedLanguageModeling(hidden_size=4, mlm_probability=0.3)

@@ -25,11 +25,14 @@ def close(a, b, **kw):
 
 
 def build_model(d, cats=(), conts=(), masking="mlm", aggregation="concat", d_output=None,
-                embedding_dims=None, emb_default=None, weight_tying=True, sampled=False, max_n=100, arch="xlnet"):
+                embedding_dims=None, emb_default=None, weight_tying=True, sampled=False, max_n=100, arch="xlnet",
+                context=()):
     import transformers4rec_amd as tr
 
     L, V = int(d["meta/L"]), int(d["meta/V"])
     schema = tr.session_schema(V - 1, L, cats, conts)
+    for name, card in context:   # per-session categorical (no LIST tag, [B] ids)
+        schema = schema + tr.Schema([tr.ColumnSchema(name, [tr.Tags.CATEGORICAL], tr.IntDomain(0, card))])
     kw = dict(max_sequence_length=L, masking=masking, aggregation=aggregation)
     if d_output:
         kw["d_output"] = d_output
@@ -90,6 +93,8 @@ def run_train_case(name, **build_kw):
     ("xlnet_mlm_multi_train", dict(cats=(("category", 40), ("brand", 9)), conts=("price", "age"), d_output=32,
                                    embedding_dims={"item_id": 16, "category": 24, "brand": 8})),
     ("xlnet_clm_item_train", dict(masking="clm", emb_default=32, weight_tying=False)),
+    ("xlnet_mlm_context_train", dict(context=(("country", 17),), d_output=32,
+                                     embedding_dims={"item_id": 24, "country": 8})),
     ("gpt2_clm_item_train", dict(masking="clm", emb_default=32, arch="gpt2")),
     ("bert_mlm_item_train", dict(emb_default=32, arch="bert")),
 ])

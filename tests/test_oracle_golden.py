@@ -93,6 +93,7 @@ def test_log_uniform_golden():
     ("xlnet_mlm_item_train", "mlm", "concat"),
     ("xlnet_mlm_multi_train", "mlm", "concat"),
     ("xlnet_clm_item_train", "clm", "concat"),
+    ("xlnet_mlm_context_train", "mlm", "concat"),
 ])
 def test_train_forward_backward_golden(name, masking, agg):
     d = gu.load(name)

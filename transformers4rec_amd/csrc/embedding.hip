@@ -25,8 +25,8 @@ enum { MASK_NONE = 0, MASK_MLM = 1, MASK_CLM = 2, MASK_CLM_INFER = 3 };
 
 struct SeqFeatParams {
     int n_feat;
-    int kind[T4R_MAX_FEATS];          // 0 categorical table lookup, 1 dense rows (precomputed)
-    const void* input[T4R_MAX_FEATS]; // kind 0: int64 ids [B*L_in] ; kind 1: float [B*L_in, dim]
+    int kind[T4R_MAX_FEATS];          // 0 table lookup, 1 dense rows (precomputed), 2 per-session table lookup
+    const void* input[T4R_MAX_FEATS]; // kind 0: int64 ids [B*L_in] ; 1: float [B*L_in, dim] ; 2: int64 ids [B]
     const float* table[T4R_MAX_FEATS];
     int dim[T4R_MAX_FEATS];
     int col[T4R_MAX_FEATS];           // output column offset (concat) / 0 (sum)
@@ -80,8 +80,10 @@ __global__ __launch_bounds__(256) void seq_features_fwd_kernel(SeqFeatParams p) 
                 }
                 float fv[4] = {0.f, 0.f, 0.f, 0.f};
                 const float* row;
-                if (p.kind[f] == 0) {
-                    long id = reinterpret_cast<const long*>(p.input[f])[ts];
+                if (p.kind[f] == 0 || p.kind[f] == 2) {
+                    // kind 2: a non-sequential (context) feature, one id per session, broadcast over
+                    // the sequence (ConcatFeatures._expand_non_sequential_features, tabular/base.py:53-63)
+                    long id = reinterpret_cast<const long*>(p.input[f])[p.kind[f] == 2 ? (long)b : ts];
                     if (id < 0 || id >= p.rows[f]) { if (p.err) *p.err = 1; id = 0; }
                     row = p.table[f] + id * p.dim[f];
                 } else {
@@ -153,6 +155,7 @@ extern "C" int t4r_seq_features_fwd(
         p.kind[f] = kind[f]; p.input[f] = input[f]; p.table[f] = table[f]; p.dim[f] = dim[f];
         p.col[f] = col ? col[f] : 0; p.rows[f] = rows ? rows[f] : 0;
         T4R_CHECK_ARG(input[f] && (kind[f] == 1 || table[f]), "seq_features: null feature pointer");
+        T4R_CHECK_ARG(kind[f] >= 0 && kind[f] <= 2, "seq_features: feature kind 0..2");
         if (agg != AGG_CONCAT) T4R_CHECK_ARG(dim[f] == W, "seq_features: element-wise needs equal dims");
     }
     p.agg = agg; p.item_feat = item_feat;
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restr
                                                              float* __restrict__ dtable, long ntok,
                                                              int W, int col, int dim, long rows,
                                                              int padding_idx, int tok_per_block,
-                                                             int use_lds) {
+                                                             int use_lds, int ids_div) {
     extern __shared__ float lds[];
     const long t0 = (long)blockIdx.x * tok_per_block;
     const long t1 = min(ntok, t0 + tok_per_block);
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restr
         for (int i = threadIdx.x; i < n; i += 256) lds[i] = 0.f;
         __syncthreads();
         for (long t = t0; t < t1; ++t) {
-            const long id = ids[t];
+            const long id = ids[t / ids_div];
             if (id == padding_idx || id < 0 || id >= rows) continue;
             for (int c = threadIdx.x; c < dim; c += 256)
                 atomicAdd(&lds[id * dim + c], dout[t * W + col + c]);
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restr
     } else {
         const int dq = dim;  // one lane per column, tokens striped over waves
         for (long t = t0 + (threadIdx.x / 64); t < t1; t += 4) {
-            const long id = ids[t];
+            const long id = ids[t / ids_div];
             if (id == padding_idx || id < 0 || id >= rows) continue;
             for (int c = threadIdx.x & 63; c < dq; c += 64)
                 atomicAdd(dtable + id * dim + c, dout[t * W + col + c]);
@@ -285,15 +288,18 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restr
     }
 }
 
+// ids_div: 1 for sequence features (one id per token), L for per-session features (id index = tok / L)
 extern "C" int t4r_embedding_bwd(void* stream, const float* dout, const long* ids, float* dtable,
-                                 long ntok, int W, int col, int dim, long rows, int padding_idx) {
+                                 long ntok, int W, int col, int dim, long rows, int padding_idx,
+                                 int ids_div) {
     if (ntok == 0) return 0;
+    T4R_CHECK_ARG(ids_div >= 1, "embedding_bwd: ids_div >= 1");
     const int use_lds = rows * dim * 4 <= 48 * 1024;
     const int tpb = use_lds ? 256 : 32;
     const size_t smem = use_lds ? (size_t)rows * dim * 4 : 0;
     hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)((ntok + tpb - 1) / tpb)), dim3(256), smem,
                        (hipStream_t)stream, dout, ids, dtable, ntok, W, col, dim, rows, padding_idx,
-                       tpb, use_lds);
+                       tpb, use_lds, ids_div);
     T4R_LAUNCH_CHECK();
     return 0;
 }

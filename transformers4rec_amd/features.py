@@ -121,7 +121,10 @@ class _SeqFeaturesFn(torch.autograd.Function):
             col, dim = mod._cols[name], mod._dims[name]
             if name in cat.embedding_tables:
                 tab = cat.embedding_tables[name].weight
-                feats.append(dict(kind=0, input=inputs[name].contiguous(), table=tab.detach(), dim=dim,
+                ids_f = inputs[name].contiguous()
+                # a [B] id tensor is a non-sequential (context) feature: looked up once per session
+                # and broadcast over L (reference: tabular/base.py:53-63)
+                feats.append(dict(kind=2 if ids_f.ndim == 1 else 0, input=ids_f, table=tab.detach(), dim=dim,
                                   col=col, rows=tab.shape[0]))
             else:
                 se = cont.embedding_tables[name]

@@ -178,10 +178,12 @@ def seq_features_fwd(feats, agg, B, L_in, L_out, W, item_feat=-1, mask_mode=MASK
 
 
 def embedding_bwd(dout, ids, d_table, col, dim, padding_idx=0):
-    ntok = ids.numel()
+    """ids [B, L] (sequence feature) or [B] (per-session context feature, gradient summed over L)"""
     W = dout.shape[-1]
+    ntok = dout.numel() // W
+    ids_div = ntok // ids.numel()
     call("t4r_embedding_bwd", _stream(), _chk(dout, torch.float32), _chk(ids, torch.int64),
-         _chk(d_table, torch.float32), ntok, W, col, dim, d_table.shape[0], padding_idx)
+         _chk(d_table, torch.float32), ntok, W, col, dim, d_table.shape[0], padding_idx, ids_div)
 
 
 def apply_mask_fwd_(x, mask, memb, mode):

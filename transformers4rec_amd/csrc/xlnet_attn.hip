@@ -309,6 +309,188 @@ __global__ __launch_bounds__(64 * HeadsPerBlock<DH>::v) void xlnet_attn_bwd_kern
     for (int i = tid; i < 2 * D; i += nthr) mypart[2 * L * D + i] = dRW[i];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward, pair-decomposed (used when L <= 32): ONE WAVE per (session, head), all 64 lanes busy.
+//   stage A: lanes stride over the L*L (i, j) pairs: recompute p_ij, form dS_ij and the dropped
+//            probability, park both in LDS;
+//   stage B: lanes stride over (row, 4-column chunk) output items and contract dS / P against the
+//            LDS-resident rows:  dq_i = sum_j dS_ij (k_j + k_r[j+L-i]),  dk_j = sum_i dS_ij (q_i + r_w),
+//            dv_j = sum_i Pd_ij dO_i,  dk_r[p] = sum_i dS_{i,p-L+i} (q_i + r_r).
+// The lane-per-row kernel above keeps 20 of 64 lanes busy at 4 waves/CU (230 us per layer at C2);
+// this form needs ~21 KB LDS per wave (7 waves/CU) and every lane works.
+#define PAIRS_NKR 8
+template <int DH>
+__global__ __launch_bounds__(64) void xlnet_attn_bwd_pairs_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    const float* __restrict__ kr, const float* __restrict__ r_w_bias, const float* __restrict__ r_r_bias,
+    const float* __restrict__ out, const float* __restrict__ lse, const float* __restrict__ dout,
+    float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv, float* __restrict__ part,
+    float* __restrict__ dkr_b, int B, int L, int n_head, float scale, long kr_bstride, DropCfg drop) {
+    constexpr int LDH = DH + 4;
+    constexpr int C = DH / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int LS = L + 1;
+    float* Qw = smem;                  // [L][LDH]   q + r_w_bias
+    float* Ks = Qw + L * LDH;          // [L][LDH]
+    float* Vs = Ks + L * LDH;          // [L][LDH]
+    float* dOs = Vs + L * LDH;         // [L][LDH]
+    float* KRs = dOs + L * LDH;        // [2L][LDH]
+    float* dSs = KRs + 2 * L * LDH;    // [L][LS]
+    float* Pds = dSs + L * LS;         // [L][LS]
+    float* Drow = Pds + L * LS;        // [L]
+    float* Lrow = Drow + L;            // [L]
+    const int D = n_head * DH;
+    const int h = blockIdx.y, hc = h * DH;
+    const int lane = threadIdx.x;
+    const int myc = lane % C;          // this lane's 4-column chunk in every stage-B item (64 % C == 0)
+    const float4 rw4 = *reinterpret_cast<const float4*>(r_w_bias + hc + 4 * myc);
+    const float4 rr4 = *reinterpret_cast<const float4*>(r_r_bias + hc + 4 * myc);
+    const float4 del4 = make_float4(rr4.x - rw4.x, rr4.y - rw4.y, rr4.z - rw4.z, rr4.w - rw4.w);
+    float4 acc_rw = make_float4(0.f, 0.f, 0.f, 0.f), acc_rr = acc_rw;
+    float4 gkr[PAIRS_NKR];
+#pragma unroll
+    for (int u = 0; u < PAIRS_NKR; ++u) gkr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int n_kr_items = 2 * L * C;
+
+    auto load_kr = [&](long boff) {
+        for (int idx = lane; idx < 2 * L * C; idx += 64) {
+            const int r = idx / C, c4 = idx % C;
+            *reinterpret_cast<float4*>(KRs + r * LDH + 4 * c4) =
+                *reinterpret_cast<const float4*>(kr + boff + (long)r * D + hc + 4 * c4);
+        }
+    };
+    if (kr_bstride == 0) load_kr(0);
+
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();
+        if (kr_bstride > 0) load_kr((long)b * kr_bstride);
+        for (int idx = lane; idx < L * C; idx += 64) {
+            const int r = idx / C, c4 = idx % C;     // c4 == myc
+            const long g = ((long)b * L + r) * D + hc + 4 * c4;
+            float4 t = *reinterpret_cast<const float4*>(q + g);
+            t.x += rw4.x; t.y += rw4.y; t.z += rw4.z; t.w += rw4.w;
+            *reinterpret_cast<float4*>(Qw + r * LDH + 4 * c4) = t;
+            *reinterpret_cast<float4*>(Ks + r * LDH + 4 * c4) = *reinterpret_cast<const float4*>(k + g);
+            *reinterpret_cast<float4*>(Vs + r * LDH + 4 * c4) = *reinterpret_cast<const float4*>(v + g);
+            *reinterpret_cast<float4*>(dOs + r * LDH + 4 * c4) = *reinterpret_cast<const float4*>(dout + g);
+        }
+        if (lane < L) {
+            const float* orow = out + ((long)b * L + lane) * D + hc;
+            const float* grow = dout + ((long)b * L + lane) * D + hc;
+            float dsum = 0.f;
+#pragma unroll
+            for (int d = 0; d < DH; d += 4) {
+                const float4 a = *reinterpret_cast<const float4*>(orow + d);
+                const float4 e = *reinterpret_cast<const float4*>(grow + d);
+                dsum += a.x * e.x + a.y * e.y + a.z * e.z + a.w * e.w;
+            }
+            Drow[lane] = dsum;
+            Lrow[lane] = lse[((long)b * n_head + h) * L + lane];
+        }
+        __syncthreads();
+        // ---- stage A: (i, j) pairs
+        const unsigned long long mbase = (unsigned long long)(b * n_head + h) * L;
+        for (int p = lane; p < L * L; p += 64) {
+            const int i = p / L, j = p - i * L;
+            const float* qi = Qw + i * LDH;
+            const float* kj = Ks + j * LDH;
+            const float* krp = KRs + (j + L - i) * LDH;
+            const float* gi = dOs + i * LDH;
+            const float* vj = Vs + j * LDH;
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < DH; d += 4) {
+                const float4 a = *reinterpret_cast<const float4*>(qi + d);
+                const float4 bk = *reinterpret_cast<const float4*>(kj + d);
+                const float4 ck = *reinterpret_cast<const float4*>(krp + d);
+                const float4 e = *reinterpret_cast<const float4*>(gi + d);
+                const float4 f = *reinterpret_cast<const float4*>(vj + d);
+                const float4 dl = *reinterpret_cast<const float4*>(r_r_bias + hc + d);
+                const float4 dw = *reinterpret_cast<const float4*>(r_w_bias + hc + d);
+                s += a.x * bk.x + a.y * bk.y + a.z * bk.z + a.w * bk.w;
+                s += (a.x + dl.x - dw.x) * ck.x + (a.y + dl.y - dw.y) * ck.y + (a.z + dl.z - dw.z) * ck.z +
+                     (a.w + dl.w - dw.w) * ck.w;
+                dp += e.x * f.x + e.y * f.y + e.z * f.z + e.w * f.w;
+            }
+            const float pr = __expf(s * scale - Lrow[i]);
+            const float msk = drop.p > 0.f ? drop_scale(drop, (mbase + i) * L + j) : 1.f;
+            dSs[i * LS + j] = pr * (dp * msk - Drow[i]) * scale;
+            Pds[i * LS + j] = pr * msk;
+        }
+        __syncthreads();
+        // ---- stage B: d q (and the bias-gradient partials), rows i
+        for (int item = lane; item < L * C; item += 64) {
+            const int i = item / C;                  // chunk == myc
+            float4 ga = make_float4(0.f, 0.f, 0.f, 0.f), gb = ga;
+            for (int j = 0; j < L; ++j) {
+                const float ds = dSs[i * LS + j];
+                const float4 a = *reinterpret_cast<const float4*>(Ks + j * LDH + 4 * myc);
+                const float4 c = *reinterpret_cast<const float4*>(KRs + (j + L - i) * LDH + 4 * myc);
+                ga.x += ds * a.x; ga.y += ds * a.y; ga.z += ds * a.z; ga.w += ds * a.w;
+                gb.x += ds * c.x; gb.y += ds * c.y; gb.z += ds * c.z; gb.w += ds * c.w;
+            }
+            *reinterpret_cast<float4*>(dq + ((long)b * L + i) * D + hc + 4 * myc) =
+                make_float4(ga.x + gb.x, ga.y + gb.y, ga.z + gb.z, ga.w + gb.w);
+            acc_rw.x += ga.x; acc_rw.y += ga.y; acc_rw.z += ga.z; acc_rw.w += ga.w;
+            acc_rr.x += gb.x; acc_rr.y += gb.y; acc_rr.z += gb.z; acc_rr.w += gb.w;
+        }
+        // d k, d v : rows j
+        for (int item = lane; item < L * C; item += 64) {
+            const int j = item / C;
+            float4 gk = make_float4(0.f, 0.f, 0.f, 0.f), gv = gk;
+            for (int i = 0; i < L; ++i) {
+                const float ds = dSs[i * LS + j];
+                const float pd = Pds[i * LS + j];
+                const float4 a = *reinterpret_cast<const float4*>(Qw + i * LDH + 4 * myc);
+                const float4 e = *reinterpret_cast<const float4*>(dOs + i * LDH + 4 * myc);
+                gk.x += ds * a.x; gk.y += ds * a.y; gk.z += ds * a.z; gk.w += ds * a.w;
+                gv.x += pd * e.x; gv.y += pd * e.y; gv.z += pd * e.z; gv.w += pd * e.w;
+            }
+            *reinterpret_cast<float4*>(dk + ((long)b * L + j) * D + hc + 4 * myc) = gk;
+            *reinterpret_cast<float4*>(dv + ((long)b * L + j) * D + hc + 4 * myc) = gv;
+        }
+        // d k_r : rows p in [0, 2L)
+#pragma unroll
+        for (int u = 0; u < PAIRS_NKR; ++u) {
+            const int item = lane + 64 * u;
+            if (item < n_kr_items) {
+                const int pp = item / C;
+                float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int i_lo = max(0, L - pp), i_hi = min(L, 2 * L - pp);   // 0 <= pp - L + i < L
+                for (int i = i_lo; i < i_hi; ++i) {
+                    const float ds = dSs[i * LS + (pp - L + i)];
+                    const float4 a = *reinterpret_cast<const float4*>(Qw + i * LDH + 4 * myc);
+                    g.x += ds * (a.x + del4.x); g.y += ds * (a.y + del4.y);
+                    g.z += ds * (a.z + del4.z); g.w += ds * (a.w + del4.w);
+                }
+                if (dkr_b) *reinterpret_cast<float4*>(dkr_b + ((long)b * 2 * L + pp) * D + hc + 4 * myc) = g;
+                else { gkr[u].x += g.x; gkr[u].y += g.y; gkr[u].z += g.z; gkr[u].w += g.w; }
+            }
+        }
+    }
+    // ---- partial sums of this workgroup: row blockIdx.x of part[.][2L*D + 2D], this head's columns
+    float* mypart = part + (long)blockIdx.x * (2 * L * D + 2 * D);
+    if (!dkr_b) {
+#pragma unroll
+        for (int u = 0; u < PAIRS_NKR; ++u) {
+            const int item = lane + 64 * u;
+            if (item < n_kr_items)
+                *reinterpret_cast<float4*>(mypart + (long)(item / C) * D + hc + 4 * myc) = gkr[u];
+        }
+    }
+    // lanes sharing a chunk (lane % C) differ by multiples of C: butterfly over those
+    for (int o = C; o < 64; o <<= 1) {
+        acc_rw.x += __shfl_xor(acc_rw.x, o, 64); acc_rw.y += __shfl_xor(acc_rw.y, o, 64);
+        acc_rw.z += __shfl_xor(acc_rw.z, o, 64); acc_rw.w += __shfl_xor(acc_rw.w, o, 64);
+        acc_rr.x += __shfl_xor(acc_rr.x, o, 64); acc_rr.y += __shfl_xor(acc_rr.y, o, 64);
+        acc_rr.z += __shfl_xor(acc_rr.z, o, 64); acc_rr.w += __shfl_xor(acc_rr.w, o, 64);
+    }
+    if (lane < C) {
+        *reinterpret_cast<float4*>(mypart + 2 * L * D + hc + 4 * lane) = acc_rw;
+        *reinterpret_cast<float4*>(mypart + 2 * L * D + D + hc + 4 * lane) = acc_rr;
+    }
+}
+
 int t4r_reduce_partials_launch(hipStream_t st, const float* part, int nblocks, float* o0, int n0, int a0,
                                float* o1, int n1, int a1, float* o2, int n2, int a2);
 
@@ -375,6 +557,16 @@ static int attn_bwd_launch(hipStream_t st, const float* q, const float* k, const
                            float* part, float* dkr, float* d_rw, float* d_rr, int B, int L, int n_head,
                            float scale, long kr_bstride, DropCfg drop) {
     const int D = n_head * DH;
+    if (L <= 32 && (DH == 16 || DH == 32 || DH == 8) && 2 * L * (DH / 4) <= 64 * PAIRS_NKR) {
+        const size_t sm2 = ((size_t)6 * L * (DH + 4) + 2 * L * (L + 1) + 2 * L) * sizeof(float);
+        const int gx = B < 512 ? B : 512;
+        hipLaunchKernelGGL(xlnet_attn_bwd_pairs_kernel<DH>, dim3(gx, n_head), dim3(64), sm2, st, q, k, v, kr, rw, rr,
+                           out, lse, dout, dq, dk, dv, part, kr_bstride > 0 ? dkr : nullptr, B, L, n_head, scale,
+                           kr_bstride, drop);
+        T4R_LAUNCH_CHECK();
+        return t4r_reduce_partials_launch(st, part, gx, kr_bstride > 0 ? nullptr : dkr, 2 * L * D, 0, d_rw, D, 1,
+                                          d_rr, D, 1);
+    }
     const size_t smem = attn_bwd_smem(L, D, n_head, kr_bstride > 0);
     static size_t attr = 0;
     if (smem > attr) {

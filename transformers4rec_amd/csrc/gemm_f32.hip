@@ -40,6 +40,7 @@ struct GemmParams {
     int accumulate;             // splitk==1 only: C += result instead of C = result
     long sA, sB, sC;            // batch strides in elements (gridDim.z = batch * splitk)
     int vecA, vecB;             // 16-byte vector loads legal for this operand
+    int xcd_order;              // XCD-aware tile order (see kernel)
     DropCfg drop;               // EPI_BIAS_GELU only: C = dropout(gelu(x + bias)), mask index row*N + col
     // A-operand transform: A holds LOGITS [rows, V]; the GEMM consumes the softmax-CE gradient
     //   a = (*gout / n_rows) * (exp(x - lse[row]) - (1-eps)*[col == y[row]] - eps/V)
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     // 52 MB of operands -- every 64-row m-tile re-streamed all of W through the fabric.
     const int TM = (p.M + BM - 1) / BM, TN = (p.N + BN - 1) / BN;
     int mt, nt;
-    if (TM * TN < 128) {                       // tiny tile grids (split-K wgrads): plain order
+    if (TM * TN < 128 || !p.xcd_order) {       // tiny tile grids (split-K wgrads): plain order
         mt = blockIdx.x / TN; nt = blockIdx.x % TN;
     } else {
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -319,7 +320,7 @@ static int launch_cfg(const GemmParams& p, int batch, hipStream_t stream) {
     }
     const int TM = (p.M + BM - 1) / BM, TN = (p.N + BN - 1) / BN;
     const int Tl = TM <= TN ? TN : TM, Ts = TM <= TN ? TM : TN;
-    const int gx = TM * TN < 128 ? TM * TN : 8 * ((Tl + 7) / 8) * Ts;   // must match the kernel's decode
+    const int gx = (TM * TN < 128 || !p.xcd_order) ? TM * TN : 8 * ((Tl + 7) / 8) * Ts;   // must match the kernel's decode
     dim3 grid(gx, 1, batch * p.splitk);
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, TA, TB>), grid, dim3(256), smem, stream, p);
     T4R_LAUNCH_CHECK();
@@ -351,6 +352,9 @@ static int launch_layout(GemmParams& p, int batch, int splitk_req, hipStream_t s
         splitk = min(splitk, 256);
     }
     p.splitk = max(1, splitk);
+    static int xcd_sel = -1;
+    if (xcd_sel < 0) { const char* e = getenv("T4R_GEMM_XCD"); xcd_sel = e ? atoi(e) : 1; }
+    p.xcd_order = xcd_sel;
     if (p.splitk > 1) {
         if (p.epilogue != EPI_NONE) { t4r_set_error("gemm: split-K needs epilogue NONE"); return -1; }
         if (!p.accumulate) {  // atomics accumulate: start from zero unless the caller accumulates

@@ -126,6 +126,7 @@ def main():
     reducer = tr.GradReducer(dense.grad, tables.grad if tables is not None else None)
     masking = model.input_features.masking
     masking.seed = 1234 + rank
+    model.transformer_block.transformer.seed = 4321 + rank      # per-rank dropout stream
     # synthetic Schema-driven sessions, resident in HBM before the timed region (8 distinct batches)
     batches = [tr.random_data_from_schema(schema, BATCH, SEQ, seed=1000 * rank + i, device=device)
                for i in range(8)]

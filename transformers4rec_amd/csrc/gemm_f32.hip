@@ -87,8 +87,11 @@ __device__ __forceinline__ float4 ld4_guard(const float* p, int valid, bool vec)
     return v;
 }
 
-template <int BM, int BN, int BK, bool TA, bool TB>
+// FEAT bit 0: softmax-gradient A operand ; bit 1: dropout in the epilogue.  Compile-time so that the
+// plain GEMM does not carry the Philox / exp code (measured: +12 % step time when it did).
+template <int BM, int BN, int BK, bool TA, bool TB, int FEAT>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
+    constexpr bool SG = (FEAT & 1) != 0, EDROP = (FEAT & 2) != 0;
     constexpr int WM = BM / 64, WN = BN / 64;          // MFMA tiles per wave per dim
     constexpr int LDA_S = BM + (TA ? 4 : 2);           // LDS row pitch (floats)
     constexpr int LDB_S = BN + (TB ? 2 : 4);
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     // itself runs in store_tiles (after the MFMAs), so the global loads still overlap compute
     float sgl[NA4];
     int sgy[NA4];
-    const float sg_g = p.sg_lse ? (p.sg_gout ? *p.sg_gout : 1.f) / p.sg_rows : 0.f;
+    const float sg_g = SG ? (p.sg_gout ? *p.sg_gout : 1.f) / p.sg_rows : 0.f;
 
     auto load_tiles = [&](int kt) {
         const int k0 = kt * BK;
@@ -156,13 +159,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 const int gk = k0 + k, gm = m0 + m4;
                 const int valid = gk < p.K ? p.M - gm : 0;
                 ra[r] = ld4_guard(A + (long)gk * p.lda + gm, valid, vecA);
-                if (p.sg_lse && valid > 0) { sgl[r] = p.sg_lse[gk]; sgy[r] = (int)p.sg_labels[gk]; }  // rows = k
+                if (SG && valid > 0) { sgl[r] = p.sg_lse[gk]; sgy[r] = (int)p.sg_labels[gk]; }  // rows = k
             } else {   // A[M][lda], k contiguous: tile row = m, 4 consecutive k
                 const int m = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
                 const int gm = m0 + m, gk = k0 + k4;
                 const int valid = gm < p.M ? p.K - gk : 0;
                 ra[r] = ld4_guard(A + (long)gm * p.lda + gk, valid, vecA);
-                if (p.sg_lse && valid > 0) { sgl[r] = p.sg_lse[gm]; sgy[r] = (int)p.sg_labels[gm]; }  // rows = m
+                if (SG && valid > 0) { sgl[r] = p.sg_lse[gm]; sgy[r] = (int)p.sg_labels[gm]; }  // rows = m
             }
         }
 #pragma unroll
@@ -188,14 +191,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             const int idx = tid + r * 256;
             if (TA) {
                 const int k = idx / (BM / 4), m4 = (idx % (BM / 4)) * 4;
-                if (p.sg_lse) {
+                if (SG) {
                     const int gk = kt * BK + k, gm = m0 + m4;
                     ra[r] = softmax_grad4(ra[r], gk < p.K ? p.M - gm : 0, sgl[r], sgy[r], gm, sg_g, p);
                 }
                 *reinterpret_cast<float4*>(as + k * LDA_S + m4) = ra[r];
             } else {
                 const int m = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
-                if (p.sg_lse) {
+                if (SG) {
                     const int gm = m0 + m, gk = kt * BK + k4;
                     ra[r] = softmax_grad4(ra[r], gm < p.M ? p.K - gk : 0, sgl[r], sgy[r], gk, sg_g, p);
                 }
@@ -291,13 +294,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                         v += bv;
                         if (p.aux) p.aux[(long)row * p.ldaux + col] = v;
                         v = gelu_erf(v);
-                        if (p.drop.p > 0.f) v *= drop_scale(p.drop, (unsigned long long)row * p.N + col);
+                        if (EDROP) v *= drop_scale(p.drop, (unsigned long long)row * p.N + col);
                     } else if (p.epilogue == EPI_BIAS_RELU) {
                         v = fmaxf(v + bv, 0.f);
                     } else if (p.epilogue == EPI_BIAS_RESID) {
                         // C = dropout(x + bias) + residual   (GPT-2: hidden + resid_dropout(c_proj(...)))
                         v += bv;
-                        if (p.drop.p > 0.f) v *= drop_scale(p.drop, (unsigned long long)row * p.N + col);
+                        if (EDROP) v *= drop_scale(p.drop, (unsigned long long)row * p.N + col);
                         v += p.aux[(long)row * p.ldaux + col];
                     }
                     if (p.accumulate) v += *cp;
@@ -308,13 +311,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     }
 }
 
-template <int BM, int BN, int BK, bool TA, bool TB>
-static int launch_cfg(const GemmParams& p, int batch, hipStream_t stream) {
+template <int BM, int BN, int BK, bool TA, bool TB, int FEAT>
+static int launch_feat(const GemmParams& p, int batch, hipStream_t stream) {
     constexpr int LDA_S = BM + (TA ? 4 : 2), LDB_S = BN + (TB ? 2 : 4);
     constexpr size_t smem = (size_t)2 * BK * (LDA_S + LDB_S) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_f32_kernel<BM, BN, BK, TA, TB>,
+        (void)hipFuncSetAttribute((const void*)gemm_f32_kernel<BM, BN, BK, TA, TB, FEAT>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
@@ -322,9 +325,25 @@ static int launch_cfg(const GemmParams& p, int batch, hipStream_t stream) {
     const int Tl = TM <= TN ? TN : TM, Ts = TM <= TN ? TM : TN;
     const int gx = (TM * TN < 128 || !p.xcd_order) ? TM * TN : 8 * ((Tl + 7) / 8) * Ts;   // must match the kernel's decode
     dim3 grid(gx, 1, batch * p.splitk);
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, TA, TB>), grid, dim3(256), smem, stream, p);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, TA, TB, FEAT>), grid, dim3(256), smem, stream, p);
     T4R_LAUNCH_CHECK();
     return 0;
+}
+
+template <int BM, int BN, int BK, bool TA, bool TB>
+static int launch_cfg(const GemmParams& p, int batch, hipStream_t stream) {
+    if (p.sg_lse) {
+        // softmax-gradient operand: only the tile the head uses is instantiated
+        if (BM == 64 && BN == 64 && BK == 16 && !TB) return launch_feat<64, 64, 16, TA, false, 1>(p, batch, stream);
+        t4r_set_error("gemm: softmax-grad operand needs the 64x64x16 tile and transB = 0");
+        return -1;
+    }
+    if (p.drop.p > 0.f && (p.epilogue == EPI_BIAS_GELU || p.epilogue == EPI_BIAS_RESID)) {
+        if (BM == 64 && BN == 64 && BK == 16) return launch_feat<64, 64, 16, TA, TB, 2>(p, batch, stream);
+        t4r_set_error("gemm: epilogue dropout needs the 64x64x16 tile");
+        return -1;
+    }
+    return launch_feat<BM, BN, BK, TA, TB, 0>(p, batch, stream);
 }
 
 template <bool TA, bool TB>

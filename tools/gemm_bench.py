@@ -41,3 +41,7 @@ bench("d_h1 (NN K=512)", T, D, 4 * D, False, False)
 bench("wgrad w2 splitk", D, 4 * D, T, True, False, splitk=-1, accumulate=True)
 bench("wgrad w1 splitk", 4 * D, D, T, True, False, splitk=-1, accumulate=True)
 bench("wgrad o splitk", D, D, T, True, False, splitk=-1, accumulate=True)
+# transposed-logits layout experiment: G^T stored [V, N_m]
+bench("T-layout dW  NN M=V K=N_m", V, D, NM, False, False, pad_a=True)
+bench("T-layout dX  TN K=V splitk", NM, D, V, True, False, splitk=-1, pad_a=True)
+bench("T-layout logits^T NT M=V N=N_m", V, NM, D, False, True)

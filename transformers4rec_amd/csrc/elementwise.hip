@@ -129,24 +129,29 @@ extern "C" int t4r_add_layernorm_fwd(void* stream, const float* a, const float* 
 // (measured: 254 us for a LayerNorm backward whose data pass takes ~10 us).
 //   out_s[i] (+)= sum_b part[b*n + off_s + i]   for up to three output segments s.
 struct ReduceSeg { float* out; int len; int accumulate; };
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part,
+// Workgroup = 16 output columns x 32 row groups: n / 16 workgroups (the reduced widths are only a
+// few hundred columns, so 64-column workgroups left the launch at 2-8 workgroups and ~15 us of
+// pure load latency).
+__global__ __launch_bounds__(512) void reduce_partials_kernel(const float* __restrict__ part,
                                                                int nblocks, int n, ReduceSeg s0,
                                                                ReduceSeg s1, ReduceSeg s2) {
-    __shared__ float sm[4][64];
-    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + c;
+    __shared__ float sm[32][17];
+    const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + c;
     float acc = 0.f;
     if (i < n) {
         int b = g;
-        for (; b + 12 < nblocks; b += 16)
-            acc += part[(long)b * n + i] + part[(long)(b + 4) * n + i] + part[(long)(b + 8) * n + i] +
-                   part[(long)(b + 12) * n + i];
-        for (; b < nblocks; b += 4) acc += part[(long)b * n + i];
+        for (; b + 96 < nblocks; b += 128)
+            acc += (part[(long)b * n + i] + part[(long)(b + 32) * n + i]) +
+                   (part[(long)(b + 64) * n + i] + part[(long)(b + 96) * n + i]);
+        for (; b < nblocks; b += 32) acc += part[(long)b * n + i];
     }
     sm[g][c] = acc;
     __syncthreads();
     if (g == 0 && i < n) {
-        const float v = sm[0][c] + sm[1][c] + sm[2][c] + sm[3][c];
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) v += sm[r][c];
         int j = i;
         ReduceSeg seg = s0;
         if (j >= s0.len) { j -= s0.len; seg = s1; if (j >= s1.len) { j -= s1.len; seg = s2; } }
@@ -159,7 +164,7 @@ int t4r_reduce_partials_launch(hipStream_t st, const float* part, int nblocks, f
     const int n = n0 + n1 + n2;
     if (n <= 0 || nblocks <= 0) return 0;
     ReduceSeg s0{o0, n0, a0}, s1{o1, n1, a1}, s2{o2, n2, a2};
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 63) / 64), dim3(256), 0, st, part, nblocks, n,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 15) / 16), dim3(512), 0, st, part, nblocks, n,
                        s0, s1, s2);
     T4R_LAUNCH_CHECK();
     return 0;

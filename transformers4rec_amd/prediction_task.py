@@ -109,6 +109,9 @@ class _NextItemHeadFn(torch.autograd.Function):
         ctx.task, ctx.neg, ctx.meta = task, neg, (B, L, D, N, V, T, width, smooth)
         ctx.save_for_backward(pos, labels, tgt, xr, xp, logits, lse)
         ctx.mark_non_differentiable(logits)
+        # without this autograd hands backward() a zero-filled [N_m, V] gradient for `logits`
+        # (a 1.1 GB fill, ~150 us per step at the 100k-item configuration)
+        ctx.set_materialize_grads(False)
         return loss, logits
 
     @staticmethod
@@ -118,6 +121,8 @@ class _NextItemHeadFn(torch.autograd.Function):
         B, L, D, N, V, T, width, smooth = ctx.meta
         mod = task.pre.module
         W = mod.output_weights
+        if dloss is None:
+            return (None,) * 7
         if ctx.neg is None:
             # CrossEntropyLoss backward is fused into the A operand of both contractions:
             # the [N_m, V] gradient is never materialised

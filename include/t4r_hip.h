@@ -51,6 +51,8 @@ int t4r_ragged_to_padded(void* stream, const void* values, const long* offsets, 
  *         1: dense rows, input[f] = fp32 [B*L_in, dim[f]] (soft embeddings, continuous pass-through)
  *         2: per-session table lookup (a3), input[f] = int64 ids [B], the row is broadcast over the
  *            sequence (features/embedding.py:229-240 2-D branch + tabular/base.py:53-63)
+ *         3: per-session dense rows, input[f] = fp32 [B, dim[f]] (a context feature after a post
+ *            transformation), broadcast over the sequence
  * agg 0 concat (col[f] = first output column) | 1 sum | 2 item * sum(others) (item_feat = index)
  * mask_mode 0 none | 1 MLM (out = mask ? memb : x) | 2 CLM train/eval (mask ? (l==L-1 ? 0 : x) : memb)
  *           | 3 CLM inference (mask ? x : memb).  L_out = L_in + 1 is the MLM-inference grid
@@ -242,6 +244,38 @@ int t4r_sampled_logits_bwd(void* stream, const float* dlogits, const float* x, c
                            int n_neg, float temperature);
 int t4r_topk(void* stream, const float* scores, int N, int V, long ld, int k, float* out_val,
              long* out_idx);
+
+/* ----------------------------------------------------------------------------------------
+ * train-time input regularisers (pre / post transformations of the input block)
+ *
+ * t4r_swap_noise: tr.StochasticSwapNoise.augment for one feature
+ * (transformers4rec/torch/tabular/transformations.py:55-93).  x/out hold n elements of elem_bytes
+ * (8: int64 ids, 4: fp32 continuous values).  item_ids[i * mask_stride] != pad_token is the padding
+ * mask of element i (config/schema.py:59-66; mask_stride = L for a per-session [B] feature, which
+ * uses mask[:, 0]; 1 otherwise).
+ * Element i is replaced when it is non-pad and its Bernoulli(p) trial succeeds; the k-th replaced
+ * element (row-major) receives masked[perm[k]], masked = the non-pad values in row-major order.
+ * bern (uint8 [n]) and perm (int64 [#non-pad]) inject the draws (parity tests replay the
+ * reference's torch.bernoulli / torch.randperm); null => device draws from Philox(seed, ctr_hi)
+ * (uniforms for the trial, a radix sort of 64-bit keys for the permutation).
+ * ws: t4r_swap_noise_ws_bytes(n) bytes of device scratch.
+ *
+ * TabularDropout (transformations.py:145-160) is t4r_dropout; the per-feature TabularLayerNorm
+ * (transformations.py:96-142, eps 1e-5) is t4r_add_layernorm_fwd/bwd with b = NULL on the
+ * feature's [tokens, dim] rows.  t4r_copy_cols moves one feature's column block between a
+ * concatenated row buffer (`wide`, row pitch ldw) and a dense [rows, dim] buffer
+ * (dir 0: wide -> narrow, 1: narrow -> wide). */
+long t4r_swap_noise_ws_bytes(long n);
+int t4r_swap_noise(void* stream, const void* x, void* out, int elem_bytes, long n,
+                   const long* item_ids, long pad_token, long mask_stride, float p,
+                   const unsigned char* bern, const long* perm, unsigned long long seed, unsigned long long ctr_hi, void* ws,
+                   long ws_bytes);
+int t4r_copy_cols(void* stream, float* wide, long ldw, int col, float* narrow, int dim, long rows,
+                  int dir);
+/* out[b, 0:dim] = sum_l wide[b*L + l, col:col+dim]: gradient of broadcasting a per-session feature
+ * over the sequence (tabular/base.py:53-63) when a post transformation sits in between. */
+int t4r_seq_sum_cols(void* stream, const float* wide, long ldw, int col, float* out, int dim, long B,
+                     int L);
 
 /* ----------------------------------------------------------------------------------------
  * optimizer: fused Adam over a flat parameter buffer (torch.optim.Adam semantics, the optimizer

@@ -13,6 +13,8 @@ Conventions inside each .npz
                           aliases of one tensor stored once; *_eval/*_infer cases reuse the
                           parameters of the matching *_train file)
   draw/bern, draw/j1, draw/j2, draw/neg   recorded torch.bernoulli / torch.multinomial draws
+  draw/ssn_bern/<module>/<feature>, draw/ssn_perm/<module>/<feature>   StochasticSwapNoise draws
+  draw/post_keep/<feature>                TabularDropout keep masks of the categorical module
   out/mask_schema, out/masked_targets, out/inputs_embeds, out/hidden,
   out/predictions, out/labels, out/loss
   g/<state_dict key>      d loss / d param   (training cases)
@@ -167,7 +169,7 @@ def run(model, x, training, testing, want_grads, with_params=True):
     else:
         d["out/predictions"] = out.detach().numpy()
     if rec.bern:
-        d["draw/bern"] = rec.bern[0].numpy()
+        d["draw/bern"] = rec.bern[-1].numpy()   # the MLM draw is the last one (swap-noise draws precede it)
     mlm = masking.__class__.__name__ == "MaskedLanguageModeling"
     multi = list(rec.multi)
     if mlm and training:
@@ -320,6 +322,112 @@ def main():
     s = LogUniformSampler(max_n_samples=20, max_id=301, min_id=1)
     save("log_uniform", {"out/dist": s.dist.numpy(), "out/unique_dist": s.unique_sampling_dist.numpy()},
          max_id=301, min_id=1, n_sample=40)
+
+    # K: train-time input regularisers of the paper configuration
+    #    (examples/t4rec_paper_experiments/t4r_paper_repro/transf_exp_main.py:71-91):
+    #    pre = StochasticSwapNoise(schema), post = [TabularDropout, "layer-norm"]
+    prepost_cases(tr, V, L, d, nh)
+
+
+class SwapRecorder:
+    """Records every StochasticSwapNoise.augment call (input, padding mask, bernoulli, randperm,
+    output) in call order while the reference runs."""
+
+    def __init__(self, tr):
+        self.cls, self.calls = tr.StochasticSwapNoise, []
+
+    def __enter__(self):
+        self._aug, self._b, self._p = self.cls.augment, torch.bernoulli, torch.randperm
+        cur = {}
+
+        rec = self
+
+        def augment(ssn, x, mask=None):
+            cur.clear()
+            b0, p0 = torch.bernoulli, torch.randperm   # whatever is installed now (e.g. DrawRecorder)
+
+            def bern(*a, **k):
+                r = rec._b(*a, **k)
+                cur.setdefault("bern", r.clone())
+                return r
+
+            def perm(*a, **k):
+                r = rec._p(*a, **k)
+                cur.setdefault("perm", r.clone())
+                return r
+
+            torch.bernoulli, torch.randperm = bern, perm
+            try:
+                out = rec._aug(ssn, x, mask)
+            finally:
+                torch.bernoulli, torch.randperm = b0, p0
+            rec.calls.append(dict(x=x.clone(), out=out.clone(), **cur))
+            return out
+
+        self.cls.augment = augment
+        return self
+
+    def __exit__(self, *exc):
+        self.cls.augment = self._aug
+
+
+def prepost_cases(tr, V, L, d, nh):
+    B = 10
+    cats, conts = (("category", 40), ("brand", 9)), ("price",)
+    feats = ["item_id", "category", "brand", "price"]
+    schema = make_schema(V, L, cats, conts)
+    for name, post_fn, agg, dims in (
+        ("xlnet_mlm_prepost_concat_train", lambda: [tr.TabularDropout(0.25), "layer-norm"], "concat",
+         {"item_id": 16, "category": 24, "brand": 8}),
+        ("xlnet_mlm_prepost_sum_train", lambda: ["layer-norm", tr.TabularDropout(0.25)], "element-wise-sum-item-multi",
+         None),
+    ):
+        conts_k = conts if agg == "concat" else ()
+        schema_k = schema if agg == "concat" else make_schema(V, L, cats, ())
+        ssn = tr.StochasticSwapNoise(pad_token=0, replacement_prob=0.3, schema=schema_k)
+        kw = dict(max_sequence_length=L, masking="mlm", aggregation=agg, pre=[ssn], post=post_fn())
+        if agg == "concat":
+            kw.update(d_output=d, continuous_soft_embeddings=True, embedding_dims=dims)
+        else:
+            kw.update(embedding_dim_default=d)
+        torch.manual_seed(100)
+        inp = tr.TabularSequenceFeatures.from_schema(schema_k, **kw)
+        cfg = tr.XLNetConfig.build(d_model=d, n_head=nh, n_layer=1, total_seq_length=L, dropout=0.0)
+        model = cfg.to_torch_model(inp, tr.NextItemPredictionTask(weight_tying=(agg != "concat")))
+        reinit(model, 101)
+        model.train()   # the regularisers follow nn.Module.training (transformations.py:59-60)
+        # (XLNetConfig dropout = 0, so the transformer and the head stay deterministic)
+        x = synth_inputs(B, L, V, cats, conts_k, seed=102)
+        cat_mod = inp.categorical_module
+        drop_mod = [t for t in cat_mod.post if isinstance(t, tr.TabularDropout)][0]
+        keep = {}
+
+        def hook(mod, args, out):
+            for k, v in out.items():
+                keep[k] = (v != 0).to(torch.uint8)   # |embedding| > 0 almost surely; checked below
+
+        hd = drop_mod.register_forward_hook(hook)
+        torch.manual_seed(103)
+        with SwapRecorder(tr) as sw:
+            dd = run(model, x, True, False, True)
+        hd.remove()
+        # augment is called once per input feature per module, modules in to_merge order
+        n_in = len(x)
+        mods = list(inp.to_merge.keys())
+        assert len(sw.calls) == n_in * len(mods), (len(sw.calls), n_in, mods)
+        for mi, mname in enumerate(mods):
+            for fi, fname in enumerate(x.keys()):
+                c = sw.calls[mi * n_in + fi]
+                assert torch.equal(c["x"], x[fname])
+                dd[f"draw/ssn_bern/{mname}/{fname}"] = c["bern"].numpy().astype(np.uint8)
+                dd[f"draw/ssn_perm/{mname}/{fname}"] = c["perm"].numpy()
+                dd[f"out/ssn/{mname}/{fname}"] = c["out"].numpy()
+        for k, v in keep.items():
+            frac = float(v.float().mean())
+            assert 0.6 < frac < 0.9, (k, frac)
+            dd[f"draw/post_keep/{k}"] = v.numpy()
+        dd["out/item_seq"] = cat_mod.item_seq.numpy()
+        save(name, dd, n_head=nh, d_model=d, n_layer=1, eps=0.03, L=L, V=V + 1, ssn_p=0.3, post_drop_p=0.25)
 
 
 if __name__ == "__main__":

@@ -375,3 +375,125 @@ def test_full_size_step_vs_oracle(multi):
         close(model.input_features.projection_module[0][0].weight.grad, p["proj"][0].grad, rtol=2e-3, atol=2e-7)
         close(model.input_features.continuous_module.embedding_tables["price"].embedding_table.weight.grad,
               p["soft"]["price"][2].grad, rtol=2e-3, atol=2e-6)
+
+
+# ------------------------------------------------------------------------------------------
+# train-time input regularisers: StochasticSwapNoise (pre), TabularDropout / TabularLayerNorm (post)
+def _prepost_model(name):
+    import transformers4rec_amd as tr
+
+    d = gu.load(name)
+    agg, post = gu.PREPOST_CASES[name]
+    L, V, dm = int(d["meta/L"]), int(d["meta/V"]), int(d["meta/d_model"])
+    concat = agg == "concat"
+    cats, conts = (("category", 40), ("brand", 9)), (("price",) if concat else ())
+    schema = tr.session_schema(V - 1, L, cats, conts)
+    ssn = tr.StochasticSwapNoise(pad_token=0, replacement_prob=float(d["meta/ssn_p"]), schema=schema)
+    post_mods = [tr.TabularDropout(op[1]) if op[0] == "dropout" else "layer-norm" for op in post]
+    kw = dict(max_sequence_length=L, masking="mlm", aggregation=agg, pre=[ssn], post=post_mods)
+    if concat:
+        kw.update(d_output=dm, continuous_soft_embeddings=True,
+                  embedding_dims={"item_id": 16, "category": 24, "brand": 8})
+    else:
+        kw.update(embedding_dim_default=dm)
+    inputs = tr.TabularSequenceFeatures.from_schema(schema, **kw)
+    cfg = tr.XLNetConfig.build(dropout=0.0, d_model=dm, n_head=int(d["meta/n_head"]), n_layer=1, total_seq_length=L)
+    model = cfg.to_torch_model(inputs, tr.NextItemPredictionTask(weight_tying=not concat))
+    load_reference_state(model, d)
+    model.to(DEV)
+    return d, model, ssn, post
+
+
+@pytest.mark.parametrize("name", sorted(gu.PREPOST_CASES))
+def test_prepost_regularisers_match_reference_and_oracle(name):
+    from transformers4rec_amd import features as F_, ops
+
+    d, model, ssn, post = _prepost_model(name)
+    agg = gu.PREPOST_CASES[name][0]
+    x = {k[3:]: gu.t(v).to(DEV) for k, v in d.items() if k.startswith("in/")}
+    draws = {}
+    for k in d:
+        if k.startswith("draw/ssn_bern/"):
+            _, _, mod, feat = k.split("/")
+            draws[(mod, feat)] = (gu.t(d[k]).to(DEV), gu.t(d[f"draw/ssn_perm/{mod}/{feat}"]).to(DEV))
+    ssn.set_draws(draws)
+    masking = model.input_features.masking
+    masking.set_draws(gu.t(d["draw/bern"]).to(DEV).to(torch.uint8), gu.t(d["draw/j1"]).to(DEV),
+                      gu.t(d["draw/j2"]).to(DEV))
+    cap = {}
+    model.input_features.register_forward_hook(lambda m, i, o: cap.__setitem__("emb", o.detach().clone()))
+    model.transformer_block.register_forward_hook(lambda m, i, o: cap.__setitem__("hid", o.detach().clone()))
+    model.train()
+    out = model(x, training=True)
+    # integer work: the swapped ids, the mask and the labels are the reference's, bit for bit
+    cat = model.input_features.categorical_module
+    assert torch.equal(cat.item_seq.cpu(), gu.t(d["out/item_seq"]))
+    assert torch.equal(masking.mask_schema.cpu(), gu.t(d["out/mask_schema"]))
+    assert torch.equal(masking.masked_targets.cpu(), gu.t(d["out/masked_targets"]))
+    assert torch.equal(out["labels"].cpu(), gu.t(d["out/labels"]))
+    # float work: the oracle with this run's own TabularDropout keep masks (Philox stream re-exported)
+    _, xs = gu.prepost_replay(d, O.swap_noise)
+    p = gu.oracle_params(d, requires_grad=True)
+    p["post_ln"] = gu.post_ln_params(d, requires_grad=True)
+    order = model.input_features._feature_order
+    B, L = x["item_id"].shape
+    keep = {}
+    pd = float(d["meta/post_drop_p"])
+    di = [i for i, op in enumerate(post) if op[0] == "dropout"][0]
+    for f, tab in p["tables"].items():
+        D = tab.shape[1]
+        ctr = ops.dropout_ctr_hi(model.input_features._post_step, 0xFE, order.index(f) * 8 + di)
+        _, m = ops.dropout(torch.ones(B * L * D, device=DEV), pd, F_._POST_SEED, ctr, want_mask=True)
+        keep[f] = m.view(B, L, D).cpu()
+        assert 0.6 < float(keep[f].float().mean()) < 0.9
+    cfg = dict(n_head=int(d["meta/n_head"]), eps=float(d["meta/eps"]), item="item_id", masking="mlm",
+               aggregation=agg, post=post, post_drop_masks=keep)
+    ref = O.session_forward(p, cfg, xs, gu.t(d["out/mask_schema"]), gu.t(d["out/masked_targets"]), True, False)
+    close(cap["emb"], ref["inputs_embeds"])
+    close(cap["hid"], ref["hidden"])
+    close(out["predictions"], ref["logits"])
+    close(out["loss"], ref["loss"])
+    assert abs(float(out["loss"].detach()) - float(ref["loss"].detach())) < 1e-3
+    out["loss"].backward()
+    ref["loss"].backward()
+    named = dict(model.named_parameters())
+    for f, tab in p["tables"].items():
+        close(named[gu.CAT + f + ".weight"].grad, tab.grad, rtol=2e-4, atol=1e-4, msg=lambda m, f=f: f"table {f}: {m}")
+    for f, (wk, bk) in gu.post_ln_grad_keys(d).items():
+        close(named[wk].grad, p["post_ln"][f][0].grad, rtol=2e-4, atol=1e-4)
+        close(named[bk].grad, p["post_ln"][f][1].grad, rtol=2e-4, atol=1e-4)
+    # eval mode: every regulariser is the identity (transformations.py:59-60; nn.Dropout)
+    model.eval()
+    ssn.set_draws(None)
+    out_e = model(x, training=False, testing=True)
+    assert torch.equal(cat.item_seq.cpu(), gu.t(d["in/item_id"]))
+    keep1 = {f: torch.ones_like(k) for f, k in keep.items()}
+    cfg_e = dict(cfg, post=[op if op[0] != "dropout" else ("dropout", 0.0) for op in post], post_drop_masks=keep1)
+    x_cpu = {k: v.cpu() for k, v in x.items()}
+    m_e, lab_e = O.mlm_targets_eval(x_cpu["item_id"])
+    with torch.no_grad():
+        ref_e = O.session_forward(p, cfg_e, x_cpu, m_e, lab_e, False, True)
+    close(out_e["predictions"], ref_e["logits"])
+
+
+def test_continuous_passthrough_columns():
+    """continuous_soft_embeddings=False: ContinuousFeatures hands the values through as width-1
+    columns of the concatenation (features/continuous.py:60-63)."""
+    import transformers4rec_amd as tr
+
+    L, V, B = 12, 50, 6
+    schema = tr.session_schema(V, L, (("category", 7),), ("price", "age"))
+    mod = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=L, aggregation="concat",
+                                                 embedding_dims={"item_id": 8, "category": 4}).to(DEV)
+    x = tr.random_data_from_schema(schema, B, L, seed=3, device=DEV)
+    out = mod(x)
+    names = sorted(["item_id", "category", "price", "age"])
+    feats = {}
+    for n in names:
+        if n in mod.categorical_module.embedding_tables:
+            feats[n] = O.embedding_lookup(x[n].cpu(), mod.categorical_module.embedding_tables[n].weight.detach().cpu())
+        else:
+            feats[n] = x[n].cpu().float().unsqueeze(-1)
+    ref = O.concat_features(feats)
+    assert out.shape == (B, L, 8 + 4 + 2)
+    assert torch.equal(out.cpu(), ref)

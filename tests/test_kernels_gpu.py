@@ -689,3 +689,78 @@ def test_gemm_resid_dropout_epilogue_and_pos_emb(ops):
     dy = torch.randn(B, L, D, generator=g)
     ops.add_pos_bwd_(cu(dy), dpos)
     close(dpos, dy.sum(0), atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------
+# StochasticSwapNoise (t4r_swap_noise)
+@pytest.mark.parametrize("name", ["xlnet_mlm_prepost_concat_train", "xlnet_mlm_prepost_sum_train"])
+def test_swap_noise_replays_reference_draws(name):
+    """every recorded augment() call of the reference (int64 ids and fp32 values), bit exact"""
+    import golden_utils as gu
+    from transformers4rec_amd import ops
+
+    d = gu.load(name)
+    ids = gu.t(d["in/item_id"]).to(DEV)
+    n_calls = 0
+    for k in d:
+        if not k.startswith("draw/ssn_bern/"):
+            continue
+        _, _, mod, feat = k.split("/")
+        x = gu.t(d["in/" + feat]).to(DEV)
+        out = ops.swap_noise(x, ids, float(d["meta/ssn_p"]), 0, gu.t(d[k]).to(DEV),
+                             gu.t(d[f"draw/ssn_perm/{mod}/{feat}"]).to(DEV))
+        assert torch.equal(out.cpu(), gu.t(d[f"out/ssn/{mod}/{feat}"])), (mod, feat)
+        n_calls += 1
+    assert n_calls >= 6
+
+
+@pytest.mark.parametrize("p", [0.1, 0.3, 0.5, 0.7])
+def test_swap_noise_device_draws_properties(p):
+    """mirrors tests/unit/torch/tabular/test_transformations.py:29-56 (replacement rate within 0.15 of
+    replacement_prob on the non-padded positions) and adds what the algorithm guarantees: padding is
+    never touched, replacements are drawn WITHOUT replacement from the non-padded values."""
+    from transformers4rec_amd import ops
+
+    B, L = 100, 80
+    g = torch.Generator().manual_seed(0)
+    ids = torch.tril(torch.randint(1, 100, (B, L), generator=g), 1)
+    uniq = (torch.arange(B * L).view(B, L) + 1) * (ids != 0)          # distinct non-pad values
+    cont = torch.tril(torch.rand((B, L), generator=g), 1)
+    per_session = torch.randint(1, 100, (B,), generator=g)
+    for x in (ids, uniq, cont, per_session):
+        out = ops.swap_noise(x.to(DEV), ids.to(DEV), p, 0, seed=7, ctr_hi=11).cpu()
+        mask = (ids != 0) if x.ndim == 2 else (ids[:, 0] != 0)
+        assert torch.equal(out[~mask], x[~mask])                       # padding untouched
+        if x is uniq:
+            changed = (out != x) & mask
+            rate = changed.float().sum() / mask.float().sum()
+            assert abs(float(rate) - p) < 0.05
+            src = out[changed]
+            assert src.unique().numel() == src.numel()                 # sampled without replacement
+            assert bool(torch.isin(src, x[mask]).all())                # ... from the non-pad values
+        elif x.ndim == 2:
+            rate = ((out != x) & mask).float().sum() / mask.float().sum()
+            assert abs(float(rate) - p) < 0.15
+        assert bool(torch.isin(out[mask], x[mask]).all())
+    # a different stream position gives a different draw; the same one reproduces
+    a = ops.swap_noise(uniq.to(DEV), ids.to(DEV), p, 0, seed=7, ctr_hi=11)
+    b = ops.swap_noise(uniq.to(DEV), ids.to(DEV), p, 0, seed=7, ctr_hi=11)
+    c = ops.swap_noise(uniq.to(DEV), ids.to(DEV), p, 0, seed=7, ctr_hi=12)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+
+
+def test_swap_noise_edge_cases():
+    from transformers4rec_amd import ops
+
+    ids = torch.zeros((4, 6), dtype=torch.int64, device=DEV)          # all padding: nothing to swap
+    x = torch.arange(24, device=DEV).view(4, 6)
+    assert torch.equal(ops.swap_noise(x, ids, 0.9), x)
+    ids[0, 0] = 5                                                     # one valid value: swaps with itself
+    assert torch.equal(ops.swap_noise(x, ids, 1.0), x)
+    ids = torch.ones((3, 5), dtype=torch.int64, device=DEV)
+    xf = torch.rand((3, 5), device=DEV)
+    assert torch.equal(ops.swap_noise(xf, ids, 0.0), xf)              # p = 0: identity
+    out = ops.swap_noise(xf, ids, 1.0, seed=1)                        # p = 1: a permutation of the values
+    assert torch.equal(out.flatten().sort().values, xf.flatten().sort().values)
+    e = torch.empty((0, 5), dtype=torch.int64, device=DEV)
+    assert ops.swap_noise(e, e, 0.5).shape == (0, 5)

@@ -140,6 +140,40 @@ def test_train_forward_backward_golden(name, masking, agg):
         torch.testing.assert_close(p["task_proj"][0].grad, g[gu.TASK + "task_block.0.0.weight"], **TOL)
 
 
+@pytest.mark.parametrize("name", sorted(gu.PREPOST_CASES))
+def test_prepost_regularisers_golden(name):
+    """StochasticSwapNoise (pre) + TabularDropout / TabularLayerNorm (post) of the paper configuration,
+    replaying the reference's own bernoulli / randperm / dropout draws."""
+    d = gu.load(name)
+    agg, post = gu.PREPOST_CASES[name]
+    x, xs = gu.prepost_replay(d, O.swap_noise)
+    for k in x:   # integer / value work: bit exact against every recorded augment() call
+        mod = "continuous_module" if x[k].is_floating_point() else "categorical_module"
+        assert torch.equal(xs[k], gu.t(d[f"out/ssn/{mod}/{k}"])), k
+    assert torch.equal(xs["item_id"], gu.t(d["out/item_seq"]))
+    assert not torch.equal(xs["item_id"], x["item_id"])
+    # the masking runs on the swapped item ids (EmbeddingFeatures.forward stores item_seq after `pre`)
+    j2 = gu.t(d["draw/j2"])
+    m, lab = O.mlm_targets_train(xs["item_id"], gu.t(d["draw/bern"]), gu.t(d["draw/j1"]), lambda mm: j2)
+    assert torch.equal(m, gu.t(d["out/mask_schema"])) and torch.equal(lab, gu.t(d["out/masked_targets"]))
+    p = gu.oracle_params(d, requires_grad=True)
+    p["post_ln"] = gu.post_ln_params(d, requires_grad=True)
+    keep = {k[len("draw/post_keep/"):]: gu.t(v) for k, v in d.items() if k.startswith("draw/post_keep/")}
+    assert set(keep) == set(p["tables"]) == set(p["post_ln"])
+    cfg = _cfg(d, masking="mlm", aggregation=agg, post=post, post_drop_masks=keep)
+    out = O.session_forward(p, cfg, xs, m, lab, True, False)
+    torch.testing.assert_close(out["inputs_embeds"], gu.t(d["out/inputs_embeds"]), **TOL)
+    torch.testing.assert_close(out["hidden"], gu.t(d["out/hidden"]), **TOL)
+    torch.testing.assert_close(out["loss"], gu.t(d["out/loss"]), **TOL)
+    out["loss"].backward()
+    g = gu.section(d, "g/")
+    for f, tab in p["tables"].items():
+        torch.testing.assert_close(tab.grad, g[gu.CAT + f + ".weight"], **TOL)
+    for f, (wk, bk) in gu.post_ln_grad_keys(d).items():
+        torch.testing.assert_close(p["post_ln"][f][0].grad, g[wk], **TOL)
+        torch.testing.assert_close(p["post_ln"][f][1].grad, g[bk], **TOL)
+
+
 @pytest.mark.parametrize("name,params_from,masking", [
     ("xlnet_mlm_item_eval", "xlnet_mlm_item_train", "mlm"),
     ("xlnet_clm_item_eval", "xlnet_clm_item_train", "clm"),

@@ -9,7 +9,8 @@ __version__ = "0.1.0"
 from .schema import ColumnSchema, IntDomain, Schema, Tags, ValueCount, random_data_from_schema, session_schema  # noqa: E402,F401
 from .masking import CausalLanguageModeling, MaskedLanguageModeling, MaskSequence  # noqa: E402,F401
 from .features import (  # noqa: E402,F401
-    SequenceEmbeddingFeatures, SoftEmbedding, SoftEmbeddingFeatures, TabularSequenceFeatures)
+    ContinuousFeatures, SequenceEmbeddingFeatures, SoftEmbedding, SoftEmbeddingFeatures, TabularSequenceFeatures)
+from .transformations import StochasticSwapNoise, TabularDropout, TabularLayerNorm  # noqa: E402,F401
 from .transformer import TransformerBlock, XLNetConfig, XLNetModel  # noqa: E402,F401
 from .transformer_hf import BertConfig, BertModel, GPT2Config, GPT2Model  # noqa: E402,F401
 from .prediction_task import LogUniformSampler, NextItemPredictionTask  # noqa: E402,F401

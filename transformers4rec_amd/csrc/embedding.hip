@@ -25,8 +25,10 @@ enum { MASK_NONE = 0, MASK_MLM = 1, MASK_CLM = 2, MASK_CLM_INFER = 3 };
 
 struct SeqFeatParams {
     int n_feat;
-    int kind[T4R_MAX_FEATS];          // 0 table lookup, 1 dense rows (precomputed), 2 per-session table lookup
-    const void* input[T4R_MAX_FEATS]; // kind 0: int64 ids [B*L_in] ; 1: float [B*L_in, dim] ; 2: int64 ids [B]
+    int kind[T4R_MAX_FEATS];          // 0 table lookup, 1 dense rows (precomputed), 2 per-session table lookup,
+                                      // 3 per-session dense rows
+    const void* input[T4R_MAX_FEATS]; // kind 0: int64 ids [B*L_in] ; 1: float [B*L_in, dim] ; 2: int64 ids [B] ;
+                                      // 3: float [B, dim]
     const float* table[T4R_MAX_FEATS];
     int dim[T4R_MAX_FEATS];
     int col[T4R_MAX_FEATS];           // output column offset (concat) / 0 (sum)
@@ -87,7 +89,9 @@ __global__ __launch_bounds__(256) void seq_features_fwd_kernel(SeqFeatParams p) 
                     if (id < 0 || id >= p.rows[f]) { if (p.err) *p.err = 1; id = 0; }
                     row = p.table[f] + id * p.dim[f];
                 } else {
-                    row = reinterpret_cast<const float*>(p.input[f]) + ts * p.dim[f];
+                    // kind 1: dense rows per token ; kind 3: dense rows per session (a context feature
+                    // that went through a post transformation), broadcast over the sequence
+                    row = reinterpret_cast<const float*>(p.input[f]) + (p.kind[f] == 3 ? (long)b : ts) * p.dim[f];
                 }
                 if (lc0 >= 0 && lc0 + 4 <= p.dim[f] && (p.dim[f] & 3) == 0) {
                     const float4 t = *reinterpret_cast<const float4*>(row + lc0);
@@ -154,8 +158,8 @@ extern "C" int t4r_seq_features_fwd(
     for (int f = 0; f < n_feat; ++f) {
         p.kind[f] = kind[f]; p.input[f] = input[f]; p.table[f] = table[f]; p.dim[f] = dim[f];
         p.col[f] = col ? col[f] : 0; p.rows[f] = rows ? rows[f] : 0;
-        T4R_CHECK_ARG(input[f] && (kind[f] == 1 || table[f]), "seq_features: null feature pointer");
-        T4R_CHECK_ARG(kind[f] >= 0 && kind[f] <= 2, "seq_features: feature kind 0..2");
+        T4R_CHECK_ARG(input[f] && (kind[f] == 1 || kind[f] == 3 || table[f]), "seq_features: null feature pointer");
+        T4R_CHECK_ARG(kind[f] >= 0 && kind[f] <= 3, "seq_features: feature kind 0..3");
         if (agg != AGG_CONCAT) T4R_CHECK_ARG(dim[f] == W, "seq_features: element-wise needs equal dims");
     }
     p.agg = agg; p.item_feat = item_feat;

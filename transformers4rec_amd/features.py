@@ -14,6 +14,7 @@ import torch
 from torch import nn
 
 from . import ops
+from .transformations import TabularDropout, TabularLayerNorm, parse_post, parse_pre
 from .masking import MaskSequence, _grad_buf, parse_masking
 from .schema import Tags, categorical_cardinalities
 
@@ -67,13 +68,26 @@ class SoftEmbedding(nn.Module):
 class SequenceEmbeddingFeatures(nn.Module):
     """Categorical sequence features; holds `embedding_tables` and the stateful `item_seq`."""
 
-    def __init__(self, table_sizes: Dict[str, tuple], item_id: Optional[str] = None, padding_idx: int = 0):
+    def __init__(self, table_sizes: Dict[str, tuple], item_id: Optional[str] = None, padding_idx: int = 0,
+                 pre=None, post=None):
         super().__init__()
         self.item_id = item_id
         self.padding_idx = padding_idx
         self.embedding_tables = nn.ModuleDict(
             {n: EmbeddingTable(v, d, padding_idx=padding_idx) for n, (v, d) in table_sizes.items()})
         self.item_seq = None
+        # pre / post transformations (TabularModule, tabular/base.py:226-283); state-dict names as the
+        # reference: `_post.<i>.feature_layer_norm.<feature>.{weight,bias}`
+        self._pre = parse_pre(pre)
+        self._post = parse_post(post, {n: d for n, (v, d) in table_sizes.items()})
+
+    @property
+    def pre(self):
+        return self._pre
+
+    @property
+    def post(self):
+        return self._post
 
     @property
     def item_embedding_table(self):
@@ -93,10 +107,75 @@ class _FeaturePost(nn.Module):
 class SoftEmbeddingFeatures(nn.Module):
     """Continuous features through SoftEmbedding (+ per-feature LayerNorm in `post`)."""
 
-    def __init__(self, table_sizes: Dict[str, tuple], layer_norm: bool = True):
+    def __init__(self, table_sizes: Dict[str, tuple], layer_norm: bool = True, pre=None, post=None):
         super().__init__()
+        if post is not None and not layer_norm:
+            raise NotImplementedError("post transformations on soft embeddings other than the built-in "
+                                      "layer norm are off the hot path")
+        self._pre = parse_pre(pre)   # `post` is replaced by the LayerNorm when layer_norm=True (embedding.py:306-309)
         self.embedding_tables = nn.ModuleDict({n: SoftEmbedding(k, d) for n, (k, d) in table_sizes.items()})
         self.post = _FeaturePost({n: d for n, (k, d) in table_sizes.items()}) if layer_norm else None
+
+
+class ContinuousFeatures(nn.Module):
+    """Continuous sequence features passed through as width-1 columns
+    (features/continuous.py:60-63: unsqueeze(-1)); no parameters."""
+
+    def __init__(self, names, pre=None, post=None):
+        super().__init__()
+        self.names = list(names)
+        self._pre = parse_pre(pre)
+        self._post = parse_post(post, {n: 1 for n in self.names})   # LayerNorm skips dim-1 features
+        self.embedding_tables = nn.ModuleDict()
+        self.post = None
+
+
+_POST_SEED = 0x7AB1E5EED
+
+
+def _post_fwd(owner, post, name, fidx, e2d, step):
+    """Applies the module's post transformations to one feature's rows e2d [rows, D].
+    Dropout directly followed by the feature's LayerNorm runs as one fused launch.
+    -> (rows after post, records for _post_bwd)"""
+    saved = []
+    mods = list(post)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, TabularDropout):
+            p = m.dropout_rate if owner.training else 0.0
+            ctr = ops.dropout_ctr_hi(step, 0xFE, fidx * 8 + i)
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if isinstance(nxt, TabularLayerNorm) and name in nxt.feature_layer_norm:
+                ln = nxt.feature_layer_norm[name]
+                drop = (p, _POST_SEED, ctr) if p > 0 else ops.NO_DROP
+                y, mean, rstd = ops.add_layernorm_fwd(e2d, None, ln.weight.detach(), ln.bias.detach(), ln.eps, drop)
+                saved.append(("ln", e2d, mean, rstd, ln, drop))
+                e2d = y
+                i += 2
+                continue
+            if p > 0:
+                e2d = ops.dropout(e2d, p, _POST_SEED, ctr).view(e2d.shape)
+                saved.append(("drop", p, ctr))
+        elif name in m.feature_layer_norm:
+            ln = m.feature_layer_norm[name]
+            y, mean, rstd = ops.add_layernorm_fwd(e2d, None, ln.weight.detach(), ln.bias.detach(), ln.eps)
+            saved.append(("ln", e2d, mean, rstd, ln, ops.NO_DROP))
+            e2d = y
+        i += 1
+    return e2d, saved
+
+
+def _post_bwd(saved, dy):
+    for rec in reversed(saved):
+        if rec[0] == "drop":
+            dy = ops.dropout(dy, rec[1], _POST_SEED, rec[2]).view(dy.shape)
+        else:
+            _, a, mean, rstd, ln, drop = rec
+            r = ops.add_layernorm_bwd(a, None, ln.weight.detach(), mean, rstd, dy, _grad_buf(ln.weight),
+                                      _grad_buf(ln.bias), drop=drop)
+            dy = r[1] if drop[0] > 0 else r
+    return dy
 
 
 class _SeqFeaturesFn(torch.autograd.Function):
@@ -116,16 +195,32 @@ class _SeqFeaturesFn(torch.autograd.Function):
             mask = masking.mask_schema
             mask_mode = masking.apply_mode(training, testing)
             L_out = mask.shape[1]
-        feats, soft_saved = [], {}
-        for name in names:
+        feats, soft_saved, post_saved = [], {}, {}
+        step = mod._post_step
+        for fidx, name in enumerate(names):
             col, dim = mod._cols[name], mod._dims[name]
             if name in cat.embedding_tables:
                 tab = cat.embedding_tables[name].weight
                 ids_f = inputs[name].contiguous()
                 # a [B] id tensor is a non-sequential (context) feature: looked up once per session
                 # and broadcast over L (reference: tabular/base.py:53-63)
-                feats.append(dict(kind=2 if ids_f.ndim == 1 else 0, input=ids_f, table=tab.detach(), dim=dim,
-                                  col=col, rows=tab.shape[0]))
+                per_session = ids_f.ndim == 1
+                f = dict(kind=2 if per_session else 0, input=ids_f, table=tab.detach(), dim=dim, col=col,
+                         rows=tab.shape[0])
+                if cat._post is not None:
+                    # post transformations act on the feature's own rows before the aggregation: gather
+                    # them densely, transform, and hand them to the aggregation as dense rows
+                    Lf = 1 if per_session else L
+                    e = ops.seq_features_fwd([dict(f, kind=0, col=0)], "concat", B, Lf, Lf, dim,
+                                             err_flag=mod._err_flag(item_ids.device)).view(B * Lf, dim)
+                    e, post_saved[name] = _post_fwd(cat, cat._post, name, fidx, e, step)
+                    f = dict(kind=3 if per_session else 1, input=e, table=None, dim=dim, col=col)
+                feats.append(f)
+            elif isinstance(cont, ContinuousFeatures):
+                x = inputs[name].contiguous().float().view(B * L, 1)
+                if cont._post is not None:
+                    x, post_saved[name] = _post_fwd(cont, cont._post, name, fidx, x, step)
+                feats.append(dict(kind=1, input=x, table=None, dim=1, col=col))
             else:
                 se = cont.embedding_tables[name]
                 ln = cont.post.feature_layer_norm[name] if cont.post is not None else None
@@ -152,8 +247,8 @@ class _SeqFeaturesFn(torch.autograd.Function):
                            bias=lin.bias.detach(), epilogue=ops.EPI_BIAS_RELU).view(B, L_out, -1)
             if masking is not None:
                 ops.apply_mask_fwd_(out, mask, memb.detach(), mask_mode)
-        ctx.mod, ctx.inputs, ctx.soft_saved = mod, inputs, soft_saved
-        ctx.mask_mode, ctx.mask, ctx.dims = mask_mode, mask, (B, L, L_out, W)
+        ctx.mod, ctx.inputs, ctx.soft_saved, ctx.post_saved = mod, inputs, soft_saved, post_saved
+        ctx.mask_mode, ctx.mask, ctx.dims, ctx.post_step = mask_mode, mask, (B, L, L_out, W), step
         ctx.agg_out = agg_out if proj is not None else None
         ctx.proj_out = out if proj is not None else None
         return out
@@ -181,11 +276,19 @@ class _SeqFeaturesFn(torch.autograd.Function):
         agg = mod._aggregation
         if agg == "element-wise-sum-item-multi":
             item = cat.item_id
-            f_item = [dict(kind=0, input=ctx.inputs[item].contiguous(), table=cat.embedding_tables[item].weight.detach(),
-                           dim=W, col=0, rows=cat.embedding_tables[item].weight.shape[0])]
-            f_other = [dict(kind=0, input=ctx.inputs[n].contiguous(), table=cat.embedding_tables[n].weight.detach(),
-                            dim=W, col=0, rows=cat.embedding_tables[n].weight.shape[0])
-                       for n in names if n != item]
+            def again(n):   # the feature as the forward aggregated it (post-transformed rows are recomputed)
+                ids_n = ctx.inputs[n].contiguous()
+                tabn = cat.embedding_tables[n].weight.detach()
+                f = dict(kind=2 if ids_n.ndim == 1 else 0, input=ids_n, table=tabn, dim=W, col=0, rows=tabn.shape[0])
+                if n in ctx.post_saved:
+                    Lf = 1 if ids_n.ndim == 1 else L
+                    e = ops.seq_features_fwd([dict(f, kind=0)], "concat", B, Lf, Lf, W).view(B * Lf, W)
+                    e, _ = _post_fwd(cat, cat._post, n, names.index(n), e, ctx.post_step)
+                    f = dict(kind=3 if ids_n.ndim == 1 else 1, input=e, table=None, dim=W, col=0)
+                return f
+
+            f_item = [again(item)]
+            f_other = [again(n) for n in names if n != item]
             e_item = ops.seq_features_fwd(f_item, "element-wise-sum", B, L, L, W)
             e_other = ops.seq_features_fwd(f_other, "element-wise-sum", B, L, L, W)
             d_item, d_other = ops.mul(d, e_other), ops.mul(d, e_item)
@@ -198,7 +301,19 @@ class _SeqFeaturesFn(torch.autograd.Function):
                 src = d
                 if agg == "element-wise-sum-item-multi":
                     src = d_item if name == cat.item_id else d_other
-                ops.embedding_bwd(src, ctx.inputs[name].contiguous(), _grad_buf(tab), col, dim, cat.padding_idx)
+                ids_f = ctx.inputs[name].contiguous()
+                if name in ctx.post_saved:
+                    src2 = src.view(B * L, -1)
+                    if ids_f.ndim == 1:     # broadcast over L: the gradient is the sum over the sequence
+                        g = ops.seq_sum_cols(src2, col, dim, B, L)
+                    else:
+                        g = ops.copy_cols_out(src2, col, dim) if src2.shape[1] != dim else src2
+                    g = _post_bwd(ctx.post_saved[name], g)
+                    ops.embedding_bwd(g, ids_f, _grad_buf(tab), 0, dim, cat.padding_idx)
+                else:
+                    ops.embedding_bwd(src, ids_f, _grad_buf(tab), col, dim, cat.padding_idx)
+            elif isinstance(cont, ContinuousFeatures):
+                continue    # no parameters behind a pass-through column
             else:
                 se = cont.embedding_tables[name]
                 ln = cont.post.feature_layer_norm[name] if cont.post is not None else None
@@ -234,7 +349,9 @@ class TabularSequenceFeatures(nn.Module):
         self.to_merge = nn.ModuleDict(mods)
         self._aggregation = aggregation
         dims = {n: t.embedding_dim for n, t in categorical_module.embedding_tables.items()}
-        if continuous_module is not None:
+        if isinstance(continuous_module, ContinuousFeatures):
+            dims.update({n: 1 for n in continuous_module.names})
+        elif continuous_module is not None:
             dims.update({n: s.embedding_table.embedding_dim for n, s in continuous_module.embedding_tables.items()})
         # ConcatFeatures order = sorted(feature names) (tabular/aggregation.py:43)
         self._feature_order = sorted(dims)
@@ -256,6 +373,7 @@ class TabularSequenceFeatures(nn.Module):
         self._masking = None
         self.set_masking(masking)
         self._err = None
+        self._post_step = 0     # Philox stream position of the post-dropout / swap-noise draws
 
     # ------------------------------------------------------------------ reference attribute contract
     @property
@@ -309,7 +427,7 @@ class TabularSequenceFeatures(nn.Module):
                     d_output=None, masking=None, embedding_dims=None, embedding_dim_default=64,
                     soft_embedding_cardinalities=None, soft_embedding_cardinality_default=10,
                     soft_embedding_dims=None, soft_embedding_dim_default=8, layer_norm=True,
-                    projection=None, continuous_projection=None, **kwargs):
+                    projection=None, continuous_projection=None, pre=None, post=None, **kwargs):
         """Same keyword surface as the reference (features/sequence.py:140-229,
         features/embedding.py:103-221, :313-410) for the arguments the hot path uses."""
         if projection is not None or continuous_projection is not None:
@@ -322,16 +440,18 @@ class TabularSequenceFeatures(nn.Module):
         item_id = item_cols[0] if item_cols else None
         embedding_dims = embedding_dims or {}
         tables = {n: (v, embedding_dims.get(n, embedding_dim_default)) for n, v in cards.items()}
-        cat = SequenceEmbeddingFeatures(tables, item_id=item_id)
+        # pre / post reach every feature module through **kwargs in the reference
+        # (features/tabular.py:150-185); soft embeddings replace `post` by their LayerNorm
+        cat = SequenceEmbeddingFeatures(tables, item_id=item_id, pre=pre, post=post)
         cont = None
         cont_names = [c for c in schema.select_by_tag(list(continuous_tags)).column_names if c not in cards]
-        if cont_names:
-            if not continuous_soft_embeddings:
-                raise NotImplementedError("continuous features need continuous_soft_embeddings=True on this path")
+        if cont_names and not continuous_soft_embeddings:
+            cont = ContinuousFeatures(cont_names, pre=pre, post=post)     # features/continuous.py:60-63
+        elif cont_names:
             sc, sd = soft_embedding_cardinalities or {}, soft_embedding_dims or {}
             cont = SoftEmbeddingFeatures(
                 {n: (sc.get(n, soft_embedding_cardinality_default), sd.get(n, soft_embedding_dim_default))
-                 for n in cont_names}, layer_norm=layer_norm)
+                 for n in cont_names}, layer_norm=layer_norm, pre=pre, post=None if layer_norm else post)
         if (masking or d_output) and not aggregation:
             aggregation = "concat"
         out = cls(cat, cont, aggregation or "concat", d_output, None, schema, max_sequence_length)
@@ -342,8 +462,30 @@ class TabularSequenceFeatures(nn.Module):
         return out
 
     # ------------------------------------------------------------------ forward
+    def _apply_pre(self, inputs):
+        """StochasticSwapNoise of each feature module on its own features (TabularModule.__call__ runs
+        `pre` before forward, tabular/base.py:389); the padding mask comes from the ORIGINAL item ids."""
+        active = {}
+        out = inputs
+        for mi, (mname, m) in enumerate(self.to_merge.items()):
+            ssn = getattr(m, "_pre", None)
+            if ssn is None or not ssn.training:
+                continue
+            if out is inputs:
+                out = dict(inputs)
+                item_ids = inputs[self.categorical_module.item_id].contiguous()
+            names = list(m.names) if isinstance(m, ContinuousFeatures) else list(m.embedding_tables.keys())
+            out.update(ssn.augment_module(inputs, [n for n in names if n in inputs], item_ids, mname, mi))
+            active[id(ssn)] = ssn
+        for ssn in active.values():     # one stream position per forward, also when modules share the object
+            ssn.next_step()
+        return out
+
     def forward(self, inputs, training=False, testing=False, **kwargs):
         cat = self.categorical_module
+        inputs = self._apply_pre(inputs)
         if cat.item_id:
-            cat.item_seq = cat.item_ids(inputs)  # stateful, as the reference (embedding.py:242-245)
+            cat.item_seq = cat.item_ids(inputs)  # stateful, as the reference (embedding.py:242-245); after `pre`
+        if self.training:
+            self._post_step += 1
         return _SeqFeaturesFn.apply(cat.item_embedding_table.weight, self, inputs, training, testing)

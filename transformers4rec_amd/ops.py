@@ -186,6 +186,41 @@ def embedding_bwd(dout, ids, d_table, col, dim, padding_idx=0):
          _chk(d_table, torch.float32), ntok, W, col, dim, d_table.shape[0], padding_idx, ids_div)
 
 
+def swap_noise(x, item_ids, p, pad_token=0, bern=None, perm=None, seed=0, ctr_hi=0):
+    """tr.StochasticSwapNoise.augment for one feature: x [B, L] or [B] (int64 ids / fp32 values);
+    item_ids [B, L] gives the padding mask.  bern (uint8, x.shape) / perm (int64 [#non-pad]) inject
+    the draws; None -> device Philox draws."""
+    if x.dtype not in (torch.int64, torch.float32):
+        raise TypeError("swap_noise: int64 ids or fp32 values")
+    n = x.numel()
+    out = torch.empty_like(x)
+    stride = item_ids.shape[1] if x.ndim == item_ids.ndim - 1 else 1
+    nb = _lib.load().t4r_swap_noise_ws_bytes(n)
+    ws = torch.empty(max(nb, 1), device=x.device, dtype=torch.uint8)
+    if bern is not None:
+        bern = bern.to(torch.uint8).contiguous()
+    call("t4r_swap_noise", _stream(), _chk(x), out.data_ptr(), x.element_size(), n,
+         _chk(item_ids, torch.int64), int(pad_token), stride, float(p), _p(bern, torch.uint8),
+         _p(perm, torch.int64), int(seed), int(ctr_hi), ws.data_ptr(), nb)
+    return out
+
+
+def copy_cols_out(wide2d, col, dim):
+    """-> contiguous [rows, dim] copy of wide2d[:, col:col+dim]"""
+    rows, ldw = wide2d.shape
+    out = torch.empty((rows, dim), device=wide2d.device, dtype=torch.float32)
+    call("t4r_copy_cols", _stream(), _chk(wide2d, torch.float32), ldw, col, out.data_ptr(), dim, rows, 0)
+    return out
+
+
+def seq_sum_cols(wide2d, col, dim, B, L):
+    """-> [B, dim] = sum over the L tokens of each session of wide2d[:, col:col+dim]"""
+    out = torch.empty((B, dim), device=wide2d.device, dtype=torch.float32)
+    call("t4r_seq_sum_cols", _stream(), _chk(wide2d, torch.float32), wide2d.shape[1], col, out.data_ptr(), dim,
+         B, L)
+    return out
+
+
 def apply_mask_fwd_(x, mask, memb, mode):
     B, L, H = x.shape
     call("t4r_apply_mask_fwd", _stream(), _chk(x), _chk(mask), _chk(memb), B, L, H, mode)

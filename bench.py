@@ -197,6 +197,17 @@ def main():
     gather_bytes = BATCH * SEQ * (8 + 4 * D_MODEL + 4 * D_MODEL)
     gather_gbs = gather_bytes / (gather_ms * 1e-3) / 1e9
 
+    # HBM bytes of that launch from the PMC counters (FETCH_SIZE x2 on gfx950, WRITE_SIZE calibrated
+    # on a known copy; collected in separate rocprofv3 --pmc passes and committed under profiles/).
+    # It is a property of the kernel + shape, not of this run: taken from the committed measurement.
+    traffic, traffic_src = None, None
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_d_pmc_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        traffic = int(tj["traffic_bytes_per_launch"] * N_m / tj["n_rows"])   # scales with the label rows
+        traffic_src = tj["source"]
+
     if rank == 0:
         res = {
             "metric": "training sessions/sec (XLNet 4x128, 100k items, seq 20, MLM, tied full softmax)",
@@ -211,7 +222,9 @@ def main():
                        "dropout": args.dropout, "label_rows_per_step": N_m, "final_loss": round(loss, 4)},
             "roofline": {"kernel": "gemm_f32_kernel<64,64,16,NT> (next-item logits X@W^T)", "bound": "mfma",
                          "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                         "algorithmic_bytes": int(4 * (N_m * D_MODEL + W.shape[0] * D_MODEL + N_m * W.shape[0])),
                          "avg_launch_ms": round(gemm_ms, 4), "flops_per_launch": flops},
             "roofline_gather": {"kernel": "seq_features_fwd_kernel<32> (embedding gather)", "bound": "hbm",
                                 "achieved": round(gather_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

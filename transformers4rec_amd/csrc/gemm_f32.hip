@@ -10,13 +10,19 @@
 //
 // Design (gfx950): v_mfma_f32_32x32x2_f32 (exact f32, 64 FLOP/clk/SIMD, 157 TF chip peak).
 // 256-thread workgroup = 4 waves as 2(M) x 2(N); block tile BM x BN x BK, wave tile
-// (BM/2) x (BN/2) = WMxWN MFMA tiles of 32x32.  Both operands are staged through LDS in a
-// k-major image  S[k][m]  (m contiguous) so that an MFMA A/B fragment (lane l -> row l&31,
-// k-slot l>>5) is one conflict-free ds_read_b32 per lane.  Operands that are k-contiguous in
-// HBM are transposed on the way into LDS (row pitch == 2 mod 32 keeps the 4 scattered
-// ds_write_b32 of one float4 conflict free); m-contiguous operands are copied with 16-byte
-// LDS stores.  Global loads for tile t+1 are issued before the MFMAs of tile t (register
-// prefetch, 2 LDS buffers, one barrier per k-tile).
+// (BM/2) x (BN/2) = WMxWN MFMA tiles of 32x32.  Each operand keeps in LDS the orientation it has
+// in HBM, so it is staged with plain 16-byte global loads and 16-byte LDS stores:
+//   k-contiguous operand (A of N?, B of ?T):  image S[m][k], row pitch BK+4 floats
+//   m-contiguous operand (A of T?, B of ?N):  image S[k][m], row pitch BM+4 floats
+// The k-slots of the MFMA are permuted so that a lane reads CONTIGUOUS k from an S[m][k] image:
+// MFMA step s of a k-tile takes physical k = (lane>>5)*(BK/2) + s for both operands (any
+// bijection k <-> (step, half) is a valid contraction order).  A lane's fragments for four steps
+// are then one ds_read_b128 (conflict free: pitch/4 is odd) instead of four half-rate
+// ds_read_b32: LDS time per k-tile drops ~2x for NT GEMMs (logits, FF, projections), which were
+// LDS-bound -- a pure-MFMA loop reaches 156 TF on this chip (tools/mfma_peak.hip), the old
+// all-S[k][m] kernel 75 TF on the logits shape.  S[k][m] images are read with ds_read_b32.
+// Global loads for tile t+1 are issued before the MFMAs of tile t (register prefetch, 2 LDS
+// buffers, one barrier per k-tile).
 // Split-K (gridDim.z) accumulates with hardware fp32 atomics into a zeroed / accumulating C:
 // this is how every weight gradient (K = tokens) and the head's dX (K = vocabulary) get
 // enough workgroups to fill 256 CUs.
@@ -93,15 +99,19 @@ template <int BM, int BN, int BK, bool TA, bool TB, int FEAT>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     constexpr bool SG = (FEAT & 1) != 0, EDROP = (FEAT & 2) != 0;
     constexpr int WM = BM / 64, WN = BN / 64;          // MFMA tiles per wave per dim
-    constexpr int LDA_S = BM + (TA ? 4 : 2);           // LDS row pitch (floats)
-    constexpr int LDB_S = BN + (TB ? 2 : 4);
+    constexpr bool A_MK = !TA, B_MK = TB;              // operand image is S[m][k] (k contiguous)
+    constexpr int LDA_S = A_MK ? BK + 4 : BM + 4;      // LDS row pitch (floats)
+    constexpr int LDB_S = B_MK ? BK + 4 : BN + 4;
+    constexpr int A_SZ = A_MK ? BM * LDA_S : BK * LDA_S;   // floats per buffer
+    constexpr int B_SZ = B_MK ? BN * LDB_S : BK * LDB_S;
+    constexpr int KH = BK / 2;                         // k-slots per lane half
     constexpr int NA4 = BM * BK / 4 / 256;             // float4 per thread per tile
     constexpr int NB4 = BN * BK / 4 / 256;
     static_assert(NA4 >= 1 && NB4 >= 1, "tile too small");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                                   // [2][BK][LDA_S]
-    float* Bs = smem + 2 * BK * LDA_S;                  // [2][BK][LDB_S]
+    float* As = smem;                                   // [2][A_SZ]
+    float* Bs = smem + 2 * A_SZ;                        // [2][B_SZ]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -149,6 +159,39 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     int sgy[NA4];
     const float sg_g = SG ? (p.sg_gout ? *p.sg_gout : 1.f) / p.sg_rows : 0.f;
 
+    // Interior k-tiles (the common case) are loaded by a branch-free lambda of plain 16-byte loads and
+    // run in their own copy of the k-loop.  The guarded lambda zero-fills partial float4s, and its
+    // "v = 0; if (..) v = load" shape makes the compiler wait for outstanding loads before it may
+    // overwrite a component (s_waitcnt vmcnt(0) in the middle of the prefetch, measured: the
+    // prefetch no longer overlaps the MFMAs); it serves edge tiles and the K tail only.
+    auto load_tiles_fast = [&](int kt) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int r = 0; r < NA4; ++r) {
+            const int idx = tid + r * 256;
+            if (TA) {
+                const int k = idx / (BM / 4), m4 = (idx % (BM / 4)) * 4;
+                ra[r] = *reinterpret_cast<const float4*>(A + (long)(k0 + k) * p.lda + m0 + m4);
+                if (SG) { sgl[r] = p.sg_lse[k0 + k]; sgy[r] = (int)p.sg_labels[k0 + k]; }
+            } else {
+                const int m = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
+                ra[r] = *reinterpret_cast<const float4*>(A + (long)(m0 + m) * p.lda + k0 + k4);
+                if (SG) { sgl[r] = p.sg_lse[m0 + m]; sgy[r] = (int)p.sg_labels[m0 + m]; }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NB4; ++r) {
+            const int idx = tid + r * 256;
+            if (!TB) {
+                const int k = idx / (BN / 4), n4 = (idx % (BN / 4)) * 4;
+                rb[r] = *reinterpret_cast<const float4*>(B + (long)(k0 + k) * p.ldb + n0 + n4);
+            } else {
+                const int n = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
+                rb[r] = *reinterpret_cast<const float4*>(B + (long)(n0 + n) * p.ldb + k0 + k4);
+            }
+        }
+    };
+
     auto load_tiles = [&](int kt) {
         const int k0 = kt * BK;
 #pragma unroll
@@ -184,8 +227,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     };
 
     auto store_tiles = [&](int buf, int kt) {
-        float* as = As + buf * BK * LDA_S;
-        float* bs = Bs + buf * BK * LDB_S;
+        float* as = As + buf * A_SZ;
+        float* bs = Bs + buf * B_SZ;
 #pragma unroll
         for (int r = 0; r < NA4; ++r) {
             const int idx = tid + r * 256;
@@ -202,10 +245,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                     const int gm = m0 + m, gk = kt * BK + k4;
                     ra[r] = softmax_grad4(ra[r], gm < p.M ? p.K - gk : 0, sgl[r], sgy[r], gk, sg_g, p);
                 }
-                as[(k4 + 0) * LDA_S + m] = ra[r].x;
-                as[(k4 + 1) * LDA_S + m] = ra[r].y;
-                as[(k4 + 2) * LDA_S + m] = ra[r].z;
-                as[(k4 + 3) * LDA_S + m] = ra[r].w;
+                *reinterpret_cast<float4*>(as + m * LDA_S + k4) = ra[r];
             }
         }
 #pragma unroll
@@ -216,10 +256,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 *reinterpret_cast<float4*>(bs + k * LDB_S + n4) = rb[r];
             } else {
                 const int n = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
-                bs[(k4 + 0) * LDB_S + n] = rb[r].x;
-                bs[(k4 + 1) * LDB_S + n] = rb[r].y;
-                bs[(k4 + 2) * LDB_S + n] = rb[r].z;
-                bs[(k4 + 3) * LDB_S + n] = rb[r].w;
+                *reinterpret_cast<float4*>(bs + n * LDB_S + k4) = rb[r];
             }
         }
     };
@@ -234,7 +271,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_tiles(kt_begin);
+    // k-tiles [kt_begin, kt_fast) are interior in m, n and k: their loads never need a guard
+    const bool interior_mn = (m0 + BM <= p.M) && (n0 + BN <= p.N) && vecA && vecB;
+    const int kt_fast = interior_mn ? min(kt_end, p.K / BK) : kt_begin;
+    if (kt_begin < kt_fast) load_tiles_fast(kt_begin); else load_tiles(kt_begin);
     store_tiles(0, kt_begin);
     __syncthreads();
 
@@ -242,28 +282,60 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     const int bcol = wn * (BN / 2) + (lane & 31);
     const int khalf = lane >> 5;
 
-    int buf = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const bool more = kt + 1 < kt_end;
-        if (more) load_tiles(kt + 1);
-        const float* as = As + buf * BK * LDA_S;
-        const float* bs = Bs + buf * BK * LDB_S;
-        // (fetching all fragments of the k-tile before the MFMAs was measured: slower in the full
-        //  step -- one more VGPR bank costs a resident wave; the simple per-step form stays)
+    // the MFMAs of one resident k-tile: four steps per fragment fetch, physical k = khalf*KH + 4*h + e
+    auto compute = [&](int buf) {
+        const float* as = As + buf * A_SZ;
+        const float* bs = Bs + buf * B_SZ;
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            const int k = 2 * kk + khalf;
-            float a[WM], b[WN];
+        for (int h = 0; h < KH / 4; ++h) {
+            float4 a[WM], b[WN];
 #pragma unroll
-            for (int i = 0; i < WM; ++i) a[i] = as[k * LDA_S + arow + i * 32];
+            for (int i = 0; i < WM; ++i) {
+                if (A_MK) {
+                    a[i] = *reinterpret_cast<const float4*>(as + (arow + i * 32) * LDA_S + khalf * KH + 4 * h);
+                } else {
+                    const float* q = as + (khalf * KH + 4 * h) * LDA_S + arow + i * 32;
+                    a[i] = make_float4(q[0], q[LDA_S], q[2 * LDA_S], q[3 * LDA_S]);
+                }
+            }
 #pragma unroll
-            for (int j = 0; j < WN; ++j) b[j] = bs[k * LDB_S + bcol + j * 32];
+            for (int j = 0; j < WN; ++j) {
+                if (B_MK) {
+                    b[j] = *reinterpret_cast<const float4*>(bs + (bcol + j * 32) * LDB_S + khalf * KH + 4 * h);
+                } else {
+                    const float* q = bs + (khalf * KH + 4 * h) * LDB_S + bcol + j * 32;
+                    b[j] = make_float4(q[0], q[LDB_S], q[2 * LDB_S], q[3 * LDB_S]);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < WN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                }
         }
+    };
+
+    int buf = 0;
+    int kt = kt_begin;
+    for (; kt + 1 < kt_fast; ++kt) {          // tile kt resident, tile kt+1 interior
+        load_tiles_fast(kt + 1);
+        // keep the prefetch ABOVE the MFMAs: left alone, the scheduler sinks the global loads below
+        // them to reuse the fragment registers and then waits for the loads right away
+        __builtin_amdgcn_sched_barrier(0);
+        compute(buf);
+        __builtin_amdgcn_sched_barrier(0);
+        store_tiles(buf ^ 1, kt + 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    for (; kt < kt_end; ++kt) {               // edge tiles / K tail
+        const bool more = kt + 1 < kt_end;
+        if (more) load_tiles(kt + 1);
+        compute(buf);
         if (more) store_tiles(buf ^ 1, kt + 1);
         __syncthreads();
         buf ^= 1;
@@ -313,8 +385,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 
 template <int BM, int BN, int BK, bool TA, bool TB, int FEAT>
 static int launch_feat(const GemmParams& p, int batch, hipStream_t stream) {
-    constexpr int LDA_S = BM + (TA ? 4 : 2), LDB_S = BN + (TB ? 2 : 4);
-    constexpr size_t smem = (size_t)2 * BK * (LDA_S + LDB_S) * sizeof(float);
+    constexpr int A_SZ = !TA ? BM * (BK + 4) : BK * (BM + 4), B_SZ = TB ? BN * (BK + 4) : BK * (BN + 4);
+    constexpr size_t smem = (size_t)2 * (A_SZ + B_SZ) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_f32_kernel<BM, BN, BK, TA, TB, FEAT>,
@@ -367,7 +439,14 @@ static int launch_layout(GemmParams& p, int batch, int splitk_req, hipStream_t s
     } else if (splitk_req < 0) {
         const long blocks = nblk(bm, bn);
         const int kt = (p.K + BK - 1) / BK;
-        splitk = (int)min((long)kt, max(1L, 1024 / max(1L, blocks)));
+        // enough workgroups to fill 256 CUs x 8 (the k-loop of one workgroup hides latency only
+        // through other resident workgroups), but at least ~20 k-tiles each so that the atomics of
+        // the epilogue stay a small part.  Measured (tools/gemm_bench.py): head dX 2765x128x100001
+        // 1076 us at 1024 workgroups, 786 us at 4096; wgrad 128x512x20480 best at 64 splits.
+        static long target = -1, min_tiles = -1;
+        if (target < 0) { const char* e = getenv("T4R_GEMM_SPLIT_TARGET"); target = e ? atol(e) : 4096; }
+        if (min_tiles < 0) { const char* e = getenv("T4R_GEMM_SPLIT_MIN_TILES"); min_tiles = e ? atol(e) : 20; }
+        splitk = (int)max(1L, min((long)kt / min_tiles, target / max(1L, blocks)));
         splitk = min(splitk, 256);
     }
     p.splitk = max(1, splitk);

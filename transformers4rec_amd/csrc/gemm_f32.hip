@@ -406,13 +406,13 @@ template <int BM, int BN, int BK, bool TA, bool TB>
 static int launch_cfg(const GemmParams& p, int batch, hipStream_t stream) {
     if (p.sg_lse) {
         // softmax-gradient operand: only the tile the head uses is instantiated
-        if (BM == 64 && BN == 64 && BK == 16 && !TB) return launch_feat<64, 64, 16, TA, false, 1>(p, batch, stream);
-        t4r_set_error("gemm: softmax-grad operand needs the 64x64x16 tile and transB = 0");
+        if (BM == 64 && BN == 64 && !TB) return launch_feat<64, 64, BK, TA, false, 1>(p, batch, stream);
+        t4r_set_error("gemm: softmax-grad operand needs the 64x64 tile and transB = 0");
         return -1;
     }
     if (p.drop.p > 0.f && (p.epilogue == EPI_BIAS_GELU || p.epilogue == EPI_BIAS_RESID)) {
-        if (BM == 64 && BN == 64 && BK == 16) return launch_feat<64, 64, 16, TA, TB, 2>(p, batch, stream);
-        t4r_set_error("gemm: epilogue dropout needs the 64x64x16 tile");
+        if (BM == 64 && BN == 64) return launch_feat<64, 64, BK, TA, TB, 2>(p, batch, stream);
+        t4r_set_error("gemm: epilogue dropout needs the 64x64 tile");
         return -1;
     }
     return launch_feat<BM, BN, BK, TA, TB, 0>(p, batch, stream);
@@ -431,14 +431,14 @@ static int launch_layout(GemmParams& p, int batch, int splitk_req, hipStream_t s
     if (tile_sel == 1) { bm = 64; bn = 128; } else if (tile_sel == 2) { bm = 128; bn = 64; }
     else if (tile_sel == 3) { bm = 64; bn = 64; } else if (tile_sel == 4) { bm = 128; bn = 128; }
     static int bk_sel = -1;
-    if (bk_sel < 0) { const char* e = getenv("T4R_GEMM_BK"); bk_sel = e ? atoi(e) : 16; }
-    const int BK = bk_sel;
+    if (bk_sel < 0) { const char* e = getenv("T4R_GEMM_BK"); bk_sel = e ? atoi(e) : 0; }
     int splitk = splitk_req;
     if (splitk_req == 0) {  // auto: only when the caller allows atomics (accumulating outputs)
         splitk = 1;
     } else if (splitk_req < 0) {
         const long blocks = nblk(bm, bn);
-        const int kt = (p.K + BK - 1) / BK;
+        const int bk0 = bk_sel ? bk_sel : 16;
+        const int kt = (p.K + bk0 - 1) / bk0;
         // enough workgroups to fill 256 CUs x 8 (the k-loop of one workgroup hides latency only
         // through other resident workgroups), but at least ~20 k-tiles each so that the atomics of
         // the epilogue stay a small part.  Measured (tools/gemm_bench.py): head dX 2765x128x100001
@@ -450,6 +450,12 @@ static int launch_layout(GemmParams& p, int batch, int splitk_req, hipStream_t s
         splitk = min(splitk, 256);
     }
     p.splitk = max(1, splitk);
+    // k-tile depth 16.  BK = 32 (16 MFMAs per barrier) wins isolated long-K launches (square 111 ->
+    // 115 TF, wgrads 72 -> 80, head dX 91 -> 96; tools/gemm_bench.py) but loses on the K = 128
+    // contractions (logits 85 -> 76 TF) and, selected per launch by K, made the whole training step
+    // slower (6.31 vs 6.23 ms, same box): the softmax-gradient variants pay for the doubled staging
+    // registers.  T4R_GEMM_BK=32 keeps it available for experiments.
+    const int BK = bk_sel ? bk_sel : 16;
     static int xcd_sel = -1;
     if (xcd_sel < 0) { const char* e = getenv("T4R_GEMM_XCD"); xcd_sel = e ? atoi(e) : 1; }
     p.xcd_order = xcd_sel;

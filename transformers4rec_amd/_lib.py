@@ -8,7 +8,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libt4r_hip.so")
+# T4R_HIP_LIB selects another build of the same ABI (A/B timing of kernel variants on one box)
+LIB_PATH = os.environ.get("T4R_HIP_LIB") or os.path.join(_HERE, "lib", "libt4r_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "t4r_hip.h")
 
 _P, _I, _L, _F, _Q = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_ulonglong

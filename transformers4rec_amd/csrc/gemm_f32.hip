@@ -28,6 +28,7 @@
 // enough workgroups to fill 256 CUs.
 #include "t4r_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -78,24 +79,30 @@ __device__ __forceinline__ float4 softmax_grad4(float4 v, int valid, float l, in
     return v;
 }
 
-// Load one float4 worth of an operand with guards.  `valid` = number of in-range elements
-// (<=0: none).  vec: 16-byte load legal.
-__device__ __forceinline__ float4 ld4_guard(const float* p, int valid, bool vec) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid >= 4 && vec) {
-        v = *reinterpret_cast<const float4*>(p);
-    } else if (valid > 0) {
-        v.x = p[0];
-        if (valid > 1) v.y = p[1];
-        if (valid > 2) v.z = p[2];
-        if (valid > 3) v.w = p[3];
-    }
+// Edge handling without branches: every staging load reads a LEGAL address (row and column
+// clamped into the operand) and the out-of-range elements are zeroed when the stage moves to LDS.
+// A guarded "v = 0; if (in range) v = load" form makes the compiler wait for the outstanding
+// loads before it may overwrite a component (s_waitcnt vmcnt(0) in the middle of the prefetch).
+// rowp: start of an in-range row; c: first column (multiple of 4); lim: columns of the row.
+// vec: 16-byte loads legal (base and row pitch multiples of 4 floats; the pitch then covers
+// ceil4(lim), so the partial last float4 of a row stays inside the row).
+template <bool VEC>
+__device__ __forceinline__ float4 ld4_clamped(const float* rowp, int c, int lim) {
+    if (VEC) return *reinterpret_cast<const float4*>(rowp + min(c, (lim - 1) & ~3));
+    const int l = lim - 1;
+    return make_float4(rowp[min(c, l)], rowp[min(c + 1, l)], rowp[min(c + 2, l)], rowp[min(c + 3, l)]);
+}
+__device__ __forceinline__ float4 mask4(float4 v, int valid) {   // keep the first `valid` elements
+    v.x = valid > 0 ? v.x : 0.f; v.y = valid > 1 ? v.y : 0.f;
+    v.z = valid > 2 ? v.z : 0.f; v.w = valid > 3 ? v.w : 0.f;
     return v;
 }
 
 // FEAT bit 0: softmax-gradient A operand ; bit 1: dropout in the epilogue.  Compile-time so that the
 // plain GEMM does not carry the Philox / exp code (measured: +12 % step time when it did).
-template <int BM, int BN, int BK, bool TA, bool TB, int FEAT>
+// VEC: both operands can be staged with 16-byte loads (decided by the host from pointers / pitches);
+// the scalar-load variant is its own instantiation so that it does not set the register budget.
+template <int BM, int BN, int BK, bool TA, bool TB, int FEAT, bool VEC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     constexpr bool SG = (FEAT & 1) != 0, EDROP = (FEAT & 2) != 0;
     constexpr int WM = BM / 64, WN = BN / 64;          // MFMA tiles per wave per dim
@@ -150,65 +157,36 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     const float* A = p.A + batch * p.sA;
     const float* B = p.B + batch * p.sB;
     float* C = p.C + batch * p.sC;
-    const bool vecA = p.vecA, vecB = p.vecB;
 
-    float4 ra[NA4], rb[NB4];
+    // Two register stages of staging data: the interior k-loop keeps the global loads of TWO k-tiles
+    // in flight (tile kt+2 is requested while tile kt is multiplied and tile kt+1 moves from its
+    // stage to LDS), so a load has two MFMA phases (~1000 cycles) to arrive instead of one.
     // softmax-gradient A operand: per-row lse / label are prefetched with the tile, the transform
-    // itself runs in store_tiles (after the MFMAs), so the global loads still overlap compute
-    float sgl[NA4];
-    int sgy[NA4];
+    // itself runs in store_tiles (after the MFMAs), so the global loads still overlap compute.
+    float4 ra0[NA4], rb0[NB4], ra1[NA4], rb1[NB4];
+    float sgl0[NA4], sgl1[NA4];
+    int sgy0[NA4], sgy1[NA4];
+#define T4R_STAGE_PARAMS float4(&ra)[NA4], float4(&rb)[NB4], float(&sgl)[NA4], int(&sgy)[NA4]
+#define T4R_S0 ra0, rb0, sgl0, sgy0
+#define T4R_S1 ra1, rb1, sgl1, sgy1
     const float sg_g = SG ? (p.sg_gout ? *p.sg_gout : 1.f) / p.sg_rows : 0.f;
 
-    // Interior k-tiles (the common case) are loaded by a branch-free lambda of plain 16-byte loads and
-    // run in their own copy of the k-loop.  The guarded lambda zero-fills partial float4s, and its
-    // "v = 0; if (..) v = load" shape makes the compiler wait for outstanding loads before it may
-    // overwrite a component (s_waitcnt vmcnt(0) in the middle of the prefetch, measured: the
-    // prefetch no longer overlaps the MFMAs); it serves edge tiles and the K tail only.
-    auto load_tiles_fast = [&](int kt) {
-        const int k0 = kt * BK;
-#pragma unroll
-        for (int r = 0; r < NA4; ++r) {
-            const int idx = tid + r * 256;
-            if (TA) {
-                const int k = idx / (BM / 4), m4 = (idx % (BM / 4)) * 4;
-                ra[r] = *reinterpret_cast<const float4*>(A + (long)(k0 + k) * p.lda + m0 + m4);
-                if (SG) { sgl[r] = p.sg_lse[k0 + k]; sgy[r] = (int)p.sg_labels[k0 + k]; }
-            } else {
-                const int m = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
-                ra[r] = *reinterpret_cast<const float4*>(A + (long)(m0 + m) * p.lda + k0 + k4);
-                if (SG) { sgl[r] = p.sg_lse[m0 + m]; sgy[r] = (int)p.sg_labels[m0 + m]; }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < NB4; ++r) {
-            const int idx = tid + r * 256;
-            if (!TB) {
-                const int k = idx / (BN / 4), n4 = (idx % (BN / 4)) * 4;
-                rb[r] = *reinterpret_cast<const float4*>(B + (long)(k0 + k) * p.ldb + n0 + n4);
-            } else {
-                const int n = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
-                rb[r] = *reinterpret_cast<const float4*>(B + (long)(n0 + n) * p.ldb + k0 + k4);
-            }
-        }
-    };
-
-    auto load_tiles = [&](int kt) {
+    // staging loads of k-tile kt (all addresses legal, see ld4_clamped)
+    auto load_tiles = [&](T4R_STAGE_PARAMS, int kt) __attribute__((always_inline)) {
         const int k0 = kt * BK;
 #pragma unroll
         for (int r = 0; r < NA4; ++r) {
             const int idx = tid + r * 256;
             if (TA) {  // A[K][lda], m contiguous: tile row = k, 4 consecutive m
                 const int k = idx / (BM / 4), m4 = (idx % (BM / 4)) * 4;
-                const int gk = k0 + k, gm = m0 + m4;
-                const int valid = gk < p.K ? p.M - gm : 0;
-                ra[r] = ld4_guard(A + (long)gk * p.lda + gm, valid, vecA);
-                if (SG && valid > 0) { sgl[r] = p.sg_lse[gk]; sgy[r] = (int)p.sg_labels[gk]; }  // rows = k
+                const int gk = min(k0 + k, p.K - 1);
+                ra[r] = ld4_clamped<VEC>(A + (long)gk * p.lda, m0 + m4, p.M);
+                if (SG) { sgl[r] = p.sg_lse[gk]; sgy[r] = (int)p.sg_labels[gk]; }      // rows = k
             } else {   // A[M][lda], k contiguous: tile row = m, 4 consecutive k
                 const int m = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
-                const int gm = m0 + m, gk = k0 + k4;
-                const int valid = gm < p.M ? p.K - gk : 0;
-                ra[r] = ld4_guard(A + (long)gm * p.lda + gk, valid, vecA);
-                if (SG && valid > 0) { sgl[r] = p.sg_lse[gm]; sgy[r] = (int)p.sg_labels[gm]; }  // rows = m
+                const int gm = min(m0 + m, p.M - 1);
+                ra[r] = ld4_clamped<VEC>(A + (long)gm * p.lda, k0 + k4, p.K);
+                if (SG) { sgl[r] = p.sg_lse[gm]; sgy[r] = (int)p.sg_labels[gm]; }      // rows = m
             }
         }
 #pragma unroll
@@ -216,36 +194,34 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             const int idx = tid + r * 256;
             if (!TB) {  // B[K][ldb], n contiguous
                 const int k = idx / (BN / 4), n4 = (idx % (BN / 4)) * 4;
-                const int gk = k0 + k, gn = n0 + n4;
-                rb[r] = ld4_guard(B + (long)gk * p.ldb + gn, gk < p.K ? p.N - gn : 0, vecB);
+                rb[r] = ld4_clamped<VEC>(B + (long)min(k0 + k, p.K - 1) * p.ldb, n0 + n4, p.N);
             } else {    // B[N][ldb], k contiguous
                 const int n = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
-                const int gn = n0 + n, gk = k0 + k4;
-                rb[r] = ld4_guard(B + (long)gn * p.ldb + gk, gn < p.N ? p.K - gk : 0, vecB);
+                rb[r] = ld4_clamped<VEC>(B + (long)min(n0 + n, p.N - 1) * p.ldb, k0 + k4, p.K);
             }
         }
     };
 
-    auto store_tiles = [&](int buf, int kt) {
+    // stage -> LDS image of buffer `buf`; zeroes what lies outside the operands (edge tiles / K tail)
+    auto store_tiles = [&](T4R_STAGE_PARAMS, int buf, int kt, bool live) __attribute__((always_inline)) {
         float* as = As + buf * A_SZ;
         float* bs = Bs + buf * B_SZ;
+        const int k0 = kt * BK;
 #pragma unroll
         for (int r = 0; r < NA4; ++r) {
             const int idx = tid + r * 256;
             if (TA) {
                 const int k = idx / (BM / 4), m4 = (idx % (BM / 4)) * 4;
-                if (SG) {
-                    const int gk = kt * BK + k, gm = m0 + m4;
-                    ra[r] = softmax_grad4(ra[r], gk < p.K ? p.M - gm : 0, sgl[r], sgy[r], gm, sg_g, p);
-                }
-                *reinterpret_cast<float4*>(as + k * LDA_S + m4) = ra[r];
+                const int gk = k0 + k, gm = m0 + m4;
+                const int valid = (live && gk < p.K) ? p.M - gm : 0;
+                if (SG) ra[r] = softmax_grad4(ra[r], valid, sgl[r], sgy[r], gm, sg_g, p);
+                *reinterpret_cast<float4*>(as + k * LDA_S + m4) = mask4(ra[r], valid);
             } else {
                 const int m = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
-                if (SG) {
-                    const int gm = m0 + m, gk = kt * BK + k4;
-                    ra[r] = softmax_grad4(ra[r], gm < p.M ? p.K - gk : 0, sgl[r], sgy[r], gk, sg_g, p);
-                }
-                *reinterpret_cast<float4*>(as + m * LDA_S + k4) = ra[r];
+                const int gm = m0 + m, gk = k0 + k4;
+                const int valid = (live && gm < p.M) ? p.K - gk : 0;
+                if (SG) ra[r] = softmax_grad4(ra[r], valid, sgl[r], sgy[r], gk, sg_g, p);
+                *reinterpret_cast<float4*>(as + m * LDA_S + k4) = mask4(ra[r], valid);
             }
         }
 #pragma unroll
@@ -253,10 +229,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             const int idx = tid + r * 256;
             if (!TB) {
                 const int k = idx / (BN / 4), n4 = (idx % (BN / 4)) * 4;
-                *reinterpret_cast<float4*>(bs + k * LDB_S + n4) = rb[r];
+                const int valid = (live && k0 + k < p.K) ? p.N - (n0 + n4) : 0;
+                *reinterpret_cast<float4*>(bs + k * LDB_S + n4) = mask4(rb[r], valid);
             } else {
                 const int n = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
-                *reinterpret_cast<float4*>(bs + n * LDB_S + k4) = rb[r];
+                const int valid = (live && n0 + n < p.N) ? p.K - (k0 + k4) : 0;
+                *reinterpret_cast<float4*>(bs + n * LDB_S + k4) = mask4(rb[r], valid);
             }
         }
     };
@@ -271,19 +249,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // k-tiles [kt_begin, kt_fast) are interior in m, n and k: their loads never need a guard
-    const bool interior_mn = (m0 + BM <= p.M) && (n0 + BN <= p.N) && vecA && vecB;
-    const int kt_fast = interior_mn ? min(kt_end, p.K / BK) : kt_begin;
-    if (kt_begin < kt_fast) load_tiles_fast(kt_begin); else load_tiles(kt_begin);
-    store_tiles(0, kt_begin);
-    __syncthreads();
-
     const int arow = wm * (BM / 2) + (lane & 31);
     const int bcol = wn * (BN / 2) + (lane & 31);
     const int khalf = lane >> 5;
 
     // the MFMAs of one resident k-tile: four steps per fragment fetch, physical k = khalf*KH + 4*h + e
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf) __attribute__((always_inline)) {
         const float* as = As + buf * A_SZ;
         const float* bs = Bs + buf * B_SZ;
 #pragma unroll
@@ -319,26 +290,35 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         }
     };
 
-    int buf = 0;
-    int kt = kt_begin;
-    for (; kt + 1 < kt_fast; ++kt) {          // tile kt resident, tile kt+1 interior
-        load_tiles_fast(kt + 1);
-        // keep the prefetch ABOVE the MFMAs: left alone, the scheduler sinks the global loads below
-        // them to reuse the fragment registers and then waits for the loads right away
-        __builtin_amdgcn_sched_barrier(0);
-        compute(buf);
-        __builtin_amdgcn_sched_barrier(0);
-        store_tiles(buf ^ 1, kt + 1);
+    // Software pipeline over the workgroup's k-tiles.  Tile i is multiplied out of LDS[buf] while
+    // tile i+1 moves from its register stage to LDS[buf^1] and tile i+2 is requested from memory,
+    // so a global load has two MFMA phases (~1000 cycles) to arrive.  The loop is branch-free and
+    // runs over PAIRS of tiles (the two stages swap roles, so the register roles are identical at
+    // every back-edge); an odd tile count is rounded up with an all-zero tile, and requests past the
+    // last tile re-read the last tile (legal addresses, data never used).  The prefetch is pinned
+    // ABOVE the MFMAs: left alone, the scheduler sinks the global loads below them to reuse the
+    // fragment registers and then waits for the loads right away.
+    {
+        const int last = kt_end - 1;
+        load_tiles(T4R_S0, kt_begin);
+        store_tiles(T4R_S0, 0, kt_begin, true);
         __syncthreads();
-        buf ^= 1;
-    }
-    for (; kt < kt_end; ++kt) {               // edge tiles / K tail
-        const bool more = kt + 1 < kt_end;
-        if (more) load_tiles(kt + 1);
-        compute(buf);
-        if (more) store_tiles(buf ^ 1, kt + 1);
-        __syncthreads();
-        buf ^= 1;
+        load_tiles(T4R_S0, min(kt_begin + 1, last));
+        int buf = 0;
+        for (int kt = kt_begin; kt < kt_end; kt += 2) {
+            load_tiles(T4R_S1, min(kt + 2, last));
+            __builtin_amdgcn_sched_barrier(0);
+            compute(buf);
+            __builtin_amdgcn_sched_barrier(0);
+            store_tiles(T4R_S0, buf ^ 1, kt + 1, kt + 1 < kt_end);
+            __syncthreads();
+            load_tiles(T4R_S0, min(kt + 3, last));
+            __builtin_amdgcn_sched_barrier(0);
+            compute(buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            store_tiles(T4R_S1, buf, kt + 2, kt + 2 < kt_end);
+            __syncthreads();
+        }
     }
 
     // epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -383,13 +363,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     }
 }
 
-template <int BM, int BN, int BK, bool TA, bool TB, int FEAT>
-static int launch_feat(const GemmParams& p, int batch, hipStream_t stream) {
+template <int BM, int BN, int BK, bool TA, bool TB, int FEAT, bool VEC>
+static int launch_vec(const GemmParams& p, int batch, hipStream_t stream) {
     constexpr int A_SZ = !TA ? BM * (BK + 4) : BK * (BM + 4), B_SZ = TB ? BN * (BK + 4) : BK * (BN + 4);
-    constexpr size_t smem = (size_t)2 * (A_SZ + B_SZ) * sizeof(float);
+    static long pad = -1;   // experiment knob: extra LDS per workgroup = fewer resident workgroups per CU
+    if (pad < 0) { const char* e = getenv("T4R_GEMM_LDS_PAD"); pad = e ? atol(e) : 0; }
+    const size_t smem = (size_t)2 * (A_SZ + B_SZ) * sizeof(float) + (size_t)pad;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_f32_kernel<BM, BN, BK, TA, TB, FEAT>,
+        (void)hipFuncSetAttribute((const void*)gemm_f32_kernel<BM, BN, BK, TA, TB, FEAT, VEC>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
@@ -397,9 +379,15 @@ static int launch_feat(const GemmParams& p, int batch, hipStream_t stream) {
     const int Tl = TM <= TN ? TN : TM, Ts = TM <= TN ? TM : TN;
     const int gx = (TM * TN < 128 || !p.xcd_order) ? TM * TN : 8 * ((Tl + 7) / 8) * Ts;   // must match the kernel's decode
     dim3 grid(gx, 1, batch * p.splitk);
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, TA, TB, FEAT>), grid, dim3(256), smem, stream, p);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, TA, TB, FEAT, VEC>), grid, dim3(256), smem, stream, p);
     T4R_LAUNCH_CHECK();
     return 0;
+}
+
+template <int BM, int BN, int BK, bool TA, bool TB, int FEAT>
+static int launch_feat(const GemmParams& p, int batch, hipStream_t stream) {
+    if (p.vecA && p.vecB) return launch_vec<BM, BN, BK, TA, TB, FEAT, true>(p, batch, stream);
+    return launch_vec<BM, BN, BK, TA, TB, FEAT, false>(p, batch, stream);
 }
 
 template <int BM, int BN, int BK, bool TA, bool TB>

@@ -92,6 +92,13 @@ __device__ __forceinline__ float4 ld4_clamped(const float* rowp, int c, int lim)
     const int l = lim - 1;
     return make_float4(rowp[min(c, l)], rowp[min(c + 1, l)], rowp[min(c + 2, l)], rowp[min(c + 3, l)]);
 }
+// Pins the point where a staged register is first consumed: nothing computed from it (edge masks,
+// the softmax-gradient transform) may be hoisted above this statement -- the compiler otherwise
+// moves such pure VALU work up to the load and waits for the load there (s_waitcnt vmcnt(0) in the
+// middle of the prefetch distance).
+__device__ __forceinline__ void pin4(float4& v) {
+    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+}
 __device__ __forceinline__ float4 mask4(float4 v, int valid) {   // keep the first `valid` elements
     v.x = valid > 0 ? v.x : 0.f; v.y = valid > 1 ? v.y : 0.f;
     v.z = valid > 2 ? v.z : 0.f; v.w = valid > 3 ? v.w : 0.f;
@@ -208,6 +215,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         float* bs = Bs + buf * B_SZ;
         const int k0 = kt * BK;
 #pragma unroll
+        for (int r = 0; r < NA4; ++r) pin4(ra[r]);
+#pragma unroll
+        for (int r = 0; r < NB4; ++r) pin4(rb[r]);
+#pragma unroll
         for (int r = 0; r < NA4; ++r) {
             const int idx = tid + r * 256;
             if (TA) {
@@ -253,72 +264,80 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     const int bcol = wn * (BN / 2) + (lane & 31);
     const int khalf = lane >> 5;
 
-    // the MFMAs of one resident k-tile: four steps per fragment fetch, physical k = khalf*KH + 4*h + e
-    auto compute = [&](int buf) __attribute__((always_inline)) {
+    // MFMA operand fragments of ONE k-tile, held in registers: NH groups of four MFMA steps
+    // (physical k = khalf*KH + 4*h + e).  They are fetched from LDS one k-tile ahead (see below).
+    constexpr int NH = KH / 4;
+    float4 fa[NH][WM], fb[NH][WN];
+    auto read_frag = [&](int buf, int h) __attribute__((always_inline)) {
         const float* as = As + buf * A_SZ;
         const float* bs = Bs + buf * B_SZ;
 #pragma unroll
-        for (int h = 0; h < KH / 4; ++h) {
-            float4 a[WM], b[WN];
-#pragma unroll
-            for (int i = 0; i < WM; ++i) {
-                if (A_MK) {
-                    a[i] = *reinterpret_cast<const float4*>(as + (arow + i * 32) * LDA_S + khalf * KH + 4 * h);
-                } else {
-                    const float* q = as + (khalf * KH + 4 * h) * LDA_S + arow + i * 32;
-                    a[i] = make_float4(q[0], q[LDA_S], q[2 * LDA_S], q[3 * LDA_S]);
-                }
+        for (int i = 0; i < WM; ++i) {
+            if (A_MK) {
+                fa[h][i] = *reinterpret_cast<const float4*>(as + (arow + i * 32) * LDA_S + khalf * KH + 4 * h);
+            } else {
+                const float* q = as + (khalf * KH + 4 * h) * LDA_S + arow + i * 32;
+                fa[h][i] = make_float4(q[0], q[LDA_S], q[2 * LDA_S], q[3 * LDA_S]);
             }
+        }
 #pragma unroll
-            for (int j = 0; j < WN; ++j) {
-                if (B_MK) {
-                    b[j] = *reinterpret_cast<const float4*>(bs + (bcol + j * 32) * LDB_S + khalf * KH + 4 * h);
-                } else {
-                    const float* q = bs + (khalf * KH + 4 * h) * LDB_S + bcol + j * 32;
-                    b[j] = make_float4(q[0], q[LDB_S], q[2 * LDB_S], q[3 * LDB_S]);
-                }
+        for (int j = 0; j < WN; ++j) {
+            if (B_MK) {
+                fb[h][j] = *reinterpret_cast<const float4*>(bs + (bcol + j * 32) * LDB_S + khalf * KH + 4 * h);
+            } else {
+                const float* q = bs + (khalf * KH + 4 * h) * LDB_S + bcol + j * 32;
+                fb[h][j] = make_float4(q[0], q[LDB_S], q[2 * LDB_S], q[3 * LDB_S]);
             }
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-                }
         }
     };
+    auto mfma_group = [&](int h) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h][i].x, fb[h][j].x, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h][i].y, fb[h][j].y, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h][i].z, fb[h][j].z, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h][i].w, fb[h][j].w, acc[i][j], 0, 0, 0);
+            }
+    };
 
-    // Software pipeline over the workgroup's k-tiles.  Tile i is multiplied out of LDS[buf] while
-    // tile i+1 moves from its register stage to LDS[buf^1] and tile i+2 is requested from memory,
-    // so a global load has two MFMA phases (~1000 cycles) to arrive.  The loop is branch-free and
-    // runs over PAIRS of tiles (the two stages swap roles, so the register roles are identical at
-    // every back-edge); an odd tile count is rounded up with an all-zero tile, and requests past the
-    // last tile re-read the last tile (legal addresses, data never used).  The prefetch is pinned
-    // ABOVE the MFMAs: left alone, the scheduler sinks the global loads below them to reuse the
-    // fragment registers and then waits for the loads right away.
+    // Software pipeline over the workgroup's k-tiles, three stages deep:
+    //   tile t   : its fragments are in registers and feed the MFMAs
+    //   tile t+1 : moves from its register stage to LDS[buf^1]; after the barrier its first fragment
+    //              group is fetched while the LAST MFMA group of tile t still runs, the other groups
+    //              right after, so no MFMA waits on an LDS read issued just before it
+    //   tile t+2 : requested from memory (two MFMA phases, ~1000 cycles, to arrive)
+    // The loop is branch-free and runs over PAIRS of tiles (the two register stages swap roles, so
+    // the register roles are identical at every back-edge); an odd tile count is rounded up with an
+    // all-zero tile, and requests past the last tile re-read the last tile (legal addresses, data
+    // never used).  sched_barriers pin the order: left alone, the scheduler sinks the global loads
+    // below the MFMAs to reuse registers and then waits for them right away.
     {
         const int last = kt_end - 1;
         load_tiles(T4R_S0, kt_begin);
         store_tiles(T4R_S0, 0, kt_begin, true);
         __syncthreads();
+#pragma unroll
+        for (int h = 0; h < NH; ++h) read_frag(0, h);
         load_tiles(T4R_S0, min(kt_begin + 1, last));
-        int buf = 0;
+#define T4R_STEP(SLOAD, SSTORE, BUFN, TNEXT)                          \
+        load_tiles(SLOAD, min((TNEXT) + 1, last));                      \
+        __builtin_amdgcn_sched_barrier(0);                              \
+        _Pragma("unroll") for (int h = 0; h < NH - 1; ++h) mfma_group(h); \
+        __builtin_amdgcn_sched_barrier(0);                              \
+        store_tiles(SSTORE, BUFN, TNEXT, (TNEXT) < kt_end);             \
+        __syncthreads();                                                \
+        read_frag(BUFN, 0);                                             \
+        __builtin_amdgcn_sched_barrier(0);                              \
+        mfma_group(NH - 1);                                             \
+        __builtin_amdgcn_sched_barrier(0);                              \
+        _Pragma("unroll") for (int h = 1; h < NH; ++h) read_frag(BUFN, h);
         for (int kt = kt_begin; kt < kt_end; kt += 2) {
-            load_tiles(T4R_S1, min(kt + 2, last));
-            __builtin_amdgcn_sched_barrier(0);
-            compute(buf);
-            __builtin_amdgcn_sched_barrier(0);
-            store_tiles(T4R_S0, buf ^ 1, kt + 1, kt + 1 < kt_end);
-            __syncthreads();
-            load_tiles(T4R_S0, min(kt + 3, last));
-            __builtin_amdgcn_sched_barrier(0);
-            compute(buf ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
-            store_tiles(T4R_S1, buf, kt + 2, kt + 2 < kt_end);
-            __syncthreads();
+            T4R_STEP(T4R_S1, T4R_S0, 1, kt + 1)
+            T4R_STEP(T4R_S0, T4R_S1, 0, kt + 2)
         }
+#undef T4R_STEP
     }
 
     // epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)

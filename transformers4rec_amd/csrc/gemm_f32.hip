@@ -60,22 +60,18 @@ struct GemmParams {
     float sg_smooth;
 };
 
-// applies the softmax-gradient transform to the `valid` leading elements of v (row fixed,
-// columns col0..col0+3)
-__device__ __forceinline__ float4 softmax_grad4(float4 v, int valid, float l, int y, int col0, float g,
+// softmax-gradient transform of four consecutive columns col0..col0+3 of one logits row.
+// Branch-free on purpose (the k-loop schedules it under MFMAs inside ONE basic block); elements
+// outside the operand are transformed too and zeroed afterwards by mask4.
+__device__ __forceinline__ float4 softmax_grad4(float4 v, float l, int y, int col0, float g,
                                                  const GemmParams& p) {
-    if (valid <= 0) return v;
     const float sub = p.sg_smooth / p.sg_V;
     const float hit = g * (1.f - p.sg_smooth);
-    float* e = &v.x;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (i < valid) {
-            float t = g * (__expf(e[i] - l) - sub);
-            if (col0 + i == y) t -= hit;
-            e[i] = t;
-        }
-    }
+    const int d = y - col0;     // 0..3 when the label column is one of the four
+    v.x = g * (__expf(v.x - l) - sub) - (d == 0 ? hit : 0.f);
+    v.y = g * (__expf(v.y - l) - sub) - (d == 1 ? hit : 0.f);
+    v.z = g * (__expf(v.z - l) - sub) - (d == 2 ? hit : 0.f);
+    v.w = g * (__expf(v.w - l) - sub) - (d == 3 ? hit : 0.f);
     return v;
 }
 
@@ -172,8 +168,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     // itself runs in store_tiles (after the MFMAs), so the global loads still overlap compute.
     float4 ra0[NA4], rb0[NB4], ra1[NA4], rb1[NB4];
     float sgl0[NA4], sgl1[NA4];
-    int sgy0[NA4], sgy1[NA4];
-#define T4R_STAGE_PARAMS float4(&ra)[NA4], float4(&rb)[NB4], float(&sgl)[NA4], int(&sgy)[NA4]
+    long sgy0[NA4], sgy1[NA4];   // labels stay 64-bit here: narrowing at load time would wait for the load
+#define T4R_STAGE_PARAMS float4(&ra)[NA4], float4(&rb)[NB4], float(&sgl)[NA4], long(&sgy)[NA4]
 #define T4R_S0 ra0, rb0, sgl0, sgy0
 #define T4R_S1 ra1, rb1, sgl1, sgy1
     const float sg_g = SG ? (p.sg_gout ? *p.sg_gout : 1.f) / p.sg_rows : 0.f;
@@ -188,12 +184,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 const int k = idx / (BM / 4), m4 = (idx % (BM / 4)) * 4;
                 const int gk = min(k0 + k, p.K - 1);
                 ra[r] = ld4_clamped<VEC>(A + (long)gk * p.lda, m0 + m4, p.M);
-                if (SG) { sgl[r] = p.sg_lse[gk]; sgy[r] = (int)p.sg_labels[gk]; }      // rows = k
+                if (SG) { sgl[r] = p.sg_lse[gk]; sgy[r] = p.sg_labels[gk]; }           // rows = k
             } else {   // A[M][lda], k contiguous: tile row = m, 4 consecutive k
                 const int m = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
                 const int gm = min(m0 + m, p.M - 1);
                 ra[r] = ld4_clamped<VEC>(A + (long)gm * p.lda, k0 + k4, p.K);
-                if (SG) { sgl[r] = p.sg_lse[gm]; sgy[r] = (int)p.sg_labels[gm]; }      // rows = m
+                if (SG) { sgl[r] = p.sg_lse[gm]; sgy[r] = p.sg_labels[gm]; }           // rows = m (L1-resident re-read)
             }
         }
 #pragma unroll
@@ -205,6 +201,31 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             } else {    // B[N][ldb], k contiguous
                 const int n = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
                 rb[r] = ld4_clamped<VEC>(B + (long)min(n0 + n, p.N - 1) * p.ldb, k0 + k4, p.K);
+            }
+        }
+    };
+
+    // softmax-gradient transform of a staged A tile, in registers (SG variants).  In the k-loop it
+    // is scheduled UNDER the MFMAs of the resident tile (sched_group_barrier pattern below): the
+    // ~50 VALU ops + 4 exp per thread otherwise sit between the MFMA phase and the barrier.
+    auto transform_stage = [&](T4R_STAGE_PARAMS, int kt, bool live) __attribute__((always_inline)) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int r = 0; r < NA4; ++r) {
+            pin4(ra[r]);
+            asm volatile("" : "+v"(sgl[r]), "+v"(sgy[r]));
+        }
+#pragma unroll
+        for (int r = 0; r < NA4; ++r) {
+            const int idx = tid + r * 256;
+            if (TA) {
+                const int k = idx / (BM / 4), m4 = (idx % (BM / 4)) * 4;
+                const int gk = k0 + k, gm = m0 + m4;
+                ra[r] = softmax_grad4(ra[r], sgl[r], (int)sgy[r], gm, sg_g, p);
+            } else {
+                const int m = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
+                const int gm = m0 + m, gk = k0 + k4;
+                ra[r] = softmax_grad4(ra[r], sgl[r], (int)sgy[r], gk, sg_g, p);
             }
         }
     };
@@ -225,13 +246,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 const int k = idx / (BM / 4), m4 = (idx % (BM / 4)) * 4;
                 const int gk = k0 + k, gm = m0 + m4;
                 const int valid = (live && gk < p.K) ? p.M - gm : 0;
-                if (SG) ra[r] = softmax_grad4(ra[r], valid, sgl[r], sgy[r], gm, sg_g, p);
                 *reinterpret_cast<float4*>(as + k * LDA_S + m4) = mask4(ra[r], valid);
             } else {
                 const int m = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
                 const int gm = m0 + m, gk = k0 + k4;
                 const int valid = (live && gm < p.M) ? p.K - gk : 0;
-                if (SG) ra[r] = softmax_grad4(ra[r], valid, sgl[r], sgy[r], gk, sg_g, p);
                 *reinterpret_cast<float4*>(as + m * LDA_S + k4) = mask4(ra[r], valid);
             }
         }
@@ -316,6 +335,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     {
         const int last = kt_end - 1;
         load_tiles(T4R_S0, kt_begin);
+        if (SG) transform_stage(T4R_S0, kt_begin, true);
         store_tiles(T4R_S0, 0, kt_begin, true);
         __syncthreads();
 #pragma unroll
@@ -324,7 +344,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 #define T4R_STEP(SLOAD, SSTORE, BUFN, TNEXT)                          \
         load_tiles(SLOAD, min((TNEXT) + 1, last));                      \
         __builtin_amdgcn_sched_barrier(0);                              \
+        if (SG) transform_stage(SSTORE, TNEXT, (TNEXT) < kt_end);       \
         _Pragma("unroll") for (int h = 0; h < NH - 1; ++h) mfma_group(h); \
+        if (SG) {   /* one MFMA, then a slice of the transform's VALU work, ... */ \
+            _Pragma("unroll") for (int g = 0; g < 4 * (NH - 1) * WM * WN; ++g) { \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      \
+                __builtin_amdgcn_sched_group_barrier(0x402, 16, 0);     \
+            }                                                           \
+        }                                                               \
         __builtin_amdgcn_sched_barrier(0);                              \
         store_tiles(SSTORE, BUFN, TNEXT, (TNEXT) < kt_end);             \
         __syncthreads();                                                \

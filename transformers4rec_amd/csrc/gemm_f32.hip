@@ -230,7 +230,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         }
     };
 
-    // stage -> LDS image of buffer `buf`; zeroes what lies outside the operands (edge tiles / K tail)
+    // stage -> LDS image of buffer `buf`.  Only k needs zeroing: rows / columns beyond M / N hold a
+    // clamped duplicate of the last row / column and only feed outputs that are never stored, but
+    // k >= K (the K tail, the zero tile that pads an odd tile count) would reach valid outputs.
+    // The zeroing is a workgroup-uniform branch taken by those tiles only: on interior k-tiles it
+    // would cost 18 VALU ops + hazard nops per k-tile between the MFMAs and the barrier.
     auto store_tiles = [&](T4R_STAGE_PARAMS, int buf, int kt, bool live) __attribute__((always_inline)) {
         float* as = As + buf * A_SZ;
         float* bs = Bs + buf * B_SZ;
@@ -239,19 +243,29 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         for (int r = 0; r < NA4; ++r) pin4(ra[r]);
 #pragma unroll
         for (int r = 0; r < NB4; ++r) pin4(rb[r]);
+        if (!live || k0 + BK > p.K) {
+#pragma unroll
+            for (int r = 0; r < NA4; ++r) {
+                const int idx = tid + r * 256;
+                if (TA) ra[r] = mask4(ra[r], (live && k0 + idx / (BM / 4) < p.K) ? 4 : 0);
+                else ra[r] = mask4(ra[r], live ? p.K - (k0 + (idx % (BK / 4)) * 4) : 0);
+            }
+#pragma unroll
+            for (int r = 0; r < NB4; ++r) {
+                const int idx = tid + r * 256;
+                if (!TB) rb[r] = mask4(rb[r], (live && k0 + idx / (BN / 4) < p.K) ? 4 : 0);
+                else rb[r] = mask4(rb[r], live ? p.K - (k0 + (idx % (BK / 4)) * 4) : 0);
+            }
+        }
 #pragma unroll
         for (int r = 0; r < NA4; ++r) {
             const int idx = tid + r * 256;
             if (TA) {
                 const int k = idx / (BM / 4), m4 = (idx % (BM / 4)) * 4;
-                const int gk = k0 + k, gm = m0 + m4;
-                const int valid = (live && gk < p.K) ? p.M - gm : 0;
-                *reinterpret_cast<float4*>(as + k * LDA_S + m4) = mask4(ra[r], valid);
+                *reinterpret_cast<float4*>(as + k * LDA_S + m4) = ra[r];
             } else {
                 const int m = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
-                const int gm = m0 + m, gk = k0 + k4;
-                const int valid = (live && gm < p.M) ? p.K - gk : 0;
-                *reinterpret_cast<float4*>(as + m * LDA_S + k4) = mask4(ra[r], valid);
+                *reinterpret_cast<float4*>(as + m * LDA_S + k4) = ra[r];
             }
         }
 #pragma unroll
@@ -259,12 +273,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             const int idx = tid + r * 256;
             if (!TB) {
                 const int k = idx / (BN / 4), n4 = (idx % (BN / 4)) * 4;
-                const int valid = (live && k0 + k < p.K) ? p.N - (n0 + n4) : 0;
-                *reinterpret_cast<float4*>(bs + k * LDB_S + n4) = mask4(rb[r], valid);
+                *reinterpret_cast<float4*>(bs + k * LDB_S + n4) = rb[r];
             } else {
                 const int n = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
-                const int valid = (live && n0 + n < p.N) ? p.K - (k0 + k4) : 0;
-                *reinterpret_cast<float4*>(bs + n * LDB_S + k4) = mask4(rb[r], valid);
+                *reinterpret_cast<float4*>(bs + n * LDB_S + k4) = rb[r];
             }
         }
     };

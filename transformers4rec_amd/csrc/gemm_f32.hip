@@ -379,45 +379,58 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 #undef T4R_STEP
     }
 
-    // epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // The mode is workgroup-uniform: it is decided ONCE and each mode has its own straight-line
+    // store loop (the per-element switch cost ~30 scalar/vector instructions per output element,
+    // a quarter of the MFMA time of a K = 128 tile).
     const float alpha = p.alpha;
+    const bool rows_full = m0 + BM <= p.M;
+    auto for_each_out = [&](auto fn) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < WM; ++i) {
+        for (int i = 0; i < WM; ++i) {
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
-            if (col >= p.N) continue;
-            float bv = 0.f;
-            if (p.epilogue != EPI_NONE && p.bias) bv = p.bias[col];
+            for (int j = 0; j < WN; ++j) {
+                const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+                if (col >= p.N) continue;
+                const int row0 = m0 + wm * (BM / 2) + i * 32 + 4 * khalf;
+                float* c0 = C + (long)row0 * p.ldc + col;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                if (row >= p.M) continue;
-                float v = alpha * acc[i][j][r];
-                float* cp = C + (long)row * p.ldc + col;
-                if (p.splitk > 1) {
-                    atomicAdd(cp, v);
-                } else {
-                    if (p.epilogue == EPI_BIAS) {
-                        v += bv;
-                    } else if (p.epilogue == EPI_BIAS_GELU) {
-                        v += bv;
-                        if (p.aux) p.aux[(long)row * p.ldaux + col] = v;
-                        v = gelu_erf(v);
-                        if (EDROP) v *= drop_scale(p.drop, (unsigned long long)row * p.N + col);
-                    } else if (p.epilogue == EPI_BIAS_RELU) {
-                        v = fmaxf(v + bv, 0.f);
-                    } else if (p.epilogue == EPI_BIAS_RESID) {
-                        // C = dropout(x + bias) + residual   (GPT-2: hidden + resid_dropout(c_proj(...)))
-                        v += bv;
-                        if (EDROP) v *= drop_scale(p.drop, (unsigned long long)row * p.N + col);
-                        v += p.aux[(long)row * p.ldaux + col];
-                    }
-                    if (p.accumulate) v += *cp;
-                    *cp = v;
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    if (!rows_full && row0 + dr >= p.M) continue;
+                    fn(c0 + (long)dr * p.ldc, row0 + dr, col, alpha * acc[i][j][r]);
                 }
             }
         }
+    };
+    if (p.splitk > 1) {
+        for_each_out([&](float* cp, int, int, float v) __attribute__((always_inline)) { atomicAdd(cp, v); });
+    } else if (p.epilogue == EPI_NONE) {
+        if (p.accumulate) for_each_out([&](float* cp, int, int, float v) __attribute__((always_inline)) { *cp += v; });
+        else for_each_out([&](float* cp, int, int, float v) __attribute__((always_inline)) { *cp = v; });
+    } else {
+        const int mode = p.epilogue;
+        const bool acc_c = p.accumulate;
+        for_each_out([&](float* cp, int row, int col, float v) __attribute__((always_inline)) {
+            const float bv = p.bias ? p.bias[col] : 0.f;
+            if (mode == EPI_BIAS) {
+                v += bv;
+            } else if (mode == EPI_BIAS_GELU) {
+                v += bv;
+                if (p.aux) p.aux[(long)row * p.ldaux + col] = v;
+                v = gelu_erf(v);
+                if (EDROP) v *= drop_scale(p.drop, (unsigned long long)row * p.N + col);
+            } else if (mode == EPI_BIAS_RELU) {
+                v = fmaxf(v + bv, 0.f);
+            } else if (mode == EPI_BIAS_RESID) {
+                // C = dropout(x + bias) + residual   (GPT-2: hidden + resid_dropout(c_proj(...)))
+                v += bv;
+                if (EDROP) v *= drop_scale(p.drop, (unsigned long long)row * p.N + col);
+                v += p.aux[(long)row * p.ldaux + col];
+            }
+            if (acc_c) v += *cp;
+            *cp = v;
+        });
     }
 }
 

@@ -40,6 +40,12 @@ const char* t4r_last_error(void);
 int t4r_ragged_max_len(void* stream, const long* offsets, int rows, int* out_max);
 int t4r_ragged_to_padded(void* stream, const void* values, const long* offsets, void* out, int rows,
                          int L, int elem_size);
+/* Batch assembly of the device-resident feed (replaces the Merlin loader + pad_batch map,
+ * utils/data_utils.py:216-494, utils/padding.py:72-122): the whole ragged column lives in HBM;
+ * a batch is `rows` row ids (any order: shuffling), out[i, c] = values[offsets[row_ids[i]] + c],
+ * right-zero-padded / truncated to L.  offsets == NULL with L = 1 gathers a scalar column. */
+int t4r_ragged_gather_to_padded(void* stream, const void* values, const long* offsets,
+                                const long* row_ids, void* out, int rows, int L, int elem_size);
 
 /* ----------------------------------------------------------------------------------------
  * a2,a3,a5,a7,a8,a13  multi-feature embedding gather + aggregation (+ fused masking epilogue)

@@ -1,0 +1,141 @@
+"""Device-resident session feed: parquet list columns -> ragged -> padded batches.
+Host parsing is checked on CPU; batch assembly (t4r_ragged_gather_to_padded) on the GPU against
+the oracle's pad_ragged (utils/padding.py:48-68 restated)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import t4r_oracle as O
+
+
+def _write_dataset(tmp_path, n=57, seed=0, files=1, max_len=30, unique=False):
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(0, max_len + 1, n)
+    lens[0], lens[1] = max_len, 0                       # a maximal and an empty session
+    items = [rng.integers(1, 1000, l).tolist() for l in lens]
+    price = [rng.random(l).astype(np.float32).tolist() for l in lens]
+    country = rng.integers(1, 18, n)
+    if unique:                                          # every session identifiable by its first item
+        items = [[10_000 + r] + row[1:] for r, row in enumerate(items)]
+        price = [(p + [0.5])[: len(items[r])] for r, p in enumerate(price)]
+    else:
+        items[5] = None                                 # null list == empty session
+    tab = pa.table({"item_id": pa.array(items, pa.list_(pa.int64())),
+                    "price": pa.array(price, pa.list_(pa.float32())),
+                    "country": pa.array(country, pa.int32())})
+    paths = []
+    per = (n + files - 1) // files
+    for f in range(files):
+        p = os.path.join(tmp_path, f"part{f}.parquet")
+        pq.write_table(tab.slice(f * per, per), p, row_group_size=13)
+        paths.append(p)
+    if not unique:
+        items[5] = []
+    return paths, items, price, country
+
+
+def test_read_ragged_columns_host(tmp_path):
+    from transformers4rec_amd.data import read_ragged_columns
+
+    paths, items, price, country = _write_dataset(str(tmp_path), files=3)
+    cols = read_ragged_columns(paths)
+    v, o = cols["item_id"]
+    assert v.dtype == np.int64 and o.dtype == np.int64 and o[0] == 0 and len(o) == len(items) + 1
+    for r, row in enumerate(items):
+        assert v[o[r]: o[r + 1]].tolist() == row
+    v, o = cols["price"]
+    assert v.dtype == np.float32
+    for r, row in enumerate(price):
+        assert np.array_equal(v[o[r]: o[r + 1]], np.asarray(row, np.float32))
+    v, o = cols["country"]
+    assert o is None and v.dtype == np.int64 and np.array_equal(v, country)
+    only = read_ragged_columns(paths[0], columns=["item_id"])
+    assert list(only) == ["item_id"]
+
+
+def _expected(cols, rows, L):
+    out = {}
+    for name, (v, o) in cols.items():
+        if o is None:
+            out[name] = torch.from_numpy(v[rows])
+        else:
+            sub_off = np.concatenate([[0], np.cumsum((o[1:] - o[:-1])[rows])])
+            sub_val = np.concatenate([v[o[r]: o[r + 1]] for r in rows] + [v[:0]])
+            out[name] = O.pad_ragged(torch.from_numpy(sub_val), torch.from_numpy(sub_off), L)
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L", [20, 7, 40])
+def test_loader_batches_match_oracle_padding(tmp_path, L):
+    from transformers4rec_amd.data import ParquetSessionLoader, read_ragged_columns
+
+    paths, *_ = _write_dataset(str(tmp_path), n=57, files=2)
+    cols = read_ragged_columns(paths)
+    dl = ParquetSessionLoader(paths, batch_size=16, max_sequence_length=L)
+    assert len(dl) == 4 and len(dl.dataset) == 57 and dl._batch_size == 16
+    seen = 0
+    for b, batch in enumerate(dl):
+        rows = np.arange(b * 16, min(57, (b + 1) * 16))
+        exp = _expected(cols, rows, L)
+        for name in exp:
+            assert batch[name].is_cuda and torch.equal(batch[name].cpu(), exp[name]), (b, name)
+        seen += len(rows)
+    assert seen == 57
+    assert len(ParquetSessionLoader(paths, batch_size=16, max_sequence_length=L, drop_last=True)) == 3
+
+
+@pytest.mark.gpu
+def test_loader_shuffle_and_sharding(tmp_path):
+    from transformers4rec_amd.data import ParquetSessionLoader, read_ragged_columns
+
+    paths, *_ = _write_dataset(str(tmp_path), n=64, files=1, unique=True)
+    cols = read_ragged_columns(paths)
+    full = _expected(cols, np.arange(64), 12)
+    key = {tuple(full["item_id"][r].tolist()) + (int(full["country"][r]),): r for r in range(64)}
+
+    def rows_of(dl):
+        out = []
+        for batch in dl:
+            for i in range(batch["item_id"].shape[0]):
+                r = key[tuple(batch["item_id"][i].tolist()) + (int(batch["country"][i]),)]
+                assert torch.equal(batch["price"][i].cpu(), full["price"][r])     # rows stay aligned across features
+                out.append(r)
+        return out
+
+    dl = ParquetSessionLoader(paths, batch_size=10, max_sequence_length=12, shuffle=True, seed=3)
+    e0, e1 = rows_of(dl), rows_of(dl)
+    assert sorted(e0) == list(range(64)) and sorted(e1) == list(range(64)) and e0 != e1 and e0 != list(range(64))
+    dl2 = ParquetSessionLoader(paths, batch_size=10, max_sequence_length=12, shuffle=True, seed=3)
+    assert rows_of(dl2) == e0                              # same (seed, epoch) -> same order
+    parts = [rows_of(ParquetSessionLoader(paths, batch_size=10, max_sequence_length=12, global_size=3, global_rank=r))
+             for r in range(3)]
+    assert sum(parts, []) == list(range(64)) and all(len(p) in (22, 20) for p in parts)
+
+
+@pytest.mark.gpu
+def test_loader_feeds_the_model(tmp_path):
+    import transformers4rec_amd as tr
+    from transformers4rec_amd.data import ParquetSessionLoader
+
+    paths, *_ = _write_dataset(str(tmp_path), n=40, files=1, max_len=12)
+    schema = tr.session_schema(999, 12, (), ("price",))
+    inputs = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=12, masking="mlm", d_output=32,
+                                                    continuous_soft_embeddings=True, embedding_dim_default=16)
+    cfg = tr.XLNetConfig.build(d_model=32, n_head=2, n_layer=1, total_seq_length=12, dropout=0.0)
+    model = cfg.to_torch_model(inputs, tr.NextItemPredictionTask(weight_tying=False)).to("cuda")
+    dl = ParquetSessionLoader(paths, batch_size=20, max_sequence_length=12, schema=schema, with_targets=True)
+    n = 0
+    for x, y in dl:
+        keep = x["item_id"][:, 0] != 0          # the reference's loaders never emit empty sessions; drop ours
+        x = {k: v[keep] for k, v in x.items()}
+        out = model(x, training=True)
+        assert torch.isfinite(out["loss"])
+        out["loss"].backward()
+        n += 1
+    assert n == 2

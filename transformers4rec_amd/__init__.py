@@ -17,3 +17,4 @@ from .prediction_task import LogUniformSampler, NextItemPredictionTask  # noqa: 
 from .model import Head, Model  # noqa: E402,F401
 from .optim import FlatParams, FusedAdam, flatten_model  # noqa: E402,F401
 from .distributed import GradReducer, shard_batch  # noqa: E402,F401
+from .data import ParquetSessionLoader, read_ragged_columns  # noqa: E402,F401

@@ -22,6 +22,7 @@ _SIGS = {
     "t4r_last_error": ("s", ""),
     "t4r_ragged_max_len": ("i", "ppip"),
     "t4r_ragged_to_padded": ("i", "ppppiii"),
+    "t4r_ragged_gather_to_padded": ("i", "pppp" + "p" + "iii"),
     "t4r_seq_features_fwd": ("i", "pippppppiiiiiiipppp"),
     "t4r_embedding_bwd": ("i", "pppp" + "liiilii"),
     "t4r_apply_mask_fwd": ("i", "ppppiiii"),

@@ -532,6 +532,40 @@ __global__ __launch_bounds__(256) void ragged_to_padded_kernel(const T* __restri
         out[(long)row * L + c] = c < len ? values[o0 + c] : (T)0;
 }
 
+// same, for a batch given by row ids into a device-resident ragged column (shuffled batches of the
+// device-resident feed): out[i, c] = values[offsets[row_ids[i]] + c].  Scalar (per-session) columns
+// are the L = 1 case with offsets == nullptr: out[i] = values[row_ids[i]].
+template <typename T>
+__global__ __launch_bounds__(256) void ragged_gather_to_padded_kernel(const T* __restrict__ values,
+                                                                       const long* __restrict__ offsets,
+                                                                       const long* __restrict__ row_ids,
+                                                                       T* __restrict__ out, int rows, int L) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= rows) return;
+    const long row = row_ids[i];
+    const long o0 = offsets ? offsets[row] : row;
+    const long len = offsets ? offsets[row + 1] - o0 : 1;
+    for (int c = threadIdx.x & 63; c < L; c += 64)
+        out[(long)i * L + c] = c < len ? values[o0 + c] : (T)0;
+}
+
+extern "C" int t4r_ragged_gather_to_padded(void* stream, const void* values, const long* offsets,
+                                           const long* row_ids, void* out, int rows, int L, int elem_size) {
+    if (rows == 0 || L == 0) return 0;
+    T4R_CHECK_ARG(elem_size == 4 || elem_size == 8, "ragged_gather_to_padded: elem_size 4 or 8");
+    T4R_CHECK_ARG(values && row_ids && out, "ragged_gather_to_padded: null pointer");
+    T4R_CHECK_ARG(offsets || L == 1, "ragged_gather_to_padded: a scalar column has L = 1");
+    dim3 grid((rows + 3) / 4), block(256);
+    if (elem_size == 8)
+        hipLaunchKernelGGL(ragged_gather_to_padded_kernel<long>, grid, block, 0, (hipStream_t)stream,
+                           (const long*)values, offsets, row_ids, (long*)out, rows, L);
+    else
+        hipLaunchKernelGGL(ragged_gather_to_padded_kernel<float>, grid, block, 0, (hipStream_t)stream,
+                           (const float*)values, offsets, row_ids, (float*)out, rows, L);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
 // row-length maximum (pad_inputs: min(max_sequence_length, batch max)); result in *out_max
 __global__ void max_row_len_kernel(const long* __restrict__ offsets, int rows, int* out_max) {
     int m = 0;

@@ -153,6 +153,19 @@ def ragged_to_padded(values, offsets, L):
     return out
 
 
+def ragged_gather_to_padded(values, offsets, row_ids, L):
+    """out[i, :] = the list of row row_ids[i] of the ragged column (values, offsets), zero-padded /
+    truncated to L; offsets=None gathers a scalar column (returns [rows])."""
+    rows = row_ids.numel()
+    if values.dtype not in (torch.int64, torch.float32):
+        raise TypeError("ragged_gather_to_padded: int64 or float32 values")
+    scalar = offsets is None
+    out = torch.empty((rows,) if scalar else (rows, L), device=values.device, dtype=values.dtype)
+    call("t4r_ragged_gather_to_padded", _stream(), _chk(values), _p(offsets, torch.int64),
+         _chk(row_ids, torch.int64), out.data_ptr(), rows, 1 if scalar else L, values.element_size())
+    return out
+
+
 def ragged_max_len(offsets):
     out = torch.empty(1, device=offsets.device, dtype=torch.int32)
     call("t4r_ragged_max_len", _stream(), _chk(offsets, torch.int64), offsets.numel() - 1, out.data_ptr())

@@ -373,7 +373,8 @@ ORDER = ("q", "k", "v", "o", "r", "r_w_bias", "r_r_bias", "ln_w", "ln_b", "w1", 
          "ff_ln_w", "ff_ln_b")
 
 
-@pytest.mark.parametrize("B,L,D,n", [(5, 20, 64, 4), (3, 21, 32, 2), (2, 7, 128, 4), (4, 33, 64, 8), (2, 64, 32, 2)])
+@pytest.mark.parametrize("B,L,D,n", [(5, 20, 64, 4), (3, 21, 32, 2), (2, 7, 128, 4), (4, 33, 64, 8), (2, 64, 32, 2),
+                                     (3, 32, 128, 4), (2, 1, 64, 2), (1100, 5, 32, 1), (4, 17, 16, 1), (2, 32, 32, 2)])
 def test_xlnet_attention_core(ops, B, L, D, n):
     g = torch.Generator().manual_seed(B * L + D)
     dh = D // n
@@ -552,7 +553,7 @@ def test_act_bwd_dropout(ops):
     close(db, pre.grad.sum(0), atol=1e-4)
 
 
-@pytest.mark.parametrize("B,L,D,n", [(5, 20, 64, 4), (3, 21, 128, 4), (4, 9, 32, 2)])
+@pytest.mark.parametrize("B,L,D,n", [(5, 20, 64, 4), (3, 21, 128, 4), (4, 9, 32, 2), (2, 32, 64, 2), (1030, 3, 32, 1)])
 def test_xlnet_attention_dropout_per_session_kr(ops, B, L, D, n):
     g = torch.Generator().manual_seed(B + L + D)
     dh = D // n

@@ -17,6 +17,7 @@
 // Forward is a single online-softmax pass and saves only the row log-sum-exp; backward
 // recomputes the probabilities (no [B,n,L,L] tensor ever goes to HBM).
 #include "t4r_common.h"
+#include <stdlib.h>
 
 #define ATT_PAD 4
 // heads (= waves) per workgroup: 4 for d_head >= 32 so the compiler may use up to 512 VGPRs
@@ -505,6 +506,21 @@ extern "C" long t4r_xlnet_attn_bwd_ws_floats(int B, int L, int D, int n_head) {
     return (long)t4r_xlnet_attn_bwd_blocks(B) * ((n_head + hpb - 1) / hpb) * (2L * L * D + 2L * D);
 }
 
+// MFMA kernels for L <= 32, d_head 16 / 32 (xlnet_attn_mfma.hip); T4R_ATTN_MFMA=0 keeps the VALU kernels
+int t4r_xlnet_attn_mfma_ok(int L, int d_head);
+int t4r_xlnet_attn_mfma_fwd(hipStream_t st, const float* q, const float* k, const float* v, const float* kr,
+                            const float* rw, const float* rr, float* out, float* lse, int B, int L, int n_head,
+                            int d_head, float scale, long kr_bstride, DropCfg drop);
+int t4r_xlnet_attn_mfma_bwd(hipStream_t st, const float* q, const float* k, const float* v, const float* kr,
+                            const float* rw, const float* rr, const float* lse, const float* dout, float* dq,
+                            float* dk, float* dv, float* part, float* dkr, float* d_rw, float* d_rr, int B, int L,
+                            int n_head, int d_head, float scale, long kr_bstride, DropCfg drop);
+static bool use_mfma(int L, int d_head) {
+    static int en = -1;
+    if (en < 0) { const char* e = getenv("T4R_ATTN_MFMA"); en = e ? atoi(e) : 1; }
+    return en && t4r_xlnet_attn_mfma_ok(L, d_head);
+}
+
 template <int DH>
 static int attn_fwd_launch(hipStream_t st, const float* q, const float* k, const float* v,
                            const float* kr, const float* rw, const float* rr, float* out, float* lse,
@@ -535,11 +551,14 @@ extern "C" int t4r_xlnet_attn_fwd(void* stream, const float* q, const float* k, 
     if (B == 0) return 0;
     T4R_CHECK_ARG(L >= 1 && L <= 64, "xlnet_attn: L must be in [1, 64]");
     const int D = n_head * d_head;
-    T4R_CHECK_ARG(attn_fwd_smem(L, D) <= 160 * 1024, "xlnet_attn: L*d_model too large for LDS");
     const float scale = 1.0f / sqrtf((float)d_head);
     hipStream_t st = (hipStream_t)stream;
     const long bs = kr_per_batch ? 2L * L * D : 0;
     const DropCfg dc = make_drop(drop_p, seed, ctr_hi);
+    if (use_mfma(L, d_head))
+        return t4r_xlnet_attn_mfma_fwd(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, B, L, n_head, d_head, scale,
+                                       bs, dc);
+    T4R_CHECK_ARG(attn_fwd_smem(L, D) <= 160 * 1024, "xlnet_attn: L*d_model too large for LDS");
     switch (d_head) {
         case 8: return attn_fwd_launch<8>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, B, L, n_head, scale, bs, dc);
         case 16: return attn_fwd_launch<16>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, B, L, n_head, scale, bs, dc);
@@ -598,11 +617,14 @@ extern "C" int t4r_xlnet_attn_bwd(void* stream, const float* q, const float* k, 
     if (B == 0) return 0;
     T4R_CHECK_ARG(L >= 1 && L <= 64, "xlnet_attn: L must be in [1, 64]");
     const int D = n_head * d_head;
-    T4R_CHECK_ARG(attn_bwd_smem(L, D, n_head) <= 160 * 1024, "xlnet_attn_bwd: L*d_model too large for LDS");
     const float scale = 1.0f / sqrtf((float)d_head);
     hipStream_t st = (hipStream_t)stream;
     const long bs = kr_per_batch ? 2L * L * D : 0;
     const DropCfg dc = make_drop(drop_p, seed, ctr_hi);
+    if (use_mfma(L, d_head))
+        return t4r_xlnet_attn_mfma_bwd(st, q, k, v, k_r, r_w_bias, r_r_bias, lse, dout, dq, dk, dv, workspace, dk_r,
+                                       d_r_w_bias, d_r_r_bias, B, L, n_head, d_head, scale, bs, dc);
+    T4R_CHECK_ARG(attn_bwd_smem(L, D, n_head) <= 160 * 1024, "xlnet_attn_bwd: L*d_model too large for LDS");
     switch (d_head) {
         case 8: return attn_bwd_launch<8>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, dout, dq, dk, dv, workspace, dk_r, d_r_w_bias, d_r_r_bias, B, L, n_head, scale, bs, dc);
         case 16: return attn_bwd_launch<16>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, dout, dq, dk, dv, workspace, dk_r, d_r_w_bias, d_r_r_bias, B, L, n_head, scale, bs, dc);

@@ -31,7 +31,18 @@ __global__ __launch_bounds__(256) void softmax_ce_fwd_kernel(const float* __rest
     const bool vec = (ld % 4 == 0) && ((uintptr_t)logits % 16 == 0);
     if (vec) {
         const int v4 = V / 4;
-        for (int i = threadIdx.x; i < v4; i += 256) {
+        int i = threadIdx.x;
+        for (; i + 256 < v4; i += 512) {      // two 16-byte loads in flight per thread
+            const float4 t = *reinterpret_cast<const float4*>(x + 4 * i);
+            const float4 u = *reinterpret_cast<const float4*>(x + 4 * (i + 256));
+            const float mx = fmaxf(fmaxf(fmaxf(t.x, t.y), fmaxf(t.z, t.w)), fmaxf(fmaxf(u.x, u.y), fmaxf(u.z, u.w)));
+            const float mn = fmaxf(m, mx);
+            s = s * __expf(m - mn) + (__expf(t.x - mn) + __expf(t.y - mn) + __expf(t.z - mn) + __expf(t.w - mn)) +
+                (__expf(u.x - mn) + __expf(u.y - mn) + __expf(u.z - mn) + __expf(u.w - mn));
+            m = mn;
+            tot += (t.x + t.y + t.z + t.w) + (u.x + u.y + u.z + u.w);
+        }
+        for (; i < v4; i += 256) {
             const float4 t = *reinterpret_cast<const float4*>(x + 4 * i);
             const float mx = fmaxf(fmaxf(t.x, t.y), fmaxf(t.z, t.w));
             const float mn = fmaxf(m, mx);

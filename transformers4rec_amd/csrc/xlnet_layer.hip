@@ -60,7 +60,7 @@ enum { P_Q = 0, P_K, P_V, P_O, P_R, P_RWB, P_RRB, P_LN1W, P_LN1B, P_W1, P_B1, P_
        P_LN2B, P_COUNT };
 
 struct LayerWs {
-    float *qkv, *kr, *av, *lse, *ao, *mean1, *rstd1, *h1, *ffpre, *ffact, *ffout, *mean2, *rstd2;
+    float *qkv, *kr, *av, *lse, *ao, *mean1, *rstd1, *h1, *ffpre, *ffact, *ffout, *mean2, *rstd2, *pe_b;
     long total;
 };
 
@@ -84,6 +84,9 @@ static LayerWs carve(float* base, int B, int L, int D, int n, int per_batch_kr) 
     w.ffout = take(T * D);
     w.mean2 = take(T);
     w.rstd2 = take(T);
+    // dropout(pos_emb) per session, kept for the backward's d r contraction (21 MB per layer at C2:
+    // with 288 GB of HBM saving beats regenerating it -- one launch less per layer)
+    w.pe_b = per_batch_kr ? take((long)B * 2L * L * D) : nullptr;
     w.total = o;
     return w;
 }
@@ -98,7 +101,7 @@ extern "C" long t4r_xlnet_layer_bwd_ws_floats(int B, int L, int D, int n_head, i
     const long nkr = (dropout ? (long)B : 1L) * 2L * L * D;
     return align4(3 * T * D) + align4(T * D) + align4(T * D) + align4(T * 4 * D) + align4(nkr) +
            align4(t4r_xlnet_attn_bwd_ws_floats(B, L, D, n_head)) + align4(t4r_colreduce_ws_floats(T, 4 * D)) +
-           (dropout ? align4(T * D) + align4(nkr) : 0);
+           (dropout ? align4(T * D) : 0);
 }
 
 #define RUN(call)                \
@@ -134,9 +137,8 @@ extern "C" int t4r_xlnet_layer_fwd(void* stream, const float* h, const float* po
     }
     if (drop) {
         // dropout(pos_emb expanded over the batch) @ r : per-session positional keys (HF :1142-1143
-        // drops the batch-expanded pos_emb, so every session gets its own mask).  The dropped copy
-        // [B*2L, D] is staged in the ffpre region (T*4D floats), which FF1 only overwrites later.
-        float* pe_b = w.ffpre;
+        // drops the batch-expanded pos_emb, so every session gets its own mask).
+        float* pe_b = w.pe_b;
         RUN(t4r_dropout(stream, pos_emb, pe_b, nullptr, (long)B * 2 * L * D, 2L * L * D, drop_p, seed,
                         C(SITE_POS)));
         RUN(t4r_gemm_launch(st, 0, 0, B * 2 * L, D, D, 1.f, pe_b, D, params[P_R], D, w.kr, D, nullptr,
@@ -187,7 +189,6 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
     float* attn_ws = take(t4r_xlnet_attn_bwd_ws_floats(B, L, D, n_head));
     float* red_ws = take(t4r_colreduce_ws_floats(T, 4 * D));
     float* dxa = drop ? take(TD) : nullptr;     // gradient of a dropped LayerNorm operand
-    float* pe_b = drop ? take(nkr) : nullptr;   // regenerated dropout(pos_emb) per session
 
     // LN2: y = LN(drop(ffout) + h1): dx = d h1 (residual part), d ffout = dxa (or dx when p = 0)
     RUN(t4r_add_layernorm_bwd(stream, w.ffout, w.h1, params[P_LN2W], w.mean2, w.rstd2, dh_out, dx, dxa,
@@ -223,8 +224,7 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
                            C(SITE_PROB)));
     // k_r = pos_emb(_b) @ r  ->  d r += pos_emb(_b)^T @ d k_r
     if (drop) {
-        RUN(t4r_dropout(stream, pos_emb, pe_b, nullptr, nkr, 2L * L * D, drop_p, seed, C(SITE_POS)));
-        RUN(t4r_gemm_launch(st, 1, 0, D, D, B * 2 * L, 1.f, pe_b, D, dkr, D, grads[P_R], D, nullptr,
+        RUN(t4r_gemm_launch(st, 1, 0, D, D, B * 2 * L, 1.f, w.pe_b, D, dkr, D, grads[P_R], D, nullptr,
                             EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
     } else {
         RUN(t4r_gemm_launch(st, 1, 0, D, D, 2 * L, 1.f, pos_emb, D, dkr, D, grads[P_R], D, nullptr,

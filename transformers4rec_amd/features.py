@@ -14,6 +14,7 @@ import torch
 from torch import nn
 
 from . import ops
+from .prediction_task_sync import wait_pending_grad as _wait_pending_grad
 from .transformations import TabularDropout, TabularLayerNorm, parse_post, parse_pre
 from .masking import MaskSequence, _grad_buf, parse_masking
 from .schema import Tags, categorical_cardinalities
@@ -298,6 +299,7 @@ class _SeqFeaturesFn(torch.autograd.Function):
                 tab = cat.embedding_tables[name].weight
                 if not tab.requires_grad:
                     continue
+                _wait_pending_grad(tab)     # the tied head's d W may still be running on its side stream
                 src = d
                 if agg == "element-wise-sum-item-multi":
                     src = d_item if name == cat.item_id else d_other

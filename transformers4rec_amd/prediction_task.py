@@ -9,6 +9,8 @@ state_dict names.  Arithmetic: csrc/masking.hip (row compaction), 
 import math
 from typing import Optional
 
+import os
+
 import torch
 from torch import nn
 
@@ -82,6 +84,22 @@ class _Pre(nn.Module):
         self.module = module
 
 
+# opt-in (T4R_HEAD_SIDE_STREAM=1): measured 5.64 -> 5.61 ms/step at C2 -- every kernel of the step already
+# fills the GPU, so there is little to overlap; off by default
+_SIDE_STREAM_ON = os.environ.get("T4R_HEAD_SIDE_STREAM", "0") == "1"
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
+from .prediction_task_sync import wait_pending_grad  # noqa: E402,F401
+
+
 class _NextItemHeadFn(torch.autograd.Function):
     """rows at label positions -> [task Linear] -> logits (full or sampled) -> mean CE."""
 
@@ -130,8 +148,29 @@ class _NextItemHeadFn(torch.autograd.Function):
             dxp = ops.gemm_softmax_grad(logits, lse, tgt, g, V, W.detach(), False, alpha=1.0 / T,
                                         label_smoothing=smooth, splitk=-1)
             if W.requires_grad:
-                ops.gemm_softmax_grad(logits, lse, tgt, g, V, xp, True, alpha=1.0 / T, label_smoothing=smooth,
-                                      out=_grad_buf(W), accumulate=True)
+                # d W only feeds the optimizer (and, when tied, the embedding scatter at the very end of
+                # the backward): it runs on a side stream, under the latency-bound kernels of the body's
+                # backward.  Ordering: the side stream waits for this point; the table's next writer
+                # (features.embedding_bwd) and everything enqueued after backward() wait for `done`.
+                gw = _grad_buf(W)
+                if _SIDE_STREAM_ON:
+                    side = _side_stream(logits.device)
+                    ready = torch.cuda.Event()
+                    ready.record()
+                    with torch.cuda.stream(side):
+                        side.wait_event(ready)
+                        ops.gemm_softmax_grad(logits, lse, tgt, g, V, xp, True, alpha=1.0 / T,
+                                              label_smoothing=smooth, out=gw, accumulate=True)
+                        done = torch.cuda.Event()
+                        done.record(side)
+                    for t in (logits, lse, tgt, g, xp, gw):
+                        t.record_stream(side)      # the caching allocator must not recycle them under the side kernel
+                    W._t4r_pending = done
+                    torch.autograd.Variable._execution_engine.queue_callback(
+                        lambda ev=done: torch.cuda.current_stream().wait_event(ev))
+                else:
+                    ops.gemm_softmax_grad(logits, lse, tgt, g, V, xp, True, alpha=1.0 / T, label_smoothing=smooth,
+                                          out=gw, accumulate=True)
         else:
             dl = ops.softmax_ce_bwd(logits, tgt, lse, dloss.contiguous(), width, smooth)
             dxp = ops.sampled_logits_bwd(dl, xp, labels, W.detach(), ctx.neg, _grad_buf(W), T)

@@ -29,7 +29,8 @@ def test_workspace_size_queries_are_pure():
     n = lib.t4r_xlnet_layer_ws_floats(1024, 20, 128, 4, 0)
     T = 1024 * 20
     assert n >= T * 128 * (3 + 1 + 1 + 1 + 4 + 4 + 1)
-    assert lib.t4r_xlnet_layer_ws_floats(1024, 20, 128, 4, 1) == n + (1024 - 1) * 2 * 20 * 128
+    # dropout: per-session k_r instead of the shared one, plus the kept dropout(pos_emb) [B, 2L, D]
+    assert lib.t4r_xlnet_layer_ws_floats(1024, 20, 128, 4, 1) == n + (1024 - 1) * 2 * 20 * 128 + 1024 * 2 * 20 * 128
     assert lib.t4r_xlnet_layer_bwd_ws_floats(8, 20, 64, 4, 0) > 0
     assert lib.t4r_dropout_ctr_hi(3, 2, 4) == (3 << 16) | (2 << 8) | 4
     assert lib.t4r_xlnet_attn_bwd_ws_floats(8, 20, 64, 4) == 8 * (2 * 20 * 64 + 2 * 64)

@@ -497,3 +497,89 @@ def test_continuous_passthrough_columns():
     ref = O.concat_features(feats)
     assert out.shape == (B, L, 8 + 4 + 2)
     assert torch.equal(out.cpu(), ref)
+
+
+# ------------------------------------------------------------------------------------------
+# the other half of the BASELINE metric: Recall@20 on a held-out split after training
+def _markov_sessions(n, L, V, seed, chain_seed=1234):
+    """sessions from a fixed first-order Markov chain over items 1..V-1 (learnable signal)"""
+    cg = torch.Generator().manual_seed(chain_seed)
+    succ = torch.randint(1, V, (V, 3), generator=cg)                  # three likely successors per item
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(5, L + 1, (n,), generator=g)
+    ids = torch.zeros((n, L), dtype=torch.int64)
+    cur = torch.randint(1, V, (n,), generator=g)
+    for t in range(L):
+        ids[:, t] = cur * (t < lens)
+        pick = torch.randint(0, 3, (n,), generator=g)
+        noise = torch.rand(n, generator=g) < 0.1
+        nxt = succ[cur, pick]
+        cur = torch.where(noise, torch.randint(1, V, (n,), generator=g), nxt)
+    return ids
+
+
+def test_recall_at_20_after_training_matches_cpu_oracle():
+    """Train the HIP path and the CPU oracle on the same Markov-chain sessions with the same initial
+    weights, mask draws and Adam hyper-parameters; evaluate Recall@20 / NDCG@20 of the last item of
+    held-out sessions (masking.py:461-465, ranking_metric.py:107-147, 242-280)."""
+    import transformers4rec_amd as tr
+
+    torch.manual_seed(0)
+    B, L, V, D, n_head, n_layer, steps = 128, 20, 400, 64, 2, 2, 120
+    schema = tr.session_schema(V - 1, L)
+    inputs = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=L, masking="mlm",
+                                                    embedding_dim_default=D)
+    cfg = tr.XLNetConfig.build(D, n_head, n_layer, total_seq_length=L, dropout=0.0, initializer_range=0.05)
+    task = tr.NextItemPredictionTask(weight_tying=True, top_ks=(10, 20))
+    model = cfg.to_torch_model(inputs, task)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(DEV)
+    dense, tables = tr.flatten_model(model)
+    opt = tr.FusedAdam([dense, tables], lr=3e-3)
+    p = gu.oracle_params({"p/" + k: v.numpy() for k, v in sd.items()}, requires_grad=True)
+    leaves = [p["tables"]["item_id"], p["masked_item_embedding"]] + [t for lp in p["layers"] for t in lp.values()]
+    ref_opt = torch.optim.Adam(leaves, lr=3e-3)
+    cfg_o = dict(n_head=n_head, eps=0.03, item="item_id", masking="mlm")
+    train = _markov_sessions(B * 8, L, V, seed=1)
+    test_ids = _markov_sessions(512, L, V, seed=2)
+    g = torch.Generator().manual_seed(3)
+    masking = model.input_features.masking
+    for step in range(steps):
+        ids = train[(step % 8) * B: (step % 8 + 1) * B]
+        bern = torch.rand(B, L, generator=g) < 0.2
+        lens = (ids != 0).sum(1)
+        j1 = (torch.rand(B, generator=g) * lens).long()
+        m1 = bern & (ids != 0)
+        m1[torch.arange(B), j1] = True
+        j2 = m1.float().argmax(1)
+        ref_opt.zero_grad()
+        m, lab = O.mlm_targets_train(ids, bern, j1, lambda mm: j2)
+        ref = O.session_forward(p, cfg_o, {"item_id": ids}, m, lab, True, False)
+        ref["loss"].backward()
+        ref_opt.step()
+        masking.set_draws(bern.to(DEV).to(torch.uint8), j1.to(DEV), j2.to(DEV))
+        out = model({"item_id": ids.to(DEV)}, training=True)
+        out["loss"].backward()
+        opt.step()
+    assert float(out["loss"]) < 0.8 * float(np.log(V))                   # it learnt something
+    close(out["loss"], ref["loss"], rtol=3e-2, atol=3e-2)                 # 120 fp32 Adam steps apart
+    # held-out evaluation: last item of every session
+    model.eval()
+    task.reset_metrics()
+    with torch.no_grad():
+        ev = model({"item_id": test_ids.to(DEV)}, testing=True)
+        hip_metrics = task.calculate_metrics(ev["predictions"], ev["labels"])
+        m_e, lab_e = O.mlm_targets_eval(test_ids)
+        ref_e = O.session_forward(p, cfg_o, {"item_id": test_ids}, m_e, lab_e, False, True)
+    r20_ref = float(O.recall_at_k(ref_e["logits"], ref_e["labels"], 20).mean())
+    n20_ref = float(O.ndcg_at_k(ref_e["logits"], ref_e["labels"], 20).mean())
+    r20 = float(hip_metrics["recall_at_20"].mean())
+    n20 = float(hip_metrics["ndcg_at_20"].mean())
+    agg = task.compute_metrics()
+    assert abs(agg["next-item/recall_at_20"] - r20) < 1e-6
+    assert r20 > 10 * 20 / V                                             # far above chance (0.05)
+    assert abs(r20 - r20_ref) < 0.04 and abs(n20 - n20_ref) < 0.04, (r20, r20_ref, n20, n20_ref)
+    # the metric kernel itself on the oracle's logits: exact
+    mm = task.calculate_metrics(ref_e["logits"].to(DEV).contiguous(), ref_e["labels"].to(DEV))
+    assert abs(float(mm["recall_at_20"].mean()) - r20_ref) < 1e-6
+    assert abs(float(mm["ndcg_at_20"].mean()) - n20_ref) < 1e-5

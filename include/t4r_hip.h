@@ -250,6 +250,15 @@ int t4r_sampled_logits_bwd(void* stream, const float* dlogits, const float* x, c
                            int n_neg, float temperature);
 int t4r_topk(void* stream, const float* scores, int N, int V, long ld, int k, float* out_val,
              long* out_idx);
+/* Fused eval head (replaces logits materialisation + torch.topk + the [N, V] one-hot of
+ * ranking_metric.py:52-59 for the metric computation): rank[row] = number of items that beat the
+ * row's target under "ties go to the lower index", from alpha * X[n_rows, D] @ W[V, D]^T computed
+ * tile by tile and never stored.  target_score[row] = that row's score of labels[row], produced by
+ * the same GEMM kernel (t4r_gemm_f32 on the gathered label rows, diagonal).  Recall@k = rank < k,
+ * NDCG@k = rank < k ? 1 / log2(rank + 2) : 0. */
+int t4r_rank_of_target_f32(void* stream, int n_rows, int V, int D, float alpha, const float* X, long ldx,
+                           const float* W, long ldw, const float* target_score, const long* labels,
+                           int* rank);
 
 /* ----------------------------------------------------------------------------------------
  * train-time input regularisers (pre / post transformations of the input block)

@@ -583,3 +583,29 @@ def test_recall_at_20_after_training_matches_cpu_oracle():
     mm = task.calculate_metrics(ref_e["logits"].to(DEV).contiguous(), ref_e["labels"].to(DEV))
     assert abs(float(mm["recall_at_20"].mean()) - r20_ref) < 1e-6
     assert abs(float(mm["ndcg_at_20"].mean()) - n20_ref) < 1e-5
+
+
+def test_fused_eval_ranks_equal_materialised_metrics():
+    """evaluate_ranks (no [N, V] scores) gives exactly the Recall/NDCG of calculate_metrics(predictions)."""
+    d = gu.load("xlnet_mlm_multi_train")
+    model = build_model(d, cats=(("category", 40), ("brand", 9)), conts=("price", "age"), d_output=32,
+                        embedding_dims={"item_id": 16, "category": 24, "brand": 8})
+    load_reference_state(model, d)
+    model.to(DEV).eval()
+    x = {k[3:]: gu.t(v).to(DEV) for k, v in d.items() if k.startswith("in/")}
+    task = model.prediction_task
+    with torch.no_grad():
+        cap = {}
+        h = model.transformer_block.register_forward_hook(lambda m, i, o: cap.__setitem__("hid", o))
+        out = model(x, testing=True)
+        h.remove()
+        task.reset_metrics()
+        a = task.calculate_metrics(out["predictions"], out["labels"])
+        agg_a = task.compute_metrics()
+        task.reset_metrics()
+        b = task.evaluate_ranks(cap["hid"])
+        agg_b = task.compute_metrics()
+    assert torch.equal(b["labels"], out["labels"])
+    for k in a:
+        assert torch.equal(a[k], b["metrics"][k]), k
+    assert agg_a == agg_b and len(agg_a) == 4

@@ -765,3 +765,34 @@ def test_swap_noise_edge_cases():
     assert torch.equal(out.flatten().sort().values, xf.flatten().sort().values)
     e = torch.empty((0, 5), dtype=torch.int64, device=DEV)
     assert ops.swap_noise(e, e, 0.5).shape == (0, 5)
+
+
+# ------------------------------------------------------------------------------------------
+# fused eval head: rank of the target without materialising the scores
+@pytest.mark.parametrize("N,V,D", [(1, 5, 8), (70, 1000, 32), (257, 4099, 128), (1500, 333, 64)])
+def test_rank_of_target_matches_topk_and_sort(N, V, D):
+    from transformers4rec_amd import ops
+
+    g = torch.Generator().manual_seed(N + V)
+    x = torch.randn((N, D), generator=g)
+    W = torch.randn((V, D), generator=g)
+    if V > 10:                       # exact ties: duplicated item rows (same score for two columns)
+        W[7] = W[3]
+        W[V - 1] = W[V // 2]
+    y = torch.randint(0, V, (N,), generator=g)
+    if V > 10:
+        y[0], y[N // 2] = 7, V // 2   # targets inside a tie group: the lower index ranks first
+    xd, Wd, yd = x.to(DEV), W.to(DEV), y.to(DEV)
+    ranks = ops.rank_of_target(xd, Wd, yd, alpha=0.5).cpu()
+    scores = ops.gemm(xd, Wd, False, True, alpha=0.5).cpu()          # the same kernel's scores
+    t = scores[torch.arange(N), y]
+    idx = torch.arange(V)[None]
+    ref = ((scores > t[:, None]) | ((scores == t[:, None]) & (idx < y[:, None]))).sum(1).to(torch.int32)
+    assert torch.equal(ranks, ref)
+    if V > 10:
+        assert int(ranks[0]) >= 1 and scores[0, 3] == scores[0, 7]   # column 3 ties with the target 7 and precedes it
+    k = min(20, V)
+    _, topi = ops.topk(scores.to(DEV), k, V)
+    hit = (topi.cpu() == y[:, None])
+    assert torch.equal(hit.any(1), ranks < k)
+    assert torch.equal(hit.float().argmax(1)[hit.any(1)].to(torch.int32), ranks[ranks < k])

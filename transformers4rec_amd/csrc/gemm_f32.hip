@@ -58,6 +58,13 @@ struct GemmParams {
     const float* sg_gout;       // device scalar (d loss), may be null (=1)
     int sg_rows, sg_V;
     float sg_smooth;
+    // rank-of-target epilogue (FEAT bit 2; fused eval head): nothing is stored; for every output row
+    // the workgroup counts the columns that beat the row's target score,
+    //   rk_count[row] += #{col < N : v > thr[row]  or  (v == thr[row] and col < label[row])},
+    // i.e. the 0-based rank of the target under "ties go to the lower index" (the top-k convention).
+    const float* rk_thr;        // null => normal epilogue
+    const long* rk_label;
+    int* rk_count;
 };
 
 // softmax-gradient transform of four consecutive columns col0..col0+3 of one logits row.
@@ -107,7 +114,7 @@ __device__ __forceinline__ float4 mask4(float4 v, int valid) {   // keep the fir
 // the scalar-load variant is its own instantiation so that it does not set the register budget.
 template <int BM, int BN, int BK, bool TA, bool TB, int FEAT, bool VEC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
-    constexpr bool SG = (FEAT & 1) != 0, EDROP = (FEAT & 2) != 0;
+    constexpr bool SG = (FEAT & 1) != 0, EDROP = (FEAT & 2) != 0, RANK = (FEAT & 4) != 0;
     constexpr int WM = BM / 64, WN = BN / 64;          // MFMA tiles per wave per dim
     constexpr bool A_MK = !TA, B_MK = TB;              // operand image is S[m][k] (k contiguous)
     constexpr int LDA_S = A_MK ? BK + 4 : BM + 4;      // LDS row pitch (floats)
@@ -384,6 +391,26 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     // store loop (the per-element switch cost ~30 scalar/vector instructions per output element,
     // a quarter of the MFMA time of a K = 128 tile).
     const float alpha = p.alpha;
+    if constexpr (RANK) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    const int rr = min(row, p.M - 1);
+                    const float v = alpha * acc[i][j][r], t = p.rk_thr[rr];
+                    const bool beats = col < p.N && (v > t || (v == t && col < (int)p.rk_label[rr]));
+                    const unsigned long long m = __ballot(beats);
+                    const int cnt = __popc((unsigned)(khalf ? (m >> 32) : (m & 0xffffffffull)));
+                    if ((lane & 31) == 0 && row < p.M && cnt) atomicAdd(p.rk_count + row, cnt);
+                }
+            }
+        }
+        return;
+    }
     const bool rows_full = m0 + BM <= p.M;
     auto for_each_out = [&](auto fn) __attribute__((always_inline)) {
 #pragma unroll
@@ -469,6 +496,11 @@ static int launch_cfg(const GemmParams& p, int batch, hipStream_t stream) {
         t4r_set_error("gemm: softmax-grad operand needs the 64x64 tile and transB = 0");
         return -1;
     }
+    if (p.rk_thr) {
+        if (BM == 64 && BN == 64 && !TA && TB && p.splitk == 1) return launch_feat<64, 64, BK, false, true, 4>(p, batch, stream);
+        t4r_set_error("gemm: the rank epilogue needs the 64x64 NT tile without split-K");
+        return -1;
+    }
     if (p.drop.p > 0.f && (p.epilogue == EPI_BIAS_GELU || p.epilogue == EPI_BIAS_RESID)) {
         if (BM == 64 && BN == 64) return launch_feat<64, 64, BK, TA, TB, 2>(p, batch, stream);
         t4r_set_error("gemm: epilogue dropout needs the 64x64 tile");
@@ -539,6 +571,8 @@ static int launch_layout(GemmParams& p, int batch, int splitk_req, hipStream_t s
 
 struct SoftmaxGradA { const float* lse; const long* labels; const float* gout; int rows, V; float smooth; };
 static thread_local const SoftmaxGradA* g_sg = nullptr;   // set only by t4r_gemm_softmax_grad_f32
+struct RankEpi { const float* thr; const long* label; int* count; };
+static thread_local const RankEpi* g_rank = nullptr;      // set only by t4r_rank_of_target_f32
 
 // Internal C++ entry used by the composite (layer / head) launchers.
 int t4r_gemm_launch(hipStream_t stream, int transA, int transB, int M, int N, int K, float alpha,
@@ -557,6 +591,8 @@ int t4r_gemm_launch(hipStream_t stream, int transA, int transB, int M, int N, in
     p.splitk = 1;
     p.drop = drop ? *drop : make_drop(0.f, 0, 0);
     p.sg_lse = nullptr; p.sg_labels = nullptr; p.sg_gout = nullptr; p.sg_rows = 1; p.sg_V = 1; p.sg_smooth = 0.f;
+    p.rk_thr = nullptr; p.rk_label = nullptr; p.rk_count = nullptr;
+    if (g_rank) { p.rk_thr = g_rank->thr; p.rk_label = g_rank->label; p.rk_count = g_rank->count; }
     if (g_sg) {
         p.sg_lse = g_sg->lse; p.sg_labels = g_sg->labels; p.sg_gout = g_sg->gout;
         p.sg_rows = g_sg->rows; p.sg_V = g_sg->V; p.sg_smooth = g_sg->smooth;
@@ -600,5 +636,30 @@ extern "C" int t4r_gemm_softmax_grad_f32(void* stream, int transA, int n_rows, i
                                    C, ldc, nullptr, EPI_NONE, nullptr, 0, splitk, accumulate, 1, 0, 0, 0,
                                    nullptr);
     g_sg = nullptr;
+    return rc;
+}
+
+// Fused eval head: rank of the target item among alpha * X @ W^T without materialising
+// the [n_rows, V] scores.  target_score[row] must be the row's own score of its label column as THIS
+// kernel computes it (run t4r_gemm_f32 on the gathered label rows of W and take the diagonal: an
+// output element's bits do not depend on its tile position).  rank[row] (int32) is overwritten with
+// #{v : score_v > target or (score_v == target and v < label)}: Recall@k = rank < k,
+// NDCG@k = rank < k ? 1 / log2(rank + 2) : 0  (ranking_metric.py:107-147, 242-280 with one relevant item).
+extern "C" int t4r_rank_of_target_f32(void* stream, int n_rows, int V, int D, float alpha, const float* X,
+                                      long ldx, const float* W, long ldw, const float* target_score,
+                                      const long* labels, int* rank) {
+    if (n_rows == 0) return 0;
+    T4R_CHECK_ARG(target_score && labels && rank, "rank_of_target: null pointer");
+    if (hipMemsetAsync(rank, 0, sizeof(int) * (size_t)n_rows, (hipStream_t)stream) != hipSuccess) {
+        t4r_set_error("rank_of_target: memset failed");
+        return -1;
+    }
+    RankEpi re{target_score, labels, rank};
+    g_rank = &re;
+    // C is never written by the rank epilogue; a non-null dummy keeps the argument check happy
+    const int rc = t4r_gemm_launch((hipStream_t)stream, 0, 1, n_rows, V, D, alpha, X, ldx, W, ldw,
+                                   reinterpret_cast<float*>(rank), V, nullptr, EPI_NONE, nullptr, 0, 1, 0, 1, 0, 0,
+                                   0, nullptr);
+    g_rank = nullptr;
     return rc;
 }

@@ -483,6 +483,25 @@ def topk(scores, k, V=None):
 
 
 # ------------------------------------------------------------------------------------ optimizer
+def rank_of_target(x, W, labels, alpha=1.0, chunk=1024):
+    """0-based rank of labels[i] among alpha * x[i] @ W^T (ties -> lower index first), int32 [N];
+    the [N, V] scores are never materialised."""
+    N, D = x.shape
+    V = W.shape[0]
+    rank = torch.empty(N, device=x.device, dtype=torch.int32)
+    labels = labels.contiguous()
+    for s0 in range(0, N, chunk):           # target scores through the SAME kernel: diagonal of x_c @ W[y_c]^T
+        xc, yc = x[s0: s0 + chunk], labels[s0: s0 + chunk]
+        n = xc.shape[0]
+        pos = yc.to(torch.int32)
+        wy = gather_rows(W, pos, n)
+        tgt = gemm(xc, wy, False, True, alpha=alpha).diagonal().contiguous()
+        call("t4r_rank_of_target_f32", _stream(), n, V, D, float(alpha), _chk(xc, torch.float32), xc.stride(0),
+             _chk(W, torch.float32), W.stride(0), _chk(tgt, torch.float32), _chk(yc, torch.int64),
+             rank[s0: s0 + chunk].data_ptr())
+    return rank
+
+
 def adam_step_(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
                weight_decay=0.0, grad_scale=1.0, zero_grad=True):
     call("t4r_adam_step", _stream(), _chk(param, torch.float32), _chk(grad, torch.float32),

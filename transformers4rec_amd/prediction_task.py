@@ -303,6 +303,43 @@ class NextItemPredictionTask(nn.Module):
             self._metric_sums[k][1] += v.numel()
         return out
 
+    def metrics_from_ranks(self, ranks):
+        """Recall@k / NDCG@k from 0-based target ranks (one relevant item per row)."""
+        out = {}
+        r = ranks.to(torch.float32)
+        for k in self.top_ks:
+            hit = ranks < k
+            out[f"recall_at_{k}"] = hit.float()
+            out[f"ndcg_at_{k}"] = torch.where(hit, 1.0 / torch.log2(r + 2.0), torch.zeros_like(r))
+        if self._metric_sums is None:
+            self._metric_sums = {k: [0.0, 0] for k in out}
+        for k, v in out.items():
+            self._metric_sums[k][0] += float(v.sum())
+            self._metric_sums[k][1] += v.numel()
+        return out
+
+    def evaluate_ranks(self, inputs):
+        """Fused evaluation head: the label rows of `inputs` [B, L, D] (the masking's
+        evaluation targets, e.g. the last item of every session) -> rank of the target item among
+        all V scores, computed tile by tile inside the logits GEMM; the [N, V] score matrix, the
+        top-k pass and the reference's [N, V] one-hot (ranking_metric.py:52-59) never exist.
+        Returns {"labels", "ranks", "metrics"}; metrics are also accumulated for compute_metrics()."""
+        x = (inputs[0] if isinstance(inputs, (tuple, list)) else inputs).float()
+        mod = self.pre.module
+        n, pos, lab = self.masking.compact_labels()
+        N = int(n.item())
+        if N == 0:
+            raise ValueError("no label positions in this batch")
+        labels = lab[:N]
+        B, L, D = x.shape
+        xr = ops.gather_rows(x.detach().contiguous().view(B * L, D), pos, N)
+        if self.task_block is not None:
+            lin = self.task_block[0][0]
+            xr = ops.gemm(xr, lin.weight.detach(), False, True, bias=lin.bias.detach(), epilogue=ops.EPI_BIAS)
+        T = float(mod.softmax_temperature) if mod.softmax_temperature else 1.0
+        ranks = ops.rank_of_target(xr, mod.output_weights.detach(), labels, 1.0 / T)
+        return {"labels": labels, "ranks": ranks, "metrics": self.metrics_from_ranks(ranks)}
+
     def compute_metrics(self, mode=None):
         if not self._metric_sums:
             return {}

@@ -257,15 +257,30 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ sco
     float* myv = cv + threadIdx.x * k;
     int* myi = ci + threadIdx.x * k;
     for (int j = 0; j < k; ++j) { myv[j] = -INFINITY; myi[j] = 0x7fffffff; }
-    for (int i = threadIdx.x; i < V; i += 256) {
-        const float v = x[i];
-        if (v > myv[k - 1] || (v == myv[k - 1] && i < myi[k - 1])) {
+    // the k-th best of this thread's list lives in a register: the common case (element does not
+    // enter the list) touches no LDS.  A thread sees its indices in increasing order, so an element
+    // equal to the threshold never displaces it (ties resolve to the lower index).
+    float thr = -INFINITY;
+    auto offer = [&](float v, int i) {
+        if (v > thr) {
             int j = k - 1;
-            while (j > 0 && (myv[j - 1] < v || (myv[j - 1] == v && myi[j - 1] > i))) {
+            while (j > 0 && (myv[j - 1] < v)) {
                 myv[j] = myv[j - 1]; myi[j] = myi[j - 1]; --j;
             }
             myv[j] = v; myi[j] = i;
+            thr = myv[k - 1];
         }
+    };
+    const bool vec = (ld % 4 == 0) && ((uintptr_t)scores % 16 == 0);
+    if (vec) {
+        const int v4 = V / 4;
+        for (int q = threadIdx.x; q < v4; q += 256) {
+            const float4 t = *reinterpret_cast<const float4*>(x + 4 * q);
+            offer(t.x, 4 * q); offer(t.y, 4 * q + 1); offer(t.z, 4 * q + 2); offer(t.w, 4 * q + 3);
+        }
+        for (int i = v4 * 4 + threadIdx.x; i < V; i += 256) offer(x[i], i);
+    } else {
+        for (int i = threadIdx.x; i < V; i += 256) offer(x[i], i);
     }
     __syncthreads();
     // k rounds: pick the best head among the 256 sorted lists

@@ -796,3 +796,25 @@ def test_rank_of_target_matches_topk_and_sort(N, V, D):
     hit = (topi.cpu() == y[:, None])
     assert torch.equal(hit.any(1), ranks < k)
     assert torch.equal(hit.float().argmax(1)[hit.any(1)].to(torch.int32), ranks[ranks < k])
+
+
+def test_topk_ties_and_fallback_path(ops):
+    """ties resolve to the lower index; rows with more than TOPK_CAP values at the threshold
+    (constant rows, heavy duplicates) take the sorted-list fallback and must agree"""
+    V, k = 5000, 10
+    s = torch.zeros(4, V)
+    s[1, 100:3000] = 1.0                                      # 2900 equal maxima -> candidate overflow
+    s[2] = torch.arange(V).float() % 7                       # many duplicates of the top value
+    s[3] = -torch.arange(V).float()                          # strictly decreasing: top-k = first k
+    v, i = ops.topk(cu(s), k)
+    order = torch.argsort(-s, dim=1, stable=True)[:, :k]      # value desc, index asc
+    assert torch.equal(i.cpu(), order)
+    assert torch.equal(v.cpu(), torch.gather(s, 1, order))
+    # padded leading dimension + V not a multiple of 4 + k = 64
+    g = torch.Generator().manual_seed(0)
+    s2 = torch.randn(3, 1003, generator=g)
+    buf = torch.full((3, 1024), 9e9)
+    buf[:, :1003] = s2
+    v2, i2 = ops.topk(cu(buf)[:, :1003], 64, 1003)
+    rv, ri = torch.topk(s2, 64, dim=-1)
+    assert torch.equal(v2.cpu(), rv) and torch.equal(i2.cpu(), ri)

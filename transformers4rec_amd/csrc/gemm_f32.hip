@@ -353,13 +353,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     // below the MFMAs to reuse registers and then waits for them right away.
     {
         const int last = kt_end - 1;
+        // the first TWO k-tiles are requested together, so the second one's latency runs under the
+        // first one's trip through LDS (K = 128 tiles are only 8 k-tiles long: the prologue counts)
         load_tiles(T4R_S0, kt_begin);
+        load_tiles(T4R_S1, min(kt_begin + 1, last));
+        __builtin_amdgcn_sched_barrier(0);
         if (SG) transform_stage(T4R_S0, kt_begin, true);
         store_tiles(T4R_S0, 0, kt_begin, true);
         __syncthreads();
 #pragma unroll
         for (int h = 0; h < NH; ++h) read_frag(0, h);
-        load_tiles(T4R_S0, min(kt_begin + 1, last));
 #define T4R_STEP(SLOAD, SSTORE, BUFN, TNEXT)                          \
         load_tiles(SLOAD, min((TNEXT) + 1, last));                      \
         __builtin_amdgcn_sched_barrier(0);                              \
@@ -380,8 +383,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         __builtin_amdgcn_sched_barrier(0);                              \
         _Pragma("unroll") for (int h = 1; h < NH; ++h) read_frag(BUFN, h);
         for (int kt = kt_begin; kt < kt_end; kt += 2) {
-            T4R_STEP(T4R_S1, T4R_S0, 1, kt + 1)
-            T4R_STEP(T4R_S0, T4R_S1, 0, kt + 2)
+            T4R_STEP(T4R_S0, T4R_S1, 1, kt + 1)
+            T4R_STEP(T4R_S1, T4R_S0, 0, kt + 2)
         }
 #undef T4R_STEP
     }

@@ -170,7 +170,7 @@ int t4r_reduce_partials_launch(hipStream_t st, const float* part, int nblocks, f
     return 0;
 }
 
-#define T4R_COLRED_ROWS 32
+#define T4R_COLRED_ROWS 16
 // workspace floats needed by the column-reducing kernels below for `rows` rows and `ncols`
 // reduced columns in total (LayerNorm backward: 2*D ; act_bwd_bias / colsum: N)
 extern "C" long t4r_colreduce_ws_floats(long rows, int ncols) {

@@ -148,10 +148,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # device pre-heat: full training steps for a fixed TIME (clock ramp), then the model / optimizer
+    # state is rolled back, so the measured run (and its final loss) does not depend on how many
+    # pre-heat steps this particular box managed
+    snap = ([f.data.clone() for f in opt.flats], [(m.clone(), v.clone()) for m, v in opt.state], opt.step_count,
+            masking._rng_offset, model.transformer_block.transformer._drop_offset)
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < args.preheat_seconds:
         out = train_step(0)
         torch.cuda.synchronize()
+    for f, d in zip(opt.flats, snap[0]):
+        f.data.copy_(d)
+    for (m, v), (m0, v0) in zip(opt.state, snap[1]):
+        m.copy_(m0)
+        v.copy_(v0)
+    opt.step_count, masking._rng_offset = snap[2], snap[3]
+    model.transformer_block.transformer._drop_offset = snap[4]
+    del snap
     for i in range(args.warmup):
         out = train_step(i)
     barrier()

@@ -14,6 +14,7 @@
 //   h1 = LN(attn_vec @ o^T + h) ; h2 = LN(W2 gelu(W1 h1 + b1) + b2 + h1)
 // Saved-for-backward activations live in one caller-provided workspace (offsets below).
 #include "t4r_common.h"
+#include <stdlib.h>
 
 int t4r_gemm_launch(hipStream_t stream, int transA, int transB, int M, int N, int K, float alpha,
                     const float* A, long lda, const float* B, long ldb, float* C, long ldc,
@@ -164,6 +165,37 @@ extern "C" int t4r_xlnet_layer_fwd(void* stream, const float* h, const float* po
     return 0;
 }
 
+// Weight-gradient contractions feed nothing but the optimizer, so the layer backward issues them on a
+// second HIP stream, under the kernels of the critical chain (LayerNorm / activation backward are
+// HBM-bound, the attention core is latency-bound: the MFMA pipes are mostly idle there).
+// Ordering is by events: the side stream waits for the producer of a wgrad's operands, the main
+// stream waits (a) before a buffer a queued wgrad still reads is overwritten and (b) at the end of
+// the call -- after the call returns, everything on `stream` is ordered after all of its work.
+// T4R_LAYER_SIDE_STREAM=0 keeps everything on one stream.
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t fork[6] = {}, done_ff2 = nullptr, done_o = nullptr, done_all = nullptr;
+    int state = 0;    // 0 untried, 1 ready, -1 disabled / failed
+};
+static thread_local SideStream g_side;
+
+static SideStream* side_stream() {
+    SideStream& ss = g_side;
+    if (ss.state == 0) {
+        const char* e = getenv("T4R_LAYER_SIDE_STREAM");
+        ss.state = -1;
+        if (!(e && atoi(e) == 0)) {
+            bool ok = hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) == hipSuccess;
+            for (int i = 0; ok && i < 6; ++i) ok = hipEventCreateWithFlags(&ss.fork[i], hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&ss.done_ff2, hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&ss.done_o, hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&ss.done_all, hipEventDisableTiming) == hipSuccess;
+            if (ok) ss.state = 1;
+        }
+    }
+    return ss.state == 1 ? &ss : nullptr;
+}
+
 // grads[] are ACCUMULATED into (zero them / let the optimizer zero them between steps).
 // dh_in [T,D] is overwritten with d loss / d h.
 extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* pos_emb,
@@ -190,6 +222,17 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
     float* red_ws = take(t4r_colreduce_ws_floats(T, 4 * D));
     float* dxa = drop ? take(TD) : nullptr;     // gradient of a dropped LayerNorm operand
 
+    SideStream* ss = side_stream();
+    int n_fork = 0;
+    // wg(): the stream a weight-gradient GEMM goes to; it first waits for everything issued on `st` so far
+    auto wg = [&]() -> hipStream_t {
+        if (!ss) return st;
+        (void)hipEventRecord(ss->fork[n_fork], st);
+        (void)hipStreamWaitEvent(ss->s, ss->fork[n_fork], 0);
+        ++n_fork;
+        return ss->s;
+    };
+
     // LN2: y = LN(drop(ffout) + h1): dx = d h1 (residual part), d ffout = dxa (or dx when p = 0)
     RUN(t4r_add_layernorm_bwd(stream, w.ffout, w.h1, params[P_LN2W], w.mean2, w.rstd2, dh_out, dx, dxa,
                               grads[P_LN2W], grads[P_LN2B], red_ws, T, D, 0, drop_p, seed, C(SITE_FF_OUT)));
@@ -197,26 +240,30 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
     // FF2: ffout = ffact @ w2^T + b2
     RUN(t4r_gemm_launch(st, 0, 0, T, 4 * D, D, 1.f, dffout, D, params[P_W2], 4 * D, dff, 4 * D, nullptr,
                         EPI_NONE, nullptr, 0, 1, 0, 1, 0, 0, 0, nullptr));
-    RUN(t4r_gemm_launch(st, 1, 0, D, 4 * D, T, 1.f, dffout, D, w.ffact, 4 * D, grads[P_W2], 4 * D, nullptr,
-                        EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
     RUN(t4r_colsum(stream, dffout, grads[P_B2], red_ws, T, D, D));
+    RUN(t4r_gemm_launch(wg(), 1, 0, D, 4 * D, T, 1.f, dffout, D, w.ffact, 4 * D, grads[P_W2], 4 * D, nullptr,
+                        EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
+    if (ss) (void)hipEventRecord(ss->done_ff2, ss->s);
     // ffact = drop(gelu(ffpre)) ; GELU' + bias1
     RUN(t4r_act_bwd_bias(stream, dff, w.ffpre, dff, grads[P_B1], red_ws, T, 4 * D, 0, drop_p, seed,
                          C(SITE_FF_ACT)));
     // FF1: ffpre = h1 @ w1^T + b1 ;  d h1 = dx (residual) + dff @ w1
+    if (ss && !drop) (void)hipStreamWaitEvent(st, ss->done_ff2, 0);   // p = 0: the FF2 wgrad reads dx, written next
     RUN(t4r_gemm_launch(st, 0, 0, T, D, 4 * D, 1.f, dff, 4 * D, params[P_W1], D, dx, D, nullptr,
                         EPI_NONE, nullptr, 0, 1, 1, 1, 0, 0, 0, nullptr));
-    RUN(t4r_gemm_launch(st, 1, 0, 4 * D, D, T, 1.f, dff, 4 * D, w.h1, D, grads[P_W1], D, nullptr,
+    RUN(t4r_gemm_launch(wg(), 1, 0, 4 * D, D, T, 1.f, dff, 4 * D, w.h1, D, grads[P_W1], D, nullptr,
                         EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
     // LN1: h1 = LN(drop(ao) + h): dh_in = d h (residual part), d ao = dxa (or dh_in when p = 0)
+    if (ss && drop) (void)hipStreamWaitEvent(st, ss->done_ff2, 0);    // the FF2 wgrad reads dxa, overwritten here
     RUN(t4r_add_layernorm_bwd(stream, w.ao, h, params[P_LN1W], w.mean1, w.rstd1, dx, dh_in, dxa,
                               grads[P_LN1W], grads[P_LN1B], red_ws, T, D, 0, drop_p, seed, C(SITE_ATTN_OUT)));
     const float* dao = drop ? dxa : dh_in;
     // O projection: ao = av @ o^T
     RUN(t4r_gemm_launch(st, 0, 0, T, D, D, 1.f, dao, D, params[P_O], D, dav, D, nullptr, EPI_NONE,
                         nullptr, 0, 1, 0, 1, 0, 0, 0, nullptr));
-    RUN(t4r_gemm_launch(st, 1, 0, D, D, T, 1.f, dao, D, w.av, D, grads[P_O], D, nullptr, EPI_NONE,
+    RUN(t4r_gemm_launch(wg(), 1, 0, D, D, T, 1.f, dao, D, w.av, D, grads[P_O], D, nullptr, EPI_NONE,
                         nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
+    if (ss) (void)hipEventRecord(ss->done_o, ss->s);
     // attention core
     RUN(t4r_xlnet_attn_bwd(stream, w.qkv, w.qkv + TD, w.qkv + 2 * TD, w.kr, params[P_RWB],
                            params[P_RRB], w.av, w.lse, dav, dqkv, dqkv + TD, dqkv + 2 * TD, dkr,
@@ -224,25 +271,33 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
                            C(SITE_PROB)));
     // k_r = pos_emb(_b) @ r  ->  d r += pos_emb(_b)^T @ d k_r
     if (drop) {
-        RUN(t4r_gemm_launch(st, 1, 0, D, D, B * 2 * L, 1.f, w.pe_b, D, dkr, D, grads[P_R], D, nullptr,
+        RUN(t4r_gemm_launch(wg(), 1, 0, D, D, B * 2 * L, 1.f, w.pe_b, D, dkr, D, grads[P_R], D, nullptr,
                             EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
     } else {
-        RUN(t4r_gemm_launch(st, 1, 0, D, D, 2 * L, 1.f, pos_emb, D, dkr, D, grads[P_R], D, nullptr,
+        RUN(t4r_gemm_launch(wg(), 1, 0, D, D, 2 * L, 1.f, pos_emb, D, dkr, D, grads[P_R], D, nullptr,
                             EPI_NONE, nullptr, 0, 1, 1, 1, 0, 0, 0, nullptr));
     }
     // q,k,v = h @ w  ->  d h += d{q,k,v} @ w^T ; d w += h^T @ d{q,k,v}
     const float* wz[3] = {params[P_Q], params[P_K], params[P_V]};
     float* gz[3] = {grads[P_Q], grads[P_K], grads[P_V]};
+    {
+        hipStream_t sw = wg();
+        if (gz[1] == gz[0] + DD && gz[2] == gz[0] + 2 * DD) {
+            RUN(t4r_gemm_launch(sw, 1, 0, D, D, T, 1.f, h, D, dqkv, D, gz[0], D, nullptr, EPI_NONE, nullptr,
+                                0, -1, 1, 3, 0, TD, DD, nullptr));
+        } else {
+            for (int z = 0; z < 3; ++z)
+                RUN(t4r_gemm_launch(sw, 1, 0, D, D, T, 1.f, h, D, dqkv + z * TD, D, gz[z], D, nullptr,
+                                    EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
+        }
+    }
+    if (ss && !drop) (void)hipStreamWaitEvent(st, ss->done_o, 0);     // p = 0: the O wgrad reads dh_in, accumulated into next
     for (int z = 0; z < 3; ++z)
         RUN(t4r_gemm_launch(st, 0, 1, T, D, D, 1.f, dqkv + z * TD, D, wz[z], D, dh_in, D, nullptr,
                             EPI_NONE, nullptr, 0, 1, 1, 1, 0, 0, 0, nullptr));
-    if (gz[1] == gz[0] + DD && gz[2] == gz[0] + 2 * DD) {
-        RUN(t4r_gemm_launch(st, 1, 0, D, D, T, 1.f, h, D, dqkv, D, gz[0], D, nullptr, EPI_NONE, nullptr,
-                            0, -1, 1, 3, 0, TD, DD, nullptr));
-    } else {
-        for (int z = 0; z < 3; ++z)
-            RUN(t4r_gemm_launch(st, 1, 0, D, D, T, 1.f, h, D, dqkv + z * TD, D, gz[z], D, nullptr,
-                                EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
+    if (ss) {   // join: the caller's stream continues after every weight gradient of this layer
+        (void)hipEventRecord(ss->done_all, ss->s);
+        (void)hipStreamWaitEvent(st, ss->done_all, 0);
     }
     return 0;
 }

@@ -185,7 +185,12 @@ static SideStream* side_stream() {
         const char* e = getenv("T4R_LAYER_SIDE_STREAM");
         ss.state = -1;
         if (!(e && atoi(e) == 0)) {
-            bool ok = hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) == hipSuccess;
+            // lowest priority: the critical chain on the caller's stream gets the CUs first
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            const char* pe = getenv("T4R_LAYER_SIDE_PRIO");
+            const int prio = pe ? atoi(pe) : lo;
+            bool ok = hipStreamCreateWithPriority(&ss.s, hipStreamNonBlocking, prio) == hipSuccess;
             for (int i = 0; ok && i < 6; ++i) ok = hipEventCreateWithFlags(&ss.fork[i], hipEventDisableTiming) == hipSuccess;
             ok = ok && hipEventCreateWithFlags(&ss.done_ff2, hipEventDisableTiming) == hipSuccess;
             ok = ok && hipEventCreateWithFlags(&ss.done_o, hipEventDisableTiming) == hipSuccess;

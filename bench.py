@@ -214,7 +214,7 @@ def main():
     # on a known copy; collected in separate rocprofv3 --pmc passes and committed under profiles/).
     # It is a property of the kernel + shape, not of this run: taken from the committed measurement.
     traffic, traffic_src = None, None
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_d_pmc_traffic.json")
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_e_pmc_traffic.json")
     if os.path.exists(tpath):
         with open(tpath) as f:
             tj = json.load(f)

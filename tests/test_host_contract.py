@@ -1,0 +1,139 @@
+"""Host-side mirror of the reference's module contract, checked without a GPU:
+state_dict names / shapes against the reference-generated fixtures, constructor and build errors
+with the reference's messages, the pre / post transformation registry strings, and the
+no-CPU-fallback rule."""
+import numpy as np
+import pytest
+import torch
+
+import golden_utils as gu
+
+
+def _build(d, **kw):
+    import transformers4rec_amd as tr
+
+    L, V = int(d["meta/L"]), int(d["meta/V"])
+    cats, conts = kw.pop("cats", ()), kw.pop("conts", ())
+    context = kw.pop("context", ())
+    arch = kw.pop("arch", "xlnet")
+    weight_tying = kw.pop("weight_tying", True)
+    sampled, max_n = kw.pop("sampled", False), kw.pop("max_n", 100)
+    schema = tr.session_schema(V - 1, L, cats, conts)
+    for name, card in context:
+        schema = schema + tr.Schema([tr.ColumnSchema(name, [tr.Tags.CATEGORICAL], tr.IntDomain(0, card))])
+    fk = dict(max_sequence_length=L, masking=kw.pop("masking", "mlm"), aggregation=kw.pop("aggregation", "concat"))
+    if conts:
+        fk["continuous_soft_embeddings"] = True
+    fk.update(kw)
+    inputs = tr.TabularSequenceFeatures.from_schema(schema, **fk)
+    ck = dict(d_model=int(d["meta/d_model"]), n_head=int(d["meta/n_head"]), n_layer=int(d["meta/n_layer"]),
+              total_seq_length=L)
+    cfg = {"xlnet": tr.XLNetConfig, "gpt2": tr.GPT2Config, "bert": tr.BertConfig}[arch].build(**ck)
+    return cfg.to_torch_model(inputs, tr.NextItemPredictionTask(weight_tying=weight_tying, sampled_softmax=sampled,
+                                                               max_n_samples=max_n))
+
+
+CASES = {
+    "xlnet_mlm_item_train": dict(embedding_dim_default=32),
+    "xlnet_mlm_multi_train": dict(cats=(("category", 40), ("brand", 9)), conts=("price", "age"), d_output=32,
+                                  embedding_dims={"item_id": 16, "category": 24, "brand": 8}),
+    "xlnet_clm_item_train": dict(masking="clm", embedding_dim_default=32, weight_tying=False),
+    "xlnet_mlm_sum_sampled_train": dict(cats=(("category", 40),), aggregation="element-wise-sum",
+                                        embedding_dim_default=32, sampled=True, max_n=20),
+    "xlnet_mlm_context_train": dict(context=(("country", 17),), d_output=32,
+                                    embedding_dims={"item_id": 24, "country": 8}),
+    "gpt2_clm_item_train": dict(masking="clm", embedding_dim_default=32, arch="gpt2"),
+    "bert_mlm_item_train": dict(embedding_dim_default=32, arch="bert"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_state_dict_names_and_shapes_match_reference(name):
+    """every tensor of the reference's state_dict has a home of the same shape (checkpoints interchange)"""
+    d = gu.load(name)
+    model = _build(d, **dict(CASES[name]))
+    own = model.state_dict()
+    ref = gu.section(d, "p/")
+    assert ref, "fixture without parameters"
+    for k, v in ref.items():
+        assert k in own, f"reference key without a home: {k}"
+        assert tuple(own[k].shape) == tuple(v.shape), (k, tuple(own[k].shape), tuple(v.shape))
+    model.load_state_dict({k: v for k, v in ref.items()}, strict=False)
+    for k, v in ref.items():
+        assert torch.equal(model.state_dict()[k], v)
+
+
+def test_prepost_state_dict_names():
+    import transformers4rec_amd as tr
+
+    d = gu.load("xlnet_mlm_prepost_concat_train")
+    schema = tr.session_schema(int(d["meta/V"]) - 1, int(d["meta/L"]), (("category", 40), ("brand", 9)), ("price",))
+    inputs = tr.TabularSequenceFeatures.from_schema(
+        schema, max_sequence_length=int(d["meta/L"]), masking="mlm", aggregation="concat", d_output=32,
+        continuous_soft_embeddings=True, embedding_dims={"item_id": 16, "category": 24, "brand": 8},
+        pre=["stochastic-swap-noise"], post=[tr.TabularDropout(0.25), "layer-norm"])
+    keys = set(inputs.state_dict())
+    want = {k[len("heads.0.body.0."):] for k in gu.section(d, "p/") if k.startswith("heads.0.body.0.")}
+    assert want <= keys, sorted(want - keys)
+    assert isinstance(inputs.categorical_module.pre, tr.StochasticSwapNoise)
+    assert [type(m).__name__ for m in inputs.categorical_module.post] == ["TabularDropout", "TabularLayerNorm"]
+    with pytest.raises(ValueError, match="unsupported post transformation"):
+        tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=20, continuous_soft_embeddings=True, post="nope")
+    with pytest.raises(ValueError):
+        tr.TabularDropout(1.0)
+
+
+def test_constructor_and_build_errors_follow_the_reference():
+    import transformers4rec_amd as tr
+
+    schema = tr.session_schema(100, 20, (("category", 10),))
+    # element-wise aggregation needs equal dims (tabular/aggregation.py:140-157)
+    with pytest.raises(ValueError, match="same dimension"):
+        tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=20, aggregation="element-wise-sum",
+                                               embedding_dims={"item_id": 16, "category": 8})
+    # masking needs an item id (features/sequence.py:225-226)
+    no_item = tr.Schema([tr.ColumnSchema("category", [tr.Tags.CATEGORICAL, tr.Tags.LIST], tr.IntDomain(0, 10),
+                                         tr.ValueCount(1, 20))])
+    with pytest.raises(ValueError, match="item_id"):
+        tr.TabularSequenceFeatures.from_schema(no_item, max_sequence_length=20, masking="mlm")
+    inputs = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=20, masking="mlm", d_output=32)
+    assert inputs.aggregation == "concat" and tuple(inputs.output_size()) == (-1, 20, 32)
+    task = tr.NextItemPredictionTask()
+    with pytest.raises(ValueError, match="3-dim"):          # prediction_task.py:371-374
+        task.build(body=None, input_size=torch.Size([-1, 32]), inputs=inputs)
+    nomask = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=20, aggregation="concat")
+    with pytest.raises(ValueError, match="masking schema"):   # prediction_task.py:402-404
+        tr.NextItemPredictionTask().build(body=None, input_size=torch.Size([-1, 20, 72]), inputs=nomask)
+    with pytest.raises(NotImplementedError):
+        tr.NextItemPredictionTask(loss=torch.nn.MSELoss())
+    # the reference's masking / architecture rules (block/transformer.py:109-134)
+    cfg = tr.GPT2Config.build(32, 2, 1, total_seq_length=20)
+    with pytest.raises(ValueError, match="is not supported by"):
+        tr.TransformerBlock(cfg, masking=inputs.masking)
+
+
+def test_cpu_tensors_are_rejected_not_silently_computed():
+    """no CPU fallback: the product path refuses host tensors instead of computing on them"""
+    import transformers4rec_amd as tr
+    from transformers4rec_amd import ops
+
+    with pytest.raises(Exception) as e:
+        ops.gemm(torch.zeros(4, 4), torch.zeros(4, 4))
+    assert "cuda" in str(e.value).lower() or "device" in str(e.value).lower() or "hip" in str(e.value).lower()
+    schema = tr.session_schema(50, 8)
+    inputs = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=8, masking="mlm", embedding_dim_default=16)
+    with pytest.raises(Exception):
+        inputs({"item_id": torch.randint(1, 50, (2, 8))}, training=True)
+
+
+def test_recall_ndcg_oracle_against_reference_known_answers():
+    """ranking_metric known answers of the reference (tests/unit/torch/test_ranking_metrics.py:48-117 shape:
+    one relevant item per row) restated on tiny inputs"""
+    import t4r_oracle as O
+
+    scores = torch.tensor([[0.9, 0.1, 0.5, 0.3], [0.2, 0.8, 0.7, 0.1]])
+    labels = torch.tensor([2, 3])
+    assert O.recall_at_k(scores, labels, 2).tolist() == [1.0, 0.0]
+    assert O.recall_at_k(scores, labels, 4).tolist() == [1.0, 1.0]
+    nd = O.ndcg_at_k(scores, labels, 4)
+    assert abs(float(nd[0]) - 1 / np.log2(3)) < 1e-6 and abs(float(nd[1]) - 1 / np.log2(5)) < 1e-6

@@ -137,3 +137,21 @@ def test_recall_ndcg_oracle_against_reference_known_answers():
     assert O.recall_at_k(scores, labels, 4).tolist() == [1.0, 1.0]
     nd = O.ndcg_at_k(scores, labels, 4)
     assert abs(float(nd[0]) - 1 / np.log2(3)) < 1e-6 and abs(float(nd[1]) - 1 / np.log2(5)) < 1e-6
+
+
+def test_missing_library_fails_loudly():
+    """no silent fallback: with the shared library absent every op raises T4RHipError"""
+    import subprocess
+    import sys
+
+    code = ("import torch, transformers4rec_amd as tr\n"
+            "from transformers4rec_amd import ops, _lib\n"
+            "try:\n"
+            "    ops.gemm(torch.zeros(4, 4), torch.zeros(4, 4))\n"
+            "except _lib.T4RHipError as e:\n"
+            "    print('RAISED', 'no CPU fallback' in str(e).lower() or 'not found' in str(e).lower())\n")
+    import os
+    env = dict(os.environ, T4R_HIP_LIB="/nonexistent/libt4r_hip.so")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert "RAISED True" in out.stdout, out.stdout + out.stderr

@@ -117,8 +117,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     constexpr bool SG = (FEAT & 1) != 0, EDROP = (FEAT & 2) != 0, RANK = (FEAT & 4) != 0;
     constexpr int WM = BM / 64, WN = BN / 64;          // MFMA tiles per wave per dim
     constexpr bool A_MK = !TA, B_MK = TB;              // operand image is S[m][k] (k contiguous)
-    constexpr int LDA_S = A_MK ? BK + 4 : BM + 4;      // LDS row pitch (floats)
-    constexpr int LDB_S = B_MK ? BK + 4 : BN + 4;
+    // S[m][k] images: row pitch BK (no padding) with the 16-byte chunk index XOR-swizzled by the row,
+    // chunk' = chunk ^ ((row / (64/BK)) % (BK/4)).  A padded pitch cannot serve both sides: the
+    // 16-byte stage stores (8 lanes = 2 rows of 16 floats, banks mod 32) need the pitch = 16 mod 32,
+    // the ds_read_b128 fragment reads (16 lanes = 16 rows, banks mod 64) need pitch/4 odd; with
+    // pitch BK+4 rocprofv3 counted SQ_LDS_BANK_CONFLICT = 1/3 of SQ_LDS_IDX_ACTIVE on NT GEMMs.
+    // S[k][m] images keep the padded pitch BM+4 (conflict free for their access patterns).
+    constexpr int LDA_S = A_MK ? BK : BM + 4;          // LDS row pitch (floats)
+    constexpr int LDB_S = B_MK ? BK : BN + 4;
+    auto swz = [](int row, int chunk) { return (chunk ^ ((row / (64 / BK)) % (BK / 4))) * 4; };
     constexpr int A_SZ = A_MK ? BM * LDA_S : BK * LDA_S;   // floats per buffer
     constexpr int B_SZ = B_MK ? BN * LDB_S : BK * LDB_S;
     constexpr int KH = BK / 2;                         // k-slots per lane half
@@ -272,7 +279,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 *reinterpret_cast<float4*>(as + k * LDA_S + m4) = ra[r];
             } else {
                 const int m = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
-                *reinterpret_cast<float4*>(as + m * LDA_S + k4) = ra[r];
+                *reinterpret_cast<float4*>(as + m * LDA_S + swz(m, k4 / 4)) = ra[r];
             }
         }
 #pragma unroll
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 *reinterpret_cast<float4*>(bs + k * LDB_S + n4) = rb[r];
             } else {
                 const int n = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
-                *reinterpret_cast<float4*>(bs + n * LDB_S + k4) = rb[r];
+                *reinterpret_cast<float4*>(bs + n * LDB_S + swz(n, k4 / 4)) = rb[r];
             }
         }
     };
@@ -312,7 +319,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
             if (A_MK) {
-                fa[h][i] = *reinterpret_cast<const float4*>(as + (arow + i * 32) * LDA_S + khalf * KH + 4 * h);
+                fa[h][i] = *reinterpret_cast<const float4*>(as + (arow + i * 32) * LDA_S + swz(arow + i * 32, khalf * (KH / 4) + h));
             } else {
                 const float* q = as + (khalf * KH + 4 * h) * LDA_S + arow + i * 32;
                 fa[h][i] = make_float4(q[0], q[LDA_S], q[2 * LDA_S], q[3 * LDA_S]);
@@ -321,7 +328,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
             if (B_MK) {
-                fb[h][j] = *reinterpret_cast<const float4*>(bs + (bcol + j * 32) * LDB_S + khalf * KH + 4 * h);
+                fb[h][j] = *reinterpret_cast<const float4*>(bs + (bcol + j * 32) * LDB_S + swz(bcol + j * 32, khalf * (KH / 4) + h));
             } else {
                 const float* q = bs + (khalf * KH + 4 * h) * LDB_S + bcol + j * 32;
                 fb[h][j] = make_float4(q[0], q[LDB_S], q[2 * LDB_S], q[3 * LDB_S]);
@@ -466,7 +473,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 
 template <int BM, int BN, int BK, bool TA, bool TB, int FEAT, bool VEC>
 static int launch_vec(const GemmParams& p, int batch, hipStream_t stream) {
-    constexpr int A_SZ = !TA ? BM * (BK + 4) : BK * (BM + 4), B_SZ = TB ? BN * (BK + 4) : BK * (BN + 4);
+    constexpr int A_SZ = !TA ? BM * BK : BK * (BM + 4), B_SZ = TB ? BN * BK : BK * (BN + 4);
     static long pad = -1;   // experiment knob: extra LDS per workgroup = fewer resident workgroups per CU
     if (pad < 0) { const char* e = getenv("T4R_GEMM_LDS_PAD"); pad = e ? atol(e) : 0; }
     const size_t smem = (size_t)2 * (A_SZ + B_SZ) * sizeof(float) + (size_t)pad;

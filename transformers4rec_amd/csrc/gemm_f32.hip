@@ -12,17 +12,22 @@
 // 256-thread workgroup = 4 waves as 2(M) x 2(N); block tile BM x BN x BK, wave tile
 // (BM/2) x (BN/2) = WMxWN MFMA tiles of 32x32.  Each operand keeps in LDS the orientation it has
 // in HBM, so it is staged with plain 16-byte global loads and 16-byte LDS stores:
-//   k-contiguous operand (A of N?, B of ?T):  image S[m][k], row pitch BK+4 floats
+//   k-contiguous operand (A of N?, B of ?T):  image S[m][k], row pitch BK, 16-byte chunks
+//                                              XOR-swizzled by the row (bank-conflict free for
+//                                              the stage stores AND the fragment reads)
 //   m-contiguous operand (A of T?, B of ?N):  image S[k][m], row pitch BM+4 floats
 // The k-slots of the MFMA are permuted so that a lane reads CONTIGUOUS k from an S[m][k] image:
 // MFMA step s of a k-tile takes physical k = (lane>>5)*(BK/2) + s for both operands (any
 // bijection k <-> (step, half) is a valid contraction order).  A lane's fragments for four steps
-// are then one ds_read_b128 (conflict free: pitch/4 is odd) instead of four half-rate
-// ds_read_b32: LDS time per k-tile drops ~2x for NT GEMMs (logits, FF, projections), which were
-// LDS-bound -- a pure-MFMA loop reaches 156 TF on this chip (tools/mfma_peak.hip), the old
-// all-S[k][m] kernel 75 TF on the logits shape.  S[k][m] images are read with ds_read_b32.
-// Global loads for tile t+1 are issued before the MFMAs of tile t (register prefetch, 2 LDS
-// buffers, one barrier per k-tile).
+// are then one ds_read_b128 instead of four half-rate ds_read_b32.  S[k][m] images are read with
+// ds_read_b32.
+// Software pipeline, three stages deep (see the k-loop): the tile being multiplied has its MFMA
+// fragments in registers, the next one is moving from its register stage into LDS, the one after
+// that is in flight from memory; staging loads are branch-free (clamped addresses, k-tail zeroed
+// on the way to LDS).  Measured end of round 1 (tools/gemm_bench.py, uniform data): square 4096^3
+// 97-116 TF/s, head logits 84-91, head dW / dX 95-105, K = 128 layer GEMMs 40-75; a pure-MFMA loop
+// reaches 156 (tools/mfma_peak.hip); tools/gemm_ablate.hip shows where the difference goes
+// (global loads ~28 %, the logits' 1.1 GB epilogue ~20 %, data-dependent clocks ~20 %).
 // Split-K (gridDim.z) accumulates with hardware fp32 atomics into a zeroed / accumulating C:
 // this is how every weight gradient (K = tokens) and the head's dX (K = vocabulary) get
 // enough workgroups to fill 256 CUs.

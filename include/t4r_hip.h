@@ -245,9 +245,11 @@ int t4r_softmax_ce_bwd(void* stream, const float* logits, const long* labels, co
 int t4r_sampled_logits_fwd(void* stream, const float* x, const long* labels, const float* W,
                            const long* neg_samples, const float* sampling_dist, float* out, int N,
                            int D, int n_neg, float temperature);
-int t4r_sampled_logits_bwd(void* stream, const float* dlogits, const float* x, const long* labels,
-                           const float* W, const long* neg_samples, float* dx, float* dW, int N, int D,
-                           int n_neg, float temperature);
+/* dlogits is modified in place (accidental-hit entries zeroed: they carry no gradient);
+ * ws = 2 * n_neg * D floats of scratch (gathered negative rows of W and their gradient). */
+int t4r_sampled_logits_bwd(void* stream, float* dlogits, const float* x, const long* labels,
+                           const float* W, const long* neg_samples, float* dx, float* dW, float* ws, int N,
+                           int D, int n_neg, float temperature);
 int t4r_topk(void* stream, const float* scores, int N, int V, long ld, int k, float* out_val,
              long* out_idx);
 /* Fused eval head (replaces logits materialisation + torch.topk + the [N, V] one-hot of

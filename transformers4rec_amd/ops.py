@@ -465,10 +465,13 @@ def sampled_logits_fwd(x, labels, W, neg, dist, temperature=1.0):
 
 
 def sampled_logits_bwd(dlogits, x, labels, W, neg, dW, temperature=1.0):
+    """dlogits is modified in place (entries of accidental hits are zeroed)"""
     N, D = x.shape
     dx = torch.empty_like(x)
+    ws = torch.empty(2 * neg.numel() * D, device=x.device, dtype=torch.float32)
     call("t4r_sampled_logits_bwd", _stream(), _chk(dlogits), _chk(x), _chk(labels, torch.int64),
-         _chk(W), _chk(neg, torch.int64), dx.data_ptr(), _chk(dW), N, D, neg.numel(), float(temperature))
+         _chk(W), _chk(neg, torch.int64), dx.data_ptr(), _chk(dW), ws.data_ptr(), N, D, neg.numel(),
+         float(temperature))
     return dx
 
 

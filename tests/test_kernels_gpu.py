@@ -641,7 +641,9 @@ def test_gemm_softmax_grad_fused(ops, N, V, D, eps):
 
 # ------------------------------------------------------------------------------------ GPT-2 / BERT attention core
 @pytest.mark.parametrize("B,L,D,n,causal,p", [(4, 20, 64, 4, True, 0.0), (3, 50, 128, 2, True, 0.0), (2, 100, 128, 2, False, 0.0),
-                                              (3, 33, 64, 4, False, 0.1), (2, 21, 32, 2, True, 0.3), (2, 128, 32, 1, True, 0.0)])
+                                              (3, 33, 64, 4, False, 0.1), (2, 21, 32, 2, True, 0.3), (2, 128, 32, 1, True, 0.0),
+                                              (3, 33, 128, 4, False, 0.1), (2, 100, 512, 8, True, 0.2), (2, 65, 64, 2, False, 0.0),
+                                              (5, 7, 64, 1, True, 0.0), (2, 96, 128, 2, False, 0.3)])
 def test_mha_fwd_bwd(ops, B, L, D, n, causal, p):
     g = torch.Generator().manual_seed(B + L + D + int(causal))
     dh = D // n

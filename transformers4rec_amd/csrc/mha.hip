@@ -20,6 +20,15 @@
 
 #define MHA_PAD 4
 
+// mha_mfma.hip: matrix-core kernels for d_head 32 / 64
+bool t4r_mha_mfma_ok(int L, int d_head, long ld, long ld_out, long ld_d);
+int t4r_mha_mfma_fwd(hipStream_t st, const float* q, const float* k, const float* v, long ld, float* out,
+                     long ld_out, float* lse, int B, int L, int n_head, int d_head, float scale, int causal,
+                     DropCfg drop);
+int t4r_mha_mfma_bwd(hipStream_t st, const float* q, const float* k, const float* v, long ld, const float* out,
+                     const float* dout, long ld_out, const float* lse, float* dq, float* dk, float* dv, long ld_d,
+                     int B, int L, int n_head, int d_head, float scale, int causal, DropCfg drop);
+
 template <int DH>
 __global__ __launch_bounds__(128) void mha_fwd_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, long ld,
@@ -241,6 +250,8 @@ extern "C" int t4r_mha_fwd(void* stream, const float* q, const float* k, const f
     const float scale = 1.0f / sqrtf((float)d_head);
     const DropCfg dc = make_drop(drop_p, seed, ctr_hi);
     hipStream_t st = (hipStream_t)stream;
+    if (t4r_mha_mfma_ok(L, d_head, ld, ld_out, 0))
+        return t4r_mha_mfma_fwd(st, q, k, v, ld, out, ld_out, lse, B, L, n_head, d_head, scale, causal, dc);
     switch (d_head) {
         case 16: return mha_fwd_launch<16>(st, q, k, v, ld, out, ld_out, lse, B, L, n_head, scale, causal, dc);
         case 32: return mha_fwd_launch<32>(st, q, k, v, ld, out, ld_out, lse, B, L, n_head, scale, causal, dc);
@@ -260,6 +271,9 @@ extern "C" int t4r_mha_bwd(void* stream, const float* q, const float* k, const f
     const float scale = 1.0f / sqrtf((float)d_head);
     const DropCfg dc = make_drop(drop_p, seed, ctr_hi);
     hipStream_t st = (hipStream_t)stream;
+    if (t4r_mha_mfma_ok(L, d_head, ld, ld_out, ld_d))
+        return t4r_mha_mfma_bwd(st, q, k, v, ld, out, dout, ld_out, lse, dq, dk, dv, ld_d, B, L, n_head, d_head, scale,
+                                causal, dc);
     switch (d_head) {
         case 16: return mha_bwd_launch<16>(st, q, k, v, ld, out, dout, ld_out, lse, dq, dk, dv, ld_d, B, L, n_head, scale, causal, dc);
         case 32: return mha_bwd_launch<32>(st, q, k, v, ld, out, dout, ld_out, lse, dq, dk, dv, ld_d, B, L, n_head, scale, causal, dc);

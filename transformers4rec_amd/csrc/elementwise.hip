@@ -35,8 +35,10 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(
         if (c0 < D) {
             v[c] = *reinterpret_cast<const FV<VEC>*>(ar + c0);
             if (drop.p > 0.f) {
+                float msk[VEC];
+                drop_scale_vec<VEC>(drop, (unsigned long long)row * D + c0, (D & 3) == 0, msk);
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) v[c].v[e] *= drop_scale(drop, (unsigned long long)row * D + c0 + e);
+                for (int e = 0; e < VEC; ++e) v[c].v[e] *= msk[e];
             }
             if (br) {
                 const FV<VEC> t = *reinterpret_cast<const FV<VEC>*>(br + c0);
@@ -214,11 +216,9 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(
             if (c0 < D) {
                 FV<VEC> x = *reinterpret_cast<const FV<VEC>*>(ar + c0);
                 if (drop.p > 0.f) {
+                    drop_scale_vec<VEC>(drop, (unsigned long long)row * D + c0, (D & 3) == 0, ds[c].v);
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) {
-                        ds[c].v[e] = drop_scale(drop, (unsigned long long)row * D + c0 + e);
-                        x.v[e] *= ds[c].v[e];
-                    }
+                    for (int e = 0; e < VEC; ++e) x.v[e] *= ds[c].v[e];
                 }
                 if (br) {
                     const FV<VEC> t = *reinterpret_cast<const FV<VEC>*>(br + c0);

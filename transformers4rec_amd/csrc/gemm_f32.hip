@@ -436,24 +436,39 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 if (col >= p.N) continue;
                 const int row0 = m0 + wm * (BM / 2) + i * 32 + 4 * khalf;
                 float* c0 = C + (long)row0 * p.ldc + col;
+                float dm[16];
+                if (EDROP) {      // epilogue dropout masks of the fragment (N % 4 == 0: whole quads are in range together)
+                    if ((p.N & 3) == 0) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            float m4[4];
+                            drop_scale_quad(p.drop, (unsigned long long)(row0 + 8 * g), (unsigned long long)p.N, col, m4);
+                            dm[4 * g] = m4[0]; dm[4 * g + 1] = m4[1]; dm[4 * g + 2] = m4[2]; dm[4 * g + 3] = m4[3];
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            dm[r] = drop_scale(p.drop, (unsigned long long)(row0 + (r & 3) + 8 * (r >> 2)) * p.N + col);
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int dr = (r & 3) + 8 * (r >> 2);
                     if (!rows_full && row0 + dr >= p.M) continue;
-                    fn(c0 + (long)dr * p.ldc, row0 + dr, col, alpha * acc[i][j][r]);
+                    fn(c0 + (long)dr * p.ldc, row0 + dr, col, alpha * acc[i][j][r], EDROP ? dm[r] : 1.f);
                 }
             }
         }
     };
     if (p.splitk > 1) {
-        for_each_out([&](float* cp, int, int, float v) __attribute__((always_inline)) { atomicAdd(cp, v); });
+        for_each_out([&](float* cp, int, int, float v, float) __attribute__((always_inline)) { atomicAdd(cp, v); });
     } else if (p.epilogue == EPI_NONE) {
-        if (p.accumulate) for_each_out([&](float* cp, int, int, float v) __attribute__((always_inline)) { *cp += v; });
-        else for_each_out([&](float* cp, int, int, float v) __attribute__((always_inline)) { *cp = v; });
+        if (p.accumulate) for_each_out([&](float* cp, int, int, float v, float) __attribute__((always_inline)) { *cp += v; });
+        else for_each_out([&](float* cp, int, int, float v, float) __attribute__((always_inline)) { *cp = v; });
     } else {
         const int mode = p.epilogue;
         const bool acc_c = p.accumulate;
-        for_each_out([&](float* cp, int row, int col, float v) __attribute__((always_inline)) {
+        for_each_out([&](float* cp, int row, int col, float v, float dmask) __attribute__((always_inline)) {
             const float bv = p.bias ? p.bias[col] : 0.f;
             if (mode == EPI_BIAS) {
                 v += bv;
@@ -461,13 +476,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 v += bv;
                 if (p.aux) p.aux[(long)row * p.ldaux + col] = v;
                 v = gelu_erf(v);
-                if (EDROP) v *= drop_scale(p.drop, (unsigned long long)row * p.N + col);
+                if (EDROP) v *= dmask;
             } else if (mode == EPI_BIAS_RELU) {
                 v = fmaxf(v + bv, 0.f);
             } else if (mode == EPI_BIAS_RESID) {
                 // C = dropout(x + bias) + residual   (GPT-2: hidden + resid_dropout(c_proj(...)))
                 v += bv;
-                if (EDROP) v *= drop_scale(p.drop, (unsigned long long)row * p.N + col);
+                if (EDROP) v *= dmask;
                 v += p.aux[(long)row * p.ldaux + col];
             }
             if (acc_c) v += *cp;

@@ -94,14 +94,17 @@ __global__ __launch_bounds__(512) void mha_mfma_fwd_kernel(
             if (kh == 0 && i < L) lb[i] = m + __logf(sum);
             const unsigned long long mbase = ((unsigned long long)(b * n_head + h) * L + min(i, L - 1)) * L;
 #pragma unroll
-            for (int kj = 0; kj < 4; ++kj)
+            for (int kj = 0; kj < 4; ++kj) {
 #pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    const int j = kj * 32 + kh * 16 + t;
-                    float pv = s[kj].v[t] * inv;
-                    if (drop.p > 0.f && j < L && kj < nT) pv *= drop_scale(drop, mbase + j);
-                    s[kj].v[t] = pv;
+                for (int t = 0; t < 16; ++t) s[kj].v[t] *= inv;
+                if (drop.p > 0.f && kj < nT && !(causal && kj > qi)) {
+                    float msk[16];
+                    const int j0 = kj * 32 + kh * 16;
+                    drop_scale_run16(drop, mbase + j0, L - j0, (L & 3) == 0, msk);
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) s[kj].v[t] *= msk[t];
                 }
+            }
             __builtin_amdgcn_sched_barrier(0);
             // out_i = sum_j P~[i][j] v_j : A = row layout, B = column fragment of V (k = j)
 #pragma unroll
@@ -203,12 +206,17 @@ __global__ __launch_bounds__(512) void mha_mfma_bwd_kernel(
                 {
                     const float drow = Dr[ic];
                     const unsigned long long mbase = ((unsigned long long)(b * n_head + h) * L + ic) * L;
+                    float msk[16];
+                    if (drop.p > 0.f) {
+                        drop_scale_run16(drop, mbase + j0 + kh * 16, L - j0 - kh * 16, (L & 3) == 0, msk);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) msk[t] = 1.f;
+                    }
 #pragma unroll
                     for (int t = 0; t < 16; ++t) {
-                        const int j = j0 + kh * 16 + t;
-                        const float msk = (drop.p > 0.f && j < L) ? drop_scale(drop, mbase + j) : 1.f;
-                        const float dpm = Sm[c * XM_SP + kh * 16 + t] * msk;
-                        Pm[c * XM_SP + kh * 16 + t] = P.v[t] * msk;
+                        const float dpm = Sm[c * XM_SP + kh * 16 + t] * msk[t];
+                        Pm[c * XM_SP + kh * 16 + t] = P.v[t] * msk[t];
                         dS.v[t] = P.v[t] * (dpm - drow) * scale;
                     }
                 }

@@ -102,6 +102,60 @@ __device__ __forceinline__ float4 drop_scale4(const DropCfg& d, unsigned long lo
     return make_float4(u32_to_unit(r.x) >= d.p ? d.inv_keep : 0.f, u32_to_unit(r.y) >= d.p ? d.inv_keep : 0.f,
                        u32_to_unit(r.z) >= d.p ? d.inv_keep : 0.f, u32_to_unit(r.w) >= d.p ? d.inv_keep : 0.f);
 }
+// masks of the 16 consecutive elements idx0 .. idx0+15 of which the first n are needed (the rest get 1).
+// aligned (wave uniform; caller guarantees idx0 % 4 == 0 and n % 4 == 0): one Philox block per four
+// elements instead of one per element -- the block function is ~300 issue cycles per wave.
+__device__ __forceinline__ void drop_scale_run16(const DropCfg& d, unsigned long long idx0, int n, bool aligned,
+                                                 float (&m)[16]) {
+    if (aligned) {
+#pragma unroll
+        for (int t = 0; t < 16; t += 4) {
+            float4 f = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (t < n) f = drop_scale4(d, idx0 + t);
+            m[t] = f.x; m[t + 1] = f.y; m[t + 2] = f.z; m[t + 3] = f.w;
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) m[t] = t < n ? drop_scale(d, idx0 + t) : 1.f;
+    }
+}
+// masks of VEC (1, 2 or 4) consecutive elements starting at idx0; aligned (wave uniform): idx0 % VEC == 0
+// and the run does not straddle a Philox block, so one block serves the whole run
+template <int VEC>
+__device__ __forceinline__ void drop_scale_vec(const DropCfg& d, unsigned long long idx0, bool aligned, float (&m)[VEC]) {
+    if (VEC > 1 && aligned) {
+        const float4 f = drop_scale4(d, idx0 & ~3ull);
+        if (VEC == 4) { m[0] = f.x; m[VEC > 1 ? 1 : 0] = f.y; m[VEC > 2 ? 2 : 0] = f.z; m[VEC > 3 ? 3 : 0] = f.w; }
+        else { const bool hi = (idx0 & 2) != 0; m[0] = hi ? f.z : f.x; m[VEC > 1 ? 1 : 0] = hi ? f.w : f.y; }
+    } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) m[e] = drop_scale(d, idx0 + e);
+    }
+}
+// Masks for an MFMA accumulator fragment: a lane holds ONE column (col) of four consecutive rows
+// row_base .. row_base+3, and the four lanes of a quad hold the four columns of one Philox block
+// (row stride N % 4 == 0, col & ~3 aligned).  Lane q = col & 3 evaluates the block of row row_base + q
+// and the quad transposes the 4 x 4 words with DPP broadcasts: one block function per lane instead of
+// four.  All four lanes of the quad must be active.
+template <int K>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, K * 0x55, 0xf, 0xf, true);
+}
+__device__ __forceinline__ void drop_scale_quad(const DropCfg& d, unsigned long long row_base, unsigned long long N,
+                                                int col, float (&m)[4]) {
+    const int q = col & 3;
+    const Philox rng(d.seed);
+    const uint4 w = rng(((row_base + q) * N + (unsigned long long)(col & ~3)) >> 2, d.ctr_hi);
+#define T4R_QSEL(K)                                                                                      \
+    {                                                                                                    \
+        const uint32_t t0 = quad_bcast<K>(w.x), t1 = quad_bcast<K>(w.y), t2 = quad_bcast<K>(w.z),        \
+                       t3 = quad_bcast<K>(w.w);                                                          \
+        const uint32_t sel = q == 0 ? t0 : (q == 1 ? t1 : (q == 2 ? t2 : t3));                            \
+        m[K] = u32_to_unit(sel) >= d.p ? d.inv_keep : 0.f;                                               \
+    }
+    T4R_QSEL(0) T4R_QSEL(1) T4R_QSEL(2) T4R_QSEL(3)
+#undef T4R_QSEL
+}
 static inline DropCfg make_drop(float p, unsigned long long seed, unsigned long long ctr_hi) {
     DropCfg d;
     d.p = p; d.inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f; d.seed = seed; d.ctr_hi = ctr_hi;

@@ -114,11 +114,12 @@ __global__ __launch_bounds__(1024) void xlnet_attn_mfma_fwd_kernel(
         Frag<16> p;
         const unsigned long long mbase = ((unsigned long long)(b * n_head + h) * L + min(c, L - 1)) * L;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int j = kh * 16 + t;
-            float pv = s[t] * inv;
-            if (drop.p > 0.f && j < L) pv *= drop_scale(drop, mbase + j);
-            p.v[t] = pv;                      // 0 for j >= L (exp(-inf))
+        for (int t = 0; t < 16; ++t) p.v[t] = s[t] * inv;      // 0 for j >= L (exp(-inf))
+        if (drop.p > 0.f) {
+            float msk[16];
+            drop_scale_run16(drop, mbase + kh * 16, L - kh * 16, (L & 3) == 0, msk);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) p.v[t] *= msk[t];
         }
         __builtin_amdgcn_sched_barrier(0);
         // out = P~ V : A = row layout, B = column fragment of V (k = j)
@@ -199,13 +200,18 @@ __global__ __launch_bounds__(1024) void xlnet_attn_mfma_bwd_kernel(
         {
             const unsigned long long mbase = ((unsigned long long)(b * n_head + h) * L + ic) * L;
             float drow = 0.f;
-            float dpm[16];
+            float dpm[16], msk[16];
+            if (drop.p > 0.f) {
+                drop_scale_run16(drop, mbase + kh * 16, L - kh * 16, (L & 3) == 0, msk);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) msk[t] = 1.f;
+            }
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const int j = kh * 16 + t;
-                const float msk = (drop.p > 0.f && j < L) ? drop_scale(drop, mbase + j) : 1.f;
-                dpm[t] = Sm[c * XM_SP + j] * msk;
-                Pm[c * XM_SP + j] = P.v[t] * msk;
+                dpm[t] = Sm[c * XM_SP + j] * msk[t];
+                Pm[c * XM_SP + j] = P.v[t] * msk[t];
                 drow += P.v[t] * dpm[t];
             }
             drow += __shfl_xor(drow, 32, 64);

@@ -26,35 +26,74 @@
 
 #include "mfma_frag.h"
 
+// Register budgets (launch bound / 64 threads launched): the backward keeps 17 KB of LDS per wave, so at
+// most 9 waves fit a CU anyway; 512 (<= 256 VGPRs, 146 used) measured 67 us vs 80 us at 1024 (<= 128
+// VGPRs), 69 us without the phase fences, 66-76 us at 256 (C2 shape, tools/attn_bench.py).
+// With the operand fragments requested one phase ahead: forward 21.0 us at 512 (167 VGPRs, was 26.2 us
+// at 1024 with loads at their uses), backward 60 us at 512 (213 VGPRs; 256 gives 60 / 72 us for
+// per-session / shared k_r).
+#ifndef T4R_ATTN_BWD_BOUNDS
+#define T4R_ATTN_BWD_BOUNDS 512
+#endif
+#ifndef T4R_ATTN_FWD_BOUNDS
+#define T4R_ATTN_FWD_BOUNDS 512
+#endif
+#ifndef T4R_ATTN_FWD_FENCE
+#define T4R_ATTN_FWD_FENCE 1
+#endif
+#ifndef T4R_ATTN_FENCE
+#define T4R_ATTN_FENCE 1
+#endif
+#if T4R_ATTN_FENCE
+#define ATTN_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define ATTN_PHASE_FENCE()
+#endif
+
 // scores of one (session, head) in ROW LAYOUT: lane (i = c, kh) gets s[t] = (ac + bd)[i][kh*16 + t] * scale
 // (garbage where i >= L or j >= L: the caller masks).  Uses Sm [32][XM_SP] and Rm [32][XM_RP].
+// The operand fragments are loaded by the caller, all at once at the top of a session (with the operands
+// of its later phases): the wave then pays the memory latency once instead of once per contraction.
 template <int DH>
-__device__ __forceinline__ void scores_row_layout(const float* qb, const float* kb, const float* krb, int D,
-                                                  int hc, int L, const Frag<DH / 2>& rw,
+struct ScoreFrags { Frag<DH / 2> q, k, kr0, kr1; };
+template <int DH>
+__device__ __forceinline__ ScoreFrags<DH> load_score_frags(const float* qb, const float* kb, const float* krb, int D,
+                                                           int hc, int L, int c, int kh) {
+    ScoreFrags<DH> f;
+    const int roff = min(c, L - 1) * D + hc + kh * (DH / 2);
+    f.q = row_frag<DH>(qb, roff);
+    f.k = row_frag<DH>(kb, roff);                                                   // B: lane column j = c
+    f.kr0 = row_frag<DH>(krb, min(c, 2 * L - 1) * D + hc + kh * (DH / 2));          // B: lane column m = c
+    f.kr1 = row_frag<DH>(krb, min(c + 32, 2 * L - 1) * D + hc + kh * (DH / 2));     //               m = c + 32
+    return f;
+}
+template <int DH>
+__device__ __forceinline__ void scores_row_layout(const ScoreFrags<DH>& f, int L, const Frag<DH / 2>& rw,
                                                   const Frag<DH / 2>& del, float scale, float* Sm, float* Rm,
                                                   int c, int kh, float (&s)[16]) {
     const int ic = min(c, L - 1);
-    const int roff = ic * D + hc + kh * (DH / 2);
-    Frag<DH / 2> qw = row_frag<DH>(qb, roff);
+    Frag<DH / 2> qw = f.q;
 #pragma unroll
     for (int t = 0; t < DH / 2; ++t) qw.v[t] += rw.v[t];
     {
-        const Frag<DH / 2> kf = row_frag<DH>(kb, roff);                        // B: lane column j = c
         f32x16 ac = zero16();
-        mfma_chain(ac, qw, kf);
+        mfma_chain(ac, qw, f.k);
 #pragma unroll
         for (int r = 0; r < 16; ++r) Sm[xm_row(r, kh) * XM_SP + c] = ac[r];
     }
 #pragma unroll
     for (int t = 0; t < DH / 2; ++t) qw.v[t] += del.v[t];                       // q + r_r_bias
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int m = min(c + 32 * half, 2 * L - 1);
-        const Frag<DH / 2> krf = row_frag<DH>(krb, m * D + hc + kh * (DH / 2));      // B: lane column m
+    {
         f32x16 raw = zero16();
-        mfma_chain(raw, qw, krf);
+        mfma_chain(raw, qw, f.kr0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Rm[xm_row(r, kh) * XM_RP + c + 32 * half] = raw[r];
+        for (int r = 0; r < 16; ++r) Rm[xm_row(r, kh) * XM_RP + c] = raw[r];
+    }
+    {
+        f32x16 raw = zero16();
+        mfma_chain(raw, qw, f.kr1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Rm[xm_row(r, kh) * XM_RP + c + 32] = raw[r];
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes are done (single-wave workgroup)
     __builtin_amdgcn_wave_barrier();
@@ -70,7 +109,7 @@ __device__ __forceinline__ void scores_row_layout(const float* qb, const float* 
 // ------------------------------------------------------------------------------------------ forward
 template <int DH>
 // launch bound 1024 although 64 threads are launched: it caps the register budget at 128 (4 waves/SIMD)
-__global__ __launch_bounds__(1024) void xlnet_attn_mfma_fwd_kernel(
+__global__ __launch_bounds__(T4R_ATTN_FWD_BOUNDS) void xlnet_attn_mfma_fwd_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const float* __restrict__ kr, const float* __restrict__ r_w_bias, const float* __restrict__ r_r_bias,
     float* __restrict__ out, float* __restrict__ lse, int B, int L, int n_head, float scale, long kr_bstride,
@@ -95,8 +134,11 @@ __global__ __launch_bounds__(1024) void xlnet_attn_mfma_fwd_kernel(
         const float* kb = k + tok0 * D;
         const float* vb = v + tok0 * D;
         float* ob = out + tok0 * D;
+        const ScoreFrags<DH> sf = load_score_frags<DH>(qb, kb, kr + (long)b * kr_bstride, D, hc, L, c, kh);
+        const Frag<16> vf = col_frag<16>(vb, hc + min(c, DH - 1), D, L, kh, 0.f);    // for P~ V, in flight early
+        __builtin_amdgcn_sched_barrier(0);    // the loads are issued here; the waits sit at the uses
         float s[16];
-        scores_row_layout<DH>(qb, kb, kr + (long)b * kr_bstride, D, hc, L, rw, del, scale, Sm, Rm, c, kh, s);
+        scores_row_layout<DH>(sf, L, rw, del, scale, Sm, Rm, c, kh, s);
         // softmax over j of row i = c (two lanes per row, 16 columns each)
         float m = -INFINITY;
 #pragma unroll
@@ -121,10 +163,10 @@ __global__ __launch_bounds__(1024) void xlnet_attn_mfma_fwd_kernel(
 #pragma unroll
             for (int t = 0; t < 16; ++t) p.v[t] *= msk[t];
         }
+#if T4R_ATTN_FWD_FENCE
         __builtin_amdgcn_sched_barrier(0);
+#endif
         // out = P~ V : A = row layout, B = column fragment of V (k = j)
-        const int dc = min(c, DH - 1);
-        const Frag<16> vf = col_frag<16>(vb, hc + dc, D, L, kh, 0.f);
         f32x16 o = zero16();
         mfma_chain(o, p, vf);
         if (c < DH) {
@@ -141,7 +183,7 @@ __global__ __launch_bounds__(1024) void xlnet_attn_mfma_fwd_kernel(
 // part: row blockIdx.x of [gridDim.x][2L*D + 2D]: d k_r (shared k_r only) | d r_w_bias | d r_r_bias,
 // this head's columns (same layout the VALU kernels use; reduced by t4r_reduce_partials_launch).
 template <int DH, bool SHARED_KR>
-__global__ __launch_bounds__(1024) void xlnet_attn_mfma_bwd_kernel(
+__global__ __launch_bounds__(T4R_ATTN_BWD_BOUNDS) void xlnet_attn_mfma_bwd_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const float* __restrict__ kr, const float* __restrict__ r_w_bias, const float* __restrict__ r_r_bias,
     const float* __restrict__ lse, const float* __restrict__ dout, float* __restrict__ dq,
@@ -178,17 +220,26 @@ __global__ __launch_bounds__(1024) void xlnet_attn_mfma_bwd_kernel(
         const int ic = min(c, L - 1);
         const int roff = ic * D + hc + kh * (DH / 2);
         const bool row_ok = c < L;
+        const ScoreFrags<DH> sf = load_score_frags<DH>(qb, kb, krb, D, hc, L, c, kh);
+        const Frag<DH / 2> dof = row_frag<DH>(gb, roff);                 // operands of dP = dO V^T, in flight early
+        const Frag<DH / 2> vf = row_frag<DH>(vb, roff);                  // lane column j = c
+        const Frag<16> kcol = col_frag<16>(kb, hc + dc, D, L, kh, 0.f);  // for d q = dS K
+        __builtin_amdgcn_sched_barrier(0);    // the loads are issued here; the waits sit at the uses
         float s[16];
-        scores_row_layout<DH>(qb, kb, krb, D, hc, L, rw, del, scale, Sm, Rm, c, kh, s);
+        scores_row_layout<DH>(sf, L, rw, del, scale, Sm, Rm, c, kh, s);
         const float lrow = lse[((long)b * n_head + h) * L + ic];
         Frag<16> P;
 #pragma unroll
         for (int t = 0; t < 16; ++t) P.v[t] = (row_ok && kh * 16 + t < L) ? __expf(s[t] - lrow) : 0.f;
-        __builtin_amdgcn_sched_barrier(0);   // phase fence: keeps later phases' operand loads out of this one
+        ATTN_PHASE_FENCE();   // keeps later phases' operand loads out of this one
+        // (operands of the NEXT phase are requested at the start of each phase: the fences keep them here)
+        Frag<16> krc[2];          // k_r column fragments for d q += d raw K_r : k = m = kh*32 + 16u + t
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) krc[u].v[t] = krb[min(kh * 32 + 16 * u + t, 2 * L - 1) * D + hc + dc];
         // dP = dO V^T (accumulator layout) -> row layout through Sm
         {
-            const Frag<DH / 2> dof = row_frag<DH>(gb, roff);
-            const Frag<DH / 2> vf = row_frag<DH>(vb, roff);                            // lane column j = c
             f32x16 dp = zero16();
             mfma_chain(dp, dof, vf);
 #pragma unroll
@@ -219,7 +270,7 @@ __global__ __launch_bounds__(1024) void xlnet_attn_mfma_bwd_kernel(
             for (int t = 0; t < 16; ++t) dS.v[t] = P.v[t] * (dpm[t] - drow) * scale;
         }
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_sched_barrier(0);   // phase fence: keeps later phases' operand loads out of this one
+        ATTN_PHASE_FENCE();   // keeps later phases' operand loads out of this one
         // d raw[i][j + L - i] = dS[i][j]  (rel_shift transposed), zero elsewhere
         for (int idx = lane; idx < 32 * XM_RP / 4; idx += 64)
             reinterpret_cast<float4*>(Rm)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -237,22 +288,18 @@ __global__ __launch_bounds__(1024) void xlnet_attn_mfma_bwd_kernel(
         for (int t = 0; t < 16; ++t) Sm[c * XM_SP + kh * 16 + t] = dS.v[t];
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_sched_barrier(0);   // phase fence: keeps later phases' operand loads out of this one
+        ATTN_PHASE_FENCE();   // keeps later phases' operand loads out of this one
         // d q = dS K + d raw K_r
+        const Frag<16> qcol = col_frag<16>(qb, hc + dc, D, L, kh, 0.f);     // for d k, d k_r (next phases)
         f32x16 dqa = zero16(), dqb = zero16();
         {
-            const Frag<16> kf = col_frag<16>(kb, hc + dc, D, L, kh, 0.f);
-            mfma_chain(dqa, dS, kf);
+            mfma_chain(dqa, dS, kcol);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {       // contraction over m (64): k = kh*32 + 16u + t
-                Frag<16> dr, krf;
+                Frag<16> dr;
 #pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    const int m = kh * 32 + 16 * u + t;
-                    dr.v[t] = Rm[c * XM_RP + m];
-                    krf.v[t] = krb[min(m, 2 * L - 1) * D + hc + dc];
-                }
-                mfma_chain(dqb, dr, krf);
+                for (int t = 0; t < 16; ++t) dr.v[t] = Rm[c * XM_RP + kh * 32 + 16 * u + t];
+                mfma_chain(dqb, dr, krc[u]);
             }
         }
         {
@@ -266,13 +313,16 @@ __global__ __launch_bounds__(1024) void xlnet_attn_mfma_bwd_kernel(
             sa += __shfl_xor(sa, 32, 64); sb += __shfl_xor(sb, 32, 64);
             acc_rw += sa; acc_rr += sb;
         }
-        __builtin_amdgcn_sched_barrier(0);   // phase fence: keeps later phases' operand loads out of this one
+        ATTN_PHASE_FENCE();   // keeps later phases' operand loads out of this one
         // d k = dS^T (q + r_w_bias) : A = dS^T read by columns from Sm, B = column fragment of q
+        const Frag<16> gcol = col_frag<16>(gb, hc + dc, D, L, kh, 0.f);     // for d v (last phase)
         {
             Frag<16> at;
 #pragma unroll
             for (int t = 0; t < 16; ++t) at.v[t] = Sm[(kh * 16 + t) * XM_SP + c];
-            const Frag<16> qf = col_frag<16>(qb, hc + dc, D, L, kh, rw_c);
+            Frag<16> qf;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) qf.v[t] = qcol.v[t] + rw_c;
             f32x16 g = zero16();
             mfma_chain(g, at, qf);
             if (c < DH) {
@@ -283,10 +333,12 @@ __global__ __launch_bounds__(1024) void xlnet_attn_mfma_bwd_kernel(
                 }
             }
         }
-        __builtin_amdgcn_sched_barrier(0);   // phase fence: keeps later phases' operand loads out of this one
+        ATTN_PHASE_FENCE();   // keeps later phases' operand loads out of this one
         // d k_r = d raw^T (q + r_r_bias) : two 32-row tiles (m = c, c + 32)
         {
-            const Frag<16> qf = col_frag<16>(qb, hc + dc, D, L, kh, rr_c);
+            Frag<16> qf;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) qf.v[t] = qcol.v[t] + rr_c;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 Frag<16> at;
@@ -309,15 +361,14 @@ __global__ __launch_bounds__(1024) void xlnet_attn_mfma_bwd_kernel(
                 }
             }
         }
-        __builtin_amdgcn_sched_barrier(0);   // phase fence: keeps later phases' operand loads out of this one
+        ATTN_PHASE_FENCE();   // keeps later phases' operand loads out of this one
         // d v = P~^T dO : P~ was parked by rows in Pm, read by columns
         {
             Frag<16> at;
 #pragma unroll
             for (int t = 0; t < 16; ++t) at.v[t] = Pm[(kh * 16 + t) * XM_SP + c];
-            const Frag<16> gf = col_frag<16>(gb, hc + dc, D, L, kh, 0.f);
             f32x16 g = zero16();
-            mfma_chain(g, at, gf);
+            mfma_chain(g, at, gcol);
             if (c < DH) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {

@@ -161,11 +161,28 @@ __global__ __launch_bounds__(512) void reduce_partials_kernel(const float* __res
     }
 }
 
+// Second-stage redirect (installed by the XLNet layer backward for the duration of one call): the
+// second stages feed parameter gradients only, so they can leave the critical chain and run on the
+// weight-gradient stream.  Each redirected launch is ordered after the first stage by its own event;
+// the installer owns the partial buffers (one per site) and joins the streams before they are reused.
+static thread_local hipStream_t g_red_side = nullptr;
+static thread_local hipEvent_t* g_red_events = nullptr;
+static thread_local int g_red_n = 0, g_red_used = 0;
+void t4r_reduce_redirect(hipStream_t side, hipEvent_t* events, int n_events) {
+    g_red_side = side; g_red_events = events; g_red_n = side ? n_events : 0; g_red_used = 0;
+}
+
 int t4r_reduce_partials_launch(hipStream_t st, const float* part, int nblocks, float* o0, int n0, int a0,
                                float* o1, int n1, int a1, float* o2, int n2, int a2) {
     const int n = n0 + n1 + n2;
     if (n <= 0 || nblocks <= 0) return 0;
     ReduceSeg s0{o0, n0, a0}, s1{o1, n1, a1}, s2{o2, n2, a2};
+    if (g_red_side && g_red_used < g_red_n) {
+        hipEvent_t ev = g_red_events[g_red_used++];
+        (void)hipEventRecord(ev, st);
+        (void)hipStreamWaitEvent(g_red_side, ev, 0);
+        st = g_red_side;
+    }
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 15) / 16), dim3(512), 0, st, part, nblocks, n,
                        s0, s1, s2);
     T4R_LAUNCH_CHECK();

@@ -30,6 +30,9 @@ int t4r_act_bwd_bias(void*, const float*, const float*, float*, float*, float*, 
                      unsigned long long, unsigned long long);
 int t4r_colsum(void*, const float*, float*, float*, long, int, long);
 long t4r_colreduce_ws_floats(long, int);
+}
+void t4r_reduce_redirect(hipStream_t side, hipEvent_t* events, int n_events);   // elementwise.hip
+extern "C" {
 int t4r_dropout(void*, const float*, float*, unsigned char*, long, long, float, unsigned long long,
                 unsigned long long);
 int t4r_xlnet_attn_fwd(void*, const float*, const float*, const float*, const float*, const float*,
@@ -102,6 +105,7 @@ extern "C" long t4r_xlnet_layer_bwd_ws_floats(int B, int L, int D, int n_head, i
     const long nkr = (dropout ? (long)B : 1L) * 2L * L * D;
     return align4(3 * T * D) + align4(T * D) + align4(T * D) + align4(T * 4 * D) + align4(nkr) +
            align4(t4r_xlnet_attn_bwd_ws_floats(B, L, D, n_head)) + align4(t4r_colreduce_ws_floats(T, 4 * D)) +
+           2 * align4(t4r_colreduce_ws_floats(T, 2 * D)) + align4(t4r_colreduce_ws_floats(T, D)) +
            (dropout ? align4(T * D) : 0);
 }
 
@@ -174,7 +178,7 @@ extern "C" int t4r_xlnet_layer_fwd(void* stream, const float* h, const float* po
 // T4R_LAYER_SIDE_STREAM=0 keeps everything on one stream.
 struct SideStream {
     hipStream_t s = nullptr;
-    hipEvent_t fork[6] = {}, done_ff2 = nullptr, done_o = nullptr, done_all = nullptr;
+    hipEvent_t fork[6] = {}, red[8] = {}, done_ff2 = nullptr, done_o = nullptr, done_all = nullptr;
     int state = 0;    // 0 untried, 1 ready, -1 disabled / failed
 };
 static thread_local SideStream g_side;
@@ -192,6 +196,7 @@ static SideStream* side_stream() {
             const int prio = pe ? atoi(pe) : lo;
             bool ok = hipStreamCreateWithPriority(&ss.s, hipStreamNonBlocking, prio) == hipSuccess;
             for (int i = 0; ok && i < 6; ++i) ok = hipEventCreateWithFlags(&ss.fork[i], hipEventDisableTiming) == hipSuccess;
+            for (int i = 0; ok && i < 8; ++i) ok = hipEventCreateWithFlags(&ss.red[i], hipEventDisableTiming) == hipSuccess;
             ok = ok && hipEventCreateWithFlags(&ss.done_ff2, hipEventDisableTiming) == hipSuccess;
             ok = ok && hipEventCreateWithFlags(&ss.done_o, hipEventDisableTiming) == hipSuccess;
             ok = ok && hipEventCreateWithFlags(&ss.done_all, hipEventDisableTiming) == hipSuccess;
@@ -224,10 +229,23 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
     float* dff = take(4 * TD);
     float* dkr = take(nkr);
     float* attn_ws = take(t4r_xlnet_attn_bwd_ws_floats(B, L, D, n_head));
-    float* red_ws = take(t4r_colreduce_ws_floats(T, 4 * D));
+    // one partial buffer per column-reduction site: their second stages run on the side stream, possibly
+    // after the next site's first stage
+    float* red_act = take(t4r_colreduce_ws_floats(T, 4 * D));
+    float* red_ln2 = take(t4r_colreduce_ws_floats(T, 2 * D));
+    float* red_ln1 = take(t4r_colreduce_ws_floats(T, 2 * D));
+    float* red_b2 = take(t4r_colreduce_ws_floats(T, D));
     float* dxa = drop ? take(TD) : nullptr;     // gradient of a dropped LayerNorm operand
 
     SideStream* ss = side_stream();
+    struct RedirectGuard {      // second stages of the column reductions -> side stream, for this call only
+        bool on;
+        RedirectGuard(SideStream* s) : on(false) {
+            static const int enabled = [] { const char* e = getenv("T4R_LAYER_SIDE_REDUCE"); return e ? atoi(e) : 1; }();
+            if (s && enabled) { t4r_reduce_redirect(s->s, s->red, 8); on = true; }
+        }
+        ~RedirectGuard() { if (on) t4r_reduce_redirect(nullptr, nullptr, 0); }
+    } redirect(ss);
     int n_fork = 0;
     // wg(): the stream a weight-gradient GEMM goes to; it first waits for everything issued on `st` so far
     auto wg = [&]() -> hipStream_t {
@@ -240,17 +258,17 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
 
     // LN2: y = LN(drop(ffout) + h1): dx = d h1 (residual part), d ffout = dxa (or dx when p = 0)
     RUN(t4r_add_layernorm_bwd(stream, w.ffout, w.h1, params[P_LN2W], w.mean2, w.rstd2, dh_out, dx, dxa,
-                              grads[P_LN2W], grads[P_LN2B], red_ws, T, D, 0, drop_p, seed, C(SITE_FF_OUT)));
+                              grads[P_LN2W], grads[P_LN2B], red_ln2, T, D, 0, drop_p, seed, C(SITE_FF_OUT)));
     const float* dffout = drop ? dxa : dx;
     // FF2: ffout = ffact @ w2^T + b2
     RUN(t4r_gemm_launch(st, 0, 0, T, 4 * D, D, 1.f, dffout, D, params[P_W2], 4 * D, dff, 4 * D, nullptr,
                         EPI_NONE, nullptr, 0, 1, 0, 1, 0, 0, 0, nullptr));
-    RUN(t4r_colsum(stream, dffout, grads[P_B2], red_ws, T, D, D));
+    RUN(t4r_colsum(stream, dffout, grads[P_B2], red_b2, T, D, D));
     RUN(t4r_gemm_launch(wg(), 1, 0, D, 4 * D, T, 1.f, dffout, D, w.ffact, 4 * D, grads[P_W2], 4 * D, nullptr,
                         EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
     if (ss) (void)hipEventRecord(ss->done_ff2, ss->s);
     // ffact = drop(gelu(ffpre)) ; GELU' + bias1
-    RUN(t4r_act_bwd_bias(stream, dff, w.ffpre, dff, grads[P_B1], red_ws, T, 4 * D, 0, drop_p, seed,
+    RUN(t4r_act_bwd_bias(stream, dff, w.ffpre, dff, grads[P_B1], red_act, T, 4 * D, 0, drop_p, seed,
                          C(SITE_FF_ACT)));
     // FF1: ffpre = h1 @ w1^T + b1 ;  d h1 = dx (residual) + dff @ w1
     if (ss && !drop) (void)hipStreamWaitEvent(st, ss->done_ff2, 0);   // p = 0: the FF2 wgrad reads dx, written next
@@ -261,7 +279,7 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
     // LN1: h1 = LN(drop(ao) + h): dh_in = d h (residual part), d ao = dxa (or dh_in when p = 0)
     if (ss && drop) (void)hipStreamWaitEvent(st, ss->done_ff2, 0);    // the FF2 wgrad reads dxa, overwritten here
     RUN(t4r_add_layernorm_bwd(stream, w.ao, h, params[P_LN1W], w.mean1, w.rstd1, dx, dh_in, dxa,
-                              grads[P_LN1W], grads[P_LN1B], red_ws, T, D, 0, drop_p, seed, C(SITE_ATTN_OUT)));
+                              grads[P_LN1W], grads[P_LN1B], red_ln1, T, D, 0, drop_p, seed, C(SITE_ATTN_OUT)));
     const float* dao = drop ? dxa : dh_in;
     // O projection: ao = av @ o^T
     RUN(t4r_gemm_launch(st, 0, 0, T, D, D, 1.f, dao, D, params[P_O], D, dav, D, nullptr, EPI_NONE,

@@ -31,9 +31,13 @@ def _p(t, dtype=None, name="tensor"):
     return None if t is None else _chk(t, dtype, name)
 
 
+_LD_ALIGN = int(__import__("os").environ.get("T4R_LOGITS_LD_ALIGN", "64"))
+
+
 def pad_ld(V):
-    """leading dimension used for [N, V] logits: rows stay 16-byte aligned"""
-    return (V + 3) // 4 * 4
+    """leading dimension used for [N, V] logits: rows start on a 256-byte boundary, so the 128-byte
+    row segments the GEMM epilogue stores (and the CE / backward kernels read) never straddle a cache line"""
+    return (V + _LD_ALIGN - 1) // _LD_ALIGN * _LD_ALIGN
 
 
 # ------------------------------------------------------------------------------------ GEMM

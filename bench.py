@@ -244,7 +244,7 @@ def main():
     # on a known copy; collected in separate rocprofv3 --pmc passes and committed under profiles/).
     # It is a property of the kernel + shape, not of this run: taken from the committed measurement.
     traffic, traffic_src = None, None
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_e_pmc_traffic.json")
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_g_pmc_traffic.json")
     if os.path.exists(tpath):
         with open(tpath) as f:
             tj = json.load(f)
@@ -263,7 +263,7 @@ def main():
                                    "tied-weight full softmax, Adam, fwd+bwd+allreduce+optimizer per step",
                        "global_batch": BATCH * world, "seq_len": SEQ, "parallelism": f"dp{world}",
                        "dropout": args.dropout, "label_rows_per_step": N_m, "final_loss": round(loss, 4)},
-            "roofline": {"kernel": "gemm_f32_kernel<64,64,16,NT> (next-item logits X@W^T)", "bound": "mfma",
+            "roofline": {"kernel": "gemm_f32_kernel<128,128,16,NT> (next-item logits X@W^T)", "bound": "mfma",
                          "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "bytes/launch", "traffic_source": traffic_src,

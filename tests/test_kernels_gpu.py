@@ -76,7 +76,7 @@ def test_gemm_epilogues_splitk_accumulate(ops):
     # padded leading dimension of C and unaligned K (logits-like: N odd)
     X, Wv = torch.randn(37, 64, generator=g), torch.randn(1001, 64, generator=g)
     out = ops.gemm(cu(X), cu(Wv), False, True, alpha=1 / 0.7, ldc=ops.pad_ld(1001))
-    assert out.stride(0) == 1004
+    assert out.stride(0) == ops.pad_ld(1001) and out.stride(0) % 64 == 0 and out.stride(0) >= 1001
     close(out, (X @ Wv.t()) / 0.7, atol=1e-4)
     # K not a multiple of 4 with a k-contiguous operand and padded lda (head dX shape)
     dl = torch.zeros(37, 1004)

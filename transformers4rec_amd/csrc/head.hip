@@ -19,6 +19,9 @@ __device__ __forceinline__ void online_merge(float& m, float& s, float m2, float
     m = mn;
 }
 
+#ifndef T4R_CE_UNROLL
+#define T4R_CE_UNROLL 4
+#endif
 // loss_row[i] = lse_i - (1-eps)*logit[i,y_i] - eps/V * sum_j logit[i,j]   (eps = label smoothing)
 __global__ __launch_bounds__(256) void softmax_ce_fwd_kernel(const float* __restrict__ logits,
                                                               const long* __restrict__ labels,
@@ -32,6 +35,24 @@ __global__ __launch_bounds__(256) void softmax_ce_fwd_kernel(const float* __rest
     if (vec) {
         const int v4 = V / 4;
         int i = threadIdx.x;
+#if T4R_CE_UNROLL == 4
+        for (; i + 768 < v4; i += 1024) {     // four 16-byte loads in flight per thread, one rescale per 16 elements
+            float4 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const float4*>(x + 4 * (i + 256 * u));
+            float mx = m;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) mx = fmaxf(mx, fmaxf(fmaxf(t[u].x, t[u].y), fmaxf(t[u].z, t[u].w)));
+            float e = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                e += (__expf(t[u].x - mx) + __expf(t[u].y - mx)) + (__expf(t[u].z - mx) + __expf(t[u].w - mx));
+                tot += (t[u].x + t[u].y) + (t[u].z + t[u].w);
+            }
+            s = s * __expf(m - mx) + e;
+            m = mx;
+        }
+#endif
         for (; i + 256 < v4; i += 512) {      // two 16-byte loads in flight per thread
             const float4 t = *reinterpret_cast<const float4*>(x + 4 * i);
             const float4 u = *reinterpret_cast<const float4*>(x + 4 * (i + 256));

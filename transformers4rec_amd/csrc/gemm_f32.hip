@@ -543,9 +543,10 @@ template <bool TA, bool TB>
 static int launch_layout(GemmParams& p, int batch, int splitk_req, hipStream_t stream) {
     // tile choice: prefer 128x128; drop to 64-wide tiles when the grid would not fill 256 CUs
     auto nblk = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * batch; };
-    // Measured on MI355X (tools/gemm_bench.py, profiles/r01_b_gemm_tile_sweep.txt): on every shape
-    // of this path the 64x64x16 tile (8 waves/SIMD resident) beats the 128-wide tiles -- the
-    // kernel is latency- not LDS-bound, so more workgroups in flight win (head dW 47 -> 79 TF/s).
+    // Measured on MI355X (tools/gemm_bench.py, profiles/r01_b_gemm_tile_sweep.txt): on the layer shapes
+    // and the head's backward products the 64x64x16 tile (7-8 waves/SIMD resident) beats the 128-wide
+    // tiles -- latency- not LDS-bound, more workgroups in flight win (head dW 47 -> 79 TF/s).  The one
+    // exception is chosen by shape below.
     int bm = 64, bn = 64;
     static int tile_sel = -1;
     if (tile_sel < 0) { const char* e = getenv("T4R_GEMM_TILE"); tile_sel = e ? atoi(e) : 0; }

@@ -107,8 +107,8 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16x6(const float* __restrict__ 
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    bf16x8 fa[2][3], fb[2][3];      // fragments of the tile being multiplied
-    auto read_frags = [&](int buf) __attribute__((always_inline)) {
+    auto multiply = [&](int buf) __attribute__((always_inline)) {
+        bf16x8 fa[2][3], fb[2][3];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
@@ -121,8 +121,6 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16x6(const float* __restrict__ 
                 fa[i][pl] = *reinterpret_cast<const bf16x8*>(&S[buf][0][pl][kh * KH_WORDS + (wm * 64 + i * 32 + c) * 4]);
                 fb[i][pl] = *reinterpret_cast<const bf16x8*>(&S[buf][1][pl][kh * KH_WORDS + (wn * 64 + i * 32 + c) * 4]);
             }
-    };
-    auto multiply = [&]() __attribute__((always_inline)) {
         if (ablate & 4) { acc[0][0][0] += (float)fa[0][0][0] + (float)fb[1][2][1] + (float)fa[1][1][0] + (float)fb[0][1][3]; return; }
         // smallest terms first; the four accumulators interleaved (independent chains back to back)
 #define TERM(PA, PB)                                                                                         \
@@ -137,24 +135,15 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16x6(const float* __restrict__ 
     load(ra[2], rb[2], min(2, last));
     store(ra[0], rb[0], 0);
     __syncthreads();
-    read_frags(0);
-    // step kt: request tile kt + 3; multiply tile kt (fragments already in registers) while tile kt + 1 is
-    // split and parked in the other LDS buffer (4 VALU + half an LDS write under every MFMA); barrier;
-    // fetch the fragments of tile kt + 1
+    // step kt: request tile kt + 3, split + park tile kt + 1 in the other LDS buffer, multiply tile kt.
+    // (Variant tried: fragments fetched right after the barrier and the split / LDS stores interleaved
+    //  under the MFMAs with sched_group_barrier (1 MFMA : 4 VALU : 1/2 DS write) -- 192 VGPRs, 2 waves per
+    //  SIMD instead of 3: logits 678 us, square 875 us, slower than this plain order.)
 #define STEP(KT_, SLOAD, SNEXT, BUF)                              \
     load(ra[SLOAD], rb[SLOAD], min((KT_) + 3, last));            \
-    __builtin_amdgcn_sched_barrier(0);                           \
-    multiply();                                                  \
     store(ra[SNEXT], rb[SNEXT], (BUF) ^ 1);                      \
-    _Pragma("unroll") for (int g = 0; g < 24; ++g) {             \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       \
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);       \
-        if ((g & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); \
-    }                                                            \
-    __builtin_amdgcn_sched_barrier(0);                           \
-    __syncthreads();                                             \
-    read_frags((BUF) ^ 1);                                       \
-    __builtin_amdgcn_sched_barrier(0);
+    multiply(BUF);                                               \
+    __syncthreads();
     for (int kt = 0; kt < KT; kt += 4) {
         STEP(kt, 3, 1, 0)
         STEP(kt + 1, 0, 2, 1)

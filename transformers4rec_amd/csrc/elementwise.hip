@@ -220,6 +220,82 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(
     }
     const int r0 = blockIdx.x * T4R_COLRED_ROWS;
     const int r1 = min(rows, r0 + T4R_COLRED_ROWS);
+    if constexpr (NC == 1) {
+        // narrow rows (D <= 64 * VEC): the wave's four rows are processed together -- branch-free loads
+        // from clamped row indices, so all twelve row segments are in flight before the first reduction
+        // (one row at a time the kernel was latency-bound: 26 us for 52 MB at D = 128)
+        constexpr int RPW = T4R_COLRED_ROWS / 4;
+        const int c0 = lane * VEC;
+        const bool cok = c0 < D;
+        const int cc = cok ? c0 : 0;
+        FV<VEC> xh[RPW], g[RPW], ds[RPW];
+        float s1[RPW], s2[RPW], rsv[RPW];
+        FV<VEC> xa[RPW], xb[RPW], dd[RPW];
+        float muv[RPW];
+#pragma unroll
+        for (int it = 0; it < RPW; ++it) {
+            const int rc = min(r0 + wave + 4 * it, rows - 1);
+            xa[it] = *reinterpret_cast<const FV<VEC>*>(a + (long)rc * D + cc);
+            if (b) xb[it] = *reinterpret_cast<const FV<VEC>*>(b + (long)rc * D + cc);
+            dd[it] = *reinterpret_cast<const FV<VEC>*>(dy + (long)rc * D + cc);
+            muv[it] = mean[rc]; rsv[it] = rstd[rc];
+        }
+#pragma unroll
+        for (int it = 0; it < RPW; ++it) {
+            const int row = r0 + wave + 4 * it;
+            const float live = (row < r1 && cok) ? 1.f : 0.f;
+            FV<VEC> x = xa[it];
+            if (drop.p > 0.f) {
+                drop_scale_vec<VEC>(drop, (unsigned long long)min(row, rows - 1) * D + cc, (D & 3) == 0, ds[it].v);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) x.v[e] *= ds[it].v[e];
+            }
+            if (b) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) x.v[e] += xb[it].v[e];
+            }
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float h = (x.v[e] - muv[it]) * rsv[it];
+                const float dv = dd[it].v[e] * live;
+                const float gg = dv * gam[0].v[e];
+                xh[it].v[e] = h;
+                g[it].v[e] = gg;
+                t1 += gg;
+                t2 += gg * h;
+                pg[0].v[e] += dv * h;
+                pb[0].v[e] += dv;
+            }
+            s1[it] = t1; s2[it] = t2;
+        }
+#pragma unroll
+        for (int it = 0; it < RPW; ++it) { s1[it] = wave_sum(s1[it]) / D; s2[it] = wave_sum(s2[it]) / D; }
+#pragma unroll
+        for (int it = 0; it < RPW; ++it) {
+            const int row = r0 + wave + 4 * it;
+            if (row < r1 && cok) {
+                float* dxr = dx + (long)row * D;
+                FV<VEC> o;
+                if (accumulate_dx) o = *reinterpret_cast<const FV<VEC>*>(dxr + c0);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float v = rsv[it] * (g[it].v[e] - s1[it] - xh[it].v[e] * s2[it]);
+                    o.v[e] = accumulate_dx ? o.v[e] + v : v;
+                }
+                *reinterpret_cast<FV<VEC>*>(dxr + c0) = o;
+                if (dxa) {   // gradient of the dropped operand `a`
+                    FV<VEC> oa;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const float v = rsv[it] * (g[it].v[e] - s1[it] - xh[it].v[e] * s2[it]);
+                        oa.v[e] = drop.p > 0.f ? v * ds[it].v[e] : v;
+                    }
+                    *reinterpret_cast<FV<VEC>*>(dxa + (long)row * D + c0) = oa;
+                }
+            }
+        }
+    } else
     for (int row = r0 + wave; row < r1; row += 4) {
         const float* ar = a + (long)row * D;
         const float* br = b ? b + (long)row * D : nullptr;

@@ -28,6 +28,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// RAW_BARRIER=1 (NOT yet run on hardware -- written after the round's GPU budget was spent): the X tile is
+// parked BEFORE the logits are stored and the step ends with s_waitcnt lgkmcnt(0) + a raw s_barrier instead
+// of __syncthreads().  __syncthreads() is a fence: every wave drains its 16 row stores (vmcnt(0)) before
+// the barrier, i.e. a store round trip per step on the critical path -- probably most of the measured
+// 3.5 us per step.  LDS visibility only needs lgkmcnt(0) + barrier; the stores need no cross-wave order.
+#ifndef RAW_BARRIER
+#define RAW_BARRIER 0
+#endif
 #define KDIM 128
 #define NCK (KDIM / 8)         // 16 chunks of 8 k per row
 #define BMS 32                 // rows of X per step
@@ -120,6 +128,9 @@ __global__ __launch_bounds__(256) void logits_wstat(const unsigned short* __rest
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, wf[kt][1], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, wf[kt][0], acc, 0, 0, 0);
         }
+#if RAW_BARRIER
+        park_tile(buf ^ 1);          // buffer buf ^ 1 was last read in step - 1 (barrier passed)
+#endif
         // logits of this 32 x 32 block: rows step*32 + (r & 3) + 8 (r >> 2) + 4 kh, column col
         if (col < N) {
             float* cp = C + (size_t)(step * BMS + 4 * kh) * ldc + col;
@@ -134,8 +145,13 @@ __global__ __launch_bounds__(256) void logits_wstat(const unsigned short* __rest
                 }
             }
         }
+#if RAW_BARRIER
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#else
         park_tile(buf ^ 1);          // buffer buf ^ 1 was last read in step - 1 (barrier passed)
         __syncthreads();
+#endif
     }
 }
 

@@ -28,11 +28,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// RAW_BARRIER=1 (NOT yet run on hardware -- written after the round's GPU budget was spent): the X tile is
-// parked BEFORE the logits are stored and the step ends with s_waitcnt lgkmcnt(0) + a raw s_barrier instead
-// of __syncthreads().  __syncthreads() is a fence: every wave drains its 16 row stores (vmcnt(0)) before
-// the barrier, i.e. a store round trip per step on the critical path -- probably most of the measured
-// 3.5 us per step.  LDS visibility only needs lgkmcnt(0) + barrier; the stores need no cross-wave order.
+// RAW_BARRIER=1: the X tile is parked BEFORE the logits are stored and the step ends with
+// s_waitcnt lgkmcnt(0) + a raw s_barrier instead of __syncthreads() (a fence: every wave drains its 16 row
+// stores, vmcnt(0), before the barrier).  Measured with the round's last GPU seconds: 588 us / 529 us
+// (594 / 551 with __syncthreads), same errors -- the store drain is NOT what makes a step 3.5 us.
+// Remaining suspects, untested: the single dependent accumulator chain per wave (48 back-to-back
+// v_mfma_f32_32x32x16_bf16 into one accumulator, only 2 waves per SIMD to fill its stalls -> try 64-row
+// steps = two independent chains sharing the W fragments) and the one-step-ahead tile request.
 #ifndef RAW_BARRIER
 #define RAW_BARRIER 0
 #endif

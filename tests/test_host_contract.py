@@ -155,3 +155,12 @@ def test_missing_library_fails_loudly():
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True,
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert "RAISED True" in out.stdout, out.stdout + out.stderr
+
+
+def test_logits_leading_dimension_is_256_byte_aligned():
+    """[N, V] logits live in a buffer whose rows start on 256-byte boundaries (with 16-byte
+    aligned rows every 128-byte store segment of the GEMM epilogue straddled two cache lines)."""
+    from transformers4rec_amd import ops
+    for V in (1, 63, 64, 65, 1001, 100001):
+        ld = ops.pad_ld(V)
+        assert ld >= V and ld % 64 == 0 and ld - V < 64

@@ -13,7 +13,15 @@ MASK_NONE, MASK_MLM, MASK_CLM, MASK_CLM_INFER = 0, 1, 2, 3
 MLM_TRAIN, MLM_EVAL_LAST, MLM_EVAL_ALL, MLM_INFER, CLM_TRAIN, CLM_LAST, CLM_INFER = range(7)
 
 
+_GPU_OK = False
+
+
 def _stream():
+    global _GPU_OK
+    if not _GPU_OK:
+        if not torch.cuda.is_available():
+            raise _lib.T4RHipError("no GPU visible to torch: the HIP path cannot run and there is no CPU path")
+        _GPU_OK = True
     return torch.cuda.current_stream().cuda_stream
 
 

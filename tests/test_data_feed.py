@@ -115,7 +115,14 @@ def test_loader_shuffle_and_sharding(tmp_path):
     assert rows_of(dl2) == e0                              # same (seed, epoch) -> same order
     parts = [rows_of(ParquetSessionLoader(paths, batch_size=10, max_sequence_length=12, global_size=3, global_rank=r))
              for r in range(3)]
-    assert sum(parts, []) == list(range(64)) and all(len(p) in (22, 20) for p in parts)
+    # every rank gets floor(64 / 3) = 21 rows and the same number of batches (a data-parallel step is one
+    # blocking all-reduce per batch: uneven shards would deadlock); the trailing 64 % 3 row is dropped
+    assert sum(parts, []) == list(range(63)) and all(len(p) == 21 for p in parts)
+    lens = {len(ParquetSessionLoader(paths, batch_size=10, max_sequence_length=12, global_size=3, global_rank=r))
+            for r in range(3)}
+    assert lens == {3}
+    with pytest.raises(ValueError):
+        ParquetSessionLoader(paths, batch_size=10, max_sequence_length=12, global_size=100, global_rank=0)
 
 
 @pytest.mark.gpu

@@ -443,7 +443,7 @@ def test_prepost_regularisers_match_reference_and_oracle(name):
     for f, tab in p["tables"].items():
         D = tab.shape[1]
         ctr = ops.dropout_ctr_hi(model.input_features._post_step, 0xFE, order.index(f) * 8 + di)
-        _, m = ops.dropout(torch.ones(B * L * D, device=DEV), pd, F_._POST_SEED, ctr, want_mask=True)
+        _, m = ops.dropout(torch.ones(B * L * D, device=DEV), pd, F_.post_seed(), ctr, want_mask=True)
         keep[f] = m.view(B, L, D).cpu()
         assert 0.6 < float(keep[f].float().mean()) < 0.9
     cfg = dict(n_head=int(d["meta/n_head"]), eps=float(d["meta/eps"]), item="item_id", masking="mlm",

@@ -164,3 +164,69 @@ def test_logits_leading_dimension_is_256_byte_aligned():
     for V in (1, 63, 64, 65, 1001, 100001):
         ld = ops.pad_ld(V)
         assert ld >= V and ld % 64 == 0 and ld - V < 64
+
+
+def test_rng_defaults_follow_torch_seed_and_rank_and_can_be_checkpointed(monkeypatch):
+    """default Philox keys derive from torch.initial_seed() + rank (not 0), the stream positions are
+    checkpointable outside the state_dict (whose names are a contract with the reference)."""
+    import transformers4rec_amd as tr
+
+    schema = tr.session_schema(50, 8)
+
+    def make():
+        inputs = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=8, masking="mlm",
+                                                        embedding_dim_default=16)
+        return tr.XLNetConfig.build(16, 2, 1, total_seq_length=8).to_torch_model(
+            inputs, tr.NextItemPredictionTask(weight_tying=True))
+
+    torch.manual_seed(11)
+    a = make()
+    sa = (a.input_features.masking.seed, a.transformer_block.transformer.seed)
+    torch.manual_seed(11)
+    b = make()
+    assert (b.input_features.masking.seed, b.transformer_block.transformer.seed) == sa   # reproducible
+    assert sa[0] != sa[1] and 0 not in sa                                                  # distinct streams
+    torch.manual_seed(12)
+    assert make().input_features.masking.seed != sa[0]                                     # follows manual_seed
+    monkeypatch.setenv("RANK", "3")
+    torch.manual_seed(11)
+    assert make().input_features.masking.seed != sa[0]                                     # and the rank
+    monkeypatch.delenv("RANK")
+    keys = list(a.state_dict().keys())
+    a.input_features.masking._rng_offset = 160
+    a.transformer_block.transformer._drop_offset = 7
+    st = tr.get_rng_state(a)
+    assert list(a.state_dict().keys()) == keys, "RNG state must stay out of the state_dict"
+    tr.set_rng_state(b, st)
+    assert b.input_features.masking._rng_offset == 160 and b.transformer_block.transformer._drop_offset == 7
+    assert b.input_features.masking.seed == a.input_features.masking.seed
+    with pytest.raises(KeyError):
+        tr.set_rng_state(b, {"nope": {"_seed": 1}})
+
+
+def test_frozen_parameters_keep_no_grad():
+    """a frozen parameter's .grad is not touched by the direct-.grad contract"""
+    from transformers4rec_amd.masking import _grad_buf
+
+    p = torch.nn.Parameter(torch.zeros(3, 2), requires_grad=False)
+    s = _grad_buf(p)
+    assert p.grad is None and s.shape == p.shape and _grad_buf(p) is s
+    q = torch.nn.Parameter(torch.zeros(3, 2))
+    assert _grad_buf(q) is q.grad
+
+
+def test_construction_time_limits():
+    import transformers4rec_amd as tr
+
+    schema = tr.session_schema(100, 64)
+    mlm = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=64, masking="mlm", embedding_dim_default=16)
+    clm = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=64, masking="clm", embedding_dim_default=16)
+    cfg = tr.XLNetConfig.build(16, 2, 1, total_seq_length=64)
+    tr.TransformerBlock(cfg, masking=clm.masking)                      # 64 positions fit
+    with pytest.raises(ValueError, match="at most 64"):                # MLM inference needs L + 1 = 65
+        tr.TransformerBlock(cfg, masking=mlm.masking)
+    # labels are item ids: a smaller target_dim would index out of range in the head kernels
+    small = tr.TabularSequenceFeatures.from_schema(tr.session_schema(100, 20), max_sequence_length=20, masking="mlm",
+                                                   embedding_dim_default=16)
+    with pytest.raises(ValueError, match="target_dim"):
+        tr.NextItemPredictionTask(target_dim=50).build(body=None, input_size=torch.Size([-1, 20, 16]), inputs=small)

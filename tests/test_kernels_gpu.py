@@ -595,7 +595,9 @@ def test_xlnet_layer_dropout_fwd_bwd(ops, B, L, D, n):
     h = torch.randn(B, L, D, generator=g)
     hr = h.clone().requires_grad_()
     C = lambda site: ops.dropout_ctr_hi(offset, layer, site)
-    masks = dict(pos=_mask(ops, (B, 2 * L, D), p_drop, seed, C(ops.SITE_POS)),
+    # the pos_emb mask is drawn once per forward and shared by every layer (HF modeling_xlnet.py:1143):
+    # its counter carries layer 255, not the layer index
+    masks = dict(pos=_mask(ops, (B, 2 * L, D), p_drop, seed, ops.dropout_ctr_hi(offset, 255, ops.SITE_POS)),
                  prob=_mask(ops, (B, n, L, L), p_drop, seed, C(ops.SITE_PROB)),
                  attn_out=_mask(ops, (B, L, D), p_drop, seed, C(ops.SITE_ATTN_OUT)),
                  ff_act=_mask(ops, (B, L, 4 * D), p_drop, seed, C(ops.SITE_FF_ACT)),

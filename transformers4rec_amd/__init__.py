@@ -18,3 +18,4 @@ from .model import Head, Model  # noqa: E402,F401
 from .optim import FlatParams, FusedAdam, flatten_model  # noqa: E402,F401
 from .distributed import GradReducer, shard_batch  # noqa: E402,F401
 from .data import ParquetSessionLoader, read_ragged_columns  # noqa: E402,F401
+from .rng import default_seed, get_rng_state, set_rng_state  # noqa: E402,F401

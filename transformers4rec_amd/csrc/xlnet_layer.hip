@@ -144,8 +144,10 @@ extern "C" int t4r_xlnet_layer_fwd(void* stream, const float* h, const float* po
         // dropout(pos_emb expanded over the batch) @ r : per-session positional keys (HF :1142-1143
         // drops the batch-expanded pos_emb, so every session gets its own mask).
         float* pe_b = w.pe_b;
+        // HF applies that dropout ONCE per forward, before the layer loop (:1143), and hands the same
+        // dropped tensor to every layer: the mask is keyed by (offset, layer 255, SITE_POS), not by the layer
         RUN(t4r_dropout(stream, pos_emb, pe_b, nullptr, (long)B * 2 * L * D, 2L * L * D, drop_p, seed,
-                        C(SITE_POS)));
+                        ctr_hi(offset, 255, SITE_POS)));
         RUN(t4r_gemm_launch(st, 0, 0, B * 2 * L, D, D, 1.f, pe_b, D, params[P_R], D, w.kr, D, nullptr,
                             EPI_NONE, nullptr, 0, 1, 0, 1, 0, 0, 0, nullptr));
     } else {

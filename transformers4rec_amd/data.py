@@ -92,8 +92,13 @@ class ParquetSessionLoader:
         if global_size is not None and global_size > 1:
             if global_rank is None or not 0 <= global_rank < global_size:
                 raise ValueError("global_rank must be in [0, global_size)")
-            per = (n + global_size - 1) // global_size
-            lo, hi = min(n, global_rank * per), min(n, (global_rank + 1) * per)
+            # every rank gets the SAME number of rows (floor(n / world); the n % world trailing rows are
+            # dropped): the data-parallel step is one blocking all-reduce per batch, so ranks with
+            # different batch counts would deadlock at the end of the epoch
+            per = n // global_size
+            if per == 0:
+                raise ValueError(f"{n} rows cannot be sharded over {global_size} ranks")
+            lo, hi = global_rank * per, (global_rank + 1) * per
         self.device = torch.device(device)
         self._batch_size = batch_size
         self.batch_size = batch_size

@@ -131,7 +131,18 @@ class ContinuousFeatures(nn.Module):
         self.post = None
 
 
-_POST_SEED = 0x7AB1E5EED
+_POST_SALT = 4
+_post_seed_value = None
+
+
+def post_seed():
+    """Philox key of the TabularDropout masks: rng.default_seed(_POST_SALT), resolved at the first draw"""
+    global _post_seed_value
+    if _post_seed_value is None:
+        from .rng import default_seed
+
+        _post_seed_value = default_seed(_POST_SALT)
+    return _post_seed_value
 
 
 def _post_fwd(owner, post, name, fidx, e2d, step):
@@ -149,14 +160,14 @@ def _post_fwd(owner, post, name, fidx, e2d, step):
             nxt = mods[i + 1] if i + 1 < len(mods) else None
             if isinstance(nxt, TabularLayerNorm) and name in nxt.feature_layer_norm:
                 ln = nxt.feature_layer_norm[name]
-                drop = (p, _POST_SEED, ctr) if p > 0 else ops.NO_DROP
+                drop = (p, post_seed(), ctr) if p > 0 else ops.NO_DROP
                 y, mean, rstd = ops.add_layernorm_fwd(e2d, None, ln.weight.detach(), ln.bias.detach(), ln.eps, drop)
                 saved.append(("ln", e2d, mean, rstd, ln, drop))
                 e2d = y
                 i += 2
                 continue
             if p > 0:
-                e2d = ops.dropout(e2d, p, _POST_SEED, ctr).view(e2d.shape)
+                e2d = ops.dropout(e2d, p, post_seed(), ctr).view(e2d.shape)
                 saved.append(("drop", p, ctr))
         elif name in m.feature_layer_norm:
             ln = m.feature_layer_norm[name]
@@ -170,7 +181,7 @@ def _post_fwd(owner, post, name, fidx, e2d, step):
 def _post_bwd(saved, dy):
     for rec in reversed(saved):
         if rec[0] == "drop":
-            dy = ops.dropout(dy, rec[1], _POST_SEED, rec[2]).view(dy.shape)
+            dy = ops.dropout(dy, rec[1], post_seed(), rec[2]).view(dy.shape)
         else:
             _, a, mean, rstd, ln, drop = rec
             r = ops.add_layernorm_bwd(a, None, ln.weight.detach(), mean, rstd, dy, _grad_buf(ln.weight),

@@ -12,11 +12,25 @@ import torch
 from torch import nn
 
 from . import ops
+from .rng import SeedMixin
 
 MaskingInfo = namedtuple("MaskingInfo", ["schema", "targets"])
 
 
 def _grad_buf(p):
+    """The buffer a HIP backward ACCUMULATES the gradient of parameter `p` into: `p.grad` itself
+    (created zero-filled on first use).  Contract of this package: the custom autograd functions
+    write parameter gradients straight into `.grad` (flat-bucket friendly: optim.FlatParams makes
+    `.grad` a view of the bucket RCCL reduces) and return None for them, so `torch.autograd.grad`
+    and per-parameter hooks do not see parameter gradients of the HIP modules.
+    A frozen parameter (`requires_grad=False`) keeps `.grad` untouched: the kernels get a scratch
+    buffer that is cached on the parameter and never read."""
+    if not p.requires_grad:
+        s = p.__dict__.get("_t4r_frozen_scratch")
+        if s is None or s.shape != p.shape or s.device != p.device:
+            s = torch.zeros_like(p)
+            p.__dict__["_t4r_frozen_scratch"] = s
+        return s
     if p.grad is None:
         p.grad = torch.zeros_like(p)
     return p.grad
@@ -40,8 +54,9 @@ class _ApplyMaskFn(torch.autograd.Function):
         return dx, None, None, None
 
 
-class MaskSequence(nn.Module):
+class MaskSequence(SeedMixin, nn.Module):
     """Base class (reference masking.py:61-243)."""
+    _seed_salt = 1
 
     def __init__(self, hidden_size: int, padding_idx: int = 0,
                  eval_on_last_item_seq_only: bool = True, **kwargs):
@@ -54,8 +69,8 @@ class MaskSequence(nn.Module):
         # trainable vector that replaces masked interactions; N(0, 0.001) (masking.py:102-108)
         self.masked_item_embedding = nn.Parameter(torch.empty(hidden_size))
         nn.init.normal_(self.masked_item_embedding, mean=0, std=0.001)
-        # device-RNG state for the training draws (Philox counter) and the parity hook
-        self.seed = 0
+        # device-RNG state for the training draws (Philox key = `seed`, default rng.default_seed():
+        # torch.initial_seed() + rank; counter `_rng_offset`, see rng.get_rng_state) and the parity hook
         self._rng_offset = 0
         self._draws = None
         # label compaction cache for the prediction head (filled by compute_masked_targets)

@@ -223,8 +223,15 @@ class NextItemPredictionTask(nn.Module):
         if not getattr(inputs, "item_id", None):
             raise ValueError("For Item Prediction task a categorical_module including an item_id column is required.")
         self.embeddings = inputs.categorical_module
+        n_items = self.embeddings.item_embedding_table.num_embeddings
         if not self.target_dim:
-            self.target_dim = self.embeddings.item_embedding_table.num_embeddings
+            self.target_dim = n_items
+        if self.target_dim < n_items:
+            # the labels ARE item ids (masking.masked_targets): the head kernels index logits / W rows with
+            # them without a range check of their own (the ids themselves are range-checked by the embedding
+            # gather, TabularSequenceFeatures.check_ids()).  torch's CrossEntropyLoss would raise at run time.
+            raise ValueError(f"target_dim ({self.target_dim}) must cover the item-id cardinality ({n_items}): "
+                             "labels are item ids")
         item_table = None
         in_dim = input_size[-1]
         if self.weight_tying:

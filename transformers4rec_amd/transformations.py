@@ -17,6 +17,7 @@ import torch
 from torch import nn
 
 from . import ops
+from .rng import SeedMixin
 
 
 class _LN(nn.Module):
@@ -30,13 +31,15 @@ class _LN(nn.Module):
         self.normalized_shape = (dim,)
 
 
-class StochasticSwapNoise(nn.Module):
+class StochasticSwapNoise(SeedMixin, nn.Module):
     """tr.StochasticSwapNoise(schema=None, pad_token=0, replacement_prob=0.1).
 
-    Device draws: Philox(seed, (step, module, feature)); `set_draws` injects the reference's
-    torch.bernoulli / torch.randperm results for one forward (parity tests)."""
+    Device draws: Philox(seed, (step, module, feature)), seed default rng.default_seed();
+    `set_draws` injects the reference's torch.bernoulli / torch.randperm results for one forward
+    (parity tests)."""
+    _seed_salt = 3
 
-    def __init__(self, schema=None, pad_token=0, replacement_prob=0.1, seed=0x55E5EED):
+    def __init__(self, schema=None, pad_token=0, replacement_prob=0.1, seed=None):
         super().__init__()
         self.schema = schema
         self.pad_token = pad_token

@@ -18,6 +18,7 @@ from torch import nn
 
 from . import ops
 from .masking import MaskedLanguageModeling, CausalLanguageModeling, MaskSequence, _grad_buf
+from .rng import SeedMixin
 
 
 @dataclass
@@ -179,7 +180,7 @@ class _WordEmbedding(nn.Module):
         self.weight = nn.Parameter(torch.empty(vocab, dim).normal_(0, std))
 
 
-class XLNetModel(nn.Module):
+class XLNetModel(SeedMixin, nn.Module):
     """Parameter container with HF XLNetModel's layout; forward(inputs_embeds) -> (hidden,)"""
 
     def __init__(self, config: XLNetConfig):
@@ -189,7 +190,7 @@ class XLNetModel(nn.Module):
         self.mask_emb = nn.Parameter(torch.empty(1, 1, config.d_model).normal_(0, config.initializer_range))
         self.layer = nn.ModuleList([XLNetLayer(config) for _ in range(config.n_layer)])
         self._pos_cache = {}
-        self.seed = 0             # Philox key of the dropout masks
+        # Philox key of the dropout masks: `seed` (default rng.default_seed(): torch.initial_seed() + rank)
         self._drop_offset = 0     # advanced once per training forward
 
     config_class = XLNetConfig
@@ -223,6 +224,9 @@ class XLNetModel(nn.Module):
         return (h,)
 
 
+XLNET_MAX_SEQ = 64
+
+
 class TransformerBlock(nn.Module):
     """Drop-in for tr.TransformerBlock (block/transformer.py:76-206) with the XLNet body on HIP."""
 
@@ -244,6 +248,17 @@ class TransformerBlock(nn.Module):
                              f"the {self.transformer.config_class.__name__} architecture")
         self.masking = masking
         self.prepare_module = None
+        # the XLNet attention kernels hold a whole key row per wave: L <= 64 (xlnet_attn.hip), and MLM
+        # inference runs the body on L + 1 positions (masking.py:406-418).  Fail at construction, not at the
+        # first inference call.
+        tsl = getattr(self.transformer.config, "total_seq_length", None)
+        if isinstance(self.transformer, XLNetModel) and tsl is not None:
+            need = tsl + (1 if isinstance(masking, MaskedLanguageModeling) else 0)
+            if need > XLNET_MAX_SEQ:
+                raise ValueError(
+                    f"XLNet on the HIP path supports sequences of at most {XLNET_MAX_SEQ} positions; "
+                    f"total_seq_length={tsl}" + (" (+1 for the MLM inference slot)" if need != tsl else "")
+                    + " exceeds it")
 
     @classmethod
     def from_registry(cls, transformer: str, d_model: int, n_head: int, n_layer: int, total_seq_length: int,

@@ -23,6 +23,7 @@ from torch import nn
 
 from . import ops
 from .masking import _grad_buf
+from .rng import SeedMixin
 
 S_IN, S_PROB, S_AO, S_FF, S_FO, S_FINAL = (ops.SITE_INPUT, ops.SITE_PROB, ops.SITE_ATTN_OUT, ops.SITE_FF_ACT,
                                            ops.SITE_FF_OUT, ops.SITE_FINAL)
@@ -279,7 +280,7 @@ class _DropFn(torch.autograd.Function):
         return ops.dropout(dy.contiguous().view(-1), p, seed, ctr).view(dy.shape), None, None, None
 
 
-class GPT2Model(nn.Module):
+class GPT2Model(SeedMixin, nn.Module):
     config_class = GPT2Config
 
     def __init__(self, config: GPT2Config):
@@ -291,7 +292,7 @@ class GPT2Model(nn.Module):
         self.wpe = _Emb(config.n_positions, config.n_embd, config.initializer_range)
         self.h = nn.ModuleList([GPT2Block(config) for _ in range(config.n_layer)])
         self.ln_f = _LN(config.n_embd, config.layer_norm_epsilon)
-        self.seed, self._drop_offset = 0, 0
+        self._drop_offset = 0      # `seed`: rng.SeedMixin (torch.initial_seed() + rank unless assigned)
 
     def forward(self, inputs_embeds=None, **kwargs):
         cfg = self.config
@@ -428,7 +429,7 @@ class _BertPooler(nn.Module):
         self.dense = _Linear(cfg.hidden_size, cfg.hidden_size, cfg.initializer_range)
 
 
-class BertModel(nn.Module):
+class BertModel(SeedMixin, nn.Module):
     config_class = BertConfig
 
     def __init__(self, config: BertConfig):
@@ -437,7 +438,7 @@ class BertModel(nn.Module):
         self.embeddings = _BertEmbeddings(config)
         self.encoder = _BertEncoder(config)
         self.pooler = _BertPooler(config)      # HF computes it, TransformerBlock drops it: never evaluated
-        self.seed, self._drop_offset = 0, 0
+        self._drop_offset = 0      # `seed`: rng.SeedMixin (torch.initial_seed() + rank unless assigned)
 
     def forward(self, inputs_embeds=None, **kwargs):
         cfg = self.config

@@ -75,6 +75,22 @@ int t4r_seq_features_fwd(void* stream, int n_feat, const int* kind, const void* 
  * ids_div = 1 (ids [B*L]) or L (per-session ids [B]: id index = tok / L). */
 int t4r_embedding_bwd(void* stream, const float* dout, const long* ids, float* d_table, long ntok,
                       int W, int col, int dim, long rows, int padding_idx, int ids_div);
+/* Deterministic form of the same backward (and the local "apply" of the row-sparse data-parallel
+ * exchange): sort the lookups by row id once (stable radix sort; depends on the ids only, so it can run in
+ * the forward pass), then a segmented sum in ascending lookup order -- one owner wave per table row, no
+ * atomics.  Replaces ATen embedding_dense_backward behind features/embedding.py:226-249.
+ *   t4r_sort_ids: keys_sorted[n] int32 ascending (padding_idx / out-of-range ids -> `rows`, last),
+ *                 perm[n] int32 = index of the lookup; ws of t4r_sort_ids_ws_bytes(n) bytes.
+ *   t4r_embedding_bwd_sorted: d_table[key, :] += sum_{lookups p with that key, ascending p}
+ *                 sum_{l < ids_div} dout[(p*ids_div + l)*W + col : +dim]; ws of
+ *                 t4r_embedding_bwd_sorted_ws_floats(n, dim) floats. */
+long t4r_sort_ids_ws_bytes(long n);
+int t4r_sort_ids(void* stream, const long* ids, long n, long rows, int padding_idx, int* keys_sorted,
+                 int* perm, void* ws, long ws_bytes);
+long t4r_embedding_bwd_sorted_ws_floats(long n, int dim);
+int t4r_embedding_bwd_sorted(void* stream, const float* dout, const int* keys_sorted, const int* perm,
+                             float* d_table, long n, int W, int col, int dim, long rows, int ids_div,
+                             float* ws);
 /* masking as its own pass (after the projection MLP), in place on x [B*L, H]; and its backward:
  * d_memb[H] += sum of dy over replaced tokens (accumulated), dy zeroed there (in place). */
 int t4r_apply_mask_fwd(void* stream, float* x, const unsigned char* mask, const float* masked_emb,

@@ -822,3 +822,42 @@ def test_topk_ties_and_fallback_path(ops):
     v2, i2 = ops.topk(cu(buf)[:, :1003], 64, 1003)
     rv, ri = torch.topk(s2, 64, dim=-1)
     assert torch.equal(v2.cpu(), rv) and torch.equal(i2.cpu(), ri)
+
+
+# ------------------------------------------------------------------------------------ deterministic table gradient
+@pytest.mark.parametrize("n,rows,dim,W,col,ids_div", [
+    (1, 10, 8, 8, 0, 1), (17, 5, 64, 64, 0, 1), (1000, 300, 128, 128, 0, 1), (20480, 100001, 128, 128, 0, 1),
+    (40000, 11, 64, 200, 72, 1),        # hot rows: every segment spans many super-chunks
+    (5000, 41, 200, 336, 100, 1),       # odd width inside a concatenated row
+    (3000, 1000, 512, 512, 0, 1), (700, 50, 600, 600, 0, 1),      # wide rows: second column block
+    (256, 17, 32, 40, 8, 20),           # per-session feature: gradient summed over the L = 20 positions
+    (300000, 1000, 64, 64, 0, 1),       # S > 1 super-chunks
+])
+def test_embedding_bwd_sorted_is_exact_and_deterministic(ops, n, rows, dim, W, col, ids_div):
+    """sort + segmented sum == index_add of the oracle (fp64 accumulation as the referee), padding and
+    out-of-range ids carry no gradient, two runs are bit-identical (no atomics)."""
+    g = torch.Generator().manual_seed(n + rows)
+    ids = torch.randint(0, rows, (n,), generator=g)          # includes padding id 0
+    if n > 4:
+        ids[3] = rows + 5                                    # out of range: ignored
+        ids[-1] = ids[0]
+    dout = torch.randn(n * ids_div, W, generator=g)
+    keys, perm = ops.sort_ids(cu(ids), rows, 0)
+    kc, pc = keys.cpu().long(), perm.cpu().long()
+    valid = (ids != 0) & (ids < rows)
+    want_keys = torch.where(valid, ids, torch.full_like(ids, rows))
+    assert torch.equal(kc, want_keys.sort(stable=True).values)
+    assert torch.equal(pc, want_keys.sort(stable=True).indices)       # stable: ascending lookup order within a row
+    grows = dout.view(n, ids_div, W)[:, :, col: col + dim].double().sum(1)
+    ref = torch.zeros(rows, dim, dtype=torch.float64).index_add_(0, ids[valid], grows[valid])
+    base = torch.randn(rows, dim, generator=g)
+    outs = []
+    for _ in range(2):
+        dt = cu(base).clone()
+        ops.embedding_bwd_sorted(cu(dout), keys, perm, dt, col, dim, ids_div)
+        outs.append(dt.cpu())
+    assert torch.equal(outs[0], outs[1]), "two runs differ: the scatter is not deterministic"
+    err = (outs[0].double() - base.double() - ref).abs().max()
+    scale = max(1.0, float(ref.abs().max()))
+    assert float(err) <= 2e-6 * scale * max(1, (n // rows) ** 0.5), float(err)
+    assert torch.equal(outs[0][0], base[0]), "the padding row received gradient"

@@ -25,6 +25,10 @@ _SIGS = {
     "t4r_ragged_gather_to_padded": ("i", "pppp" + "p" + "iii"),
     "t4r_seq_features_fwd": ("i", "pippppppiiiiiiipppp"),
     "t4r_embedding_bwd": ("i", "pppp" + "liiilii"),
+    "t4r_sort_ids_ws_bytes": ("l", "l"),
+    "t4r_sort_ids": ("i", "pp" + "lli" + "ppp" + "l"),
+    "t4r_embedding_bwd_sorted_ws_floats": ("l", "li"),
+    "t4r_embedding_bwd_sorted": ("i", "ppppp" + "liiili" + "p"),
     "t4r_apply_mask_fwd": ("i", "ppppiiii"),
     "t4r_apply_mask_bwd": ("i", "ppppiiii"),
     "t4r_mul": ("i", "ppppl"),

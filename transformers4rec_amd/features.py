@@ -8,6 +8,7 @@ with the same constructor arguments for the hot path, attribute contract (`maski
 csrc/embedding.hip / gemm_f32.hip through one fused autograd function.
 """
 import math
+import os
 from typing import Dict, Optional
 
 import torch
@@ -18,6 +19,53 @@ from .prediction_task_sync import wait_pending_grad as _wait_pending_grad
 from .transformations import TabularDropout, TabularLayerNorm, parse_post, parse_pre
 from .masking import MaskSequence, _grad_buf, parse_masking
 from .schema import Tags, categorical_cardinalities
+
+# table-gradient scatter: "sorted" = stable sort by row id (done in the forward pass: it depends on the ids
+# only) + segmented sum, deterministic, one owner per row (csrc/embedding_sorted.hip); "atomic" = fp32 row
+# atomics (csrc/embedding.hip), kept for A/B timing
+_EMB_BWD = os.environ.get("T4R_EMB_BWD", "sorted")
+
+
+def _table_scatter(ctx, name, grad_rows, ids_f, tab, col, dim, padding_idx):
+    """d table += gradient rows of one feature.  grad_rows [n_lookups * ids_div, W]"""
+    ids_div = grad_rows.numel() // grad_rows.shape[-1] // ids_f.numel()
+    sink = getattr(tab, "_t4r_sparse_sink", None)
+    if sink is not None:            # data-parallel row-sparse exchange (distributed.SparseRowExchange)
+        sink.add(tab, ids_f, grad_rows, col, dim, ids_div, padding_idx)
+        return
+    if _EMB_BWD == "atomic":
+        ops.embedding_bwd(grad_rows, ids_f, _grad_buf(tab), col, dim, padding_idx)
+        return
+    srt = ctx.sorted_ids.get(name)
+    if srt is None:
+        srt = ops.sort_ids(ids_f, tab.shape[0], padding_idx)
+    elif len(srt) == 3:         # sorted on the side stream during the forward pass
+        cur = torch.cuda.current_stream()
+        cur.wait_event(srt[2])
+        srt[0].record_stream(cur)
+        srt[1].record_stream(cur)
+    ops.embedding_bwd_sorted(grad_rows, srt[0], srt[1], _grad_buf(tab), col, dim, ids_div)
+
+
+_SORT_STREAMS = {}
+
+
+def _sort_ids_forward(ids, rows, padding_idx):
+    """the forward-pass sort, on a side stream: it feeds only the backward, so it runs under the gather and
+    the transformer body instead of in front of them (T4R_EMB_SORT_STREAM=0: on the caller's stream)"""
+    if os.environ.get("T4R_EMB_SORT_STREAM", "1") == "0":
+        return ops.sort_ids(ids, rows, padding_idx)
+    dev = ids.device
+    key = (dev.type, dev.index)
+    if key not in _SORT_STREAMS:
+        _SORT_STREAMS[key] = torch.cuda.Stream(device=dev)
+    side = _SORT_STREAMS[key]
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        keys, perm = ops.sort_ids(ids, rows, padding_idx)
+        done = torch.cuda.Event()
+        done.record(side)
+    return keys, perm, done
 
 
 class EmbeddingTable(nn.Module):
@@ -260,6 +308,14 @@ class _SeqFeaturesFn(torch.autograd.Function):
             if masking is not None:
                 ops.apply_mask_fwd_(out, mask, memb.detach(), mask_mode)
         ctx.mod, ctx.inputs, ctx.soft_saved, ctx.post_saved = mod, inputs, soft_saved, post_saved
+        # the sort behind the deterministic table gradient depends on the ids only: done here, in the forward
+        ctx.sorted_ids = {}
+        if training and _EMB_BWD != "atomic":
+            for name in names:
+                if name in cat.embedding_tables:
+                    tab = cat.embedding_tables[name].weight
+                    if tab.requires_grad and getattr(tab, "_t4r_sparse_sink", None) is None:
+                        ctx.sorted_ids[name] = _sort_ids_forward(inputs[name].contiguous(), tab.shape[0], cat.padding_idx)
         ctx.mask_mode, ctx.mask, ctx.dims, ctx.post_step = mask_mode, mask, (B, L, L_out, W), step
         ctx.agg_out = agg_out if proj is not None else None
         ctx.proj_out = out if proj is not None else None
@@ -322,9 +378,9 @@ class _SeqFeaturesFn(torch.autograd.Function):
                     else:
                         g = ops.copy_cols_out(src2, col, dim) if src2.shape[1] != dim else src2
                     g = _post_bwd(ctx.post_saved[name], g)
-                    ops.embedding_bwd(g, ids_f, _grad_buf(tab), 0, dim, cat.padding_idx)
+                    _table_scatter(ctx, name, g, ids_f, tab, 0, dim, cat.padding_idx)
                 else:
-                    ops.embedding_bwd(src, ids_f, _grad_buf(tab), col, dim, cat.padding_idx)
+                    _table_scatter(ctx, name, src.view(-1, src.shape[-1]), ids_f, tab, col, dim, cat.padding_idx)
             elif isinstance(cont, ContinuousFeatures):
                 continue    # no parameters behind a pass-through column
             else:

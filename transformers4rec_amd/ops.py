@@ -211,6 +211,34 @@ def embedding_bwd(dout, ids, d_table, col, dim, padding_idx=0):
          _chk(d_table, torch.float32), ntok, W, col, dim, d_table.shape[0], padding_idx, ids_div)
 
 
+def sort_ids(ids, rows, padding_idx=0):
+    """stable sort of the lookups by table row -> (keys_sorted int32 [n], perm int32 [n]); padding /
+    out-of-range ids carry the key `rows` and come last.  Depends on the ids only (forward-pass work)."""
+    ids = ids.contiguous().view(-1)
+    n = ids.numel()
+    keys = torch.empty(n, device=ids.device, dtype=torch.int32)
+    perm = torch.empty(n, device=ids.device, dtype=torch.int32)
+    nb = _lib.load().t4r_sort_ids_ws_bytes(n)
+    ws = torch.empty(max(nb, 1), device=ids.device, dtype=torch.uint8)
+    call("t4r_sort_ids", _stream(), _chk(ids, torch.int64), n, int(rows), int(padding_idx), keys.data_ptr(),
+         perm.data_ptr(), ws.data_ptr(), nb)
+    return keys, perm
+
+
+def embedding_bwd_sorted(dout, keys, perm, d_table, col, dim, ids_div=1):
+    """deterministic d_table[id] += gradient rows (ascending lookup order, one owner per row, no atomics).
+    dout [n * ids_div, W]; (keys, perm) from sort_ids."""
+    W = dout.shape[-1]
+    n = keys.numel()
+    if dout.numel() != n * ids_div * W:
+        raise ValueError("embedding_bwd_sorted: dout rows != lookups * ids_div")
+    ws = torch.empty(max(1, _lib.load().t4r_embedding_bwd_sorted_ws_floats(n, dim)), device=dout.device,
+                     dtype=torch.float32)
+    call("t4r_embedding_bwd_sorted", _stream(), _chk(dout, torch.float32), _chk(keys, torch.int32),
+         _chk(perm, torch.int32), _chk(d_table, torch.float32), n, W, col, dim, d_table.shape[0], int(ids_div),
+         ws.data_ptr())
+
+
 def swap_noise(x, item_ids, p, pad_token=0, bern=None, perm=None, seed=0, ctr_hi=0):
     """tr.StochasticSwapNoise.augment for one feature: x [B, L] or [B] (int64 ids / fp32 values);
     item_ids [B, L] gives the padding mask.  bern (uint8, x.shape) / perm (int64 [#non-pad]) inject

@@ -161,6 +161,28 @@ int t4r_gemm_softmax_grad_f32(void* stream, int transA, int n_rows, int V, int N
                               const float* grad_out, float label_smoothing, const float* B, long ldb,
                               float* C, long ldc, int splitk, int accumulate);
 
+/* Non-materialising head: output projection + softmax cross-entropy WITHOUT an [N, V] logits tensor
+ * (the form that can run a 10 M-item vocabulary: 15 k x 10 M logits would be 600 GB).
+ * replaces: model/prediction_task.py:664-669 (logits = X @ W^T, / T) + :446 (CrossEntropyLoss(), mean;
+ * torch/losses.py:4-20 label smoothing) and their autograd, when `predictions` are not requested.
+ * The vocabulary is streamed in chunks of chunk_cols columns (multiple of 4) through one
+ * [N, chunk] buffer of t4r_linear_softmax_ce_chunk_floats(N, chunk_cols) floats (size it to stay in the
+ * 256 MB Infinity Cache); fwd keeps online (max, sum-exp) statistics (stats: 4*N floats scratch), bwd
+ * recomputes each chunk and forms the softmax gradient inside the A operand of the two contractions.
+ *   fwd: loss_rows[N], lse[N], *loss_mean (may be NULL) for softmax(alpha * X[N,D] @ W[V,D]^T) vs labels
+ *   bwd: dX[N,D] = alpha * dlogits @ W (overwritten); dW[V,D] += alpha * dlogits^T @ X (NULL: skipped),
+ *        dlogits = (*grad_out / N) * (softmax - (1-eps) onehot - eps/V); grad_out NULL = 1.
+ * Every label must be in [0, V). */
+long t4r_linear_softmax_ce_chunk_floats(int N, int chunk_cols);
+int t4r_linear_softmax_ce_fwd(void* stream, const float* X, long ldx, const float* W, long ldw,
+                              const long* labels, int N, int V, int D, float alpha, float label_smoothing,
+                              int chunk_cols, float* chunk_buf, float* stats, float* loss_rows, float* lse,
+                              float* loss_mean);
+int t4r_linear_softmax_ce_bwd(void* stream, const float* X, long ldx, const float* W, long ldw,
+                              const long* labels, const float* lse, const float* grad_out, int N, int V, int D,
+                              float alpha, float label_smoothing, int chunk_cols, float* chunk_buf, float* dX,
+                              long lddx, float* dW, long lddw);
+
 /* residual + LayerNorm:  y = LN(a + b) (b may be NULL).
  * replaces: HF :142-152, :297-305 (post-LN), tabular/transformations.py:128-132.
  * backward recomputes x = a + b; dgamma/dbeta accumulated; dx overwritten (or += if accumulate_dx). */

@@ -609,3 +609,223 @@ def test_fused_eval_ranks_equal_materialised_metrics():
     for k in a:
         assert torch.equal(a[k], b["metrics"][k]), k
     assert agg_a == agg_b and len(agg_a) == 4
+
+
+# ------------------------------------------------------------------------------------------
+# non-materialising head and the large configurations (items 1a, 1c)
+@pytest.mark.parametrize("name,kw", [
+    ("xlnet_mlm_item_train", dict(emb_default=32)),
+    ("xlnet_mlm_multi_train", dict(cats=(("category", 40), ("brand", 9)), conts=("price", "age"), d_output=32,
+                                   embedding_dims={"item_id": 16, "category": 24, "brand": 8})),
+    ("xlnet_clm_item_train", dict(masking="clm", emb_default=32, weight_tying=False)),
+])
+def test_fused_head_matches_reference_and_materialised_path(name, kw, monkeypatch):
+    """head_mode='fused' (no [N, V] logits, lazy predictions) against the reference fixture and against the
+    materialised path: loss <= 1e-5, every gradient, and predictions once somebody asks for them."""
+    from transformers4rec_amd.prediction_task import LazyPredictions
+
+    res = {}
+    for mode in ("materialize", "fused"):
+        d, model, x, cap, hooks = run_train_case(name, **kw)
+        model.prediction_task.head_mode = mode
+        out = model(x, training=True)
+        out["loss"].backward()
+        res[mode] = (out, {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    (om, gm), (of, gf) = res["materialize"], res["fused"]
+    assert isinstance(of["predictions"], LazyPredictions) and not of["predictions"].is_materialized
+    assert torch.is_tensor(om["predictions"])
+    assert abs(float(of["loss"].detach()) - float(om["loss"].detach())) < 1e-5
+    assert abs(float(of["loss"].detach()) - float(d["out/loss"])) < 1e-4
+    assert torch.equal(of["labels"], om["labels"])
+    assert sorted(gm) == sorted(gf)
+    for n in gm:
+        close(gf[n], gm[n], rtol=1e-4, atol=2e-7, msg=lambda m, n=n: f"{n}: {m}")
+    ref_g = gu.section(d, "g/")
+    for n, p in dict(gf).items():
+        if n in ref_g:
+            close(p, ref_g[n], rtol=2e-3, atol=2e-6, msg=lambda m, n=n: f"{n} vs reference: {m}")
+    # lazy predictions: shape known without computing; any tensor use computes the same logits
+    lp = of["predictions"]
+    assert tuple(lp.shape) == tuple(om["predictions"].shape) and not lp.is_materialized
+    close(torch.softmax(lp, -1), torch.softmax(om["predictions"], -1), rtol=0, atol=1e-6)
+    assert lp.is_materialized
+    close(lp.materialize(), gu.t(d["out/predictions"]), rtol=0, atol=1e-4)
+    m = model.calculate_metrics(lp, of["labels"])
+    assert set(m) >= {"recall_at_10", "ndcg_at_20"}
+
+
+def test_fused_head_allocates_no_logits_and_auto_mode(monkeypatch):
+    """no [N, V] allocation on the fused path (torch.cuda.max_memory_allocated), 'auto' picks it by size"""
+    import transformers4rec_amd as tr
+
+    B, L, V, D = 512, 20, 200_000, 64
+    schema = tr.session_schema(V, L)
+    peaks = {}
+    for mode in ("fused", "materialize"):
+        torch.manual_seed(0)
+        inputs = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=L, masking="clm", embedding_dim_default=D)
+        cfg = tr.XLNetConfig.build(D, 2, 1, total_seq_length=L, dropout=0.0)
+        model = cfg.to_torch_model(inputs, tr.NextItemPredictionTask(weight_tying=True, head_mode=mode)).to(DEV)
+        batch = tr.random_data_from_schema(schema, B, L, seed=2, device=DEV)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        out = model(batch, training=True)
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        N = out["labels"].numel()
+        peaks[mode] = (torch.cuda.max_memory_allocated() - base, 4 * N * V, float(out["loss"].detach()))
+        del model, out
+    (pf, logits_bytes, lf), (pm, _, lm) = peaks["fused"], peaks["materialize"]
+    assert logits_bytes > 2e9                                   # the test is about a tensor worth avoiding
+    assert pm > logits_bytes                                    # the materialised path holds it ...
+    assert pf < 0.25 * logits_bytes, (pf, logits_bytes)         # ... the fused one never does
+    assert abs(lf - lm) < 1e-5
+    t = tr.NextItemPredictionTask()
+    assert t.resolve_head_mode(2765, 100_001) == "materialize" and t.resolve_head_mode(15_360, 10_000_001) == "fused"
+    monkeypatch.setenv("T4R_HEAD_MODE", "fused")
+    assert t.resolve_head_mode(10, 10) == "fused"
+
+
+def _gpt2_oracle_params(sd):
+    return O.gpt2_params_from_state({k: v.clone().requires_grad_() for k, v in sd.items()
+                                     if k.startswith("heads.0.body.1.transformer.")}, "heads.0.body.1.transformer.")
+
+
+def test_c4_full_size_step_vs_oracle():
+    """BASELINE.json configs[3] at FULL size on one GPU's share: GPT-2 d_model 256, 6 layers, 1 M items, seq 50,
+    batch 1024, causal LM, sampled softmax (100 negatives, log-uniform), tied weights.  One training step (dropout 0)
+    on the HIP path vs the CPU oracle with the same negatives: loss, labels, table gradient, a layer gradient."""
+    import transformers4rec_amd as tr
+
+    torch.manual_seed(0)
+    torch.set_num_threads(32)
+    B, L, V, D, NH, NL = 1024, 50, 1_000_000, 256, 4, 6
+    schema = tr.session_schema(V, L)
+    inputs = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=L, masking="clm", embedding_dim_default=D)
+    cfg = tr.GPT2Config.build(D, NH, NL, total_seq_length=L, dropout=0.0)
+    model = cfg.to_torch_model(inputs, tr.NextItemPredictionTask(weight_tying=True, sampled_softmax=True, max_n_samples=100))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(DEV)
+    data = tr.random_data_from_schema(schema, B, L, seed=21)
+    sampler = model.prediction_task.pre.module.sampler
+    torch.manual_seed(3)
+    neg = sampler.sample(torch.ones(4, dtype=torch.long, device=DEV))
+    sampler.sample = lambda labels: neg
+    out = model({k: v.to(DEV) for k, v in data.items()}, training=True)
+    out["loss"].backward()
+    ids = data["item_id"]
+    mask, labels = O.clm_targets(ids, True, False)
+    m = model.input_features.masking
+    assert torch.equal(m.mask_schema.cpu(), mask) and torch.equal(m.masked_targets.cpu(), labels)   # integer work: exact
+    # oracle: lookup -> CLM input masking -> GPT-2 -> label rows -> sampled logits -> CE
+    table = sd["heads.0.body.0.to_merge.categorical_module.embedding_tables.item_id.weight"].clone().requires_grad_()
+    memb = sd["heads.0.body.0._masking.masked_item_embedding"].clone().requires_grad_()
+    P = _gpt2_oracle_params(sd)
+    x = O.apply_mask_clm(O.embedding_lookup(ids, table), mask, memb, True, False)
+    h = O.gpt2_model(x, P, NH)
+    xr, y = O.remove_pad_rows(h, labels)
+    dist = O.unique_sampling_dist(O.log_uniform_dist(V + 1, 1), 200)
+    close(sampler.unique_sampling_dist, dist, rtol=1e-6, atol=1e-12)
+    logits = O.sampled_logits(xr, y, table, neg.cpu(), dist, 1.0)
+    loss = O.cross_entropy(logits, torch.zeros_like(y))
+    loss.backward()
+    assert out["labels"].numel() == y.numel() and y.numel() > 20_000
+    assert abs(float(out["loss"].detach()) - float(loss)) < 1e-4
+    assert float((out["predictions"].detach().cpu() - logits.detach()).abs().max()) < 1e-3
+    g_hip = model.input_features.item_embedding_table.weight.grad.cpu()
+    close(g_hip, table.grad, rtol=1e-3, atol=2e-7)
+    close(g_hip.sum(0), table.grad.sum(0), rtol=1e-3, atol=1e-6)
+    blk = model.transformer_block.transformer.h[0]
+    close(blk.mlp.c_fc.weight.grad, P["blocks"][0]["c_fc_w"].grad, rtol=2e-3, atol=2e-7)
+    close(model.transformer_block.transformer.wpe.weight.grad[:L], P["wpe"].grad[:L], rtol=2e-3, atol=2e-7)
+    close(m.masked_item_embedding.grad, memb.grad, rtol=2e-3, atol=2e-7)
+
+
+def _bert_c5_model(tr, V, L, D, NH, NL, device=None):
+    schema = tr.session_schema(V, L)
+    ctx = torch.device(device) if device else torch.device("cpu")
+    with ctx:
+        inputs = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=L, masking="mlm", embedding_dim_default=D)
+        cfg = tr.BertConfig.build(D, NH, NL, total_seq_length=L, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+        model = cfg.to_torch_model(inputs, tr.NextItemPredictionTask(weight_tying=True, head_mode="fused"))
+    return model, schema
+
+
+def test_c5_reduced_vocab_parity_vs_oracle():
+    """BASELINE.json configs[4] body (BERT d_model 512, 12 layers, 8 heads, seq 100, MLM, tied full softmax) at a
+    CPU-checkable size (1 M items, batch 64): one training step on the non-materialising head vs the oracle."""
+    import transformers4rec_amd as tr
+
+    torch.manual_seed(0)
+    torch.set_num_threads(32)
+    B, L, V, D, NH, NL = 64, 100, 1_000_000, 512, 8, 12
+    model, schema = _bert_c5_model(tr, V, L, D, NH, NL)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(DEV)
+    data = tr.random_data_from_schema(schema, B, L, seed=5)
+    out = model({k: v.to(DEV) for k, v in data.items()}, training=True)
+    out["loss"].backward()
+    m = model.input_features.masking
+    mask, labels = m.mask_schema.cpu(), m.masked_targets.cpu()
+    ids = data["item_id"]
+    assert torch.equal(labels, torch.where(mask, ids, torch.zeros_like(ids)))
+    table = sd["heads.0.body.0.to_merge.categorical_module.embedding_tables.item_id.weight"].clone().requires_grad_()
+    memb = sd["heads.0.body.0._masking.masked_item_embedding"].clone().requires_grad_()
+    pre = "heads.0.body.1.transformer."
+    P = O.bert_params_from_state({k: v.clone().requires_grad_() for k, v in sd.items() if k.startswith(pre)}, pre)
+    x = O.apply_mask_mlm(O.embedding_lookup(ids, table), mask, memb, True, False)
+    h = O.bert_model(x, P, NH, 0.03)
+    xr, y = O.remove_pad_rows(h, labels)
+    loss = O.cross_entropy(O.head_logits(xr, table, 1.0), y)
+    loss.backward()
+    assert torch.equal(out["labels"].cpu(), y)
+    assert abs(float(out["loss"].detach()) - float(loss)) < 1e-4
+    g_hip = model.input_features.item_embedding_table.weight.grad.cpu()
+    close(g_hip, table.grad, rtol=1e-3, atol=2e-7)
+    close(g_hip.sum(0), table.grad.sum(0), rtol=1e-3, atol=2e-6)
+    lay = model.transformer_block.transformer.encoder.layer[0]
+    close(m.masked_item_embedding.grad, memb.grad, rtol=2e-3, atol=2e-7)
+    close(lay.intermediate.dense.weight.grad, P["layers"][0]["i_w"].grad, rtol=2e-3, atol=2e-7)
+    close(model.transformer_block.transformer.embeddings.position_embeddings.weight.grad[:L], P["pos"].grad[:L],
+          rtol=2e-3, atol=2e-7)
+
+
+def test_c5_full_vocabulary_step_runs():
+    """C5 at its vocabulary: 10 M items x 512 (20 GB fp32 table), 12-layer BERT, seq 100 -- one fwd+bwd step on the
+    non-materialising head (the [N, V] logits would be 4 * N * 10^7 bytes: 150 GB at this batch of 256).  Checks
+    what is size-independent: loss ~ ln V at init, softmax rows sum to one => the head's table gradient columns
+    sum to zero, i.e. sum_v dW[v, :] equals the lookup scatter alone; peak memory far below the logits."""
+    import transformers4rec_amd as tr
+
+    torch.manual_seed(0)
+    B, L, V, D, NH, NL = 256, 100, 10_000_000, 512, 8, 12
+    model, schema = _bert_c5_model(tr, V, L, D, NH, NL, device=DEV)
+    model.train()
+    batch = tr.random_data_from_schema(schema, B, L, seed=9, device=DEV)
+    cap = {}
+    def grab(mod, i, o):        # (a forward hook's return value would replace the output)
+        o.register_hook(lambda gr: cap.__setitem__("d_emb", gr.detach().clone()))
+
+    model.input_features.register_forward_hook(grab)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    out = model(batch, training=True)
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    N = out["labels"].numel()
+    peak = torch.cuda.max_memory_allocated() - base
+    assert N > 2000 and abs(float(out["loss"].detach()) - np.log(V + 1)) < 0.3
+    table = model.input_features.item_embedding_table.weight
+    assert peak < 4.0 * table.numel() * 4 and peak < 0.5 * 4.0 * N * V, (peak, 4.0 * N * V)
+    g = table.grad
+    assert torch.isfinite(g).all()
+    # checksum of checksums: rows of (softmax - onehot) sum to zero, so the head's dW columns sum to zero and
+    # sum_v g[v, :] is the lookup scatter alone = sum of d loss / d inputs_embeds over the positions whose
+    # embedding reached the body (non-pad, not replaced by the [MASK] vector)
+    ids, mask = batch["item_id"], model.input_features.masking.mask_schema
+    want = cap["d_emb"][(ids != 0) & ~mask].double().sum(0)
+    got = g.double().sum(0)
+    assert float(g.abs().max()) > 0
+    assert float((got - want).abs().max()) < 1e-2 * float(want.abs().max()) + 1e-6, (got[:4], want[:4])

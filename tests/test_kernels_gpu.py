@@ -861,3 +861,32 @@ def test_embedding_bwd_sorted_is_exact_and_deterministic(ops, n, rows, dim, W, c
     scale = max(1.0, float(ref.abs().max()))
     assert float(err) <= 2e-6 * scale * max(1, (n // rows) ** 0.5), float(err)
     assert torch.equal(outs[0][0], base[0]), "the padding row received gradient"
+
+
+# ------------------------------------------------------------------------------------ non-materialising head
+@pytest.mark.parametrize("N,V,D,eps,chunk", [(37, 1001, 64, 0.0, 256), (130, 5003, 128, 0.1, 1024),
+                                              (64, 3000, 32, 0.0, None), (5, 777, 16, 0.2, 64)])
+def test_linear_softmax_ce_fused_fwd_bwd(ops, N, V, D, eps, chunk):
+    """chunk-streamed linear + softmax-CE (no [N, V] tensor) == torch autograd of F.cross_entropy(x @ W^T / T),
+    including label smoothing, temperature, labels in the first / last chunk and a ragged last chunk."""
+    g = torch.Generator().manual_seed(N * 7 + V)
+    x = torch.randn(N, D, generator=g).requires_grad_()
+    W = (0.3 * torch.randn(V, D, generator=g)).requires_grad_()
+    y = torch.randint(0, V, (N,), generator=g)
+    y[0], y[-1] = 0, V - 1
+    T = 0.7
+    loss = torch.nn.functional.cross_entropy((x @ W.t()) / T, y, label_smoothing=eps)
+    (loss * 1.3).backward()
+    lh, rows, lse = ops.linear_softmax_ce_fwd(cu(x.detach()), cu(W.detach()), cu(y), 1 / T, eps, chunk_cols=chunk)
+    assert abs(float(lh) - float(loss)) < 2e-6 * max(1.0, abs(float(loss)))
+    close(lse, torch.logsumexp((x @ W.t()).detach() / T, 1), rtol=1e-6, atol=2e-6)
+    close(rows.mean(), loss.detach(), rtol=1e-6, atol=2e-6)
+    dW = torch.ones(V, D, device=DEV)
+    dx = ops.linear_softmax_ce_bwd(cu(x.detach()), cu(W.detach()), cu(y), lse, torch.tensor(1.3, device=DEV), dW=dW,
+                                   alpha=1 / T, label_smoothing=eps, chunk_cols=chunk)
+    close(dx, x.grad, rtol=1e-4, atol=1e-6)
+    close(dW - 1, W.grad, rtol=1e-4, atol=2e-6)
+    # same bits as the materialised pipeline's statistics (the chunks come from the same GEMM)
+    logits = ops.gemm(cu(x.detach()), cu(W.detach()), False, True, alpha=1 / T, ldc=ops.pad_ld(V))
+    _, _, lse_m = ops.softmax_ce_fwd(logits, cu(y), V, eps)
+    close(lse, lse_m, rtol=0, atol=2e-6)

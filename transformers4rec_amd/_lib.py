@@ -61,6 +61,9 @@ _SIGS = {
     "t4r_xlnet_layer_bwd": ("i", "ppppppppp" + "iiiif" + "fQQi"),
     "t4r_softmax_ce_fwd": ("i", "pppppp" + "iilf"),
     "t4r_softmax_ce_bwd": ("i", "pppppp" + "iilf"),
+    "t4r_linear_softmax_ce_chunk_floats": ("l", "ii"),
+    "t4r_linear_softmax_ce_fwd": ("i", "pplpl" + "p" + "iiiffi" + "ppppp"),
+    "t4r_linear_softmax_ce_bwd": ("i", "pplpl" + "ppp" + "iiiffi" + "pplpl"),
     "t4r_sampled_logits_fwd": ("i", "ppppppp" + "iiif"),
     "t4r_sampled_logits_bwd": ("i", "ppppppppp" + "iiif"),
     "t4r_topk": ("i", "pp" + "iili" + "pp"),

@@ -62,6 +62,7 @@ struct GemmParams {
     const long* sg_labels;
     const float* sg_gout;       // device scalar (d loss), may be null (=1)
     int sg_rows, sg_V;
+    int sg_yoff;                // column of the FIRST logit of A in the vocabulary (chunk-streamed head): label - sg_yoff is A's column
     float sg_smooth;
     // rank-of-target epilogue (FEAT bit 2; fused eval head): nothing is stored; for every output row
     // the workgroup counts the columns that beat the row's target score,
@@ -240,11 +241,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             if (TA) {
                 const int k = idx / (BM / 4), m4 = (idx % (BM / 4)) * 4;
                 const int gk = k0 + k, gm = m0 + m4;
-                ra[r] = softmax_grad4(ra[r], sgl[r], (int)sgy[r], gm, sg_g, p);
+                ra[r] = softmax_grad4(ra[r], sgl[r], (int)(sgy[r] - p.sg_yoff), gm, sg_g, p);
             } else {
                 const int m = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
                 const int gm = m0 + m, gk = k0 + k4;
-                ra[r] = softmax_grad4(ra[r], sgl[r], (int)sgy[r], gk, sg_g, p);
+                ra[r] = softmax_grad4(ra[r], sgl[r], (int)(sgy[r] - p.sg_yoff), gk, sg_g, p);
             }
         }
     };
@@ -605,7 +606,7 @@ static int launch_layout(GemmParams& p, int batch, int splitk_req, hipStream_t s
     return launch_cfg<64, 64, 32, TA, TB>(p, batch, stream);
 }
 
-struct SoftmaxGradA { const float* lse; const long* labels; const float* gout; int rows, V; float smooth; };
+struct SoftmaxGradA { const float* lse; const long* labels; const float* gout; int rows, V; float smooth; int yoff; };
 static thread_local const SoftmaxGradA* g_sg = nullptr;   // set only by t4r_gemm_softmax_grad_f32
 struct RankEpi { const float* thr; const long* label; int* count; };
 static thread_local const RankEpi* g_rank = nullptr;      // set only by t4r_rank_of_target_f32
@@ -626,12 +627,12 @@ int t4r_gemm_launch(hipStream_t stream, int transA, int transB, int M, int N, in
     p.vecB = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0) && (sB % 4 == 0);
     p.splitk = 1;
     p.drop = drop ? *drop : make_drop(0.f, 0, 0);
-    p.sg_lse = nullptr; p.sg_labels = nullptr; p.sg_gout = nullptr; p.sg_rows = 1; p.sg_V = 1; p.sg_smooth = 0.f;
+    p.sg_lse = nullptr; p.sg_labels = nullptr; p.sg_gout = nullptr; p.sg_rows = 1; p.sg_V = 1; p.sg_smooth = 0.f; p.sg_yoff = 0;
     p.rk_thr = nullptr; p.rk_label = nullptr; p.rk_count = nullptr;
     if (g_rank) { p.rk_thr = g_rank->thr; p.rk_label = g_rank->label; p.rk_count = g_rank->count; }
     if (g_sg) {
         p.sg_lse = g_sg->lse; p.sg_labels = g_sg->labels; p.sg_gout = g_sg->gout;
-        p.sg_rows = g_sg->rows; p.sg_V = g_sg->V; p.sg_smooth = g_sg->smooth;
+        p.sg_rows = g_sg->rows; p.sg_V = g_sg->V; p.sg_smooth = g_sg->smooth; p.sg_yoff = g_sg->yoff;
     }
     if (transA) {
         if (transB) return launch_layout<true, true>(p, batch, splitk, stream);
@@ -659,20 +660,30 @@ extern "C" int t4r_gemm_f32(void* stream, int transA, int transB, int M, int N, 
 // where dlogits = (*grad_out / N_rows) * (softmax(logits) - target) is formed from `logits`,
 // `lse` and `labels` while the tile is staged.  Replaces model/prediction_task.py:446 (loss
 // backward through CrossEntropyLoss) + the autograd of :664.
+// logits holds the columns [yoff, yoff + Vc) of the full [n_rows, V] logits (Vc = V, yoff = 0: all of them);
+// the label-smoothing term eps / V and the mean 1 / n_rows refer to the full problem.
+int t4r_gemm_softmax_grad_launch(hipStream_t stream, int transA, int n_rows, int Vc, int V, int yoff, int N,
+                                 float alpha, const float* logits, long ld_logits, const float* lse,
+                                 const long* labels, const float* grad_out, float label_smoothing, const float* B,
+                                 long ldb, float* C, long ldc, int splitk, int accumulate) {
+    T4R_CHECK_ARG(lse && labels && logits, "gemm_softmax_grad: null operand");
+    SoftmaxGradA sg{lse, labels, grad_out, n_rows, V, label_smoothing, yoff};
+    g_sg = &sg;
+    const int M = transA ? Vc : n_rows, K = transA ? n_rows : Vc;
+    const int rc = t4r_gemm_launch(stream, transA, 0, M, N, K, alpha, logits, ld_logits, B, ldb,
+                                   C, ldc, nullptr, EPI_NONE, nullptr, 0, splitk, accumulate, 1, 0, 0, 0,
+                                   nullptr);
+    g_sg = nullptr;
+    return rc;
+}
+
 extern "C" int t4r_gemm_softmax_grad_f32(void* stream, int transA, int n_rows, int V, int N, float alpha,
                                          const float* logits, long ld_logits, const float* lse,
                                          const long* labels, const float* grad_out, float label_smoothing,
                                          const float* B, long ldb, float* C, long ldc, int splitk,
                                          int accumulate) {
-    T4R_CHECK_ARG(lse && labels && logits, "gemm_softmax_grad: null operand");
-    SoftmaxGradA sg{lse, labels, grad_out, n_rows, V, label_smoothing};
-    g_sg = &sg;
-    const int M = transA ? V : n_rows, K = transA ? n_rows : V;
-    const int rc = t4r_gemm_launch((hipStream_t)stream, transA, 0, M, N, K, alpha, logits, ld_logits, B, ldb,
-                                   C, ldc, nullptr, EPI_NONE, nullptr, 0, splitk, accumulate, 1, 0, 0, 0,
-                                   nullptr);
-    g_sg = nullptr;
-    return rc;
+    return t4r_gemm_softmax_grad_launch((hipStream_t)stream, transA, n_rows, V, V, 0, N, alpha, logits, ld_logits,
+                                        lse, labels, grad_out, label_smoothing, B, ldb, C, ldc, splitk, accumulate);
 }
 
 // Fused eval head: rank of the target item among alpha * X @ W^T without materialising

@@ -451,3 +451,161 @@ extern "C" int t4r_topk(void* stream, const float* scores, int N, int V, long ld
     T4R_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------
+// Non-materialising head: linear (tied / untied output projection) + softmax cross-entropy without
+// an [N, V] logits tensor.  Replaces prediction_task.py:664-669 (X @ W^T, / T) + :446 (CrossEntropyLoss)
+// and their autograd when `predictions` are not asked for -- the only form that can run C5
+// (15 k label rows x 10 M items = 600 GB of logits).
+//
+// The vocabulary is streamed in chunks of `chunk_cols` columns through ONE [N, chunk] buffer sized to
+// stay in the 256 MB Infinity Cache: the chunk's logits are produced by the same fp32 MFMA GEMM as the
+// materialised head (bit-identical values), consumed by an online (max, sum-exp) update, and dropped.
+// The backward recomputes each chunk (one extra GEMM: 4 instead of 3 vocabulary-wide products) and feeds
+// it to the two gradient contractions whose A operand forms the softmax gradient on the fly
+// (t4r_gemm_softmax_grad_launch): neither the logits nor their gradient ever exist at [N, V].
+//   stats: m[N] | s[N] | tot[N] | tgt[N]   (running max, sum exp(x - m), sum x, logit of the label)
+int t4r_gemm_launch(hipStream_t stream, int transA, int transB, int M, int N, int K, float alpha,
+                    const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+                    const float* bias, int epilogue, float* aux, long ldaux, int splitk,
+                    int accumulate, int batch, long sA, long sB, long sC, const DropCfg* drop);
+int t4r_gemm_softmax_grad_launch(hipStream_t stream, int transA, int n_rows, int Vc, int V, int yoff, int N,
+                                 float alpha, const float* logits, long ld_logits, const float* lse,
+                                 const long* labels, const float* grad_out, float label_smoothing, const float* B,
+                                 long ldb, float* C, long ldc, int splitk, int accumulate);
+
+// one workgroup per row: online softmax statistics of the chunk's Vc columns merged into the running ones
+__global__ __launch_bounds__(256) void ce_chunk_stats_kernel(const float* __restrict__ chunk, long ld, int Vc,
+                                                              int v0, const long* __restrict__ labels,
+                                                              float* __restrict__ stats, int N, int first) {
+    const int row = blockIdx.x;
+    const float* x = chunk + (long)row * ld;
+    float m = -INFINITY, s = 0.f, tot = 0.f;
+    const int v4 = Vc / 4;                      // ld % 4 == 0 and the buffer is 16-byte aligned (host checks)
+    int i = threadIdx.x;
+    for (; i + 768 < v4; i += 1024) {
+        float4 t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const float4*>(x + 4 * (i + 256 * u));
+        float mx = m;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mx = fmaxf(mx, fmaxf(fmaxf(t[u].x, t[u].y), fmaxf(t[u].z, t[u].w)));
+        float e = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            e += (__expf(t[u].x - mx) + __expf(t[u].y - mx)) + (__expf(t[u].z - mx) + __expf(t[u].w - mx));
+            tot += (t[u].x + t[u].y) + (t[u].z + t[u].w);
+        }
+        s = s * __expf(m - mx) + e;
+        m = mx;
+    }
+    for (; i < v4; i += 256) {
+        const float4 t = *reinterpret_cast<const float4*>(x + 4 * i);
+        const float mx = fmaxf(fmaxf(t.x, t.y), fmaxf(t.z, t.w));
+        const float mn = fmaxf(m, mx);
+        s = s * __expf(m - mn) + __expf(t.x - mn) + __expf(t.y - mn) + __expf(t.z - mn) + __expf(t.w - mn);
+        m = mn;
+        tot += t.x + t.y + t.z + t.w;
+    }
+    for (int k = v4 * 4 + threadIdx.x; k < Vc; k += 256) {
+        const float t = x[k];
+        const float mn = fmaxf(m, t);
+        s = s * __expf(m - mn) + __expf(t - mn);
+        m = mn;
+        tot += t;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+        online_merge(m, s, m2, s2);
+        tot += __shfl_xor(tot, o, 64);
+    }
+    __shared__ float sm[4], ss[4], st[4];
+    if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = m; ss[threadIdx.x >> 6] = s; st[threadIdx.x >> 6] = tot; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) { online_merge(m, s, sm[w], ss[w]); tot += st[w]; }
+        float* pm = stats + row; float* ps = stats + N + row; float* pt = stats + 2L * N + row; float* pg = stats + 3L * N + row;
+        if (!first) { online_merge(m, s, *pm, *ps); tot += *pt; }
+        *pm = m; *ps = s; *pt = tot;
+        const long y = labels[row] - v0;
+        if (y >= 0 && y < Vc) *pg = x[y];
+    }
+}
+
+__global__ __launch_bounds__(256) void ce_finalize_kernel(const float* __restrict__ stats, float* __restrict__ loss_row,
+                                                           float* __restrict__ lse_out, int N, int V, float smoothing) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= N) return;
+    const float lse = stats[row] + __logf(stats[N + row]);
+    float loss = lse - stats[3L * N + row];
+    if (smoothing > 0.f) loss = (1.f - smoothing) * loss + smoothing * (lse - stats[2L * N + row] / V);
+    loss_row[row] = loss;
+    lse_out[row] = lse;
+}
+
+static long chunk_ld(int c) { return ((long)c + 63) / 64 * 64; }     // rows on 256-byte boundaries (as ops.pad_ld)
+
+// floats of the [N, chunk] logits buffer both passes stream the vocabulary through
+extern "C" long t4r_linear_softmax_ce_chunk_floats(int N, int chunk_cols) {
+    return (long)N * chunk_ld(chunk_cols);
+}
+
+// loss_rows[N], lse[N], *loss_mean = mean CE of softmax(alpha * X @ W^T) against labels.
+// chunk_buf: t4r_linear_softmax_ce_chunk_floats(N, chunk_cols) floats, 16-byte aligned; stats: 4*N floats.
+// Every label must be in [0, V).
+extern "C" int t4r_linear_softmax_ce_fwd(void* stream, const float* X, long ldx, const float* W, long ldw,
+                                         const long* labels, int N, int V, int D, float alpha,
+                                         float label_smoothing, int chunk_cols, float* chunk_buf, float* stats,
+                                         float* loss_rows, float* lse, float* loss_mean) {
+    if (N <= 0) return 0;
+    T4R_CHECK_ARG(X && W && labels && chunk_buf && stats && loss_rows && lse, "linear_softmax_ce_fwd: null pointer");
+    T4R_CHECK_ARG(chunk_cols >= 4 && chunk_cols % 4 == 0, "linear_softmax_ce_fwd: chunk_cols must be a multiple of 4");
+    T4R_CHECK_ARG((uintptr_t)chunk_buf % 16 == 0, "linear_softmax_ce_fwd: chunk buffer must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const long ld = chunk_ld(chunk_cols);
+    for (int v0 = 0; v0 < V; v0 += chunk_cols) {
+        const int vc = V - v0 < chunk_cols ? V - v0 : chunk_cols;
+        const int rc = t4r_gemm_launch(st, 0, 1, N, vc, D, alpha, X, ldx, W + (long)v0 * ldw, ldw, chunk_buf, ld,
+                                       nullptr, 0, nullptr, 0, 1, 0, 1, 0, 0, 0, nullptr);
+        if (rc != 0) return rc;
+        hipLaunchKernelGGL(ce_chunk_stats_kernel, dim3(N), dim3(256), 0, st, chunk_buf, ld, vc, v0, labels, stats, N,
+                           v0 == 0 ? 1 : 0);
+    }
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3((N + 255) / 256), dim3(256), 0, st, stats, loss_rows, lse, N, V,
+                       label_smoothing);
+    if (loss_mean) hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, st, loss_rows, N, loss_mean);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+// backward of the above for a scalar upstream gradient *grad_out (null: 1):
+//   dX[N, D]  = alpha * dlogits @ W          (overwritten)
+//   dW[V, D] += alpha * dlogits^T @ X        (accumulated; null: skipped)
+// with dlogits = (*grad_out / N) * (softmax - (1-eps) onehot - eps/V) recomputed chunk by chunk from `lse`.
+extern "C" int t4r_linear_softmax_ce_bwd(void* stream, const float* X, long ldx, const float* W, long ldw,
+                                         const long* labels, const float* lse, const float* grad_out, int N, int V,
+                                         int D, float alpha, float label_smoothing, int chunk_cols,
+                                         float* chunk_buf, float* dX, long lddx, float* dW, long lddw) {
+    if (N <= 0) return 0;
+    T4R_CHECK_ARG(X && W && labels && lse && chunk_buf && dX, "linear_softmax_ce_bwd: null pointer");
+    T4R_CHECK_ARG(chunk_cols >= 4 && chunk_cols % 4 == 0, "linear_softmax_ce_bwd: chunk_cols must be a multiple of 4");
+    hipStream_t st = (hipStream_t)stream;
+    const long ld = chunk_ld(chunk_cols);
+    for (int v0 = 0; v0 < V; v0 += chunk_cols) {
+        const int vc = V - v0 < chunk_cols ? V - v0 : chunk_cols;
+        int rc = t4r_gemm_launch(st, 0, 1, N, vc, D, alpha, X, ldx, W + (long)v0 * ldw, ldw, chunk_buf, ld,
+                                 nullptr, 0, nullptr, 0, 1, 0, 1, 0, 0, 0, nullptr);
+        if (rc != 0) return rc;
+        // d X (+)= dlogits_chunk @ W[v0 : v0 + vc]      (split-K over the chunk's columns)
+        rc = t4r_gemm_softmax_grad_launch(st, 0, N, vc, V, v0, D, alpha, chunk_buf, ld, lse, labels, grad_out,
+                                          label_smoothing, W + (long)v0 * ldw, ldw, dX, lddx, -1, v0 == 0 ? 0 : 1);
+        if (rc != 0) return rc;
+        if (dW) {   // d W[v0 : v0 + vc] += dlogits_chunk^T @ X
+            rc = t4r_gemm_softmax_grad_launch(st, 1, N, vc, V, v0, D, alpha, chunk_buf, ld, lse, labels, grad_out,
+                                              label_smoothing, X, ldx, dW + (long)v0 * lddw, lddw, 1, 1);
+            if (rc != 0) return rc;
+        }
+    }
+    return 0;
+}

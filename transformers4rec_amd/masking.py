@@ -76,6 +76,7 @@ class MaskSequence(SeedMixin, nn.Module):
         # label compaction cache for the prediction head (filled by compute_masked_targets)
         self._row_count = None
         self._compact = None
+        self._n_host = None
 
     # ---- parity hook: replay recorded torch.bernoulli / torch.multinomial draws once
     def set_draws(self, bern=None, j1=None, j2=None):
@@ -101,7 +102,26 @@ class MaskSequence(SeedMixin, nn.Module):
             self._rng_offset += item_ids.numel()
         self.mask_schema, self.masked_targets = mask, labels
         self._row_count, self._compact = counts, None
+        self._n_host = None
+        if mode not in (ops.MLM_INFER, ops.CLM_INFER):
+            # the head needs the number of label rows ON THE HOST (it shapes the compacted operands).  Compact
+            # now and start the 4-byte copy: it completes while the host is still enqueueing the transformer,
+            # so n_labels() at the head does not drain the device queue (a mid-step `.item()` would)
+            n, _, _ = self.compact_labels()
+            host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            host.copy_(n, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._n_host = (host, ev)
         return MaskingInfo(mask, labels)
+
+    def n_labels(self) -> int:
+        """number of label rows of the last compute_masked_targets (train / eval modes), on the host"""
+        if self._n_host is None:
+            return int(self.compact_labels()[0].item())
+        host, ev = self._n_host
+        ev.synchronize()
+        return int(host[0])
 
     def compact_labels(self):
         """(n_labels [1] i32, label_pos [B*L] i32, labels [B*L] i64) in remove_pad_3d order."""

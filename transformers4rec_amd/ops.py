@@ -495,6 +495,47 @@ def softmax_ce_bwd(logits, labels, lse, grad_out, V, label_smoothing=0.0):
     return buf
 
 
+_CHUNK_BYTES = int(__import__("os").environ.get("T4R_HEAD_CHUNK_MB", "96")) << 20
+
+
+def head_chunk_cols(N, V):
+    """columns per vocabulary chunk of the non-materialising head: the [N, chunk] logits buffer stays
+    inside the 256 MB Infinity Cache (default 96 MB), a multiple of 1024 columns, at most V rounded up"""
+    c = max(1024, (_CHUNK_BYTES // (4 * max(N, 1))) // 1024 * 1024)
+    return int(min(c, (V + 1023) // 1024 * 1024))
+
+
+def linear_softmax_ce_fwd(x, W, labels, alpha=1.0, label_smoothing=0.0, chunk_cols=None):
+    """mean CE of softmax(alpha * x @ W^T) vs labels without an [N, V] tensor -> (loss, loss_rows, lse)"""
+    N, D = x.shape
+    V = W.shape[0]
+    c = chunk_cols or head_chunk_cols(N, V)
+    dev = x.device
+    buf = torch.empty(_lib.load().t4r_linear_softmax_ce_chunk_floats(N, c), device=dev, dtype=torch.float32)
+    stats = torch.empty(4 * N, device=dev, dtype=torch.float32)
+    loss_rows = torch.empty(N, device=dev, dtype=torch.float32)
+    lse = torch.empty(N, device=dev, dtype=torch.float32)
+    loss = torch.empty((), device=dev, dtype=torch.float32)
+    call("t4r_linear_softmax_ce_fwd", _stream(), _chk(x, torch.float32), x.stride(0), W.data_ptr(), W.stride(0),
+         _chk(labels, torch.int64), N, V, D, float(alpha), float(label_smoothing), c, buf.data_ptr(),
+         stats.data_ptr(), loss_rows.data_ptr(), lse.data_ptr(), loss.data_ptr())
+    return loss, loss_rows, lse
+
+
+def linear_softmax_ce_bwd(x, W, labels, lse, grad_out, dW=None, alpha=1.0, label_smoothing=0.0, chunk_cols=None):
+    """-> dx [N, D]; dW [V, D] is accumulated into when given"""
+    N, D = x.shape
+    V = W.shape[0]
+    c = chunk_cols or head_chunk_cols(N, V)
+    buf = torch.empty(_lib.load().t4r_linear_softmax_ce_chunk_floats(N, c), device=x.device, dtype=torch.float32)
+    dx = torch.empty((N, D), device=x.device, dtype=torch.float32)
+    call("t4r_linear_softmax_ce_bwd", _stream(), _chk(x, torch.float32), x.stride(0), W.data_ptr(), W.stride(0),
+         _chk(labels, torch.int64), _chk(lse, torch.float32), _p(grad_out), N, V, D, float(alpha),
+         float(label_smoothing), c, buf.data_ptr(), dx.data_ptr(), D,
+         None if dW is None else _chk(dW, torch.float32), 0 if dW is None else dW.stride(0))
+    return dx
+
+
 def sampled_logits_fwd(x, labels, W, neg, dist, temperature=1.0):
     N, D = x.shape
     S = neg.numel()

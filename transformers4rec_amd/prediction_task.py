@@ -116,13 +116,22 @@ class _NextItemHeadFn(torch.autograd.Function):
         if lin is not None:
             xp = ops.gemm(xr, lin.weight.detach(), False, True, bias=lin.bias.detach(), epilogue=ops.EPI_BIAS)
         V = W.shape[0]
+        smooth = float(getattr(task.loss, "label_smoothing", 0.0) or 0.0)
+        ctx.fused = neg is None and task.resolve_head_mode(N, V) == "fused"
+        if ctx.fused:
+            # non-materialising head: the vocabulary streams through one cache-sized [N, chunk] buffer,
+            # online softmax statistics forward, chunk recomputation backward (csrc/head.hip)
+            loss, _rows, lse = ops.linear_softmax_ce_fwd(xp, W.detach(), labels, 1.0 / T, smooth)
+            ctx.task, ctx.neg, ctx.meta = task, None, (B, L, D, N, V, T, V, smooth)
+            ctx.save_for_backward(pos, labels, labels, xr, xp, lse, lse)
+            ctx.set_materialize_grads(False)
+            return loss, None
         if neg is None:
             logits = ops.gemm(xp, W.detach(), False, True, alpha=1.0 / T, ldc=ops.pad_ld(V))
             tgt, width = labels, V
         else:
             logits = ops.sampled_logits_fwd(xp, labels, W.detach(), neg, mod.sampler.correction_dist, T)
             tgt, width = torch.zeros_like(labels), logits.shape[1]
-        smooth = float(getattr(task.loss, "label_smoothing", 0.0) or 0.0)
         loss, _rows, lse = ops.softmax_ce_fwd(logits, tgt, width, smooth)
         ctx.task, ctx.neg, ctx.meta = task, neg, (B, L, D, N, V, T, width, smooth)
         ctx.save_for_backward(pos, labels, tgt, xr, xp, logits, lse)
@@ -141,7 +150,11 @@ class _NextItemHeadFn(torch.autograd.Function):
         W = mod.output_weights
         if dloss is None:
             return (None,) * 7
-        if ctx.neg is None:
+        if ctx.fused:
+            dxp = ops.linear_softmax_ce_bwd(xp, W.detach(), labels, lse, dloss.contiguous(),
+                                            dW=_grad_buf(W) if W.requires_grad else None, alpha=1.0 / T,
+                                            label_smoothing=smooth)
+        elif ctx.neg is None:
             # CrossEntropyLoss backward is fused into the A operand of both contractions:
             # the [N_m, V] gradient is never materialised
             g = dloss.contiguous()
@@ -185,14 +198,69 @@ class _NextItemHeadFn(torch.autograd.Function):
         return dx.view(B, L, D), None, None, None, None, None, None
 
 
+class LazyPredictions:
+    """`predictions` of the non-materialising head: the [N, V] logits are computed (one GEMM) the first
+    time anything looks at them -- `.materialize()`, any tensor attribute / method, indexing, or any
+    torch function taking this object -- and cached.  Shape / dtype / device are known without computing."""
+
+    def __init__(self, compute, shape, device):
+        self._compute, self._value = compute, None
+        self.shape, self.device, self.dtype = torch.Size(shape), device, torch.float32
+
+    def materialize(self):
+        if self._value is None:
+            self._value = self._compute()
+            self._compute = None
+        return self._value
+
+    @property
+    def is_materialized(self):
+        return self._value is not None
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def dim(self):
+        return len(self.shape)
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, idx):
+        return self.materialize()[idx]
+
+    def __getattr__(self, name):         # only reached for names not defined above: tensor methods
+        if name.startswith("__") or name in ("_compute", "_value"):
+            raise AttributeError(name)
+        return getattr(self.materialize(), name)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        un = lambda a: a.materialize() if isinstance(a, LazyPredictions) else a
+        args = tuple(un(a) for a in args)
+        kwargs = {k: un(v) for k, v in (kwargs or {}).items()}
+        return func(*args, **kwargs)
+
+    def __repr__(self):
+        state = "materialized" if self.is_materialized else "not computed"
+        return f"LazyPredictions(shape={tuple(self.shape)}, {state})"
+
+
 class NextItemPredictionTask(nn.Module):
     """Drop-in for tr.NextItemPredictionTask on the hot path."""
 
     def __init__(self, loss: nn.Module = None, metrics=None, task_block=None, task_name: str = "next-item",
                  weight_tying: bool = False, softmax_temperature: float = 1, padding_idx: int = 0,
                  target_dim: int = None, sampled_softmax: Optional[bool] = False,
-                 max_n_samples: Optional[int] = 100, top_ks=(10, 20)):
+                 max_n_samples: Optional[int] = 100, top_ks=(10, 20), head_mode: str = "auto"):
         super().__init__()
+        if head_mode not in ("auto", "materialize", "fused"):
+            raise ValueError("head_mode must be 'auto', 'materialize' or 'fused'")
+        # full-softmax training / evaluation head (beyond the reference's signature):
+        #   "materialize": logits [N, V] in HBM, `predictions` is that tensor (what the reference returns)
+        #   "fused"      : no [N, V] tensor; `predictions` is a LazyPredictions that computes them on first use
+        #   "auto"       : materialise while the logits are small (<= T4R_HEAD_AUTO_GB, default 4 GB), else fused
+        self.head_mode = head_mode
         loss = loss if loss is not None else nn.CrossEntropyLoss()
         if not isinstance(loss, nn.CrossEntropyLoss):
             raise NotImplementedError("the HIP head fuses torch.nn.CrossEntropyLoss (optionally label-smoothed)")
@@ -253,6 +321,30 @@ class NextItemPredictionTask(nn.Module):
             self.to(device)
         return self
 
+    def resolve_head_mode(self, N, V):
+        mode = os.environ.get("T4R_HEAD_MODE") or self.head_mode
+        if mode == "auto":
+            limit = float(os.environ.get("T4R_HEAD_AUTO_GB", "4")) * (1 << 30)
+            mode = "materialize" if 4.0 * N * ops.pad_ld(V) <= limit else "fused"
+        return mode
+
+    def _lazy_predictions(self, x, pos, labels, N):
+        mod = self.pre.module
+        W = mod.output_weights
+        T = float(mod.softmax_temperature) if mod.softmax_temperature else 1.0
+        xd = x.detach()
+
+        def compute():
+            B, L, D = xd.shape
+            xr = ops.gather_rows(xd.contiguous().view(B * L, D), pos, N)
+            if self.task_block is not None:
+                lin = self.task_block[0][0]
+                xr = ops.gemm(xr, lin.weight.detach(), False, True, bias=lin.bias.detach(), epilogue=ops.EPI_BIAS)
+            V = W.shape[0]
+            return ops.gemm(xr, W.detach(), False, True, alpha=1.0 / T, ldc=ops.pad_ld(V))[:, :V]
+
+        return LazyPredictions(compute, (N, W.shape[0]), x.device)
+
     # ------------------------------------------------------------------ forward
     def forward(self, inputs, targets=None, training=False, testing=False, top_k=None, **kwargs):
         if isinstance(inputs, (tuple, list)):
@@ -261,13 +353,17 @@ class NextItemPredictionTask(nn.Module):
         mod = self.pre.module
         if training or testing:
             n, pos, lab = self.masking.compact_labels()
-            N = int(n.item())  # host sync: the logits tensor the API returns is [N, V]
+            # N shapes the row-compacted operands; it was copied to the host right after the masking kernel
+            # (masking.n_labels): by now it has long arrived, so this does not drain the queue
+            N = self.masking.n_labels()
             labels = lab[:N]
             if N == 0:
                 raise ValueError("no label positions in this batch")
             neg = mod.sampler.sample(labels) if (self.sampled_softmax and training) else None
             loss, logits = _NextItemHeadFn.apply(x, mod.output_weights, self, pos, labels, N, neg)
-            if neg is None:
+            if logits is None:          # non-materialising head: the logits exist only if somebody asks
+                preds, y = self._lazy_predictions(x, pos, labels, N), labels
+            elif neg is None:
                 preds = logits[:, : mod.output_weights.shape[0]]
                 y = labels
             else:
@@ -334,7 +430,7 @@ class NextItemPredictionTask(nn.Module):
         x = (inputs[0] if isinstance(inputs, (tuple, list)) else inputs).float()
         mod = self.pre.module
         n, pos, lab = self.masking.compact_labels()
-        N = int(n.item())
+        N = self.masking.n_labels()
         if N == 0:
             raise ValueError("no label positions in this batch")
         labels = lab[:N]

@@ -5,11 +5,20 @@
   (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL over xGMI)
 
 A "step" = one full training pass of the hot path over one synthetic batch already resident in
-HBM: masking -> embedding gather -> 4-layer XLNet -> next-item head (tied full softmax, logits
-materialised as the reference returns them) -> backward -> gradient all-reduce -> fused Adam.
+HBM: masking -> embedding gather -> 4-layer XLNet -> next-item head (tied full softmax) ->
+backward -> gradient exchange -> fused Adam.
 Workload = BASELINE.json configs[1]: item vocab 100k, d_model 128, 4 layers, 4 heads, seq 20,
-per-GPU batch 1024 (weak scaling: global batch 1024*N; 8192 at N=8), MLM p=0.15, fp32.
-Prints ONE JSON line on rank 0 (metric/value contract + `roofline` + `cpu_baseline`).
+per-GPU batch 1024 (weak scaling: global batch 1024*N; 8192 at N=8), MLM p=0.15, fp32, every
+reference dropout site active (p = 0.3).
+Prints ONE JSON line on rank 0: the metric/value contract + `roofline` (+ `roofline_gather`) +
+`cpu_baseline` + `recall_at_20` (the other half of BASELINE.json's metric).
+
+Data-parallel wiring (N > 1): the table bucket's dense part (the tied head's d W) is final right after
+the head's backward: its all-reduce is launched there, on its own stream, under the transformer's
+backward; the lookup scatter of the input block travels row-sparse ((ids, rows) all-gather + the
+deterministic sorted scatter on every rank); the small dense bucket is reduced at the end.
+The functions below are importable without a GPU: tests/test_distributed_cpu.py drives
+`make_train_step` / `timed_region` with a stub model over gloo.
 """
 import argparse
 import json
@@ -27,24 +36,86 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 
-def build(device, dropout):
+def rank_seeds(rank):
+    """per-rank Philox keys of the MLM draws and the dropout masks (ranks must not replay each other)"""
+    return 1234 + rank, 4321 + rank
+
+
+def build(device, dropout, v_items=V_ITEMS, d_model=D_MODEL, n_layer=N_LAYER, n_head=N_HEAD, seq=SEQ, lr=1e-3):
     import transformers4rec_amd as tr
 
-    schema = tr.session_schema(V_ITEMS, SEQ)
+    schema = tr.session_schema(v_items, seq)
     torch.manual_seed(0)
-    inputs = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=SEQ, masking="mlm",
-                                                    embedding_dim_default=D_MODEL)
-    cfg = tr.XLNetConfig.build(D_MODEL, N_HEAD, N_LAYER, total_seq_length=SEQ, dropout=dropout)
+    inputs = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=seq, masking="mlm",
+                                                    embedding_dim_default=d_model)
+    cfg = tr.XLNetConfig.build(d_model, n_head, n_layer, total_seq_length=seq, dropout=dropout)
     model = cfg.to_torch_model(inputs, tr.NextItemPredictionTask(weight_tying=True))
     model.to(device)
     dense, tables = tr.flatten_model(model)
-    opt = tr.FusedAdam([dense, tables], lr=1e-3)
+    opt = tr.FusedAdam([dense, tables], lr=lr)
     return tr, schema, model, dense, tables, opt
 
 
-def cpu_baseline(seconds_budget=15.0):
-    """The oracle ("port" of the reference algorithm, plain torch fp32 on the host cores) timed on
-    a bounded sample of the same workload: full V / d_model / layers, smaller batch."""
+def setup_data_parallel(tr, model, dense, tables, world):
+    """-> (reducer, hook handle or None).  N > 1: async table all-reduce after the head's backward + row-sparse
+    exchange of the lookup scatter; N = 1: everything local (the reducer only runs the local scatter)."""
+    sparse = None
+    hook = None
+    if world > 1 or os.environ.get("T4R_BENCH_SPARSE", "0") == "1":
+        sparse = tr.SparseRowExchange()
+        sparse.attach(*[p for _, p, _ in tables.entries])
+    reducer = tr.GradReducer(dense.grad, tables.grad if tables is not None else None, sparse=sparse)
+    if world > 1 and sparse is not None:
+        hook = tr.head_backward_hook(model, reducer.reduce_tables_async)
+    return reducer, hook
+
+
+def make_train_step(model, batches, reducer, opt):
+    def train_step(i):
+        x = batches[i % len(batches)]
+        out = model(x, training=True)
+        out["loss"].backward()          # N > 1: the head-backward hook launches the table all-reduce here
+        reducer.reduce_all()
+        opt.step(grad_scale=reducer.grad_scale)
+        return out
+
+    return train_step
+
+
+def timed_region(train_step, warmup, steps, world, device, first_step=0):
+    """W untimed steps, then EXACTLY K steps bracketed by barrier + device sync, MAX over ranks.
+    -> (seconds, last output, label rows seen)"""
+    import torch.distributed as dist
+
+    sync = torch.cuda.synchronize if torch.device(device).type == "cuda" else (lambda: None)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        sync()
+
+    out = None
+    for i in range(warmup):
+        out = train_step(first_step + i)
+    barrier()
+    t0 = time.perf_counter()
+    n_lab = 0
+    for i in range(steps):
+        out = train_step(first_step + warmup + i)
+        n_lab += out["labels"].numel()
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    return float(tmax.item()), out, n_lab
+
+
+# --------------------------------------------------------------------------------------------- CPU leg
+def cpu_baseline(dropout, seconds_budget=25.0, max_steps=8):
+    """The oracle ("port" of the reference algorithm, plain torch fp32 on the host cores) timed on a bounded
+    sample of the SAME workload: full V / d_model / layers / batch 1024 and the reference's dropout law
+    (one torch.bernoulli mask per dropout site per step, as nn.Dropout draws them on the CPU path)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import t4r_oracle as O
     import transformers4rec_amd as tr
@@ -53,7 +124,7 @@ def cpu_baseline(seconds_budget=15.0):
     # the MI355X host: 32 threads measured best on the GPU box; the count used is reported.
     cores = min(os.cpu_count() or 1, int(os.environ.get("T4R_CPU_BASELINE_THREADS", "32")))
     torch.set_num_threads(cores)
-    B = 256
+    B = BATCH
     g = torch.Generator().manual_seed(0)
     rn = lambda *s, std=0.01: (std * torch.randn(*s, generator=g)).requires_grad_()
     D, n, dh = D_MODEL, N_HEAD, D_MODEL // N_HEAD
@@ -63,12 +134,12 @@ def cpu_baseline(seconds_budget=15.0):
                    w2=rn(D, 4 * D), b2=torch.zeros(D, requires_grad=True),
                    ff_ln_w=torch.ones(D, requires_grad=True), ff_ln_b=torch.zeros(D, requires_grad=True))
               for _ in range(N_LAYER)]
-    params = dict(tables={"item_id": rn(V_ITEMS + 1, D, std=0.05)}, masked_item_embedding=rn(D, std=0.001),
-                  layers=layers, soft={}, proj=None, task_proj=None, output_layer=None)
-    leaves = [params["tables"]["item_id"], params["masked_item_embedding"]] + [t for lp in layers for t in lp.values()]
+    table, memb = rn(V_ITEMS + 1, D, std=0.05), rn(D, std=0.001)
+    leaves = [table, memb] + [t for lp in layers for t in lp.values()]
     opt = torch.optim.Adam(leaves, lr=1e-3)
     schema = tr.session_schema(V_ITEMS, SEQ)
-    cfg = dict(n_head=N_HEAD, eps=0.03, item="item_id", masking="mlm")
+    p = dropout
+    keep = lambda *shape: torch.bernoulli(torch.full(shape, 1.0 - p))
 
     def step(seed):
         ids = tr.random_data_from_schema(schema, B, SEQ, seed=seed)["item_id"]
@@ -77,24 +148,143 @@ def cpu_baseline(seconds_budget=15.0):
         j1 = (torch.rand(B) * lens).long()
         m, lab = O.mlm_targets_train(ids, bern, j1, lambda mm: mm.float().argmax(1))
         opt.zero_grad()
-        out = O.session_forward(params, cfg, {"item_id": ids}, m, lab, True, False)
-        out["loss"].backward()
+        x = O.apply_mask_mlm(O.embedding_lookup(ids, table), m, memb, True, False)
+        if p > 0:
+            s = 1.0 / (1.0 - p)
+            h = x * keep(B, SEQ, D) * s                                   # HF :1116
+            pos_mask = keep(B, 2 * SEQ, D)                                # HF :1143, once per forward
+            for lp in layers:
+                masks = dict(pos=pos_mask, prob=keep(B, n, SEQ, SEQ), attn_out=keep(B, SEQ, D),
+                             ff_act=keep(B, SEQ, 4 * D), ff_out=keep(B, SEQ, D))
+                h = O.xlnet_layer_dropout(h, lp, n, 0.03, masks, p)
+            h = h * keep(B, SEQ, D) * s                                   # HF :1177
+        else:
+            h = O.xlnet_model(x, layers, n, 0.03)
+        xr, y = O.remove_pad_rows(h, lab)
+        loss = O.cross_entropy(O.head_logits(xr, table, 1.0), y)
+        loss.backward()
         opt.step()
 
-    step(0)  # warm-up (page-faults ~100 MB of logits)
+    step(0)  # warm-up (page-faults ~1 GB of logits)
     t0 = time.perf_counter()
     n_steps = 0
     while True:
         step(1 + n_steps)
         n_steps += 1
         el = time.perf_counter() - t0
-        if el > seconds_budget or n_steps >= 8:
+        if el > seconds_budget or n_steps >= max_steps:
             break
     return {"value": round(B * n_steps / el, 2), "unit": "sessions/s", "cores": cores, "kind": "port",
             "sample": f"{n_steps} train steps (fwd+bwd+Adam) of batch {B} at full V=100001, d=128, 4 layers, "
-                      f"seq 20, dropout 0, oracle/t4r_oracle.py on {cores} host threads"}
+                      f"seq 20, dropout {p} (a torch.bernoulli mask per site), oracle/t4r_oracle.py on {cores} "
+                      "host threads; the reference-verbatim CPU number (build container) is "
+                      "profiles/r02_cpu_reference_bench.json"}
 
 
+# --------------------------------------------------------------------------------------------- Recall@20
+def markov_sessions(n, seq, active, seed, p_follow=0.8, min_len=5):
+    """sessions of a fixed first-order Markov chain over the item ids `active` (next = succ[cur] with
+    probability p_follow, else uniform), lengths ~ U[min_len, seq] as the reference's synthetic recipe
+    (torch/utils/schema_utils.py:72-80): learnable signal for Recall@20."""
+    g = torch.Generator().manual_seed(seed)
+    gs = torch.Generator().manual_seed(12345)                    # the chain itself is fixed
+    A = active.numel()
+    succ = torch.randperm(A, generator=gs)
+    cur = torch.randint(0, A, (n,), generator=g)
+    cols = [cur]
+    for _ in range(seq - 1):
+        follow = torch.rand(n, generator=g) < p_follow
+        cur = torch.where(follow, succ[cur], torch.randint(0, A, (n,), generator=g))
+        cols.append(cur)
+    idx = torch.stack(cols, 1)
+    lens = torch.randint(min_len, seq + 1, (n,), generator=g)
+    m = torch.arange(seq)[None] < lens[:, None]
+    return active[idx] * m
+
+
+def recall_probe(device, dropout, train_steps=200, lockstep_steps=60):
+    """Recall@20 / NDCG@20 of next-item prediction on a held-out split after K training steps on Markov-chain
+    sessions: (a) the benchmarked configuration on the HIP path (fused evaluation head: ranks inside the logits
+    GEMM); (b) a reduced configuration trained in LOCKSTEP on the HIP path and on the CPU oracle -- same init,
+    same device-drawn MLM masks fed to the oracle, same Adam -- so the two metric values are comparable."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import golden_utils as gu
+    import t4r_oracle as O
+
+    res = {}
+    # ---- (a) benchmarked configuration, 2000 active items spread over the 100k vocabulary
+    tr, schema, model, dense, tables, opt = build(device, dropout, lr=2e-3)
+    active = 1 + torch.arange(2000) * (V_ITEMS // 2000)
+    model.train()
+    t0 = time.perf_counter()
+    for i in range(train_steps):
+        x = {"item_id": markov_sessions(BATCH, SEQ, active, 10 + i).to(device)}
+        out = model(x, training=True)
+        out["loss"].backward()
+        opt.step()
+    model.eval()
+    task = model.prediction_task
+    task.reset_metrics()
+    with torch.no_grad():
+        for j in range(4):
+            x = {"item_id": markov_sessions(BATCH, SEQ, active, 900_000 + j).to(device)}
+            h = model.heads[0].body(x, training=False, testing=True)
+            task.evaluate_ranks(h)
+    mt = task.compute_metrics()
+    torch.cuda.synchronize()
+    res["hip_bench_config"] = {"recall_at_20": round(mt["next-item/recall_at_20"], 4),
+                               "ndcg_at_20": round(mt["next-item/ndcg_at_20"], 4), "train_steps": train_steps,
+                               "eval_sessions": 4 * BATCH, "final_train_loss": round(float(out["loss"].detach()), 4),
+                               "seconds": round(time.perf_counter() - t0, 2)}
+    del model, opt, dense, tables
+    # ---- (b) lockstep HIP / oracle at reduced size
+    Vr, Br, Dr, NLr = 2000, 256, 64, 2
+    tr, schema, model, dense, tables, opt = build(device, 0.0, v_items=Vr, d_model=Dr, n_layer=NLr, n_head=4, lr=2e-3)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    p = gu.oracle_params({"p/" + k: v.numpy() for k, v in sd.items()}, requires_grad=True)
+    leaves = [p["tables"]["item_id"], p["masked_item_embedding"]] + [t for lp in p["layers"] for t in lp.values()]
+    oopt = torch.optim.Adam(leaves, lr=2e-3)
+    cfg = dict(n_head=4, eps=0.03, item="item_id", masking="mlm")
+    active_r = 1 + torch.arange(Vr - 1)
+    masking = model.input_features.masking
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    model.train()
+    for i in range(lockstep_steps):
+        ids = markov_sessions(Br, SEQ, active_r, 50_000 + i)
+        out = model({"item_id": ids.to(device)}, training=True)
+        out["loss"].backward()
+        opt.step()
+        oopt.zero_grad()
+        ref = O.session_forward(p, cfg, {"item_id": ids}, masking.mask_schema.cpu(), masking.masked_targets.cpu(),
+                                True, False)
+        ref["loss"].backward()
+        oopt.step()
+    model.eval()
+    task = model.prediction_task
+    task.reset_metrics()
+    rec_o, ndcg_o, n_o = 0.0, 0.0, 0
+    with torch.no_grad():
+        for j in range(2):
+            ids = markov_sessions(512, SEQ, active_r, 990_000 + j)
+            h = model.heads[0].body({"item_id": ids.to(device)}, training=False, testing=True)
+            task.evaluate_ranks(h)
+            m, lab = O.mlm_targets_eval(ids)
+            ro = O.session_forward(p, cfg, {"item_id": ids}, m, lab, False, True)
+            rec_o += float(O.recall_at_k(ro["logits"], ro["labels"], 20).sum())
+            ndcg_o += float(O.ndcg_at_k(ro["logits"], ro["labels"], 20).sum())
+            n_o += ro["labels"].numel()
+    mt = task.compute_metrics()
+    res["lockstep_reduced"] = {
+        "config": f"V={Vr}, d={Dr}, {NLr} layers, batch {Br}, {lockstep_steps} steps, dropout 0, same init / masks / Adam",
+        "hip": {"recall_at_20": round(mt["next-item/recall_at_20"], 4), "ndcg_at_20": round(mt["next-item/ndcg_at_20"], 4),
+                "final_train_loss": round(float(out["loss"].detach()), 5)},
+        "cpu_oracle": {"recall_at_20": round(rec_o / n_o, 4), "ndcg_at_20": round(ndcg_o / n_o, 4),
+                       "final_train_loss": round(float(ref["loss"].detach()), 5)}}
+    return res
+
+
+# --------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,6 +295,7 @@ def main():
                          "(a fresh process measured 7.7 ms/step in its first second, 7.1 ms afterwards)")
     ap.add_argument("--dropout", type=float, default=0.3)  # XLNetConfig.build default (config/transformer.py:442)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-recall", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -123,62 +314,36 @@ def main():
     tr, schema, model, dense, tables, opt = build(device, args.dropout)
     from transformers4rec_amd import ops
 
-    reducer = tr.GradReducer(dense.grad, tables.grad if tables is not None else None)
+    reducer, _hook = setup_data_parallel(tr, model, dense, tables, world)
     masking = model.input_features.masking
-    masking.seed = 1234 + rank
-    model.transformer_block.transformer.seed = 4321 + rank      # per-rank dropout stream
+    masking.seed, model.transformer_block.transformer.seed = rank_seeds(rank)
     # synthetic Schema-driven sessions, resident in HBM before the timed region (8 distinct batches)
     batches = [tr.random_data_from_schema(schema, BATCH, SEQ, seed=1000 * rank + i, device=device)
                for i in range(8)]
     model.train()
-
-    timers = {"head_logits_gemm": [], "gather": []}
-    state = {"n_labels": 0, "timing": False}
-
-    def train_step(i):
-        x = batches[i % len(batches)]
-        out = model(x, training=True)
-        out["loss"].backward()
-        reducer.reduce_all()
-        opt.step(grad_scale=reducer.grad_scale)
-        return out
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    train_step = make_train_step(model, batches, reducer, opt)
 
     # device pre-heat: full training steps for a fixed TIME (clock ramp), then the model / optimizer
     # state is rolled back, so the measured run (and its final loss) does not depend on how many
     # pre-heat steps this particular box managed
     snap = ([f.data.clone() for f in opt.flats], [(m.clone(), v.clone()) for m, v in opt.state], opt.step_count,
-            masking._rng_offset, model.transformer_block.transformer._drop_offset)
+            tr.get_rng_state(model))
     t_pre = time.perf_counter()
+    n_pre = 0
     while time.perf_counter() - t_pre < args.preheat_seconds:
-        out = train_step(0)
+        train_step(0)
         torch.cuda.synchronize()
+        n_pre += 1
+    preheat_s = time.perf_counter() - t_pre
     for f, d in zip(opt.flats, snap[0]):
         f.data.copy_(d)
     for (m, v), (m0, v0) in zip(opt.state, snap[1]):
         m.copy_(m0)
         v.copy_(v0)
-    opt.step_count, masking._rng_offset = snap[2], snap[3]
-    model.transformer_block.transformer._drop_offset = snap[4]
+    opt.step_count = snap[2]
+    tr.set_rng_state(model, snap[3])
     del snap
-    for i in range(args.warmup):
-        out = train_step(i)
-    barrier()
-    t0 = time.perf_counter()
-    n_lab = 0
-    for i in range(args.steps):
-        out = train_step(args.warmup + i)
-        n_lab += out["labels"].numel()
-    barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dt, out, n_lab = timed_region(train_step, args.warmup, args.steps, world, device)
     loss = float(out["loss"].detach())
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream
@@ -188,6 +353,7 @@ def main():
     xr = torch.randn(N_m, D_MODEL, device=device)
     ld = ops.pad_ld(W.shape[0])
     buf = torch.empty((N_m, ld), device=device)
+
     def timed(fn, reps=20):
         """average device time of `fn` over `reps` back-to-back launches (HIP events on the launch stream)"""
         for _ in range(3):
@@ -206,6 +372,7 @@ def main():
     # embedding gather (HBM bound): bytes = T * (8 id + 512 row read + 512 row write)
     ids = batches[0]["item_id"]
     feats = [dict(kind=0, input=ids, table=W, dim=D_MODEL, col=0, rows=W.shape[0])]
+
     def graph_timed(fn, reps=50):
         """as `timed`, with the launches replayed from one HIP graph: a 5 us kernel is otherwise
         measured at the host's launch rate (ctypes call ~10 us), not at its own duration.
@@ -242,37 +409,57 @@ def main():
     gather_bytes = BATCH * SEQ * (8 + 4 * D_MODEL + 4 * D_MODEL)
     gather_gbs = gather_bytes / (gather_ms * 1e-3) / 1e9
     # the same kernel on the tokens of the GLOBAL batch (8192 sessions, the size north_star quotes the
-    # gather target on): at 20 480 tokens (21 MB) the launch ramp is a third of the kernel
+    # gather target on), against a table that does NOT fit the caches (10 M rows x 128 = 5.1 GB, fresh ids
+    # per launch position): at 20 480 tokens (21 MB) the launch ramp is a third of the kernel
     GB = 8192
-    ids_g = torch.randint(1, W.shape[0], (GB, SEQ), device=device)
-    feats_g = [dict(kind=0, input=ids_g, table=W, dim=D_MODEL, col=0, rows=W.shape[0])]
-    gather_g_ms = graph_timed(lambda: ops.seq_features_fwd(feats_g, "concat", GB, SEQ, SEQ, D_MODEL), reps=20)
+    big_rows = 10_000_001
+    Wbig = torch.empty((big_rows, D_MODEL), device=device).normal_()
+    ids_g = [torch.randint(1, big_rows, (GB, SEQ), device=device) for _ in range(4)]
+    feats_g = [[dict(kind=0, input=t, table=Wbig, dim=D_MODEL, col=0, rows=big_rows)] for t in ids_g]
+    state = {"k": 0}
+
+    def gather_big():
+        state["k"] += 1
+        ops.seq_features_fwd(feats_g[state["k"] % 4], "concat", GB, SEQ, SEQ, D_MODEL)
+
+    gather_g_ms = graph_timed(gather_big, reps=20)
     gather_g_bytes = GB * SEQ * (8 + 4 * D_MODEL + 4 * D_MODEL)
     gather_g_gbs = gather_g_bytes / (gather_g_ms * 1e-3) / 1e9
+    del Wbig, ids_g, feats_g
 
-    # HBM bytes of that launch from the PMC counters (FETCH_SIZE x2 on gfx950, WRITE_SIZE calibrated
+    # HBM bytes of the launches from the PMC counters (FETCH_SIZE x2 on gfx950, WRITE_SIZE calibrated
     # on a known copy; collected in separate rocprofv3 --pmc passes and committed under profiles/).
     # It is a property of the kernel + shape, not of this run: taken from the committed measurement.
+    def committed(name):
+        for rnd in ("r02", "r01_g"):
+            path = os.path.join(ROOT, "profiles", f"{rnd}_{name}.json")
+            if os.path.exists(path):
+                with open(path) as f:
+                    return json.load(f)
+        return None
+
     traffic, traffic_src = None, None
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_g_pmc_traffic.json")
-    if os.path.exists(tpath):
-        with open(tpath) as f:
-            tj = json.load(f)
+    tj = committed("pmc_traffic")
+    if tj is not None:
         traffic = int(tj["traffic_bytes_per_launch"] * N_m / tj["n_rows"])   # scales with the label rows
         traffic_src = tj["source"]
+    gj = committed("pmc_traffic_gather")
 
     if rank == 0:
         res = {
-            "metric": "training sessions/sec (XLNet 4x128, 100k items, seq 20, MLM, tied full softmax)",
+            "metric": "training sessions/sec (XLNet 4x128, 100k items, seq 20, MLM, tied full softmax) + Recall@20",
             "value": round(BATCH * world * args.steps / dt, 1), "unit": "sessions/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: synthetic schema, item vocab 100k (100001 table rows), "
                                    "d_model 128, 4-layer 4-head XLNet, seq_len 20, per-GPU batch 1024, MLM p=0.15, "
-                                   "tied-weight full softmax, Adam, fwd+bwd+allreduce+optimizer per step",
+                                   "tied-weight full softmax, Adam, fwd+bwd+gradient exchange+optimizer per step",
                        "global_batch": BATCH * world, "seq_len": SEQ, "parallelism": f"dp{world}",
-                       "dropout": args.dropout, "label_rows_per_step": N_m, "final_loss": round(loss, 4)},
+                       "dropout": args.dropout, "label_rows_per_step": N_m, "final_loss": round(loss, 4),
+                       "head_mode": model.prediction_task.resolve_head_mode(N_m, W.shape[0]),
+                       "preheat_s": round(preheat_s, 2), "preheat_steps": n_pre,
+                       "timed_region_s": round(dt, 4)},
             "roofline": {"kernel": "gemm_f32_kernel<128,128,16,NT> (next-item logits X@W^T)", "bound": "mfma",
                          "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
@@ -281,17 +468,27 @@ def main():
                          "avg_launch_ms": round(gemm_ms, 4), "flops_per_launch": flops},
             "roofline_gather": {"kernel": "seq_features_fwd_fast_kernel<32, 2> (embedding gather)", "bound": "hbm",
                                 "achieved": round(gather_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": round(gather_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                                "frac": round(gather_gbs / HBM_PEAK_GBS, 4),
+                                "traffic": None if gj is None else gj.get("traffic_bytes_per_launch_c2"),
                                 "avg_launch_ms": round(gather_ms, 5), "bytes_per_launch": gather_bytes,
-                                "at_global_batch_8192": {"achieved": round(gather_g_gbs, 1),
-                                                         "frac": round(gather_g_gbs / HBM_PEAK_GBS, 4),
-                                                         "avg_launch_ms": round(gather_g_ms, 5),
-                                                         "bytes_per_launch": gather_g_bytes}},
+                                "note": "per-GPU batch: 20 480 tokens against the 51 MB table (cache resident)",
+                                "at_global_batch_8192_out_of_cache": {
+                                    "achieved": round(gather_g_gbs, 1), "frac": round(gather_g_gbs / HBM_PEAK_GBS, 4),
+                                    "avg_launch_ms": round(gather_g_ms, 5), "bytes_per_launch": gather_g_bytes,
+                                    "table": "10 000 001 x 128 fp32 (5.1 GB), 4 id sets rotated",
+                                    "traffic": None if gj is None else gj.get("traffic_bytes_per_launch_8192"),
+                                    "traffic_source": None if gj is None else gj.get("source")}},
         }
+        if not args.no_recall and world == 1:
+            try:
+                res["recall_at_20"] = recall_probe(device, args.dropout)
+            except Exception as exc:      # noqa: BLE001 - never lose the throughput line to the metric probe
+                res["recall_at_20"] = {"error": f"{type(exc).__name__}: {exc}"}
         if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline()
+            res["cpu_baseline"] = cpu_baseline(args.dropout)
         print(json.dumps(res), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

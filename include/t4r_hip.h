@@ -288,6 +288,13 @@ int t4r_sampled_logits_fwd(void* stream, const float* x, const long* labels, con
 int t4r_sampled_logits_bwd(void* stream, float* dlogits, const float* x, const long* labels,
                            const float* W, const long* neg_samples, float* dx, float* dW, float* ws, int N,
                            int D, int n_neg, float temperature);
+/* row-sparse form of the same backward: the weight gradient is returned as rows instead of being added
+ * into a dense [V, D] buffer -- rows_out[(N + n_neg), D] = gradient rows of the ids labels[0..N) ++
+ * neg_samples[0..n_neg).  The caller sums them into the table (t4r_sort_ids + t4r_embedding_bwd_sorted,
+ * deterministic) or exchanges them between data-parallel ranks (all_gather(ids, rows)). */
+int t4r_sampled_logits_bwd_rows(void* stream, float* dlogits, const float* x, const long* labels,
+                                const float* W, const long* neg_samples, float* dx, float* rows_out,
+                                float* ws, int N, int D, int n_neg, float temperature);
 int t4r_topk(void* stream, const float* scores, int N, int V, long ld, int k, float* out_val,
              long* out_idx);
 /* Fused eval head (replaces logits materialisation + torch.topk + the [N, V] one-hot of

@@ -130,3 +130,169 @@ def test_flat_params_views_and_regrad():
     a.grad = None
     f.ensure_grads()
     assert a.grad.data_ptr() == f.grad.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------ row-sparse exchange
+def _cpu_apply(d_table, ids, rows, padding_idx):
+    """what ops.scatter_rows_sorted does on the GPU: ids equal to padding_idx or out of range carry nothing"""
+    keep = (ids != padding_idx) & (ids >= 0) & (ids < d_table.shape[0])
+    d_table.index_add_(0, ids[keep], rows[keep])
+
+
+def _sparse_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from transformers4rec_amd.distributed import GradReducer, SparseRowExchange
+
+    V, D = 40, 6
+    g = torch.Generator().manual_seed(100 + rank)
+    table = torch.nn.Parameter(torch.zeros(V, D))
+    table.grad = torch.randn(V, D, generator=g)                 # the dense part (a tied head's d W)
+    dense = torch.randn(11, generator=g)
+    dense_part = table.grad.clone()
+    # two sparse contributions with DIFFERENT sizes per rank: the lookup scatter (ids with padding 0,
+    # rows inside a wider concatenated gradient) and a sampled head's rows (no padding id)
+    n1 = 9 + rank
+    ids1 = torch.randint(0, V, (n1,), generator=g)
+    wide = torch.randn(n1, 10, generator=g)
+    n2 = 5 + 2 * rank
+    ids2 = torch.randint(0, V, (n2,), generator=g)
+    rows2 = torch.randn(n2, D, generator=g)
+    sparse = SparseRowExchange(apply_fn=_cpu_apply)
+    sparse.attach(table)
+    assert table._t4r_sparse_sink is sparse
+
+    class _Ops:      # the column slice the HIP op would take
+        pass
+    rows1 = wide[:, 2: 2 + D].contiguous()
+    sparse.add_rows(table, ids1, rows1, padding_idx=0)
+    sparse.add_rows(table, ids2, rows2, padding_idx=-1)
+    red = GradReducer(dense, table.grad, sparse=sparse)
+    red.reduce_tables_async()
+    red.reduce_all()
+    # expectation, computed the dense way: every rank scatters locally, then one dense all-reduce
+    local = dense_part.clone()
+    _cpu_apply(local, ids1, rows1, 0)
+    _cpu_apply(local, ids2, rows2, -1)
+    dist.all_reduce(local, op=dist.ReduceOp.SUM)
+    gathered = [torch.zeros_like(table.grad) for _ in range(world)]
+    dist.all_gather(gathered, table.grad)
+    if rank == 0:
+        ret["got"], ret["want"] = table.grad.clone(), local
+        ret["identical_on_all_ranks"] = all(torch.equal(gathered[0], t) for t in gathered)
+        ret["bytes"] = sparse.bytes_exchanged
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_sparse_exchange_equals_dense_reduce():
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_sparse_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    torch.testing.assert_close(ret["got"], ret["want"], rtol=1e-6, atol=1e-6)
+    assert ret["identical_on_all_ranks"], "replicas would drift: the sparse apply must give the same bits everywhere"
+    assert ret["bytes"] > 0
+
+
+def test_sparse_exchange_single_process_is_local_apply():
+    from transformers4rec_amd.distributed import GradReducer, SparseRowExchange
+
+    table = torch.nn.Parameter(torch.zeros(7, 3))
+    sp = SparseRowExchange(apply_fn=_cpu_apply).attach(table)
+    sp.add_rows(table, torch.tensor([1, 0, 1, 6]), torch.ones(4, 3), padding_idx=0)
+    GradReducer(torch.zeros(2), None, sparse=sp).reduce_all()
+    assert table.grad[1].tolist() == [2.0] * 3 and table.grad[0].tolist() == [0.0] * 3 and table.grad[6].tolist() == [1.0] * 3
+    SparseRowExchange.detach(table)
+    assert not hasattr(table, "_t4r_sparse_sink")
+
+
+# ------------------------------------------------------------------------------------------ bench.py's N > 1 wiring
+class _StubTask(torch.nn.Module):
+    def resolve_head_mode(self, n, v):
+        return "materialize"
+
+
+class _StubModel(torch.nn.Module):
+    """stands in for the HIP model: a tied 'table' (dense head gradient + row-sparse lookup scatter through
+    the sink, like features._table_scatter) and a dense block whose output carries the head-backward hook"""
+
+    def __init__(self, V=30, D=4):
+        super().__init__()
+        self.table = torch.nn.Parameter(torch.randn(V, D))
+        self.transformer_block = torch.nn.Linear(D, D)
+        self.seen_seeds = None
+
+    def forward(self, x, training=True):
+        ids = x["item_id"]
+        emb = self.table.detach()[ids].requires_grad_()            # lookups are NOT tracked by autograd, as on HIP
+        h = self.transformer_block(emb)
+        logits = h.reshape(-1, h.shape[-1]) @ self.table.t()        # tied head: dense d table through autograd
+        labels = ids.reshape(-1)
+        loss = torch.nn.functional.cross_entropy(logits, labels)
+
+        def scatter(g):                                             # what features._table_scatter does
+            sink = getattr(self.table, "_t4r_sparse_sink", None)
+            rows = g.reshape(-1, g.shape[-1])
+            if sink is not None:
+                sink.add_rows(self.table, labels, rows, padding_idx=0)
+            else:
+                self.table.grad.index_add_(0, labels, rows)
+        emb.register_hook(scatter)
+        return {"loss": loss, "labels": labels}
+
+
+class _StubOpt:
+    def __init__(self):
+        self.scales = []
+
+    def step(self, grad_scale=1.0):
+        self.scales.append(grad_scale)
+
+
+def _bench_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    import transformers4rec_amd as tr
+    from transformers4rec_amd.optim import FlatParams
+
+    torch.manual_seed(0)
+    model = _StubModel()
+    tables = FlatParams([("table", model.table)])
+    dense = FlatParams([(n, p) for n, p in model.transformer_block.named_parameters()])
+    sparse = tr.SparseRowExchange(apply_fn=_cpu_apply).attach(model.table)
+    reducer = tr.GradReducer(dense.grad, tables.grad, sparse=sparse)
+    launched = []
+    orig = reducer.reduce_tables_async
+    reducer.reduce_tables_async = lambda: (launched.append(float(tables.grad.abs().sum())), orig())[1]
+    tr.head_backward_hook(model, reducer.reduce_tables_async)
+    g = torch.Generator().manual_seed(50 + rank)                   # every rank its own data
+    batches = [{"item_id": torch.randint(1, 30, (4, 5), generator=g)} for _ in range(3)]
+    opt = _StubOpt()
+    step = bench.make_train_step(model, batches, reducer, opt)
+    dense.grad.zero_(); tables.grad.zero_()
+    out = step(0)
+    # after one step every rank holds the SAME (summed) gradients
+    both = [torch.zeros_like(tables.grad) for _ in range(world)]
+    dist.all_gather(both, tables.grad)
+    same_tables = torch.equal(both[0], both[1])
+    dboth = [torch.zeros_like(dense.grad) for _ in range(world)]
+    dist.all_gather(dboth, dense.grad)
+    dt, out, n_lab = bench.timed_region(step, 1, 3, world, "cpu", first_step=1)
+    if rank == 0:
+        ret.update(same_tables=same_tables, same_dense=torch.equal(dboth[0], dboth[1]), launched=list(launched[:1]),
+                   scales=list(opt.scales), dt=dt, n_lab=n_lab, seeds=[bench.rank_seeds(r) for r in range(world)])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_train_step_wiring_world2():
+    """bench.py's own make_train_step / timed_region / head-backward hook / rank seeds on 2 gloo ranks"""
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_bench_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert ret["same_tables"] and ret["same_dense"]
+    assert ret["launched"] and ret["launched"][0] > 0      # the table all-reduce started once the head's dense d W existed
+    assert ret["scales"] == [0.5] * 5                        # 1/world folded into the optimizer, every step
+    assert ret["dt"] > 0 and ret["n_lab"] == 3 * 20
+    assert len({s[0] for s in ret["seeds"]}) == world and len({s[1] for s in ret["seeds"]}) == world

@@ -829,3 +829,43 @@ def test_c5_full_vocabulary_step_runs():
     got = g.double().sum(0)
     assert float(g.abs().max()) > 0
     assert float((got - want).abs().max()) < 1e-2 * float(want.abs().max()) + 1e-6, (got[:4], want[:4])
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("xlnet_mlm_multi_train", dict(cats=(("category", 40), ("brand", 9)), conts=("price", "age"), d_output=32,
+                                   embedding_dims={"item_id": 16, "category": 24, "brand": 8})),
+    ("xlnet_mlm_context_train", dict(context=(("country", 17),), d_output=32,
+                                     embedding_dims={"item_id": 24, "country": 8})),
+    ("xlnet_mlm_sum_sampled_train", dict(cats=(("category", 40),), aggregation="element-wise-sum", emb_default=32,
+                                         sampled=True, max_n=20)),
+])
+def test_row_sparse_sink_gives_the_same_table_gradients(name, kw):
+    """the data-parallel row-sparse path on one process: table gradients collected as (ids, rows) by a
+    SparseRowExchange and applied by GradReducer.reduce_all == the direct scatter, and == the reference"""
+    import transformers4rec_amd as tr
+
+    grads = {}
+    for use_sink in (False, True):
+        d, model, x, cap, hooks = run_train_case(name, **kw)
+        if "draw/neg_tries" in d:
+            neg = gu.t(d["draw/neg_tries"]).unique()[: int(d["meta/max_n_samples"])].to(DEV)
+            model.prediction_task.pre.module.sampler.sample = lambda labels, neg=neg: neg
+        tabs = [p for n, p in model.named_parameters() if ".embedding_tables." in n and "continuous_module" not in n]
+        red = None
+        if use_sink:
+            sink = tr.SparseRowExchange().attach(*tabs)
+            red = tr.GradReducer(torch.zeros(1, device=DEV), None, sparse=sink)
+        out = model(x, training=True)
+        out["loss"].backward()
+        if use_sink:
+            assert len(sink._pending) >= len(tabs) - 1
+            red.reduce_all()
+            assert not sink._pending
+        grads[use_sink] = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    assert sorted(grads[False]) == sorted(grads[True])
+    for n in grads[False]:
+        close(grads[True][n], grads[False][n], rtol=1e-5, atol=1e-7, msg=lambda m, n=n: f"{n}: {m}")
+    ref_g = gu.section(d, "g/")
+    for n, g in grads[True].items():
+        if n in ref_g and ".embedding_tables." in n:
+            close(g, ref_g[n], rtol=2e-4, atol=1e-4, msg=lambda m, n=n: f"{n} vs reference: {m}")

@@ -16,6 +16,6 @@ from .transformer_hf import BertConfig, BertModel, GPT2Config, GPT2Model  # noqa
 from .prediction_task import LogUniformSampler, NextItemPredictionTask  # noqa: E402,F401
 from .model import Head, Model  # noqa: E402,F401
 from .optim import FlatParams, FusedAdam, flatten_model  # noqa: E402,F401
-from .distributed import GradReducer, shard_batch  # noqa: E402,F401
+from .distributed import GradReducer, SparseRowExchange, head_backward_hook, shard_batch  # noqa: E402,F401
 from .data import ParquetSessionLoader, read_ragged_columns  # noqa: E402,F401
 from .rng import default_seed, get_rng_state, set_rng_state  # noqa: E402,F401

@@ -66,6 +66,7 @@ _SIGS = {
     "t4r_linear_softmax_ce_bwd": ("i", "pplpl" + "ppp" + "iiiffi" + "pplpl"),
     "t4r_sampled_logits_fwd": ("i", "ppppppp" + "iiif"),
     "t4r_sampled_logits_bwd": ("i", "ppppppppp" + "iiif"),
+    "t4r_sampled_logits_bwd_rows": ("i", "ppppppppp" + "iiif"),
     "t4r_topk": ("i", "pp" + "iili" + "pp"),
     "t4r_rank_of_target_f32": ("i", "p" + "iiif" + "pl" + "pl" + "ppp"),
     "t4r_swap_noise_ws_bytes": ("l", "l"),

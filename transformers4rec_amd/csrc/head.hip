@@ -258,8 +258,9 @@ __global__ __launch_bounds__(256) void sampled_rows_kernel(const float* __restri
 // positive column: dx[row,:] += g0/T * W[y,:] ; dW[y,:] += g0/T * x[row,:]   (one wave per row)
 __global__ __launch_bounds__(256) void sampled_pos_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                                const long* __restrict__ y, const float* __restrict__ W,
-                                                               float* __restrict__ dx, float* __restrict__ dW, int N,
-                                                               int D, int S, float inv_t) {
+                                                               float* __restrict__ dx, float* __restrict__ dW,
+                                                               float* __restrict__ rows_out, int N, int D, int S,
+                                                               float inv_t) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= N) return;
@@ -267,21 +268,27 @@ __global__ __launch_bounds__(256) void sampled_pos_bwd_kernel(const float* __res
     const float gv = g[(long)row * (S + 1)] * inv_t;
     for (int d = lane; d < D; d += 64) {
         dx[(long)row * D + d] += gv * W[yi * D + d];
-        atomicAdd(dW + yi * D + d, gv * x[(long)row * D + d]);
+        if (rows_out) rows_out[(long)row * D + d] = gv * x[(long)row * D + d];     // row-sparse form: d W[y_row] contribution
+        else atomicAdd(dW + yi * D + d, gv * x[(long)row * D + d]);
     }
 }
 
 // dlogits is MODIFIED in place (accidental-hit entries zeroed).  ws: 2 * n_neg * D floats of scratch.
-extern "C" int t4r_sampled_logits_bwd(void* stream, float* dlogits, const float* x, const long* labels,
-                                      const float* W, const long* neg_samples, float* dx, float* dW,
-                                      float* ws, int N, int D, int n_neg, float temperature) {
+// rows_out == null: the weight gradient is accumulated into the dense dW[V, D] (atomics on the label rows).
+// rows_out != null (dW ignored): ROW-SPARSE form -- rows_out[(N + n_neg), D] receives the gradient rows of
+// the ids (labels[0..N) ++ neg_samples[0..n_neg)); the caller sums them into the table with the
+// deterministic sorted scatter (t4r_embedding_bwd_sorted) or exchanges them between data-parallel ranks
+// (a 1 M x 256 table gradient is 1 GB dense, ~50 MB as rows).
+static int sampled_logits_bwd_impl(void* stream, float* dlogits, const float* x, const long* labels,
+                                   const float* W, const long* neg_samples, float* dx, float* dW,
+                                   float* rows_out, float* ws, int N, int D, int n_neg, float temperature) {
     if (N == 0) return 0;
     T4R_CHECK_ARG(ws != nullptr, "sampled_logits_bwd: workspace (2 * n_neg * D floats) required");
     hipStream_t st = (hipStream_t)stream;
     const int S = n_neg;
     const float inv_t = temperature != 0.f ? 1.f / temperature : 1.f;
     float* w_neg = ws;
-    float* dw_neg = ws + (long)S * D;
+    float* dw_neg = rows_out ? rows_out + (long)N * D : ws + (long)S * D;
     const long ns = (long)N * S, sd = (long)S * D;
     hipLaunchKernelGGL(sampled_mask_hits_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, dlogits,
                        labels, neg_samples, N, S);
@@ -296,12 +303,29 @@ extern "C" int t4r_sampled_logits_bwd(void* stream, float* dlogits, const float*
     rc = t4r_gemm_launch(st, 1, 0, S, D, N, inv_t, dlogits + 1, S + 1, x, D, dw_neg, D, nullptr, 0, nullptr, 0, -1,
                          0, 1, 0, 0, 0, nullptr);
     if (rc) return rc;
-    hipLaunchKernelGGL(sampled_rows_kernel, dim3((unsigned)((sd + 255) / 256)), dim3(256), 0, st, W, neg_samples,
-                       nullptr, dW, dw_neg, S, D);
+    if (!rows_out)
+        hipLaunchKernelGGL(sampled_rows_kernel, dim3((unsigned)((sd + 255) / 256)), dim3(256), 0, st, W, neg_samples,
+                           nullptr, dW, dw_neg, S, D);
     hipLaunchKernelGGL(sampled_pos_bwd_kernel, dim3((N + 3) / 4), dim3(256), 0, st, dlogits, x, labels, W, dx, dW,
-                       N, D, S, inv_t);
+                       rows_out, N, D, S, inv_t);
     T4R_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int t4r_sampled_logits_bwd(void* stream, float* dlogits, const float* x, const long* labels,
+                                      const float* W, const long* neg_samples, float* dx, float* dW,
+                                      float* ws, int N, int D, int n_neg, float temperature) {
+    T4R_CHECK_ARG(dW != nullptr, "sampled_logits_bwd: dW required");
+    return sampled_logits_bwd_impl(stream, dlogits, x, labels, W, neg_samples, dx, dW, nullptr, ws, N, D, n_neg,
+                                   temperature);
+}
+
+extern "C" int t4r_sampled_logits_bwd_rows(void* stream, float* dlogits, const float* x, const long* labels,
+                                           const float* W, const long* neg_samples, float* dx, float* rows_out,
+                                           float* ws, int N, int D, int n_neg, float temperature) {
+    T4R_CHECK_ARG(rows_out != nullptr, "sampled_logits_bwd_rows: rows_out required");
+    return sampled_logits_bwd_impl(stream, dlogits, x, labels, W, neg_samples, dx, nullptr, rows_out, ws, N, D,
+                                   n_neg, temperature);
 }
 
 // ------------------------------------------------------------------------------------------

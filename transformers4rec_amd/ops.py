@@ -556,6 +556,27 @@ def sampled_logits_bwd(dlogits, x, labels, W, neg, dW, temperature=1.0):
     return dx
 
 
+def sampled_logits_bwd_rows(dlogits, x, labels, W, neg, temperature=1.0):
+    """row-sparse form: -> (dx [N, D], ids [N + S] = labels ++ neg, rows [N + S, D] gradient rows of W[ids]);
+    dlogits is modified in place (entries of accidental hits are zeroed)"""
+    N, D = x.shape
+    S = neg.numel()
+    dx = torch.empty_like(x)
+    rows = torch.empty((N + S, D), device=x.device, dtype=torch.float32)
+    ws = torch.empty(2 * S * D, device=x.device, dtype=torch.float32)
+    call("t4r_sampled_logits_bwd_rows", _stream(), _chk(dlogits), _chk(x), _chk(labels, torch.int64),
+         _chk(W), _chk(neg, torch.int64), dx.data_ptr(), rows.data_ptr(), ws.data_ptr(), N, D, S,
+         float(temperature))
+    ids = torch.cat([labels, neg.to(labels.dtype)])        # index glue (N + S int64)
+    return dx, ids, rows
+
+
+def scatter_rows_sorted(d_table, ids, rows, padding_idx=-1):
+    """d_table[ids[i]] += rows[i], deterministic (sort + segmented sum); padding_idx = -1: every id counts"""
+    keys, perm = sort_ids(ids, d_table.shape[0], padding_idx)
+    embedding_bwd_sorted(rows, keys, perm, d_table, 0, rows.shape[1], 1)
+
+
 def topk(scores, k, V=None):
     N = scores.shape[0]
     V = scores.shape[1] if V is None else V

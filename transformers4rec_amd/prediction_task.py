@@ -87,6 +87,8 @@ class _Pre(nn.Module):
 # opt-in (T4R_HEAD_SIDE_STREAM=1): measured 5.64 -> 5.61 ms/step at C2 -- every kernel of the step already
 # fills the GPU, so there is little to overlap; off by default
 _SIDE_STREAM_ON = os.environ.get("T4R_HEAD_SIDE_STREAM", "0") == "1"
+# sampled softmax: weight gradient as (ids, rows) + deterministic sorted scatter (default) instead of row atomics
+_SAMPLED_ROWS = os.environ.get("T4R_SAMPLED_ROWS", "1") == "1"
 _SIDE_STREAMS = {}
 
 
@@ -186,7 +188,17 @@ class _NextItemHeadFn(torch.autograd.Function):
                                           out=gw, accumulate=True)
         else:
             dl = ops.softmax_ce_bwd(logits, tgt, lse, dloss.contiguous(), width, smooth)
-            dxp = ops.sampled_logits_bwd(dl, xp, labels, W.detach(), ctx.neg, _grad_buf(W), T)
+            sink = getattr(W, "_t4r_sparse_sink", None)
+            if sink is not None or (_SAMPLED_ROWS and W.requires_grad):
+                # row-sparse weight gradient: (N + S) rows instead of atomics into a dense [V, D] buffer;
+                # summed deterministically here, or exchanged between data-parallel ranks by the sink
+                dxp, ids, rows = ops.sampled_logits_bwd_rows(dl, xp, labels, W.detach(), ctx.neg, T)
+                if sink is not None:
+                    sink.add_rows(W, ids, rows, padding_idx=-1)
+                else:
+                    ops.scatter_rows_sorted(_grad_buf(W), ids, rows)
+            else:
+                dxp = ops.sampled_logits_bwd(dl, xp, labels, W.detach(), ctx.neg, _grad_buf(W), T)
         lin = task.task_block[0][0] if task.task_block is not None else None
         dxr = dxp
         if lin is not None:

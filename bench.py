@@ -202,7 +202,7 @@ def markov_sessions(n, seq, active, seed, p_follow=0.8, min_len=5):
     return active[idx] * m
 
 
-def recall_probe(device, dropout, train_steps=200, lockstep_steps=60):
+def recall_probe(device, dropout, train_steps=200, lockstep_steps=250):
     """Recall@20 / NDCG@20 of next-item prediction on a held-out split after K training steps on Markov-chain
     sessions: (a) the benchmarked configuration on the HIP path (fused evaluation head: ranks inside the logits
     GEMM); (b) a reduced configuration trained in LOCKSTEP on the HIP path and on the CPU oracle -- same init,
@@ -240,11 +240,11 @@ def recall_probe(device, dropout, train_steps=200, lockstep_steps=60):
     del model, opt, dense, tables
     # ---- (b) lockstep HIP / oracle at reduced size
     Vr, Br, Dr, NLr = 2000, 256, 64, 2
-    tr, schema, model, dense, tables, opt = build(device, 0.0, v_items=Vr, d_model=Dr, n_layer=NLr, n_head=4, lr=2e-3)
+    tr, schema, model, dense, tables, opt = build(device, 0.0, v_items=Vr, d_model=Dr, n_layer=NLr, n_head=4, lr=5e-3)
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     p = gu.oracle_params({"p/" + k: v.numpy() for k, v in sd.items()}, requires_grad=True)
     leaves = [p["tables"]["item_id"], p["masked_item_embedding"]] + [t for lp in p["layers"] for t in lp.values()]
-    oopt = torch.optim.Adam(leaves, lr=2e-3)
+    oopt = torch.optim.Adam(leaves, lr=5e-3)
     cfg = dict(n_head=4, eps=0.03, item="item_id", masking="mlm")
     active_r = 1 + torch.arange(Vr - 1)
     masking = model.input_features.masking

@@ -816,7 +816,9 @@ def test_c5_full_vocabulary_step_runs():
     torch.cuda.synchronize()
     N = out["labels"].numel()
     peak = torch.cuda.max_memory_allocated() - base
-    assert N > 2000 and abs(float(out["loss"].detach()) - np.log(V + 1)) < 0.3
+    # at init the logits are ~N(0, s^2) with s = |h| * 0.05 ~ 1.1 (LayerNorm-ed hidden of width 512): loss ~ ln V + s^2/2
+    loss0 = float(out["loss"].detach())
+    assert N > 2000 and 0.0 < loss0 - np.log(V + 1) < 1.2, loss0
     table = model.input_features.item_embedding_table.weight
     assert peak < 4.0 * table.numel() * 4 and peak < 0.5 * 4.0 * N * V, (peak, 4.0 * N * V)
     g = table.grad

@@ -871,3 +871,64 @@ def test_row_sparse_sink_gives_the_same_table_gradients(name, kw):
     for n, g in grads[True].items():
         if n in ref_g and ".embedding_tables." in n:
             close(g, ref_g[n], rtol=2e-4, atol=1e-4, msg=lambda m, n=n: f"{n} vs reference: {m}")
+
+
+# ------------------------------------------------------------------------------------------
+# precision modes of the dense contractions
+@pytest.mark.parametrize("mode", ["fp32_bf16x3", "auto"])
+def test_fp32_accurate_split_mode_matches_reference(mode):
+    """the fp32-accurate form on the bf16 matrix cores (exact 3-way split) keeps the reference parity of the fp32
+    path: fixture loss / logits / every gradient at the SAME tolerances as test_train_step_matches_reference"""
+    from transformers4rec_amd import ops
+
+    name, kw = "xlnet_mlm_multi_train", dict(cats=(("category", 40), ("brand", 9)), conts=("price", "age"), d_output=32,
+                                             embedding_dims={"item_id": 16, "category": 24, "brand": 8})
+    d, model, x, cap, hooks = run_train_case(name, **kw)
+    with ops.precision(mode):
+        out = model(x, training=True)
+        out["loss"].backward()
+    close(cap["hid"], gu.t(d["out/hidden"]))
+    close(out["predictions"], gu.t(d["out/predictions"]))
+    assert abs(float(out["loss"].detach()) - float(d["out/loss"])) < 1e-4
+    named = dict(model.named_parameters())
+    for k, ref in gu.section(d, "g/").items():
+        close(named[k].grad, ref, rtol=2e-4, atol=1e-4, msg=lambda m, k=k: f"{k}: {m}")
+
+
+@pytest.mark.parametrize("mode,dtype", [("bf16", torch.bfloat16), ("fp16", torch.float16)])
+def test_mixed_precision_mode(mode, dtype):
+    """C5's precision mode (reference: HF Trainer fp16=True -> autocast, trainer.py:363-367; master weights fp32):
+    half-precision operands in every dense contraction, fp32 accumulation / LayerNorm / softmax / CE.
+    Reported separately from the fp32 gate: compared with (a) the fp32 HIP path and (b) the CPU oracle
+    under torch.autocast -- the reference's AMP semantics -- at half-precision tolerances."""
+    import transformers4rec_amd as tr
+    from transformers4rec_amd import ops
+
+    name, kw = "xlnet_mlm_item_train", dict(emb_default=32)
+    res = {}
+    for m in ("fp32", mode):
+        d, model, x, cap, hooks = run_train_case(name, **kw)
+        with ops.precision(m):
+            out = model(x, training=True)
+            out["loss"].backward()
+        res[m] = (float(out["loss"].detach()), out["predictions"].detach().cpu(), cap["hid"].cpu(),
+                  {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert ops.get_precision() == "fp32"
+    l32, p32, h32, g32 = res["fp32"]
+    lh, ph, hh, gh = res[mode]
+    eps = 2.0 ** -8 if mode == "bf16" else 2.0 ** -11
+    assert lh != l32, "the mode did not change the arithmetic"
+    assert abs(lh - l32) < 40 * eps * max(1.0, abs(l32)), (lh, l32)
+    assert float((ph - p32).abs().max()) < 60 * eps * float(p32.abs().max())
+    assert float((hh - h32).abs().max()) < 60 * eps * float(h32.abs().max())
+    for n in g32:
+        a, b = gh[n], g32[n]
+        assert float((a - b).abs().max()) <= 100 * eps * float(b.abs().max()) + 1e-7, n
+    # (b) the reference's AMP semantics on the CPU: the oracle under autocast
+    mk = model.input_features.masking
+    p = gu.oracle_params(d, requires_grad=False)
+    ids = {k[3:]: gu.t(v) for k, v in d.items() if k.startswith("in/")}
+    with torch.autocast(device_type="cpu", dtype=dtype):
+        ref = O.session_forward(p, dict(n_head=int(d["meta/n_head"]), eps=0.03, item="item_id", masking="mlm"), ids,
+                                gu.t(d["out/mask_schema"]), gu.t(d["out/masked_targets"]), True, False)
+    assert abs(lh - float(ref["loss"])) < 60 * eps * max(1.0, abs(l32)), (lh, float(ref["loss"]))

@@ -890,3 +890,85 @@ def test_linear_softmax_ce_fused_fwd_bwd(ops, N, V, D, eps, chunk):
     logits = ops.gemm(cu(x.detach()), cu(W.detach()), False, True, alpha=1 / T, ldc=ops.pad_ld(V))
     _, _, lse_m = ops.softmax_ce_fwd(logits, cu(y), V, eps)
     close(lse, lse_m, rtol=0, atol=2e-6)
+
+
+# ------------------------------------------------------------------------------------ bf16 / fp16 matrix-core GEMM variants
+def _round_to(x, mode):
+    if mode == "bf16":
+        return x.to(torch.bfloat16).float()
+    if mode == "fp16":
+        return x.to(torch.float16).float()
+    return x
+
+
+@pytest.mark.parametrize("mode", ["fp32_bf16x3", "bf16", "fp16"])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (76, 132, 36), (300, 64, 512), (36, 1004, 128), (4, 8, 4),
+                                   (260, 384, 100), (1024, 260, 64)])
+def test_gemm_precision_modes_layouts(ops, mode, ta, tb, M, N, K):
+    """the bf16 / fp16 matrix-core variants of the GEMM in every layout (dims multiples of 4: 16-byte loadable):
+    fp32_bf16x3 must meet the fp32 kernel's tolerance; the mixed-precision modes must equal the product of the
+    ROUNDED operands accumulated in fp32 (that is their definition), which is also close to the fp32 product."""
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + ta * 2 + tb)
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    B = torch.randn((N, K) if tb else (K, N), generator=g)
+    Ar, Br = _round_to(A, mode), _round_to(B, mode)
+    ref = (Ar.t() if ta else Ar).double() @ (Br.t() if tb else Br).double()
+    with ops.precision(mode):
+        assert ops.get_precision() == mode
+        out = ops.gemm(cu(A), cu(B), bool(ta), bool(tb), alpha=0.5)
+    assert ops.get_precision() == "fp32"
+    close(out, (0.5 * ref).float(), rtol=1e-5, atol=1e-4)
+    if mode != "fp32_bf16x3":     # and the rounding itself costs what half precision costs, no more
+        full = (A.t() if ta else A).double() @ (B.t() if tb else B).double()
+        tol = (2 ** -8 if mode == "bf16" else 2 ** -11) * 4 * (K ** 0.5)
+        assert float((out.cpu().double() - 0.5 * full).abs().max()) < tol
+
+
+@pytest.mark.parametrize("mode", ["fp32_bf16x3", "bf16", "fp16"])
+def test_gemm_precision_modes_features(ops, mode):
+    """epilogues, split-K, accumulate, batch stride, the 128 x 128 tile and the softmax-gradient A operand"""
+    g = torch.Generator().manual_seed(11)
+    rnd = lambda x: _round_to(x, mode)
+    tol = dict(rtol=1e-4, atol=2e-4)
+    with ops.precision(mode):
+        M, N, K = 200, 192, 96
+        A, W, bias = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+        pre = rnd(A) @ rnd(W).t() + bias
+        aux = torch.empty((M, N), device=DEV)
+        out = ops.gemm(cu(A), cu(W), False, True, bias=cu(bias), epilogue=ops.EPI_BIAS_GELU, aux=aux)
+        close(aux, pre, **tol)
+        close(out, torch.nn.functional.gelu(pre), **tol)
+        close(ops.gemm(cu(A), cu(W), False, True, bias=cu(bias), epilogue=ops.EPI_BIAS_RELU), torch.relu(pre), **tol)
+        res = torch.randn(M, N, generator=g)
+        close(ops.gemm(cu(A), cu(W), False, True, bias=cu(bias), epilogue=ops.EPI_BIAS_RESID, aux=cu(res)), pre + res, **tol)
+        # split-K wgrad shape (TN, long K), overwrite / accumulate
+        K2 = 5000
+        A2, B2 = torch.randn(K2, 72, generator=g), torch.randn(K2, 92, generator=g)
+        ref = (rnd(A2).t().double() @ rnd(B2).double()).float()
+        close(ops.gemm(cu(A2), cu(B2), True, False, splitk=-1), ref, rtol=1e-4, atol=2e-3)
+        acc = cu(torch.ones(72, 92))
+        ops.gemm(cu(A2), cu(B2), True, False, splitk=-1, accumulate=True, out=acc)
+        close(acc, ref + 1, rtol=1e-4, atol=2e-3)
+        # large plain NT product: the one-plane precisions take the 128 x 128 tile here
+        X, Wv = torch.randn(1100, 64, generator=g), torch.randn(40004, 64, generator=g)
+        out = ops.gemm(cu(X), cu(Wv), False, True, alpha=1 / 0.7, ldc=ops.pad_ld(40004))
+        close(out, (rnd(X) @ rnd(Wv).t()) / 0.7, **tol)
+        # the head's backward products with the softmax gradient formed in the A operand
+        Nr, V, D = 130, 5004, 128
+        x = torch.randn(Nr, D, generator=g)
+        Wt = 0.3 * torch.randn(V, D, generator=g)
+        y = torch.randint(0, V, (Nr,), generator=g)
+        logits = x @ Wt.t()
+        buf = torch.zeros(Nr, ops.pad_ld(V), device=DEV)
+        buf[:, :V] = cu(logits)
+        lg = buf[:, :V]
+    _, _, lse = ops.softmax_ce_fwd(lg, cu(y), V, 0.0)
+    dl = (torch.softmax(logits, 1) - torch.nn.functional.one_hot(y, V)) / Nr
+    with ops.precision(mode):
+        dx = ops.gemm_softmax_grad(lg, lse, cu(y), None, V, cu(Wt), False, splitk=-1)
+        dW = torch.zeros(V, D, device=DEV)
+        ops.gemm_softmax_grad(lg, lse, cu(y), None, V, cu(x), True, out=dW, accumulate=True)
+    loose = dict(rtol=2e-2, atol=2e-5) if mode != "fp32_bf16x3" else dict(rtol=1e-4, atol=2e-6)
+    close(dx, dl @ Wt, **loose)
+    close(dW, dl.t() @ x, **loose)

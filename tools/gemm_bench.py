@@ -25,6 +25,9 @@ def bench(name, M, N, K, ta, tb, **kw):
     print(f"{name:34s} M={M:6d} N={N:6d} K={K:6d} {'T' if ta else 'N'}{'T' if tb else 'N'} {ms*1e3:9.1f} us {tf:7.1f} TF/s", flush=True)
 
 T, D, V, NM = 20480, 128, 100001, 2765
+if len(sys.argv) > 1:
+    ops.set_precision(sys.argv[1])
+print("precision:", ops.get_precision(), flush=True)
 bench("square 4096 NT", 4096, 4096, 4096, False, True)
 bench("square 4096 NN", 4096, 4096, 4096, False, False)
 bench("square 4096 TN", 4096, 4096, 4096, True, False)
@@ -41,6 +44,12 @@ bench("d_h1 (NN K=512)", T, D, 4 * D, False, False)
 bench("wgrad w2 splitk", D, 4 * D, T, True, False, splitk=-1, accumulate=True)
 bench("wgrad w1 splitk", 4 * D, D, T, True, False, splitk=-1, accumulate=True)
 bench("wgrad o splitk", D, D, T, True, False, splitk=-1, accumulate=True)
+bench("C5 body qkv T=102400 D=512", 102400, 512, 512, False, True)
+bench("C5 body ff1 T=102400 512->3072", 102400, 3072, 512, False, True)
+bench("C5 wgrad ff1", 3072, 512, 102400, True, False, splitk=-1, accumulate=True)
+bench("C4 body ff1 T=51200 256->1024", 51200, 1024, 256, False, False)
+if "--all" not in sys.argv:
+    sys.exit(0)
 # transposed-logits layout experiment: G^T stored [V, N_m]
 bench("T-layout dW  NN M=V K=N_m", V, D, NM, False, False, pad_a=True)
 bench("T-layout dX  TN K=V splitk", NM, D, V, True, False, splitk=-1, pad_a=True)

@@ -46,6 +46,8 @@ _SIGS = {
     "t4r_add_pos_bwd": ("i", "ppp" + "iii"),
     "t4r_dropout_ctr_hi": ("Q", "Qii"),
     "t4r_dropout": ("i", "pppp" + "llfQQ"),
+    "t4r_set_precision": ("v", "i"),
+    "t4r_get_precision": ("i", ""),
     "t4r_gemm_softmax_grad_f32": ("i", "piiiif" + "plpppf" + "plpl" + "ii"),
     "t4r_add_layernorm_fwd": ("i", "pppppppp" + "iif" + "fQQ"),
     "t4r_add_layernorm_bwd": ("i", "pppppppppppp" + "iii" + "fQQ"),
@@ -102,7 +104,7 @@ def load():
     lib = ctypes.CDLL(LIB_PATH)
     for name, (ret, args) in _SIGS.items():
         fn = getattr(lib, name)
-        fn.restype = ctypes.c_char_p if ret == "s" else _C[ret]
+        fn.restype = ctypes.c_char_p if ret == "s" else (None if ret == "v" else _C[ret])
         fn.argtypes = [_C[a] for a in args]
     _lib = lib
     return lib

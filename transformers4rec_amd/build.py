@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libt4r_hip.so")
-SOURCES = ["gemm_f32.hip", "elementwise.hip", "embedding.hip", "masking.hip", "xlnet_attn.hip",
+SOURCES = ["gemm_f32.hip", "gemm_half.hip", "elementwise.hip", "embedding.hip", "masking.hip", "xlnet_attn.hip",
            "head.hip", "xlnet_layer.hip", "mha.hip", "swap_noise.hip", "xlnet_attn_mfma.hip", "mha_mfma.hip",
            "embedding_sorted.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",

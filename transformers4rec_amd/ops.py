@@ -49,6 +49,37 @@ def pad_ld(V):
 
 
 # ------------------------------------------------------------------------------------ GEMM
+PRECISIONS = {"fp32": 0, "fp32_bf16x3": 1, "bf16": 2, "fp16": 3, "auto": 4}
+
+
+def set_precision(mode):
+    """precision of every dense contraction launched from now on (include/t4r_hip.h: t4r_set_precision):
+    "fp32" (fp32 matrix cores, default) | "fp32_bf16x3" (fp32-accurate on the bf16 cores, exact 3-way split) |
+    "bf16" / "fp16" (mixed precision as the reference's AMP: half operands, fp32 accumulation, fp32 master
+    weights) | "auto".  Returns the previous mode name."""
+    prev = get_precision()
+    _lib.load().t4r_set_precision(PRECISIONS[mode] if isinstance(mode, str) else int(mode))
+    return prev
+
+
+def get_precision():
+    m = _lib.load().t4r_get_precision()
+    return next(k for k, v in PRECISIONS.items() if v == m)
+
+
+class precision:
+    """with ops.precision("bf16"): ...  (restores the previous mode)"""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = set_precision(self.mode)
+
+    def __exit__(self, *exc):
+        set_precision(self.prev)
+
+
 def gemm(a, b, trans_a=False, trans_b=False, alpha=1.0, bias=None, epilogue=EPI_NONE, out=None,
          aux=None, splitk=1, accumulate=False, ldc=None, drop=(0.0, 0, 0)):
     """out[M,N] = alpha * op(a) @ op(b) (+epilogue).  a, b 2-D row-major fp32."""

@@ -153,14 +153,14 @@ int t4r_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, floa
 
 /* Precision of every dense contraction launched after the call (process-wide setting; T4R_GEMM_PREC sets
  * the default):
- *   0  fp32 operands on the fp32 matrix cores -- the reference's own arithmetic (default)
+ *   0  fp32 operands on the fp32 matrix cores -- the reference's own arithmetic
  *   1  fp32-accurate products on the BF16 matrix cores: each operand is cut into three bf16 pieces (exact
  *      split) while staged, six v_mfma_f32_32x32x16_bf16 partial products per K = 16, fp32 accumulation
  *   2  mixed precision, bf16 operands (round to nearest even), fp32 accumulation, fp32 outputs
  *   3  mixed precision, fp16 operands -- the reference's AMP mode (torch/trainer.py:363-367: HF Trainer
  *      fp16=True -> torch.cuda.amp.autocast; model/prediction_task.py:430); master weights stay fp32,
  *      LayerNorm / softmax / cross-entropy / the attention core stay fp32
- *   4  auto: fp32 accuracy, form 1 on the shapes where it measured faster than form 0
+ *   4  auto (default): fp32 accuracy, form 1 on the shapes where it measured faster than form 0
  * Launches whose operands are not 16-byte loadable, and the exact-rank evaluation epilogue, stay on form 0. */
 void t4r_set_precision(int mode);
 int t4r_get_precision(void);

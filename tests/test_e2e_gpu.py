@@ -913,7 +913,6 @@ def test_mixed_precision_mode(mode, dtype):
             out["loss"].backward()
         res[m] = (float(out["loss"].detach()), out["predictions"].detach().cpu(), cap["hid"].cpu(),
                   {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters() if p.grad is not None})
-    assert ops.get_precision() == "fp32"
     l32, p32, h32, g32 = res["fp32"]
     lh, ph, hh, gh = res[mode]
     eps = 2.0 ** -8 if mode == "bf16" else 2.0 ** -11

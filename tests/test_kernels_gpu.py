@@ -267,11 +267,13 @@ def _feat_setup(g, B, L, dims, cards):
     return ids, tabs
 
 
-@pytest.mark.parametrize("dims", [(128,), (64, 24, 8), (16, 12, 6), (32, 32, 32)])
+@pytest.mark.parametrize("dims", [(128,), (64, 24, 8), (16, 12, 6), (32, 32, 32),
+                                  (128, 64, 64, 64, 8, 8),        # C3's 336-wide row: fast path, 2 chunks per lane
+                                  (256, 200, 128, 64), (512, 512)])  # 648- and 1024-wide rows: 3-4 chunks per lane
 def test_seq_features_concat_and_mask_modes(ops, dims):
     g = torch.Generator().manual_seed(sum(dims))
     B, L = 37, 20
-    cards = [500, 40, 9][: len(dims)]
+    cards = [500, 40, 9, 77, 13, 300][: len(dims)]
     ids, tabs = _feat_setup(g, B, L, dims, cards)
     cols = np.cumsum([0] + list(dims))
     W = int(cols[-1])
@@ -914,10 +916,11 @@ def test_gemm_precision_modes_layouts(ops, mode, ta, tb, M, N, K):
     B = torch.randn((N, K) if tb else (K, N), generator=g)
     Ar, Br = _round_to(A, mode), _round_to(B, mode)
     ref = (Ar.t() if ta else Ar).double() @ (Br.t() if tb else Br).double()
+    before = ops.get_precision()
     with ops.precision(mode):
         assert ops.get_precision() == mode
         out = ops.gemm(cu(A), cu(B), bool(ta), bool(tb), alpha=0.5)
-    assert ops.get_precision() == "fp32"
+    assert ops.get_precision() == before            # the default is "auto" unless T4R_GEMM_PREC says otherwise
     close(out, (0.5 * ref).float(), rtol=1e-5, atol=1e-4)
     if mode != "fp32_bf16x3":     # and the rounding itself costs what half precision costs, no more
         full = (A.t() if ta else A).double() @ (B.t() if tb else B).double()

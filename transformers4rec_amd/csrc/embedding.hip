@@ -138,32 +138,37 @@ __global__ __launch_bounds__(256) void seq_features_fwd_kernel(SeqFeatParams p) 
     }
 }
 
-// Concatenation fast path: every feature width and column offset a multiple of 4 and the row no wider
-// than one 16-byte chunk per lane of the group, so a lane owns ONE (feature, chunk) for all its
-// tokens; U consecutive tokens per lane group with all id loads, then all row loads, in flight
-// together (the generic kernel has one dependent id -> row chain per lane).
-template <int GROUP, int U>
+// Concatenation fast path: every feature width and column offset a multiple of 4, so a lane owns fixed
+// (feature, 16-byte chunk) pairs for all its tokens -- NCH chunks per lane (chunk j of lane gl = columns
+// (gl + GROUP*j)*4 ..), i.e. rows up to GROUP*NCH*4 = 1024 floats wide (C3's 336-wide concatenation of
+// item 128 + 3 x 64 + 2 x 8 soft-embedding rows takes GROUP 64, NCH 2).  U consecutive tokens per lane group
+// with all id loads, then all row loads, in flight together (the generic kernel has one dependent
+// id -> row chain per lane).
+template <int GROUP, int U, int NCH>
 __global__ __launch_bounds__(256) void seq_features_fwd_fast_kernel(SeqFeatParams p) {
     const int gl = threadIdx.x & (GROUP - 1);
     const int grp = (int)(((long)blockIdx.x * 256 + threadIdx.x) / GROUP);
     const int ntok = p.B * p.L_out;
-    const int c0 = gl * 4;
     const int tok0 = grp * U;
-    if (c0 >= p.W || tok0 >= ntok) return;
-    int kind = 0, dim = 4, lc0 = 0;
-    long rows = 0;
-    const void* input = nullptr;
-    const float* table = nullptr;
-    for (int f = 0; f < p.n_feat; ++f) {
-        if (c0 >= p.col[f] && c0 < p.col[f] + p.dim[f]) {
-            kind = p.kind[f]; dim = p.dim[f]; lc0 = c0 - p.col[f]; rows = p.rows[f]; input = p.input[f];
-            table = p.table[f];
+    if (gl * 4 >= p.W || tok0 >= ntok) return;
+    int kind[NCH], dim[NCH], lc0[NCH];
+    long rows[NCH];
+    const void* input[NCH];
+    const float* table[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c0 = (gl + GROUP * j) * 4;
+        kind[j] = -1; dim[j] = 4; lc0[j] = 0; rows[j] = 0; input[j] = nullptr; table[j] = nullptr;
+        for (int f = 0; f < p.n_feat; ++f) {
+            if (c0 < p.W && c0 >= p.col[f] && c0 < p.col[f] + p.dim[f]) {
+                kind[j] = p.kind[f]; dim[j] = p.dim[f]; lc0[j] = c0 - p.col[f]; rows[j] = p.rows[f];
+                input[j] = p.input[f]; table[j] = p.table[f];
+            }
         }
     }
     const int mode = p.mask_mode;
-    const float* src[U];
     bool use[U], zero[U];
-    long id[U];
+    long id[U][NCH];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int tok = min(tok0 + u, ntok - 1);
@@ -174,29 +179,41 @@ __global__ __launch_bounds__(256) void seq_features_fwd_fast_kernel(SeqFeatParam
         if (mode == MASK_MLM) use[u] = !m;
         else if (mode == MASK_CLM) { use[u] = m; zero[u] = (l == p.L_out - 1); }
         else if (mode == MASK_CLM_INFER) use[u] = m;
-        const long r = (kind >= 2) ? (long)b : (long)ts;
-        id[u] = r;
-        if (kind == 0 || kind == 2) id[u] = reinterpret_cast<const long*>(input)[r];
-    }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        if (kind == 0 || kind == 2) {
-            if (id[u] < 0 || id[u] >= rows) { if (p.err) *p.err = 1; id[u] = 0; }
-            src[u] = table + id[u] * dim + lc0;
-        } else {
-            src[u] = reinterpret_cast<const float*>(input) + id[u] * dim + lc0;
+        for (int j = 0; j < NCH; ++j) {
+            const long r = (kind[j] >= 2) ? (long)b : (long)ts;
+            id[u][j] = r;
+            if (kind[j] == 0 || kind[j] == 2) id[u][j] = reinterpret_cast<const long*>(input[j])[r];
         }
     }
-    float4 v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (use[u] && !zero[u]) v[u] = *reinterpret_cast<const float4*>(src[u]);
-        else if (!use[u]) v[u] = *reinterpret_cast<const float4*>(p.masked_emb + c0);
-    }
+    const float* src[U][NCH];
 #pragma unroll
     for (int u = 0; u < U; ++u)
-        if (tok0 + u < ntok) *reinterpret_cast<float4*>(p.out + (long)(tok0 + u) * p.W + c0) = v[u];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            if (kind[j] == 0 || kind[j] == 2) {
+                if (id[u][j] < 0 || id[u][j] >= rows[j]) { if (p.err) *p.err = 1; id[u][j] = 0; }
+                src[u][j] = table[j] + id[u][j] * dim[j] + lc0[j];
+            } else {
+                src[u][j] = reinterpret_cast<const float*>(input[j]) + id[u][j] * dim[j] + lc0[j];
+            }
+        }
+    float4 v[U][NCH];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            v[u][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kind[j] < 0) continue;
+            if (use[u] && !zero[u]) v[u][j] = *reinterpret_cast<const float4*>(src[u][j]);
+            else if (!use[u]) v[u][j] = *reinterpret_cast<const float4*>(p.masked_emb + (gl + GROUP * j) * 4);
+        }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+            if (tok0 + u < ntok && kind[j] >= 0)
+                *reinterpret_cast<float4*>(p.out + (long)(tok0 + u) * p.W + (gl + GROUP * j) * 4) = v[u][j];
 }
 
 static int pick_group(int W) {
@@ -236,18 +253,23 @@ extern "C" int t4r_seq_features_fwd(
     const int g = pick_group(W);
     static int fast_u = -1;
     if (fast_u < 0) { const char* e = getenv("T4R_GATHER_U"); fast_u = e ? atoi(e) : 2; }
-    bool fast_ok = fast_u > 0 && agg == AGG_CONCAT && (W & 3) == 0 && W <= g * 4 && g >= 8 &&
+    const int units = (W + 3) / 4;
+    const int nch = (units + g - 1) / g;                // 16-byte chunks per lane
+    bool fast_ok = fast_u > 0 && agg == AGG_CONCAT && (W & 3) == 0 && nch <= 4 && g >= 8 &&
                    (long)B * L_out * g < 0x7fffffffL;
     for (int f = 0; f < n_feat && fast_ok; ++f) fast_ok = (p.dim[f] & 3) == 0 && (p.col[f] & 3) == 0;
     if (fast_ok) {
-        const int U = fast_u >= 4 ? 4 : 2;
+        const int U = (fast_u >= 4 && nch == 1) ? 4 : 2;
         const long groups = ((long)B * L_out + U - 1) / U;
         dim3 fgrid((unsigned)((groups * g + 255) / 256));
         hipStream_t fst = (hipStream_t)stream;
 #define T4R_FAST(G)                                                                                          \
-    if (U == 4) hipLaunchKernelGGL((seq_features_fwd_fast_kernel<G, 4>), fgrid, dim3(256), 0, fst, p);        \
-    else hipLaunchKernelGGL((seq_features_fwd_fast_kernel<G, 2>), fgrid, dim3(256), 0, fst, p)
-        switch (g) {
+    if (U == 4) hipLaunchKernelGGL((seq_features_fwd_fast_kernel<G, 4, 1>), fgrid, dim3(256), 0, fst, p);     \
+    else hipLaunchKernelGGL((seq_features_fwd_fast_kernel<G, 2, 1>), fgrid, dim3(256), 0, fst, p)
+        if (nch > 1) {      // rows wider than 256 floats: the 64-lane group, 2 or 4 chunks per lane
+            if (nch == 2) hipLaunchKernelGGL((seq_features_fwd_fast_kernel<64, 2, 2>), fgrid, dim3(256), 0, fst, p);
+            else hipLaunchKernelGGL((seq_features_fwd_fast_kernel<64, 2, 4>), fgrid, dim3(256), 0, fst, p);
+        } else switch (g) {
             case 8: T4R_FAST(8); break;
             case 16: T4R_FAST(16); break;
             case 32: T4R_FAST(32); break;

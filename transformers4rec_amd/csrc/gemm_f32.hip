@@ -32,18 +32,18 @@ static int launch_cfg(const GemmParams& p, int batch, hipStream_t stream) {
 }
 
 // ---- precision of the contraction (process-wide; the backward runs on autograd's thread, so not thread-local)
-//   0 fp32 matrix cores (default; the reference's own arithmetic)
+//   0 fp32 matrix cores (the reference's own arithmetic)
 //   1 fp32-accurate on the bf16 matrix cores (exact 3-way split, six products) wherever the operands allow it
 //   2 / 3 mixed precision, bf16 / fp16 operands, fp32 accumulation (the reference's AMP: trainer.py:363-367)
-//   4 auto: fp32 accuracy, the split form on the shapes where it measured faster (see auto_split)
+//   4 auto (default): fp32 accuracy, the split form on the shapes where it measured faster (see auto_split)
 static std::atomic<int> g_prec{-1};
 extern "C" void t4r_set_precision(int mode) { g_prec.store(mode < 0 || mode > 4 ? 0 : mode); }
 extern "C" int t4r_get_precision(void) {
     int m = g_prec.load();
     if (m < 0) {
         const char* e = getenv("T4R_GEMM_PREC");
-        m = e ? atoi(e) : 0;
-        if (m < 0 || m > 4) m = 0;
+        m = e ? atoi(e) : 4;        // default: auto (fp32 accuracy; the split form where it is faster)
+        if (m < 0 || m > 4) m = 4;
         g_prec.store(m);
     }
     return m;

@@ -54,9 +54,9 @@ PRECISIONS = {"fp32": 0, "fp32_bf16x3": 1, "bf16": 2, "fp16": 3, "auto": 4}
 
 def set_precision(mode):
     """precision of every dense contraction launched from now on (include/t4r_hip.h: t4r_set_precision):
-    "fp32" (fp32 matrix cores, default) | "fp32_bf16x3" (fp32-accurate on the bf16 cores, exact 3-way split) |
+    "fp32" (fp32 matrix cores) | "fp32_bf16x3" (fp32-accurate on the bf16 cores, exact 3-way split) |
     "bf16" / "fp16" (mixed precision as the reference's AMP: half operands, fp32 accumulation, fp32 master
-    weights) | "auto".  Returns the previous mode name."""
+    weights) | "auto" (default: fp32 accuracy, the split form where it is faster).  Returns the previous mode."""
     prev = get_precision()
     _lib.load().t4r_set_precision(PRECISIONS[mode] if isinstance(mode, str) else int(mode))
     return prev

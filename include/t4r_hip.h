@@ -235,18 +235,23 @@ int t4r_colsum(void* stream, const float* x, float* out, float* ws, long rows, i
  * q,k,v,out [B*L, n_head*d_head]; k_r [2L, D] = pos_emb @ r (kr_per_batch: [B,2L,D], one set per
  * session, used when pos_emb dropout is on); lse [B,n,L]; L <= 64.  drop_p: attention-probability
  * dropout (HF :132), mask index ((b*n+h)*L+i)*L+j.
- * backward: d_r_w_bias / d_r_r_bias accumulated, the rest overwritten (dk_r has k_r's shape). */
+ * backward: d_r_w_bias / d_r_r_bias accumulated, the rest overwritten (dk_r has k_r's shape).
+ * key_len (device int32 [B], may be NULL = the reference's behaviour: NO padding mask): opt-in
+ * padding mask -- keys at positions >= key_len[b] get the score -1e30 except on the diagonal, as HF XLNet does
+ * when it is given an attention_mask (modeling_xlnet.py: attn_score - 1e30 * attn_mask, non_tgt_mask keeps
+ * i == j).  t4r_session_lengths produces key_len from the item ids. */
+int t4r_session_lengths(void* stream, const long* item_ids, int B, int L, int padding_idx, int extra, int* out);
 int t4r_xlnet_attn_fwd(void* stream, const float* q, const float* k, const float* v, const float* k_r,
                        const float* r_w_bias, const float* r_r_bias, float* out, float* lse, int B,
                        int L, int n_head, int d_head, int kr_per_batch, float drop_p,
-                       unsigned long long seed, unsigned long long ctr_hi);
+                       unsigned long long seed, unsigned long long ctr_hi, const int* key_len);
 long t4r_xlnet_attn_bwd_ws_floats(int B, int L, int D, int n_head);
 int t4r_xlnet_attn_bwd(void* stream, const float* q, const float* k, const float* v, const float* k_r,
                        const float* r_w_bias, const float* r_r_bias, const float* out,
                        const float* lse, const float* dout, float* dq, float* dk, float* dv,
                        float* dk_r, float* d_r_w_bias, float* d_r_r_bias, float* workspace, int B,
                        int L, int n_head, int d_head, int kr_per_batch, float drop_p,
-                       unsigned long long seed, unsigned long long ctr_hi);
+                       unsigned long long seed, unsigned long long ctr_hi, const int* key_len);
 /* a16  scaled-dot-product attention core of the GPT-2 (causal) and BERT blocks
  * replaces: HF gpt2/modeling_gpt2.py eager_attention_forward :54-72 ; HF bert BertSelfAttention.
  * q,k,v rows of `ld` floats (3*D for GPT-2's fused c_attn output), head h at columns h*d_head..;
@@ -277,11 +282,12 @@ long t4r_xlnet_layer_ws_floats(int B, int L, int D, int n_head, int dropout);
 long t4r_xlnet_layer_bwd_ws_floats(int B, int L, int D, int n_head, int dropout);
 int t4r_xlnet_layer_fwd(void* stream, const float* h, const float* pos_emb, const float* const* params,
                         float* ws, float* h_out, int B, int L, int D, int n_head, float ln_eps,
-                        float drop_p, unsigned long long seed, unsigned long long offset, int layer_idx);
+                        float drop_p, unsigned long long seed, unsigned long long offset, int layer_idx,
+                        const int* key_len);
 int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* pos_emb, const float* const* params,
                         float* const* grads, const float* ws, float* bws, const float* dh_out,
                         float* dh_in, int B, int L, int D, int n_head, float ln_eps, float drop_p,
-                        unsigned long long seed, unsigned long long offset, int layer_idx);
+                        unsigned long long seed, unsigned long long offset, int layer_idx, const int* key_len);
 
 /* ----------------------------------------------------------------------------------------
  * a18-a21  next-item head

@@ -931,3 +931,38 @@ def test_mixed_precision_mode(mode, dtype):
         ref = O.session_forward(p, dict(n_head=int(d["meta/n_head"]), eps=0.03, item="item_id", masking="mlm"), ids,
                                 gu.t(d["out/mask_schema"]), gu.t(d["out/masked_targets"]), True, False)
     assert abs(lh - float(ref["loss"])) < 60 * eps * max(1.0, abs(l32)), (lh, float(ref["loss"]))
+
+
+def test_mask_padding_option_end_to_end():
+    """TransformerBlock(mask_padding=True): train step vs the oracle with the same key mask; the default (False)
+    stays the reference's unmasked attention (fixture parity is what every other test checks)."""
+    import transformers4rec_amd as tr
+
+    d = gu.load("xlnet_mlm_item_train")
+    res = {}
+    for mp in (False, True):
+        model = build_model(d, emb_default=32)
+        load_reference_state(model, d)
+        model.transformer_block.mask_padding = mp
+        model.to(DEV)
+        x = {k[3:]: gu.t(v).to(DEV) for k, v in d.items() if k.startswith("in/")}
+        model.input_features.masking.set_draws(gu.t(d["draw/bern"]).to(DEV).to(torch.uint8), gu.t(d["draw/j1"]).to(DEV),
+                                               gu.t(d["draw/j2"]).to(DEV))
+        out = model(x, training=True)
+        out["loss"].backward()
+        res[mp] = (out, model)
+    p = gu.oracle_params(d, requires_grad=True)
+    ids = gu.t(d["in/item_id"])
+    key_len = (ids != 0).sum(1).to(torch.int32)
+    mask, labels = gu.t(d["out/mask_schema"]), gu.t(d["out/masked_targets"])
+    xe = O.apply_mask_mlm(O.embedding_lookup(ids, p["tables"]["item_id"]), mask, p["masked_item_embedding"], True, False)
+    h = O.xlnet_model(xe, p["layers"], int(d["meta/n_head"]), 0.03, key_len=key_len)
+    xr, y = O.remove_pad_rows(h, labels)
+    loss = O.cross_entropy(O.head_logits(xr, p["tables"]["item_id"], 1.0), y)
+    loss.backward()
+    out_t, model_t = res[True]
+    assert abs(float(out_t["loss"].detach()) - float(loss)) < 1e-4
+    close(model_t.input_features.item_embedding_table.weight.grad, p["tables"]["item_id"].grad, rtol=2e-4, atol=1e-4)
+    close(model_t.transformer_block.transformer.layer[0].rel_attn.q.grad, p["layers"][0]["q"].grad, rtol=2e-4, atol=1e-4)
+    assert abs(float(res[False][0]["loss"].detach()) - float(d["out/loss"])) < 1e-4       # default: the reference
+    assert abs(float(out_t["loss"].detach()) - float(res[False][0]["loss"].detach())) > 1e-6

@@ -975,3 +975,37 @@ def test_gemm_precision_modes_features(ops, mode):
     loose = dict(rtol=2e-2, atol=2e-5) if mode != "fp32_bf16x3" else dict(rtol=1e-4, atol=2e-6)
     close(dx, dl @ Wt, **loose)
     close(dW, dl.t() @ x, **loose)
+
+
+# ------------------------------------------------------------------------------------ opt-in attention padding mask
+@pytest.mark.parametrize("B,L,D,n", [(6, 20, 128, 4), (5, 20, 64, 4), (4, 40, 64, 4), (3, 9, 32, 4), (4, 32, 64, 2)])
+def test_xlnet_attention_padding_mask(ops, B, L, D, n):
+    """key_len (opt-in, default off): keys >= key_len[b] masked except on the diagonal, forward and backward of the
+    whole layer on both kernel families (matrix-core: L <= 32 and d_head 16 / 32; VALU otherwise) vs the oracle,
+    whose mask is pinned against HF XLNetModel(attention_mask=...) in tests/test_oracle_vs_hf.py."""
+    g = torch.Generator().manual_seed(B * 5 + L + D)
+    prm = _layer_params(g, D, n)
+    pr = {k: v.clone().requires_grad_() for k, v in prm.items()}
+    h = torch.randn(B, L, D, generator=g)
+    hr = h.clone().requires_grad_()
+    key_len = torch.randint(1, L + 1, (B,), generator=g).to(torch.int32)
+    key_len[0], key_len[-1] = L, 1
+    ref = O.xlnet_layer(hr, pr, n, 0.03, key_len=key_len)
+    dout = torch.randn(B, L, D, generator=g)
+    ref.backward(dout)
+    pos = cu(O.xlnet_pos_emb(L, D))
+    params = [cu(prm[k]) for k in ORDER]
+    out, ws = ops.xlnet_layer_fwd(cu(h).view(B * L, D), pos, params, B, L, n, 0.03, key_len=cu(key_len))
+    close(out, ref.detach().reshape(B * L, D), atol=5e-5)
+    plain, _ = ops.xlnet_layer_fwd(cu(h).view(B * L, D), pos, params, B, L, n, 0.03)
+    assert float((plain - out).abs().max()) > 1e-4          # and None keeps the reference's unmasked attention
+    grads = [torch.zeros_like(t) for t in params]
+    dh = ops.xlnet_layer_bwd(cu(h).view(B * L, D), pos, params, grads, ws, cu(dout).view(B * L, D), B, L, n, 0.03,
+                             key_len=cu(key_len))
+    close(dh, hr.grad.reshape(B * L, D), rtol=1e-4, atol=3e-4)
+    for k, gt in zip(ORDER, grads):
+        close(gt.reshape(-1), pr[k].grad.reshape(-1), rtol=1e-4, atol=8e-4, msg=lambda mm, k=k: f"{k}: {mm}")
+    # session_lengths: non-pad count (+ the MLM inference slot)
+    ids = (torch.arange(L)[None] < key_len[:, None]).long() * 7
+    assert torch.equal(ops.session_lengths(cu(ids)).cpu(), key_len)
+    assert torch.equal(ops.session_lengths(cu(ids), 0, 1).cpu(), key_len + 1)

@@ -78,3 +78,26 @@ def test_bert_restatement_matches_hf(B, L, D, n, layers):
         ref = m(inputs_embeds=x)[0]
         got = O.bert_model(x, O.bert_params_from_state(m.state_dict()), n, 0.03)
     torch.testing.assert_close(got, ref, rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("B,L,D,n,layers", [(4, 20, 64, 4, 2), (3, 9, 32, 2, 1)])
+def test_xlnet_padding_mask_restatement_matches_hf(B, L, D, n, layers):
+    """the opt-in padding mask (oracle key_padding_mask; kernels: key_len) == HF XLNetModel given an attention_mask:
+    padded keys get -1e30 except on the diagonal (modeling_xlnet.py non_tgt_mask)."""
+    cfg = transformers.XLNetConfig(
+        d_model=D, d_inner=4 * D, n_layer=layers, n_head=n, attn_type="bi", ff_activation="gelu",
+        initializer_range=0.01, layer_norm_eps=0.03, dropout=0.0, pad_token_id=0, vocab_size=1, mem_len=1)
+    torch.manual_seed(1)
+    m = transformers.XLNetModel(cfg).eval()
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            p.copy_(1 + 0.1 * torch.randn_like(p) if "layer_norm.weight" in name else 0.1 * torch.randn_like(p))
+    x = torch.randn(B, L, D)
+    key_len = torch.tensor([L, 1, L // 2, 3][:B], dtype=torch.int32)
+    attn_mask = (torch.arange(L)[None] < key_len[:, None]).float()
+    with torch.no_grad():
+        ref = m(inputs_embeds=x, attention_mask=attn_mask)[0]
+        got = O.xlnet_model(x, [O.xlnet_layer_params_from_hf(l) for l in m.layer], n, 0.03, key_len=key_len)
+        unmasked = O.xlnet_model(x, [O.xlnet_layer_params_from_hf(l) for l in m.layer], n, 0.03)
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5)
+    assert float((got - unmasked).abs().max()) > 1e-3          # the mask matters on these inputs

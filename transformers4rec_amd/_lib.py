@@ -54,13 +54,14 @@ _SIGS = {
     "t4r_colreduce_ws_floats": ("l", "li"),
     "t4r_act_bwd_bias": ("i", "pppppp" + "lii" + "fQQ"),
     "t4r_colsum": ("i", "pppp" + "lil"),
-    "t4r_xlnet_attn_fwd": ("i", "ppppppppp" + "iiii" + "ifQQ"),
+    "t4r_session_lengths": ("i", "pp" + "iiii" + "p"),
+    "t4r_xlnet_attn_fwd": ("i", "ppppppppp" + "iiii" + "ifQQ" + "p"),
     "t4r_xlnet_attn_bwd_ws_floats": ("l", "iiii"),
-    "t4r_xlnet_attn_bwd": ("i", "p" * 17 + "iiii" + "ifQQ"),
+    "t4r_xlnet_attn_bwd": ("i", "p" * 17 + "iiii" + "ifQQ" + "p"),
     "t4r_xlnet_layer_ws_floats": ("l", "iiiii"),
     "t4r_xlnet_layer_bwd_ws_floats": ("l", "iiiii"),
-    "t4r_xlnet_layer_fwd": ("i", "pppppp" + "iiiif" + "fQQi"),
-    "t4r_xlnet_layer_bwd": ("i", "ppppppppp" + "iiiif" + "fQQi"),
+    "t4r_xlnet_layer_fwd": ("i", "pppppp" + "iiiif" + "fQQi" + "p"),
+    "t4r_xlnet_layer_bwd": ("i", "ppppppppp" + "iiiif" + "fQQi" + "p"),
     "t4r_softmax_ce_fwd": ("i", "pppppp" + "iilf"),
     "t4r_softmax_ce_bwd": ("i", "pppppp" + "iilf"),
     "t4r_linear_softmax_ce_chunk_floats": ("l", "ii"),

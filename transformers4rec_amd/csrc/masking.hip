@@ -330,3 +330,23 @@ extern "C" int t4r_last_positions(void* stream, const long* item_ids, int B, int
     T4R_LAUNCH_CHECK();
     return 0;
 }
+
+// number of non-padding positions per session (+ extra), int32 [B]: the key_len of the opt-in attention
+// padding mask (sessions are right-padded: utils/padding.py:48-68, so the valid keys are a prefix)
+__global__ __launch_bounds__(256) void session_lengths_kernel(const long* __restrict__ ids, int B, int L,
+                                                               int padding_idx, int extra, int* __restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int n = 0;
+    for (int l = 0; l < L; ++l) n += ids[(long)b * L + l] != padding_idx ? 1 : 0;
+    out[b] = n + extra;
+}
+extern "C" int t4r_session_lengths(void* stream, const long* item_ids, int B, int L, int padding_idx, int extra,
+                                   int* out) {
+    if (B <= 0) return 0;
+    T4R_CHECK_ARG(item_ids && out && L >= 1, "session_lengths: bad arguments");
+    hipLaunchKernelGGL(session_lengths_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, item_ids, B, L,
+                       padding_idx, extra, out);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}

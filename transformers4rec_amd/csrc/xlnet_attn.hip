@@ -17,6 +17,8 @@
 // Forward is a single online-softmax pass and saves only the row log-sum-exp; backward
 // recomputes the probabilities (no [B,n,L,L] tensor ever goes to HBM).
 #include "t4r_common.h"
+// additive score of a masked key (opt-in padding mask): HF modeling_xlnet.py subtracts 1e30 * attn_mask in fp32
+#define T4R_KEY_MASKED (-1e30f)
 #include <stdlib.h>
 
 #define ATT_PAD 4
@@ -31,7 +33,7 @@ __global__ __launch_bounds__(64 * HeadsPerBlock<DH>::v) void xlnet_attn_fwd_kern
     const float* __restrict__ r_w_bias, const float* __restrict__ r_r_bias,  // [D]
     float* __restrict__ out,           // [B*L, D]
     float* __restrict__ lse,           // [B, n, L]
-    int B, int L, int n_head, float scale, long kr_bstride, DropCfg drop) {
+    int B, int L, int n_head, float scale, long kr_bstride, DropCfg drop, const int* key_len) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int D = n_head * DH;
     const int LD = D + ATT_PAD;
@@ -73,6 +75,7 @@ __global__ __launch_bounds__(64 * HeadsPerBlock<DH>::v) void xlnet_attn_fwd_kern
 #pragma unroll
         for (int d = 0; d < DH; ++d) o[d] = 0.f;
         float m = -INFINITY, l = 0.f;
+        const int klen = key_len ? key_len[b] : L;
         for (int j = 0; j < L; ++j) {
             const float* kj = Ks + j * LD + hc;
             const float* krp = KRs + (j + L - i) * LD + hc;
@@ -85,6 +88,7 @@ __global__ __launch_bounds__(64 * HeadsPerBlock<DH>::v) void xlnet_attn_fwd_kern
                 s += qr[d] * c.x + qr[d + 1] * c.y + qr[d + 2] * c.z + qr[d + 3] * c.w;
             }
             s *= scale;
+            if (j >= klen && j != i) s = T4R_KEY_MASKED;     // opt-in padding mask (HF: score - 1e30 * mask, diagonal kept)
             const float mn = fmaxf(m, s);
             const float alpha = __expf(m - mn);
             const float pj = __expf(s - mn);
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(64 * HeadsPerBlock<DH>::v) void xlnet_attn_bwd_kern
     float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
     float* __restrict__ part,          // [grid][2L*D + 2*D]
     float* __restrict__ dkr_b,         // per-batch d k_r [B][2L][D] (kr_bstride > 0) or null
-    int B, int L, int n_head, float scale, long kr_bstride, DropCfg drop) {
+    int B, int L, int n_head, float scale, long kr_bstride, DropCfg drop, const int* key_len) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int D = n_head * DH;
     const int LD = D + ATT_PAD;
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(64 * HeadsPerBlock<DH>::v) void xlnet_attn_bwd_kern
                     s += qr[d] * c.x + qr[d + 1] * c.y + qr[d + 2] * c.z + qr[d + 3] * c.w;
                     dp += gq.x * e.x + gq.y * e.y + gq.z * e.z + gq.w * e.w;
                 }
-                const float p = __expf(s * scale - lse_i);
+                const float p = (key_len && j >= key_len[b] && j != i) ? 0.f : __expf(s * scale - lse_i);
                 const float msk = drop.p > 0.f ? prow[j] : 1.f;
                 const float ds = p * (dp * msk - Di) * scale;
                 prow[j] = p * msk;    // dropped probability: what multiplied v in the forward
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(64) void xlnet_attn_bwd_pairs_kernel(
     const float* __restrict__ kr, const float* __restrict__ r_w_bias, const float* __restrict__ r_r_bias,
     const float* __restrict__ out, const float* __restrict__ lse, const float* __restrict__ dout,
     float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv, float* __restrict__ part,
-    float* __restrict__ dkr_b, int B, int L, int n_head, float scale, long kr_bstride, DropCfg drop) {
+    float* __restrict__ dkr_b, int B, int L, int n_head, float scale, long kr_bstride, DropCfg drop, const int* key_len) {
     constexpr int LDH = DH + 4;
     constexpr int C = DH / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(64) void xlnet_attn_bwd_pairs_kernel(
                      (a.w + dl.w - dw.w) * ck.w;
                 dp += e.x * f.x + e.y * f.y + e.z * f.z + e.w * f.w;
             }
-            const float pr = __expf(s * scale - Lrow[i]);
+            const float pr = (key_len && j >= key_len[b] && j != i) ? 0.f : __expf(s * scale - Lrow[i]);
             const float msk = drop.p > 0.f ? drop_scale(drop, (mbase + i) * L + j) : 1.f;
             dSs[i * LS + j] = pr * (dp * msk - Drow[i]) * scale;
             Pds[i * LS + j] = pr * msk;
@@ -510,11 +514,11 @@ extern "C" long t4r_xlnet_attn_bwd_ws_floats(int B, int L, int D, int n_head) {
 int t4r_xlnet_attn_mfma_ok(int L, int d_head);
 int t4r_xlnet_attn_mfma_fwd(hipStream_t st, const float* q, const float* k, const float* v, const float* kr,
                             const float* rw, const float* rr, float* out, float* lse, int B, int L, int n_head,
-                            int d_head, float scale, long kr_bstride, DropCfg drop);
+                            int d_head, float scale, long kr_bstride, DropCfg drop, const int* key_len);
 int t4r_xlnet_attn_mfma_bwd(hipStream_t st, const float* q, const float* k, const float* v, const float* kr,
                             const float* rw, const float* rr, const float* lse, const float* dout, float* dq,
                             float* dk, float* dv, float* part, float* dkr, float* d_rw, float* d_rr, int B, int L,
-                            int n_head, int d_head, float scale, long kr_bstride, DropCfg drop);
+                            int n_head, int d_head, float scale, long kr_bstride, DropCfg drop, const int* key_len);
 static bool use_mfma(int L, int d_head) {
     static int en = -1;
     if (en < 0) { const char* e = getenv("T4R_ATTN_MFMA"); en = e ? atoi(e) : 1; }
@@ -524,7 +528,7 @@ static bool use_mfma(int L, int d_head) {
 template <int DH>
 static int attn_fwd_launch(hipStream_t st, const float* q, const float* k, const float* v,
                            const float* kr, const float* rw, const float* rr, float* out, float* lse,
-                           int B, int L, int n_head, float scale, long kr_bstride, DropCfg drop) {
+                           int B, int L, int n_head, float scale, long kr_bstride, DropCfg drop, const int* key_len) {
     const int D = n_head * DH;
     const size_t smem = attn_fwd_smem(L, D);
     static size_t attr = 0;
@@ -536,7 +540,7 @@ static int attn_fwd_launch(hipStream_t st, const float* q, const float* k, const
     constexpr int HPB = HeadsPerBlock<DH>::v;
     const int waves = n_head < HPB ? n_head : HPB;
     hipLaunchKernelGGL(xlnet_attn_fwd_kernel<DH>, dim3(B, (n_head + HPB - 1) / HPB), dim3(64 * waves), smem, st, q, k, v, kr, rw,
-                       rr, out, lse, B, L, n_head, scale, kr_bstride, drop);
+                       rr, out, lse, B, L, n_head, scale, kr_bstride, drop, key_len);
     T4R_LAUNCH_CHECK();
     return 0;
 }
@@ -547,7 +551,7 @@ extern "C" int t4r_xlnet_attn_fwd(void* stream, const float* q, const float* k, 
                                   const float* k_r, const float* r_w_bias, const float* r_r_bias,
                                   float* out, float* lse, int B, int L, int n_head, int d_head,
                                   int kr_per_batch, float drop_p, unsigned long long seed,
-                                  unsigned long long ctr_hi) {
+                                  unsigned long long ctr_hi, const int* key_len) {
     if (B == 0) return 0;
     T4R_CHECK_ARG(L >= 1 && L <= 64, "xlnet_attn: L must be in [1, 64]");
     const int D = n_head * d_head;
@@ -557,13 +561,13 @@ extern "C" int t4r_xlnet_attn_fwd(void* stream, const float* q, const float* k, 
     const DropCfg dc = make_drop(drop_p, seed, ctr_hi);
     if (use_mfma(L, d_head))
         return t4r_xlnet_attn_mfma_fwd(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, B, L, n_head, d_head, scale,
-                                       bs, dc);
+                                       bs, dc, key_len);
     T4R_CHECK_ARG(attn_fwd_smem(L, D) <= 160 * 1024, "xlnet_attn: L*d_model too large for LDS");
     switch (d_head) {
-        case 8: return attn_fwd_launch<8>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, B, L, n_head, scale, bs, dc);
-        case 16: return attn_fwd_launch<16>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, B, L, n_head, scale, bs, dc);
-        case 32: return attn_fwd_launch<32>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, B, L, n_head, scale, bs, dc);
-        case 64: return attn_fwd_launch<64>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, B, L, n_head, scale, bs, dc);
+        case 8: return attn_fwd_launch<8>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, B, L, n_head, scale, bs, dc, key_len);
+        case 16: return attn_fwd_launch<16>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, B, L, n_head, scale, bs, dc, key_len);
+        case 32: return attn_fwd_launch<32>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, B, L, n_head, scale, bs, dc, key_len);
+        case 64: return attn_fwd_launch<64>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, B, L, n_head, scale, bs, dc, key_len);
     }
     t4r_set_error("xlnet_attn: d_head must be 8, 16, 32 or 64");
     return -1;
@@ -574,14 +578,14 @@ static int attn_bwd_launch(hipStream_t st, const float* q, const float* k, const
                            const float* kr, const float* rw, const float* rr, const float* out,
                            const float* lse, const float* dout, float* dq, float* dk, float* dv,
                            float* part, float* dkr, float* d_rw, float* d_rr, int B, int L, int n_head,
-                           float scale, long kr_bstride, DropCfg drop) {
+                           float scale, long kr_bstride, DropCfg drop, const int* key_len) {
     const int D = n_head * DH;
     if (L <= 32 && (DH == 16 || DH == 32 || DH == 8) && 2 * L * (DH / 4) <= 64 * PAIRS_NKR) {
         const size_t sm2 = ((size_t)6 * L * (DH + 4) + 2 * L * (L + 1) + 2 * L) * sizeof(float);
         const int gx = B < 512 ? B : 512;
         hipLaunchKernelGGL(xlnet_attn_bwd_pairs_kernel<DH>, dim3(gx, n_head), dim3(64), sm2, st, q, k, v, kr, rw, rr,
                            out, lse, dout, dq, dk, dv, part, kr_bstride > 0 ? dkr : nullptr, B, L, n_head, scale,
-                           kr_bstride, drop);
+                           kr_bstride, drop, key_len);
         T4R_LAUNCH_CHECK();
         return t4r_reduce_partials_launch(st, part, gx, kr_bstride > 0 ? nullptr : dkr, 2 * L * D, 0, d_rw, D, 1,
                                           d_rr, D, 1);
@@ -599,7 +603,7 @@ static int attn_bwd_launch(hipStream_t st, const float* q, const float* k, const
     const int nblocks = t4r_xlnet_attn_bwd_blocks(B);
     hipLaunchKernelGGL(xlnet_attn_bwd_kernel<DH>, dim3(nblocks, hg), dim3(64 * waves), smem, st, q, k, v, kr,
                        rw, rr, out, lse, dout, dq, dk, dv, part, kr_bstride > 0 ? dkr : nullptr, B, L, n_head,
-                       scale, kr_bstride, drop);
+                       scale, kr_bstride, drop, key_len);
     T4R_LAUNCH_CHECK();
     // d k_r overwritten (shared k_r: summed over sessions here), bias gradients accumulated
     return t4r_reduce_partials_launch(st, part, nblocks * hg, kr_bstride > 0 ? nullptr : dkr, 2 * L * D, 0,
@@ -613,7 +617,7 @@ extern "C" int t4r_xlnet_attn_bwd(void* stream, const float* q, const float* k, 
                                   float* dk, float* dv, float* dk_r, float* d_r_w_bias,
                                   float* d_r_r_bias, float* workspace, int B, int L, int n_head,
                                   int d_head, int kr_per_batch, float drop_p, unsigned long long seed,
-                                  unsigned long long ctr_hi) {
+                                  unsigned long long ctr_hi, const int* key_len) {
     if (B == 0) return 0;
     T4R_CHECK_ARG(L >= 1 && L <= 64, "xlnet_attn: L must be in [1, 64]");
     const int D = n_head * d_head;
@@ -623,12 +627,12 @@ extern "C" int t4r_xlnet_attn_bwd(void* stream, const float* q, const float* k, 
     const DropCfg dc = make_drop(drop_p, seed, ctr_hi);
     if (use_mfma(L, d_head))
         return t4r_xlnet_attn_mfma_bwd(st, q, k, v, k_r, r_w_bias, r_r_bias, lse, dout, dq, dk, dv, workspace, dk_r,
-                                       d_r_w_bias, d_r_r_bias, B, L, n_head, d_head, scale, bs, dc);
+                                       d_r_w_bias, d_r_r_bias, B, L, n_head, d_head, scale, bs, dc, key_len);
     T4R_CHECK_ARG(attn_bwd_smem(L, D, n_head) <= 160 * 1024, "xlnet_attn_bwd: L*d_model too large for LDS");
     switch (d_head) {
-        case 8: return attn_bwd_launch<8>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, dout, dq, dk, dv, workspace, dk_r, d_r_w_bias, d_r_r_bias, B, L, n_head, scale, bs, dc);
-        case 16: return attn_bwd_launch<16>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, dout, dq, dk, dv, workspace, dk_r, d_r_w_bias, d_r_r_bias, B, L, n_head, scale, bs, dc);
-        case 32: return attn_bwd_launch<32>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, dout, dq, dk, dv, workspace, dk_r, d_r_w_bias, d_r_r_bias, B, L, n_head, scale, bs, dc);
+        case 8: return attn_bwd_launch<8>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, dout, dq, dk, dv, workspace, dk_r, d_r_w_bias, d_r_r_bias, B, L, n_head, scale, bs, dc, key_len);
+        case 16: return attn_bwd_launch<16>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, dout, dq, dk, dv, workspace, dk_r, d_r_w_bias, d_r_r_bias, B, L, n_head, scale, bs, dc, key_len);
+        case 32: return attn_bwd_launch<32>(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, dout, dq, dk, dv, workspace, dk_r, d_r_w_bias, d_r_r_bias, B, L, n_head, scale, bs, dc, key_len);
     }
     t4r_set_error("xlnet_attn_bwd: d_head must be 8, 16 or 32");
     return -1;

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(T4R_ATTN_FWD_BOUNDS) void xlnet_attn_mfma_fwd_kerne
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const float* __restrict__ kr, const float* __restrict__ r_w_bias, const float* __restrict__ r_r_bias,
     float* __restrict__ out, float* __restrict__ lse, int B, int L, int n_head, float scale, long kr_bstride,
-    DropCfg drop) {
+    DropCfg drop, const int* key_len) {
     __shared__ __attribute__((aligned(16))) float Sm[32 * XM_SP];
     __shared__ __attribute__((aligned(16))) float Rm[32 * XM_RP];
     const int lane = threadIdx.x;
@@ -141,9 +141,11 @@ __global__ __launch_bounds__(T4R_ATTN_FWD_BOUNDS) void xlnet_attn_mfma_fwd_kerne
         scores_row_layout<DH>(sf, L, rw, del, scale, Sm, Rm, c, kh, s);
         // softmax over j of row i = c (two lanes per row, 16 columns each)
         float m = -INFINITY;
+        const int klen = key_len ? key_len[b] : L;     // opt-in padding mask: keys >= klen masked, the diagonal kept (HF)
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             if (kh * 16 + t >= L) s[t] = -INFINITY;
+            else if (kh * 16 + t >= klen && kh * 16 + t != c) s[t] = -1e30f;
             m = fmaxf(m, s[t]);
         }
         m = fmaxf(m, __shfl_xor(m, 32, 64));
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(T4R_ATTN_BWD_BOUNDS) void xlnet_attn_mfma_bwd_kerne
     const float* __restrict__ kr, const float* __restrict__ r_w_bias, const float* __restrict__ r_r_bias,
     const float* __restrict__ lse, const float* __restrict__ dout, float* __restrict__ dq,
     float* __restrict__ dk, float* __restrict__ dv, float* __restrict__ part, float* __restrict__ dkr_b, int B,
-    int L, int n_head, float scale, long kr_bstride, DropCfg drop) {
+    int L, int n_head, float scale, long kr_bstride, DropCfg drop, const int* key_len) {
     __shared__ __attribute__((aligned(16))) float Sm[32 * XM_SP];
     __shared__ __attribute__((aligned(16))) float Pm[32 * XM_SP];   // dropped probabilities, parked for d v
     __shared__ __attribute__((aligned(16))) float Rm[32 * XM_RP];
@@ -229,8 +231,10 @@ __global__ __launch_bounds__(T4R_ATTN_BWD_BOUNDS) void xlnet_attn_mfma_bwd_kerne
         scores_row_layout<DH>(sf, L, rw, del, scale, Sm, Rm, c, kh, s);
         const float lrow = lse[((long)b * n_head + h) * L + ic];
         Frag<16> P;
+        const int klen = key_len ? key_len[b] : L;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) P.v[t] = (row_ok && kh * 16 + t < L) ? __expf(s[t] - lrow) : 0.f;
+        for (int t = 0; t < 16; ++t)
+            P.v[t] = (row_ok && kh * 16 + t < L && !(kh * 16 + t >= klen && kh * 16 + t != c)) ? __expf(s[t] - lrow) : 0.f;
         ATTN_PHASE_FENCE();   // keeps later phases' operand loads out of this one
         // (operands of the NEXT phase are requested at the start of each phase: the fences keep them here)
         Frag<16> krc[2];          // k_r column fragments for d q += d raw K_r : k = m = kh*32 + 16u + t
@@ -406,14 +410,14 @@ int t4r_xlnet_attn_mfma_blocks(int B) { return B < 1024 ? B : 1024; }
 
 int t4r_xlnet_attn_mfma_fwd(hipStream_t st, const float* q, const float* k, const float* v, const float* kr,
                             const float* rw, const float* rr, float* out, float* lse, int B, int L, int n_head,
-                            int d_head, float scale, long kr_bstride, DropCfg drop) {
+                            int d_head, float scale, long kr_bstride, DropCfg drop, const int* key_len) {
     const dim3 grid(B < 4096 ? B : 4096, n_head), block(64);
     if (d_head == 32)
         hipLaunchKernelGGL(xlnet_attn_mfma_fwd_kernel<32>, grid, block, 0, st, q, k, v, kr, rw, rr, out, lse, B, L,
-                           n_head, scale, kr_bstride, drop);
+                           n_head, scale, kr_bstride, drop, key_len);
     else
         hipLaunchKernelGGL(xlnet_attn_mfma_fwd_kernel<16>, grid, block, 0, st, q, k, v, kr, rw, rr, out, lse, B, L,
-                           n_head, scale, kr_bstride, drop);
+                           n_head, scale, kr_bstride, drop, key_len);
     T4R_LAUNCH_CHECK();
     return 0;
 }
@@ -421,14 +425,14 @@ int t4r_xlnet_attn_mfma_fwd(hipStream_t st, const float* q, const float* k, cons
 int t4r_xlnet_attn_mfma_bwd(hipStream_t st, const float* q, const float* k, const float* v, const float* kr,
                             const float* rw, const float* rr, const float* lse, const float* dout, float* dq,
                             float* dk, float* dv, float* part, float* dkr, float* d_rw, float* d_rr, int B, int L,
-                            int n_head, int d_head, float scale, long kr_bstride, DropCfg drop) {
+                            int n_head, int d_head, float scale, long kr_bstride, DropCfg drop, const int* key_len) {
     const int D = n_head * d_head;
     const int gx = t4r_xlnet_attn_mfma_blocks(B);
     const dim3 grid(gx, n_head), block(64);
     float* dkr_b = kr_bstride > 0 ? dkr : nullptr;
 #define T4R_BWD(DHV, SH)                                                                                      \
     hipLaunchKernelGGL((xlnet_attn_mfma_bwd_kernel<DHV, SH>), grid, block, 0, st, q, k, v, kr, rw, rr, lse, dout, dq, \
-                       dk, dv, part, dkr_b, B, L, n_head, scale, kr_bstride, drop)
+                       dk, dv, part, dkr_b, B, L, n_head, scale, kr_bstride, drop, key_len)
     if (d_head == 32) { if (dkr_b) T4R_BWD(32, false); else T4R_BWD(32, true); }
     else { if (dkr_b) T4R_BWD(16, false); else T4R_BWD(16, true); }
 #undef T4R_BWD

@@ -37,11 +37,11 @@ int t4r_dropout(void*, const float*, float*, unsigned char*, long, long, float, 
                 unsigned long long);
 int t4r_xlnet_attn_fwd(void*, const float*, const float*, const float*, const float*, const float*,
                        const float*, float*, float*, int, int, int, int, int, float, unsigned long long,
-                       unsigned long long);
+                       unsigned long long, const int*);
 int t4r_xlnet_attn_bwd(void*, const float*, const float*, const float*, const float*, const float*,
                        const float*, const float*, const float*, const float*, float*, float*, float*,
                        float*, float*, float*, float*, int, int, int, int, int, float,
-                       unsigned long long, unsigned long long);
+                       unsigned long long, unsigned long long, const int*);
 long t4r_xlnet_attn_bwd_ws_floats(int, int, int, int);
 }
 
@@ -118,7 +118,8 @@ extern "C" long t4r_xlnet_layer_bwd_ws_floats(int B, int L, int D, int n_head, i
 extern "C" int t4r_xlnet_layer_fwd(void* stream, const float* h, const float* pos_emb,
                                    const float* const* params, float* ws, float* h_out, int B, int L,
                                    int D, int n_head, float ln_eps, float drop_p,
-                                   unsigned long long seed, unsigned long long offset, int layer_idx) {
+                                   unsigned long long seed, unsigned long long offset, int layer_idx,
+                                   const int* key_len) {
     if (B == 0) return 0;
     T4R_CHECK_ARG(D % n_head == 0 && D % 4 == 0, "xlnet_layer: d_model must divide by n_head and 4");
     T4R_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "xlnet_layer: dropout p in [0, 1)");
@@ -155,7 +156,7 @@ extern "C" int t4r_xlnet_layer_fwd(void* stream, const float* h, const float* po
                             EPI_NONE, nullptr, 0, 1, 0, 1, 0, 0, 0, nullptr));
     }
     RUN(t4r_xlnet_attn_fwd(stream, w.qkv, w.qkv + TD, w.qkv + 2 * TD, w.kr, params[P_RWB],
-                           params[P_RRB], w.av, w.lse, B, L, n_head, dh, drop, drop_p, seed, C(SITE_PROB)));
+                           params[P_RRB], w.av, w.lse, B, L, n_head, dh, drop, drop_p, seed, C(SITE_PROB), key_len));
     // attn_out[t, h] = sum_{nd} av[t, nd] * o[h, nd]
     RUN(t4r_gemm_launch(st, 0, 1, T, D, D, 1.f, w.av, D, params[P_O], D, w.ao, D, nullptr, EPI_NONE,
                         nullptr, 0, 1, 0, 1, 0, 0, 0, nullptr));
@@ -214,7 +215,7 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
                                    const float* const* params, float* const* grads, const float* ws,
                                    float* bws, const float* dh_out, float* dh_in, int B, int L, int D,
                                    int n_head, float ln_eps, float drop_p, unsigned long long seed,
-                                   unsigned long long offset, int layer_idx) {
+                                   unsigned long long offset, int layer_idx, const int* key_len) {
     if (B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const int T = B * L, dh = D / n_head;
@@ -293,7 +294,7 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
     RUN(t4r_xlnet_attn_bwd(stream, w.qkv, w.qkv + TD, w.qkv + 2 * TD, w.kr, params[P_RWB],
                            params[P_RRB], w.av, w.lse, dav, dqkv, dqkv + TD, dqkv + 2 * TD, dkr,
                            grads[P_RWB], grads[P_RRB], attn_ws, B, L, n_head, dh, drop, drop_p, seed,
-                           C(SITE_PROB)));
+                           C(SITE_PROB), key_len));
     // k_r = pos_emb(_b) @ r  ->  d r += pos_emb(_b)^T @ d k_r
     if (drop) {
         RUN(t4r_gemm_launch(wg(), 1, 0, D, D, B * 2 * L, 1.f, w.pe_b, D, dkr, D, grads[P_R], D, nullptr,

@@ -77,6 +77,7 @@ class MaskSequence(SeedMixin, nn.Module):
         self._row_count = None
         self._compact = None
         self._n_host = None
+        self.last_item_ids = None
 
     # ---- parity hook: replay recorded torch.bernoulli / torch.multinomial draws once
     def set_draws(self, bern=None, j1=None, j2=None):
@@ -101,6 +102,7 @@ class MaskSequence(SeedMixin, nn.Module):
         if mode == ops.MLM_TRAIN:
             self._rng_offset += item_ids.numel()
         self.mask_schema, self.masked_targets = mask, labels
+        self.last_item_ids = item_ids            # read by TransformerBlock(mask_padding=True)
         self._row_count, self._compact = counts, None
         self._n_host = None
         if mode not in (ops.MLM_INFER, ops.CLM_INFER):

@@ -392,20 +392,30 @@ def last_positions(item_ids, Lgrid, is_mlm, padding_idx=0):
 
 
 # ------------------------------------------------------------------------------------ attention / layer
-def xlnet_attn_fwd(q, k, v, k_r, r_w_bias, r_r_bias, B, L, n_head, drop=NO_DROP):
-    """k_r [2L, D] (shared) or [B*2L, D] (per session)."""
+def session_lengths(item_ids, padding_idx=0, extra=0):
+    """int32 [B]: number of non-padding positions of every session (+ extra: the [MASK] slot of the MLM
+    inference grid) -- the key_len of the opt-in attention padding mask"""
+    B, L = item_ids.shape
+    out = torch.empty(B, device=item_ids.device, dtype=torch.int32)
+    call("t4r_session_lengths", _stream(), _chk(item_ids, torch.int64), B, L, int(padding_idx), int(extra),
+         out.data_ptr())
+    return out
+
+
+def xlnet_attn_fwd(q, k, v, k_r, r_w_bias, r_r_bias, B, L, n_head, drop=NO_DROP, key_len=None):
+    """k_r [2L, D] (shared) or [B*2L, D] (per session).  key_len int32 [B]: opt-in padding mask."""
     D = q.shape[-1]
     per_b = int(k_r.shape[0] == B * 2 * L and B > 1)
     out = torch.empty((B * L, D), device=q.device, dtype=torch.float32)
     lse = torch.empty((B, n_head, L), device=q.device, dtype=torch.float32)
     call("t4r_xlnet_attn_fwd", _stream(), _chk(q), _chk(k), _chk(v), _chk(k_r), _chk(r_w_bias),
          _chk(r_r_bias), out.data_ptr(), lse.data_ptr(), B, L, n_head, D // n_head, per_b,
-         float(drop[0]), int(drop[1]), int(drop[2]))
+         float(drop[0]), int(drop[1]), int(drop[2]), _p(key_len, torch.int32))
     return out, lse
 
 
 def xlnet_attn_bwd(q, k, v, k_r, r_w_bias, r_r_bias, out, lse, dout, d_rw, d_rr, B, L, n_head,
-                   drop=NO_DROP):
+                   drop=NO_DROP, key_len=None):
     D = q.shape[-1]
     dev = q.device
     per_b = int(k_r.shape[0] == B * 2 * L and B > 1)
@@ -416,7 +426,7 @@ def xlnet_attn_bwd(q, k, v, k_r, r_w_bias, r_r_bias, out, lse, dout, d_rw, d_rr,
     call("t4r_xlnet_attn_bwd", _stream(), _chk(q), _chk(k), _chk(v), _chk(k_r), _chk(r_w_bias),
          _chk(r_r_bias), _chk(out), _chk(lse), _chk(dout), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
          dkr.data_ptr(), _chk(d_rw), _chk(d_rr), ws.data_ptr(), B, L, n_head, D // n_head, per_b,
-         float(drop[0]), int(drop[1]), int(drop[2]))
+         float(drop[0]), int(drop[1]), int(drop[2]), _p(key_len, torch.int32))
     return dq, dk, dv, dkr
 
 
@@ -474,7 +484,7 @@ def xlnet_layer_bwd_ws_floats(B, L, D, n_head, dropout=False):
 
 
 def xlnet_layer_fwd(h, pos_emb, params, B, L, n_head, eps, ws=None, drop_p=0.0, seed=0, offset=0,
-                    layer_idx=0):
+                    layer_idx=0, key_len=None):
     """h [B*L, D]; params: sequence of 15 tensors in XLNET_PARAM_ORDER.  -> (h_out, ws)"""
     D = h.shape[-1]
     if ws is None:
@@ -484,12 +494,12 @@ def xlnet_layer_fwd(h, pos_emb, params, B, L, n_head, eps, ws=None, drop_p=0.0, 
     parr, _keep = ptr_array([_chk(p, torch.float32, "xlnet param") for p in params])
     call("t4r_xlnet_layer_fwd", _stream(), _chk(h, torch.float32), _chk(pos_emb, torch.float32), parr,
          ws.data_ptr(), out.data_ptr(), B, L, D, n_head, float(eps), float(drop_p), int(seed),
-         int(offset), int(layer_idx))
+         int(offset), int(layer_idx), _p(key_len, torch.int32))
     return out, ws
 
 
 def xlnet_layer_bwd(h, pos_emb, params, grads, ws, dh_out, B, L, n_head, eps, bws=None, drop_p=0.0,
-                    seed=0, offset=0, layer_idx=0):
+                    seed=0, offset=0, layer_idx=0, key_len=None):
     D = h.shape[-1]
     if bws is None:
         bws = torch.empty(xlnet_layer_bwd_ws_floats(B, L, D, n_head, drop_p > 0), device=h.device,
@@ -499,7 +509,7 @@ def xlnet_layer_bwd(h, pos_emb, params, grads, ws, dh_out, B, L, n_head, eps, bw
     garr, _k2 = ptr_array([_chk(g, torch.float32) for g in grads])
     call("t4r_xlnet_layer_bwd", _stream(), _chk(h), _chk(pos_emb), parr, garr, _chk(ws),
          bws.data_ptr(), _chk(dh_out), dh_in.data_ptr(), B, L, D, n_head, float(eps), float(drop_p),
-         int(seed), int(offset), int(layer_idx))
+         int(seed), int(offset), int(layer_idx), _p(key_len, torch.int32))
     return dh_in
 
 

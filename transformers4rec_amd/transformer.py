@@ -135,14 +135,14 @@ def relative_positional_encoding(L, D):
 
 class _XLNetLayerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, h, anchor, layer, pos_emb, n_head, eps, drop):
+    def forward(ctx, h, anchor, layer, pos_emb, n_head, eps, drop, key_len=None):
         B, L, D = h.shape
         h2 = h.contiguous().view(B * L, D)
         params = [p.detach() for p in layer.ordered_params()]
         p, seed, offset, idx = drop
         out, ws = ops.xlnet_layer_fwd(h2, pos_emb, params, B, L, n_head, eps, drop_p=p, seed=seed,
-                                      offset=offset, layer_idx=idx)
-        ctx.layer, ctx.pos_emb, ctx.cfg, ctx.drop = layer, pos_emb, (B, L, D, n_head, eps), drop
+                                      offset=offset, layer_idx=idx, key_len=key_len)
+        ctx.layer, ctx.pos_emb, ctx.cfg, ctx.drop, ctx.key_len = layer, pos_emb, (B, L, D, n_head, eps), drop, key_len
         ctx.save_for_backward(h2, ws)
         return out.view(B, L, D)
 
@@ -155,8 +155,8 @@ class _XLNetLayerFn(torch.autograd.Function):
         grads = [_grad_buf(q) for q in plist]
         dh = ops.xlnet_layer_bwd(h2, ctx.pos_emb, [q.detach() for q in plist], grads, ws,
                                  dout.contiguous().view(B * L, D), B, L, n_head, eps, drop_p=p, seed=seed,
-                                 offset=offset, layer_idx=idx)
-        return dh.view(B, L, D), None, None, None, None, None, None
+                                 offset=offset, layer_idx=idx, key_len=ctx.key_len)
+        return dh.view(B, L, D), None, None, None, None, None, None, None
 
 
 class _DropoutFn(torch.autograd.Function):
@@ -201,7 +201,9 @@ class XLNetModel(SeedMixin, nn.Module):
             self._pos_cache[key] = relative_positional_encoding(L, self.config.d_model).to(device).contiguous()
         return self._pos_cache[key]
 
-    def forward(self, inputs_embeds=None, **kwargs):
+    def forward(self, inputs_embeds=None, key_len=None, **kwargs):
+        """key_len: optional int32 [B] of valid key counts (opt-in padding mask, TransformerBlock(mask_padding=True));
+        None reproduces the reference, which passes no attention mask."""
         cfg = self.config
         B, L, D = inputs_embeds.shape
         if D != cfg.d_model:
@@ -218,7 +220,7 @@ class XLNetModel(SeedMixin, nn.Module):
             h = _DropoutFn.apply(h, p, self.seed, ops.dropout_ctr_hi(offset, 255, ops.SITE_INPUT))
         for i, layer in enumerate(self.layer):
             h = _XLNetLayerFn.apply(h, layer.rel_attn.q, layer, pos, cfg.n_head, cfg.layer_norm_eps,
-                                    (p, self.seed, offset, i))
+                                    (p, self.seed, offset, i), key_len)
         if p > 0:
             h = _DropoutFn.apply(h, p, self.seed, ops.dropout_ctr_hi(offset, 255, ops.SITE_FINAL))
         return (h,)
@@ -230,8 +232,14 @@ XLNET_MAX_SEQ = 64
 class TransformerBlock(nn.Module):
     """Drop-in for tr.TransformerBlock (block/transformer.py:76-206) with the XLNet body on HIP."""
 
-    def __init__(self, transformer, masking: Optional[MaskSequence] = None, prepare_module=None):
+    def __init__(self, transformer, masking: Optional[MaskSequence] = None, prepare_module=None,
+                 mask_padding: bool = False):
+        """mask_padding (beyond the reference's signature, default off = the reference's arithmetic): the XLNet
+        attention ignores padded keys (score -1e30 except on the diagonal, as HF XLNet with an attention_mask);
+        the key counts come from the item ids the masking module saw (non-pad positions, + the [MASK] slot at
+        MLM inference)."""
         super().__init__()
+        self.mask_padding = bool(mask_padding)
         from .transformer_hf import BertConfig, BertModel, GPT2Config, GPT2Model
 
         if isinstance(transformer, (XLNetConfig, GPT2Config, BertConfig)):
@@ -273,6 +281,15 @@ class TransformerBlock(nn.Module):
 
     def forward(self, inputs_embeds, **kwargs):
         # the reference passes inputs_embeds only for XLNet + MLM/CLM (block/transformer.py:183-199)
+        if self.mask_padding:
+            if not isinstance(self.transformer, XLNetModel):
+                raise NotImplementedError("mask_padding is implemented for the XLNet body")
+            ids = getattr(self.masking, "last_item_ids", None) if self.masking is not None else None
+            if ids is None:
+                raise ValueError("mask_padding needs the masking module to have seen the item ids of this batch")
+            extra = inputs_embeds.shape[1] - ids.shape[1]       # 1 on the MLM inference grid (the [MASK] slot)
+            key_len = ops.session_lengths(ids.contiguous(), self.masking.padding_idx, extra)
+            return self.transformer(inputs_embeds=inputs_embeds, key_len=key_len)[0]
         return self.transformer(inputs_embeds=inputs_embeds)[0]
 
     def _get_name(self):

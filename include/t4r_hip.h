@@ -255,15 +255,17 @@ int t4r_xlnet_attn_bwd(void* stream, const float* q, const float* k, const float
 /* a16  scaled-dot-product attention core of the GPT-2 (causal) and BERT blocks
  * replaces: HF gpt2/modeling_gpt2.py eager_attention_forward :54-72 ; HF bert BertSelfAttention.
  * q,k,v rows of `ld` floats (3*D for GPT-2's fused c_attn output), head h at columns h*d_head..;
- * out/dout rows of ld_out; lse [B,n,L]; L <= 128; d_head 16|32|64.  No padding mask (reference
- * semantics).  drop_p: attention-probability dropout, mask index ((b*n+h)*L+i)*L+j. */
+ * out/dout rows of ld_out; lse [B,n,L]; L <= 128; d_head 16|32|64.  key_len NULL = no padding mask (the
+ * reference's behaviour); key_len int32 [B] (opt-in): keys >= key_len[b] are masked for every query, as HF does
+ * with an attention_mask (finfo.min added to the scores).  drop_p: attention-probability dropout, mask index
+ * ((b*n+h)*L+i)*L+j. */
 int t4r_mha_fwd(void* stream, const float* q, const float* k, const float* v, long ld, float* out,
                 long ld_out, float* lse, int B, int L, int n_head, int d_head, int causal, float drop_p,
-                unsigned long long seed, unsigned long long ctr_hi);
+                unsigned long long seed, unsigned long long ctr_hi, const int* key_len);
 int t4r_mha_bwd(void* stream, const float* q, const float* k, const float* v, long ld, const float* out,
                 const float* dout, long ld_out, const float* lse, float* dq, float* dk, float* dv, long ld_d,
                 int B, int L, int n_head, int d_head, int causal, float drop_p, unsigned long long seed,
-                unsigned long long ctr_hi);
+                unsigned long long ctr_hi, const int* key_len);
 /* learned position (+ token-type row 0) embeddings: out[t] = x[t] + pos[t % L] (+ token_type);
  * backward accumulates d_pos[l] += sum_b dy[b,l]  (HF gpt2 :576-577 wpe ; HF bert embeddings) */
 int t4r_add_pos_fwd(void* stream, const float* x, const float* pos, const float* token_type, float* out,

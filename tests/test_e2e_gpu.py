@@ -966,3 +966,34 @@ def test_mask_padding_option_end_to_end():
     close(model_t.transformer_block.transformer.layer[0].rel_attn.q.grad, p["layers"][0]["q"].grad, rtol=2e-4, atol=1e-4)
     assert abs(float(res[False][0]["loss"].detach()) - float(d["out/loss"])) < 1e-4       # default: the reference
     assert abs(float(out_t["loss"].detach()) - float(res[False][0]["loss"].detach())) > 1e-6
+
+
+@pytest.mark.parametrize("arch,name,masking", [("gpt2", "gpt2_clm_item_train", "clm"), ("bert", "bert_mlm_item_train", "mlm")])
+def test_mask_padding_option_gpt2_bert(arch, name, masking):
+    """mask_padding=True on the GPT-2 / BERT bodies: hidden states of the valid positions vs the oracle with the key mask"""
+    d = gu.load(name)
+    model = build_model(d, masking=masking, emb_default=32, arch=arch)
+    load_reference_state(model, d)
+    model.transformer_block.mask_padding = True
+    model.to(DEV).eval()
+    x = {k[3:]: gu.t(v).to(DEV) for k, v in d.items() if k.startswith("in/")}
+    cap = {}
+    model.input_features.register_forward_hook(lambda m, i, o: cap.__setitem__("emb", o.detach().cpu()))
+    model.transformer_block.register_forward_hook(lambda m, i, o: cap.__setitem__("hid", o.detach().cpu()))
+    with torch.no_grad():
+        model(x, testing=True)
+    ids = gu.t(d["in/item_id"])
+    key_len = (ids != 0).sum(1).to(torch.int32)
+    sd = {k: gu.t(v) for k, v in d.items() if k.startswith("p/heads.0.body.1.transformer.")}
+    pre = "p/heads.0.body.1.transformer."
+    nh = int(d["meta/n_head"])
+    if arch == "gpt2":
+        ref = O.gpt2_model(cap["emb"], O.gpt2_params_from_state(sd, pre), nh, 1e-5, key_len=key_len)
+        unm = O.gpt2_model(cap["emb"], O.gpt2_params_from_state(sd, pre), nh, 1e-5)
+    else:
+        ref = O.bert_model(cap["emb"], O.bert_params_from_state(sd, pre), nh, 0.03, key_len=key_len)
+        unm = O.bert_model(cap["emb"], O.bert_params_from_state(sd, pre), nh, 0.03)
+    valid = ids != 0
+    close(cap["hid"][valid], ref[valid], rtol=1e-4, atol=5e-5)
+    if arch == "bert":          # (a causal body never lets a valid query see a padded key: the mask changes nothing there)
+        assert float((ref[valid] - unm[valid]).abs().max()) > 1e-5

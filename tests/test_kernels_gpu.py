@@ -1009,3 +1009,38 @@ def test_xlnet_attention_padding_mask(ops, B, L, D, n):
     ids = (torch.arange(L)[None] < key_len[:, None]).long() * 7
     assert torch.equal(ops.session_lengths(cu(ids)).cpu(), key_len)
     assert torch.equal(ops.session_lengths(cu(ids), 0, 1).cpu(), key_len + 1)
+
+
+@pytest.mark.parametrize("B,L,D,n,causal,p", [(4, 20, 64, 2, True, 0.0), (3, 50, 128, 2, True, 0.0), (4, 100, 128, 2, False, 0.0),
+                                              (3, 33, 32, 2, False, 0.0), (3, 21, 64, 2, True, 0.2), (4, 96, 256, 4, False, 0.1)])
+def test_mha_padding_mask(ops, B, L, D, n, causal, p):
+    """opt-in key padding mask of the GPT-2 / BERT attention core (both kernel families) vs the oracle's sdpa,
+    whose mask is pinned against HF in tests/test_oracle_vs_hf.py; None keeps the unmasked reference behaviour."""
+    g = torch.Generator().manual_seed(B + L + D + int(causal))
+    dh = D // n
+    seed, ctr = 5, ops.dropout_ctr_hi(3, 1, ops.SITE_PROB)
+    key_len = torch.randint(1, L + 1, (B,), generator=g).to(torch.int32)
+    key_len[0], key_len[-1] = L, 1
+    qkv = torch.randn(B * L, 3 * D, generator=g)
+    qkv_r = qkv.clone().requires_grad_()
+    q, k, v = (qkv_r[:, i * D:(i + 1) * D].view(B, L, n, dh).transpose(1, 2) for i in range(3))
+    s = q @ k.transpose(-1, -2) / dh ** 0.5
+    if causal:
+        s = s.masked_fill(~torch.tril(torch.ones(L, L, dtype=torch.bool)), float("-inf"))
+    s = s.masked_fill(torch.arange(L)[None, None, None, :] >= key_len.reshape(-1, 1, 1, 1).long(), float("-inf"))
+    prob = torch.softmax(s, -1)
+    if p > 0:
+        prob = prob * _mask(ops, (B, n, L, L), p, seed, ctr) / (1 - p)
+    ref = (prob @ v).transpose(1, 2).reshape(B * L, D)
+    dout = torch.randn(B * L, D, generator=g)
+    ref.backward(dout)
+    dq = cu(qkv)
+    drop = (p, seed, ctr) if p > 0 else ops.NO_DROP
+    kl = cu(key_len)
+    out, lse = ops.mha_fwd(dq[:, :D], dq[:, D:2 * D], dq[:, 2 * D:], B, L, n, causal, drop, key_len=kl)
+    close(out, ref.detach(), atol=3e-5)
+    dqkv = ops.mha_bwd(dq[:, :D], dq[:, D:2 * D], dq[:, 2 * D:], out, lse, cu(dout), B, L, n, causal, drop, fused_out=True,
+                       key_len=kl)
+    close(dqkv, qkv_r.grad, rtol=1e-4, atol=2e-4)
+    plain, _ = ops.mha_fwd(dq[:, :D], dq[:, D:2 * D], dq[:, 2 * D:], B, L, n, causal, drop)
+    assert float((plain - out).abs().max()) > 1e-4

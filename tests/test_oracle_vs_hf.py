@@ -101,3 +101,32 @@ def test_xlnet_padding_mask_restatement_matches_hf(B, L, D, n, layers):
         unmasked = O.xlnet_model(x, [O.xlnet_layer_params_from_hf(l) for l in m.layer], n, 0.03)
     torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5)
     assert float((got - unmasked).abs().max()) > 1e-3          # the mask matters on these inputs
+
+
+@pytest.mark.parametrize("arch", ["gpt2", "bert"])
+def test_gpt2_bert_padding_mask_restatement_matches_hf(arch):
+    """opt-in padding mask of the GPT-2 / BERT bodies == HF given an attention_mask (keys masked for every query).
+    Compared on the VALID positions: a fully padded query row is arithmetic noise in both implementations."""
+    B, L, D, n = 4, 12, 32, 2
+    key_len = torch.tensor([L, 1, 7, 3], dtype=torch.int32)
+    attn_mask = (torch.arange(L)[None] < key_len[:, None]).long()
+    x = torch.randn(B, L, D)
+    if arch == "gpt2":
+        cfg = transformers.GPT2Config(n_embd=D, n_inner=4 * D, n_layer=2, n_head=n, activation_function="gelu",
+                                      resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0, n_positions=L, vocab_size=1)
+        m = transformers.GPT2Model(cfg).eval()
+        _rand_init(m, 3)
+        with torch.no_grad():
+            ref = m(inputs_embeds=x, attention_mask=attn_mask)[0]
+            got = O.gpt2_model(x, O.gpt2_params_from_state(m.state_dict()), n, 1e-5, key_len=key_len)
+    else:
+        cfg = transformers.BertConfig(hidden_size=D, num_hidden_layers=2, num_attention_heads=n, hidden_act="gelu",
+                                      layer_norm_eps=0.03, max_position_embeddings=L + 2, vocab_size=1,
+                                      hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+        m = transformers.BertModel(cfg).eval()
+        _rand_init(m, 4)
+        with torch.no_grad():
+            ref = m(inputs_embeds=x, attention_mask=attn_mask)[0]
+            got = O.bert_model(x, O.bert_params_from_state(m.state_dict()), n, 0.03, key_len=key_len)
+    valid = attn_mask.bool()
+    torch.testing.assert_close(got[valid], ref[valid], rtol=1e-5, atol=2e-5)

@@ -40,8 +40,8 @@ _SIGS = {
     "t4r_scatter_rows_add": ("i", "ppppii"),
     "t4r_last_positions": ("i", "ppiiiilp"),
     "t4r_gemm_f32": ("i", "piiiiif" + "plplpl" + "pipl" + "iii" + "lll" + "fQQ"),
-    "t4r_mha_fwd": ("i", "pppplplp" + "iiiii" + "fQQ"),
-    "t4r_mha_bwd": ("i", "pppplpplppppl" + "iiiii" + "fQQ"),
+    "t4r_mha_fwd": ("i", "pppplplp" + "iiiii" + "fQQ" + "p"),
+    "t4r_mha_bwd": ("i", "pppplpplppppl" + "iiiii" + "fQQ" + "p"),
     "t4r_add_pos_fwd": ("i", "ppppp" + "iii"),
     "t4r_add_pos_bwd": ("i", "ppp" + "iii"),
     "t4r_dropout_ctr_hi": ("Q", "Qii"),

@@ -98,6 +98,10 @@ static int launch_layout(GemmParams& p, int batch, int splitk_req, hipStream_t s
         // wins the large plain products (C5 body 2459 -> 2233 us, square 4096 1051 -> 944 us, logits 700 -> 693 us)
         // and loses or ties below ~20 GFLOP
         if (!feat && prec == 1 && split_tile == 0 && p.M >= 1024 && p.N >= 512 && 2.0 * p.M * p.N * (double)p.K >= 2e10) big = 2;
+        // experiment: the softmax-gradient products of the head on the 128 x 64 tile (T4R_GEMM_SG_TILE=2)
+        static int sg_tile = -1;
+        if (sg_tile < 0) { const char* e = getenv("T4R_GEMM_SG_TILE"); sg_tile = e ? atoi(e) : 0; }
+        if (p.sg_lse && prec == 1 && sg_tile == 2 && p.M >= 1024) big = 2;
         bm = big ? 128 : 64;
         bn = big == 1 ? 128 : 64;
         half_big = big;

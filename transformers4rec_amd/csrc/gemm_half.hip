@@ -11,7 +11,8 @@ template <int BM, int BN, bool TA, bool TB, int PREC>
 static int half_cfg(const GemmParams& p, int batch, hipStream_t stream) {
     if (p.sg_lse) {
         if constexpr (BM == 64 && BN == 64 && !TB) return launch_vec<64, 64, 32, TA, false, 1, true, PREC>(p, batch, stream);
-        t4r_set_error("gemm (half): softmax-grad operand needs the 64x64 tile and transB = 0");
+        if constexpr (BM == 128 && BN == 64 && !TB && PREC == 1) return launch_vec<128, 64, 32, TA, false, 1, true, 1>(p, batch, stream);
+        t4r_set_error("gemm (half): softmax-grad operand needs the 64x64 (or, split form, 128x64) tile and transB = 0");
         return -1;
     }
     if (p.drop.p > 0.f && (p.epilogue == EPI_BIAS_GELU || p.epilogue == EPI_BIAS_RESID)) {

@@ -24,16 +24,16 @@
 bool t4r_mha_mfma_ok(int L, int d_head, long ld, long ld_out, long ld_d);
 int t4r_mha_mfma_fwd(hipStream_t st, const float* q, const float* k, const float* v, long ld, float* out,
                      long ld_out, float* lse, int B, int L, int n_head, int d_head, float scale, int causal,
-                     DropCfg drop);
+                     DropCfg drop, const int* key_len);
 int t4r_mha_mfma_bwd(hipStream_t st, const float* q, const float* k, const float* v, long ld, const float* out,
                      const float* dout, long ld_out, const float* lse, float* dq, float* dk, float* dv, long ld_d,
-                     int B, int L, int n_head, int d_head, float scale, int causal, DropCfg drop);
+                     int B, int L, int n_head, int d_head, float scale, int causal, DropCfg drop, const int* key_len);
 
 template <int DH>
 __global__ __launch_bounds__(128) void mha_fwd_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, long ld,
     float* __restrict__ out, long ld_out, float* __restrict__ lse, int B, int L, int n_head, float scale,
-    int causal, DropCfg drop) {
+    int causal, DropCfg drop, const int* key_len) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int LDH = DH + MHA_PAD;
     float* Ks = smem;             // [L][LDH]
@@ -59,7 +59,9 @@ __global__ __launch_bounds__(128) void mha_fwd_kernel(
         o[d] = o[d + 1] = o[d + 2] = o[d + 3] = 0.f;
     }
     float m = -INFINITY, l = 0.f;
-    const int jend = causal ? i + 1 : L;
+    // opt-in padding mask: keys >= key_len[b] are masked for every query (HF adds finfo.min to their scores)
+    const int klen = key_len ? max(1, min(L, key_len[b])) : L;
+    const int jend = min(causal ? i + 1 : L, klen);
     for (int j = 0; j < jend; ++j) {
         const float* kj = Ks + j * LDH;
         float s = 0.f;
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(128) void mha_bwd_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, long ld,
     const float* __restrict__ out, const float* __restrict__ dout, long ld_out,
     const float* __restrict__ lse, float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
-    long ld_d, int B, int L, int n_head, float scale, int causal, DropCfg drop) {
+    long ld_d, int B, int L, int n_head, float scale, int causal, DropCfg drop, const int* key_len) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int LDH = DH + MHA_PAD;
     float* Ks = smem;              // [L][LDH]
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(128) void mha_bwd_kernel(
         float g[DH];
 #pragma unroll
         for (int d = 0; d < DH; ++d) g[d] = 0.f;
-        const int jend = causal ? i + 1 : L;
+        const int jend = min(causal ? i + 1 : L, key_len ? max(1, min(L, key_len[b])) : L);
         for (int j = 0; j < jend; ++j) {
             const float* kj = Ks + j * LDH;
             const float* vj = Vs + j * LDH;
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(128) void mha_bwd_kernel(
                 s += qq.x * a.x + qq.y * a.y + qq.z * a.z + qq.w * a.w;
                 dp += gg.x * e.x + gg.y * e.y + gg.z * e.z + gg.w * e.w;
             }
-            const float p = __expf(s * scale - Ls[i]);
+            const float p = (key_len && j >= max(1, min(L, key_len[b]))) ? 0.f : __expf(s * scale - Ls[i]);
             const float msk = drop.p > 0.f ? drop_scale(drop, (mbase + i) * L + j) : 1.f;
             const float ds = p * (dp * msk - Ds[i]) * scale;
             const float pd = p * msk;
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(128) void mha_bwd_kernel(
 
 template <int DH>
 static int mha_fwd_launch(hipStream_t st, const float* q, const float* k, const float* v, long ld, float* out,
-                          long ld_out, float* lse, int B, int L, int n, float scale, int causal, DropCfg dc) {
+                          long ld_out, float* lse, int B, int L, int n, float scale, int causal, DropCfg dc, const int* key_len) {
     const size_t smem = (size_t)2 * L * (DH + MHA_PAD) * sizeof(float);
     static size_t attr = 0;
     if (smem > attr) {
@@ -219,14 +221,14 @@ static int mha_fwd_launch(hipStream_t st, const float* q, const float* k, const 
         attr = smem;
     }
     hipLaunchKernelGGL(mha_fwd_kernel<DH>, dim3(B, n), dim3(L <= 64 ? 64 : 128), smem, st, q, k, v, ld, out, ld_out,
-                       lse, B, L, n, scale, causal, dc);
+                       lse, B, L, n, scale, causal, dc, key_len);
     T4R_LAUNCH_CHECK();
     return 0;
 }
 template <int DH>
 static int mha_bwd_launch(hipStream_t st, const float* q, const float* k, const float* v, long ld, const float* out,
                           const float* dout, long ld_out, const float* lse, float* dq, float* dk, float* dv,
-                          long ld_d, int B, int L, int n, float scale, int causal, DropCfg dc) {
+                          long ld_d, int B, int L, int n, float scale, int causal, DropCfg dc, const int* key_len) {
     const size_t smem = ((size_t)4 * L * (DH + MHA_PAD) + 2 * L) * sizeof(float);
     static size_t attr = 0;
     if (smem > attr) {
@@ -234,7 +236,7 @@ static int mha_bwd_launch(hipStream_t st, const float* q, const float* k, const 
         attr = smem;
     }
     hipLaunchKernelGGL(mha_bwd_kernel<DH>, dim3(B, n), dim3(L <= 64 ? 64 : 128), smem, st, q, k, v, ld, out, dout,
-                       ld_out, lse, dq, dk, dv, ld_d, B, L, n, scale, causal, dc);
+                       ld_out, lse, dq, dk, dv, ld_d, B, L, n, scale, causal, dc, key_len);
     T4R_LAUNCH_CHECK();
     return 0;
 }
@@ -243,7 +245,7 @@ static int mha_bwd_launch(hipStream_t st, const float* q, const float* k, const 
 // head h at columns [h*d_head, (h+1)*d_head).  out/dout rows of ld_out floats.  lse [B, n, L].
 extern "C" int t4r_mha_fwd(void* stream, const float* q, const float* k, const float* v, long ld, float* out,
                            long ld_out, float* lse, int B, int L, int n_head, int d_head, int causal,
-                           float drop_p, unsigned long long seed, unsigned long long ctr_hi) {
+                           float drop_p, unsigned long long seed, unsigned long long ctr_hi, const int* key_len) {
     if (B == 0) return 0;
     T4R_CHECK_ARG(L >= 1 && L <= 128, "mha: L must be in [1, 128]");
     T4R_CHECK_ARG(ld % 4 == 0 && ld_out % 4 == 0, "mha: row strides must be multiples of 4");
@@ -251,11 +253,11 @@ extern "C" int t4r_mha_fwd(void* stream, const float* q, const float* k, const f
     const DropCfg dc = make_drop(drop_p, seed, ctr_hi);
     hipStream_t st = (hipStream_t)stream;
     if (t4r_mha_mfma_ok(L, d_head, ld, ld_out, 0))
-        return t4r_mha_mfma_fwd(st, q, k, v, ld, out, ld_out, lse, B, L, n_head, d_head, scale, causal, dc);
+        return t4r_mha_mfma_fwd(st, q, k, v, ld, out, ld_out, lse, B, L, n_head, d_head, scale, causal, dc, key_len);
     switch (d_head) {
-        case 16: return mha_fwd_launch<16>(st, q, k, v, ld, out, ld_out, lse, B, L, n_head, scale, causal, dc);
-        case 32: return mha_fwd_launch<32>(st, q, k, v, ld, out, ld_out, lse, B, L, n_head, scale, causal, dc);
-        case 64: return mha_fwd_launch<64>(st, q, k, v, ld, out, ld_out, lse, B, L, n_head, scale, causal, dc);
+        case 16: return mha_fwd_launch<16>(st, q, k, v, ld, out, ld_out, lse, B, L, n_head, scale, causal, dc, key_len);
+        case 32: return mha_fwd_launch<32>(st, q, k, v, ld, out, ld_out, lse, B, L, n_head, scale, causal, dc, key_len);
+        case 64: return mha_fwd_launch<64>(st, q, k, v, ld, out, ld_out, lse, B, L, n_head, scale, causal, dc, key_len);
     }
     t4r_set_error("mha: d_head must be 16, 32 or 64");
     return -1;
@@ -264,7 +266,7 @@ extern "C" int t4r_mha_fwd(void* stream, const float* q, const float* k, const f
 extern "C" int t4r_mha_bwd(void* stream, const float* q, const float* k, const float* v, long ld,
                            const float* out, const float* dout, long ld_out, const float* lse, float* dq,
                            float* dk, float* dv, long ld_d, int B, int L, int n_head, int d_head, int causal,
-                           float drop_p, unsigned long long seed, unsigned long long ctr_hi) {
+                           float drop_p, unsigned long long seed, unsigned long long ctr_hi, const int* key_len) {
     if (B == 0) return 0;
     T4R_CHECK_ARG(L >= 1 && L <= 128, "mha: L must be in [1, 128]");
     T4R_CHECK_ARG(ld % 4 == 0 && ld_out % 4 == 0 && ld_d % 4 == 0, "mha: row strides must be multiples of 4");
@@ -273,11 +275,11 @@ extern "C" int t4r_mha_bwd(void* stream, const float* q, const float* k, const f
     hipStream_t st = (hipStream_t)stream;
     if (t4r_mha_mfma_ok(L, d_head, ld, ld_out, ld_d))
         return t4r_mha_mfma_bwd(st, q, k, v, ld, out, dout, ld_out, lse, dq, dk, dv, ld_d, B, L, n_head, d_head, scale,
-                                causal, dc);
+                                causal, dc, key_len);
     switch (d_head) {
-        case 16: return mha_bwd_launch<16>(st, q, k, v, ld, out, dout, ld_out, lse, dq, dk, dv, ld_d, B, L, n_head, scale, causal, dc);
-        case 32: return mha_bwd_launch<32>(st, q, k, v, ld, out, dout, ld_out, lse, dq, dk, dv, ld_d, B, L, n_head, scale, causal, dc);
-        case 64: return mha_bwd_launch<64>(st, q, k, v, ld, out, dout, ld_out, lse, dq, dk, dv, ld_d, B, L, n_head, scale, causal, dc);
+        case 16: return mha_bwd_launch<16>(st, q, k, v, ld, out, dout, ld_out, lse, dq, dk, dv, ld_d, B, L, n_head, scale, causal, dc, key_len);
+        case 32: return mha_bwd_launch<32>(st, q, k, v, ld, out, dout, ld_out, lse, dq, dk, dv, ld_d, B, L, n_head, scale, causal, dc, key_len);
+        case 64: return mha_bwd_launch<64>(st, q, k, v, ld, out, dout, ld_out, lse, dq, dk, dv, ld_d, B, L, n_head, scale, causal, dc, key_len);
     }
     t4r_set_error("mha: d_head must be 16, 32 or 64");
     return -1;

@@ -39,12 +39,13 @@ template <int DH>
 __global__ __launch_bounds__(512) void mha_mfma_fwd_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld,
     float* __restrict__ out, int ld_out, float* __restrict__ lse, int B, int L, int n_head, float scale,
-    int causal, DropCfg drop) {
+    int causal, DropCfg drop, const int* key_len) {
     __shared__ __attribute__((aligned(16))) float Sm[32 * XM_SP];
     const int lane = threadIdx.x;
     const int h = blockIdx.y, hc = h * DH;
     const int nT = (L + 31) >> 5;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        const int klen = key_len ? max(1, min(L, key_len[b])) : L;   // opt-in padding mask: keys >= klen masked
         const float* qb = q + (long)b * L * ld + hc;
         const float* kb = k + (long)b * L * ld + hc;
         const float* vb = v + (long)b * L * ld + hc;
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(512) void mha_mfma_fwd_kernel(
                     for (int t = 0; t < 16; ++t) {
                         const int j = kj * 32 + kh * 16 + t;
                         const float x = Sm[c * XM_SP + kh * 16 + t] * scale;
-                        s[kj].v[t] = (j < L && (!causal || j <= i)) ? x : -INFINITY;
+                        s[kj].v[t] = (j < klen && (!causal || j <= i)) ? x : -INFINITY;
                     }
                     __builtin_amdgcn_wave_barrier();
                 } else {
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(512) void mha_mfma_bwd_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld,
     const float* __restrict__ out, const float* __restrict__ dout, int ld_out, const float* __restrict__ lse,
     float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv, int ld_d, int B, int L, int n_head,
-    float scale, int causal, DropCfg drop) {
+    float scale, int causal, DropCfg drop, const int* key_len) {
     __shared__ __attribute__((aligned(16))) float Sm[32 * XM_SP];
     __shared__ __attribute__((aligned(16))) float Pm[32 * XM_SP];   // dropped probabilities, parked for d v
     __shared__ float Dr[128];                                       // D_i = dO_i . O_i
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(512) void mha_mfma_bwd_kernel(
     const int h = blockIdx.y, hc = h * DH;
     const int nT = (L + 31) >> 5;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        const int klen = key_len ? max(1, min(L, key_len[b])) : L;
         const float* qb = q + (long)b * L * ld + hc;
         const float* kb = k + (long)b * L * ld + hc;
         const float* vb = v + (long)b * L * ld + hc;
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(512) void mha_mfma_bwd_kernel(
 #pragma unroll
                 for (int t = 0; t < 16; ++t) {
                     const int j = j0 + kh * 16 + t;
-                    const bool ok = i < L && j < L && (!causal || j <= i);
+                    const bool ok = i < L && j < klen && (!causal || j <= i);
                     P.v[t] = ok ? __expf(Sm[c * XM_SP + kh * 16 + t] * scale - lrow) : 0.f;
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -296,28 +298,28 @@ static int mha_mfma_blocks(int B) { return B < 8192 ? B : 8192; }
 
 int t4r_mha_mfma_fwd(hipStream_t st, const float* q, const float* k, const float* v, long ld, float* out,
                      long ld_out, float* lse, int B, int L, int n_head, int d_head, float scale, int causal,
-                     DropCfg drop) {
+                     DropCfg drop, const int* key_len) {
     const dim3 grid(mha_mfma_blocks(B), n_head), block(64);
     if (d_head == 64)
         hipLaunchKernelGGL(mha_mfma_fwd_kernel<64>, grid, block, 0, st, q, k, v, (int)ld, out, (int)ld_out, lse, B, L,
-                           n_head, scale, causal, drop);
+                           n_head, scale, causal, drop, key_len);
     else
         hipLaunchKernelGGL(mha_mfma_fwd_kernel<32>, grid, block, 0, st, q, k, v, (int)ld, out, (int)ld_out, lse, B, L,
-                           n_head, scale, causal, drop);
+                           n_head, scale, causal, drop, key_len);
     T4R_LAUNCH_CHECK();
     return 0;
 }
 
 int t4r_mha_mfma_bwd(hipStream_t st, const float* q, const float* k, const float* v, long ld, const float* out,
                      const float* dout, long ld_out, const float* lse, float* dq, float* dk, float* dv, long ld_d,
-                     int B, int L, int n_head, int d_head, float scale, int causal, DropCfg drop) {
+                     int B, int L, int n_head, int d_head, float scale, int causal, DropCfg drop, const int* key_len) {
     const dim3 grid(mha_mfma_blocks(B), n_head), block(64);
     if (d_head == 64)
         hipLaunchKernelGGL(mha_mfma_bwd_kernel<64>, grid, block, 0, st, q, k, v, (int)ld, out, dout, (int)ld_out, lse,
-                           dq, dk, dv, (int)ld_d, B, L, n_head, scale, causal, drop);
+                           dq, dk, dv, (int)ld_d, B, L, n_head, scale, causal, drop, key_len);
     else
         hipLaunchKernelGGL(mha_mfma_bwd_kernel<32>, grid, block, 0, st, q, k, v, (int)ld, out, dout, (int)ld_out, lse,
-                           dq, dk, dv, (int)ld_d, B, L, n_head, scale, causal, drop);
+                           dq, dk, dv, (int)ld_d, B, L, n_head, scale, causal, drop, key_len);
     T4R_LAUNCH_CHECK();
     return 0;
 }

@@ -430,7 +430,7 @@ def xlnet_attn_bwd(q, k, v, k_r, r_w_bias, r_r_bias, out, lse, dout, d_rw, d_rr,
     return dq, dk, dv, dkr
 
 
-def mha_fwd(q, k, v, B, L, n_head, causal, drop=NO_DROP):
+def mha_fwd(q, k, v, B, L, n_head, causal, drop=NO_DROP, key_len=None):
     """q,k,v: [B*L, D] views that may be column slices of one [B*L, 3D] buffer (row stride = ld)."""
     D = q.shape[1]
     ld = q.stride(0)
@@ -438,11 +438,12 @@ def mha_fwd(q, k, v, B, L, n_head, causal, drop=NO_DROP):
     out = torch.empty((B * L, D), device=q.device, dtype=torch.float32)
     lse = torch.empty((B, n_head, L), device=q.device, dtype=torch.float32)
     call("t4r_mha_fwd", _stream(), q.data_ptr(), k.data_ptr(), v.data_ptr(), ld, out.data_ptr(), D,
-         lse.data_ptr(), B, L, n_head, D // n_head, int(causal), float(drop[0]), int(drop[1]), int(drop[2]))
+         lse.data_ptr(), B, L, n_head, D // n_head, int(causal), float(drop[0]), int(drop[1]), int(drop[2]),
+         _p(key_len, torch.int32))
     return out, lse
 
 
-def mha_bwd(q, k, v, out, lse, dout, B, L, n_head, causal, drop=NO_DROP, fused_out=False):
+def mha_bwd(q, k, v, out, lse, dout, B, L, n_head, causal, drop=NO_DROP, fused_out=False, key_len=None):
     """-> dq, dk, dv.  fused_out: one [B*L, 3D] buffer (column blocks q|k|v), returned as the single tensor."""
     D = q.shape[1]
     ld = q.stride(0)
@@ -455,7 +456,7 @@ def mha_bwd(q, k, v, out, lse, dout, B, L, n_head, causal, drop=NO_DROP, fused_o
         buf, ldd = None, D
     call("t4r_mha_bwd", _stream(), q.data_ptr(), k.data_ptr(), v.data_ptr(), ld, _chk(out), _chk(dout), D,
          _chk(lse), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ldd, B, L, n_head, D // n_head, int(causal),
-         float(drop[0]), int(drop[1]), int(drop[2]))
+         float(drop[0]), int(drop[1]), int(drop[2]), _p(key_len, torch.int32))
     return buf if fused_out else (dq, dk, dv)
 
 

@@ -234,8 +234,9 @@ class TransformerBlock(nn.Module):
 
     def __init__(self, transformer, masking: Optional[MaskSequence] = None, prepare_module=None,
                  mask_padding: bool = False):
-        """mask_padding (beyond the reference's signature, default off = the reference's arithmetic): the XLNet
-        attention ignores padded keys (score -1e30 except on the diagonal, as HF XLNet with an attention_mask);
+        """mask_padding (beyond the reference's signature, default off = the reference's arithmetic): the attention
+        ignores padded keys as the HF body does when it is given an attention_mask (XLNet: score -1e30 except on the
+        diagonal; GPT-2 / BERT: masked for every query);
         the key counts come from the item ids the masking module saw (non-pad positions, + the [MASK] slot at
         MLM inference)."""
         super().__init__()
@@ -282,8 +283,6 @@ class TransformerBlock(nn.Module):
     def forward(self, inputs_embeds, **kwargs):
         # the reference passes inputs_embeds only for XLNet + MLM/CLM (block/transformer.py:183-199)
         if self.mask_padding:
-            if not isinstance(self.transformer, XLNetModel):
-                raise NotImplementedError("mask_padding is implemented for the XLNet body")
             ids = getattr(self.masking, "last_item_ids", None) if self.masking is not None else None
             if ids is None:
                 raise ValueError("mask_padding needs the masking module to have seen the item ids of this batch")

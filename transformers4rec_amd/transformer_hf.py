@@ -176,16 +176,17 @@ class _GPT2BlockFn(torch.autograd.Function):
     """HF GPT2Block.forward (gpt2 :262-309): pre-LN causal attention + pre-LN GELU MLP, residual adds."""
 
     @staticmethod
-    def forward(ctx, h, anchor, blk, n_head, drop):
+    def forward(ctx, h, anchor, blk, n_head, drop, key_len=None):
         B, L, D = h.shape
         T = B * L
         p, seed, off, li = drop
+        ctx.key_len = key_len
         h2 = h.contiguous().view(T, D)
         a, m = blk.attn, blk.mlp
         x1, mean1, rstd1 = ops.add_layernorm_fwd(h2, None, blk.ln_1.weight.detach(), blk.ln_1.bias.detach(), blk.ln_1.eps)
         qkv = ops.gemm(x1, a.c_attn.weight.detach(), bias=a.c_attn.bias.detach(), epilogue=ops.EPI_BIAS)
         att, lse = ops.mha_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, L, n_head, True,
-                               _drop(p, seed, off, li, S_PROB))
+                               _drop(p, seed, off, li, S_PROB), key_len=key_len)
         h1 = ops.gemm(att, a.c_proj.weight.detach(), bias=a.c_proj.bias.detach(), epilogue=ops.EPI_BIAS_RESID,
                       aux=h2, drop=_drop(p, seed, off, li, S_AO))
         x2, mean2, rstd2 = ops.add_layernorm_fwd(h1, None, blk.ln_2.weight.detach(), blk.ln_2.bias.detach(), blk.ln_2.eps)
@@ -220,13 +221,13 @@ class _GPT2BlockFn(torch.autograd.Function):
         ops.gemm(att, da, True, False, splitk=-1, accumulate=True, out=_grad_buf(a.c_proj.weight))
         ops.colsum_(da, _grad_buf(a.c_proj.bias))
         dqkv = ops.mha_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], att, lse, datt, B, L, n_head, True,
-                           _drop(p, seed, off, li, S_PROB), fused_out=True)
+                           _drop(p, seed, off, li, S_PROB), fused_out=True, key_len=ctx.key_len)
         dx1 = ops.gemm(dqkv, a.c_attn.weight.detach(), False, True)
         ops.gemm(x1, dqkv, True, False, splitk=-1, accumulate=True, out=_grad_buf(a.c_attn.weight))
         ops.colsum_(dqkv, _grad_buf(a.c_attn.bias))
         ops.add_layernorm_bwd(h2, None, blk.ln_1.weight.detach(), mean1, rstd1, dx1, _grad_buf(blk.ln_1.weight),
                               _grad_buf(blk.ln_1.bias), dx=dh, accumulate_dx=True)
-        return dh.view(B, L, D), None, None, None, None
+        return dh.view(B, L, D), None, None, None, None, None
 
 
 class _PosEmbFn(torch.autograd.Function):
@@ -294,7 +295,7 @@ class GPT2Model(SeedMixin, nn.Module):
         self.ln_f = _LN(config.n_embd, config.layer_norm_epsilon)
         self._drop_offset = 0      # `seed`: rng.SeedMixin (torch.initial_seed() + rank unless assigned)
 
-    def forward(self, inputs_embeds=None, **kwargs):
+    def forward(self, inputs_embeds=None, key_len=None, **kwargs):
         cfg = self.config
         B, L, D = inputs_embeds.shape
         if L > cfg.n_positions:
@@ -308,7 +309,7 @@ class GPT2Model(SeedMixin, nn.Module):
         if p > 0:
             h = _DropFn.apply(h, p, self.seed, ops.dropout_ctr_hi(off, 255, S_IN))
         for i, blk in enumerate(self.h):
-            h = _GPT2BlockFn.apply(h, blk.ln_1.weight, blk, cfg.n_head, (p, self.seed, off, i))
+            h = _GPT2BlockFn.apply(h, blk.ln_1.weight, blk, cfg.n_head, (p, self.seed, off, i), key_len)
         return (_LNFn.apply(h, self.ln_f),)
 
 
@@ -352,15 +353,16 @@ class _BertLayerFn(torch.autograd.Function):
     """HF BertLayer.forward: post-LN bidirectional attention + GELU MLP (no attention mask)."""
 
     @staticmethod
-    def forward(ctx, h, anchor, lay, n_head, drop):
+    def forward(ctx, h, anchor, lay, n_head, drop, key_len=None):
         B, L, D = h.shape
         T = B * L
         ph, pa, seed, off, li = drop
+        ctx.key_len = key_len
         h2 = h.contiguous().view(T, D)
         s, so, it, o = lay.attention.self, lay.attention.output, lay.intermediate, lay.output
         lin = lambda x, l: ops.gemm(x, l.weight.detach(), False, True, bias=l.bias.detach(), epilogue=ops.EPI_BIAS)
         q, k, v = lin(h2, s.query), lin(h2, s.key), lin(h2, s.value)
-        att, lse = ops.mha_fwd(q, k, v, B, L, n_head, False, _drop(pa, seed, off, li, S_PROB))
+        att, lse = ops.mha_fwd(q, k, v, B, L, n_head, False, _drop(pa, seed, off, li, S_PROB), key_len=key_len)
         ao = lin(att, so.dense)
         h1, mean1, rstd1 = ops.add_layernorm_fwd(ao, h2, so.LayerNorm.weight.detach(), so.LayerNorm.bias.detach(),
                                                  so.LayerNorm.eps, _drop(ph, seed, off, li, S_AO))
@@ -397,14 +399,15 @@ class _BertLayerFn(torch.autograd.Function):
         datt = ops.gemm(dao, so.dense.weight.detach(), False, False)
         ops.gemm(dao, att, True, False, splitk=-1, accumulate=True, out=_grad_buf(so.dense.weight))
         ops.colsum_(dao, _grad_buf(so.dense.bias))
-        dq, dk, dv = ops.mha_bwd(q, k, v, att, lse, datt, B, L, n_head, False, _drop(pa, seed, off, li, S_PROB))
+        dq, dk, dv = ops.mha_bwd(q, k, v, att, lse, datt, B, L, n_head, False, _drop(pa, seed, off, li, S_PROB),
+                                 key_len=ctx.key_len)
         if dh is dao:
             dh = dh.clone()
         for g, l in ((dq, s.query), (dk, s.key), (dv, s.value)):
             ops.gemm(g, l.weight.detach(), False, False, accumulate=True, out=dh)
             ops.gemm(g, h2, True, False, splitk=-1, accumulate=True, out=_grad_buf(l.weight))
             ops.colsum_(g, _grad_buf(l.bias))
-        return dh.view(B, L, D), None, None, None, None
+        return dh.view(B, L, D), None, None, None, None, None
 
 
 class _BertEmbeddings(nn.Module):
@@ -440,7 +443,7 @@ class BertModel(SeedMixin, nn.Module):
         self.pooler = _BertPooler(config)      # HF computes it, TransformerBlock drops it: never evaluated
         self._drop_offset = 0      # `seed`: rng.SeedMixin (torch.initial_seed() + rank unless assigned)
 
-    def forward(self, inputs_embeds=None, **kwargs):
+    def forward(self, inputs_embeds=None, key_len=None, **kwargs):
         cfg = self.config
         B, L, D = inputs_embeds.shape
         if L > cfg.max_position_embeddings:
@@ -458,5 +461,5 @@ class BertModel(SeedMixin, nn.Module):
             h = _DropFn.apply(h, ph, self.seed, ops.dropout_ctr_hi(off, 255, S_IN))
         for i, lay in enumerate(self.encoder.layer):
             h = _BertLayerFn.apply(h, lay.attention.self.query.weight, lay, cfg.num_attention_heads,
-                                   (ph, pa, self.seed, off, i))
+                                   (ph, pa, self.seed, off, i), key_len)
         return (h,)

@@ -148,6 +148,16 @@ __device__ __forceinline__ uint32_t pk_bf16_rne(float a, float b) {
 template <int PREC>
 __device__ __forceinline__ void cvt_pair(float a, float b, uint32_t (&w)[PREC == 1 ? 3 : 1]) {
     if constexpr (PREC == 1) {
+#ifdef T4R_SPLIT_TRUNC      // A/B build only: truncation cuts (biased, see above)
+        const uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
+        const float ta = a - __uint_as_float(ua & 0xffff0000u), tb = b - __uint_as_float(ub & 0xffff0000u);
+        const uint32_t va = __float_as_uint(ta), vb = __float_as_uint(tb);
+        const float qa = ta - __uint_as_float(va & 0xffff0000u), qb = tb - __uint_as_float(vb & 0xffff0000u);
+        w[0] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+        w[1] = __builtin_amdgcn_perm(vb, va, 0x07060302u);
+        w[2] = __builtin_amdgcn_perm(__float_as_uint(qb), __float_as_uint(qa), 0x07060302u);
+        return;
+#endif
         w[0] = pk_bf16_rne(a, b);
         const float ra = a - __uint_as_float(w[0] << 16), rb = b - __uint_as_float(w[0] & 0xffff0000u);
         w[1] = pk_bf16_rne(ra, rb);

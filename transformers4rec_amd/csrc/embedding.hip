@@ -252,14 +252,18 @@ extern "C" int t4r_seq_features_fwd(
     // (10 M-row table: 66 % -> 76 % at 163 840 tokens, 61 % -> 67 % at 1.3 M tokens)
     const int g = pick_group(W);
     static int fast_u = -1;
-    if (fast_u < 0) { const char* e = getenv("T4R_GATHER_U"); fast_u = e ? atoi(e) : 2; }
+    static bool fast_u_set = false;
+    if (fast_u < 0) { const char* e = getenv("T4R_GATHER_U"); fast_u_set = e != nullptr; fast_u = e ? atoi(e) : 2; }
     const int units = (W + 3) / 4;
     const int nch = (units + g - 1) / g;                // 16-byte chunks per lane
     bool fast_ok = fast_u > 0 && agg == AGG_CONCAT && (W & 3) == 0 && nch <= 4 && g >= 8 &&
                    (long)B * L_out * g < 0x7fffffffL;
     for (int f = 0; f < n_feat && fast_ok; ++f) fast_ok = (p.dim[f] & 3) == 0 && (p.col[f] & 3) == 0;
     if (fast_ok) {
-        const int U = (fast_u >= 4 && nch == 1) ? 4 : 2;
+        // tokens per lane group: 2 for rows up to 256 floats (table above); 4 for the two-chunk rows (C3's 336-wide
+        // concatenation: 61 % -> 72 % of 8 TB/s at 163 840 tokens, 58 % -> 78 % at 1.3 M with a 10 M-row item table,
+        // profiles/r02_e_c3_gather.txt); T4R_GATHER_U overrides
+        const int U = nch == 2 ? ((fast_u_set && fast_u < 4) ? 2 : 4) : ((fast_u >= 4 && nch == 1) ? 4 : 2);
         const long groups = ((long)B * L_out + U - 1) / U;
         dim3 fgrid((unsigned)((groups * g + 255) / 256));
         hipStream_t fst = (hipStream_t)stream;
@@ -267,7 +271,8 @@ extern "C" int t4r_seq_features_fwd(
     if (U == 4) hipLaunchKernelGGL((seq_features_fwd_fast_kernel<G, 4, 1>), fgrid, dim3(256), 0, fst, p);     \
     else hipLaunchKernelGGL((seq_features_fwd_fast_kernel<G, 2, 1>), fgrid, dim3(256), 0, fst, p)
         if (nch > 1) {      // rows wider than 256 floats: the 64-lane group, 2 or 4 chunks per lane
-            if (nch == 2) hipLaunchKernelGGL((seq_features_fwd_fast_kernel<64, 2, 2>), fgrid, dim3(256), 0, fst, p);
+            if (nch == 2 && U == 4) hipLaunchKernelGGL((seq_features_fwd_fast_kernel<64, 4, 2>), fgrid, dim3(256), 0, fst, p);
+            else if (nch == 2) hipLaunchKernelGGL((seq_features_fwd_fast_kernel<64, 2, 2>), fgrid, dim3(256), 0, fst, p);
             else hipLaunchKernelGGL((seq_features_fwd_fast_kernel<64, 2, 4>), fgrid, dim3(256), 0, fst, p);
         } else switch (g) {
             case 8: T4R_FAST(8); break;

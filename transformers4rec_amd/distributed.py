@@ -104,8 +104,12 @@ class SparseRowExchange:
                 rows = torch.cat([rows, torch.zeros((nmax - rows.shape[0], D), device=rows.device, dtype=rows.dtype)])
             ids_all = torch.empty(self.world * nmax, device=ids.device, dtype=ids.dtype)
             rows_all = torch.empty((self.world * nmax, D), device=rows.device, dtype=rows.dtype)
-            dist.all_gather_into_tensor(ids_all, ids, group=self.group)
-            dist.all_gather_into_tensor(rows_all, rows, group=self.group)
+            if dist.get_backend(self.group) == "nccl":
+                dist.all_gather_into_tensor(ids_all, ids, group=self.group)
+                dist.all_gather_into_tensor(rows_all, rows, group=self.group)
+            else:       # gloo (tests): the list form, straight into the rank-major slices
+                dist.all_gather(list(ids_all.chunk(self.world)), ids, group=self.group)
+                dist.all_gather(list(rows_all.chunk(self.world)), rows, group=self.group)
             self.bytes_exchanged += ids_all.numel() * 8 + rows_all.numel() * 4
             # rank-major concatenation + stable sort => summation order (rank, lookup), the same everywhere
             self.apply_fn(tgt, ids_all, rows_all, pad)

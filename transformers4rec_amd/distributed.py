@@ -138,6 +138,9 @@ class GradReducer:
             if self._stream is None:
                 self._stream = torch.cuda.Stream()
             self._stream.wait_stream(torch.cuda.current_stream())
+            from .prediction_task import _SIDE_STREAMS     # the head's d W may still be running on its side stream
+            for side in _SIDE_STREAMS.values():
+                self._stream.wait_stream(side)
             with torch.cuda.stream(self._stream):
                 self._pending = dist.all_reduce(self.tables, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:

@@ -84,9 +84,12 @@ class _Pre(nn.Module):
         self.module = module
 
 
-# opt-in (T4R_HEAD_SIDE_STREAM=1): measured 5.64 -> 5.61 ms/step at C2 -- every kernel of the step already
-# fills the GPU, so there is little to overlap; off by default
-_SIDE_STREAM_ON = os.environ.get("T4R_HEAD_SIDE_STREAM", "0") == "1"
+# the tied / untied head's d W on a side stream, under the body's backward (T4R_HEAD_SIDE_STREAM=0 turns it off).
+# Round 1: 5.64 -> 5.61 ms/step (opt-in then); round 2, with the faster split-form products: 5.17 / 5.12 -> 5.10 / 5.05
+# ms on one box (-1.4 %), so it is on by default.  Consumers order themselves after it: the input block's scatter
+# (wait_pending_grad), the optimizer (autograd callback below), the data-parallel table all-reduce
+# (distributed.GradReducer.reduce_tables_async waits for this stream).
+_SIDE_STREAM_ON = os.environ.get("T4R_HEAD_SIDE_STREAM", "1") == "1"
 # sampled softmax: weight gradient as (ids, rows) + deterministic sorted scatter (default) instead of row atomics
 _SAMPLED_ROWS = os.environ.get("T4R_SAMPLED_ROWS", "1") == "1"
 _SIDE_STREAMS = {}

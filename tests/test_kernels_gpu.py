@@ -1044,3 +1044,31 @@ def test_mha_padding_mask(ops, B, L, D, n, causal, p):
     close(dqkv, qkv_r.grad, rtol=1e-4, atol=2e-4)
     plain, _ = ops.mha_fwd(dq[:, :D], dq[:, D:2 * D], dq[:, 2 * D:], B, L, n, causal, drop)
     assert float((plain - out).abs().max()) > 1e-4
+
+
+def test_fp16_softmax_gradient_is_scaled_into_range(ops):
+    """fp16 mode, large vocabulary: (1/N) (softmax - onehot) ~ 1e-9 underflows fp16 (smallest subnormal 6e-8); the
+    operand is scaled by a power of two before rounding and alpha undoes it (the reference's GradScaler, per launch)."""
+    g = torch.Generator().manual_seed(3)
+    N, V, D = 3000, 40000, 64
+    x = torch.randn(N, D, generator=g)
+    W = 0.05 * torch.randn(V, D, generator=g)
+    y = torch.randint(0, V, (N,), generator=g)
+    logits = x @ W.t()
+    dl = (torch.softmax(logits, 1) - torch.nn.functional.one_hot(y, V)) / N
+    assert float(dl.abs().median()) < 6e-8                       # most entries are below fp16's range unscaled
+    buf = torch.zeros(N, ops.pad_ld(V), device=DEV)
+    buf[:, :V] = cu(logits)
+    lg = buf[:, :V]
+    _, _, lse = ops.softmax_ce_fwd(lg, cu(y), V, 0.0)
+    with ops.precision("fp16"):
+        dx = ops.gemm_softmax_grad(lg, lse, cu(y), None, V, cu(W), False, splitk=-1)
+        dW = torch.zeros(V, D, device=DEV)
+        ops.gemm_softmax_grad(lg, lse, cu(y), None, V, cu(x), True, out=dW, accumulate=True)
+    ref_dx, ref_dW = dl @ W, dl.t() @ x
+    # half-precision tolerance relative to the largest entry; an unscaled fp16 operand loses the whole softmax term
+    assert float((dx.cpu() - ref_dx).abs().max()) < 4e-3 * float(ref_dx.abs().max())
+    assert float((dW.cpu() - ref_dW).abs().max()) < 4e-3 * float(ref_dW.abs().max())
+    nolabel = torch.ones(V, dtype=torch.bool)
+    nolabel[y] = False                                            # rows that only see the softmax term
+    assert float((dW.cpu()[nolabel] - ref_dW[nolabel]).abs().max()) < 2e-2 * float(ref_dW[nolabel].abs().max())

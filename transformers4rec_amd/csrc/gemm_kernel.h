@@ -281,7 +281,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 #define T4R_STAGE_PARAMS float4(&ra)[NA4], float4(&rb)[NB4], float(&sgl)[NA4], long(&sgy)[NA4]
 #define T4R_S0 ra0, rb0, sgl0, sgy0
 #define T4R_S1 ra1, rb1, sgl1, sgy1
-    const float sg_g = SG ? (p.sg_gout ? *p.sg_gout : 1.f) / p.sg_rows : 0.f;
+    // fp16 operands (PREC 3): the softmax gradient (g/N) (p - onehot) of a large vocabulary lies far below fp16's
+    // smallest subnormal (6e-8): p ~ 1e-7 at 10 M items, 1/N ~ 1e-4.  It is scaled into range by a power of two
+    // chosen from g/N itself (|g/N| 2^k in [2^13, 2^14)) and the epilogue's alpha undoes it exactly -- the per-launch
+    // form of what torch.cuda.amp.GradScaler does for the reference (trainer.py:363-367); it composes with a
+    // user-level loss scale, which only changes g.
+    float sg_g = 0.f, sg_unscale = 1.f;
+    if (SG) {
+        sg_g = (p.sg_gout ? *p.sg_gout : 1.f) / p.sg_rows;
+        if (PREC == 3) {
+            int ex;
+            (void)frexpf(fabsf(sg_g), &ex);
+            sg_unscale = ldexpf(1.f, ex - 14);
+            sg_g *= ldexpf(1.f, 14 - ex);
+        }
+    }
 
     // staging loads of k-tile kt (all addresses legal, see ld4_clamped)
     auto load_tiles = [&](T4R_STAGE_PARAMS, int kt) __attribute__((always_inline)) {
@@ -612,7 +626,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     // The mode is workgroup-uniform: it is decided ONCE and each mode has its own straight-line
     // store loop (the per-element switch cost ~30 scalar/vector instructions per output element,
     // a quarter of the MFMA time of a K = 128 tile).
-    const float alpha = p.alpha;
+    const float alpha = p.alpha * sg_unscale;
     if constexpr (RANK) {
 #pragma unroll
         for (int i = 0; i < WM; ++i) {

@@ -302,9 +302,15 @@ int t4r_softmax_ce_fwd(void* stream, const float* logits, const long* labels, fl
 int t4r_softmax_ce_bwd(void* stream, const float* logits, const long* labels, const float* lse,
                        const float* grad_out, float* dlogits, int N, int V, long ld,
                        float label_smoothing);
+/* ws: n_neg * D floats (the negatives' scores then are one X @ W_neg^T contraction on the matrix cores); NULL: row-wise */
 int t4r_sampled_logits_fwd(void* stream, const float* x, const long* labels, const float* W,
                            const long* neg_samples, const float* sampling_dist, float* out, int N,
-                           int D, int n_neg, float temperature);
+                           int D, int n_neg, float temperature, float* ws);
+/* n draws (with replacement) from LogUniformSampler's distribution over [min_id, max_id) (prediction_task.py:766-786,
+ * 843-848: torch.multinomial(self.dist, n_tries, replacement=True)) by the closed-form inverse CDF
+ * id = min_id + floor(R^u) - 1, R = max_id - min_id + 1, u = Philox(seed, (i, ctr_hi)); out int64 [n] */
+int t4r_log_uniform_sample(void* stream, long* out, int n, long min_id, long max_id, unsigned long long seed,
+                           unsigned long long ctr_hi);
 /* dlogits is modified in place (accidental-hit entries zeroed: they carry no gradient);
  * ws = 2 * n_neg * D floats of scratch (gathered negative rows of W and their gradient). */
 int t4r_sampled_logits_bwd(void* stream, float* dlogits, const float* x, const long* labels,

@@ -1072,3 +1072,31 @@ def test_fp16_softmax_gradient_is_scaled_into_range(ops):
     nolabel = torch.ones(V, dtype=torch.bool)
     nolabel[y] = False                                            # rows that only see the softmax term
     assert float((dW.cpu()[nolabel] - ref_dW[nolabel]).abs().max()) < 2e-2 * float(ref_dW[nolabel].abs().max())
+
+
+def test_log_uniform_device_sampler_matches_the_reference_distribution(ops):
+    """the closed-form inverse-CDF sampler draws from exactly LogUniformSampler.dist (prediction_task.py:766-786):
+    range, zero mass below min_id, and bin frequencies of 400 k draws against the distribution's own bin masses."""
+    import transformers4rec_amd as tr
+
+    V, min_id, n = 100_001, 1, 400_000
+    s = tr.LogUniformSampler(max_n_samples=100, max_id=V, min_id=min_id)
+    ids = ops.log_uniform_sample(n, min_id, V, 1234, 7, DEV).cpu()
+    assert int(ids.min()) >= min_id and int(ids.max()) < V
+    edges = torch.unique(torch.logspace(0, 5, 26).long().clamp_(min_id, V))
+    cdf = torch.cat([torch.zeros(1, dtype=torch.float64), s.dist.double().cumsum(0)])
+    for lo, hi in zip(edges[:-1].tolist(), edges[1:].tolist()):
+        want = float(cdf[hi] - cdf[lo]) * n
+        got = int(((ids >= lo) & (ids < hi)).sum())
+        assert abs(got - want) < 5 * (want ** 0.5) + 5, (lo, hi, got, want)
+    # another stream position gives other draws; the same position repeats
+    again = ops.log_uniform_sample(1000, min_id, V, 1234, 7, DEV).cpu()
+    other = ops.log_uniform_sample(1000, min_id, V, 1234, 8, DEV).cpu()
+    assert torch.equal(again, ids[:1000]) and not torch.equal(other, again)
+    # the module: unique, sorted, truncated, on the labels' device -- as the reference's sample()
+    s.to(DEV)
+    neg = s.sample(torch.ones(3, dtype=torch.long, device=DEV))
+    assert neg.device.type == "cuda" and neg.numel() <= 100 and bool((neg[1:] > neg[:-1]).all())
+    s.device_sampler = False
+    neg2 = s.sample(torch.ones(3, dtype=torch.long, device=DEV))
+    assert neg2.numel() <= 100 and int(neg2.min()) >= min_id

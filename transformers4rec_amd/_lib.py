@@ -67,7 +67,8 @@ _SIGS = {
     "t4r_linear_softmax_ce_chunk_floats": ("l", "ii"),
     "t4r_linear_softmax_ce_fwd": ("i", "pplpl" + "p" + "iiiffi" + "ppppp"),
     "t4r_linear_softmax_ce_bwd": ("i", "pplpl" + "ppp" + "iiiffi" + "pplpl"),
-    "t4r_sampled_logits_fwd": ("i", "ppppppp" + "iiif"),
+    "t4r_sampled_logits_fwd": ("i", "ppppppp" + "iiif" + "p"),
+    "t4r_log_uniform_sample": ("i", "pp" + "ill" + "QQ"),
     "t4r_sampled_logits_bwd": ("i", "ppppppppp" + "iiif"),
     "t4r_sampled_logits_bwd_rows": ("i", "ppppppppp" + "iiif"),
     "t4r_topk": ("i", "pp" + "iili" + "pp"),

@@ -215,13 +215,88 @@ __global__ __launch_bounds__(256) void sampled_logits_kernel(
     }
 }
 
+// GEMM form (ws given): the S negatives are shared by all rows, so their scores are ONE dense contraction
+// X[N,D] @ W_neg[S,D]^T on the matrix cores (W_neg gathered into ws) instead of N*S row dot products re-reading the
+// S rows of W for every row (C4: 27 k rows x 100 negatives x 1 KB = 2.8 GB through L2, 545 us); the fix-up kernel
+// adds the positive column (one row of W per label), the log-q corrections, the accidental-hit constant and 1/T.
+__global__ __launch_bounds__(256) void sampled_fix_kernel(const float* __restrict__ x, const long* __restrict__ y,
+                                                           const float* __restrict__ W, const long* __restrict__ neg,
+                                                           const float* __restrict__ qdist, float* __restrict__ out, int N,
+                                                           int D, int S, float inv_t) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const long yi = y[row];
+    const float* xr = x + (long)row * D;
+    const float* wr = W + yi * D;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s += xr[d] * wr[d];
+    s = wave_sum(s);
+    float* orow = out + (long)row * (S + 1);
+    if (lane == 0) orow[0] = (s - __logf(qdist[yi] + 1e-16f)) * inv_t;
+    for (int c = lane; c < S; c += 64) {
+        const long id = neg[c];
+        float v = orow[1 + c] - __logf(qdist[id] + 1e-16f);
+        if (id == yi) v = -65504.0f / 100.0f;
+        orow[1 + c] = v * inv_t;
+    }
+}
+__global__ __launch_bounds__(256) void sampled_rows_kernel(const float* __restrict__ W, const long* __restrict__ ids,
+                                                            float* __restrict__ out, float* __restrict__ dW,
+                                                            const float* __restrict__ add, int n, int D);
+int t4r_gemm_launch(hipStream_t stream, int transA, int transB, int M, int N, int K, float alpha,
+                    const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+                    const float* bias, int epilogue, float* aux, long ldaux, int splitk,
+                    int accumulate, int batch, long sA, long sB, long sC, const DropCfg* drop);
+
+// ws: n_neg * D floats of scratch (NULL: the row-wise kernel)
 extern "C" int t4r_sampled_logits_fwd(void* stream, const float* x, const long* labels, const float* W,
                                       const long* neg_samples, const float* sampling_dist, float* out,
-                                      int N, int D, int n_neg, float temperature) {
+                                      int N, int D, int n_neg, float temperature, float* ws) {
     if (N == 0) return 0;
     const float inv_t = temperature != 0.f ? 1.f / temperature : 1.f;
-    hipLaunchKernelGGL(sampled_logits_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x,
+    hipStream_t st = (hipStream_t)stream;
+    if (ws && n_neg >= 4) {
+        const long sd = (long)n_neg * D;
+        hipLaunchKernelGGL(sampled_rows_kernel, dim3((unsigned)((sd + 255) / 256)), dim3(256), 0, st, W, neg_samples, ws,
+                           nullptr, nullptr, n_neg, D);
+        T4R_LAUNCH_CHECK();
+        const int rc = t4r_gemm_launch(st, 0, 1, N, n_neg, D, 1.f, x, D, ws, D, out + 1, n_neg + 1, nullptr, 0, nullptr,
+                                       0, 1, 0, 1, 0, 0, 0, nullptr);
+        if (rc) return rc;
+        hipLaunchKernelGGL(sampled_fix_kernel, dim3((N + 3) / 4), dim3(256), 0, st, x, labels, W, neg_samples,
+                           sampling_dist, out, N, D, n_neg, inv_t);
+        T4R_LAUNCH_CHECK();
+        return 0;
+    }
+    hipLaunchKernelGGL(sampled_logits_kernel, dim3((N + 3) / 4), dim3(256), 0, st, x,
                        labels, W, neg_samples, sampling_dist, out, N, D, n_neg, inv_t);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+// Negative sampling of the sampled-softmax head: n draws (with replacement) from the log-uniform distribution
+// of LogUniformSampler (prediction_task.py:766-786): P(min_id + j) = (ln(j + 2) - ln(j + 1)) / ln(R), j = 0 .. R - 2,
+// R = max_id - min_id + 1.  The reference materialises that distribution and calls torch.multinomial (a
+// renormalisation + prefix sum over all V categories per call: 0.5 ms per step at 1 M items); the CDF is
+// ln(j + 2) / ln R, so the draw is its inverse in closed form: j = floor(R^u) - 1, u ~ U[0, 1) from Philox.
+__global__ void log_uniform_sample_kernel(long* __restrict__ out, int n, long min_id, long R, unsigned long long seed,
+                                          unsigned long long ctr_hi) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Philox rng(seed);
+    const uint4 r = rng((unsigned long long)i, ctr_hi);
+    const double u = ((double)r.x * 4294967296.0 + (double)r.y) * (1.0 / 18446744073709551616.0);   // 64 random bits
+    long j = (long)floor(exp(u * log((double)R))) - 1;
+    j = j < 0 ? 0 : (j > R - 2 ? R - 2 : j);
+    out[i] = min_id + j;
+}
+extern "C" int t4r_log_uniform_sample(void* stream, long* out, int n, long min_id, long max_id,
+                                      unsigned long long seed, unsigned long long ctr_hi) {
+    if (n <= 0) return 0;
+    T4R_CHECK_ARG(out && max_id - min_id + 1 >= 2, "log_uniform_sample: need at least two ids");
+    hipLaunchKernelGGL(log_uniform_sample_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, n,
+                       min_id, max_id - min_id + 1, seed, ctr_hi);
     T4R_LAUNCH_CHECK();
     return 0;
 }

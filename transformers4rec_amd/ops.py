@@ -582,8 +582,17 @@ def sampled_logits_fwd(x, labels, W, neg, dist, temperature=1.0):
     N, D = x.shape
     S = neg.numel()
     out = torch.empty((N, S + 1), device=x.device, dtype=torch.float32)
+    ws = torch.empty(max(1, S * D), device=x.device, dtype=torch.float32)
     call("t4r_sampled_logits_fwd", _stream(), _chk(x), _chk(labels, torch.int64), _chk(W),
-         _chk(neg, torch.int64), _chk(dist, torch.float32), out.data_ptr(), N, D, S, float(temperature))
+         _chk(neg, torch.int64), _chk(dist, torch.float32), out.data_ptr(), N, D, S, float(temperature),
+         ws.data_ptr())
+    return out
+
+
+def log_uniform_sample(n, min_id, max_id, seed, ctr_hi, device):
+    """n ids ~ LogUniformSampler's distribution over [min_id, max_id) (with replacement), int64 [n]"""
+    out = torch.empty(n, device=device, dtype=torch.int64)
+    call("t4r_log_uniform_sample", _stream(), out.data_ptr(), int(n), int(min_id), int(max_id), int(seed), int(ctr_hi))
     return out
 
 

@@ -175,6 +175,25 @@ int t4r_gemm_softmax_grad_f32(void* stream, int transA, int n_rows, int V, int N
                               const float* grad_out, float label_smoothing, const float* B, long ldb,
                               float* C, long ldc, int splitk, int accumulate);
 
+/* Materialised tied full-softmax head for d_model 32 / 64 / 96 / 128, fp32-accurate on the BF16 matrix cores
+ * (csrc/head_split.hip): the same three contractions as t4r_gemm_f32 (logits) and t4r_gemm_softmax_grad_f32
+ * (d X, d W) of model/prediction_task.py:664 and its autograd through CrossEntropyLoss (:446), with the operand
+ * cutting hoisted out of the inner loops.  ws: t4r_head_split_ws_bytes(N, V, D) bytes, 16-byte aligned, owned by the
+ * caller from _prepare (forward) until the last backward product; _dx and _dw use disjoint parts of it and may run
+ * on different streams.  logits [N, ld] holds the columns [yoff, yoff + Vc) of the [N, V] problem (Vc = V, yoff = 0:
+ * all of them); W passed to _dx points at row yoff.  No atomics: results are bit-reproducible. */
+int t4r_head_split_supported(int D);
+long t4r_head_split_ws_bytes(int N, int V, int D);
+int t4r_head_split_prepare(void* stream, const float* X, long ldx, int N, int D, int V, void* ws);
+int t4r_head_split_logits(void* stream, const void* ws, const float* W, long ldw, float* C, long ldc, int N, int V,
+                          int D, float alpha);
+int t4r_head_split_dw(void* stream, const void* ws, const float* logits, long ld, const float* lse,
+                      const long* labels, const float* grad_out, float label_smoothing, float* dW, long lddw,
+                      int N, int Vc, int V, int yoff, int D, float alpha, int accumulate);
+int t4r_head_split_dx(void* stream, void* ws, const float* logits, long ld, const float* lse, const long* labels,
+                      const float* grad_out, float label_smoothing, const float* W, long ldw, float* dX, long lddx,
+                      int N, int Vc, int V, int yoff, int D, float alpha, int accumulate);
+
 /* Non-materialising head: output projection + softmax cross-entropy WITHOUT an [N, V] logits tensor
  * (the form that can run a 10 M-item vocabulary: 15 k x 10 M logits would be 600 GB).
  * replaces: model/prediction_task.py:664-669 (logits = X @ W^T, / T) + :446 (CrossEntropyLoss(), mean;

@@ -49,6 +49,12 @@ _SIGS = {
     "t4r_set_precision": ("v", "i"),
     "t4r_get_precision": ("i", ""),
     "t4r_gemm_softmax_grad_f32": ("i", "piiiif" + "plpppf" + "plpl" + "ii"),
+    "t4r_head_split_supported": ("i", "i"),
+    "t4r_head_split_ws_bytes": ("l", "iii"),
+    "t4r_head_split_prepare": ("i", "ppl" + "iii" + "p"),
+    "t4r_head_split_logits": ("i", "ppplpl" + "iiif"),
+    "t4r_head_split_dw": ("i", "ppplpppf" + "pl" + "iiiii" + "fi"),
+    "t4r_head_split_dx": ("i", "ppplpppf" + "plpl" + "iiiii" + "fi"),
     "t4r_add_layernorm_fwd": ("i", "pppppppp" + "iif" + "fQQ"),
     "t4r_add_layernorm_bwd": ("i", "pppppppppppp" + "iii" + "fQQ"),
     "t4r_colreduce_ws_floats": ("l", "li"),

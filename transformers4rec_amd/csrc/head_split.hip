@@ -1,0 +1,506 @@
+// Next-item head (tied full softmax) for d_model <= 128, fp32-accurate on the BF16 matrix cores.
+//
+// Replaces, for D = 32 / 64 / 96 / 128, the three vocabulary-wide contractions of
+// transformers4rec/torch/model/prediction_task.py:664 (logits = X @ W^T) and of its autograd
+// (d X = dlogits @ W, d W = dlogits^T @ X, with CrossEntropyLoss' backward :446 formed on the fly from the
+// stored logits) -- 2.1 of the 4.8 ms training step at BASELINE configs[1] when they ran through the general
+// GEMM (gemm_kernel.h, PREC 1).  Same arithmetic as PREC 1: every operand is cut into three bf16 pieces
+// (x = hi + mid + lo exactly, round-to-nearest cuts) and the six largest partial products are accumulated in
+// fp32 by v_mfma_f32_32x32x16_bf16.  What changes is WHERE the cutting happens: the general kernel re-cuts every
+// operand tile each time a workgroup stages it (the VALU work equals the matrix-core time), here
+//   * X [N, D] (a few thousand label rows) is cut ONCE per step into fragment-ordered plane blocks
+//     (split_mk / split_km kernels: 24 KB per 32 rows);
+//   * logits: a workgroup keeps its 128 rows of W as MFMA B fragments IN REGISTERS for its whole life (cut once per
+//     workgroup, the whole K = D extent: 96 VGPRs at D = 128) and streams the X plane blocks through LDS --
+//     no conversion and one ds_read_b128 per two MFMAs in the loop;
+//   * d W: the softmax-gradient fragment G^T (vocabulary x rows) is computed by the lane that feeds it to the
+//     matrix core, straight from coalesced logit loads -- every element of the [N, V] gradient is formed and cut
+//     exactly once in the whole grid and never touches LDS; X arrives as pre-cut plane blocks through LDS;
+//   * d X: the same scheme with rows as M (each lane walks its own logits row), W^T as pre-cut plane blocks
+//     (split_km over the table, once per step), split over the vocabulary into deterministic partial sums
+//     (no atomics) that a small kernel adds in a fixed order.
+// MFMA operand convention used by all kernels here: the k-slot (lane >> 5, i) of step s holds physical
+// k = 16 s + 8 (lane >> 5) + i, i = position in the lane's 16 bytes -- the same map for A and B, so any
+// consistent order is a valid contraction order.
+#include "gemm_kernel.h"
+
+namespace {
+
+constexpr float kLog2e = 1.4426950408889634f;
+// native vector type for everything that is staged: assigning HIP's uint4 struct between address spaces becomes a
+// memcpy that keeps the staging array in scratch memory
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void split8(const float (&x)[8], u32x4 (&w)[3]) {
+    uint32_t a[3], b[3], c[3], d[3];
+    cvt_pair<1>(x[0], x[1], a);
+    cvt_pair<1>(x[2], x[3], b);
+    cvt_pair<1>(x[4], x[5], c);
+    cvt_pair<1>(x[6], x[7], d);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) w[pl] = u32x4{a[pl], b[pl], c[pl], d[pl]};
+}
+// the six partial products of one K = 16 step, smallest first
+__device__ __forceinline__ f32x16 mfma6(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x16 acc) {
+    acc = mfma_bf16(a[1], b[1], acc);
+    acc = mfma_bf16(a[2], b[0], acc);
+    acc = mfma_bf16(a[0], b[2], acc);
+    acc = mfma_bf16(a[1], b[0], acc);
+    acc = mfma_bf16(a[0], b[1], acc);
+    acc = mfma_bf16(a[0], b[0], acc);
+    return acc;
+}
+
+// ---- plane blocks.  One block = 32 rows of a row-major fp32 matrix [n_rows, D], as three bf16 planes:
+//   MK image (rows are the M / N index of the product, D is K):  [plane][chunk = d / 8][row % 32] x 16 bytes = 8 consecutive d
+//   KM image (rows are K, D is the N index):                     [plane][kc = (row % 32) / 8][d] x 16 bytes = 8 consecutive rows
+// Both are 12 D u32x4 (24 KB at D = 128); rows >= n_rows are zero.
+template <int NB>
+__global__ __launch_bounds__(256) void split_mk_kernel(const float* __restrict__ src, long ld, int n_rows,
+                                                        u32x4* __restrict__ dst) {
+    constexpr int D = 32 * NB, CH = D / 8;
+    const int b = blockIdx.x;
+    for (int idx = threadIdx.x; idx < CH * 32; idx += 256) {
+        const int r = idx & 31, c = idx >> 5, row = b * 32 + r;
+        float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (row < n_rows) {
+            const float4 u = *reinterpret_cast<const float4*>(src + (long)row * ld + 8 * c);
+            const float4 v = *reinterpret_cast<const float4*>(src + (long)row * ld + 8 * c + 4);
+            x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = v.x; x[5] = v.y; x[6] = v.z; x[7] = v.w;
+        }
+        u32x4 w[3];
+        split8(x, w);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) dst[((long)b * 3 + pl) * (CH * 32) + c * 32 + r] = w[pl];
+    }
+}
+template <int NB>
+__global__ __launch_bounds__(256) void split_km_kernel(const float* __restrict__ src, long ld, int n_rows,
+                                                        u32x4* __restrict__ dst) {
+    constexpr int D = 32 * NB;
+    const int b = blockIdx.x;
+    for (int idx = threadIdx.x; idx < 4 * D; idx += 256) {
+        const int d = idx % D, kc = idx / D;
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int row = b * 32 + 8 * kc + e;
+            x[e] = row < n_rows ? src[(long)row * ld + d] : 0.f;
+        }
+        u32x4 w[3];
+        split8(x, w);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) dst[(((long)b * 3 + pl) * 4 + kc) * D + d] = w[pl];
+    }
+}
+
+// ---- logits:  C[N, V] = alpha * X @ W^T.  grid (ceil(V / 128), row splits); X as MK plane blocks.
+template <int NB>
+__global__ __launch_bounds__(256) void head_logits_split_kernel(const u32x4* __restrict__ XA, const float* __restrict__ W,
+                                                                 long ldw, float* __restrict__ C, long ldc, int N, int V,
+                                                                 float alpha, int nblk, int blk_per) {
+    constexpr int KS = 2 * NB, CH = 4 * NB;
+    constexpr int BLK = 12 * 32 * NB;      // u32x4 per plane block
+    constexpr int SN = (BLK + 255) / 256;
+    __shared__ u32x4 lds[2][BLK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, khalf = lane >> 5;
+    const int b_begin = blockIdx.y * blk_per, b_end = min(nblk, b_begin + blk_per);
+    if (b_begin >= b_end) return;
+    const int col = blockIdx.x * 128 + 32 * wave + l32;
+
+    // this lane's 8-element pieces of row `col` of W, cut once
+    u32x4 Bf[KS][3];
+    {
+        const float* wr = W + (long)min(col, V - 1) * ldw + 8 * khalf;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const float4 u = *reinterpret_cast<const float4*>(wr + 16 * s);
+            const float4 v = *reinterpret_cast<const float4*>(wr + 16 * s + 4);
+            const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+            split8(x, Bf[s]);
+        }
+    }
+
+    u32x4 st[SN];
+    auto g_load = [&](int b) __attribute__((always_inline)) {
+        const u32x4* src = XA + (long)b * BLK;
+#pragma unroll
+        for (int i = 0; i < SN; ++i)
+            if (BLK % 256 == 0 || i * 256 + tid < BLK) st[i] = src[i * 256 + tid];
+    };
+    auto s_store = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < SN; ++i)
+            if (BLK % 256 == 0 || i * 256 + tid < BLK) lds[buf][i * 256 + tid] = st[i];
+    };
+    g_load(b_begin);
+    s_store(0);
+    __syncthreads();
+    for (int b = b_begin; b < b_end; ++b) {
+        const int buf = (b - b_begin) & 1;
+        // unconditional (the last pass re-reads its own block); pinned BEFORE the MFMAs -- left alone the scheduler sinks
+        // the loads below them and the full L2 latency is exposed at the LDS stores
+        g_load(min(b + 1, b_end - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            u32x4 a[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) a[pl] = lds[buf][(pl * CH + 2 * s + khalf) * 32 + l32];
+            acc = mfma6(a, Bf[s], acc);
+        }
+        // next block -> LDS before the logits are stored: the wait for its loads must not cover the HBM stores
+        s_store(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (col < V) {
+            const int row0 = b * 32 + 4 * khalf;
+            float* c0 = C + (long)row0 * ldc + col;
+            if (b * 32 + 32 <= N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c0[(long)((r & 3) + 8 * (r >> 2)) * ldc] = alpha * acc[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    if (row0 + dr < N) c0[(long)dr * ldc] = alpha * acc[r];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// softmax-CE gradient of one logit:  g * (exp(x - lse) - eps / V) - [col == y] * g * (1 - eps),  l2 = lse * log2(e)
+struct SgScalars { float g, sub, hit; };
+__device__ __forceinline__ float sg_value(float x, float l2, bool is_label, const SgScalars& q) {
+    const float t = __builtin_amdgcn_exp2f(fmaf(x, kLog2e, -l2));
+    return fmaf(q.g, t, -q.sub) - (is_label ? q.hit : 0.f);
+}
+
+// ---- d W[Vc, D] (+)= alpha * G^T @ X.  grid ceil(Vc / 128); wave w owns vocabulary rows 32 w .. 32 w + 31 of the tile.
+template <int NB>
+__global__ __launch_bounds__(256) void head_dw_split_kernel(const float* __restrict__ logits, long ld,
+                                                             const float* __restrict__ lse, const long* __restrict__ labels,
+                                                             const float* __restrict__ gout, const u32x4* __restrict__ XT,
+                                                             float* __restrict__ dW, long lddw, int N, int Vc, int V,
+                                                             int yoff, float smooth, float alpha, int accumulate, int nblk) {
+    constexpr int D = 32 * NB;
+    constexpr int BLK = 12 * 32 * NB;
+    constexpr int SN = (BLK + 255) / 256;
+    __shared__ u32x4 lds[2][BLK];
+    __shared__ float2 rinfo[2][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, khalf = lane >> 5;
+    const int v = blockIdx.x * 128 + 32 * wave + l32;
+    const float* lp = logits + min(v, Vc - 1);
+    SgScalars q;
+    q.g = (gout ? *gout : 1.f) / N;
+    q.sub = q.g * smooth / V;
+    q.hit = q.g * (1.f - smooth);
+
+    u32x4 st[SN];
+    float2 ri = make_float2(0.f, 0.f);
+    float xn[16];
+    auto g_load = [&](int b) __attribute__((always_inline)) {
+        const u32x4* src = XT + (long)b * BLK;
+#pragma unroll
+        for (int i = 0; i < SN; ++i)
+            if (BLK % 256 == 0 || i * 256 + tid < BLK) st[i] = src[i * 256 + tid];
+        if (tid < 32) {
+            const int row = b * 32 + tid;
+            // rows past the end: X is zero there; exp2(-huge) = 0 keeps their gradient finite
+            ri = row < N ? make_float2(lse[row] * kLog2e, __int_as_float((int)(labels[row] - yoff)))
+                         : make_float2(1e30f, __int_as_float(-1));
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xn[8 * s + e] = lp[(long)min(b * 32 + 16 * s + 8 * khalf + e, N - 1) * ld];
+    };
+    auto s_store = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < SN; ++i)
+            if (BLK % 256 == 0 || i * 256 + tid < BLK) lds[buf][i * 256 + tid] = st[i];
+        if (tid < 32) rinfo[buf][tid] = ri;
+    };
+    f32x16 acc[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    g_load(0);
+    s_store(0);
+    __syncthreads();
+    for (int b = 0; b < nblk; ++b) {
+        const int buf = b & 1;
+        float xc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) xc[i] = xn[i];
+        g_load(min(b + 1, nblk - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        u32x4 af[2][3];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float gv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float2 in = rinfo[buf][16 * s + 8 * khalf + e];
+                gv[e] = sg_value(xc[8 * s + e], in.x, __float_as_int(in.y) == v, q);
+            }
+            split8(gv, af[s]);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                u32x4 bf[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) bf[pl] = lds[buf][(pl * 4 + 2 * s + khalf) * D + 32 * j + l32];
+                acc[j] = mfma6(af[s], bf, acc[j]);
+            }
+        s_store(buf ^ 1);
+        __syncthreads();
+    }
+    const int v0 = blockIdx.x * 128 + 32 * wave + 4 * khalf;
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int vr = v0 + (r & 3) + 8 * (r >> 2);
+            if (vr < Vc) {
+                float* cp = dW + (long)vr * lddw + 32 * j + l32;
+                const float val = alpha * acc[j][r];
+                *cp = accumulate ? *cp + val : val;
+            }
+        }
+}
+
+// ---- d X partial sums:  part[split][N, D] = alpha * G[:, k-range] @ W[k-range, :].  grid (ceil(N / 128), splits);
+// wave w owns rows 32 w .. 32 w + 31 of the tile, each lane walks its own logits row.
+template <int NB>
+__global__ __launch_bounds__(256) void head_dx_split_kernel(const float* __restrict__ logits, long ld,
+                                                             const float* __restrict__ lse, const long* __restrict__ labels,
+                                                             const float* __restrict__ gout, const u32x4* __restrict__ WT,
+                                                             float* __restrict__ part, int N, int Vc, int V, int yoff,
+                                                             float smooth, float alpha, int nkt, int kt_per) {
+    constexpr int D = 32 * NB;
+    constexpr int BLK = 12 * 32 * NB;
+    constexpr int SN = (BLK + 255) / 256;
+    __shared__ u32x4 lds[2][BLK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, khalf = lane >> 5;
+    const int kt_begin = blockIdx.y * kt_per, kt_end = min(nkt, kt_begin + kt_per);
+    if (kt_begin >= kt_end) return;
+    const int row = blockIdx.x * 128 + 32 * wave + l32, rc = min(row, N - 1);
+    const float* lp = logits + (long)rc * ld;
+    const float l2 = lse[rc] * kLog2e;
+    const int y = (int)(labels[rc] - yoff);
+    SgScalars q;
+    q.g = (gout ? *gout : 1.f) / N;
+    q.sub = q.g * smooth / V;
+    q.hit = q.g * (1.f - smooth);
+    const int ldm4 = (int)ld - 4;
+
+    u32x4 st[SN];
+    float4 xn[4];
+    auto g_load = [&](int kt) __attribute__((always_inline)) {
+        const u32x4* src = WT + (long)kt * BLK;
+#pragma unroll
+        for (int i = 0; i < SN; ++i)
+            if (BLK % 256 == 0 || i * 256 + tid < BLK) st[i] = src[i * 256 + tid];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int c = kt * 32 + 16 * s + 8 * khalf;       // the pitch is a multiple of 4: both loads stay inside the row
+            xn[2 * s] = *reinterpret_cast<const float4*>(lp + min(c, ldm4));
+            xn[2 * s + 1] = *reinterpret_cast<const float4*>(lp + min(c + 4, ldm4));
+        }
+    };
+    auto s_store = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < SN; ++i)
+            if (BLK % 256 == 0 || i * 256 + tid < BLK) lds[buf][i * 256 + tid] = st[i];
+    };
+    f32x16 acc[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    g_load(kt_begin);
+    s_store(0);
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int buf = (kt - kt_begin) & 1;
+        float xc[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { xc[4 * i] = xn[i].x; xc[4 * i + 1] = xn[i].y; xc[4 * i + 2] = xn[i].z; xc[4 * i + 3] = xn[i].w; }
+        g_load(min(kt + 1, kt_end - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt * 32 + 32 > Vc) {        // vocabulary tail: columns past the end carry no gradient (their W rows are zero, keep G finite)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (kt * 32 + 16 * (i >> 3) + 8 * khalf + (i & 7) >= Vc) xc[i] = -INFINITY;
+        }
+        u32x4 af[2][3];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int dy = y - (kt * 32 + 16 * s + 8 * khalf);
+            float gv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gv[e] = sg_value(xc[8 * s + e], l2, dy == e, q);
+            split8(gv, af[s]);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                u32x4 bf[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) bf[pl] = lds[buf][(pl * 4 + 2 * s + khalf) * D + 32 * j + l32];
+                acc[j] = mfma6(af[s], bf, acc[j]);
+            }
+        s_store(buf ^ 1);
+        __syncthreads();
+    }
+    float* pp = part + (long)blockIdx.y * N * D;
+    const int r0 = blockIdx.x * 128 + 32 * wave + 4 * khalf;
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = r0 + (r & 3) + 8 * (r >> 2);
+            if (rr < N) pp[(long)rr * D + 32 * j + l32] = alpha * acc[j][r];
+        }
+}
+
+// out[row, :] (+)= sum over the splits, in split order (deterministic)
+__global__ __launch_bounds__(256) void head_dx_reduce_kernel(const float* __restrict__ part, int n_split, long nd4, int d4,
+                                                              float* __restrict__ out, long ldo, int accumulate) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nd4) return;
+    float4 s = reinterpret_cast<const float4*>(part)[i];
+    for (int k = 1; k < n_split; ++k) {
+        const float4 t = reinterpret_cast<const float4*>(part)[(long)k * nd4 + i];
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    float4* op = reinterpret_cast<float4*>(out + (i / d4) * ldo + (i % d4) * 4);
+    if (accumulate) { const float4 o = *op; s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
+    *op = s;
+}
+
+// workspace layout (bytes): XA | XT | WT | d X partials
+struct HeadWs { long xa, xt, wt, part, total; int nblk, nkt, max_split; };
+HeadWs head_ws(int N, int V, int D) {
+    HeadWs w;
+    w.nblk = (N + 31) / 32;
+    w.nkt = (V + 31) / 32;
+    const long blk = 12L * D * 16;
+    w.max_split = 64;
+    w.xa = 0;
+    w.xt = w.xa + w.nblk * blk;
+    w.wt = w.xt + w.nblk * blk;
+    w.part = w.wt + w.nkt * blk;
+    w.total = w.part + (long)w.max_split * N * D * 4;
+    return w;
+}
+bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+#define T4R_NB_SWITCH(D, CALL)                \
+    switch ((D) / 32) {                       \
+        case 1: { constexpr int NB = 1; CALL; } break; \
+        case 2: { constexpr int NB = 2; CALL; } break; \
+        case 3: { constexpr int NB = 3; CALL; } break; \
+        default: { constexpr int NB = 4; CALL; } break; \
+    }
+
+// 1 when these kernels take the shape (the callers fall back to the general GEMM otherwise)
+extern "C" int t4r_head_split_supported(int D) { return D >= 32 && D <= 128 && D % 32 == 0; }
+
+extern "C" long t4r_head_split_ws_bytes(int N, int V, int D) {
+    if (!t4r_head_split_supported(D) || N <= 0 || V <= 0) return 0;
+    return head_ws(N, V, D).total;
+}
+
+// cuts X [N, D] (the head's input rows) into the plane blocks the three contractions consume
+extern "C" int t4r_head_split_prepare(void* stream, const float* X, long ldx, int N, int D, int V, void* ws) {
+    if (N <= 0) return 0;
+    T4R_CHECK_ARG(t4r_head_split_supported(D) && X && ws, "head_split_prepare: unsupported width or null pointer");
+    T4R_CHECK_ARG(aligned16(X) && ldx % 4 == 0 && aligned16(ws), "head_split_prepare: X must be 16-byte aligned with a pitch multiple of 4");
+    const HeadWs w = head_ws(N, V, D);
+    hipStream_t st = (hipStream_t)stream;
+    u32x4* xa = reinterpret_cast<u32x4*>((char*)ws + w.xa);
+    u32x4* xt = reinterpret_cast<u32x4*>((char*)ws + w.xt);
+    T4R_NB_SWITCH(D, hipLaunchKernelGGL(split_mk_kernel<NB>, dim3(w.nblk), dim3(256), 0, st, X, ldx, N, xa));
+    T4R_NB_SWITCH(D, hipLaunchKernelGGL(split_km_kernel<NB>, dim3(w.nblk), dim3(256), 0, st, X, ldx, N, xt));
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+// C[N, V] = alpha * X @ W^T from the prepared workspace
+extern "C" int t4r_head_split_logits(void* stream, const void* ws, const float* W, long ldw, float* C, long ldc, int N,
+                                     int V, int D, float alpha) {
+    if (N <= 0 || V <= 0) return 0;
+    T4R_CHECK_ARG(t4r_head_split_supported(D) && W && C && ws, "head_split_logits: unsupported width or null pointer");
+    T4R_CHECK_ARG(aligned16(W) && ldw % 4 == 0, "head_split_logits: W must be 16-byte aligned with a pitch multiple of 4");
+    const HeadWs w = head_ws(N, V, D);
+    static int per_env = -1;
+    if (per_env < 0) { const char* e = getenv("T4R_HEAD_ROWS_PER_WG"); per_env = e ? atoi(e) : 12; }
+    const int blk_per = max(1, min(w.nblk, per_env));
+    const int rs = (w.nblk + blk_per - 1) / blk_per;
+    const u32x4* xa = reinterpret_cast<const u32x4*>((const char*)ws + w.xa);
+    dim3 grid((V + 127) / 128, rs);
+    T4R_NB_SWITCH(D, hipLaunchKernelGGL(head_logits_split_kernel<NB>, grid, dim3(256), 0, (hipStream_t)stream, xa, W, ldw, C,
+                                        ldc, N, V, alpha, w.nblk, blk_per));
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+// d W[Vc, D] (+)= alpha * dlogits^T @ X;  logits holds the columns [yoff, yoff + Vc) of the [N, V] problem
+extern "C" int t4r_head_split_dw(void* stream, const void* ws, const float* logits, long ld, const float* lse,
+                                 const long* labels, const float* grad_out, float label_smoothing, float* dW, long lddw,
+                                 int N, int Vc, int V, int yoff, int D, float alpha, int accumulate) {
+    if (N <= 0 || Vc <= 0) return 0;
+    T4R_CHECK_ARG(t4r_head_split_supported(D) && logits && lse && labels && dW && ws, "head_split_dw: unsupported width or null pointer");
+    const HeadWs w = head_ws(N, V, D);
+    const u32x4* xt = reinterpret_cast<const u32x4*>((const char*)ws + w.xt);
+    T4R_NB_SWITCH(D, hipLaunchKernelGGL(head_dw_split_kernel<NB>, dim3((Vc + 127) / 128), dim3(256), 0, (hipStream_t)stream,
+                                        logits, ld, lse, labels, grad_out, xt, dW, lddw, N, Vc, V, yoff, label_smoothing,
+                                        alpha, accumulate, w.nblk));
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+// d X[N, D] (+)= alpha * dlogits @ W[yoff : yoff + Vc];  W points at row yoff
+extern "C" int t4r_head_split_dx(void* stream, void* ws, const float* logits, long ld, const float* lse,
+                                 const long* labels, const float* grad_out, float label_smoothing, const float* W, long ldw,
+                                 float* dX, long lddx, int N, int Vc, int V, int yoff, int D, float alpha, int accumulate) {
+    if (N <= 0 || Vc <= 0) return 0;
+    T4R_CHECK_ARG(t4r_head_split_supported(D) && logits && lse && labels && dX && W && ws, "head_split_dx: unsupported width or null pointer");
+    T4R_CHECK_ARG(aligned16(logits) && ld % 4 == 0 && ld >= 8 && aligned16(dX) && lddx % 4 == 0,
+                  "head_split_dx: logits / dX must be 16-byte aligned with pitches multiple of 4");
+    const HeadWs w = head_ws(N, V, D);
+    hipStream_t st = (hipStream_t)stream;
+    u32x4* wt = reinterpret_cast<u32x4*>((char*)ws + w.wt);
+    float* part = reinterpret_cast<float*>((char*)ws + w.part);
+    const int nkt = (Vc + 31) / 32, row_tiles = (N + 127) / 128;
+    T4R_NB_SWITCH(D, hipLaunchKernelGGL(split_km_kernel<NB>, dim3(nkt), dim3(256), 0, st, W, ldw, Vc, wt));
+    static int target = -1;
+    if (target < 0) { const char* e = getenv("T4R_HEAD_DX_WGS"); target = e ? atoi(e) : 1536; }
+    int splits = max(1, min(min(w.max_split, nkt / 8), target / row_tiles));
+    const int kt_per = (nkt + splits - 1) / splits;
+    splits = (nkt + kt_per - 1) / kt_per;          // every split owns at least one k-tile
+    T4R_NB_SWITCH(D, hipLaunchKernelGGL(head_dx_split_kernel<NB>, dim3(row_tiles, splits), dim3(256), 0, st, logits, ld, lse,
+                                        labels, grad_out, wt, part, N, Vc, V, yoff, label_smoothing, alpha, nkt, kt_per));
+    const long nd4 = (long)N * D / 4;
+    hipLaunchKernelGGL(head_dx_reduce_kernel, dim3((unsigned)((nd4 + 255) / 256)), dim3(256), 0, st, part, splits, nd4, D / 4,
+                       dX, lddx, accumulate);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}

@@ -120,6 +120,49 @@ def gemm_softmax_grad(logits, lse, labels, grad_out, V, b, trans_a, alpha=1.0, l
     return out
 
 
+# ---- materialised head for d_model <= 128 (csrc/head_split.hip)
+def head_split_supported(D):
+    return bool(_lib.load().t4r_head_split_supported(int(D)))
+
+
+def head_split_prepare(x, V):
+    """cuts the head's input rows x [N, D] into the plane blocks of the three products; returns the workspace"""
+    N, D = x.shape
+    nbytes = _lib.load().t4r_head_split_ws_bytes(N, int(V), D)
+    ws = torch.empty(max(nbytes, 16), device=x.device, dtype=torch.uint8)
+    call("t4r_head_split_prepare", _stream(), _chk(x, torch.float32), x.stride(0), N, D, int(V), ws.data_ptr())
+    return ws
+
+
+def head_split_logits(ws, x, W, alpha=1.0, ldc=None):
+    N, D = x.shape
+    V = W.shape[0]
+    ldc = V if ldc is None else ldc
+    buf = torch.empty((N, ldc), device=x.device, dtype=torch.float32)
+    call("t4r_head_split_logits", _stream(), ws.data_ptr(), _chk(W, torch.float32), W.stride(0), buf.data_ptr(), ldc,
+         N, V, D, float(alpha))
+    return buf[:, :V]
+
+
+def head_split_dw(ws, logits, lse, labels, grad_out, V, D, out, alpha=1.0, label_smoothing=0.0, accumulate=True, yoff=0):
+    N, Vc = logits.shape
+    call("t4r_head_split_dw", _stream(), ws.data_ptr(), logits.data_ptr(), logits.stride(0), _chk(lse, torch.float32),
+         _chk(labels, torch.int64), _p(grad_out), float(label_smoothing), out.data_ptr(), out.stride(0), N, Vc, int(V),
+         int(yoff), int(D), float(alpha), int(accumulate))
+    return out
+
+
+def head_split_dx(ws, logits, lse, labels, grad_out, V, W, alpha=1.0, label_smoothing=0.0, out=None, accumulate=False, yoff=0):
+    N, Vc = logits.shape
+    D = W.shape[1]
+    if out is None:
+        out = torch.empty((N, D), device=logits.device, dtype=torch.float32)
+    call("t4r_head_split_dx", _stream(), ws.data_ptr(), logits.data_ptr(), logits.stride(0), _chk(lse, torch.float32),
+         _chk(labels, torch.int64), _p(grad_out), float(label_smoothing), W.data_ptr(), W.stride(0), out.data_ptr(),
+         out.stride(0), N, Vc, int(V), int(yoff), D, float(alpha), int(accumulate))
+    return out
+
+
 # ------------------------------------------------------------------------------------ LN / act
 SITE_INPUT, SITE_POS, SITE_PROB, SITE_ATTN_OUT, SITE_FF_ACT, SITE_FF_OUT, SITE_FINAL = range(7)
 NO_DROP = (0.0, 0, 0)

@@ -895,6 +895,42 @@ def test_fp32_accurate_split_mode_matches_reference(mode):
         close(named[k].grad, ref, rtol=2e-4, atol=1e-4, msg=lambda m, k=k: f"{k}: {m}")
 
 
+def test_head_split_path_is_taken_and_agrees_with_the_general_gemm(monkeypatch):
+    """the d_model <= 128 head (csrc/head_split.hip) replaces the general GEMM for >= 2 GFLOP products in the
+    fp32-accurate modes: same loss, predictions and gradients as the general path on the same model and batch"""
+    import transformers4rec_amd as tr
+    from transformers4rec_amd import ops, prediction_task as pt
+
+    torch.manual_seed(0)
+    V, L, D, B = 30_000, 20, 128, 128
+    schema = tr.session_schema(V, L)
+    inputs = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=L, masking="mlm", embedding_dim_default=D)
+    model = tr.XLNetConfig.build(D, 4, 2, total_seq_length=L).to_torch_model(inputs, tr.NextItemPredictionTask(weight_tying=True)).to("cuda")
+    x = tr.random_data_from_schema(schema, B, L, seed=1, device="cuda")
+    taken = []
+    real = ops.head_split_logits
+    monkeypatch.setattr(ops, "head_split_logits", lambda *a, **k: (taken.append(1), real(*a, **k))[1])
+    from transformers4rec_amd.rng import get_rng_state, set_rng_state
+
+    res = {}
+    model.train()
+    state = get_rng_state(model)
+    for on in (True, False):
+        monkeypatch.setattr(pt, "_HEAD_SPLIT", on)
+        model.zero_grad(set_to_none=True)
+        set_rng_state(model, state)                             # the same MLM mask and dropout masks both times
+        out = model(x, training=True)
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        res[on] = (float(out["loss"].detach()), out["predictions"].detach().clone(),
+                   {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert len(taken) == 1
+    assert abs(res[True][0] - res[False][0]) < 1e-5
+    close(res[True][1], res[False][1], rtol=1e-5, atol=1e-5)
+    for n, g in res[True][2].items():
+        close(g, res[False][2][n], rtol=2e-4, atol=1e-6, msg=lambda m, n=n: f"{n}: {m}")
+
+
 @pytest.mark.parametrize("mode,dtype", [("bf16", torch.bfloat16), ("fp16", torch.float16)])
 def test_mixed_precision_mode(mode, dtype):
     """C5's precision mode (reference: HF Trainer fp16=True -> autocast, trainer.py:363-367; master weights fp32):

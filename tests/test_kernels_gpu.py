@@ -1100,3 +1100,77 @@ def test_log_uniform_device_sampler_matches_the_reference_distribution(ops):
     s.device_sampler = False
     neg2 = s.sample(torch.ones(3, dtype=torch.long, device=DEV))
     assert neg2.numel() <= 100 and int(neg2.min()) >= min_id
+
+
+# ------------------------------------------------------------------------------------------
+# materialised head for d_model <= 128 (csrc/head_split.hip)
+def _head_reference(x, W, labels, alpha, smooth, gout, logits, yoff=0, V=None):
+    """fp64: logits, and the two backward products formed from the GIVEN fp32 logits (the kernels' input)"""
+    N, Vc = logits.shape
+    V = Vc if V is None else V
+    lg = alpha * (x.double() @ W.double().t())
+    return lg
+
+
+@pytest.mark.parametrize("N,V,D,alpha,smooth", [(77, 1000, 64, 1.0, 0.0), (33, 257, 32, 1.0, 0.0), (130, 999, 96, 2.0, 0.0),
+                                                 (200, 5000, 128, 0.5, 0.1), (1, 40, 128, 1.0, 0.0)])
+def test_head_split_products_match_fp64(ops, N, V, D, alpha, smooth):
+    """logits, d X, d W of the hoisted-cut head against fp64 (errors at the level of the fp32 matrix-core path,
+    transformers4rec/torch/model/prediction_task.py:664 + autograd through CrossEntropyLoss :446)"""
+    g = torch.Generator(device=DEV).manual_seed(N)
+    x = torch.randn(N, D, device=DEV, generator=g)
+    W = torch.randn(V, D, device=DEV, generator=g) * 0.3
+    labels = torch.randint(0, V, (N,), device=DEV, generator=g)
+    gout = torch.tensor(1.7, device=DEV)
+    ws = ops.head_split_prepare(x, V)
+    logits = ops.head_split_logits(ws, x, W, alpha=alpha, ldc=ops.pad_ld(V))
+    lg64 = alpha * (x.double() @ W.double().t())
+    assert float((logits.double() - lg64).abs().max()) < 2e-6 * float(lg64.abs().max())
+    _, _, lse = ops.softmax_ce_fwd(logits, labels, V, smooth)
+    p = torch.softmax(logits.double(), dim=1)
+    onehot = torch.zeros_like(p)
+    onehot[torch.arange(N, device=DEV), labels] = 1.0
+    G = (1.7 / N) * (p - (1 - smooth) * onehot - smooth / V)
+    dX64, dW64 = alpha * (G @ W.double()), alpha * (G.t() @ x.double())
+    dX = ops.head_split_dx(ws, logits, lse, labels, gout, V, W, alpha=alpha, label_smoothing=smooth)
+    dW0 = torch.randn(V, D, device=DEV, generator=g) * float(dW64.abs().max())
+    dW = dW0.clone()
+    ops.head_split_dw(ws, logits, lse, labels, gout, V, D, dW, alpha=alpha, label_smoothing=smooth, accumulate=True)
+    dWn = torch.full((V, D), float("nan"), device=DEV)
+    ops.head_split_dw(ws, logits, lse, labels, gout, V, D, dWn, alpha=alpha, label_smoothing=smooth, accumulate=False)
+    assert float((dX.double() - dX64).abs().max()) < 5e-6 * float(dX64.abs().max())
+    assert float((dWn.double() - dW64).abs().max()) < 5e-6 * float(dW64.abs().max())
+    assert float((dW.double() - dW0.double() - dW64).abs().max()) < 1e-5 * float(dW64.abs().max())
+    # no atomics anywhere: a second run gives the same bits
+    dX2 = ops.head_split_dx(ws, logits, lse, labels, gout, V, W, alpha=alpha, label_smoothing=smooth)
+    dW2 = torch.empty_like(dWn)
+    ops.head_split_dw(ws, logits, lse, labels, gout, V, D, dW2, alpha=alpha, label_smoothing=smooth, accumulate=False)
+    assert torch.equal(dX, dX2) and torch.equal(dWn, dW2)
+    # agreement with the general path it replaces
+    with ops.precision("fp32"):
+        dX_g = ops.gemm_softmax_grad(logits, lse, labels, gout, V, W, False, alpha=alpha, label_smoothing=smooth, splitk=-1)
+    close(dX, dX_g, rtol=1e-4, atol=1e-5 * float(dX64.abs().max()))
+
+
+def test_head_split_vocabulary_chunk(ops):
+    """logits holding only the columns [yoff, yoff + Vc) of the problem (the chunk-streamed form): labels outside the
+    chunk contribute only their softmax mass, eps / V and 1 / N refer to the full problem"""
+    N, V, D, yoff, Vc = 50, 900, 64, 256, 300
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(N, D, device=DEV, generator=g)
+    W = torch.randn(V, D, device=DEV, generator=g) * 0.3
+    labels = torch.randint(0, V, (N,), device=DEV, generator=g)
+    ws = ops.head_split_prepare(x, V)
+    full = ops.head_split_logits(ws, x, W, ldc=ops.pad_ld(V))
+    _, _, lse = ops.softmax_ce_fwd(full, labels, V, 0.1)
+    chunk = torch.empty((N, ops.pad_ld(Vc)), device=DEV)[:, :Vc]
+    chunk.copy_(full[:, yoff:yoff + Vc])
+    p = torch.exp(full.double() - lse.double()[:, None])
+    onehot = torch.zeros_like(p)
+    onehot[torch.arange(N, device=DEV), labels] = 1.0
+    G = ((p - 0.9 * onehot - 0.1 / V) / N)[:, yoff:yoff + Vc]
+    dX = ops.head_split_dx(ws, chunk, lse, labels, None, V, W[yoff:yoff + Vc], label_smoothing=0.1, yoff=yoff)
+    dW = torch.zeros(Vc, D, device=DEV)
+    ops.head_split_dw(ws, chunk, lse, labels, None, V, D, dW, label_smoothing=0.1, accumulate=False, yoff=yoff)
+    close(dX, (G @ W[yoff:yoff + Vc].double()).float(), rtol=1e-4, atol=1e-7)
+    close(dW, (G.t() @ x.double()).float(), rtol=1e-4, atol=1e-7)

@@ -204,29 +204,32 @@ __global__ __launch_bounds__(256) void head_dw_split_kernel(const float* __restr
     q.hit = q.g * (1.f - smooth);
 
     u32x4 st[SN];
-    float2 ri = make_float2(0.f, 0.f);
+    float ri_lse = 0.f;
+    long ri_lab = 0;
     float xn[16];
+    // every load is unconditional and nothing computed from it appears before s_store: a guarded load (tid < 32) or a
+    // conversion right behind it puts an s_waitcnt vmcnt(0) into the middle of the prefetch
     auto g_load = [&](int b) __attribute__((always_inline)) {
         const u32x4* src = XT + (long)b * BLK;
 #pragma unroll
         for (int i = 0; i < SN; ++i)
             if (BLK % 256 == 0 || i * 256 + tid < BLK) st[i] = src[i * 256 + tid];
-        if (tid < 32) {
-            const int row = b * 32 + tid;
-            // rows past the end: X is zero there; exp2(-huge) = 0 keeps their gradient finite
-            ri = row < N ? make_float2(lse[row] * kLog2e, __int_as_float((int)(labels[row] - yoff)))
-                         : make_float2(1e30f, __int_as_float(-1));
-        }
+        const int row = min(b * 32 + (tid & 31), N - 1);
+        ri_lse = lse[row];
+        ri_lab = labels[row];
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int e = 0; e < 8; ++e) xn[8 * s + e] = lp[(long)min(b * 32 + 16 * s + 8 * khalf + e, N - 1) * ld];
     };
-    auto s_store = [&](int buf) __attribute__((always_inline)) {
+    auto s_store = [&](int buf, int b) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < SN; ++i)
             if (BLK % 256 == 0 || i * 256 + tid < BLK) lds[buf][i * 256 + tid] = st[i];
-        if (tid < 32) rinfo[buf][tid] = ri;
+        // rows past the end: X is zero there; exp2(-huge) = 0 keeps their gradient finite
+        const bool live = b * 32 + (tid & 31) < N;
+        if (tid < 32)
+            rinfo[buf][tid] = live ? make_float2(ri_lse * kLog2e, __int_as_float((int)(ri_lab - yoff))) : make_float2(1e30f, __int_as_float(-1));
     };
     f32x16 acc[NB];
 #pragma unroll
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(256) void head_dw_split_kernel(const float* __restr
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
     g_load(0);
-    s_store(0);
+    s_store(0, 0);
     __syncthreads();
     for (int b = 0; b < nblk; ++b) {
         const int buf = b & 1;
@@ -264,21 +267,24 @@ __global__ __launch_bounds__(256) void head_dw_split_kernel(const float* __restr
                 for (int pl = 0; pl < 3; ++pl) bf[pl] = lds[buf][(pl * 4 + 2 * s + khalf) * D + 32 * j + l32];
                 acc[j] = mfma6(af[s], bf, acc[j]);
             }
-        s_store(buf ^ 1);
+        s_store(buf ^ 1, min(b + 1, nblk - 1));
         __syncthreads();
     }
     const int v0 = blockIdx.x * 128 + 32 * wave + 4 * khalf;
 #pragma unroll
-    for (int j = 0; j < NB; ++j)
+    for (int j = 0; j < NB; ++j) {
+        float* cp = dW + (long)v0 * lddw + 32 * j + l32;
+        float old[16];
+        if (accumulate) {           // all sixteen reads in flight together
+#pragma unroll
+            for (int r = 0; r < 16; ++r) old[r] = cp[(long)min((r & 3) + 8 * (r >> 2), Vc - 1 - v0) * lddw];
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int vr = v0 + (r & 3) + 8 * (r >> 2);
-            if (vr < Vc) {
-                float* cp = dW + (long)vr * lddw + 32 * j + l32;
-                const float val = alpha * acc[j][r];
-                *cp = accumulate ? *cp + val : val;
-            }
+            const int dr = (r & 3) + 8 * (r >> 2);
+            if (v0 + dr < Vc) cp[(long)dr * lddw] = alpha * acc[j][r] + (accumulate ? old[r] : 0.f);
         }
+    }
 }
 
 // ---- d X partial sums:  part[split][N, D] = alpha * G[:, k-range] @ W[k-range, :].  grid (ceil(N / 128), splits);

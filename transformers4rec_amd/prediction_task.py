@@ -120,6 +120,18 @@ def _side_stream(device):
 from .prediction_task_sync import wait_pending_grad  # noqa: E402,F401
 
 
+_HEAD_SPLIT = os.environ.get("T4R_HEAD_SPLIT", "1") != "0"
+
+
+def _head_split_ok(xp, W, N, V):
+    """the materialised head for d_model <= 128 (csrc/head_split.hip): fp32-accurate precision modes only, shapes the
+    general GEMM would also send to the split form (>= 2 GFLOP), 16-byte loadable operands"""
+    D = W.shape[1]
+    return (_HEAD_SPLIT and N > 0 and ops.get_precision() in ("auto", "fp32_bf16x3") and ops.head_split_supported(D)
+            and 2.0 * N * V * D >= 2e9 and W.stride(1) == 1 and W.stride(0) % 4 == 0 and W.data_ptr() % 16 == 0
+            and xp.is_contiguous() and xp.data_ptr() % 16 == 0)
+
+
 class _NextItemHeadFn(torch.autograd.Function):
     """rows at label positions -> [task Linear] -> logits (full or sampled) -> mean CE."""
 
@@ -146,14 +158,21 @@ class _NextItemHeadFn(torch.autograd.Function):
             ctx.save_for_backward(pos, labels, labels, xr, xp, lse, lse)
             ctx.set_materialize_grads(False)
             return loss, None
+        hws = None
         if neg is None:
-            logits = ops.gemm(xp, W.detach(), False, True, alpha=1.0 / T, ldc=ops.pad_ld(V))
+            if _head_split_ok(xp, W, N, V):
+                # d_model <= 128: operands cut once, W-stationary logits (csrc/head_split.hip)
+                hws = ops.head_split_prepare(xp, V)
+                logits = ops.head_split_logits(hws, xp, W.detach(), alpha=1.0 / T, ldc=ops.pad_ld(V))
+            else:
+                logits = ops.gemm(xp, W.detach(), False, True, alpha=1.0 / T, ldc=ops.pad_ld(V))
             tgt, width = labels, V
         else:
             logits = ops.sampled_logits_fwd(xp, labels, W.detach(), neg, mod.sampler.correction_dist, T)
             tgt, width = torch.zeros_like(labels), logits.shape[1]
         loss, _rows, lse = ops.softmax_ce_fwd(logits, tgt, width, smooth)
         ctx.task, ctx.neg, ctx.meta = task, neg, (B, L, D, N, V, T, width, smooth)
+        ctx.hws = hws
         ctx.save_for_backward(pos, labels, tgt, xr, xp, logits, lse)
         ctx.mark_non_differentiable(logits)
         # without this autograd hands backward() a zero-filled [N_m, V] gradient for `logits`
@@ -178,8 +197,21 @@ class _NextItemHeadFn(torch.autograd.Function):
             # CrossEntropyLoss backward is fused into the A operand of both contractions:
             # the [N_m, V] gradient is never materialised
             g = dloss.contiguous()
-            dxp = ops.gemm_softmax_grad(logits, lse, tgt, g, V, W.detach(), False, alpha=1.0 / T,
-                                        label_smoothing=smooth, splitk=-1)
+            hws = ctx.hws
+            Dh = W.shape[1]
+            if hws is not None:
+                dxp = ops.head_split_dx(hws, logits, lse, tgt, g, V, W.detach(), alpha=1.0 / T, label_smoothing=smooth)
+            else:
+                dxp = ops.gemm_softmax_grad(logits, lse, tgt, g, V, W.detach(), False, alpha=1.0 / T,
+                                            label_smoothing=smooth, splitk=-1)
+
+            def d_w(gw):
+                if hws is not None:
+                    ops.head_split_dw(hws, logits, lse, tgt, g, V, Dh, gw, alpha=1.0 / T, label_smoothing=smooth,
+                                      accumulate=True)
+                else:
+                    ops.gemm_softmax_grad(logits, lse, tgt, g, V, xp, True, alpha=1.0 / T, label_smoothing=smooth,
+                                          out=gw, accumulate=True)
             if W.requires_grad:
                 # d W only feeds the optimizer (and, when tied, the embedding scatter at the very end of
                 # the backward): it runs on a side stream, under the latency-bound kernels of the body's
@@ -192,18 +224,16 @@ class _NextItemHeadFn(torch.autograd.Function):
                     ready.record()
                     with torch.cuda.stream(side):
                         side.wait_event(ready)
-                        ops.gemm_softmax_grad(logits, lse, tgt, g, V, xp, True, alpha=1.0 / T,
-                                              label_smoothing=smooth, out=gw, accumulate=True)
+                        d_w(gw)
                         done = torch.cuda.Event()
                         done.record(side)
-                    for t in (logits, lse, tgt, g, xp, gw):
+                    for t in (logits, lse, tgt, g, xp, gw) + (() if hws is None else (hws,)):
                         t.record_stream(side)      # the caching allocator must not recycle them under the side kernel
                     W._t4r_pending = done
                     torch.autograd.Variable._execution_engine.queue_callback(
                         lambda ev=done: torch.cuda.current_stream().wait_event(ev))
                 else:
-                    ops.gemm_softmax_grad(logits, lse, tgt, g, V, xp, True, alpha=1.0 / T, label_smoothing=smooth,
-                                          out=gw, accumulate=True)
+                    d_w(gw)
         else:
             dl = ops.softmax_ce_bwd(logits, tgt, lse, dloss.contiguous(), width, smooth)
             sink = getattr(W, "_t4r_sparse_sink", None)

@@ -373,7 +373,16 @@ def main():
     # the step runs in the library's default precision mode ("auto": fp32 accuracy, the exact 3-way bf16 split with
     # six bf16 matrix-core products on the large contractions); the same launch is timed in both forms
     mode = ops.get_precision()
-    gemm_ms = timed(lambda: ops.gemm(xr, W, False, True, out=buf[:, : W.shape[0]]))
+    from transformers4rec_amd.prediction_task import _head_split_ok
+
+    general_ms = timed(lambda: ops.gemm(xr, W, False, True, out=buf[:, : W.shape[0]]))
+    head_split = _head_split_ok(xr, W, N_m, W.shape[0])
+    if head_split:      # the launch the step issues at this shape: csrc/head_split.hip (operands cut once, W-stationary)
+        hws = ops.head_split_prepare(xr, W.shape[0])
+        gemm_ms = timed(lambda: ops.call("t4r_head_split_logits_ce", ops._stream(), hws.data_ptr(), W.data_ptr(), W.stride(0),
+                                         buf.data_ptr(), ld, None, None, None, None, N_m, W.shape[0], D_MODEL, 1.0, 0.0))
+    else:
+        gemm_ms = general_ms
     with ops.precision("fp32"):
         gemm_ms_f32 = timed(lambda: ops.gemm(xr, W, False, True, out=buf[:, : W.shape[0]]))
     flops = 2.0 * N_m * W.shape[0] * D_MODEL
@@ -474,7 +483,10 @@ def main():
                        "precision_mode": mode,
                        "preheat_s": round(preheat_s, 2), "preheat_steps": n_pre,
                        "timed_region_s": round(dt, 4)},
-            "roofline": {"kernel": ("gemm_f32_kernel<128,64,32,NT,PREC=1> (next-item logits X@W^T; fp32-accurate: exact "
+            "roofline": {"kernel": ("head_logits_ce_kernel<4> (next-item logits X@W^T + the softmax statistics of the loss; fp32-accurate: "
+                                    "exact 3-way bf16 split, six v_mfma_f32_32x32x16_bf16 products per K=16; W fragments "
+                                    "register-resident, X plane blocks through LDS)") if head_split else
+                                   ("gemm_f32_kernel<128,64,32,NT,PREC=1> (next-item logits X@W^T; fp32-accurate: exact "
                                     "3-way bf16 split, six v_mfma_f32_32x32x16_bf16 products per K=16)") if split else
                                    "gemm_f32_kernel<128,128,16,NT> (next-item logits X@W^T)",
                          "bound": "mfma", "precision_mode": mode,
@@ -485,6 +497,10 @@ def main():
                          "fp32_equivalent": {"achieved": round(flops / (gemm_ms * 1e-3) / 1e12, 2),
                                              "peak": MFMA_F32_PEAK_TFLOPS,
                                              "frac": round(flops / (gemm_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)},
+                         "hbm_side": {"algorithmic_GBps": round(4e-9 * (N_m * D_MODEL + W.shape[0] * D_MODEL + N_m * W.shape[0]) / (gemm_ms * 1e-3), 1),
+                                      "frac_of_hbm_peak": round(4e-9 * (N_m * D_MODEL + W.shape[0] * D_MODEL + N_m * W.shape[0]) / (gemm_ms * 1e-3) / HBM_PEAK_GBS, 4),
+                                      "note": "the launch also writes the [N, V] logits once (1.1 GB): its second bound"},
+                         "general_gemm_same_shape_ms": round(general_ms, 4),
                          "fp32_matrix_core_form": {"avg_launch_ms": round(gemm_ms_f32, 4),
                                                    "achieved": round(flops / (gemm_ms_f32 * 1e-3) / 1e12, 2),
                                                    "frac": round(flops / (gemm_ms_f32 * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)},

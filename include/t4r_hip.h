@@ -187,6 +187,14 @@ long t4r_head_split_ws_bytes(int N, int V, int D);
 int t4r_head_split_prepare(void* stream, const float* X, long ldx, int N, int D, int V, void* ws);
 int t4r_head_split_logits(void* stream, const void* ws, const float* W, long ldw, float* C, long ldc, int N, int V,
                           int D, float alpha);
+/* logits + mean cross-entropy (label smoothing as losses.py:4-20) in ONE pass over the vocabulary: the logits are
+ * stored as by _logits, the softmax statistics are reduced inside the product's workgroups (one partial per row and
+ * 128-column tile in ws) and merged by a small kernel -- replaces t4r_softmax_ce_fwd's second pass over [N, V].
+ * loss_rows [N], lse [N]; loss_mean (device scalar) may be NULL; labels == NULL runs the product (and its per-tile
+ * statistics) alone. */
+int t4r_head_split_logits_ce(void* stream, void* ws, const float* W, long ldw, float* C, long ldc, const long* labels,
+                             float* loss_rows, float* lse, float* loss_mean, int N, int V, int D, float alpha,
+                             float label_smoothing);
 int t4r_head_split_dw(void* stream, const void* ws, const float* logits, long ld, const float* lse,
                       const long* labels, const float* grad_out, float label_smoothing, float* dW, long lddw,
                       int N, int Vc, int V, int yoff, int D, float alpha, int accumulate);

@@ -908,8 +908,8 @@ def test_head_split_path_is_taken_and_agrees_with_the_general_gemm(monkeypatch):
     model = tr.XLNetConfig.build(D, 4, 2, total_seq_length=L).to_torch_model(inputs, tr.NextItemPredictionTask(weight_tying=True)).to("cuda")
     x = tr.random_data_from_schema(schema, B, L, seed=1, device="cuda")
     taken = []
-    real = ops.head_split_logits
-    monkeypatch.setattr(ops, "head_split_logits", lambda *a, **k: (taken.append(1), real(*a, **k))[1])
+    real = ops.head_split_logits_ce
+    monkeypatch.setattr(ops, "head_split_logits_ce", lambda *a, **k: (taken.append(1), real(*a, **k))[1])
     from transformers4rec_amd.rng import get_rng_state, set_rng_state
 
     res = {}

@@ -1126,7 +1126,14 @@ def test_head_split_products_match_fp64(ops, N, V, D, alpha, smooth):
     logits = ops.head_split_logits(ws, x, W, alpha=alpha, ldc=ops.pad_ld(V))
     lg64 = alpha * (x.double() @ W.double().t())
     assert float((logits.double() - lg64).abs().max()) < 2e-6 * float(lg64.abs().max())
-    _, _, lse = ops.softmax_ce_fwd(logits, labels, V, smooth)
+    loss, rows, lse = ops.softmax_ce_fwd(logits, labels, V, smooth)
+    # the one-pass form: same logits (to rounding), statistics merged from the per-tile partials
+    lg2, loss2, rows2, lse2 = ops.head_split_logits_ce(ws, x, W, labels, alpha=alpha, label_smoothing=smooth, ldc=ops.pad_ld(V))
+    close(lg2, logits, rtol=0, atol=4e-6 * float(lg64.abs().max()))
+    ref_rows = torch.nn.functional.cross_entropy(lg2.double(), labels, reduction="none", label_smoothing=smooth)
+    assert float((rows2.double() - ref_rows).abs().max()) < 1e-5
+    assert float((lse2.double() - torch.logsumexp(lg2.double(), 1)).abs().max()) < 1e-5
+    assert abs(float(loss2) - float(ref_rows.mean())) < 1e-5
     p = torch.softmax(logits.double(), dim=1)
     onehot = torch.zeros_like(p)
     onehot[torch.arange(N, device=DEV), labels] = 1.0

@@ -34,11 +34,16 @@ def check(N, V, D, alpha=1.0, smooth=0.0, seed=0):
     ws = ops.head_split_prepare(x, V)
     logits = ops.head_split_logits(ws, x, W, alpha=alpha, ldc=ops.pad_ld(V))
     loss, _, lse = ops.softmax_ce_fwd(logits, labels, V, smooth)
-    dW0 = torch.randn(V, D, device=dev, generator=g)
+    dW0 = torch.randn(V, D, device=dev, generator=g) * 1e-4
     dW = dW0.clone()
     ops.head_split_dw(ws, logits, lse, labels, gout, V, D, dW, alpha=alpha, label_smoothing=smooth, accumulate=True)
     dX = ops.head_split_dx(ws, logits, lse, labels, gout, V, W, alpha=alpha, label_smoothing=smooth)
     lg64, dX64, dW64 = reference(x, W, labels, alpha, smooth, 1.7, logits)
+    lg2, loss2, rows2, lse2 = ops.head_split_logits_ce(ws, x, W, labels, alpha=alpha, label_smoothing=smooth, ldc=ops.pad_ld(V))
+    lse64 = torch.logsumexp(lg2.double(), dim=1)
+    e_ce = (float((lg2 - logits).abs().max()), float((lse2.double() - lse64).abs().max()),
+            abs(float(loss2) - float(loss)), float((rows2 - _).abs().max()))
+    print(f"    fused CE: |logits - separate| {e_ce[0]:.1e}  |lse - fp64| {e_ce[1]:.1e}  |loss - separate| {e_ce[2]:.1e}  rows {e_ce[3]:.1e}")
     e_l = float((logits.double() - lg64).abs().max() / lg64.abs().max())
     e_x = float((dX.double() - dX64).abs().max() / dX64.abs().max())
     e_w = float(((dW - dW0).double() - dW64).abs().max() / dW64.abs().max())
@@ -52,7 +57,7 @@ def check(N, V, D, alpha=1.0, smooth=0.0, seed=0):
     f_w = float((dW_g.double() - dW64).abs().max() / dW64.abs().max())
     print(f"N={N:5d} V={V:6d} D={D:3d} alpha={alpha} eps={smooth}: rel err vs fp64  logits {e_l:.2e} (fp32 MFMA {f_l:.2e})"
           f"  dX {e_x:.2e} ({f_x:.2e})  dW {e_w:.2e} ({f_w:.2e})", flush=True)
-    ok = e_l < 4 * max(f_l, 1e-7) and e_x < 4 * max(f_x, 1e-6) and e_w < 4 * max(f_w, 1e-6)
+    ok = e_l < 4 * max(f_l, 1e-7) and e_x < 4 * max(f_x, 1e-6) and e_w < 4 * max(f_w, 1e-6) and max(e_ce) < 2e-5
     return ok
 
 
@@ -84,6 +89,7 @@ def bench(N=2780, V=100001, D=128):
     rows = []
     rows.append(("prepare (cut X)", timeit(lambda: ops.head_split_prepare(x, V)), 0))
     rows.append(("logits  head_split", timeit(lambda: ops.head_split_logits(ws, x, W, ldc=ops.pad_ld(V))), fl))
+    rows.append(("logits + CE fused", timeit(lambda: ops.head_split_logits_ce(ws, x, W, labels, ldc=ops.pad_ld(V))), fl))
     rows.append(("dW      head_split", timeit(lambda: ops.head_split_dw(ws, logits, lse, labels, gout, V, D, dW)), fl))
     rows.append(("dX      head_split", timeit(lambda: ops.head_split_dx(ws, logits, lse, labels, gout, V, W, out=dX)), fl))
     for mode in ("auto", "fp32"):

@@ -53,6 +53,7 @@ _SIGS = {
     "t4r_head_split_ws_bytes": ("l", "iii"),
     "t4r_head_split_prepare": ("i", "ppl" + "iii" + "p"),
     "t4r_head_split_logits": ("i", "ppplpl" + "iiif"),
+    "t4r_head_split_logits_ce": ("i", "ppplpl" + "pppp" + "iiiff"),
     "t4r_head_split_dw": ("i", "ppplpppf" + "pl" + "iiiii" + "fi"),
     "t4r_head_split_dx": ("i", "ppplpppf" + "plpl" + "iiiii" + "fi"),
     "t4r_add_layernorm_fwd": ("i", "pppppppp" + "iif" + "fQQ"),

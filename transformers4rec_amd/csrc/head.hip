@@ -123,6 +123,12 @@ __global__ __launch_bounds__(1024) void mean_kernel(const float* __restrict__ x,
     }
 }
 
+int t4r_mean_launch(hipStream_t stream, const float* x, int n, float* out) {      // used by head_split.hip
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, stream, x, n, out);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int t4r_softmax_ce_fwd(void* stream, const float* logits, const long* labels,
                                   float* loss_rows, float* lse, float* loss_mean, int N, int V, long ld,
                                   float label_smoothing) {

@@ -176,6 +176,169 @@ __global__ __launch_bounds__(256) void head_logits_split_kernel(const u32x4* __r
     }
 }
 
+// ---- logits + cross-entropy statistics in one pass.  Same product with the operand roles swapped (W fragments as the
+// A operand): the accumulator of lane (l32, khalf) then holds SIXTEEN VOCABULARY columns of ONE row of X -- the row's
+// (max, sum-exp, sum) over them are lane-local reductions, the lane pair (khalf 0 / 1) and the four waves merge
+// through one shuffle and 2 KB of LDS, and each workgroup leaves one partial triple per (row, 128-column tile):
+// softmax_ce_fwd's second pass over the 1.1 GB of logits (0.24 ms at BASELINE configs[1]) becomes a 26 MB merge.
+// Stores: a lane owns four consecutive columns per accumulator quad -> one 16-byte store each.
+__device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2) {
+    const float mn = fmaxf(m, m2);
+    const float ref = mn == -INFINITY ? 0.f : mn;
+    s = s * __builtin_amdgcn_exp2f((m - ref) * kLog2e) + s2 * __builtin_amdgcn_exp2f((m2 - ref) * kLog2e);
+    m = mn;
+}
+template <int NB>
+__global__ __launch_bounds__(256) void head_logits_ce_kernel(const u32x4* __restrict__ XA, const float* __restrict__ W,
+                                                              long ldw, float* __restrict__ C, long ldc, int N, int V,
+                                                              float alpha, int nblk, int blk_per, int vec_ok,
+                                                              float* __restrict__ st_m, float* __restrict__ st_s,
+                                                              float* __restrict__ st_t) {
+    constexpr int KS = 2 * NB, CH = 4 * NB;
+    constexpr int BLK = 12 * 32 * NB;
+    constexpr int SN = (BLK + 255) / 256;
+    __shared__ u32x4 lds[2][BLK];
+    __shared__ float4 sst[2][4][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, khalf = lane >> 5;
+    const int b_begin = blockIdx.y * blk_per, b_end = min(nblk, b_begin + blk_per);
+    if (b_begin >= b_end) return;
+    const int vbase = blockIdx.x * 128 + 32 * wave;
+    const bool tail_tile = blockIdx.x * 128 + 128 > V;
+
+    u32x4 Wf[KS][3];
+    {
+        const float* wr = W + (long)min(vbase + l32, V - 1) * ldw + 8 * khalf;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const float4 u = *reinterpret_cast<const float4*>(wr + 16 * s);
+            const float4 v = *reinterpret_cast<const float4*>(wr + 16 * s + 4);
+            const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+            split8(x, Wf[s]);
+        }
+    }
+    u32x4 st[SN];
+    auto g_load = [&](int b) __attribute__((always_inline)) {
+        const u32x4* src = XA + (long)b * BLK;
+#pragma unroll
+        for (int i = 0; i < SN; ++i)
+            if (BLK % 256 == 0 || i * 256 + tid < BLK) st[i] = src[i * 256 + tid];
+    };
+    auto s_store = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < SN; ++i)
+            if (BLK % 256 == 0 || i * 256 + tid < BLK) lds[buf][i * 256 + tid] = st[i];
+    };
+    // the four waves' partials of one row block -> one triple per row (threads 0..31, after the block's barrier)
+    auto flush_stats = [&](int buf, int b) __attribute__((always_inline)) {
+        if (tid < 32) {
+            float4 a = sst[buf][0][tid];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float4 o = sst[buf][w][tid];
+                lse_merge(a.x, a.y, o.x, o.y);
+                a.z += o.z;
+            }
+            const int row = b * 32 + tid;
+            if (row < N) {
+                const long o = (long)blockIdx.x * N + row;
+                st_m[o] = a.x;
+                st_s[o] = a.y;
+                if (st_t) st_t[o] = a.z;
+            }
+        }
+    };
+    g_load(b_begin);
+    s_store(0);
+    __syncthreads();
+    for (int b = b_begin; b < b_end; ++b) {
+        const int buf = (b - b_begin) & 1;
+        g_load(min(b + 1, b_end - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        if (b > b_begin) flush_stats(buf ^ 1, b - 1);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            u32x4 xf[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) xf[pl] = lds[buf][(pl * CH + 2 * s + khalf) * 32 + l32];
+            acc = mfma6(Wf[s], xf, acc);
+        }
+        s_store(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // lane (l32, khalf): row b*32 + l32 of X, columns vbase + 8 g + 4 khalf + (0..3), g = 0..3
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = alpha * acc[r];
+        const int row = b * 32 + l32;
+        const int c0 = vbase + 4 * khalf;
+        if (row < N) {
+            float* cr = C + (long)row * ldc + c0;
+            if (vec_ok && !tail_tile) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(cr + 8 * g) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (c0 + 8 * (r >> 2) + (r & 3) < V) cr[8 * (r >> 2) + (r & 3)] = v[r];
+            }
+        }
+        float t = 0.f;
+        if (tail_tile) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool in = c0 + 8 * (r >> 2) + (r & 3) < V;
+                t += in ? v[r] : 0.f;
+                v[r] = in ? v[r] : -INFINITY;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += v[r];
+        }
+        float m = v[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) m = fmaxf(m, v[r]);
+        const float ref = (m == -INFINITY ? 0.f : m) * kLog2e;
+        float se = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) se += __builtin_amdgcn_exp2f(fmaf(v[r], kLog2e, -ref));
+        lse_merge(m, se, __shfl_xor(m, 32, 64), __shfl_xor(se, 32, 64));
+        t += __shfl_xor(t, 32, 64);
+        if (khalf == 0) sst[buf][wave][l32] = make_float4(m, se, t, 0.f);
+        __syncthreads();
+    }
+    flush_stats((b_end - 1 - b_begin) & 1, b_end - 1);
+}
+
+// per row: merge the column tiles' partial triples -> lse, loss  (32 rows x 8 tile slices per workgroup)
+//   loss_row = lse - (1 - eps) * logit[y] - eps / V * sum_j logit[j]      (torch CrossEntropyLoss, label smoothing eps)
+__global__ __launch_bounds__(256) void head_ce_finalize_kernel(const float* __restrict__ st_m, const float* __restrict__ st_s,
+                                                                const float* __restrict__ st_t, int n_tiles, int N, int V,
+                                                                const float* __restrict__ C, long ldc,
+                                                                const long* __restrict__ labels, float smoothing,
+                                                                float* __restrict__ loss_rows, float* __restrict__ lse_out) {
+    __shared__ float sm[8][32], ss[8][32], stt[8][32];
+    const int r = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int row = min(blockIdx.x * 32 + r, N - 1);
+    float m = -INFINITY, s = 0.f, t = 0.f;
+    for (int k = sl; k < n_tiles; k += 8) {
+        const long o = (long)k * N + row;
+        lse_merge(m, s, st_m[o], st_s[o]);
+        if (st_t) t += st_t[o];
+    }
+    sm[sl][r] = m; ss[sl][r] = s; stt[sl][r] = t;
+    __syncthreads();
+    if (sl == 0 && blockIdx.x * 32 + r < N) {
+        for (int k = 1; k < 8; ++k) { lse_merge(m, s, sm[k][r], ss[k][r]); t += stt[k][r]; }
+        const float lse = m + __logf(s);
+        float loss = lse - C[(long)row * ldc + labels[row]];
+        if (smoothing > 0.f) loss = (1.f - smoothing) * loss + smoothing * (lse - t / V);
+        loss_rows[row] = loss;
+        lse_out[row] = lse;
+    }
+}
+
 // softmax-CE gradient of one logit:  g * (exp(x - lse) - eps / V) - [col == y] * g * (1 - eps),  l2 = lse * log2(e)
 struct SgScalars { float g, sub, hit; };
 __device__ __forceinline__ float sg_value(float x, float l2, bool is_label, const SgScalars& q) {
@@ -400,7 +563,7 @@ __global__ __launch_bounds__(256) void head_dx_reduce_kernel(const float* __rest
 }
 
 // workspace layout (bytes): XA | XT | WT | d X partials
-struct HeadWs { long xa, xt, wt, part, total; int nblk, nkt, max_split; };
+struct HeadWs { long xa, xt, wt, part, stats, total; int nblk, nkt, max_split, ntile; };
 HeadWs head_ws(int N, int V, int D) {
     HeadWs w;
     w.nblk = (N + 31) / 32;
@@ -411,7 +574,9 @@ HeadWs head_ws(int N, int V, int D) {
     w.xt = w.xa + w.nblk * blk;
     w.wt = w.xt + w.nblk * blk;
     w.part = w.wt + w.nkt * blk;
-    w.total = w.part + (long)w.max_split * N * D * 4;
+    w.stats = w.part + (long)w.max_split * N * D * 4;
+    w.ntile = (V + 127) / 128;
+    w.total = w.stats + 3L * w.ntile * N * 4;
     return w;
 }
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -466,6 +631,36 @@ extern "C" int t4r_head_split_logits(void* stream, const void* ws, const float* 
                                         ldc, N, V, alpha, w.nblk, blk_per));
     T4R_LAUNCH_CHECK();
     return 0;
+}
+
+// logits + mean cross-entropy in one pass over the vocabulary: C as t4r_head_split_logits, plus loss_rows [N], lse [N]
+// and (optional) the mean loss -- replaces t4r_softmax_ce_fwd on the materialised logits
+int t4r_mean_launch(hipStream_t stream, const float* x, int n, float* out);      // head.hip
+extern "C" int t4r_head_split_logits_ce(void* stream, void* ws, const float* W, long ldw, float* C, long ldc,
+                                        const long* labels, float* loss_rows, float* lse, float* loss_mean, int N, int V,
+                                        int D, float alpha, float label_smoothing) {
+    hipStream_t st = (hipStream_t)stream;
+    if (N <= 0 || V <= 0) return loss_mean ? t4r_mean_launch(st, loss_rows, 0, loss_mean) : 0;
+    T4R_CHECK_ARG(t4r_head_split_supported(D) && W && C && ws && (!labels || (loss_rows && lse)), "head_split_logits_ce: unsupported width or null pointer");
+    T4R_CHECK_ARG(aligned16(W) && ldw % 4 == 0, "head_split_logits_ce: W must be 16-byte aligned with a pitch multiple of 4");
+    const HeadWs w = head_ws(N, V, D);
+    static int per_env = -1;
+    if (per_env < 0) { const char* e = getenv("T4R_HEAD_ROWS_PER_WG"); per_env = e ? atoi(e) : 12; }
+    const int blk_per = max(1, min(w.nblk, per_env));
+    const int rs = (w.nblk + blk_per - 1) / blk_per;
+    const u32x4* xa = reinterpret_cast<const u32x4*>((const char*)ws + w.xa);
+    float* sm = reinterpret_cast<float*>((char*)ws + w.stats);
+    float* ss = sm + (long)w.ntile * N;
+    float* stt = label_smoothing > 0.f ? ss + (long)w.ntile * N : nullptr;
+    const int vec_ok = aligned16(C) && ldc % 4 == 0;
+    dim3 grid(w.ntile, rs);
+    T4R_NB_SWITCH(D, hipLaunchKernelGGL(head_logits_ce_kernel<NB>, grid, dim3(256), 0, st, xa, W, ldw, C, ldc, N, V, alpha,
+                                        w.nblk, blk_per, vec_ok, sm, ss, stt));
+    if (labels)       // labels == NULL: the product and its per-tile statistics only (timing the dominant kernel alone)
+        hipLaunchKernelGGL(head_ce_finalize_kernel, dim3((N + 31) / 32), dim3(256), 0, st, sm, ss, stt, w.ntile, N, V, C, ldc,
+                           labels, label_smoothing, loss_rows, lse);
+    T4R_LAUNCH_CHECK();
+    return labels && loss_mean ? t4r_mean_launch(st, loss_rows, N, loss_mean) : 0;
 }
 
 // d W[Vc, D] (+)= alpha * dlogits^T @ X;  logits holds the columns [yoff, yoff + Vc) of the [N, V] problem

@@ -144,6 +144,22 @@ def head_split_logits(ws, x, W, alpha=1.0, ldc=None):
     return buf[:, :V]
 
 
+def head_split_logits_ce(ws, x, W, labels, alpha=1.0, label_smoothing=0.0, ldc=None):
+    """logits [N, V] (view of an [N, ldc] buffer) + (mean loss, loss rows, lse) in one pass over the vocabulary"""
+    N, D = x.shape
+    V = W.shape[0]
+    ldc = V if ldc is None else ldc
+    dev = x.device
+    buf = torch.empty((N, ldc), device=dev, dtype=torch.float32)
+    loss_rows = torch.empty(N, device=dev, dtype=torch.float32)
+    lse = torch.empty(N, device=dev, dtype=torch.float32)
+    loss = torch.empty((), device=dev, dtype=torch.float32)
+    call("t4r_head_split_logits_ce", _stream(), ws.data_ptr(), _chk(W, torch.float32), W.stride(0), buf.data_ptr(), ldc,
+         _chk(labels, torch.int64), loss_rows.data_ptr(), lse.data_ptr(), loss.data_ptr(), N, V, D, float(alpha),
+         float(label_smoothing))
+    return buf[:, :V], loss, loss_rows, lse
+
+
 def head_split_dw(ws, logits, lse, labels, grad_out, V, D, out, alpha=1.0, label_smoothing=0.0, accumulate=True, yoff=0):
     N, Vc = logits.shape
     call("t4r_head_split_dw", _stream(), ws.data_ptr(), logits.data_ptr(), logits.stride(0), _chk(lse, torch.float32),

@@ -162,15 +162,18 @@ class _NextItemHeadFn(torch.autograd.Function):
         if neg is None:
             if _head_split_ok(xp, W, N, V):
                 # d_model <= 128: operands cut once, W-stationary logits (csrc/head_split.hip)
+                # (and the softmax statistics reduced inside the product: no second pass over [N, V])
                 hws = ops.head_split_prepare(xp, V)
-                logits = ops.head_split_logits(hws, xp, W.detach(), alpha=1.0 / T, ldc=ops.pad_ld(V))
+                logits, loss, _rows, lse = ops.head_split_logits_ce(hws, xp, W.detach(), labels, alpha=1.0 / T,
+                                                                    label_smoothing=smooth, ldc=ops.pad_ld(V))
             else:
                 logits = ops.gemm(xp, W.detach(), False, True, alpha=1.0 / T, ldc=ops.pad_ld(V))
             tgt, width = labels, V
         else:
             logits = ops.sampled_logits_fwd(xp, labels, W.detach(), neg, mod.sampler.correction_dist, T)
             tgt, width = torch.zeros_like(labels), logits.shape[1]
-        loss, _rows, lse = ops.softmax_ce_fwd(logits, tgt, width, smooth)
+        if hws is None:
+            loss, _rows, lse = ops.softmax_ce_fwd(logits, tgt, width, smooth)
         ctx.task, ctx.neg, ctx.meta = task, neg, (B, L, D, N, V, T, width, smooth)
         ctx.hws = hws
         ctx.save_for_backward(pos, labels, tgt, xr, xp, logits, lse)

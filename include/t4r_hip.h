@@ -175,6 +175,12 @@ int t4r_gemm_softmax_grad_f32(void* stream, int transA, int n_rows, int V, int N
                               const float* grad_out, float label_smoothing, const float* B, long ldb,
                               float* C, long ldc, int splitk, int accumulate);
 
+/* Row threshold of the token-stationary body GEMM (csrc/tok_gemm.hip: t4r_gemm_f32 takes it, in the fp32-accurate
+ * precision modes, for op(A) = A with at least this many rows, N % 32 == 0, K in {32, 64, 96, 128, 256, 384, 512}).
+ * Default 32 768 (T4R_TOK_GEMM_MIN_M); a negative value restores the default. */
+void t4r_set_tok_gemm_min_rows(int rows);
+int t4r_get_tok_gemm_min_rows(void);
+
 /* Materialised tied full-softmax head for d_model 32 / 64 / 96 / 128, fp32-accurate on the BF16 matrix cores
  * (csrc/head_split.hip): the same three contractions as t4r_gemm_f32 (logits) and t4r_gemm_softmax_grad_f32
  * (d X, d W) of model/prediction_task.py:664 and its autograd through CrossEntropyLoss (:446), with the operand

@@ -1181,3 +1181,75 @@ def test_head_split_vocabulary_chunk(ops):
     ops.head_split_dw(ws, chunk, lse, labels, None, V, D, dW, label_smoothing=0.1, accumulate=False, yoff=yoff)
     close(dX, (G @ W[yoff:yoff + Vc].double()).float(), rtol=1e-4, atol=1e-7)
     close(dW, (G.t() @ x.double()).float(), rtol=1e-4, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------
+# token-stationary GEMM of the transformer body (csrc/tok_gemm.hip)
+@pytest.mark.parametrize("M,N,K,tb", [(640, 128, 128, True), (640, 128, 128, False), (1000, 512, 128, True),
+                                      (777, 128, 512, True), (640, 512, 128, False), (530, 128, 512, False),
+                                      (600, 96, 64, True), (512, 64, 256, False), (1500, 32, 32, True)])
+def test_tok_gemm_matches_fp64(ops, M, N, K, tb):
+    """tokens x small weight in the default (fp32-accurate) mode goes through the token-stationary kernel: every
+    supported width / orientation against fp64, at the accuracy of the fp32 matrix-core path"""
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    A = torch.randn(M, K, device=DEV, generator=g)
+    B = torch.randn((N, K) if tb else (K, N), device=DEV, generator=g) * 0.2
+    ref = A.double() @ (B.double().t() if tb else B.double())
+    with ops.tok_gemm_min_rows(512):
+        _tok_gemm_checks(ops, A, B, tb, ref, M, N, g)
+
+
+def _tok_gemm_checks(ops, A, B, tb, ref, M, N, g):
+    out = ops.gemm(A, B, False, tb, alpha=0.7)
+    with ops.precision("fp32"):
+        gen = ops.gemm(A, B, False, tb, alpha=0.7)
+    scale = float(ref.abs().max())
+    e_new, e_gen = float((out.double() - 0.7 * ref).abs().max()) / scale, float((gen.double() - 0.7 * ref).abs().max()) / scale
+    assert e_new < max(2e-6, 3 * e_gen), (e_new, e_gen)
+    # accumulate into an existing C with a padded pitch
+    buf = torch.randn(M, N + 32, device=DEV, generator=g)
+    c0 = buf[:, :N].clone()
+    ops.gemm(A, B, False, tb, out=buf[:, :N], accumulate=True)
+    close(buf[:, :N], (c0.double() + ref).float(), rtol=1e-5, atol=2e-5 * scale)
+
+
+def test_tok_gemm_epilogues_batch_and_dropout_masks(ops):
+    """bias / GELU (+ pre-activation aux) / ReLU / residual epilogues, the batched q-k-v form, and the SAME Philox
+    dropout mask as the general kernel (element index row * N + col): zeros in the same places, survivors equal"""
+    with ops.tok_gemm_min_rows(512):
+        _tok_gemm_epilogue_checks(ops)
+
+
+def _tok_gemm_epilogue_checks(ops):
+    g = torch.Generator(device=DEV).manual_seed(11)
+    M, N, K = 900, 512, 128
+    A = torch.randn(M, K, device=DEV, generator=g)
+    W = torch.randn(N, K, device=DEV, generator=g) * 0.2
+    bias = torch.randn(N, device=DEV, generator=g)
+    pre = (A.double() @ W.double().t() + bias.double()).float()
+    aux = torch.empty((M, N), device=DEV)
+    out = ops.gemm(A, W, False, True, bias=bias, epilogue=ops.EPI_BIAS_GELU, aux=aux)
+    close(aux, pre, atol=2e-5)
+    close(out, torch.nn.functional.gelu(pre), atol=2e-5)
+    close(ops.gemm(A, W, False, True, bias=bias, epilogue=ops.EPI_BIAS_RELU), torch.relu(pre), atol=2e-5)
+    close(ops.gemm(A, W, False, True, bias=bias, epilogue=ops.EPI_BIAS), pre, atol=2e-5)
+    drop = (0.3, 1234, ops.dropout_ctr_hi(5, 2, ops.SITE_FF_ACT))
+    d_new = ops.gemm(A, W, False, True, bias=bias, epilogue=ops.EPI_BIAS_GELU, aux=aux, drop=drop)
+    with ops.precision("fp32"):
+        d_gen = ops.gemm(A, W, False, True, bias=bias, epilogue=ops.EPI_BIAS_GELU, aux=aux, drop=drop)
+    assert torch.equal(d_new == 0, d_gen == 0) and 0.25 < float((d_new == 0).float().mean()) < 0.35
+    close(d_new, d_gen, atol=3e-5)
+    res = torch.randn(M, N, device=DEV, generator=g)
+    r_new = ops.gemm(A, W, False, True, bias=bias, epilogue=ops.EPI_BIAS_RESID, aux=res, drop=drop)
+    with ops.precision("fp32"):
+        r_gen = ops.gemm(A, W, False, True, bias=bias, epilogue=ops.EPI_BIAS_RESID, aux=res, drop=drop)
+    close(r_new, r_gen, atol=3e-5)
+    # batched: three adjacent [K, N] weights, one launch (the q / k / v projections of xlnet_layer.hip)
+    T, D = 768, 128
+    h = torch.randn(T, D, device=DEV, generator=g)
+    w3 = torch.randn(3, D, D, device=DEV, generator=g) * 0.2
+    qkv = torch.empty(3, T, D, device=DEV)
+    ops.call("t4r_gemm_f32", ops._stream(), 0, 0, T, D, D, 1.0, h.data_ptr(), D, w3.data_ptr(), D, qkv.data_ptr(), D,
+             None, 0, None, 0, 1, 0, 3, 0, D * D, T * D, 0.0, 0, 0)
+    for z in range(3):
+        close(qkv[z], (h.double() @ w3[z].double()).float(), atol=2e-5)

@@ -49,6 +49,8 @@ _SIGS = {
     "t4r_set_precision": ("v", "i"),
     "t4r_get_precision": ("i", ""),
     "t4r_gemm_softmax_grad_f32": ("i", "piiiif" + "plpppf" + "plpl" + "ii"),
+    "t4r_set_tok_gemm_min_rows": ("v", "i"),
+    "t4r_get_tok_gemm_min_rows": ("i", ""),
     "t4r_head_split_supported": ("i", "i"),
     "t4r_head_split_ws_bytes": ("l", "iii"),
     "t4r_head_split_prepare": ("i", "ppl" + "iii" + "p"),

@@ -49,6 +49,7 @@ extern "C" int t4r_get_precision(void) {
     return m;
 }
 int t4r_gemm_half_dispatch(const GemmParams& p, int batch, int ta, int tb, int big, int prec, hipStream_t stream);
+int t4r_tok_gemm_try(const GemmParams& p, int batch, int ta, int tb, hipStream_t stream);     // tok_gemm.hip
 
 // shapes on which the split form beat the fp32 matrix cores (tools/gemm_bench.py --prec, profiles/r02_*)
 static bool auto_split(const GemmParams& p, bool ta, bool tb) {
@@ -59,6 +60,15 @@ static bool auto_split(const GemmParams& p, bool ta, bool tb) {
 
 template <bool TA, bool TB>
 static int launch_layout(GemmParams& p, int batch, int splitk_req, hipStream_t stream) {
+    // tokens x small weight in an fp32-accurate mode: the token-stationary kernel (operands cut once, tok_gemm.hip)
+    if (!TA && (splitk_req == 0 || splitk_req == 1)) {
+        const int mode = t4r_get_precision();
+        if (mode == 4 || mode == 1) {
+            p.splitk = 1;
+            const int rc = t4r_tok_gemm_try(p, batch, TA, TB, stream);
+            if (rc) return rc < 0 ? rc : 0;
+        }
+    }
     // tile choice: prefer 128x128; drop to 64-wide tiles when the grid would not fill 256 CUs
     auto nblk = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * batch; };
     // Measured on MI355X (tools/gemm_bench.py, profiles/r01_b_gemm_tile_sweep.txt): on the layer shapes

@@ -311,18 +311,19 @@ __global__ __launch_bounds__(256) void head_logits_ce_kernel(const u32x4* __rest
     flush_stats((b_end - 1 - b_begin) & 1, b_end - 1);
 }
 
-// per row: merge the column tiles' partial triples -> lse, loss  (32 rows x 8 tile slices per workgroup)
+// per row: merge the column tiles' partial triples -> lse, loss  (32 rows x 32 tile slices per workgroup: a row's ~800
+// partials are read by 32 threads, adjacent threads read adjacent rows)
 //   loss_row = lse - (1 - eps) * logit[y] - eps / V * sum_j logit[j]      (torch CrossEntropyLoss, label smoothing eps)
-__global__ __launch_bounds__(256) void head_ce_finalize_kernel(const float* __restrict__ st_m, const float* __restrict__ st_s,
-                                                                const float* __restrict__ st_t, int n_tiles, int N, int V,
-                                                                const float* __restrict__ C, long ldc,
-                                                                const long* __restrict__ labels, float smoothing,
-                                                                float* __restrict__ loss_rows, float* __restrict__ lse_out) {
-    __shared__ float sm[8][32], ss[8][32], stt[8][32];
+__global__ __launch_bounds__(1024) void head_ce_finalize_kernel(const float* __restrict__ st_m, const float* __restrict__ st_s,
+                                                                 const float* __restrict__ st_t, int n_tiles, int N, int V,
+                                                                 const float* __restrict__ C, long ldc,
+                                                                 const long* __restrict__ labels, float smoothing,
+                                                                 float* __restrict__ loss_rows, float* __restrict__ lse_out) {
+    __shared__ float sm[32][33], ss[32][33], stt[32][33];
     const int r = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int row = min(blockIdx.x * 32 + r, N - 1);
     float m = -INFINITY, s = 0.f, t = 0.f;
-    for (int k = sl; k < n_tiles; k += 8) {
+    for (int k = sl; k < n_tiles; k += 32) {
         const long o = (long)k * N + row;
         lse_merge(m, s, st_m[o], st_s[o]);
         if (st_t) t += st_t[o];
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(256) void head_ce_finalize_kernel(const float* __re
     sm[sl][r] = m; ss[sl][r] = s; stt[sl][r] = t;
     __syncthreads();
     if (sl == 0 && blockIdx.x * 32 + r < N) {
-        for (int k = 1; k < 8; ++k) { lse_merge(m, s, sm[k][r], ss[k][r]); t += stt[k][r]; }
+        for (int k = 1; k < 32; ++k) { lse_merge(m, s, sm[k][r], ss[k][r]); t += stt[k][r]; }
         const float lse = m + __logf(s);
         float loss = lse - C[(long)row * ldc + labels[row]];
         if (smoothing > 0.f) loss = (1.f - smoothing) * loss + smoothing * (lse - t / V);
@@ -657,7 +658,7 @@ extern "C" int t4r_head_split_logits_ce(void* stream, void* ws, const float* W, 
     T4R_NB_SWITCH(D, hipLaunchKernelGGL(head_logits_ce_kernel<NB>, grid, dim3(256), 0, st, xa, W, ldw, C, ldc, N, V, alpha,
                                         w.nblk, blk_per, vec_ok, sm, ss, stt));
     if (labels)       // labels == NULL: the product and its per-tile statistics only (timing the dominant kernel alone)
-        hipLaunchKernelGGL(head_ce_finalize_kernel, dim3((N + 31) / 32), dim3(256), 0, st, sm, ss, stt, w.ntile, N, V, C, ldc,
+        hipLaunchKernelGGL(head_ce_finalize_kernel, dim3((N + 31) / 32), dim3(1024), 0, st, sm, ss, stt, w.ntile, N, V, C, ldc,
                            labels, label_smoothing, loss_rows, lse);
     T4R_LAUNCH_CHECK();
     return labels && loss_mean ? t4r_mean_launch(st, loss_rows, N, loss_mean) : 0;

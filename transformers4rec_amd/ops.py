@@ -120,6 +120,23 @@ def gemm_softmax_grad(logits, lse, labels, grad_out, V, b, trans_a, alpha=1.0, l
     return out
 
 
+class tok_gemm_min_rows:
+    """context manager: row threshold of the token-stationary body GEMM (csrc/tok_gemm.hip; default 32 768)"""
+
+    def __init__(self, rows):
+        self.rows = int(rows)
+
+    def __enter__(self):
+        lib = _lib.load()
+        self.prev = lib.t4r_get_tok_gemm_min_rows()
+        lib.t4r_set_tok_gemm_min_rows(self.rows)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.load().t4r_set_tok_gemm_min_rows(self.prev)
+        return False
+
+
 # ---- materialised head for d_model <= 128 (csrc/head_split.hip)
 def head_split_supported(D):
     return bool(_lib.load().t4r_head_split_supported(int(D)))
@@ -710,7 +727,8 @@ def rank_of_target(x, W, labels, alpha=1.0, chunk=1024):
         n = xc.shape[0]
         pos = yc.to(torch.int32)
         wy = gather_rows(W, pos, n)
-        tgt = gemm(xc, wy, False, True, alpha=alpha).diagonal().contiguous()
+        with precision("fp32"):         # the rank epilogue always runs on the fp32 matrix cores: same arithmetic here
+            tgt = gemm(xc, wy, False, True, alpha=alpha).diagonal().contiguous()
         call("t4r_rank_of_target_f32", _stream(), n, V, D, float(alpha), _chk(xc, torch.float32), xc.stride(0),
              _chk(W, torch.float32), W.stride(0), _chk(tgt, torch.float32), _chk(yc, torch.int64),
              rank[s0: s0 + chunk].data_ptr())

@@ -318,11 +318,12 @@ long t4r_xlnet_layer_bwd_ws_floats(int B, int L, int D, int n_head, int dropout)
 int t4r_xlnet_layer_fwd(void* stream, const float* h, const float* pos_emb, const float* const* params,
                         float* ws, float* h_out, int B, int L, int D, int n_head, float ln_eps,
                         float drop_p, unsigned long long seed, unsigned long long offset, int layer_idx,
-                        const int* key_len);
+                        const int* key_len, const float* pos_emb_b);
 int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* pos_emb, const float* const* params,
                         float* const* grads, const float* ws, float* bws, const float* dh_out,
                         float* dh_in, int B, int L, int D, int n_head, float ln_eps, float drop_p,
-                        unsigned long long seed, unsigned long long offset, int layer_idx, const int* key_len);
+                        unsigned long long seed, unsigned long long offset, int layer_idx, const int* key_len,
+                        const float* pos_emb_b);
 
 /* ----------------------------------------------------------------------------------------
  * a18-a21  next-item head

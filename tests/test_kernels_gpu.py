@@ -617,6 +617,16 @@ def test_xlnet_layer_dropout_fwd_bwd(ops, B, L, D, n):
     close(dh, hr.grad.reshape(B * L, D), rtol=1e-4, atol=3e-4)
     for k, gt in zip(ORDER, grads):
         close(gt.reshape(-1), pr[k].grad.reshape(-1), rtol=1e-4, atol=8e-4, msg=lambda mm, k=k: f"{k}: {mm}")
+    # the dropped positional encoding handed in by the caller (drawn once per forward, shared by the layers):
+    # bit-identical to the layer drawing its own copy
+    pe_b = ops.xlnet_pos_emb_dropout(pos, B, p_drop, seed, offset)
+    out2, ws2 = ops.xlnet_layer_fwd(cu(h).view(B * L, D), pos, params, B, L, n, 0.03, pos_emb_b=pe_b, **kw)
+    assert torch.equal(out2, out)
+    grads2 = [torch.zeros_like(t) for t in params]
+    dh2 = ops.xlnet_layer_bwd(cu(h).view(B * L, D), pos, params, grads2, ws2, cu(dout).view(B * L, D), B, L, n, 0.03,
+                              pos_emb_b=pe_b, **kw)
+    close(dh2, dh, rtol=0, atol=1e-6)
+    close(grads2[ORDER.index("r")], grads[ORDER.index("r")], rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("N,V,D,eps", [(37, 1001, 64, 0.0), (130, 5003, 128, 0.1)])

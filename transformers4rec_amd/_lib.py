@@ -69,8 +69,8 @@ _SIGS = {
     "t4r_xlnet_attn_bwd": ("i", "p" * 17 + "iiii" + "ifQQ" + "p"),
     "t4r_xlnet_layer_ws_floats": ("l", "iiiii"),
     "t4r_xlnet_layer_bwd_ws_floats": ("l", "iiiii"),
-    "t4r_xlnet_layer_fwd": ("i", "pppppp" + "iiiif" + "fQQi" + "p"),
-    "t4r_xlnet_layer_bwd": ("i", "ppppppppp" + "iiiif" + "fQQi" + "p"),
+    "t4r_xlnet_layer_fwd": ("i", "pppppp" + "iiiif" + "fQQi" + "pp"),
+    "t4r_xlnet_layer_bwd": ("i", "ppppppppp" + "iiiif" + "fQQi" + "pp"),
     "t4r_softmax_ce_fwd": ("i", "pppppp" + "iilf"),
     "t4r_softmax_ce_bwd": ("i", "pppppp" + "iilf"),
     "t4r_linear_softmax_ce_chunk_floats": ("l", "ii"),

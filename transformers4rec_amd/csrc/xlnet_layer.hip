@@ -119,7 +119,7 @@ extern "C" int t4r_xlnet_layer_fwd(void* stream, const float* h, const float* po
                                    const float* const* params, float* ws, float* h_out, int B, int L,
                                    int D, int n_head, float ln_eps, float drop_p,
                                    unsigned long long seed, unsigned long long offset, int layer_idx,
-                                   const int* key_len) {
+                                   const int* key_len, const float* pos_emb_b) {
     if (B == 0) return 0;
     T4R_CHECK_ARG(D % n_head == 0 && D % 4 == 0, "xlnet_layer: d_model must divide by n_head and 4");
     T4R_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "xlnet_layer: dropout p in [0, 1)");
@@ -144,11 +144,16 @@ extern "C" int t4r_xlnet_layer_fwd(void* stream, const float* h, const float* po
     if (drop) {
         // dropout(pos_emb expanded over the batch) @ r : per-session positional keys (HF :1142-1143
         // drops the batch-expanded pos_emb, so every session gets its own mask).
-        float* pe_b = w.pe_b;
         // HF applies that dropout ONCE per forward, before the layer loop (:1143), and hands the same
-        // dropped tensor to every layer: the mask is keyed by (offset, layer 255, SITE_POS), not by the layer
-        RUN(t4r_dropout(stream, pos_emb, pe_b, nullptr, (long)B * 2 * L * D, 2L * L * D, drop_p, seed,
-                        ctr_hi(offset, 255, SITE_POS)));
+        // dropped tensor to every layer: the mask is keyed by (offset, layer 255, SITE_POS), not by the layer.
+        // pos_emb_b: that tensor [B, 2L, D], made once by the caller (t4r_dropout with this key) and shared by all
+        // layers; NULL: this layer makes its own copy in its workspace (same values, one launch per layer)
+        const float* pe_b = pos_emb_b;
+        if (!pe_b) {
+            RUN(t4r_dropout(stream, pos_emb, w.pe_b, nullptr, (long)B * 2 * L * D, 2L * L * D, drop_p, seed,
+                            ctr_hi(offset, 255, SITE_POS)));
+            pe_b = w.pe_b;
+        }
         RUN(t4r_gemm_launch(st, 0, 0, B * 2 * L, D, D, 1.f, pe_b, D, params[P_R], D, w.kr, D, nullptr,
                             EPI_NONE, nullptr, 0, 1, 0, 1, 0, 0, 0, nullptr));
     } else {
@@ -215,7 +220,8 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
                                    const float* const* params, float* const* grads, const float* ws,
                                    float* bws, const float* dh_out, float* dh_in, int B, int L, int D,
                                    int n_head, float ln_eps, float drop_p, unsigned long long seed,
-                                   unsigned long long offset, int layer_idx, const int* key_len) {
+                                   unsigned long long offset, int layer_idx, const int* key_len,
+                                   const float* pos_emb_b) {
     if (B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const int T = B * L, dh = D / n_head;
@@ -297,7 +303,7 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
                            C(SITE_PROB), key_len));
     // k_r = pos_emb(_b) @ r  ->  d r += pos_emb(_b)^T @ d k_r
     if (drop) {
-        RUN(t4r_gemm_launch(wg(), 1, 0, D, D, B * 2 * L, 1.f, w.pe_b, D, dkr, D, grads[P_R], D, nullptr,
+        RUN(t4r_gemm_launch(wg(), 1, 0, D, D, B * 2 * L, 1.f, pos_emb_b ? pos_emb_b : w.pe_b, D, dkr, D, grads[P_R], D, nullptr,
                             EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
     } else {
         RUN(t4r_gemm_launch(wg(), 1, 0, D, D, 2 * L, 1.f, pos_emb, D, dkr, D, grads[P_R], D, nullptr,

@@ -560,8 +560,14 @@ def xlnet_layer_bwd_ws_floats(B, L, D, n_head, dropout=False):
     return _lib.load().t4r_xlnet_layer_bwd_ws_floats(B, L, D, n_head, int(bool(dropout)))
 
 
+def xlnet_pos_emb_dropout(pos_emb, B, p, seed, offset):
+    """dropout(pos_emb expanded over the batch) [B, 2L, D] with the key every layer uses (HF modeling_xlnet.py:1143
+    drops it once per forward): pass the result as `pos_emb_b` to xlnet_layer_fwd / _bwd of all layers"""
+    return dropout(pos_emb.contiguous().view(-1), p, seed, dropout_ctr_hi(offset, 255, SITE_POS), n_total=B * pos_emb.numel())
+
+
 def xlnet_layer_fwd(h, pos_emb, params, B, L, n_head, eps, ws=None, drop_p=0.0, seed=0, offset=0,
-                    layer_idx=0, key_len=None):
+                    layer_idx=0, key_len=None, pos_emb_b=None):
     """h [B*L, D]; params: sequence of 15 tensors in XLNET_PARAM_ORDER.  -> (h_out, ws)"""
     D = h.shape[-1]
     if ws is None:
@@ -571,12 +577,12 @@ def xlnet_layer_fwd(h, pos_emb, params, B, L, n_head, eps, ws=None, drop_p=0.0, 
     parr, _keep = ptr_array([_chk(p, torch.float32, "xlnet param") for p in params])
     call("t4r_xlnet_layer_fwd", _stream(), _chk(h, torch.float32), _chk(pos_emb, torch.float32), parr,
          ws.data_ptr(), out.data_ptr(), B, L, D, n_head, float(eps), float(drop_p), int(seed),
-         int(offset), int(layer_idx), _p(key_len, torch.int32))
+         int(offset), int(layer_idx), _p(key_len, torch.int32), _p(pos_emb_b, torch.float32))
     return out, ws
 
 
 def xlnet_layer_bwd(h, pos_emb, params, grads, ws, dh_out, B, L, n_head, eps, bws=None, drop_p=0.0,
-                    seed=0, offset=0, layer_idx=0, key_len=None):
+                    seed=0, offset=0, layer_idx=0, key_len=None, pos_emb_b=None):
     D = h.shape[-1]
     if bws is None:
         bws = torch.empty(xlnet_layer_bwd_ws_floats(B, L, D, n_head, drop_p > 0), device=h.device,
@@ -586,7 +592,7 @@ def xlnet_layer_bwd(h, pos_emb, params, grads, ws, dh_out, B, L, n_head, eps, bw
     garr, _k2 = ptr_array([_chk(g, torch.float32) for g in grads])
     call("t4r_xlnet_layer_bwd", _stream(), _chk(h), _chk(pos_emb), parr, garr, _chk(ws),
          bws.data_ptr(), _chk(dh_out), dh_in.data_ptr(), B, L, D, n_head, float(eps), float(drop_p),
-         int(seed), int(offset), int(layer_idx), _p(key_len, torch.int32))
+         int(seed), int(offset), int(layer_idx), _p(key_len, torch.int32), _p(pos_emb_b, torch.float32))
     return dh_in
 
 

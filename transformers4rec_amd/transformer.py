@@ -135,14 +135,15 @@ def relative_positional_encoding(L, D):
 
 class _XLNetLayerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, h, anchor, layer, pos_emb, n_head, eps, drop, key_len=None):
+    def forward(ctx, h, anchor, layer, pos_emb, n_head, eps, drop, key_len=None, pos_emb_b=None):
         B, L, D = h.shape
         h2 = h.contiguous().view(B * L, D)
         params = [p.detach() for p in layer.ordered_params()]
         p, seed, offset, idx = drop
         out, ws = ops.xlnet_layer_fwd(h2, pos_emb, params, B, L, n_head, eps, drop_p=p, seed=seed,
-                                      offset=offset, layer_idx=idx, key_len=key_len)
+                                      offset=offset, layer_idx=idx, key_len=key_len, pos_emb_b=pos_emb_b)
         ctx.layer, ctx.pos_emb, ctx.cfg, ctx.drop, ctx.key_len = layer, pos_emb, (B, L, D, n_head, eps), drop, key_len
+        ctx.pos_emb_b = pos_emb_b
         ctx.save_for_backward(h2, ws)
         return out.view(B, L, D)
 
@@ -155,8 +156,8 @@ class _XLNetLayerFn(torch.autograd.Function):
         grads = [_grad_buf(q) for q in plist]
         dh = ops.xlnet_layer_bwd(h2, ctx.pos_emb, [q.detach() for q in plist], grads, ws,
                                  dout.contiguous().view(B * L, D), B, L, n_head, eps, drop_p=p, seed=seed,
-                                 offset=offset, layer_idx=idx, key_len=ctx.key_len)
-        return dh.view(B, L, D), None, None, None, None, None, None, None
+                                 offset=offset, layer_idx=idx, key_len=ctx.key_len, pos_emb_b=ctx.pos_emb_b)
+        return dh.view(B, L, D), None, None, None, None, None, None, None, None
 
 
 class _DropoutFn(torch.autograd.Function):
@@ -218,9 +219,11 @@ class XLNetModel(SeedMixin, nn.Module):
         h = inputs_embeds
         if p > 0:
             h = _DropoutFn.apply(h, p, self.seed, ops.dropout_ctr_hi(offset, 255, ops.SITE_INPUT))
+        # dropout(pos_emb) is drawn once per forward and shared by the layers (HF :1143)
+        pos_b = ops.xlnet_pos_emb_dropout(pos, B, p, self.seed, offset) if p > 0 else None
         for i, layer in enumerate(self.layer):
             h = _XLNetLayerFn.apply(h, layer.rel_attn.q, layer, pos, cfg.n_head, cfg.layer_norm_eps,
-                                    (p, self.seed, offset, i), key_len)
+                                    (p, self.seed, offset, i), key_len, pos_b)
         if p > 0:
             h = _DropoutFn.apply(h, p, self.seed, ops.dropout_ctr_hi(offset, 255, ops.SITE_FINAL))
         return (h,)

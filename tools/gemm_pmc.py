@@ -23,3 +23,13 @@ run(NM, V, D, False, True)            # head logits
 run(V, D, NM, True, False)            # head dW
 run(NM, D, V, False, False, splitk=-1)  # head dX
 run(T, 4 * D, D, False, True)         # ff1
+# the materialised head for d_model <= 128 (csrc/head_split.hip): prepare, logits + CE statistics, d X, d W
+x = torch.randn(NM, D, device="cuda"); W = torch.randn(V, D, device="cuda") * 0.3
+labels = torch.randint(0, V, (NM,), device="cuda"); g = torch.tensor(1.0, device="cuda")
+dW = torch.zeros(V, D, device="cuda")
+for _ in range(3):
+    ws = ops.head_split_prepare(x, V)
+    logits, loss, rows, lse = ops.head_split_logits_ce(ws, x, W, labels, ldc=ops.pad_ld(V))
+    ops.head_split_dx(ws, logits, lse, labels, g, V, W)
+    ops.head_split_dw(ws, logits, lse, labels, g, V, D, dW)
+torch.cuda.synchronize()

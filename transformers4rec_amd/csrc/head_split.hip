@@ -30,6 +30,7 @@ constexpr float kLog2e = 1.4426950408889634f;
 // native vector type for everything that is staged: assigning HIP's uint4 struct between address spaces becomes a
 // memcpy that keeps the staging array in scratch memory
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
@@ -188,22 +189,46 @@ __device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2
     s = s * __builtin_amdgcn_exp2f((m - ref) * kLog2e) + s2 * __builtin_amdgcn_exp2f((m2 - ref) * kLog2e);
     m = mn;
 }
+// 4 x 4 transpose between the four lanes of a quad and four registers: on return x[g] holds what lane (quad base + g)
+// had in x[t], t = this lane's position in the quad (two DPP exchange steps).
+__device__ __forceinline__ void quad_transpose4(float (&x)[4], int t) {
+    const bool odd = t & 1, hi = t & 2;
+    {   // exchange with lane t ^ 1: the odd lane gives its x[0], x[2], the even lane its x[1], x[3]
+        const float s0 = odd ? x[0] : x[1], s1 = odd ? x[2] : x[3];
+        const float r0 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s0), 0xB1, 0xf, 0xf, true));
+        const float r1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s1), 0xB1, 0xf, 0xf, true));
+        if (odd) { x[0] = r0; x[2] = r1; } else { x[1] = r0; x[3] = r1; }
+    }
+    {   // exchange with lane t ^ 2
+        const float s0 = hi ? x[0] : x[2], s1 = hi ? x[1] : x[3];
+        const float r0 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s0), 0x4E, 0xf, 0xf, true));
+        const float r1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s1), 0x4E, 0xf, 0xf, true));
+        if (hi) { x[0] = r0; x[1] = r1; } else { x[2] = r0; x[3] = r1; }
+    }
+}
+
 template <int NB>
 __global__ __launch_bounds__(256) void head_logits_ce_kernel(const u32x4* __restrict__ XA, const float* __restrict__ W,
                                                               long ldw, float* __restrict__ C, long ldc, int N, int V,
                                                               float alpha, int nblk, int blk_per, int vec_ok,
                                                               float* __restrict__ st_m, float* __restrict__ st_s,
-                                                              float* __restrict__ st_t) {
+                                                              float* __restrict__ st_t, int n_tile, int n_split) {
     constexpr int KS = 2 * NB, CH = 4 * NB;
     constexpr int BLK = 12 * 32 * NB;
     constexpr int SN = (BLK + 255) / 256;
     __shared__ u32x4 lds[2][BLK];
     __shared__ float4 sst[2][4][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, khalf = lane >> 5;
-    const int b_begin = blockIdx.y * blk_per, b_end = min(nblk, b_begin + blk_per);
+    // XCD-aware order (workgroup b runs on XCD b % 8): the row splits of ONE column tile sit on one XCD, eight
+    // dispatch slots apart, so its 64 KB of W come into that L2 once (row-major order: FETCH_SIZE 450 MB per launch,
+    // every split re-read its tile through the fabric)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tile = (slot / n_split) * 8 + xcd, rsi = slot % n_split;
+    if (tile >= n_tile) return;
+    const int b_begin = rsi * blk_per, b_end = min(nblk, b_begin + blk_per);
     if (b_begin >= b_end) return;
-    const int vbase = blockIdx.x * 128 + 32 * wave;
-    const bool tail_tile = blockIdx.x * 128 + 128 > V;
+    const int vbase = tile * 128 + 32 * wave;
+    const bool tail_tile = tile * 128 + 128 > V;
 
     u32x4 Wf[KS][3];
     {
@@ -240,7 +265,7 @@ __global__ __launch_bounds__(256) void head_logits_ce_kernel(const u32x4* __rest
             }
             const int row = b * 32 + tid;
             if (row < N) {
-                const long o = (long)blockIdx.x * N + row;
+                const long o = (long)tile * N + row;
                 st_m[o] = a.x;
                 st_s[o] = a.y;
                 if (st_t) st_t[o] = a.z;
@@ -273,16 +298,33 @@ __global__ __launch_bounds__(256) void head_logits_ce_kernel(const u32x4* __rest
         for (int r = 0; r < 16; ++r) v[r] = alpha * acc[r];
         const int row = b * 32 + l32;
         const int c0 = vbase + 4 * khalf;
-        if (row < N) {
-            float* cr = C + (long)row * ldc + c0;
-            if (vec_ok && !tail_tile) {
+        if (vec_ok && !tail_tile) {
+            // full-line stores: the quad's four rows x four column groups are transposed through DPP, so that one store
+            // instruction covers EIGHT lanes = all 128 bytes of a row (storing the accumulator layout as it is writes
+            // 32 bytes per row and instruction: FETCH_SIZE showed a third of the logits lines read back for merging)
+            const int t = l32 & 3;
+            float w[4][4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(cr + 8 * g) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
-            } else {
+            for (int i = 0; i < 4; ++i) {
+                float x[4] = {v[i], v[4 + i], v[8 + i], v[12 + i]};
+                quad_transpose4(x, t);
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (c0 + 8 * (r >> 2) + (r & 3) < V) cr[8 * (r >> 2) + (r & 3)] = v[r];
+                for (int g = 0; g < 4; ++g) w[g][i] = x[g];
             }
+            const int rq = b * 32 + (l32 & ~3);
+            float* cq = C + (long)rq * ldc + vbase + 8 * t + 4 * khalf;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (rq + g < N) {
+                    // streaming store: the 1.1 GB of logits must not push the X plane blocks out of L2
+                    const f32x4 o = {w[g][0], w[g][1], w[g][2], w[g][3]};
+                    __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(cq + (long)g * ldc));
+                }
+        } else if (row < N) {
+            float* cr = C + (long)row * ldc + c0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (c0 + 8 * (r >> 2) + (r & 3) < V) cr[8 * (r >> 2) + (r & 3)] = v[r];
         }
         float t = 0.f;
         if (tail_tile) {
@@ -458,15 +500,19 @@ __global__ __launch_bounds__(256) void head_dx_split_kernel(const float* __restr
                                                              const float* __restrict__ lse, const long* __restrict__ labels,
                                                              const float* __restrict__ gout, const u32x4* __restrict__ WT,
                                                              float* __restrict__ part, int N, int Vc, int V, int yoff,
-                                                             float smooth, float alpha, int nkt, int kt_per) {
+                                                             float smooth, float alpha, int nkt, int kt_per, int row_tiles) {
     constexpr int D = 32 * NB;
     constexpr int BLK = 12 * 32 * NB;
     constexpr int SN = (BLK + 255) / 256;
     __shared__ u32x4 lds[2][BLK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, khalf = lane >> 5;
-    const int kt_begin = blockIdx.y * kt_per, kt_end = min(nkt, kt_begin + kt_per);
+    // XCD-aware order: the row tiles that share one vocabulary split (one slice of the W^T planes) run on one XCD
+    // (row-major order: FETCH_SIZE 1.85 GB per launch = the logits + the 77 MB of planes once per XCD)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int rt = slot % row_tiles, split = (slot / row_tiles) * 8 + xcd;
+    const int kt_begin = split * kt_per, kt_end = min(nkt, kt_begin + kt_per);
     if (kt_begin >= kt_end) return;
-    const int row = blockIdx.x * 128 + 32 * wave + l32, rc = min(row, N - 1);
+    const int row = rt * 128 + 32 * wave + l32, rc = min(row, N - 1);
     const float* lp = logits + (long)rc * ld;
     const float l2 = lse[rc] * kLog2e;
     const int y = (int)(labels[rc] - yoff);
@@ -537,8 +583,8 @@ __global__ __launch_bounds__(256) void head_dx_split_kernel(const float* __restr
         s_store(buf ^ 1);
         __syncthreads();
     }
-    float* pp = part + (long)blockIdx.y * N * D;
-    const int r0 = blockIdx.x * 128 + 32 * wave + 4 * khalf;
+    float* pp = part + (long)split * N * D;
+    const int r0 = rt * 128 + 32 * wave + 4 * khalf;
 #pragma unroll
     for (int j = 0; j < NB; ++j)
 #pragma unroll
@@ -654,9 +700,9 @@ extern "C" int t4r_head_split_logits_ce(void* stream, void* ws, const float* W, 
     float* ss = sm + (long)w.ntile * N;
     float* stt = label_smoothing > 0.f ? ss + (long)w.ntile * N : nullptr;
     const int vec_ok = aligned16(C) && ldc % 4 == 0;
-    dim3 grid(w.ntile, rs);
+    dim3 grid(8 * ((w.ntile + 7) / 8) * rs);
     T4R_NB_SWITCH(D, hipLaunchKernelGGL(head_logits_ce_kernel<NB>, grid, dim3(256), 0, st, xa, W, ldw, C, ldc, N, V, alpha,
-                                        w.nblk, blk_per, vec_ok, sm, ss, stt));
+                                        w.nblk, blk_per, vec_ok, sm, ss, stt, w.ntile, rs));
     if (labels)       // labels == NULL: the product and its per-tile statistics only (timing the dominant kernel alone)
         hipLaunchKernelGGL(head_ce_finalize_kernel, dim3((N + 31) / 32), dim3(1024), 0, st, sm, ss, stt, w.ntile, N, V, C, ldc,
                            labels, label_smoothing, loss_rows, lse);
@@ -698,8 +744,9 @@ extern "C" int t4r_head_split_dx(void* stream, void* ws, const float* logits, lo
     int splits = max(1, min(min(w.max_split, nkt / 8), target / row_tiles));
     const int kt_per = (nkt + splits - 1) / splits;
     splits = (nkt + kt_per - 1) / kt_per;          // every split owns at least one k-tile
-    T4R_NB_SWITCH(D, hipLaunchKernelGGL(head_dx_split_kernel<NB>, dim3(row_tiles, splits), dim3(256), 0, st, logits, ld, lse,
-                                        labels, grad_out, wt, part, N, Vc, V, yoff, label_smoothing, alpha, nkt, kt_per));
+    T4R_NB_SWITCH(D, hipLaunchKernelGGL(head_dx_split_kernel<NB>, dim3(row_tiles * 8 * ((splits + 7) / 8)), dim3(256), 0, st,
+                                        logits, ld, lse, labels, grad_out, wt, part, N, Vc, V, yoff, label_smoothing, alpha,
+                                        nkt, kt_per, row_tiles));
     const long nd4 = (long)N * D / 4;
     hipLaunchKernelGGL(head_dx_reduce_kernel, dim3((unsigned)((nd4 + 255) / 256)), dim3(256), 0, st, part, splits, nd4, D / 4,
                        dX, lddx, accumulate);

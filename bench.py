@@ -334,7 +334,15 @@ def main():
             tr.get_rng_state(model))
     t_pre = time.perf_counter()
     n_pre = 0
-    while time.perf_counter() - t_pre < args.preheat_seconds:
+    go = torch.ones(1, device=device, dtype=torch.int32)
+    while True:
+        # N > 1: every rank must run the SAME number of pre-heat steps (each step holds collectives), so the ranks agree
+        # on continuing: stop as soon as any rank's clock says so
+        go.fill_(1 if time.perf_counter() - t_pre < args.preheat_seconds else 0)
+        if world > 1:
+            dist.all_reduce(go, op=dist.ReduceOp.MIN)
+        if int(go.item()) == 0:
+            break
         train_step(0)
         torch.cuda.synchronize()
         n_pre += 1

@@ -307,13 +307,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world == 1 and args.gpus > 1:
         raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # T4R_BENCH_BACKEND=gloo (with T4R_BENCH_SHARE_GPU=1: all ranks on one device) exercises the N > 1 code path of this
+    # file on a single-GPU box; the measured configuration is always nccl (= RCCL), one rank per GPU
+    backend = os.environ.get("T4R_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("T4R_BENCH_SHARE_GPU", "0") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     tr, schema, model, dense, tables, opt = build(device, args.dropout)
     from transformers4rec_amd import ops

@@ -895,7 +895,8 @@ def test_fp32_accurate_split_mode_matches_reference(mode):
         close(named[k].grad, ref, rtol=2e-4, atol=1e-4, msg=lambda m, k=k: f"{k}: {m}")
 
 
-def test_head_split_path_is_taken_and_agrees_with_the_general_gemm(monkeypatch):
+@pytest.mark.parametrize("smooth,temp", [(0.0, 1.0), (0.1, 0.7)])
+def test_head_split_path_is_taken_and_agrees_with_the_general_gemm(monkeypatch, smooth, temp):
     """the d_model <= 128 head (csrc/head_split.hip) replaces the general GEMM for >= 2 GFLOP products in the
     fp32-accurate modes: same loss, predictions and gradients as the general path on the same model and batch"""
     import transformers4rec_amd as tr
@@ -905,7 +906,9 @@ def test_head_split_path_is_taken_and_agrees_with_the_general_gemm(monkeypatch):
     V, L, D, B = 30_000, 20, 128, 128
     schema = tr.session_schema(V, L)
     inputs = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=L, masking="mlm", embedding_dim_default=D)
-    model = tr.XLNetConfig.build(D, 4, 2, total_seq_length=L).to_torch_model(inputs, tr.NextItemPredictionTask(weight_tying=True)).to("cuda")
+    task = tr.NextItemPredictionTask(weight_tying=True, softmax_temperature=temp,
+                                     loss=torch.nn.CrossEntropyLoss(label_smoothing=smooth))
+    model = tr.XLNetConfig.build(D, 4, 2, total_seq_length=L).to_torch_model(inputs, task).to("cuda")
     x = tr.random_data_from_schema(schema, B, L, seed=1, device="cuda")
     taken = []
     real = ops.head_split_logits_ce

@@ -63,7 +63,8 @@ def setup_data_parallel(tr, model, dense, tables, world):
     sparse = None
     hook = None
     if world > 1 or os.environ.get("T4R_BENCH_SPARSE", "0") == "1":
-        sparse = tr.SparseRowExchange()
+        # full-softmax head: only the lookup scatter is row-sparse, B * L rows on every rank (weak scaling)
+        sparse = tr.SparseRowExchange(equal_sizes=True)
         sparse.attach(*[p for _, p, _ in tables.entries])
     reducer = tr.GradReducer(dense.grad, tables.grad if tables is not None else None, sparse=sparse)
     if world > 1 and sparse is not None:

@@ -194,6 +194,37 @@ def test_row_sparse_exchange_equals_dense_reduce():
     assert ret["bytes"] > 0
 
 
+def _equal_sizes_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from transformers4rec_amd.distributed import GradReducer, SparseRowExchange
+
+    V, D, n = 30, 4, 12
+    g = torch.Generator().manual_seed(7 + rank)
+    table = torch.nn.Parameter(torch.zeros(V, D))
+    table.grad = torch.zeros(V, D)
+    ids, rows = torch.randint(0, V, (n,), generator=g), torch.randn(n, D, generator=g)
+    sp = SparseRowExchange(apply_fn=_cpu_apply, equal_sizes=True).attach(table)
+    sp.add_rows(table, ids, rows, padding_idx=0)
+    GradReducer(torch.zeros(3), table.grad, sparse=sp).reduce_all()
+    ret[rank] = dict(grad=table.grad.clone(), ids=ids, rows=rows)
+    dist.destroy_process_group()
+
+
+def test_sparse_exchange_equal_sizes_skips_the_size_gather():
+    """equal_sizes=True (every rank brings the same number of rows): same result as the dense sum, no size exchange"""
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_equal_sizes_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    want = torch.zeros(30, 4)
+    for r in range(world):
+        keep = ret[r]["ids"] != 0
+        want.index_add_(0, ret[r]["ids"][keep], ret[r]["rows"][keep])
+    for r in range(world):
+        assert torch.allclose(ret[r]["grad"], want, atol=1e-6)
+    assert torch.equal(ret[0]["grad"], ret[1]["grad"])
+
+
 def test_sparse_exchange_single_process_is_local_apply():
     from transformers4rec_amd.distributed import GradReducer, SparseRowExchange
 

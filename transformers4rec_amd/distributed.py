@@ -39,7 +39,11 @@ class SparseRowExchange:
     called by GradReducer.reduce_all after the dense reductions -- makes every rank apply every rank's
     rows.  grad_of(param) -> the buffer to add into (default: param.grad, created if missing)."""
 
-    def __init__(self, group=None, apply_fn=None, grad_of=None):
+    def __init__(self, group=None, apply_fn=None, grad_of=None, equal_sizes=False):
+        # equal_sizes: every rank contributes the same number of rows to every exchange (the lookup scatter of equal
+        # per-rank batches: B * L rows) -- the per-step size all-gather and its host synchronisation are skipped.
+        # Leave False whenever the counts can differ (a sampled head's label rows).
+        self.equal_sizes = equal_sizes
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.apply_fn = apply_fn or _hip_apply
@@ -92,11 +96,13 @@ class SparseRowExchange:
             if self.world == 1:
                 self.apply_fn(tgt, ids, rows, pad)
                 continue
-            n = torch.tensor([ids.numel()], device=ids.device, dtype=torch.int64)
-            sizes = [torch.zeros_like(n) for _ in range(self.world)]
-            dist.all_gather(sizes, n, group=self.group)
-            sizes = [int(s.item()) for s in sizes]
-            nmax = max(sizes)
+            if self.equal_sizes:
+                nmax = ids.numel()
+            else:
+                n = torch.tensor([ids.numel()], device=ids.device, dtype=torch.int64)
+                sizes = [torch.zeros_like(n) for _ in range(self.world)]
+                dist.all_gather(sizes, n, group=self.group)
+                nmax = max(int(s.item()) for s in sizes)
             D = rows.shape[1]
             if ids.numel() < nmax:      # ranks with fewer rows (label counts differ) pad with ignored ids
                 fill = pad if pad >= 0 else tgt.shape[0]           # out-of-range id: carries no gradient

@@ -241,7 +241,12 @@ int t4r_tok_gemm_try(const GemmParams& p, int batch, int ta, int tb, hipStream_t
     static int on = -1;
     if (on < 0) { const char* e = getenv("T4R_TOK_GEMM"); on = e ? atoi(e) : 1; }
     if (!on || ta || p.sg_lse || p.rk_thr || p.splitk > 1) return 0;
-    if (p.M < t4r_get_tok_gemm_min_rows() || p.N % 32 || p.N < 32 || p.K % 32 || p.K < 32 || p.K > 512) return 0;
+    // below the row threshold only the wide, short products without an epilogue (K <= 128, N >= 512: d ff = d ffout @ W2
+    // at 20 480 tokens) -- the one body shape of configs[1] where this kernel was faster INSIDE the step (56 vs 81 us)
+    static int wide = -1;
+    if (wide < 0) { const char* e = getenv("T4R_TOK_GEMM_WIDE"); wide = e ? atoi(e) : 1; }
+    const bool wide_short = wide && p.K <= 128 && p.N >= 512 && p.epilogue == EPI_NONE && p.M >= 8192;
+    if ((p.M < t4r_get_tok_gemm_min_rows() && !wide_short) || p.N % 32 || p.N < 32 || p.K % 32 || p.K < 32 || p.K > 512) return 0;
     if (p.K > 128 && p.K % 128) return 0;
     if (!p.vecA || (tb && !p.vecB)) return 0;
     const int nbk = p.K > 128 ? 4 : p.K / 32, KC = p.K > 128 ? p.K / 128 : 1;

@@ -2,7 +2,11 @@
 """Benchmark of the session-sequence hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL over xGMI)
+  (N > 1: one rank per GPU, RCCL over xGMI.  Either launched by `python -m torch.distributed.run
+   --nproc-per-node N bench.py --gpus N ...` (RANK / LOCAL_RANK / WORLD_SIZE in the environment), or called
+   plainly as `python bench.py --gpus N ...`: with WORLD_SIZE unset the script re-executes itself under
+   torch.distributed.run on 127.0.0.1 and passes rank 0's JSON line through -- the reference's launch contract,
+   docs/source/multi_gpu_train.md:27-40)
 
 A "step" = one full training pass of the hot path over one synthetic batch already resident in
 HBM: masking -> embedding gather -> 4-layer XLNet -> next-item head (tied full softmax) ->
@@ -289,6 +293,107 @@ def recall_probe(device, dropout, train_steps=200, lockstep_steps=600):
     return res
 
 
+# --------------------------------------------------------------------------------------------- launch
+def _free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n, argv=None):
+    """`python bench.py --gpus N` without a launcher: re-execute this file as N ranks of ONE node under
+    torch.distributed.run (rendezvous on 127.0.0.1: the container hostname may not resolve).  stdout / stderr are
+    inherited, so rank 0's JSON line is this process's output; returns the launcher's exit code."""
+    import subprocess
+
+    env = os.environ.copy()
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this platform (RCCL)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)]
+    cmd += list(sys.argv[1:] if argv is None else argv)
+    return subprocess.call(cmd, env=env)
+
+
+class _StubModel(torch.nn.Module):
+    """T4R_BENCH_STUB=1 only: a CPU stand-in with the HIP model's gradient plumbing (a tied table whose lookup
+    gradient goes through the row-sparse sink, a dense block carrying the head-backward hook), so that the LAUNCH
+    and data-parallel wiring of this file -- self_launch, setup_data_parallel, make_train_step, timed_region, the
+    JSON contract -- can be run end to end on a box without GPUs (tests/test_bench_launch_cpu.py).  Its output is
+    marked `"stub": true` and is not a measurement."""
+
+    def __init__(self, V=64, D=8):
+        super().__init__()
+        self.table = torch.nn.Parameter(torch.randn(V, D) * 0.1)
+        self.transformer_block = torch.nn.Linear(D, D)
+
+    def forward(self, x, training=True):
+        ids = x["item_id"]
+        emb = self.table.detach()[ids].requires_grad_()            # lookups are not tracked by autograd, as on HIP
+        h = self.transformer_block(emb)
+        labels = ids.reshape(-1)
+        loss = torch.nn.functional.cross_entropy(h.reshape(-1, h.shape[-1]) @ self.table.t(), labels)
+
+        def scatter(g):
+            sink = getattr(self.table, "_t4r_sparse_sink", None)
+            rows = g.reshape(-1, g.shape[-1])
+            if sink is not None:
+                sink.add_rows(self.table, labels, rows, padding_idx=0)
+            else:
+                self.table.grad.index_add_(0, labels, rows)
+        emb.register_hook(scatter)
+        return {"loss": loss, "labels": labels}
+
+
+def _stub_main(args, world, rank):
+    """the N-rank flow of main() on CPU tensors over gloo (see _StubModel)"""
+    import torch.distributed as dist
+
+    import transformers4rec_amd as tr
+    from transformers4rec_amd.optim import FlatParams
+
+    if world > 1:
+        dist.init_process_group("gloo")
+    torch.manual_seed(0)
+    model = _StubModel()
+    tables = FlatParams([("table", model.table)])
+    dense = FlatParams([(n, p) for n, p in model.transformer_block.named_parameters()])
+
+    def cpu_apply(d_table, ids, rows, padding_idx):
+        keep = ids != padding_idx
+        d_table.index_add_(0, ids[keep], rows[keep])
+
+    sparse = tr.SparseRowExchange(apply_fn=cpu_apply, equal_sizes=True).attach(model.table)
+    reducer = tr.GradReducer(dense.grad, tables.grad, sparse=sparse)
+    if world > 1:
+        tr.head_backward_hook(model, reducer.reduce_tables_async)
+
+    class _Sgd:
+        def step(self, grad_scale=1.0):
+            for f in (dense, tables):
+                f.data.add_(f.grad, alpha=-0.05 * grad_scale)
+                f.grad.zero_()
+
+    g = torch.Generator().manual_seed(1000 + rank)
+    batches = [{"item_id": torch.randint(1, 64, (16, 5), generator=g)} for _ in range(4)]
+    step = make_train_step(model, batches, reducer, _Sgd())
+    dt, out, n_lab = timed_region(step, args.warmup, args.steps, world, "cpu")
+    if rank == 0:
+        print(json.dumps({"metric": "launch-plumbing stub (no GPU, not a measurement)", "stub": True,
+                          "value": round(16 * world * args.steps / dt, 1), "unit": "sessions/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "synthetic", "config": {"workload": "stub", "global_batch": 16 * world,
+                                                          "parallelism": f"dp{world}",
+                                                          "final_loss": round(float(out["loss"].detach()), 4),
+                                                          "label_rows": n_lab}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 # --------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -306,8 +411,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # called without a launcher: become the launcher (one rank per GPU of this node)
+        raise SystemExit(self_launch(args.gpus))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
+    if os.environ.get("T4R_BENCH_STUB", "0") == "1":
+        return _stub_main(args, world, rank)
     # T4R_BENCH_BACKEND=gloo (with T4R_BENCH_SHARE_GPU=1: all ranks on one device) exercises the N > 1 code path of this
     # file on a single-GPU box; the measured configuration is always nccl (= RCCL), one rank per GPU
     backend = os.environ.get("T4R_BENCH_BACKEND", "nccl")

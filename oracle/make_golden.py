@@ -327,6 +327,185 @@ def main():
     #    (examples/t4rec_paper_experiments/t4r_paper_repro/transf_exp_main.py:71-91):
     #    pre = StochasticSwapNoise(schema), post = [TabularDropout, "layer-norm"]
     prepost_cases(tr, V, L, d, nh)
+    round3_cases(tr)
+
+
+# ------------------------------------------------------------------------------------------ round 3
+def json_schema(path, names=None):
+    """the reference's schema.json (tensorflow-metadata JSON form read by merlin_standard_lib.Schema.from_json,
+    merlin_standard_lib/schema/schema.py) -> the stand-in Schema container"""
+    import json
+
+    with open(path) as f:
+        js = json.load(f)
+    cols = []
+    for ft in js["feature"]:
+        if names is not None and ft["name"] not in names:
+            continue
+        tags = [Tags(t) if t in {x.value for x in Tags} else t for t in ft.get("annotation", {}).get("tag", [])]
+        dom = ft.get("intDomain")
+        vc = ft.get("valueCount")
+        cols.append(ColumnSchema(
+            ft["name"], tags=tags,
+            int_domain=_IntDomain(int(dom.get("min", 0)), int(dom["max"]), dom.get("isCategorical", False)) if dom else None,
+            value_count=_ValueCount(int(vc.get("min", 0)), int(vc["max"])) if vc else None))
+    return Schema(cols)
+
+
+def ranking_metric_case(tr):
+    """L: the reference's ranking metrics (torch/ranking_metric.py) on random scores, per row and aggregated
+    over two update() calls -- pins the rank-based restatement (transformers4rec_amd/ranking_metric.py)"""
+    from transformers4rec.torch import ranking_metric as rm
+    from transformers4rec.torch.utils import torch_utils
+
+    g = torch.Generator().manual_seed(110)
+    N, V, ks = 96, 57, [1, 5, 10, 20]
+    scores = torch.randn(N, V, generator=g)
+    labels = torch.randint(0, V, (N,), generator=g)
+    labels[:8] = scores[:8].argmax(-1)                      # some rank-0 rows
+    d = {"in/scores": scores.numpy(), "in/labels": labels.numpy()}
+    onehot = torch_utils.tranform_label_to_onehot(labels, V)
+    for cls in (rm.NDCGAt, rm.AvgPrecisionAt, rm.RecallAt, rm.PrecisionAt, rm.DCGAt):
+        m = cls(top_ks=ks, labels_onehot=True)
+        name = rs.camelcase_to_snakecase(cls.__name__)
+        d[f"out/rows/{name}"] = m._metric(ks, scores, onehot).numpy()
+        m.reset()
+        m.update(scores[:40], labels[:40])
+        m.update(scores[40:], labels[40:])
+        d[f"out/mean/{name}"] = m.compute().numpy()
+    save("ranking_metrics", d, top_ks=ks)
+
+
+def c1_cases(tr):
+    """M: BASELINE configs[0] (C1): the first 100 sessions of the reference's own testing data
+    (transformers4rec/data/testing/{data.parquet,schema.json}), item id only, padded / truncated to 20 by the
+    reference's pad_batch, XLNet d_model 64 / 2 layers / 4 heads, MLM, tied next-item head: train (loss, logits,
+    labels, every gradient), eval and inference."""
+    import pyarrow.parquet as pq
+    from transformers4rec.torch.utils.padding import pad_batch
+
+    root = os.path.join(rs.REFERENCE_ROOT, "transformers4rec", "data", "testing")
+    L, d, nh, nl, B = 20, 64, 4, 2, 100
+    schema = json_schema(os.path.join(root, "schema.json"), names=["item_id/list"])
+    col = pq.read_table(os.path.join(root, "data.parquet"), columns=["item_id/list"]).column(0).combine_chunks()
+    col = col.slice(0, B)
+    offs = torch.from_numpy(np.asarray(col.offsets, dtype=np.int64))
+    vals = torch.from_numpy(col.values.to_numpy(zero_copy_only=False)[int(offs[0]): int(offs[-1])].astype(np.int64))
+    offs = offs - offs[0]
+    x = pad_batch({"item_id/list__values": vals, "item_id/list__offsets": offs}, {"item_id/list": L})
+    assert x["item_id/list"].shape == (B, L)
+    torch.manual_seed(120)
+    inputs = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=L, masking="mlm",
+                                                    embedding_dim_default=d)
+    cfg = tr.XLNetConfig.build(d_model=d, n_head=nh, n_layer=nl, total_seq_length=L, dropout=0.0)
+    model = cfg.to_torch_model(inputs, tr.NextItemPredictionTask(weight_tying=True))
+    reinit(model, 121)
+    V = model.heads[0].body[0].categorical_module.item_embedding_table.weight.shape[0]
+    meta = dict(n_head=nh, d_model=d, n_layer=nl, eps=0.03, L=L, V=V, rows=B)
+    torch.manual_seed(122)
+    g = torch.Generator().manual_seed(123)
+    probe_cols = torch.unique(torch.cat([x["item_id/list"].reshape(-1), torch.randint(0, V, (192,), generator=g)]))
+
+    def shrink(dd):
+        """[N, V] score matrices and the [V, d] table / table gradient do not fit a small fixture: keep the columns
+        (rows) of every item id of the batch + 192 random ones exactly, and fp64 reductions over the rest"""
+        pr = dd.pop("out/predictions")
+        dd["sel/cols"] = probe_cols.numpy()
+        dd["out/predictions_sel"] = pr[:, probe_cols.numpy()]
+        dd["out/predictions_lse"] = torch.logsumexp(torch.from_numpy(pr).double(), -1).numpy()
+        dd["out/predictions_rowsum"] = pr.astype(np.float64).sum(-1)
+        dd["out/predictions_argmax"] = pr.argmax(-1)
+        for k in list(dd):
+            if k.startswith("g/") and dd[k].shape == (V, d):
+                gtab = dd.pop(k)
+                dd["gsel/" + k[2:]] = gtab[probe_cols.numpy()]
+                dd["gsum/" + k[2:]] = gtab.astype(np.float64).sum(0)
+                dd["gabs/" + k[2:]] = np.abs(gtab.astype(np.float64)).sum(0)
+        return dd
+
+    dd = shrink(run(model, x, True, False, True, with_params=False))
+    # the wire form of the same rows (what data.parquet holds, untruncated) and the schema.json entry of the column:
+    # the GPU test writes them back to a parquet / json pair and feeds them through ParquetSessionLoader + from_json
+    dd["in_ragged/item_id/list__values"], dd["in_ragged/item_id/list__offsets"] = vals.numpy(), offs.numpy()
+    import json
+
+    with open(os.path.join(root, "schema.json")) as f:
+        ent = [ft for ft in json.load(f)["feature"] if ft["name"] == "item_id/list"]
+    dd["meta/schema_json"] = np.asarray(json.dumps({"feature": ent}))
+    # parameters: everything but the [V, d] table is stored; the table (13 MB of noise) is stored as its RECIPE --
+    # reinit() draws every parameter from Generator(reinit_seed) in named_parameters order -- which the test
+    # replays and checks against the stored parameters before trusting the table it produces
+    seen = set()
+    for k, v in model.state_dict().items():
+        if v.data_ptr() in seen:
+            continue
+        seen.add(v.data_ptr())
+        if tuple(v.shape) == (V, d):
+            dd["sel/table_rows"] = v.detach().numpy()[probe_cols.numpy()].copy()
+            dd["meta/table_key"] = np.asarray(k)
+        else:
+            dd["p/" + k] = v.detach().numpy().copy()
+    named = list(model.named_parameters())
+    dd["meta/param_order"] = np.asarray([n for n, _ in named])
+    dd["meta/param_shapes"] = np.asarray([",".join(str(int(z)) for z in p.shape) for _, p in named])
+    dd["meta/reinit_seed"] = np.asarray(121)
+    save("c1_yoochoose_train", dd, **meta)
+    save("c1_yoochoose_eval", shrink(run(model, x, False, True, False, with_params=False)), **meta)
+    save("c1_yoochoose_infer", shrink(run(model, x, False, False, False, with_params=False)), **meta)
+
+
+def embedding_bag_cases(tr):
+    """N: EmbeddingFeatures' EmbeddingBag branch (features/embedding.py:86-93, 229-240, 260-273): per-row bags as
+    2-D [B, K] ids, ragged (values, offsets) bags and 1-D [B] ids, combiners mean and sum; outputs and the table
+    gradients of  sum_f <out_f, c_f>  with fixed random c_f."""
+    from transformers4rec.torch.features.embedding import EmbeddingFeatures, FeatureConfig, TableConfig
+
+    g = torch.Generator().manual_seed(130)
+    B = 37
+    for comb in ("mean", "sum"):
+        cfgs = {"genres": FeatureConfig(TableConfig(50, 24, name="genres", combiner=comb)),
+                "tags": FeatureConfig(TableConfig(400, 64, name="tags", combiner=comb)),
+                "country": FeatureConfig(TableConfig(19, 8, name="country", combiner=comb))}
+        torch.manual_seed(131)
+        mod = EmbeddingFeatures(cfgs)
+        with torch.no_grad():
+            for p in mod.parameters():
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+        genres = torch.randint(0, 50, (B, 5), generator=g)             # fixed-width bags, padding id 0 included
+        lens = torch.randint(0, 9, (B,), generator=g)                   # ragged bags, some EMPTY
+        lens[0], lens[B - 1] = 0, 3
+        offs = torch.cat([torch.zeros(1, dtype=torch.int64), lens.cumsum(0)])[:-1]
+        tvals = torch.randint(0, 400, (int(lens.sum()),), generator=g)
+        country = torch.randint(0, 19, (B,), generator=g)
+        # 2-D and 1-D ids run through the UNMODIFIED module.  The (values, offsets) tuple branch (:229-236) cannot: it
+        # calls `self.embedding_tables[name](values, offsets[:, 0])`, but EmbeddingBagWrapper.forward(self, input,
+        # **kwargs) (:260-273) accepts no positional offsets -> TypeError in the reference as shipped (and no reference
+        # test covers it).  The fixture follows the evident intent of that line: torch.nn.EmbeddingBag.forward(table,
+        # values.squeeze(-1), offsets[:, 0]) on the module's own table.
+        out = mod({"genres": genres, "country": country})
+        try:
+            mod({"tags": (tvals.unsqueeze(-1), offs.unsqueeze(-1))})
+            raise AssertionError("the reference's tuple branch ran: regenerate this fixture through it")
+        except TypeError:
+            pass
+        out["tags"] = torch.nn.EmbeddingBag.forward(mod.embedding_tables["tags"], tvals.unsqueeze(-1).squeeze(-1),
+                                                    offs.unsqueeze(-1)[:, 0])
+        c = {k: torch.randn(v.shape, generator=g) for k, v in out.items()}
+        sum((out[k] * c[k]).sum() for k in out).backward()
+        d = {"in/genres": genres.numpy(), "in/tags_values": tvals.numpy(), "in/tags_offsets": offs.numpy(),
+             "in/country": country.numpy()}
+        for k in out:
+            d["out/" + k] = out[k].detach().numpy()
+            d["c/" + k] = c[k].numpy()
+            d["p/" + k] = mod.embedding_tables[k].weight.detach().numpy().copy()
+            d["g/" + k] = mod.embedding_tables[k].weight.grad.numpy().copy()
+        save(f"embedding_bag_{comb}", d, combiner=comb, B=B)
+
+
+def round3_cases(tr):
+    ranking_metric_case(tr)
+    c1_cases(tr)
+    embedding_bag_cases(tr)
 
 
 class SwapRecorder:
@@ -431,4 +610,8 @@ def prepost_cases(tr, V, L, d, nh):
 
 
 if __name__ == "__main__":
-    main()
+    if "--round3" in sys.argv:          # only the fixtures added in round 3 (the others are unchanged)
+        torch.set_num_threads(4)
+        round3_cases(rs.import_reference())
+    else:
+        main()

@@ -1,0 +1,49 @@
+"""`python bench.py --gpus N` must be launchable as the driver calls it: without
+torch.distributed.run around it, the script re-executes itself as N ranks on 127.0.0.1 and prints ONE JSON
+line from rank 0.  Run here end to end on CPU: T4R_BENCH_STUB=1 swaps the HIP model for bench._StubModel
+(same gradient plumbing: tied table + row-sparse sink + head-backward hook) and RCCL for gloo; the launcher,
+`setup`/`make_train_step`/`timed_region` and the JSON contract are bench.py's own code."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(argv, extra_env=None):
+    env = os.environ.copy()
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(T4R_BENCH_STUB="1", OMP_NUM_THREADS="1")
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True,
+                          text=True, timeout=300)
+
+
+def _json_lines(stdout):
+    return [json.loads(l) for l in stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_self_launches_two_ranks():
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout                      # rank 0 only
+    res = lines[0]
+    assert res["stub"] is True and res["n_gpus"] == 2 and res["steps"] == 3 and res["warmup"] == 1
+    assert res["config"]["global_batch"] == 32 and res["config"]["parallelism"] == "dp2"
+    assert res["scaling"] == "weak" and res["higher_is_better"] is True and res["value"] > 0
+    assert res["config"]["label_rows"] == 3 * 16 * 5
+
+
+def test_bench_single_rank_needs_no_launcher():
+    r = _run(["--gpus", "1", "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    (res,) = _json_lines(r.stdout)
+    assert res["n_gpus"] == 1 and res["config"]["parallelism"] == "dp1"
+
+
+def test_bench_rejects_a_launcher_world_size_mismatch():
+    r = _run(["--gpus", "4", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)

@@ -258,3 +258,95 @@ def test_gpt2_bert_block_golden(name, arch):
     logits = O.head_logits(xr, sd[gu.CAT + "item_id.weight"])
     torch.testing.assert_close(logits, gu.t(d["out/predictions"]), **TOL)
     torch.testing.assert_close(O.cross_entropy(logits, y), gu.t(d["out/loss"]), **TOL)
+
+
+# ----------------------------------------------------------------------------- round 3 fixtures
+def test_ranking_metrics_golden():
+    """the reference's NDCG / AvgPrecision / Recall / Precision / DCG @k (ranking_metric.py) per row and averaged over
+    two update() calls, against (a) the oracle's general restatement and (b) the product's rank-based forms"""
+    from transformers4rec_amd import ranking_metric as RM
+
+    d = gu.load("ranking_metrics")
+    scores, labels, ks = gu.t(d["in/scores"]), gu.t(d["in/labels"]), [int(k) for k in d["meta/top_ks"]]
+    fns = {"ndcg_at": O.ndcg_at_k, "avg_precision_at": O.avg_precision_at_k, "recall_at": O.recall_at_k,
+           "precision_at": O.precision_at_k, "dcg_at": O.dcg_at_k}
+    # rank of the target: number of items scored strictly higher (no ties in random floats)
+    ranks = (scores > scores.gather(1, labels[:, None])).sum(1)
+    assert int((ranks == 0).sum()) >= 8
+    for cls in (RM.NDCGAt, RM.AvgPrecisionAt, RM.RecallAt, RM.PrecisionAt, RM.DCGAt):
+        m = cls(top_ks=ks, labels_onehot=True)
+        ref_rows = gu.t(d[f"out/rows/{m.name}"])
+        for j, k in enumerate(ks):
+            torch.testing.assert_close(fns[m.name](scores, labels, k), ref_rows[:, j], rtol=1e-6, atol=1e-6)
+        got = m.from_ranks(ranks)
+        torch.testing.assert_close(got, ref_rows, rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(got.mean(0), gu.t(d[f"out/mean/{m.name}"]), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("comb", ["mean", "sum"])
+def test_embedding_bag_golden(comb):
+    d = gu.load(f"embedding_bag_{comb}")
+    tabs = {k: gu.t(d["p/" + k]).clone().requires_grad_() for k in ("genres", "tags", "country")}
+    out = {"genres": O.embedding_bag(tabs["genres"], ids=gu.t(d["in/genres"]), combiner=comb),
+           "country": O.embedding_bag(tabs["country"], ids=gu.t(d["in/country"]), combiner=comb),
+           "tags": O.embedding_bag(tabs["tags"], values=gu.t(d["in/tags_values"]), offsets=gu.t(d["in/tags_offsets"]),
+                                   combiner=comb)}
+    for k in out:
+        torch.testing.assert_close(out[k], gu.t(d["out/" + k]), **TOL)
+    sum((out[k] * gu.t(d["c/" + k])).sum() for k in out).backward()
+    for k in out:
+        torch.testing.assert_close(tabs[k].grad, gu.t(d["g/" + k]), **TOL)
+    # empty bags give zero rows (torch.nn.EmbeddingBag semantics the fixture froze)
+    assert float(out["tags"][0].abs().sum()) == 0.0
+
+
+def _c1_check_scores(d, logits):
+    cols = gu.t(d["sel/cols"])
+    torch.testing.assert_close(logits[:, cols], gu.t(d["out/predictions_sel"]), **TOL)
+    torch.testing.assert_close(torch.logsumexp(logits.double(), -1), gu.t(d["out/predictions_lse"]), rtol=1e-6, atol=1e-5)
+    torch.testing.assert_close(logits.double().sum(-1), gu.t(d["out/predictions_rowsum"]), rtol=1e-5, atol=2e-2)
+    assert torch.equal(logits.argmax(-1), gu.t(d["out/predictions_argmax"]))
+
+
+def test_c1_yoochoose_golden():
+    """BASELINE configs[0]: first 100 sessions of the reference's testing data, XLNet d 64 x 2 x 4 heads, MLM, tied"""
+    d = gu.c1_load()
+    item = "item_id/list"
+    x = {item: gu.t(d["in/" + item])}
+    # the padded batch IS pad_batch of the wire form the parquet holds
+    assert torch.equal(O.pad_ragged(gu.t(d["in_ragged/" + item + "__values"]), gu.t(d["in_ragged/" + item + "__offsets"]),
+                                    int(d["meta/L"])), x[item])
+    j2 = gu.t(d["draw/j2"])
+    m, lab = O.mlm_targets_train(x[item], gu.t(d["draw/bern"]), gu.t(d["draw/j1"]), lambda _: j2)
+    assert torch.equal(m, gu.t(d["out/mask_schema"])) and torch.equal(lab, gu.t(d["out/masked_targets"]))
+    p = gu.oracle_params(d, requires_grad=True)
+    cfg = dict(n_head=int(d["meta/n_head"]), eps=float(d["meta/eps"]), item=item, masking="mlm")
+    out = O.session_forward(p, cfg, x, m, lab, True, False)
+    torch.testing.assert_close(out["inputs_embeds"], gu.t(d["out/inputs_embeds"]), **TOL)
+    torch.testing.assert_close(out["hidden"], gu.t(d["out/hidden"]), **TOL)
+    assert torch.equal(out["labels"], gu.t(d["out/labels"]))
+    _c1_check_scores(d, out["logits"].detach())
+    torch.testing.assert_close(out["loss"], gu.t(d["out/loss"]), **TOL)
+    out["loss"].backward()
+    g = gu.section(d, "g/")
+    gt = p["tables"][item].grad
+    key = str(d["meta/table_key"])
+    torch.testing.assert_close(gt[gu.t(d["sel/cols"])], gu.t(d["gsel/" + key]), **TOL)
+    torch.testing.assert_close(gt.double().sum(0), gu.t(d["gsum/" + key]), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gt.double().abs().sum(0), gu.t(d["gabs/" + key]), rtol=1e-5, atol=1e-5)
+    for i, lp in enumerate(p["layers"]):
+        for ok, rk in (("q", "rel_attn.q"), ("r", "rel_attn.r"), ("w1", "ff.layer_1.weight"), ("b2", "ff.layer_2.bias"),
+                       ("ff_ln_w", "ff.layer_norm.weight")):
+            torch.testing.assert_close(lp[ok].grad, g[gu.XL + f"{i}." + rk], **TOL)
+    # eval (last item) and inference paths of the same model
+    e = gu.c1_load("c1_yoochoose_eval")
+    m, lab = O.mlm_targets_eval(x[item], True)
+    assert torch.equal(m, gu.t(e["out/mask_schema"])) and torch.equal(lab, gu.t(e["out/masked_targets"]))
+    pe = gu.oracle_params(d)
+    oe = O.session_forward(pe, cfg, x, m, lab, False, True)
+    _c1_check_scores(e, oe["logits"])
+    torch.testing.assert_close(oe["loss"], gu.t(e["out/loss"]), **TOL)
+    f = gu.c1_load("c1_yoochoose_infer")
+    m, lab = O.mlm_targets_inference(x[item])
+    oi = O.session_forward(pe, cfg, x, m, lab, False, False)
+    _c1_check_scores(f, oi["logits"])

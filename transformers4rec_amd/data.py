@@ -77,11 +77,14 @@ class ParquetSessionLoader:
     paths: parquet file(s); schema: optional `tr.Schema` (selects the columns); columns: explicit
     column list otherwise.  shuffle: new device permutation per epoch (seed + epoch).
     with_targets: yield `(inputs, None)` tuples, the shape `Model.fit` iterates
-    (torch/model/base.py:669-718)."""
+    (torch/model/base.py:669-718).  drop_uneven (with global_size > 1): True = equal shards, trailing
+    n % world rows dropped with a warning (training); False = every row kept, shard sizes differ by at most
+    one (evaluation loaders)."""
 
     def __init__(self, paths, batch_size: int, max_sequence_length: int, schema=None, columns=None,
                  device="cuda", shuffle=False, drop_last=False, global_size: Optional[int] = None,
-                 global_rank: Optional[int] = None, seed: int = 0, with_targets: bool = False):
+                 global_rank: Optional[int] = None, seed: int = 0, with_targets: bool = False,
+                 drop_uneven: bool = True):
         if batch_size <= 0 or max_sequence_length <= 0:
             raise ValueError("batch_size and max_sequence_length must be positive")
         if schema is not None and columns is None:
@@ -92,13 +95,24 @@ class ParquetSessionLoader:
         if global_size is not None and global_size > 1:
             if global_rank is None or not 0 <= global_rank < global_size:
                 raise ValueError("global_rank must be in [0, global_size)")
-            # every rank gets the SAME number of rows (floor(n / world); the n % world trailing rows are
-            # dropped): the data-parallel step is one blocking all-reduce per batch, so ranks with
-            # different batch counts would deadlock at the end of the epoch
             per = n // global_size
             if per == 0:
                 raise ValueError(f"{n} rows cannot be sharded over {global_size} ranks")
-            lo, hi = global_rank * per, (global_rank + 1) * per
+            if drop_uneven:
+                # TRAINING: every rank gets the SAME number of rows (floor(n / world); the n % world trailing
+                # rows are dropped): the data-parallel step is one blocking all-reduce per batch, so ranks with
+                # different batch counts would deadlock at the end of the epoch
+                lo, hi = global_rank * per, (global_rank + 1) * per
+                if n % global_size:
+                    import warnings
+
+                    warnings.warn(f"ParquetSessionLoader: {n % global_size} trailing row(s) of {n} dropped so that the "
+                                  f"{global_size} ranks see equal shards (drop_uneven=False keeps them, for evaluation)")
+            else:
+                # EVALUATION (no per-batch collective: the metric sums are reduced once, in compute_metrics): balanced
+                # contiguous shards covering every row, the first n % world ranks take one row more
+                lo = global_rank * per + min(global_rank, n % global_size)
+                hi = lo + per + (1 if global_rank < n % global_size else 0)
         self.device = torch.device(device)
         self._batch_size = batch_size
         self.batch_size = batch_size

@@ -18,6 +18,15 @@ state_dict name, same objects, no copy) -- so gradients land in the reference pa
 and an optimizer built on `model.parameters()` trains as before.  The shadow is built lazily on
 the first forward and is not registered as a sub-module.
 
+Data parallelism: the HIP backward writes parameter gradients straight into `.grad` (the autograd
+functions return None for parameters), so AccumulateGrad hooks never fire and torch DDP -- what HF
+Trainer wraps the reference model in (torch/trainer.py:131-161) -- would never see them: with
+`find_unused_parameters=True` every HIP parameter is marked unused and the replicas diverge silently.
+A training forward under `torch.distributed` world_size > 1 therefore RAISES until the caller has
+wired a gradient exchange that reads `.grad` after backward and says so: `sync_gradients(model)`
+(one flat all-reduce of every `.grad`, averaged: DDP's semantics) between `backward()` and
+`optimizer.step()`, or `distributed.GradReducer` / `SparseRowExchange` + `allow_data_parallel()`.
+
 There is no CPU fallback: a CPU tensor raises _lib.T4RHipError like the rest of the package.
 Configurations off the hot path (PLM/RTD masking, custom projection blocks, pretrained-embedding
 modules, transformer bodies other than XLNet / GPT-2 / BERT) raise NotImplementedError when the
@@ -349,6 +358,57 @@ def drop_shadow(mod):
     mod.__dict__.pop(_SHADOW, None)
 
 
+_DP = {"acknowledged": False}
+
+
+def allow_data_parallel(flag=True):
+    """The caller exchanges the `.grad` buffers itself after backward (distributed.GradReducer /
+    SparseRowExchange, or `sync_gradients`): lifts the world_size > 1 guard of the drop-in forward."""
+    _DP["acknowledged"] = bool(flag)
+
+
+def sync_gradients(model, group=None):
+    """Data-parallel gradient exchange for a drop-in model: ONE flat all-reduce over every parameter's
+    `.grad` (missing gradients count as zero), divided by the world size -- what torch DDP computes for the
+    reference.  Call between `loss.backward()` and `optimizer.step()` on every rank.
+    Works on any backend / device (gloo on CPU in tests, RCCL on the GPUs)."""
+    import torch.distributed as dist
+
+    allow_data_parallel(True)
+    if not (dist.is_available() and dist.is_initialized()):
+        return model
+    world = dist.get_world_size(group)
+    if world == 1:
+        return model
+    params = [p for p in model.parameters() if p.requires_grad]
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.mul_(1.0 / world)
+    o = 0
+    for p in params:
+        n = p.numel()
+        p.grad.copy_(flat[o:o + n].view_as(p.grad))
+        o += n
+    return model
+
+
+def _check_data_parallel(mod, training):
+    """raises when a training forward runs on > 1 ranks and nobody has taken charge of the gradients"""
+    if not (training or mod.training) or _DP["acknowledged"]:
+        return
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        raise RuntimeError(
+            "dropin: training on torch.distributed world_size > 1, but the HIP backward writes parameter "
+            "gradients into .grad without autograd hooks, so torch DDP (HF Trainer's wrapper) cannot see them. "
+            "Call transformers4rec_amd.dropin.sync_gradients(model) between backward() and optimizer.step(), "
+            "or wire distributed.GradReducer / SparseRowExchange and call dropin.allow_data_parallel().")
+
+
 class _HipFeaturesMixin:
     _t4r_hip = True
 
@@ -356,6 +416,7 @@ class _HipFeaturesMixin:
         return _shadow_of(self, shadow_features)
 
     def forward(self, inputs, training=False, testing=False, **kwargs):
+        _check_data_parallel(self, training)
         sh = self.hip_shadow()
         if sh.training != self.training:
             sh.train(self.training)

@@ -61,6 +61,10 @@ def _sort_ids_forward(ids, rows, padding_idx):
         _SORT_STREAMS[key] = torch.cuda.Stream(device=dev)
     side = _SORT_STREAMS[key]
     side.wait_stream(torch.cuda.current_stream())
+    # `ids` may be a temporary (.contiguous() of a sliced / transposed batch) that the caller drops right after this
+    # enqueue: tell the caching allocator that the side stream still reads it, or the block could be handed to a
+    # main-stream allocation under the running sort
+    ids.record_stream(side)
     with torch.cuda.stream(side):
         keys, perm = ops.sort_ids(ids, rows, padding_idx)
         done = torch.cuda.Event()
@@ -191,6 +195,12 @@ def post_seed():
 
         _post_seed_value = default_seed(_POST_SALT)
     return _post_seed_value
+
+
+def set_post_seed(value):
+    """restores the TabularDropout key (rng.set_rng_state); None re-resolves it at the next draw"""
+    global _post_seed_value
+    _post_seed_value = None if value is None else int(value) & 0x7FFFFFFFFFFFFFFF
 
 
 def _post_fwd(owner, post, name, fidx, e2d, step):

@@ -17,6 +17,7 @@ from torch import nn
 from . import ops
 from .features import _Linear
 from .masking import MaskedLanguageModeling, _grad_buf
+from .ranking_metric import coerce as coerce_metric, default_metrics
 from .rng import SeedMixin
 
 
@@ -338,12 +339,16 @@ class NextItemPredictionTask(nn.Module):
         self.sampled_softmax = sampled_softmax
         self.max_n_samples = max_n_samples
         self.top_ks = tuple(top_ks)
+        # metrics: rank-based descriptors (ranking_metric.py of this package), registry names, or the reference's own
+        # metric objects (recognised by class name); default = the reference's DEFAULT_METRICS at `top_ks`
+        self.metrics = tuple(default_metrics(self.top_ks) if metrics is None
+                             else [coerce_metric(m, self.top_ks) for m in metrics])
         self.task_block = None
         self.item_embedding_table = None
         self.masking = None
         self.embeddings = None
         self.pre = None
-        self._metric_sums = None
+        self._metric_acc = None
 
     def build(self, body=None, input_size=None, device=None, inputs=None, task_block=None, pre=None):
         """Called by the Head/Model (prediction_task.py:369-417)."""
@@ -450,39 +455,38 @@ class NextItemPredictionTask(nn.Module):
         return ops.topk(scores, top_k, V)
 
     # ------------------------------------------------------------------ ranking metrics (N1)
-    def calculate_metrics(self, predictions, targets):
-        """Recall@k / NDCG@k with one relevant item per row (ranking_metric.py:107-147,242-280;
-        labels_onehot=True) from a fused top-k -- no [N, V] one-hot."""
-        kmax = max(self.top_ks)
-        _, idx = ops.topk(predictions, kmax, predictions.shape[1])
-        hit = idx == targets.unsqueeze(-1)
+    def _rank_metrics(self, ranks):
+        """{"<metric>_<k>": per-row values} for the task's metrics, from 0-based target ranks, and their
+        accumulation for compute_metrics(): (sum, count) per entry, kept ON THE DEVICE in fp64 -- no host
+        synchronisation per batch."""
         out = {}
-        ranks = torch.arange(kmax, device=idx.device, dtype=torch.float32)
-        gain = 1.0 / torch.log2(ranks + 2.0)
-        for k in self.top_ks:
-            out[f"recall_at_{k}"] = hit[:, :k].any(-1).float()
-            out[f"ndcg_at_{k}"] = (hit[:, :k].float() * gain[:k]).sum(-1)
-        if self._metric_sums is None:
-            self._metric_sums = {k: [0.0, 0] for k in out}
-        for k, v in out.items():
-            self._metric_sums[k][0] += float(v.sum())
-            self._metric_sums[k][1] += v.numel()
+        for m in self.metrics:
+            vals = m.from_ranks(ranks)
+            for j, k in enumerate(m.top_ks):
+                out[f"{m.name}_{k}"] = vals[:, j]
+        names = self._metric_names()
+        add = torch.stack([out[n].sum(dtype=torch.float64) for n in names]
+                          + [torch.tensor(float(ranks.numel()), dtype=torch.float64, device=ranks.device)])
+        self._metric_acc = add if self._metric_acc is None else self._metric_acc + add
         return out
 
+    def _metric_names(self):
+        return [f"{m.name}_{k}" for m in self.metrics for k in m.top_ks]
+
+    def calculate_metrics(self, predictions, targets):
+        """The task's ranking metrics with one relevant item per row (ranking_metric.py:52-59 labels_onehot=True)
+        from a fused top-k of the scores -- no [N, V] one-hot.  A target outside the top max(k) gets rank
+        max(k): every metric of the path is zero from there on."""
+        kmax = max(k for m in self.metrics for k in m.top_ks)
+        _, idx = ops.topk(predictions, kmax, predictions.shape[1])
+        hit = idx == targets.unsqueeze(-1)
+        pos = torch.arange(kmax, device=idx.device, dtype=torch.int64)
+        ranks = torch.where(hit, pos, torch.full_like(pos, kmax)).min(dim=-1).values
+        return self._rank_metrics(ranks)
+
     def metrics_from_ranks(self, ranks):
-        """Recall@k / NDCG@k from 0-based target ranks (one relevant item per row)."""
-        out = {}
-        r = ranks.to(torch.float32)
-        for k in self.top_ks:
-            hit = ranks < k
-            out[f"recall_at_{k}"] = hit.float()
-            out[f"ndcg_at_{k}"] = torch.where(hit, 1.0 / torch.log2(r + 2.0), torch.zeros_like(r))
-        if self._metric_sums is None:
-            self._metric_sums = {k: [0.0, 0] for k in out}
-        for k, v in out.items():
-            self._metric_sums[k][0] += float(v.sum())
-            self._metric_sums[k][1] += v.numel()
-        return out
+        """The task's ranking metrics from 0-based target ranks (one relevant item per row)."""
+        return self._rank_metrics(ranks.to(torch.int64))
 
     def evaluate_ranks(self, inputs):
         """Fused evaluation head: the label rows of `inputs` [B, L, D] (the masking's
@@ -506,13 +510,34 @@ class NextItemPredictionTask(nn.Module):
         ranks = ops.rank_of_target(xr, mod.output_weights.detach(), labels, 1.0 / T)
         return {"labels": labels, "ranks": ranks, "metrics": self.metrics_from_ranks(ranks)}
 
-    def compute_metrics(self, mode=None):
-        if not self._metric_sums:
+    def compute_metrics(self, mode=None, group=None):
+        """{"<task>/<metric>_<k>": mean over ALL rows seen since reset_metrics()}.  Under torch.distributed
+        (world_size > 1) the (sum, count) state is all-reduced first -- the reference `cat`-synchronises the
+        per-row values of its torchmetrics state and averages them (ranking_metric.py:50,64-66; gathered by HF
+        Trainer's evaluation loop, torch/trainer.py:519-525): the same mean over every rank's rows.
+        COLLECTIVE: every rank must call it (a rank that evaluated nothing contributes zeros)."""
+        import torch.distributed as dist
+
+        names = self._metric_names()
+        acc = self._metric_acc
+        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        if distributed:
+            if acc is None:
+                dev = next((p.device for p in self.parameters()), None) or \
+                    self.pre.module.output_weights.device
+                if dist.get_backend(group) == "nccl" and dev.type != "cuda":
+                    dev = torch.device("cuda", torch.cuda.current_device())
+                acc = torch.zeros(len(names) + 1, dtype=torch.float64, device=dev)
+            acc = acc.clone()
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+        if acc is None:
             return {}
-        return {f"{self.task_name}/{k}": s / max(n, 1) for k, (s, n) in self._metric_sums.items()}
+        vals = acc.cpu().tolist()
+        n = max(vals[-1], 1.0)
+        return {f"{self.task_name}/{k}": v / n for k, v in zip(names, vals[:-1])}
 
     def reset_metrics(self):
-        self._metric_sums = None
+        self._metric_acc = None
 
     def metric_name(self, name):
         return f"{self.task_name}/{name}"

@@ -46,9 +46,16 @@ class SeedMixin:
         self._seed = None if value is None else int(value) & _MASK63
 
 
+_POST_KEY = "__tabular_dropout_seed__"     # reserved entry: the process-wide TabularDropout key (features.post_seed)
+
+
 def get_rng_state(model):
-    """{module path: {attr: value}} for every module of `model` that owns a device-RNG stream."""
-    out = {}
+    """{module path: {attr: value}} for every module of `model` that owns a device-RNG stream, plus the
+    process-wide TabularDropout key under `_POST_KEY` (resolved here, so that a resumed run whose
+    torch.initial_seed() differs still replays the same masks)."""
+    from . import features
+
+    out = {_POST_KEY: {"_seed": features.post_seed()}}
     for name, m in model.named_modules():
         st = {a: getattr(m, a) for a in _STATE_ATTRS if isinstance(getattr(m, a, None), int)}
         if isinstance(m, SeedMixin):
@@ -61,6 +68,11 @@ def get_rng_state(model):
 def set_rng_state(model, state):
     mods = dict(model.named_modules())
     for name, st in state.items():
+        if name == _POST_KEY:
+            from . import features
+
+            features.set_post_seed(st["_seed"])
+            continue
         if name not in mods:
             raise KeyError(f"set_rng_state: no module named {name!r}")
         for a, v in st.items():

@@ -55,6 +55,31 @@ class Schema:
     def __init__(self, feature=None):
         self.feature = list(feature or [])
 
+    @classmethod
+    def from_json(cls, path_or_text):
+        """The reference's schema file (transformers4rec/data/testing/schema.json: the tensorflow-metadata JSON
+        form that merlin_standard_lib.Schema.from_json reads, merlin_standard_lib/schema/schema.py): per feature
+        `name`, `annotation.tag`, `intDomain {min, max, isCategorical}`, `valueCount {min, max}`.  Accepts a path
+        or the JSON text.  Tags this package does not model stay plain strings (tag selection compares values)."""
+        import json
+        import os
+
+        if isinstance(path_or_text, (str, os.PathLike)) and os.path.exists(str(path_or_text)):
+            with open(path_or_text) as f:
+                js = json.load(f)
+        else:
+            js = json.loads(path_or_text)
+        known = {t.value: t for t in Tags}
+        cols = []
+        for ft in js.get("feature", []):
+            tags = [known.get(t, t) for t in ft.get("annotation", {}).get("tag", [])]
+            dom, vc = ft.get("intDomain"), ft.get("valueCount")
+            cols.append(ColumnSchema(
+                ft["name"], tags,
+                IntDomain(int(dom.get("min", 0)), int(dom["max"]), bool(dom.get("isCategorical", False))) if dom else None,
+                ValueCount(int(vc.get("min", 0)), int(vc["max"])) if vc else None))
+        return cls(cols)
+
     @property
     def column_names(self):
         return [c.name for c in self.feature]

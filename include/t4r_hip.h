@@ -91,6 +91,23 @@ long t4r_embedding_bwd_sorted_ws_floats(long n, int dim);
 int t4r_embedding_bwd_sorted(void* stream, const float* dout, const int* keys_sorted, const int* perm,
                              float* d_table, long n, int W, int col, int dim, long rows, int ids_div,
                              float* ws);
+/* a3  EmbeddingBag branch: one bag of ids per row -> one combined row.
+ * replaces: features/embedding.py:226-240 (EmbeddingFeatures.forward: 2-D ids, (values, offsets) tuples, 1-D ids)
+ *           with :86-93 / :260-273 (EmbeddingBagWrapper(mode = TableConfig.combiner)) and :416-460 (the combiner
+ *           option set "mean" | "sum" | "sqrtn"), i.e. torch.nn.EmbeddingBag WITHOUT a padding index: id 0 is an
+ *           ordinary row, an empty bag gives a zero row.
+ * matrix form: offsets == NULL, values [n_bags * fixed_k] (fixed_k = 1 for 1-D ids); ragged form: values [n_values],
+ * offsets [n_bags], bag b = values[offsets[b] : offsets[b+1]) and the last bag runs to n_values.
+ * combiner 0 sum | 1 mean (/ n_b) | 2 sqrtn (/ sqrt(n_b)).  out[b, col : col + dim] (row pitch ld_out floats).
+ * *err (device int, may be NULL) is set to 1 on an id outside [0, rows).
+ * t4r_embedding_bag_bwd_rows: the transpose as rows -- rows_out[i, :] = scale(bag of i) * dout[bag of i, col : col + dim]
+ * for every member lookup i; the caller sums them into the table with t4r_sort_ids(values, padding_idx = -1) +
+ * t4r_embedding_bwd_sorted (deterministic) or hands them to the row-sparse data-parallel exchange. */
+int t4r_embedding_bag_fwd(void* stream, const float* table, long rows, int dim, const long* values,
+                          const long* offsets, long n_bags, long n_values, int fixed_k, int combiner, float* out,
+                          long ld_out, int col, int* err);
+int t4r_embedding_bag_bwd_rows(void* stream, const float* dout, long ld, int col, int dim, const long* offsets,
+                               long n_bags, long n_values, int fixed_k, int combiner, float* rows_out);
 /* masking as its own pass (after the projection MLP), in place on x [B*L, H]; and its backward:
  * d_memb[H] += sum of dy over replaced tokens (accumulated), dy zeroed there (in place). */
 int t4r_apply_mask_fwd(void* stream, float* x, const unsigned char* mask, const float* masked_emb,

@@ -327,3 +327,95 @@ def test_bench_train_step_wiring_world2():
     assert ret["scales"] == [0.5] * 5                        # 1/world folded into the optimizer, every step
     assert ret["dt"] > 0 and ret["n_lab"] == 3 * 20
     assert len({s[0] for s in ret["seeds"]}) == world and len({s[1] for s in ret["seeds"]}) == world
+
+
+# ------------------------------------------------------------------------------------------ cross-rank evaluation metrics
+def _metrics_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import transformers4rec_amd as tr
+
+    g = torch.Generator().manual_seed(5)
+    ranks_all = torch.randint(0, 40, (101,), generator=g)          # target ranks of 101 label rows
+    cut = [0, 37, 101]                                              # uneven shards (eval loaders keep every row)
+    task = tr.NextItemPredictionTask(weight_tying=True)
+    mine = ranks_all[cut[rank]: cut[rank + 1]]
+    if rank == 0:                                                   # two batches on one rank, one on the other
+        task.metrics_from_ranks(mine[:10])
+        task.metrics_from_ranks(mine[10:])
+    else:
+        task.metrics_from_ranks(mine)
+    agg = task.compute_metrics()
+    # a rank that evaluated nothing still takes part in the collective and contributes zeros
+    idle = tr.NextItemPredictionTask(weight_tying=True)
+    idle.pre = type("P", (), {"module": type("M", (), {"output_weights": torch.zeros(1)})()})()
+    if rank == 0:
+        idle.metrics_from_ranks(ranks_all)
+    agg_idle = idle.compute_metrics()
+    ret[rank] = (agg, agg_idle)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_compute_metrics_reduces_over_ranks():
+    """Recall / NDCG / AvgPrecision at N > 1 = the mean over EVERY rank's label rows (the reference cat-syncs the
+    torchmetrics state, ranking_metric.py:50; trainer.py:519-525), identical on all ranks"""
+    import transformers4rec_amd as tr
+
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_metrics_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(5)
+    ranks_all = torch.randint(0, 40, (101,), generator=g)
+    single = tr.NextItemPredictionTask(weight_tying=True)
+    single.metrics_from_ranks(ranks_all)
+    want = single.compute_metrics()
+    assert set(want) == {f"next-item/{m}_{k}" for m in ("ndcg_at", "avg_precision_at", "recall_at") for k in (10, 20)}
+    for r in range(world):
+        agg, agg_idle = ret[r]
+        for k, v in want.items():
+            assert abs(agg[k] - v) < 1e-12 and abs(agg_idle[k] - v) < 1e-12, (r, k)
+    # closed forms on the full set
+    hit20 = (ranks_all < 20).double()
+    assert abs(want["next-item/recall_at_20"] - float(hit20.mean())) < 1e-12
+    assert abs(want["next-item/avg_precision_at_20"] - float((hit20 / (ranks_all.double() + 1)).mean())) < 1e-6
+
+
+def _sync_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from transformers4rec_amd import dropin
+
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+    model.train()
+    # the guard: a training forward of a drop-in module on > 1 ranks raises until somebody owns the gradient exchange
+    dropin.allow_data_parallel(False)
+    try:
+        dropin._check_data_parallel(model, True)
+        guarded = False
+    except RuntimeError as e:
+        guarded = "sync_gradients" in str(e)
+    x = torch.full((5, 4), float(rank + 1))
+    model(x).sum().backward()
+    model[1].bias.grad = None                                       # a parameter without gradient on this rank
+    local = [None if p.grad is None else p.grad.clone() for p in model.parameters()]
+    dropin.sync_gradients(model)
+    dropin._check_data_parallel(model, True)                        # acknowledged now
+    ret[rank] = (guarded, local, [p.grad.clone() for p in model.parameters()])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dropin_sync_gradients_and_ddp_guard():
+    """the HIP backward bypasses autograd hooks, so DDP would never reduce the drop-in's gradients:
+    the forward raises on world_size > 1 until `sync_gradients` (flat averaged all-reduce of every .grad) is wired"""
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_sync_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert ret[0][0] and ret[1][0]
+    for i in range(4):
+        l0, l1 = ret[0][1][i], ret[1][1][i]
+        want = (torch.zeros_like(ret[0][2][i]) if l0 is None else l0) * 0.5 + (torch.zeros_like(ret[0][2][i]) if l1 is None else l1) * 0.5
+        torch.testing.assert_close(ret[0][2][i], want)
+        assert torch.equal(ret[0][2][i], ret[1][2][i])

@@ -230,3 +230,72 @@ def test_construction_time_limits():
                                                    embedding_dim_default=16)
     with pytest.raises(ValueError, match="target_dim"):
         tr.NextItemPredictionTask(target_dim=50).build(body=None, input_size=torch.Size([-1, 20, 16]), inputs=small)
+
+
+def test_rng_state_carries_the_tabular_dropout_key():
+    """the process-wide TabularDropout key is part of get / set_rng_state, so a resumed run with another
+    torch.initial_seed() replays the same post-dropout masks"""
+    import transformers4rec_amd as tr
+    from transformers4rec_amd import features, rng
+
+    m = torch.nn.Linear(2, 2)
+    features.set_post_seed(None)
+    torch.manual_seed(21)
+    st = tr.get_rng_state(m)
+    key = st[rng._POST_KEY]["_seed"]
+    assert key == features.post_seed()
+    features.set_post_seed(None)
+    torch.manual_seed(22)
+    assert features.post_seed() != key                     # another global seed -> another key ...
+    tr.set_rng_state(m, st)
+    assert features.post_seed() == key                     # ... unless the saved state is restored
+    features.set_post_seed(None)
+
+
+def test_loader_shards_training_equal_eval_complete(tmp_path):
+    """equal shards (trailing rows dropped, with a warning) only for training; evaluation loaders keep
+    every row, shard sizes differing by at most one"""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    import transformers4rec_amd as tr
+
+    n = 11
+    col = pa.array([[i + 1] * (1 + i % 3) for i in range(n)], type=pa.list_(pa.int64()))
+    path = str(tmp_path / "d.parquet")
+    pq.write_table(pa.table({"item_id": col}), path)
+    with pytest.warns(UserWarning, match="dropped"):
+        train = [tr.ParquetSessionLoader(path, 4, 5, device="cpu", global_size=3, global_rank=r) for r in range(3)]
+    assert [len(l.dataset) for l in train] == [3, 3, 3]
+    ev = [tr.ParquetSessionLoader(path, 4, 5, device="cpu", global_size=3, global_rank=r, drop_uneven=False)
+          for r in range(3)]
+    assert [len(l.dataset) for l in ev] == [4, 4, 3]
+    spans = [(l._row0, l._row0 + l._rows) for l in ev]
+    assert spans == [(0, 4), (4, 8), (8, 11)]              # contiguous, complete, disjoint
+
+
+def test_schema_from_json_text():
+    import transformers4rec_amd as tr
+    from transformers4rec_amd.schema import categorical_cardinalities
+
+    js = ('{"feature": [{"name": "item_id/list", "type": "INT", "intDomain": {"name": "item_id/list", "min": "1", "max": "51996", '
+          '"isCategorical": true}, "valueCount": {"min": "2", "max": "185"}, "annotation": {"tag": ["item_id", "list", '
+          '"categorical", "item"]}}, {"name": "user_age", "type": "FLOAT", "annotation": {"tag": ["continuous"]}}]}')
+    s = tr.Schema.from_json(js)
+    assert s.column_names == ["item_id/list", "user_age"] and s.item_id_column_name == "item_id/list"
+    assert categorical_cardinalities(s) == {"item_id/list": 51997}
+    assert s.feature[0].value_count.max == 185 and s.select_by_tag(tr.Tags.CONTINUOUS).column_names == ["user_age"]
+
+
+def test_ranking_metric_argument_forms():
+    import transformers4rec_amd as tr
+    from transformers4rec_amd import ranking_metric as RM
+
+    class NDCGAt:                                           # stands for the reference's metric object: recognised by name
+        top_ks, labels_onehot = [3, 7], True
+
+    t = tr.NextItemPredictionTask(metrics=[NDCGAt(), "map", RM.RecallAt(top_ks=[5])])
+    assert [(m.name, m.top_ks) for m in t.metrics] == [("ndcg_at", [3, 7]), ("avg_precision_at", [10, 20]), ("recall_at", [5])]
+    out = t.metrics_from_ranks(torch.tensor([0, 4, 6, 30]))
+    assert out["recall_at_5"].tolist() == [1.0, 1.0, 0.0, 0.0]
+    assert out["avg_precision_at_10"].tolist() == pytest.approx([1.0, 0.2, 1 / 7, 0.0])
+    assert t.compute_metrics()["next-item/recall_at_5"] == 0.5

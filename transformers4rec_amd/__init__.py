@@ -9,7 +9,10 @@ __version__ = "0.1.0"
 from .schema import ColumnSchema, IntDomain, Schema, Tags, ValueCount, random_data_from_schema, session_schema  # noqa: E402,F401
 from .masking import CausalLanguageModeling, MaskedLanguageModeling, MaskSequence  # noqa: E402,F401
 from .features import (  # noqa: E402,F401
-    ContinuousFeatures, SequenceEmbeddingFeatures, SoftEmbedding, SoftEmbeddingFeatures, TabularSequenceFeatures)
+    ContinuousFeatures, EmbeddingFeatures, FeatureConfig, SequenceEmbeddingFeatures, SoftEmbedding,
+    SoftEmbeddingFeatures, TableConfig, TabularSequenceFeatures)
+from . import ranking_metric  # noqa: E402,F401
+from .ranking_metric import AvgPrecisionAt, DCGAt, NDCGAt, PrecisionAt, RecallAt  # noqa: E402,F401
 from .transformations import StochasticSwapNoise, TabularDropout, TabularLayerNorm  # noqa: E402,F401
 from .transformer import TransformerBlock, XLNetConfig, XLNetModel  # noqa: E402,F401
 from .transformer_hf import BertConfig, BertModel, GPT2Config, GPT2Model  # noqa: E402,F401

@@ -29,6 +29,8 @@ _SIGS = {
     "t4r_sort_ids": ("i", "pp" + "lli" + "ppp" + "l"),
     "t4r_embedding_bwd_sorted_ws_floats": ("l", "li"),
     "t4r_embedding_bwd_sorted": ("i", "ppppp" + "liiili" + "p"),
+    "t4r_embedding_bag_fwd": ("i", "pp" + "li" + "pp" + "llii" + "p" + "li" + "p"),
+    "t4r_embedding_bag_bwd_rows": ("i", "pp" + "lii" + "p" + "llii" + "p"),
     "t4r_apply_mask_fwd": ("i", "ppppiiii"),
     "t4r_apply_mask_bwd": ("i", "ppppiiii"),
     "t4r_mul": ("i", "ppppl"),

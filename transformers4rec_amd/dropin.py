@@ -304,8 +304,12 @@ def shadow_task(ref):
         raise NotImplementedError("dropin: the HIP head fuses torch.nn.CrossEntropyLoss(mean) (optionally "
                                   "label-smoothed); other losses are off the hot path")
     pm = ref.pre.module
+    try:        # the reference task's torchmetrics objects, recognised by class name (ranking_metric.coerce)
+        metrics = [P.coerce_metric(m) for m in getattr(ref, "metrics", None) or []] or None
+    except NotImplementedError:
+        metrics = None      # non-rank metrics stay the reference's business (its calculate_metrics still runs them)
     with _meta():
-        sh = P.NextItemPredictionTask(loss=loss, task_name=ref.task_name, weight_tying=ref.weight_tying,
+        sh = P.NextItemPredictionTask(loss=loss, metrics=metrics, task_name=ref.task_name, weight_tying=ref.weight_tying,
                                       softmax_temperature=ref.softmax_temperature, padding_idx=ref.padding_idx,
                                       target_dim=ref.target_dim, sampled_softmax=ref.sampled_softmax,
                                       max_n_samples=ref.max_n_samples)

@@ -151,6 +151,189 @@ class SequenceEmbeddingFeatures(nn.Module):
         return inputs[self.item_id]
 
 
+class TableConfig:
+    """features/embedding.py:416-460: vocabulary_size, dim, initializer, combiner ("mean" | "sum" | "sqrtn"), name"""
+
+    def __init__(self, vocabulary_size: int, dim: int, initializer=None, combiner: str = "mean", name: Optional[str] = None):
+        if not isinstance(vocabulary_size, int) or vocabulary_size < 1:
+            raise ValueError("Invalid vocabulary_size {}.".format(vocabulary_size))
+        if not isinstance(dim, int) or dim < 1:
+            raise ValueError("Invalid dim {}.".format(dim))
+        if combiner not in ("mean", "sum", "sqrtn"):
+            raise ValueError("Invalid combiner {}".format(combiner))
+        self.vocabulary_size, self.dim, self.combiner, self.name = vocabulary_size, dim, combiner, name
+        self.initializer = initializer
+
+    def __repr__(self):
+        return (f"TableConfig(vocabulary_size={self.vocabulary_size!r}, dim={self.dim!r}, "
+                f"combiner={self.combiner!r}, name={self.name!r})")
+
+
+class FeatureConfig:
+    """features/embedding.py:391-413"""
+
+    def __init__(self, table: TableConfig, max_sequence_length: int = 0, name: Optional[str] = None):
+        self.table, self.max_sequence_length, self.name = table, max_sequence_length, name
+
+
+class _BagTable(nn.Module):
+    """EmbeddingBagWrapper-shaped parameter holder (`weight`, `mode`); torch.nn.EmbeddingBag's default init N(0, 1)
+    unless the TableConfig carries an initializer (features/embedding.py:86-93)."""
+
+    def __init__(self, num_embeddings, embedding_dim, mode="mean", initializer=None):
+        super().__init__()
+        self.num_embeddings, self.embedding_dim, self.mode = num_embeddings, embedding_dim, mode
+        self.weight = nn.Parameter(torch.empty(num_embeddings, embedding_dim))
+        nn.init.normal_(self.weight)
+        if initializer is not None:
+            initializer(self.weight)
+
+    def extra_repr(self):
+        return f"{self.num_embeddings}, {self.embedding_dim}, mode={self.mode!r}"
+
+
+class _EmbeddingBagsFn(torch.autograd.Function):
+    """all bag lookups of one EmbeddingFeatures call.  forward: `t4r_embedding_bag_fwd` per feature, into its own
+    [B, dim] tensor or (concat) into its columns of ONE [B, W] buffer; backward: per-lookup gradient rows
+    (`t4r_embedding_bag_bwd_rows`) summed into the table by the deterministic sorted scatter, or handed to the
+    data-parallel row-sparse sink.  Table gradients go straight into `.grad`, as everywhere on this path."""
+
+    @staticmethod
+    def forward(ctx, anchor, tables, lookups, concat, err):
+        # lookups: [(values int64, offsets int64 | None, combiner)] aligned with `tables`
+        B = lookups[0][1].numel() if lookups[0][1] is not None else lookups[0][0].shape[0]
+        cols, c = [], 0
+        for t in tables:
+            cols.append(c)
+            c += t.shape[1] if concat else 0
+        wide = torch.empty((B, c), device=anchor.device, dtype=torch.float32) if concat else None
+        outs, saved = [], []
+        for t, (vals, offs, comb), col in zip(tables, lookups, cols):
+            vals = vals.contiguous()
+            offs = None if offs is None else offs.contiguous()
+            outs.append(ops.embedding_bag_fwd(t.detach(), vals, offs, comb, out=wide, col=col, err_flag=err))
+            saved.append((vals, offs, comb, 0 if offs is not None else vals.numel() // max(vals.shape[0], 1), col))
+        ctx.tables, ctx.saved, ctx.concat = tables, saved, concat
+        return (wide,) if concat else tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        for i, (tab, (vals, offs, comb, fixed_k, col)) in enumerate(zip(ctx.tables, ctx.saved)):
+            dout = douts[0] if ctx.concat else douts[i]
+            if dout is None:
+                continue
+            rows = ops.embedding_bag_bwd_rows(dout.contiguous(), vals.numel(), tab.shape[1], offs, fixed_k, comb, col=col)
+            ids = vals.view(-1)
+            sink = getattr(tab, "_t4r_sparse_sink", None)
+            if sink is not None:
+                sink.add_rows(tab, ids, rows, padding_idx=-1)
+            else:
+                ops.scatter_rows_sorted(_grad_buf(tab), ids, rows, padding_idx=-1)
+        return None, None, None, None, None
+
+
+class EmbeddingFeatures(nn.Module):
+    """Drop-in for tr.EmbeddingFeatures (features/embedding.py:43-249), the NON-sequential categorical module whose
+    tables are EmbeddingBags: per feature `inputs[name]` is
+
+      * int64 [B]              -> bags of one id                       -> [B, dim]
+      * int64 [B, K]           -> one bag of K ids per row (id 0 counts) -> [B, dim]
+      * (values, offsets)      -> ragged bags; values [n] or [n, 1], offsets [B] or [B, 1] (the Merlin loader's
+                                  sparse form, :229-236)                 -> [B, dim]
+
+    combined with the table's `combiner`.  ("sqrtn" = sum / sqrt(n) is what TableConfig documents; the reference's
+    torch.nn.EmbeddingBag rejects that mode at run time, and its tuple branch raises a TypeError as shipped -- the
+    fixtures tests/golden/embedding_bag_*.npz record what the reference does compute.)
+    forward returns {name: [B, dim]} (aggregation=None) or their concatenation in sorted-name order
+    (aggregation="concat", tabular/aggregation.py:35-47).  state_dict names: `embedding_tables.<name>.weight`."""
+
+    def __init__(self, feature_config: Dict[str, FeatureConfig], item_id: Optional[str] = None, pre=None, post=None,
+                 aggregation: Optional[str] = None, schema=None):
+        super().__init__()
+        if pre is not None or post is not None:
+            raise NotImplementedError("pre / post transformations on EmbeddingFeatures are off the hot path")
+        if aggregation not in (None, "concat"):
+            raise NotImplementedError("EmbeddingFeatures on the HIP path aggregates with None or 'concat'")
+        self.item_id, self.feature_config, self.aggregation, self.schema = item_id, feature_config, aggregation, schema
+        tables = {}
+        for name, feature in feature_config.items():
+            t = feature.table
+            if name not in tables:
+                tables[name] = _BagTable(t.vocabulary_size, t.dim, t.combiner, t.initializer)
+        self.embedding_tables = nn.ModuleDict(tables)
+        self.item_seq = None
+        self._err = None
+
+    @classmethod
+    def from_schema(cls, schema, embedding_dims=None, embedding_dim_default: int = 64, infer_embedding_sizes=False,
+                    infer_embedding_sizes_multiplier: float = 2.0, embeddings_initializers=None,
+                    combiner: str = "mean", tags=None, item_id=None, automatic_build=True,
+                    max_sequence_length=None, aggregation=None, pre=None, post=None, **kwargs):
+        """features/embedding.py:95-221"""
+        if infer_embedding_sizes:
+            raise NotImplementedError("infer_embedding_sizes is off the hot path: pass embedding_dims")
+        if tags:
+            schema = schema.select_by_tag(tags)
+        ids = schema.select_by_tag(Tags.ITEM_ID)
+        if not item_id and len(ids) > 0:
+            if len(ids) > 1:
+                raise ValueError("Multiple columns with tag ITEM_ID found. Please specify the item_id column name.")
+            item_id = ids.column_names[0]
+        embedding_dims = embedding_dims or {}
+        inits = embeddings_initializers or {}
+        cfg = {name: FeatureConfig(TableConfig(card, embedding_dims.get(name, embedding_dim_default),
+                                               initializer=inits.get(name), combiner=combiner, name=name))
+               for name, card in categorical_cardinalities(schema).items()}
+        if not cfg:
+            return None
+        return cls(cfg, item_id=item_id, pre=pre, post=post, aggregation=aggregation, schema=schema)
+
+    @property
+    def item_embedding_table(self):
+        assert self.item_id is not None
+        return self.embedding_tables[self.item_id]
+
+    def item_ids(self, inputs):
+        return inputs[self.item_id]
+
+    def check_ids(self):
+        """raises if a lookup since the last call saw an id outside its table (one host sync)"""
+        if self._err is not None and int(self._err.item()) != 0:
+            self._err.zero_()
+            raise IndexError("EmbeddingFeatures: id outside [0, vocabulary_size)")
+
+    def forward(self, inputs, **kwargs):
+        names = [n for n in (sorted(self.feature_config) if self.aggregation == "concat" else self.feature_config)
+                 if n in inputs]
+        if not names:
+            return {}
+        tables, lookups = [], []
+        for name in names:
+            val = inputs[name]
+            tab = self.embedding_tables[name]
+            if isinstance(val, tuple):
+                values, offsets = val
+                values = values.reshape(-1)
+                offsets = offsets[:, 0] if offsets.ndim == 2 else offsets
+            else:
+                values, offsets = val, None
+                if val.ndim not in (1, 2):
+                    raise ValueError(f"EmbeddingFeatures: {name} must be [B], [B, K] or a (values, offsets) tuple")
+            tables.append(tab.weight)
+            lookups.append((values, offsets, tab.mode))
+        dev = tables[0].device
+        if self._err is None or self._err.device != dev:
+            self._err = torch.zeros(1, dtype=torch.int32, device=dev)
+        concat = self.aggregation == "concat"
+        outs = _EmbeddingBagsFn.apply(tables[0], tables, lookups, concat, self._err)
+        if self.item_id:
+            self.item_seq = self.item_ids(inputs)
+        return outs[0] if concat else dict(zip(names, outs))
+
+    def forward_output_size(self, input_sizes=None):
+        return {name: torch.Size([-1, f.table.dim]) for name, f in self.feature_config.items()}
+
+
 class _FeaturePost(nn.Module):
     def __init__(self, dims: Dict[str, int]):
         super().__init__()

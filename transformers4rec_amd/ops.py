@@ -346,6 +346,35 @@ def embedding_bwd_sorted(dout, keys, perm, d_table, col, dim, ids_div=1):
          ws.data_ptr())
 
 
+BAG_COMBINER = {"sum": 0, "mean": 1, "sqrtn": 2}
+
+
+def embedding_bag_fwd(table, values, offsets=None, combiner="mean", out=None, col=0, err_flag=None):
+    """torch.nn.EmbeddingBag(mode=combiner) without a padding index.  values: int64 [B, K] / [B] (matrix form,
+    offsets None) or [n] with offsets int64 [B] (ragged form).  -> [B, dim] (or the columns [col, col + dim) of `out`)."""
+    rows, dim = table.shape
+    if offsets is None:
+        v2 = values.view(values.shape[0], -1)
+        n_bags, fixed_k = v2.shape[0], v2.shape[1]
+    else:
+        n_bags, fixed_k = offsets.numel(), 0
+    if out is None:
+        out = torch.empty((n_bags, dim), device=table.device, dtype=torch.float32)
+    call("t4r_embedding_bag_fwd", _stream(), _chk(table, torch.float32), rows, dim, _chk(values, torch.int64),
+         _p(offsets, torch.int64), n_bags, values.numel(), fixed_k, BAG_COMBINER[combiner], out.data_ptr(),
+         out.stride(0), col, _p(err_flag))
+    return out
+
+
+def embedding_bag_bwd_rows(dout, n_values, dim, offsets=None, fixed_k=0, combiner="mean", col=0):
+    """gradient row of every member lookup, [n_values, dim] in lookup order (see t4r_embedding_bag_bwd_rows)"""
+    rows = torch.empty((n_values, dim), device=dout.device, dtype=torch.float32)
+    n_bags = dout.shape[0]
+    call("t4r_embedding_bag_bwd_rows", _stream(), _chk(dout, torch.float32), dout.stride(0), col, dim,
+         _p(offsets, torch.int64), n_bags, n_values, fixed_k, BAG_COMBINER[combiner], rows.data_ptr())
+    return rows
+
+
 def swap_noise(x, item_ids, p, pad_token=0, bern=None, perm=None, seed=0, ctr_hi=0):
     """tr.StochasticSwapNoise.augment for one feature: x [B, L] or [B] (int64 ids / fp32 values);
     item_ids [B, L] gives the padding mask.  bern (uint8, x.shape) / perm (int64 [#non-pad]) inject

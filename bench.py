@@ -187,6 +187,59 @@ def cpu_baseline(dropout, seconds_budget=25.0, max_steps=8):
                       "profiles/r02_cpu_reference_bench.json"}
 
 
+def cpu_baseline_reference(dropout, steps=3, threads=None):
+    """The UNMODIFIED reference (transformers4rec.torch + HF XLNet, imported from /root/reference through
+    oracle/ref_standins.py) timed on THIS host's cores on the same workload -- only where the reference tree exists
+    (the build container; the GPU box has no /root/reference, there the committed measurement is quoted instead).
+    -> dict or None"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    try:
+        import ref_standins as rs
+    except Exception:      # noqa: BLE001
+        return None
+    if not os.path.isdir(rs.REFERENCE_ROOT):
+        path = os.path.join(ROOT, "profiles", "r02_cpu_reference_bench.json")
+        if os.path.exists(path):
+            with open(path) as f:
+                j = json.load(f)
+            return {"value": j["sessions_per_s_median"], "unit": "sessions/s", "cores": j["threads"], "kind": "reference",
+                    "measured_here": False,
+                    "sample": "committed measurement profiles/r02_cpu_reference_bench.json (build container, "
+                              f"{j['threads']} threads; /root/reference does not exist on this box): {j['what']}"}
+        return None
+    import make_golden as mg
+    import transformers4rec_amd as hip
+
+    tr = rs.import_reference()
+    from transformers4rec.config import transformer as tconf
+
+    cores = threads or min(os.cpu_count() or 1, int(os.environ.get("T4R_CPU_BASELINE_THREADS", "32")))
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    inputs = tr.TabularSequenceFeatures.from_schema(mg.make_schema(V_ITEMS, SEQ), max_sequence_length=SEQ, masking="mlm",
+                                                    embedding_dim_default=D_MODEL)
+    cfg = tconf.XLNetConfig.build(d_model=D_MODEL, n_head=N_HEAD, n_layer=N_LAYER, total_seq_length=SEQ, dropout=dropout)
+    model = cfg.to_torch_model(inputs, tr.NextItemPredictionTask(weight_tying=True))
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    hschema = hip.session_schema(V_ITEMS, SEQ)
+    times = []
+    for i in range(1 + steps):
+        x = hip.random_data_from_schema(hschema, BATCH, SEQ, seed=100 + i)
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        out = model(x, training=True)
+        out["loss"].backward()
+        opt.step()
+        if i:
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(BATCH / med, 2), "unit": "sessions/s", "cores": cores, "kind": "reference", "measured_here": True,
+            "sample": f"{steps} train steps (fwd+bwd+Adam) of batch {BATCH}, unmodified transformers4rec.torch + HF XLNetModel "
+                      f"on {cores} host threads of this box, median"}
+
+
 # --------------------------------------------------------------------------------------------- Recall@20
 def markov_sessions(n, seq, active, seed, p_follow=0.8, min_len=5):
     """sessions of a fixed first-order Markov chain over the item ids `active` (next = succ[cur] with
@@ -243,7 +296,9 @@ def recall_probe(device, dropout, train_steps=200, lockstep_steps=600):
     mt = task.compute_metrics()
     torch.cuda.synchronize()
     res["hip_bench_config"] = {"recall_at_20": round(mt["next-item/recall_at_20"], 4),
-                               "ndcg_at_20": round(mt["next-item/ndcg_at_20"], 4), "train_steps": train_steps,
+                               "ndcg_at_20": round(mt["next-item/ndcg_at_20"], 4),
+                               "avg_precision_at_20": round(mt["next-item/avg_precision_at_20"], 4),
+                               "train_steps": train_steps,
                                "eval_sessions": 4 * BATCH, "final_train_loss": round(float(out["loss"].detach()), 4),
                                "seconds": round(time.perf_counter() - t0, 2)}
     del model, opt, dense, tables
@@ -291,6 +346,42 @@ def recall_probe(device, dropout, train_steps=200, lockstep_steps=600):
         "cpu_oracle": {"recall_at_20": round(rec_o / n_o, 4), "ndcg_at_20": round(ndcg_o / n_o, 4),
                        "final_train_loss": round(float(ref["loss"].detach()), 5)}}
     return res
+
+
+def recall_probe_dp(device, dropout, world, rank, train_steps=200):
+    """N > 1 form of part (a) of `recall_probe`: the benchmarked configuration trained data-parallel (every rank its own
+    Markov sessions, the same gradient exchange as the timed steps), evaluated on held-out sessions SHARDED over the
+    ranks; `compute_metrics()` all-reduces the (sum, count) state, so the value is the mean over every rank's label rows
+    (the reference cat-syncs its torchmetrics state: ranking_metric.py:50, trainer.py:519-525).  Collective: every rank
+    runs it."""
+    tr, schema, model, dense, tables, opt = build(device, dropout, lr=2e-3)
+    masking = model.input_features.masking
+    masking.seed, model.transformer_block.transformer.seed = rank_seeds(rank)
+    reducer, _hook = setup_data_parallel(tr, model, dense, tables, world)
+    active = 1 + torch.arange(2000) * (V_ITEMS // 2000)
+    model.train()
+    t0 = time.perf_counter()
+    for i in range(train_steps):
+        x = {"item_id": markov_sessions(BATCH, SEQ, active, 10 + i * world + rank).to(device)}
+        out = model(x, training=True)
+        out["loss"].backward()
+        reducer.reduce_all()
+        opt.step(grad_scale=reducer.grad_scale)
+    model.eval()
+    task = model.prediction_task
+    task.reset_metrics()
+    with torch.no_grad():
+        for j in range(4):
+            x = {"item_id": markov_sessions(BATCH, SEQ, active, 900_000 + j * world + rank).to(device)}
+            task.evaluate_ranks(model.heads[0].body(x, training=False, testing=True))
+    mt = task.compute_metrics()             # all-reduce over the ranks
+    torch.cuda.synchronize()
+    return {"hip_bench_config_dp": {
+        "recall_at_20": round(mt["next-item/recall_at_20"], 4), "ndcg_at_20": round(mt["next-item/ndcg_at_20"], 4),
+        "avg_precision_at_20": round(mt["next-item/avg_precision_at_20"], 4), "train_steps": train_steps,
+        "global_batch": BATCH * world, "eval_sessions": 4 * BATCH * world,
+        "final_train_loss_rank0": round(float(out["loss"].detach()), 4), "seconds": round(time.perf_counter() - t0, 2),
+        "note": "metric state (sum, count) all-reduced over the ranks in compute_metrics"}}
 
 
 # --------------------------------------------------------------------------------------------- launch
@@ -593,6 +684,15 @@ def main():
         traffic_src = tj["source"]
     gj = committed("pmc_traffic_gather")
 
+    # bytes every rank hands to the collectives per step (payload, not wire traffic: a ring all-reduce moves
+    # 2 (N-1)/N of it per link): the dense bucket, the tables bucket (tied head: dense d W) and the row-sparse exchange
+    sparse = getattr(reducer, "sparse", None)
+    comm = {"dense_bucket_bytes": int(dense.grad.numel() * 4) if world > 1 else 0,
+            "tables_bucket_bytes": int(tables.grad.numel() * 4) if world > 1 and reducer.tables is not None else 0,
+            "row_sparse_gathered_bytes": int((sparse.bytes_exchanged if sparse is not None else 0) //
+                                             max(1, n_pre + args.warmup + args.steps)),
+            "note": "per rank and step; the tables all-reduce starts right after the head's backward and runs under the "
+                    "transformer body's backward; the dense bucket and the (ids, rows) all-gather are exposed"}
     if rank == 0:
         res = {
             "metric": "training sessions/sec (XLNet 4x128, 100k items, seq 20, MLM, tied full softmax) + Recall@20",
@@ -630,7 +730,9 @@ def main():
                          "fp32_matrix_core_form": {"avg_launch_ms": round(gemm_ms_f32, 4),
                                                    "achieved": round(flops / (gemm_ms_f32 * 1e-3) / 1e12, 2),
                                                    "frac": round(flops / (gemm_ms_f32 * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)},
-                         "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                         "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "traffic_source": None if traffic_src is None else
+                         "committed (not measured in this run; scaled by the label rows): " + traffic_src,
                          "algorithmic_bytes": int(4 * (N_m * D_MODEL + W.shape[0] * D_MODEL + N_m * W.shape[0])),
                          "avg_launch_ms": round(gemm_ms, 4), "flops_per_launch": flops,
                          "executed_flops_per_launch": executed},
@@ -647,6 +749,16 @@ def main():
                                     "traffic": None if gj is None else gj.get("traffic_bytes_per_launch_8192"),
                                     "traffic_source": None if gj is None else gj.get("source")}},
         }
+        res["comm"] = comm
+    # Recall@20, the other half of the metric.  N > 1: a collective probe, every rank takes part (T4R_BENCH_DP_RECALL=0
+    # skips it on all ranks alike)
+    probe = None
+    if not args.no_recall and world > 1 and os.environ.get("T4R_BENCH_DP_RECALL", "1") == "1":
+        del model, opt, dense, tables, reducer, train_step, batches
+        probe = recall_probe_dp(device, args.dropout, world, rank)
+    if rank == 0:
+        if probe is not None:
+            res["recall_at_20"] = probe
         if not args.no_recall and world == 1:
             try:
                 res["recall_at_20"] = recall_probe(device, args.dropout)
@@ -654,6 +766,12 @@ def main():
                 res["recall_at_20"] = {"error": f"{type(exc).__name__}: {exc}"}
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args.dropout)
+            try:        # the reference itself beside the port: run here when its tree exists, else the committed number
+                ref = cpu_baseline_reference(args.dropout)
+            except Exception as exc:      # noqa: BLE001
+                ref = {"error": f"{type(exc).__name__}: {exc}"}
+            if ref is not None:
+                res["cpu_baseline"]["reference_verbatim"] = ref
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -608,7 +608,7 @@ def test_fused_eval_ranks_equal_materialised_metrics():
     assert torch.equal(b["labels"], out["labels"])
     for k in a:
         assert torch.equal(a[k], b["metrics"][k]), k
-    assert agg_a == agg_b and len(agg_a) == 4
+    assert agg_a == agg_b and len(agg_a) == 6       # NDCG, AvgPrecision, Recall @ 10, 20 (the reference default set)
 
 
 # ------------------------------------------------------------------------------------------

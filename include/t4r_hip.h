@@ -322,6 +322,34 @@ int t4r_add_pos_fwd(void* stream, const float* x, const float* pos, const float*
                     int B, int L, int D);
 int t4r_add_pos_bwd(void* stream, const float* dy, float* d_pos, int B, int L, int D);
 
+/* Fused feed-forward block of the XLNet layer (token-tile-stationary, csrc/xlnet_fused.hip; d_model 32 | 64 | 128,
+ * d_inner = 4 d_model): ONE launch per direction instead of the GEMM / activation / LayerNorm chain; fp32-accurate
+ * products on the bf16 matrix cores (exact three-way operand cuts, six partial products, fp32 accumulation).
+ * replaces: HF modeling_xlnet.py:297-305 XLNetFeedForward.forward -- layer_1, gelu(erf), dropout, layer_2, dropout,
+ *           layer_norm(output + inp) -- and its backward (ATen addmm / gelu_backward / native_layer_norm_backward).
+ * prepare: cuts W1 [4D, D] and W2 [D, 4D] into bf16 planes (both orientations) in `planes`
+ *      (t4r_xlnet_ff_planes_floats(D) floats); once per weight update, shared by fwd and bwd.
+ * fwd: h1 [T, D] -> hout [T, D].  Training form: ffpre, ffact [T, 4D], ffout [T, D], mean, rstd [T] are all given and
+ *      saved for the backward, the Philox masks of the two dropout sites are keyed (seed, ctr_act / ctr_out), element
+ *      index row * width + col as everywhere.  Inference form: all five NULL and drop_p = 0.
+ * bwd: dy [T, D] = d loss / d hout -> dh1 [T, D] (overwritten), plus the rows the two weight gradients contract over,
+ *      dffout [T, D] and dpre [T, 4D] (overwritten; d W2 += dffout^T @ ffact, d W1 += dpre^T @ h1 are issued by the
+ *      caller); d_gamma, d_beta, d_b2 [D], d_b1 [4D] are ACCUMULATED (per-workgroup partial sums + a reduction, no
+ *      atomics).  part: t4r_xlnet_ff_bwd_part_floats(T, D) floats of scratch. */
+int t4r_xlnet_fused_supported(int D);
+long t4r_xlnet_ff_bwd_part_floats(long T, int D);
+long t4r_xlnet_ff_planes_floats(int D);
+int t4r_xlnet_ff_prepare(void* stream, const float* W1, const float* W2, int D, float* planes);
+int t4r_xlnet_ff_fwd(void* stream, const float* h1, const float* planes, const float* b1, const float* b2,
+                     const float* gamma, const float* beta, float* ffpre, float* ffact, float* ffout, float* mean,
+                     float* rstd, float* hout, int T, int D, float eps, float drop_p, unsigned long long seed,
+                     unsigned long long ctr_act, unsigned long long ctr_out);
+int t4r_xlnet_ff_bwd(void* stream, const float* dy, const float* ffout, const float* h1, const float* mean,
+                     const float* rstd, const float* gamma, const float* ffpre, const float* planes, float* dh1,
+                     float* dffout, float* dpre, float* d_gamma, float* d_beta, float* d_b2, float* d_b1, float* part,
+                     int T, int D, float drop_p, unsigned long long seed, unsigned long long ctr_act,
+                     unsigned long long ctr_out);
+
 /* params / grads: host arrays of 15 device pointers in the order
  *   q, k, v, o, r [D,n,dh] ; r_w_bias, r_r_bias [n,dh] ; rel_attn.layer_norm.{weight,bias} ;
  *   ff.layer_1.{weight [4D,D], bias} ; ff.layer_2.{weight [D,4D], bias} ; ff.layer_norm.{weight,bias}

@@ -69,6 +69,12 @@ _SIGS = {
     "t4r_xlnet_attn_fwd": ("i", "ppppppppp" + "iiii" + "ifQQ" + "p"),
     "t4r_xlnet_attn_bwd_ws_floats": ("l", "iiii"),
     "t4r_xlnet_attn_bwd": ("i", "p" * 17 + "iiii" + "ifQQ" + "p"),
+    "t4r_xlnet_fused_supported": ("i", "i"),
+    "t4r_xlnet_ff_bwd_part_floats": ("l", "li"),
+    "t4r_xlnet_ff_planes_floats": ("l", "i"),
+    "t4r_xlnet_ff_prepare": ("i", "pppip"),
+    "t4r_xlnet_ff_fwd": ("i", "p" + "pppppp" + "pppppp" + "iiff" + "QQQ"),
+    "t4r_xlnet_ff_bwd": ("i", "p" + "pppppppp" + "pppppppp" + "iif" + "QQQ"),
     "t4r_xlnet_layer_ws_floats": ("l", "iiiii"),
     "t4r_xlnet_layer_bwd_ws_floats": ("l", "iiiii"),
     "t4r_xlnet_layer_fwd": ("i", "pppppp" + "iiiif" + "fQQi" + "pp"),

@@ -40,12 +40,35 @@ __device__ __forceinline__ int wave_sum_i(int v) {
     return v;
 }
 
+// erf(x), branch-free, <= 1 ulp (two minimax fits, N. Juffa's single-precision erff: |x| <= 0.927734375 an odd
+// polynomial in x, beyond it 1 - exp(p(|x|)) -- both evaluated, one selected: ~20 VALU ops, no divergent branches;
+// the ocml erff is a three-way branch per element, ~3x the issue slots inside a GEMM epilogue).
+__device__ __forceinline__ float erf_bf(float a) {
+    const float t = fabsf(a), s = a * a;
+    float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+    const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+    r = fmaf(r, s, u);
+    r = fmaf(r, t, -1.06777877e-1f);
+    r = fmaf(r, t, -6.34846687e-1f);
+    r = fmaf(r, t, -1.28717512e-1f);
+    r = fmaf(r, t, -t);
+    r = 1.0f - __expf(r);               // r <= -0.92 here when selected: exp2(r log2 e) is good to ~2e-7 relative
+    r = copysignf(r, a);
+    float q = -5.96761703e-4f;
+    q = fmaf(q, s, 4.99119423e-3f);
+    q = fmaf(q, s, -2.67681349e-2f);
+    q = fmaf(q, s, 1.12819925e-1f);
+    q = fmaf(q, s, -3.76125336e-1f);
+    q = fmaf(q, s, 1.28379166e-1f);
+    q = fmaf(q, a, a);
+    return t > 0.927734375f ? r : q;
+}
 // exact (erf) GELU, as torch.nn.functional.gelu(approximate="none") / HF ACT2FN["gelu"]
 __device__ __forceinline__ float gelu_erf(float x) {
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    return 0.5f * x * (1.0f + erf_bf(x * 0.70710678118654752440f));
 }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float cdf = 0.5f * (1.0f + erf_bf(x * 0.70710678118654752440f));
     const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
     return cdf + x * pdf;
 }
@@ -72,6 +95,25 @@ struct Philox {
         return make_uint4(c0, c1, c2, c3);
     }
 };
+// The same block function in resumable form: a kernel that hides its Philox work in the shadow of matrix instructions
+// evaluates it a round or two at a time (csrc/xlnet_fused.hip).  philox_begin + 10 x philox_round == Philox::operator().
+struct PhiloxState { uint32_t c0, c1, c2, c3, a, b; };
+__device__ __forceinline__ PhiloxState philox_begin(uint64_t seed, uint64_t ctr_lo, uint64_t ctr_hi) {
+    PhiloxState s;
+    s.c0 = (uint32_t)ctr_lo; s.c1 = (uint32_t)(ctr_lo >> 32); s.c2 = (uint32_t)ctr_hi; s.c3 = (uint32_t)(ctr_hi >> 32);
+    s.a = (uint32_t)seed; s.b = (uint32_t)(seed >> 32);
+    return s;
+}
+__device__ __forceinline__ void philox_round(PhiloxState& s) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * s.c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * s.c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ s.c1 ^ s.a;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ s.c3 ^ s.b;
+    const uint32_t n3 = (uint32_t)p0;
+    s.c0 = n0; s.c1 = n1; s.c2 = n2; s.c3 = n3;
+    s.a += 0x9E3779B9u; s.b += 0xBB67AE85u;
+}
 __device__ __forceinline__ float u32_to_unit(uint32_t x) {  // [0,1)
     return (float)(x >> 8) * (1.0f / 16777216.0f);
 }

@@ -1,0 +1,569 @@
+// Token-tile-stationary fused kernels of the XLNet layer (round 3): one workgroup owns a tile of 16*R token rows
+// and runs a whole sub-block of the layer on it, activations never leaving the CU between the GEMMs.
+//
+//   xlnet_ff_fwd_kernel   h1 -> FF1 + bias + GELU(erf) + dropout -> FF2 + bias + dropout + residual -> LayerNorm
+//                         (HF modeling_xlnet.py XLNetFeedForward.forward :297-305; five launches of the chain in
+//                          xlnet_layer.hip: two GEMMs with epilogues, LayerNorm -- and no second trip of the
+//                          [T, 4D] activation through HBM)
+//   xlnet_ff_bwd_kernel   d h2 -> LayerNorm backward -> d ffout -> FF2 dX -> GELU' / dropout -> FF1 dX + residual
+//                         (+ per-workgroup partial sums of d gamma, d beta, d b2, d b1; the weight gradients stay
+//                          separate token-reducing GEMMs fed by the d ffout / d pre rows this kernel writes)
+//
+// Arithmetic: fp32-accurate products on the BF16 matrix cores -- every operand is cut into three bf16 planes
+// (x = hi + mid + lo exactly, round-to-nearest cuts) and the six largest partial products are accumulated in fp32 by
+// v_mfma_f32_16x16x32_bf16 (the scheme of gemm_kernel.h PREC 1 / head_split.hip: error at the level of an fp32 FMA chain).
+// The WEIGHTS are cut once per layer call by split_planes_kernel (also in transposed order for the backward), the token
+// tile once when it enters LDS, the activation chunk once in the producing epilogue.
+// Why not the fp32 matrix instruction (the first version of this file used v_mfma_f32_16x16x4_f32): measured on this chip
+// (tools/mfma_valu_overlap.hip) VALU work does NOT issue in the shadow of matrix instructions of the same SIMD -- fp32 MFMA
+// + VALU = the sum of both, bf16 MFMA + VALU nearly so -- and the GELU / Philox epilogue here is ~40 % of the fp32 MFMA time:
+// 77 us per forward launch however finely the epilogue was interleaved.  So the total of (matrix cycles + VALU cycles) is
+// what counts, and six bf16 MFMAs (6 x 16 cycles per 16x16x32) cost 2.7x less than the eight fp32 ones (8 x 32).
+//
+// The products are formed TRANSPOSED -- the weight is the MFMA "A" operand (m = output feature), the token tile is "B"
+// (n = token) -- so that
+//   * an accumulator lane holds FOUR CONSECUTIVE FEATURES of ONE token: bias / GELU / Philox mask (one block = four
+//     consecutive columns of a row, the indexing of every other kernel here) / residual / stores are all 16-byte;
+//   * NW = D/16 waves split the FEATURE dimension: every wave works on all 16*R tokens, so 20 480 tokens on 256 CUs
+//     (80 per CU, R = 5) load every SIMD equally -- splitting tokens over waves cannot (20 tokens per SIMD);
+//   * each weight tile is fetched once per workgroup (L2-resident: 1.5 MB of planes per layer for 256 workgroups).
+// Operand fragments (16x16x32: lane (i = lane & 15, kg = lane >> 4) holds k = 32 s + 8 kg .. + 7) are one 16-byte load
+// per plane from a k-contiguous row: global for the weight planes, LDS for the token planes.
+// LDS: token planes [3][16R][D + 16] bf16 (B operand of FF1; the 32-byte row pad makes the 16-byte fragment reads of a
+// ds_read_b128 lane group hit 16 distinct bank quads: SQ_LDS_BANK_CONFLICT was 46 % of the LDS cycles with D + 8),
+// activation-chunk planes [3][16R][D + 16] (written by the
+// FF1 epilogue, B operand of FF2; d_inner = 4 D is walked in four chunks of D, two barriers per chunk).
+#include "t4r_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+int t4r_reduce_partials_launch(hipStream_t st, const float* part, int nblocks, float* o0, int n0, int a0,
+                               float* o1, int n1, int a1, float* o2, int n2, int a2);   // elementwise.hip
+
+__device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ u32x4 ldq(const uint16_t* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ f32x4 mfma_bf(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// two fp32 values -> one packed bf16 pair per plane (low half = first value), x = hi + mid + lo exactly; every cut rounds
+// to nearest even (v_cvt_pk_bf16_f32) so that the dropped 2^-24 terms carry no systematic sign (gemm_kernel.h cvt_pair)
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+    const f32x2v v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2v));
+}
+__device__ __forceinline__ void cut3(float a, float b, uint32_t (&w)[3]) {
+    w[0] = pk_bf16(a, b);
+    const float ra = a - __uint_as_float(w[0] << 16), rb = b - __uint_as_float(w[0] & 0xffff0000u);
+    w[1] = pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(w[1] << 16), sb = rb - __uint_as_float(w[1] & 0xffff0000u);
+    w[2] = pk_bf16(sa, sb);
+}
+// the six partial products kept (planes 0 hi, 1 mid, 2 lo), smallest first
+#define T4R_SIX(X) X(1, 1) X(2, 0) X(0, 2) X(1, 0) X(0, 1) X(0, 0)
+
+// ------------------------------------------------------------------------------------------------ weight planes
+// src [rows][cols] fp32 -> dst planes [3][rows][cols] bf16 and (dstT != NULL) transposed planes [3][cols][rows].
+// One thread per pair of consecutive columns.
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, int rows, int cols,
+                                                            uint16_t* __restrict__ dst, uint16_t* __restrict__ dstT) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;         // pair index
+    const long npair = (long)rows * cols / 2;
+    if (i >= npair) return;
+    const int r = (int)(i / (cols / 2)), c = (int)(i % (cols / 2)) * 2;
+    const float2 v = *reinterpret_cast<const float2*>(src + (long)r * cols + c);
+    uint32_t w[3];
+    cut3(v.x, v.y, w);
+    const long plane = (long)rows * cols;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        *reinterpret_cast<uint32_t*>(dst + pl * plane + (long)r * cols + c) = w[pl];
+        if (dstT) {
+            dstT[pl * plane + (long)c * rows + r] = (uint16_t)(w[pl] & 0xffffu);
+            dstT[pl * plane + (long)(c + 1) * rows + r] = (uint16_t)(w[pl] >> 16);
+        }
+    }
+}
+
+struct FFPlanes {      // bf16 planes of one layer's feed-forward weights (t4r_xlnet_ff_prepare)
+    const uint16_t *W1p, *W2p, *W1Tp, *W2Tp;    // [3][4D][D], [3][D][4D], [3][D][4D] (= W1^T), [3][4D][D] (= W2^T)
+};
+static FFPlanes carve_planes(const void* base, int D) {
+    const uint16_t* b = (const uint16_t*)base;
+    const long m = 3L * 4 * D * D;
+    return FFPlanes{b, b + m, b + 2 * m, b + 3 * m};
+}
+
+struct FFFwdParams {
+    const float *h1, *b1, *b2, *gamma, *beta;
+    FFPlanes w;
+    float *ffpre, *ffact, *ffout, *mean, *rstd, *hout;     // ffpre / ffact / ffout / mean / rstd: all given (training) or all NULL
+    int T;
+    float eps;
+    DropCfg drop_act, drop_out;
+};
+
+// acc[r] += A_tile (16 features x D) . B_r (D x 16 tokens) for every token block r, three-plane operands, six products.
+// The weight fragment is requested one product ahead (load_a3: 3 D/32 16-byte loads from the L2-resident planes, issued
+// before the previous product / epilogue so that their latency never sits in front of the matrix instructions).
+// ap: plane 0 of the weight matrix at this lane's row and k offset 8 kg (row-major, k contiguous), apl: plane stride;
+// bp: plane 0 of the LDS token planes at this lane's token row offset + 8 kg, bpl: plane stride, blocks 16 * P rows apart
+template <int D>
+struct AFrag { u32x4 v[D / 32][3]; };
+#ifndef T4R_FF_PREFETCH
+#define T4R_FF_PREFETCH 0   /* A/B, same box: fragments requested one product ahead cost 67 us per forward launch against 60 (237 VGPRs instead of 143) */
+#endif
+template <int D>
+__device__ __forceinline__ void load_a3(AFrag<D>& a, const uint16_t* __restrict__ ap, long apl) {
+#pragma unroll
+    for (int s = 0; s < D / 32; ++s)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) a.v[s][pl] = ldq(ap + pl * apl + 32 * s);
+}
+template <int D, int R, int P>
+__device__ __forceinline__ void product3(const AFrag<D>& a, const uint16_t* bp, int bpl, f32x4 (&acc)[R]) {
+    constexpr int KS = D / 32;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        u32x4 b[R][3];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) b[r][pl] = ldq(bp + pl * bpl + r * 16 * P + 32 * s);
+#define T4R_PROD(PA, PB)                                                        \
+        _Pragma("unroll") for (int r = 0; r < R; ++r) acc[r] = mfma_bf(a.v[s][PA], b[r][PB], acc[r]);
+        T4R_SIX(T4R_PROD)
+#undef T4R_PROD
+    }
+}
+
+// FULL: every row of the tile is a token; TRAIN: the backward's activations are saved and the Philox masks evaluated
+// (p = 0 keeps everything); !TRAIN (inference: nothing saved, p = 0): neither.
+template <int D, int R, bool FULL, bool TRAIN>
+__device__ __forceinline__ void ff_fwd_body(const FFFwdParams& p, uint16_t* smem) {
+    constexpr int NW = D / 16, NT = NW * 64, RT = 16 * R, PH = D + 16, PLN = RT * PH, DI = 4 * D;
+    uint16_t* sh_h = smem;                                   // [3][RT][PH] token planes
+    uint16_t* sh_a = sh_h + 3 * PLN;                         // [3][RT][PH] activation-chunk planes
+    float* sh_red = reinterpret_cast<float*>(sh_a + 3 * PLN);   // [2][NW][RT]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, g = lane >> 4;
+    const long t0 = (long)blockIdx.x * RT;
+    for (int i = tid; i < RT * (D / 4); i += NT) {
+        const int row = i / (D / 4), c4 = (i % (D / 4)) * 4;
+        const long t = FULL ? t0 + row : min(t0 + row, (long)p.T - 1);
+        const float4 v = ld4(p.h1 + t * D + c4);
+        uint32_t w0[3], w1[3];
+        cut3(v.x, v.y, w0);
+        cut3(v.z, v.w, w1);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            *reinterpret_cast<uint2*>(sh_h + pl * PLN + row * PH + c4) = make_uint2(w0[pl], w1[pl]);
+    }
+    __syncthreads();
+    f32x4 acc2[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc2[r] = zero4();
+    const int boff = n * PH + 8 * g;                          // this lane's B-fragment offset inside a token block
+    const long wpl = (long)DI * D;                            // plane stride of every weight-plane matrix (4 D * D)
+    const uint16_t* w1p = p.w.W1p + (long)(16 * w + n) * D + 8 * g;       // + c D D: chunk c
+    const uint16_t* w2p = p.w.W2p + (long)(16 * w + n) * DI + 8 * g;      // + c D
+    AFrag<D> a1, a2;
+    load_a3<D>(a1, w1p, wpl);
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {
+        f32x4 acc1[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc1[r] = zero4();
+#if T4R_FF_PREFETCH
+        load_a3<D>(a2, w2p + c * D, wpl);                     // FF2's fragment: in flight under FF1 and the epilogue
+        product3<D, R, PH>(a1, sh_h + boff, PLN, acc1);
+        load_a3<D>(a1, w1p + (long)min(c + 1, 3) * D * D, wpl);   // next chunk's FF1 fragment: in flight under the epilogue and FF2
+#else
+        load_a3<D>(a1, w1p + (long)c * D * D, wpl);
+        product3<D, R, PH>(a1, sh_h + boff, PLN, acc1);
+#endif
+        // epilogue of chunk c: lane = (token r*16 + n, features d0 .. d0 + 3 of d_inner)
+        const int d0 = c * D + 16 * w + 4 * g;
+        const float4 bias = ld4(p.b1 + d0);
+        if (c > 0) __syncthreads();                           // every wave has finished reading the previous chunk's planes
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const long t = t0 + r * 16 + n;
+            float4 v = make_float4(acc1[r][0] + bias.x, acc1[r][1] + bias.y, acc1[r][2] + bias.z, acc1[r][3] + bias.w);
+            const bool in = FULL || t < p.T;
+            if (TRAIN && in) st4(p.ffpre + t * DI + d0, v);
+            v = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
+            if (TRAIN) {
+                const float4 m = drop_scale4(p.drop_act, (unsigned long long)t * DI + d0);
+                v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+            }
+            if (TRAIN && in) st4(p.ffact + t * DI + d0, v);
+            uint32_t w0[3], w1[3];
+            cut3(v.x, v.y, w0);
+            cut3(v.z, v.w, w1);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                *reinterpret_cast<uint2*>(sh_a + pl * PLN + (r * 16 + n) * PH + 16 * w + 4 * g) = make_uint2(w0[pl], w1[pl]);
+        }
+        __syncthreads();
+#if !T4R_FF_PREFETCH
+        load_a3<D>(a2, w2p + c * D, wpl);
+#endif
+        product3<D, R, PH>(a2, sh_a + boff, PLN, acc2);
+    }
+    // epilogue 2: + b2, dropout, + residual, LayerNorm over the D features of a token (split over the NW waves)
+    const int f0 = 16 * w + 4 * g;
+    const float4 bias2 = ld4(p.b2 + f0), gam = ld4(p.gamma + f0), bet = ld4(p.beta + f0);
+    float4 x[R];
+    float sum[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long t = t0 + r * 16 + n;
+        const long tc = FULL ? t : min(t, (long)p.T - 1);
+        float4 v = make_float4(acc2[r][0] + bias2.x, acc2[r][1] + bias2.y, acc2[r][2] + bias2.z, acc2[r][3] + bias2.w);
+        if (TRAIN && (FULL || t < p.T)) st4(p.ffout + t * D + f0, v);
+        if (TRAIN) {
+            const float4 m = drop_scale4(p.drop_out, (unsigned long long)t * D + f0);
+            v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+        }
+        const float4 hres = ld4(p.h1 + tc * D + f0);          // the residual in fp32 (L2 hit: this tile was just read)
+        v.x += hres.x; v.y += hres.y; v.z += hres.z; v.w += hres.w;
+        x[r] = v;
+        float s = (v.x + v.y) + (v.z + v.w);
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        sum[r] = s;
+    }
+    if (g == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) sh_red[w * RT + r * 16 + n] = sum[r];
+    }
+    __syncthreads();
+    float mu[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) s += sh_red[ww * RT + r * 16 + n];
+        mu[r] = s * (1.0f / D);
+        const float dx = x[r].x - mu[r], dy = x[r].y - mu[r], dz = x[r].z - mu[r], dw = x[r].w - mu[r];
+        float q = (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        q += __shfl_xor(q, 16, 64);
+        q += __shfl_xor(q, 32, 64);
+        sum[r] = q;
+    }
+    float* sh_red2 = sh_red + NW * RT;
+    if (g == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) sh_red2[w * RT + r * 16 + n] = sum[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long t = t0 + r * 16 + n;
+        float q = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) q += sh_red2[ww * RT + r * 16 + n];
+        const float rs = rsqrtf(q * (1.0f / D) + p.eps);
+        if (FULL || t < p.T) {
+            st4(p.hout + t * D + f0, make_float4((x[r].x - mu[r]) * rs * gam.x + bet.x, (x[r].y - mu[r]) * rs * gam.y + bet.y,
+                                                 (x[r].z - mu[r]) * rs * gam.z + bet.z, (x[r].w - mu[r]) * rs * gam.w + bet.w));
+            if (TRAIN && w == 0 && g == 0) { p.mean[t] = mu[r]; p.rstd[t] = rs; }
+        }
+    }
+}
+
+template <int D, int R>
+__global__ __launch_bounds__(D * 4) void xlnet_ff_fwd_kernel(FFFwdParams p) {
+    extern __shared__ uint16_t smem16[];
+    // whole tiles run the unpredicated body; only the last workgroup of a ragged launch pays for the row guards
+    const bool full = (long)(blockIdx.x + 1) * 16 * R <= p.T;
+    if (p.ffpre != nullptr) {
+        if (full) ff_fwd_body<D, R, true, true>(p, smem16);
+        else ff_fwd_body<D, R, false, true>(p, smem16);
+    } else {
+        if (full) ff_fwd_body<D, R, true, false>(p, smem16);
+        else ff_fwd_body<D, R, false, false>(p, smem16);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------- backward
+struct FFBwdParams {
+    const float *dy, *ffout, *h1, *mean, *rstd, *gamma, *ffpre;
+    FFPlanes w;
+    float *dh1, *dffout, *dpre;       // [T, D], [T, D], [T, 4D]
+    float *partA, *partB;             // per-workgroup partial sums [nWG][3D] (d gamma | d beta | d b2), [nWG][4D] (d b1)
+    int T;
+    DropCfg drop_act, drop_out;
+};
+
+template <int D, int R>
+__global__ __launch_bounds__(D * 4) void xlnet_ff_bwd_kernel(FFBwdParams p) {
+    constexpr int NW = D / 16, RT = 16 * R, PH = D + 16, PLN = RT * PH, DI = 4 * D;
+    extern __shared__ uint16_t smem16[];
+    uint16_t* sh_dfo = smem16;                                  // [3][RT][PH]  d ffout planes (B operand of the FF2 dX product)
+    uint16_t* sh_dp = sh_dfo + 3 * PLN;                         // [3][RT][PH]  d pre chunk planes (B operand of the FF1 dX product)
+    float* sh_part = reinterpret_cast<float*>(sh_dp + 3 * PLN);    // [NW][3][D]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, g = lane >> 4;
+    const long t0 = (long)blockIdx.x * RT;
+    // ---- phase A: LayerNorm backward, one token row per wave at a time (lane = two consecutive features)
+    {
+        const int c0 = lane * 2;
+        const bool act_lane = c0 < D;
+        float gam[2], pg[2], pb[2], pb2[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { gam[e] = act_lane ? p.gamma[c0 + e] : 0.f; pg[e] = pb[e] = pb2[e] = 0.f; }
+        for (int row = w; row < RT; row += NW) {
+            const long t = t0 + row;
+            float dxa[2] = {0.f, 0.f}, dx[2] = {0.f, 0.f};
+            if (t < p.T) {      // wave-uniform
+                const float mu = p.mean[t], rs = p.rstd[t];
+                float xh[2] = {0.f, 0.f}, gg[2] = {0.f, 0.f}, dyv[2] = {0.f, 0.f}, m[2] = {1.f, 1.f};
+                float s1 = 0.f, s2 = 0.f;
+                if (act_lane) {
+                    drop_scale_vec<2>(p.drop_out, (unsigned long long)t * D + c0, true, m);
+                    const float2 fo = *reinterpret_cast<const float2*>(p.ffout + t * D + c0);
+                    const float2 hh = *reinterpret_cast<const float2*>(p.h1 + t * D + c0);
+                    const float2 dd = *reinterpret_cast<const float2*>(p.dy + t * D + c0);
+                    const float xv[2] = {fo.x * m[0] + hh.x, fo.y * m[1] + hh.y};
+                    dyv[0] = dd.x; dyv[1] = dd.y;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        xh[e] = (xv[e] - mu) * rs;
+                        gg[e] = dyv[e] * gam[e];
+                        s1 += gg[e];
+                        s2 += gg[e] * xh[e];
+                    }
+                }
+                s1 = wave_sum(s1) * (1.0f / D);
+                s2 = wave_sum(s2) * (1.0f / D);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    dx[e] = act_lane ? rs * (gg[e] - s1 - xh[e] * s2) : 0.f;
+                    dxa[e] = dx[e] * m[e];
+                    pg[e] += dyv[e] * xh[e];
+                    pb[e] += dyv[e];
+                    pb2[e] += dxa[e];
+                }
+                if (act_lane) {
+                    // residual part of d h1 (the FF1 dX product is added at the end) and the rows of the FF2 weight gradient
+                    *reinterpret_cast<float2*>(p.dh1 + t * D + c0) = make_float2(dx[0], dx[1]);
+                    *reinterpret_cast<float2*>(p.dffout + t * D + c0) = make_float2(dxa[0], dxa[1]);
+                }
+            }
+            if (act_lane) {
+                uint32_t wd[3];
+                cut3(dxa[0], dxa[1], wd);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint32_t*>(sh_dfo + pl * PLN + row * PH + c0) = wd[pl];
+            }
+        }
+        if (act_lane) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                sh_part[(w * 3 + 0) * D + c0 + e] = pg[e];
+                sh_part[(w * 3 + 1) * D + c0 + e] = pb[e];
+                sh_part[(w * 3 + 2) * D + c0 + e] = pb2[e];
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 3 * D; i += NW * 64) {
+        float s = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) s += sh_part[ww * 3 * D + i];
+        p.partA[(long)blockIdx.x * 3 * D + i] = s;
+    }
+    // ---- phase B: d pre = (d ffout @ W2) * gelu'(pre) * mask, chunk by chunk; d h1 += d pre @ W1
+    f32x4 acc3[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc3[r] = zero4();
+    const int boff = n * PH + 8 * g;
+    const long wpl = (long)DI * D;
+    const uint16_t* w2tp = p.w.W2Tp + (long)(16 * w + n) * D + 8 * g;     // + c D D: chunk c
+    const uint16_t* w1tp = p.w.W1Tp + (long)(16 * w + n) * DI + 8 * g;    // + c D
+    AFrag<D> a2, a3;
+    load_a3<D>(a2, w2tp, wpl);
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {
+        const int d0 = c * D + 16 * w + 4 * g;
+        load_a3<D>(a3, w1tp + c * D, wpl);
+        float4 pre[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const long t = min(t0 + r * 16 + n, (long)p.T - 1);
+            pre[r] = ld4(p.ffpre + t * DI + d0);
+        }
+        f32x4 acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = zero4();
+        // d ff^T[d][token] = sum_f W2^T[d][f] d ffout[token][f]
+        product3<D, R, PH>(a2, sh_dfo + boff, PLN, acc);
+        load_a3<D>(a2, w2tp + (long)min(c + 1, 3) * D * D, wpl);
+        if (c > 0) __syncthreads();                           // the previous chunk's planes have been read by every wave
+        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const long t = t0 + r * 16 + n;
+            float4 v = make_float4(acc[r][0] * gelu_erf_grad(pre[r].x), acc[r][1] * gelu_erf_grad(pre[r].y),
+                                   acc[r][2] * gelu_erf_grad(pre[r].z), acc[r][3] * gelu_erf_grad(pre[r].w));
+            const float4 m = drop_scale4(p.drop_act, (unsigned long long)t * DI + d0);
+            v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+            if (t < p.T) st4(p.dpre + t * DI + d0, v);           // rows beyond T are exact zeros (d ffout rows are)
+            uint32_t w0[3], w1[3];
+            cut3(v.x, v.y, w0);
+            cut3(v.z, v.w, w1);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                *reinterpret_cast<uint2*>(sh_dp + pl * PLN + (r * 16 + n) * PH + 16 * w + 4 * g) = make_uint2(w0[pl], w1[pl]);
+            cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+        }
+        // d b1 partial: sum over the tile's tokens = over r (above) and over the 16 lanes n of a lane group
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            cs.x += __shfl_xor(cs.x, o, 64); cs.y += __shfl_xor(cs.y, o, 64);
+            cs.z += __shfl_xor(cs.z, o, 64); cs.w += __shfl_xor(cs.w, o, 64);
+        }
+        if (n == 0) st4(p.partB + (long)blockIdx.x * DI + d0, cs);
+        __syncthreads();
+        // d h1^T[k][token] += sum_{d in chunk} W1^T[k][d] d pre[token][d]
+        product3<D, R, PH>(a3, sh_dp + boff, PLN, acc3);
+    }
+    // d h1 = residual part (written in phase A by this workgroup, ordered by the barriers above) + d pre @ W1
+    const int k0 = 16 * w + 4 * g;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long t = t0 + r * 16 + n;
+        if (t < p.T) {
+            const float4 o = ld4(p.dh1 + t * D + k0);
+            st4(p.dh1 + t * D + k0, make_float4(o.x + acc3[r][0], o.y + acc3[r][1], o.z + acc3[r][2], o.w + acc3[r][3]));
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------- host side
+static int pick_r(long T) {
+    // smallest tile (fewest padded rows) whose grid still fits one residency of the 256 CUs; 5 beyond that
+    const long blocks16 = (T + 15) / 16;
+    if (blocks16 <= 256) return 1;
+    if (blocks16 <= 512) return 2;
+    if (blocks16 <= 768) return 3;
+    return 5;
+}
+
+extern "C" int t4r_xlnet_fused_supported(int D) { return D == 32 || D == 64 || D == 128; }
+extern "C" long t4r_xlnet_ff_bwd_part_floats(long T, int D) { return ((T + 15) / 16) * 7L * D; }
+// floats (4-byte units) of the weight-plane buffer of one layer: four matrices x three bf16 planes x 4 D^2 elements
+extern "C" long t4r_xlnet_ff_planes_floats(int D) { return 4L * 3 * 4 * D * D / 2; }
+
+// cuts W1 [4D, D] and W2 [D, 4D] into bf16 planes, in both orientations (forward and backward operand forms)
+extern "C" int t4r_xlnet_ff_prepare(void* stream, const float* W1, const float* W2, int D, float* planes) {
+    T4R_CHECK_ARG(t4r_xlnet_fused_supported(D), "xlnet_ff_prepare: d_model must be 32, 64 or 128");
+    T4R_CHECK_ARG(W1 && W2 && planes, "xlnet_ff_prepare: null pointer");
+    const FFPlanes f = carve_planes(planes, D);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned nb = (unsigned)((4L * D * D / 2 + 255) / 256);
+    hipLaunchKernelGGL(split_planes_kernel, dim3(nb), dim3(256), 0, st, W1, 4 * D, D, const_cast<uint16_t*>(f.W1p),
+                       const_cast<uint16_t*>(f.W1Tp));
+    hipLaunchKernelGGL(split_planes_kernel, dim3(nb), dim3(256), 0, st, W2, D, 4 * D, const_cast<uint16_t*>(f.W2p),
+                       const_cast<uint16_t*>(f.W2Tp));
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int D, int R>
+static int ff_fwd_launch(hipStream_t st, const FFFwdParams& p) {
+    constexpr int RT = 16 * R, PH = D + 16, NW = D / 16;
+    const size_t smem = (size_t)(6 * RT * PH) * 2 + (size_t)(2 * NW * RT) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)xlnet_ff_fwd_kernel<D, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr = true;
+    }
+    hipLaunchKernelGGL((xlnet_ff_fwd_kernel<D, R>), dim3((unsigned)((p.T + RT - 1) / RT)), dim3(D * 4), smem, st, p);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+template <int D, int R>
+static int ff_bwd_launch(hipStream_t st, const FFBwdParams& p) {
+    constexpr int RT = 16 * R, PH = D + 16, NW = D / 16;
+    const size_t smem = (size_t)(6 * RT * PH) * 2 + (size_t)(NW * 3 * D) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)xlnet_ff_bwd_kernel<D, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr = true;
+    }
+    hipLaunchKernelGGL((xlnet_ff_bwd_kernel<D, R>), dim3((unsigned)((p.T + RT - 1) / RT)), dim3(D * 4), smem, st, p);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+#define FUSED_DISPATCH(FN, D, R, ...)                                                           \
+    do {                                                                                        \
+        switch ((D) * 8 + (R)) {                                                                \
+            case 32 * 8 + 1: return FN<32, 1>(__VA_ARGS__);   case 32 * 8 + 2: return FN<32, 2>(__VA_ARGS__);   \
+            case 32 * 8 + 3: return FN<32, 3>(__VA_ARGS__);   case 32 * 8 + 5: return FN<32, 5>(__VA_ARGS__);   \
+            case 64 * 8 + 1: return FN<64, 1>(__VA_ARGS__);   case 64 * 8 + 2: return FN<64, 2>(__VA_ARGS__);   \
+            case 64 * 8 + 3: return FN<64, 3>(__VA_ARGS__);   case 64 * 8 + 5: return FN<64, 5>(__VA_ARGS__);   \
+            case 128 * 8 + 1: return FN<128, 1>(__VA_ARGS__); case 128 * 8 + 2: return FN<128, 2>(__VA_ARGS__); \
+            case 128 * 8 + 3: return FN<128, 3>(__VA_ARGS__); case 128 * 8 + 5: return FN<128, 5>(__VA_ARGS__); \
+        }                                                                                       \
+    } while (0)
+
+// Fused feed-forward block, forward.  h1 [T, D] -> hout [T, D]; saves ffpre / ffact [T, 4D], ffout [T, D], mean / rstd [T]
+// for the backward when the pointers are given (all or none).  planes: the buffer t4r_xlnet_ff_prepare filled.
+// replaces: HF modeling_xlnet.py:297-305 (layer_1, activation, dropout, layer_2, dropout, layer_norm(output + inp))
+extern "C" int t4r_xlnet_ff_fwd(void* stream, const float* h1, const float* planes, const float* b1, const float* b2,
+                                const float* gamma, const float* beta, float* ffpre, float* ffact, float* ffout, float* mean,
+                                float* rstd, float* hout, int T, int D, float eps, float drop_p, unsigned long long seed,
+                                unsigned long long ctr_act, unsigned long long ctr_out) {
+    if (T <= 0) return 0;
+    T4R_CHECK_ARG(t4r_xlnet_fused_supported(D), "xlnet_ff_fwd: d_model must be 32, 64 or 128");
+    T4R_CHECK_ARG(h1 && planes && b1 && b2 && gamma && beta && hout, "xlnet_ff_fwd: null pointer");
+    const bool train = ffpre != nullptr;
+    T4R_CHECK_ARG((ffact != nullptr) == train && (ffout != nullptr) == train && (mean != nullptr) == train &&
+                      (rstd != nullptr) == train, "xlnet_ff_fwd: ffpre, ffact, ffout, mean, rstd are saved together or not at all");
+    T4R_CHECK_ARG(train || drop_p == 0.f, "xlnet_ff_fwd: dropout needs the saved activations (training mode)");
+    FFFwdParams p{h1, b1, b2, gamma, beta, carve_planes(planes, D), ffpre, ffact, ffout, mean, rstd, hout, T, eps,
+                  make_drop(drop_p, seed, ctr_act), make_drop(drop_p, seed, ctr_out)};
+    const int R = pick_r(T);
+    FUSED_DISPATCH(ff_fwd_launch, D, R, (hipStream_t)stream, p);
+    t4r_set_error("xlnet_ff_fwd: no instantiation");
+    return -1;
+}
+
+// Fused feed-forward block, backward (input gradients + bias / LayerNorm parameter gradients; the two weight gradients
+// d W2 += d ffout^T @ ffact and d W1 += d pre^T @ h1 are token-reducing GEMMs the caller issues on the rows written here).
+//   dy [T, D] = d loss / d hout;  dh1 [T, D] (overwritten) = d loss / d h1;  dffout [T, D], dpre [T, 4D] (overwritten);
+//   d_gamma, d_beta, d_b2 [D], d_b1 [4D] ACCUMULATED;  part: t4r_xlnet_ff_bwd_part_floats(T, D) floats of scratch.
+extern "C" int t4r_xlnet_ff_bwd(void* stream, const float* dy, const float* ffout, const float* h1, const float* mean,
+                                const float* rstd, const float* gamma, const float* ffpre, const float* planes,
+                                float* dh1, float* dffout, float* dpre, float* d_gamma, float* d_beta,
+                                float* d_b2, float* d_b1, float* part, int T, int D, float drop_p,
+                                unsigned long long seed, unsigned long long ctr_act, unsigned long long ctr_out) {
+    if (T <= 0) return 0;
+    T4R_CHECK_ARG(t4r_xlnet_fused_supported(D), "xlnet_ff_bwd: d_model must be 32, 64 or 128");
+    T4R_CHECK_ARG(dy && ffout && h1 && mean && rstd && gamma && ffpre && planes && dh1 && dffout && dpre && part,
+                  "xlnet_ff_bwd: null pointer");
+    const int R = pick_r(T);
+    const int nwg = (T + 16 * R - 1) / (16 * R);
+    float* partA = part;
+    float* partB = part + (long)nwg * 3 * D;
+    FFBwdParams p{dy, ffout, h1, mean, rstd, gamma, ffpre, carve_planes(planes, D), dh1, dffout, dpre, partA, partB, T,
+                  make_drop(drop_p, seed, ctr_act), make_drop(drop_p, seed, ctr_out)};
+    hipStream_t st = (hipStream_t)stream;
+    auto launch = [&]() -> int {
+        FUSED_DISPATCH(ff_bwd_launch, D, R, st, p);
+        t4r_set_error("xlnet_ff_bwd: no instantiation");
+        return -1;
+    };
+    const int rc = launch();
+    if (rc != 0) return rc;
+    int rc2 = t4r_reduce_partials_launch(st, partA, nwg, d_gamma, D, 1, d_beta, D, 1, d_b2, D, 1);
+    if (rc2 != 0) return rc2;
+    return t4r_reduce_partials_launch(st, partB, nwg, d_b1, 4 * D, 1, nullptr, 0, 0, nullptr, 0, 0);
+}

@@ -43,6 +43,22 @@ int t4r_xlnet_attn_bwd(void*, const float*, const float*, const float*, const fl
                        float*, float*, float*, float*, int, int, int, int, int, float,
                        unsigned long long, unsigned long long, const int*);
 long t4r_xlnet_attn_bwd_ws_floats(int, int, int, int);
+// xlnet_fused.hip: token-tile-stationary feed-forward block (one launch forward, one backward)
+int t4r_xlnet_fused_supported(int D);
+long t4r_xlnet_ff_bwd_part_floats(long T, int D);
+long t4r_xlnet_ff_planes_floats(int D);
+int t4r_xlnet_ff_prepare(void*, const float*, const float*, int, float*);
+int t4r_xlnet_ff_fwd(void*, const float*, const float*, const float*, const float*, const float*, const float*,
+                     float*, float*, float*, float*, float*, float*, int, int, float, float,
+                     unsigned long long, unsigned long long, unsigned long long);
+int t4r_xlnet_ff_bwd(void*, const float*, const float*, const float*, const float*, const float*, const float*,
+                     const float*, const float*, float*, float*, float*, float*, float*, float*, float*,
+                     float*, int, int, float, unsigned long long, unsigned long long, unsigned long long);
+}
+// T4R_XLNET_FUSED=0 restores the launch chain (A/B timing); default: fused kernels where they exist (d_model 32/64/128)
+static bool use_fused(int D) {
+    static const int on = [] { const char* e = getenv("T4R_XLNET_FUSED"); return e ? atoi(e) : 1; }();
+    return on && t4r_xlnet_fused_supported(D);
 }
 
 // dropout sites of one layer (HF modeling_xlnet.py): pos_emb :1143 (model level, but the mask is per
@@ -64,7 +80,7 @@ enum { P_Q = 0, P_K, P_V, P_O, P_R, P_RWB, P_RRB, P_LN1W, P_LN1B, P_W1, P_B1, P_
        P_LN2B, P_COUNT };
 
 struct LayerWs {
-    float *qkv, *kr, *av, *lse, *ao, *mean1, *rstd1, *h1, *ffpre, *ffact, *ffout, *mean2, *rstd2, *pe_b;
+    float *qkv, *kr, *av, *lse, *ao, *mean1, *rstd1, *h1, *ffpre, *ffact, *ffout, *mean2, *rstd2, *pe_b, *planes;
     long total;
 };
 
@@ -91,6 +107,8 @@ static LayerWs carve(float* base, int B, int L, int D, int n, int per_batch_kr) 
     // dropout(pos_emb) per session, kept for the backward's d r contraction (21 MB per layer at C2:
     // with 288 GB of HBM saving beats regenerating it -- one launch less per layer)
     w.pe_b = per_batch_kr ? take((long)B * 2L * L * D) : nullptr;
+    // bf16 planes of the feed-forward weights (fused kernels: cut once in the forward, reused by the backward)
+    w.planes = t4r_xlnet_fused_supported(D) ? take(t4r_xlnet_ff_planes_floats(D)) : nullptr;
     w.total = o;
     return w;
 }
@@ -106,7 +124,7 @@ extern "C" long t4r_xlnet_layer_bwd_ws_floats(int B, int L, int D, int n_head, i
     return align4(3 * T * D) + align4(T * D) + align4(T * D) + align4(T * 4 * D) + align4(nkr) +
            align4(t4r_xlnet_attn_bwd_ws_floats(B, L, D, n_head)) + align4(t4r_colreduce_ws_floats(T, 4 * D)) +
            2 * align4(t4r_colreduce_ws_floats(T, 2 * D)) + align4(t4r_colreduce_ws_floats(T, D)) +
-           (dropout ? align4(T * D) : 0);
+           (dropout ? align4(T * D) : 0) + align4(T * D) + align4(t4r_xlnet_ff_bwd_part_floats(T, D));
 }
 
 #define RUN(call)                \
@@ -167,6 +185,12 @@ extern "C" int t4r_xlnet_layer_fwd(void* stream, const float* h, const float* po
                         nullptr, 0, 1, 0, 1, 0, 0, 0, nullptr));
     RUN(t4r_add_layernorm_fwd(stream, w.ao, h, params[P_LN1W], params[P_LN1B], w.h1, w.mean1, w.rstd1,
                               T, D, ln_eps, drop_p, seed, C(SITE_ATTN_OUT)));
+    if (use_fused(D)) {
+        RUN(t4r_xlnet_ff_prepare(stream, params[P_W1], params[P_W2], D, w.planes));
+        return t4r_xlnet_ff_fwd(stream, w.h1, w.planes, params[P_B1], params[P_B2], params[P_LN2W],
+                                params[P_LN2B], w.ffpre, w.ffact, w.ffout, w.mean2, w.rstd2, h_out, T, D, ln_eps, drop_p,
+                                seed, C(SITE_FF_ACT), C(SITE_FF_OUT));
+    }
     const DropCfg dff = make_drop(drop_p, seed, C(SITE_FF_ACT));
     RUN(t4r_gemm_launch(st, 0, 1, T, 4 * D, D, 1.f, w.h1, D, params[P_W1], D, w.ffact, 4 * D,
                         params[P_B1], EPI_BIAS_GELU, w.ffpre, 4 * D, 1, 0, 1, 0, 0, 0, &dff));
@@ -245,6 +269,10 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
     float* red_ln1 = take(t4r_colreduce_ws_floats(T, 2 * D));
     float* red_b2 = take(t4r_colreduce_ws_floats(T, D));
     float* dxa = drop ? take(TD) : nullptr;     // gradient of a dropped LayerNorm operand
+    float* dfo = take(TD);                      // fused feed-forward backward: d ffout rows (own buffer: the FF2 weight
+                                                // gradient may still read them while the attention half runs)
+    float* ff_part = take(t4r_xlnet_ff_bwd_part_floats(T, D));
+    const bool fused = use_fused(D);
 
     SideStream* ss = side_stream();
     struct RedirectGuard {      // second stages of the column reductions -> side stream, for this call only
@@ -265,6 +293,17 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
         return ss->s;
     };
 
+    if (fused) {
+        // one launch: LayerNorm backward -> d ffout -> FF2 dX -> GELU' / dropout -> FF1 dX + residual (+ the partial
+        // sums of d gamma, d beta, d b2, d b1, reduced by two small launches on the weight-gradient stream)
+        RUN(t4r_xlnet_ff_bwd(stream, dh_out, w.ffout, w.h1, w.mean2, w.rstd2, params[P_LN2W], w.ffpre, w.planes,
+                             dx, dfo, dff, grads[P_LN2W], grads[P_LN2B], grads[P_B2], grads[P_B1], ff_part,
+                             T, D, drop_p, seed, C(SITE_FF_ACT), C(SITE_FF_OUT)));
+        RUN(t4r_gemm_launch(wg(), 1, 0, D, 4 * D, T, 1.f, dfo, D, w.ffact, 4 * D, grads[P_W2], 4 * D, nullptr,
+                            EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
+        RUN(t4r_gemm_launch(wg(), 1, 0, 4 * D, D, T, 1.f, dff, 4 * D, w.h1, D, grads[P_W1], D, nullptr,
+                            EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
+    } else {
     // LN2: y = LN(drop(ffout) + h1): dx = d h1 (residual part), d ffout = dxa (or dx when p = 0)
     RUN(t4r_add_layernorm_bwd(stream, w.ffout, w.h1, params[P_LN2W], w.mean2, w.rstd2, dh_out, dx, dxa,
                               grads[P_LN2W], grads[P_LN2B], red_ln2, T, D, 0, drop_p, seed, C(SITE_FF_OUT)));
@@ -285,8 +324,9 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
                         EPI_NONE, nullptr, 0, 1, 1, 1, 0, 0, 0, nullptr));
     RUN(t4r_gemm_launch(wg(), 1, 0, 4 * D, D, T, 1.f, dff, 4 * D, w.h1, D, grads[P_W1], D, nullptr,
                         EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
+    }
     // LN1: h1 = LN(drop(ao) + h): dh_in = d h (residual part), d ao = dxa (or dh_in when p = 0)
-    if (ss && drop) (void)hipStreamWaitEvent(st, ss->done_ff2, 0);    // the FF2 wgrad reads dxa, overwritten here
+    if (ss && drop && !fused) (void)hipStreamWaitEvent(st, ss->done_ff2, 0);    // the FF2 wgrad reads dxa, overwritten here
     RUN(t4r_add_layernorm_bwd(stream, w.ao, h, params[P_LN1W], w.mean1, w.rstd1, dx, dh_in, dxa,
                               grads[P_LN1W], grads[P_LN1B], red_ln1, T, D, 0, drop_p, seed, C(SITE_ATTN_OUT)));
     const float* dao = drop ? dxa : dh_in;

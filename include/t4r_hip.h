@@ -322,24 +322,49 @@ int t4r_add_pos_fwd(void* stream, const float* x, const float* pos, const float*
                     int B, int L, int D);
 int t4r_add_pos_bwd(void* stream, const float* dy, float* d_pos, int B, int L, int D);
 
-/* Fused feed-forward block of the XLNet layer (token-tile-stationary, csrc/xlnet_fused.hip; d_model 32 | 64 | 128,
- * d_inner = 4 d_model): ONE launch per direction instead of the GEMM / activation / LayerNorm chain; fp32-accurate
- * products on the bf16 matrix cores (exact three-way operand cuts, six partial products, fp32 accumulation).
- * replaces: HF modeling_xlnet.py:297-305 XLNetFeedForward.forward -- layer_1, gelu(erf), dropout, layer_2, dropout,
- *           layer_norm(output + inp) -- and its backward (ATen addmm / gelu_backward / native_layer_norm_backward).
- * prepare: cuts W1 [4D, D] and W2 [D, 4D] into bf16 planes (both orientations) in `planes`
- *      (t4r_xlnet_ff_planes_floats(D) floats); once per weight update, shared by fwd and bwd.
- * fwd: h1 [T, D] -> hout [T, D].  Training form: ffpre, ffact [T, 4D], ffout [T, D], mean, rstd [T] are all given and
- *      saved for the backward, the Philox masks of the two dropout sites are keyed (seed, ctr_act / ctr_out), element
- *      index row * width + col as everywhere.  Inference form: all five NULL and drop_p = 0.
- * bwd: dy [T, D] = d loss / d hout -> dh1 [T, D] (overwritten), plus the rows the two weight gradients contract over,
- *      dffout [T, D] and dpre [T, 4D] (overwritten; d W2 += dffout^T @ ffact, d W1 += dpre^T @ h1 are issued by the
- *      caller); d_gamma, d_beta, d_b2 [D], d_b1 [4D] are ACCUMULATED (per-workgroup partial sums + a reduction, no
- *      atomics).  part: t4r_xlnet_ff_bwd_part_floats(T, D) floats of scratch. */
+/* Token-tile-stationary fused kernels of the XLNet layer (csrc/xlnet_fused.hip, xlnet_fused_attn.hip; d_model 32 | 64 |
+ * 128, d_inner = 4 d_model).  One workgroup owns 16 R token rows and runs a whole sub-block on them; fp32-accurate
+ * products on the bf16 matrix cores (exact three-way operand cuts, six partial products, fp32 accumulation).  The weights
+ * are cut ONCE per layer call into bf16 planes (t4r_xlnet_layer_prepare; `planes`: t4r_xlnet_layer_planes_floats(D)
+ * floats, shared by every entry point below and by forward and backward).  t4r_xlnet_layer_fwd / _bwd use them by default
+ * (T4R_XLNET_FUSED=0: the GEMM / element-wise launch chain).
+ *
+ * prepare: params = host array of the layer's 15 device pointers (order of t4r_xlnet_layer_fwd); one launch.
+ *          t4r_xlnet_ff_prepare: the feed-forward planes only (same buffer layout).
+ * qkv_proj:  q, k, v = h @ W_{q,k,v}  (HF modeling_xlnet.py:251-258, three einsum('ibh,hnd->ibnd')): qkv [3][T][D].
+ * kr_proj:   k_r = pos @ r (HF :266 with :1142-1143): pos [rows, D] = the positional encoding [2L, D] or its per-session
+ *            dropped copy [B 2L, D].
+ * oproj_ln:  h1 = LayerNorm(dropout(attn_vec @ o^T) + h)  (HF post_attention :142-152).  Training form saves ao [T, D]
+ *            (projection before dropout), mean, rstd [T]; inference form: all three NULL, drop_p = 0.
+ * ln1_bwd:   dy = d loss / d h1 -> dh (residual part of d loss / d h), dao (rows of the o weight gradient
+ *            d o += dao^T @ attn_vec, issued by the caller), dav = d loss / d attn_vec, all [T, D] overwritten;
+ *            d_gamma, d_beta ACCUMULATED; part: t4r_xlnet_ln1_bwd_part_floats(T, D) floats.
+ * dh:        dh [T, D] += d q @ W_q^T + d k @ W_k^T + d v @ W_v^T   (dqkv [3][T][D]).
+ * ff_fwd:    replaces HF :297-305 XLNetFeedForward.forward -- layer_1, gelu(erf), dropout, layer_2, dropout,
+ *            layer_norm(output + inp).  h1 [T, D] -> hout [T, D].  Training form: ffpre, ffact [T, 4D], ffout [T, D], mean,
+ *            rstd [T] are all given and saved for the backward, the Philox masks of the two dropout sites are keyed
+ *            (seed, ctr_act / ctr_out), element index row * width + col as everywhere.  Inference form: all five NULL.
+ * ff_bwd:    dy [T, D] = d loss / d hout -> dh1 [T, D] (overwritten), plus the rows the two weight gradients contract over,
+ *            dffout [T, D] and dpre [T, 4D] (overwritten; d W2 += dffout^T @ ffact, d W1 += dpre^T @ h1 are issued by the
+ *            caller); d_gamma, d_beta, d_b2 [D], d_b1 [4D] are ACCUMULATED (per-workgroup partial sums + a reduction, no
+ *            atomics).  part: t4r_xlnet_ff_bwd_part_floats(T, D) floats of scratch. */
 int t4r_xlnet_fused_supported(int D);
-long t4r_xlnet_ff_bwd_part_floats(long T, int D);
+long t4r_xlnet_layer_planes_floats(int D);
+int t4r_xlnet_layer_prepare(void* stream, const float* const* params, int D, float* planes);
 long t4r_xlnet_ff_planes_floats(int D);
 int t4r_xlnet_ff_prepare(void* stream, const float* W1, const float* W2, int D, float* planes);
+int t4r_xlnet_qkv_proj(void* stream, const float* h, const float* planes, float* qkv, long T, int D);
+int t4r_xlnet_kr_proj(void* stream, const float* pos, const float* planes, float* kr, long rows, int D);
+int t4r_xlnet_oproj_ln(void* stream, const float* av, const float* h, const float* planes, const float* gamma,
+                       const float* beta, float* ao, float* mean, float* rstd, float* h1, long T, int D, float eps,
+                       float drop_p, unsigned long long seed, unsigned long long ctr_hi);
+long t4r_xlnet_ln1_bwd_part_floats(long T, int D);
+int t4r_xlnet_ln1_bwd(void* stream, const float* dy, const float* ao, const float* h, const float* mean, const float* rstd,
+                      const float* gamma, const float* planes, float* dh, float* dao, float* dav, float* d_gamma,
+                      float* d_beta, float* part, long T, int D, float drop_p, unsigned long long seed,
+                      unsigned long long ctr_hi);
+int t4r_xlnet_dh(void* stream, const float* dqkv, const float* planes, float* dh, long T, int D);
+long t4r_xlnet_ff_bwd_part_floats(long T, int D);
 int t4r_xlnet_ff_fwd(void* stream, const float* h1, const float* planes, const float* b1, const float* b2,
                      const float* gamma, const float* beta, float* ffpre, float* ffact, float* ffout, float* mean,
                      float* rstd, float* hout, int T, int D, float eps, float drop_p, unsigned long long seed,

@@ -71,6 +71,14 @@ _SIGS = {
     "t4r_xlnet_attn_bwd": ("i", "p" * 17 + "iiii" + "ifQQ" + "p"),
     "t4r_xlnet_fused_supported": ("i", "i"),
     "t4r_xlnet_ff_bwd_part_floats": ("l", "li"),
+    "t4r_xlnet_layer_planes_floats": ("l", "i"),
+    "t4r_xlnet_layer_prepare": ("i", "ppip"),
+    "t4r_xlnet_qkv_proj": ("i", "pppp" + "li"),
+    "t4r_xlnet_kr_proj": ("i", "pppp" + "li"),
+    "t4r_xlnet_oproj_ln": ("i", "p" + "ppppp" + "pppp" + "liff" + "QQ"),
+    "t4r_xlnet_ln1_bwd_part_floats": ("l", "li"),
+    "t4r_xlnet_ln1_bwd": ("i", "p" + "ppppppp" + "pppppp" + "lif" + "QQ"),
+    "t4r_xlnet_dh": ("i", "pppp" + "li"),
     "t4r_xlnet_ff_planes_floats": ("l", "i"),
     "t4r_xlnet_ff_prepare": ("i", "pppip"),
     "t4r_xlnet_ff_fwd": ("i", "p" + "pppppp" + "pppppp" + "iiff" + "QQQ"),

@@ -33,114 +33,16 @@
 // ds_read_b128 lane group hit 16 distinct bank quads: SQ_LDS_BANK_CONFLICT was 46 % of the LDS cycles with D + 8),
 // activation-chunk planes [3][16R][D + 16] (written by the
 // FF1 epilogue, B operand of FF2; d_inner = 4 D is walked in four chunks of D, two barriers per chunk).
-#include "t4r_common.h"
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
-typedef float f32x2v __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-int t4r_reduce_partials_launch(hipStream_t st, const float* part, int nblocks, float* o0, int n0, int a0,
-                               float* o1, int n1, int a1, float* o2, int n2, int a2);   // elementwise.hip
-
-__device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
-__device__ __forceinline__ u32x4 ldq(const uint16_t* p) { return *reinterpret_cast<const u32x4*>(p); }
-__device__ __forceinline__ f32x4 mfma_bf(u32x4 a, u32x4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-// two fp32 values -> one packed bf16 pair per plane (low half = first value), x = hi + mid + lo exactly; every cut rounds
-// to nearest even (v_cvt_pk_bf16_f32) so that the dropped 2^-24 terms carry no systematic sign (gemm_kernel.h cvt_pair)
-__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
-    const f32x2v v = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2v));
-}
-__device__ __forceinline__ void cut3(float a, float b, uint32_t (&w)[3]) {
-    w[0] = pk_bf16(a, b);
-    const float ra = a - __uint_as_float(w[0] << 16), rb = b - __uint_as_float(w[0] & 0xffff0000u);
-    w[1] = pk_bf16(ra, rb);
-    const float sa = ra - __uint_as_float(w[1] << 16), sb = rb - __uint_as_float(w[1] & 0xffff0000u);
-    w[2] = pk_bf16(sa, sb);
-}
-// the six partial products kept (planes 0 hi, 1 mid, 2 lo), smallest first
-#define T4R_SIX(X) X(1, 1) X(2, 0) X(0, 2) X(1, 0) X(0, 1) X(0, 0)
-
-// ------------------------------------------------------------------------------------------------ weight planes
-// src [rows][cols] fp32 -> dst planes [3][rows][cols] bf16 and (dstT != NULL) transposed planes [3][cols][rows].
-// One thread per pair of consecutive columns.
-__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, int rows, int cols,
-                                                            uint16_t* __restrict__ dst, uint16_t* __restrict__ dstT) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;         // pair index
-    const long npair = (long)rows * cols / 2;
-    if (i >= npair) return;
-    const int r = (int)(i / (cols / 2)), c = (int)(i % (cols / 2)) * 2;
-    const float2 v = *reinterpret_cast<const float2*>(src + (long)r * cols + c);
-    uint32_t w[3];
-    cut3(v.x, v.y, w);
-    const long plane = (long)rows * cols;
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-        *reinterpret_cast<uint32_t*>(dst + pl * plane + (long)r * cols + c) = w[pl];
-        if (dstT) {
-            dstT[pl * plane + (long)c * rows + r] = (uint16_t)(w[pl] & 0xffffu);
-            dstT[pl * plane + (long)(c + 1) * rows + r] = (uint16_t)(w[pl] >> 16);
-        }
-    }
-}
-
-struct FFPlanes {      // bf16 planes of one layer's feed-forward weights (t4r_xlnet_ff_prepare)
-    const uint16_t *W1p, *W2p, *W1Tp, *W2Tp;    // [3][4D][D], [3][D][4D], [3][D][4D] (= W1^T), [3][4D][D] (= W2^T)
-};
-static FFPlanes carve_planes(const void* base, int D) {
-    const uint16_t* b = (const uint16_t*)base;
-    const long m = 3L * 4 * D * D;
-    return FFPlanes{b, b + m, b + 2 * m, b + 3 * m};
-}
+#include "xlnet_fused.h"
 
 struct FFFwdParams {
     const float *h1, *b1, *b2, *gamma, *beta;
-    FFPlanes w;
+    LayerPlanes w;
     float *ffpre, *ffact, *ffout, *mean, *rstd, *hout;     // ffpre / ffact / ffout / mean / rstd: all given (training) or all NULL
     int T;
     float eps;
     DropCfg drop_act, drop_out;
 };
-
-// acc[r] += A_tile (16 features x D) . B_r (D x 16 tokens) for every token block r, three-plane operands, six products.
-// The weight fragment is requested one product ahead (load_a3: 3 D/32 16-byte loads from the L2-resident planes, issued
-// before the previous product / epilogue so that their latency never sits in front of the matrix instructions).
-// ap: plane 0 of the weight matrix at this lane's row and k offset 8 kg (row-major, k contiguous), apl: plane stride;
-// bp: plane 0 of the LDS token planes at this lane's token row offset + 8 kg, bpl: plane stride, blocks 16 * P rows apart
-template <int D>
-struct AFrag { u32x4 v[D / 32][3]; };
-#ifndef T4R_FF_PREFETCH
-#define T4R_FF_PREFETCH 0   /* A/B, same box: fragments requested one product ahead cost 67 us per forward launch against 60 (237 VGPRs instead of 143) */
-#endif
-template <int D>
-__device__ __forceinline__ void load_a3(AFrag<D>& a, const uint16_t* __restrict__ ap, long apl) {
-#pragma unroll
-    for (int s = 0; s < D / 32; ++s)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) a.v[s][pl] = ldq(ap + pl * apl + 32 * s);
-}
-template <int D, int R, int P>
-__device__ __forceinline__ void product3(const AFrag<D>& a, const uint16_t* bp, int bpl, f32x4 (&acc)[R]) {
-    constexpr int KS = D / 32;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        u32x4 b[R][3];
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) b[r][pl] = ldq(bp + pl * bpl + r * 16 * P + 32 * s);
-#define T4R_PROD(PA, PB)                                                        \
-        _Pragma("unroll") for (int r = 0; r < R; ++r) acc[r] = mfma_bf(a.v[s][PA], b[r][PB], acc[r]);
-        T4R_SIX(T4R_PROD)
-#undef T4R_PROD
-    }
-}
 
 // FULL: every row of the tile is a token; TRAIN: the backward's activations are saved and the Philox masks evaluated
 // (p = 0 keeps everything); !TRAIN (inference: nothing saved, p = 0): neither.
@@ -294,7 +196,7 @@ __global__ __launch_bounds__(D * 4) void xlnet_ff_fwd_kernel(FFFwdParams p) {
 // -------------------------------------------------------------------------------------------------- backward
 struct FFBwdParams {
     const float *dy, *ffout, *h1, *mean, *rstd, *gamma, *ffpre;
-    FFPlanes w;
+    LayerPlanes w;
     float *dh1, *dffout, *dpre;       // [T, D], [T, D], [T, 4D]
     float *partA, *partB;             // per-workgroup partial sums [nWG][3D] (d gamma | d beta | d b2), [nWG][4D] (d b1)
     int T;
@@ -457,24 +359,6 @@ static int pick_r(long T) {
 
 extern "C" int t4r_xlnet_fused_supported(int D) { return D == 32 || D == 64 || D == 128; }
 extern "C" long t4r_xlnet_ff_bwd_part_floats(long T, int D) { return ((T + 15) / 16) * 7L * D; }
-// floats (4-byte units) of the weight-plane buffer of one layer: four matrices x three bf16 planes x 4 D^2 elements
-extern "C" long t4r_xlnet_ff_planes_floats(int D) { return 4L * 3 * 4 * D * D / 2; }
-
-// cuts W1 [4D, D] and W2 [D, 4D] into bf16 planes, in both orientations (forward and backward operand forms)
-extern "C" int t4r_xlnet_ff_prepare(void* stream, const float* W1, const float* W2, int D, float* planes) {
-    T4R_CHECK_ARG(t4r_xlnet_fused_supported(D), "xlnet_ff_prepare: d_model must be 32, 64 or 128");
-    T4R_CHECK_ARG(W1 && W2 && planes, "xlnet_ff_prepare: null pointer");
-    const FFPlanes f = carve_planes(planes, D);
-    hipStream_t st = (hipStream_t)stream;
-    const unsigned nb = (unsigned)((4L * D * D / 2 + 255) / 256);
-    hipLaunchKernelGGL(split_planes_kernel, dim3(nb), dim3(256), 0, st, W1, 4 * D, D, const_cast<uint16_t*>(f.W1p),
-                       const_cast<uint16_t*>(f.W1Tp));
-    hipLaunchKernelGGL(split_planes_kernel, dim3(nb), dim3(256), 0, st, W2, D, 4 * D, const_cast<uint16_t*>(f.W2p),
-                       const_cast<uint16_t*>(f.W2Tp));
-    T4R_LAUNCH_CHECK();
-    return 0;
-}
-
 template <int D, int R>
 static int ff_fwd_launch(hipStream_t st, const FFFwdParams& p) {
     constexpr int RT = 16 * R, PH = D + 16, NW = D / 16;

@@ -1,0 +1,535 @@
+// Token-tile-stationary kernels of the ATTENTION half of the XLNet layer (round 3), built from the pieces of
+// xlnet_fused.h (three-plane bf16 operands cut once, six-product MFMA chain, transposed products: weight = A operand):
+//
+//   xlnet_proj_kernel      rows [T, D] -> NM matrices [T, D] each:  q, k, v = h @ W_{q,k,v}   (NM = 3, one launch, the token
+//                          tile is read and cut once for the three products), and  k_r = pos_emb(_b) @ r  (NM = 1)
+//                          (HF modeling_xlnet.py :251-258 einsum('ibh,hnd->ibnd') x 3, :266 k_head_r)
+//   xlnet_oproj_ln_kernel  attn_vec -> o-projection + dropout + residual + LayerNorm -> h1      (HF post_attention :142-152)
+//   xlnet_ln1_bwd_kernel   d h1 -> LayerNorm backward -> d attn_out (rows of the o weight gradient) -> d attn_vec = d ao @ o
+//                          (+ partial sums of d gamma, d beta)
+//   xlnet_dh_kernel        d h += d q @ W_q^T + d k @ W_k^T + d v @ W_v^T    (three products into one accumulator; the
+//                          d q / d k / d v tiles take turns in two LDS plane buffers)
+//   layer_planes_kernel    one launch cuts all nine weight matrices of a layer into their bf16 planes (xlnet_fused.h)
+//
+// The attention core itself (scores, relative shift, softmax, dropout, P @ v) stays xlnet_attn_mfma.hip.
+// Each replaces one or two launches of the general GEMM + an element-wise / LayerNorm launch of the chain in
+// xlnet_layer.hip; what they save is the operand cutting per 64 x 64 tile of the general kernel, the LayerNorm round
+// trips and the launch boundaries (measured per layer at the benchmark size, same box: see DESIGN.md).
+#include "xlnet_fused.h"
+
+// ---------------------------------------------------------------------------------------------- weight planes of a layer
+struct PlaneJob {
+    const float* src;      // [rows][cols] fp32
+    uint16_t* dst;         // plane 0 of the destination matrix [3][drows][dcols]
+    int rows, cols;        // source shape
+    int dcols;             // destination row pitch
+    long dplane;           // destination plane stride
+    int r0, c0;            // destination offset of this source
+    int transpose;         // dst[r0 + c][c0 + r] = src[r][c]  instead of  dst[r0 + r][c0 + c]
+    long pair0;            // first pair index of this job in the launch
+};
+#define T4R_MAX_PLANE_JOBS 16
+struct PlaneJobs { PlaneJob j[T4R_MAX_PLANE_JOBS]; int n; long total; };
+
+__global__ __launch_bounds__(256) void layer_planes_kernel(PlaneJobs jobs) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= jobs.total) return;
+    int k = 0;
+#pragma unroll 1
+    for (int q = 1; q < jobs.n; ++q) k = i >= jobs.j[q].pair0 ? q : k;
+    const PlaneJob& jb = jobs.j[k];
+    const long li = i - jb.pair0;
+    const int r = (int)(li / (jb.cols / 2)), c = (int)(li % (jb.cols / 2)) * 2;
+    const float2 v = *reinterpret_cast<const float2*>(jb.src + (long)r * jb.cols + c);
+    uint32_t w[3];
+    cut3(v.x, v.y, w);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        uint16_t* d = jb.dst + pl * jb.dplane;
+        if (!jb.transpose) {
+            *reinterpret_cast<uint32_t*>(d + (long)(jb.r0 + r) * jb.dcols + jb.c0 + c) = w[pl];
+        } else {
+            d[(long)(jb.r0 + c) * jb.dcols + jb.c0 + r] = (uint16_t)(w[pl] & 0xffffu);
+            d[(long)(jb.r0 + c + 1) * jb.dcols + jb.c0 + r] = (uint16_t)(w[pl] >> 16);
+        }
+    }
+}
+
+extern "C" long t4r_xlnet_layer_planes_floats(int D) { return layer_planes_floats(D); }
+
+static void add_job(PlaneJobs& js, const float* src, int rows, int cols, const uint16_t* dst, int drows, int dcols, int r0,
+                    int c0, int transpose) {
+    PlaneJob& j = js.j[js.n++];
+    j.src = src; j.dst = const_cast<uint16_t*>(dst); j.rows = rows; j.cols = cols; j.dcols = dcols;
+    j.dplane = (long)drows * dcols; j.r0 = r0; j.c0 = c0; j.transpose = transpose; j.pair0 = js.total;
+    js.total += (long)rows * cols / 2;
+}
+
+// params: host array of the layer's 15 device pointers in the order of t4r_xlnet_layer_fwd (q, k, v, o, r, ..., W1 at 9,
+// W2 at 11); any of the attention weights may be NULL (feed-forward planes only: t4r_xlnet_ff_prepare)
+static int prepare_launch(hipStream_t st, const float* q, const float* k, const float* v, const float* o, const float* r,
+                          const float* W1, const float* W2, int D, float* planes) {
+    const LayerPlanes P = carve_planes(planes, D);
+    PlaneJobs js;
+    js.n = 0; js.total = 0;
+    const float* z[3] = {q, k, v};
+    for (int i = 0; i < 3; ++i) {
+        if (!z[i]) continue;
+        add_job(js, z[i], D, D, P.QKVT, 3 * D, D, i * D, 0, 1);
+        add_job(js, z[i], D, D, P.QKVN, D, 3 * D, 0, i * D, 0);
+    }
+    if (r) add_job(js, r, D, D, P.RT, D, D, 0, 0, 1);
+    if (o) {
+        add_job(js, o, D, D, P.ON, D, D, 0, 0, 0);
+        add_job(js, o, D, D, P.OT, D, D, 0, 0, 1);
+    }
+    if (W1) {
+        add_job(js, W1, 4 * D, D, P.W1p, 4 * D, D, 0, 0, 0);
+        add_job(js, W1, 4 * D, D, P.W1Tp, D, 4 * D, 0, 0, 1);
+    }
+    if (W2) {
+        add_job(js, W2, D, 4 * D, P.W2p, D, 4 * D, 0, 0, 0);
+        add_job(js, W2, D, 4 * D, P.W2Tp, 4 * D, D, 0, 0, 1);
+    }
+    if (js.total == 0) return 0;
+    hipLaunchKernelGGL(layer_planes_kernel, dim3((unsigned)((js.total + 255) / 256)), dim3(256), 0, st, js);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int t4r_xlnet_fused_supported(int D);
+
+// cuts every weight matrix of one layer into its bf16 planes: ONE launch per layer call (planes:
+// t4r_xlnet_layer_planes_floats(D) floats).  params: host array of 15 device pointers, order of t4r_xlnet_layer_fwd.
+extern "C" int t4r_xlnet_layer_prepare(void* stream, const float* const* params, int D, float* planes) {
+    T4R_CHECK_ARG(t4r_xlnet_fused_supported(D), "xlnet_layer_prepare: d_model must be 32, 64 or 128");
+    T4R_CHECK_ARG(params && planes, "xlnet_layer_prepare: null pointer");
+    return prepare_launch((hipStream_t)stream, params[0], params[1], params[2], params[3], params[4], params[9], params[11], D,
+                          planes);
+}
+// the feed-forward planes only (stand-alone use of t4r_xlnet_ff_fwd / _bwd); same buffer layout and size
+extern "C" int t4r_xlnet_ff_prepare(void* stream, const float* W1, const float* W2, int D, float* planes) {
+    T4R_CHECK_ARG(t4r_xlnet_fused_supported(D), "xlnet_ff_prepare: d_model must be 32, 64 or 128");
+    T4R_CHECK_ARG(W1 && W2 && planes, "xlnet_ff_prepare: null pointer");
+    return prepare_launch((hipStream_t)stream, nullptr, nullptr, nullptr, nullptr, nullptr, W1, W2, D, planes);
+}
+extern "C" long t4r_xlnet_ff_planes_floats(int D) { return layer_planes_floats(D); }
+
+// ---------------------------------------------------------------------------------------------- shared device pieces
+// rows t0 .. t0 + RT - 1 of src [T, D] (clamped to T - 1) -> three bf16 planes [3][RT][PH] in LDS
+template <int D, int RT, int NT, int PH>
+__device__ __forceinline__ void tile_to_planes(const float* __restrict__ src, long t0, long T, uint16_t* sh, int tid) {
+    constexpr int PLN = RT * PH;
+    for (int i = tid; i < RT * (D / 4); i += NT) {
+        const int row = i / (D / 4), c4 = (i % (D / 4)) * 4;
+        const long t = min(t0 + row, T - 1);
+        const float4 v = ld4(src + t * D + c4);
+        uint32_t w0[3], w1[3];
+        cut3(v.x, v.y, w0);
+        cut3(v.z, v.w, w1);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            *reinterpret_cast<uint2*>(sh + pl * PLN + row * PH + c4) = make_uint2(w0[pl], w1[pl]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- projections
+struct ProjParams {
+    const float* in;          // [T, D]
+    const uint16_t* planes;   // plane 0 of the weight-plane matrix [NM D][D] (rows = output feature)
+    float* out;               // NM matrices [T, D], `ostride` floats apart
+    long ostride;
+    long T;
+};
+
+template <int D, int R, int NM>
+__global__ __launch_bounds__(D * 4) void xlnet_proj_kernel(ProjParams p) {
+    constexpr int NW = D / 16, NT = NW * 64, RT = 16 * R, PH = D + 16, PLN = RT * PH;
+    extern __shared__ uint16_t smem16[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, g = lane >> 4;
+    const long t0 = (long)blockIdx.x * RT;
+    tile_to_planes<D, RT, NT, PH>(p.in, t0, p.T, smem16, tid);
+    __syncthreads();
+    const int boff = n * PH + 8 * g;
+    const long wpl = (long)NM * D * D;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        f32x4 acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = zero4();
+        AFrag<D> a;
+        load_a3<D>(a, p.planes + (long)(m * D + 16 * w + n) * D + 8 * g, wpl);
+        product3<D, R, PH>(a, smem16 + boff, PLN, acc);
+        float* o = p.out + m * p.ostride + 16 * w + 4 * g;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const long t = t0 + r * 16 + n;
+            if (t < p.T) st4(o + t * D, make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- o-projection + LayerNorm
+struct OProjParams {
+    const float *av, *h, *gamma, *beta;    // attn_vec [T, D], layer input h [T, D] (residual), LayerNorm parameters
+    const uint16_t* planes;                // ON planes [D][D]
+    float *ao, *mean, *rstd, *h1;          // saved o-projection output (pre dropout), statistics (all NULL: inference), out
+    long T;
+    float eps;
+    DropCfg drop;
+};
+
+template <int D, int R, bool TRAIN>
+__device__ __forceinline__ void oproj_body(const OProjParams& p, uint16_t* smem16) {
+    constexpr int NW = D / 16, NT = NW * 64, RT = 16 * R, PH = D + 16, PLN = RT * PH;
+    float* sh_red = reinterpret_cast<float*>(smem16 + 3 * PLN);      // [2][NW][RT]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, g = lane >> 4;
+    const long t0 = (long)blockIdx.x * RT;
+    tile_to_planes<D, RT, NT, PH>(p.av, t0, p.T, smem16, tid);
+    AFrag<D> a;
+    load_a3<D>(a, p.planes + (long)(16 * w + n) * D + 8 * g, (long)D * D);
+    __syncthreads();
+    f32x4 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = zero4();
+    product3<D, R, PH>(a, smem16 + n * PH + 8 * g, PLN, acc);
+    const int f0 = 16 * w + 4 * g;
+    const float4 gam = ld4(p.gamma + f0), bet = ld4(p.beta + f0);
+    float4 x[R];
+    float sum[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long t = t0 + r * 16 + n;
+        const long tc = min(t, p.T - 1);
+        float4 v = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+        if (TRAIN && t < p.T) st4(p.ao + t * D + f0, v);
+        if (TRAIN) {
+            const float4 m = drop_scale4(p.drop, (unsigned long long)t * D + f0);
+            v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+        }
+        const float4 hres = ld4(p.h + tc * D + f0);
+        v.x += hres.x; v.y += hres.y; v.z += hres.z; v.w += hres.w;
+        x[r] = v;
+        float s = (v.x + v.y) + (v.z + v.w);
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        sum[r] = s;
+    }
+    if (g == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) sh_red[w * RT + r * 16 + n] = sum[r];
+    }
+    __syncthreads();
+    float mu[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) s += sh_red[ww * RT + r * 16 + n];
+        mu[r] = s * (1.0f / D);
+        const float dx = x[r].x - mu[r], dy = x[r].y - mu[r], dz = x[r].z - mu[r], dw = x[r].w - mu[r];
+        float q = (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        q += __shfl_xor(q, 16, 64);
+        q += __shfl_xor(q, 32, 64);
+        sum[r] = q;
+    }
+    float* sh_red2 = sh_red + NW * RT;
+    if (g == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) sh_red2[w * RT + r * 16 + n] = sum[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long t = t0 + r * 16 + n;
+        float q = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) q += sh_red2[ww * RT + r * 16 + n];
+        const float rs = rsqrtf(q * (1.0f / D) + p.eps);
+        if (t < p.T) {
+            st4(p.h1 + t * D + f0, make_float4((x[r].x - mu[r]) * rs * gam.x + bet.x, (x[r].y - mu[r]) * rs * gam.y + bet.y,
+                                               (x[r].z - mu[r]) * rs * gam.z + bet.z, (x[r].w - mu[r]) * rs * gam.w + bet.w));
+            if (TRAIN && w == 0 && g == 0) { p.mean[t] = mu[r]; p.rstd[t] = rs; }
+        }
+    }
+}
+template <int D, int R>
+__global__ __launch_bounds__(D * 4) void xlnet_oproj_ln_kernel(OProjParams p) {
+    extern __shared__ uint16_t smem16[];
+    if (p.ao != nullptr) oproj_body<D, R, true>(p, smem16);
+    else oproj_body<D, R, false>(p, smem16);
+}
+
+// ---------------------------------------------------------------------------------------------- LayerNorm 1 backward + d attn_vec
+struct Ln1BwdParams {
+    const float *dy, *ao, *h, *mean, *rstd, *gamma;     // d loss / d h1; o-projection output (pre dropout); layer input; stats
+    const uint16_t* planes;                             // OT planes [D][D]
+    float *dh, *dao, *dav;                              // [T, D] each, overwritten: residual part of d h, d attn_out, d attn_vec
+    float* part;                                        // [nWG][2 D] partial sums (d gamma | d beta)
+    long T;
+    DropCfg drop;
+};
+
+template <int D, int R>
+__global__ __launch_bounds__(D * 4) void xlnet_ln1_bwd_kernel(Ln1BwdParams p) {
+    constexpr int NW = D / 16, RT = 16 * R, PH = D + 16, PLN = RT * PH;
+    extern __shared__ uint16_t smem16[];
+    uint16_t* sh_d = smem16;                                         // [3][RT][PH] d attn_out planes
+    float* sh_part = reinterpret_cast<float*>(sh_d + 3 * PLN);       // [NW][2][D]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, g = lane >> 4;
+    const long t0 = (long)blockIdx.x * RT;
+    AFrag<D> a;
+    load_a3<D>(a, p.planes + (long)(16 * w + n) * D + 8 * g, (long)D * D);
+    {
+        const int c0 = lane * 2;
+        const bool act_lane = c0 < D;
+        float gam[2], pg[2] = {0.f, 0.f}, pb[2] = {0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) gam[e] = act_lane ? p.gamma[c0 + e] : 0.f;
+        for (int row = w; row < RT; row += NW) {
+            const long t = t0 + row;
+            float dxa[2] = {0.f, 0.f};
+            if (t < p.T) {      // wave-uniform
+                const float mu = p.mean[t], rs = p.rstd[t];
+                float xh[2] = {0.f, 0.f}, gg[2] = {0.f, 0.f}, dyv[2] = {0.f, 0.f}, m[2] = {1.f, 1.f}, dx[2];
+                float s1 = 0.f, s2 = 0.f;
+                if (act_lane) {
+                    drop_scale_vec<2>(p.drop, (unsigned long long)t * D + c0, true, m);
+                    const float2 fo = *reinterpret_cast<const float2*>(p.ao + t * D + c0);
+                    const float2 hh = *reinterpret_cast<const float2*>(p.h + t * D + c0);
+                    const float2 dd = *reinterpret_cast<const float2*>(p.dy + t * D + c0);
+                    const float xv[2] = {fo.x * m[0] + hh.x, fo.y * m[1] + hh.y};
+                    dyv[0] = dd.x; dyv[1] = dd.y;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        xh[e] = (xv[e] - mu) * rs;
+                        gg[e] = dyv[e] * gam[e];
+                        s1 += gg[e];
+                        s2 += gg[e] * xh[e];
+                    }
+                }
+                s1 = wave_sum(s1) * (1.0f / D);
+                s2 = wave_sum(s2) * (1.0f / D);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    dx[e] = act_lane ? rs * (gg[e] - s1 - xh[e] * s2) : 0.f;
+                    dxa[e] = dx[e] * m[e];
+                    pg[e] += dyv[e] * xh[e];
+                    pb[e] += dyv[e];
+                }
+                if (act_lane) {
+                    *reinterpret_cast<float2*>(p.dh + t * D + c0) = make_float2(dx[0], dx[1]);
+                    *reinterpret_cast<float2*>(p.dao + t * D + c0) = make_float2(dxa[0], dxa[1]);
+                }
+            }
+            if (act_lane) {
+                uint32_t wd[3];
+                cut3(dxa[0], dxa[1], wd);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint32_t*>(sh_d + pl * PLN + row * PH + c0) = wd[pl];
+            }
+        }
+        if (act_lane) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                sh_part[(w * 2 + 0) * D + c0 + e] = pg[e];
+                sh_part[(w * 2 + 1) * D + c0 + e] = pb[e];
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * D; i += NW * 64) {
+        float s = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) s += sh_part[ww * 2 * D + i];
+        p.part[(long)blockIdx.x * 2 * D + i] = s;
+    }
+    // d attn_vec^T[nd][token] = sum_h o[h][nd] d ao[token][h]
+    f32x4 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = zero4();
+    product3<D, R, PH>(a, sh_d + n * PH + 8 * g, PLN, acc);
+    const int f0 = 16 * w + 4 * g;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long t = t0 + r * 16 + n;
+        if (t < p.T) st4(p.dav + t * D + f0, make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- d h from d q, d k, d v
+struct DhParams {
+    const float* dqkv;        // [3][T][D]
+    const uint16_t* planes;   // QKVN planes [D][3 D]
+    float* dh;                // [T, D], ACCUMULATED into (holds the LayerNorm-backward residual part)
+    long T;
+};
+
+template <int D, int R>
+__global__ __launch_bounds__(D * 4) void xlnet_dh_kernel(DhParams p) {
+    constexpr int NW = D / 16, NT = NW * 64, RT = 16 * R, PH = D + 16, PLN = RT * PH;
+    extern __shared__ uint16_t smem16[];     // [2][3][RT][PH]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, g = lane >> 4;
+    const long t0 = (long)blockIdx.x * RT;
+    const long TD = p.T * D;
+    const uint16_t* wp = p.planes + (long)(16 * w + n) * 3 * D + 8 * g;
+    const long wpl = 3L * D * D;
+    f32x4 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = zero4();
+    tile_to_planes<D, RT, NT, PH>(p.dqkv, t0, p.T, smem16, tid);
+    __syncthreads();
+#pragma unroll
+    for (int z = 0; z < 3; ++z) {
+        AFrag<D> a;
+        load_a3<D>(a, wp + z * D, wpl);
+        uint16_t* cur = smem16 + (z & 1) * 3 * PLN;
+        if (z < 2) tile_to_planes<D, RT, NT, PH>(p.dqkv + (z + 1) * TD, t0, p.T, smem16 + ((z + 1) & 1) * 3 * PLN, tid);
+        product3<D, R, PH>(a, cur + n * PH + 8 * g, PLN, acc);
+        if (z < 2) __syncthreads();
+    }
+    const int k0 = 16 * w + 4 * g;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long t = t0 + r * 16 + n;
+        if (t < p.T) {
+            const float4 o = ld4(p.dh + t * D + k0);
+            st4(p.dh + t * D + k0, make_float4(o.x + acc[r][0], o.y + acc[r][1], o.z + acc[r][2], o.w + acc[r][3]));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+static int pick_r(long T) {
+    const long blocks16 = (T + 15) / 16;
+    if (blocks16 <= 256) return 1;
+    if (blocks16 <= 512) return 2;
+    if (blocks16 <= 768) return 3;
+    return 5;
+}
+
+#define ATTN_DISPATCH(CALL, D, R)                                                              \
+    switch ((D) * 8 + (R)) {                                                                   \
+        case 32 * 8 + 1: CALL(32, 1); break;   case 32 * 8 + 2: CALL(32, 2); break;            \
+        case 32 * 8 + 3: CALL(32, 3); break;   case 32 * 8 + 5: CALL(32, 5); break;            \
+        case 64 * 8 + 1: CALL(64, 1); break;   case 64 * 8 + 2: CALL(64, 2); break;            \
+        case 64 * 8 + 3: CALL(64, 3); break;   case 64 * 8 + 5: CALL(64, 5); break;            \
+        case 128 * 8 + 1: CALL(128, 1); break; case 128 * 8 + 2: CALL(128, 2); break;          \
+        case 128 * 8 + 3: CALL(128, 3); break; case 128 * 8 + 5: CALL(128, 5); break;          \
+        default: t4r_set_error("xlnet fused: no instantiation"); return -1;                    \
+    }
+
+template <typename K>
+static void set_smem(K kernel, size_t smem) {
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+}
+
+// q, k, v = h @ W_{q,k,v}: out = qkv [3][T][D] (one launch).  planes: t4r_xlnet_layer_prepare's buffer.
+extern "C" int t4r_xlnet_qkv_proj(void* stream, const float* h, const float* planes, float* qkv, long T, int D) {
+    if (T <= 0) return 0;
+    T4R_CHECK_ARG(t4r_xlnet_fused_supported(D) && h && planes && qkv, "xlnet_qkv_proj: bad arguments");
+    const int R = pick_r(T);
+    ProjParams p{h, carve_planes(planes, D).QKVT, qkv, T * D, T};
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(DD, RR)                                                                                             \
+    {                                                                                                            \
+        const size_t smem = (size_t)3 * 16 * RR * (DD + 16) * 2;                                                 \
+        { static bool once = false; if (!once) { set_smem(xlnet_proj_kernel<DD, RR, 3>, smem); once = true; } }                                                            \
+        hipLaunchKernelGGL((xlnet_proj_kernel<DD, RR, 3>), dim3((unsigned)((T + 16 * RR - 1) / (16 * RR))), dim3(DD * 4), smem, st, p); \
+    }
+    ATTN_DISPATCH(CALL, D, R)
+#undef CALL
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+// k_r = pos @ r: pos [rows, D] (the positional encoding [2L, D], or its per-session dropped copy [B 2L, D]) -> kr [rows, D]
+extern "C" int t4r_xlnet_kr_proj(void* stream, const float* pos, const float* planes, float* kr, long rows, int D) {
+    if (rows <= 0) return 0;
+    T4R_CHECK_ARG(t4r_xlnet_fused_supported(D) && pos && planes && kr, "xlnet_kr_proj: bad arguments");
+    const int R = pick_r(rows);
+    ProjParams p{pos, carve_planes(planes, D).RT, kr, 0, rows};
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(DD, RR)                                                                                             \
+    {                                                                                                            \
+        const size_t smem = (size_t)3 * 16 * RR * (DD + 16) * 2;                                                 \
+        { static bool once = false; if (!once) { set_smem(xlnet_proj_kernel<DD, RR, 1>, smem); once = true; } }                                                            \
+        hipLaunchKernelGGL((xlnet_proj_kernel<DD, RR, 1>), dim3((unsigned)((rows + 16 * RR - 1) / (16 * RR))), dim3(DD * 4), smem, st, p); \
+    }
+    ATTN_DISPATCH(CALL, D, R)
+#undef CALL
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+// h1 = LayerNorm(dropout(attn_vec @ o^T) + h).  Training: ao [T, D] (pre-dropout projection), mean, rstd [T] saved;
+// inference: all three NULL and drop_p = 0.
+extern "C" int t4r_xlnet_oproj_ln(void* stream, const float* av, const float* h, const float* planes, const float* gamma,
+                                  const float* beta, float* ao, float* mean, float* rstd, float* h1, long T, int D, float eps,
+                                  float drop_p, unsigned long long seed, unsigned long long ctr_hi) {
+    if (T <= 0) return 0;
+    T4R_CHECK_ARG(t4r_xlnet_fused_supported(D) && av && h && planes && gamma && beta && h1, "xlnet_oproj_ln: bad arguments");
+    const bool train = ao != nullptr;
+    T4R_CHECK_ARG((mean != nullptr) == train && (rstd != nullptr) == train, "xlnet_oproj_ln: ao, mean, rstd go together");
+    T4R_CHECK_ARG(train || drop_p == 0.f, "xlnet_oproj_ln: dropout needs the saved activations");
+    const int R = pick_r(T);
+    OProjParams p{av, h, gamma, beta, carve_planes(planes, D).ON, ao, mean, rstd, h1, T, eps, make_drop(drop_p, seed, ctr_hi)};
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(DD, RR)                                                                                             \
+    {                                                                                                            \
+        const size_t smem = (size_t)3 * 16 * RR * (DD + 16) * 2 + (size_t)2 * (DD / 16) * 16 * RR * 4;           \
+        { static bool once = false; if (!once) { set_smem(xlnet_oproj_ln_kernel<DD, RR>, smem); once = true; } }                                                           \
+        hipLaunchKernelGGL((xlnet_oproj_ln_kernel<DD, RR>), dim3((unsigned)((T + 16 * RR - 1) / (16 * RR))), dim3(DD * 4), smem, st, p); \
+    }
+    ATTN_DISPATCH(CALL, D, R)
+#undef CALL
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" long t4r_xlnet_ln1_bwd_part_floats(long T, int D) { return ((T + 15) / 16) * 2L * D; }
+
+// LayerNorm-1 backward + d attn_vec.  dy = d loss / d h1.  Overwrites dh (residual part of d loss / d h), dao (d loss / d of
+// the o-projection output: rows of the o weight gradient d o += dao^T @ attn_vec) and dav (d loss / d attn_vec);
+// d_gamma, d_beta ACCUMULATED.  part: t4r_xlnet_ln1_bwd_part_floats(T, D) floats.
+extern "C" int t4r_xlnet_ln1_bwd(void* stream, const float* dy, const float* ao, const float* h, const float* mean,
+                                 const float* rstd, const float* gamma, const float* planes, float* dh, float* dao, float* dav,
+                                 float* d_gamma, float* d_beta, float* part, long T, int D, float drop_p,
+                                 unsigned long long seed, unsigned long long ctr_hi) {
+    if (T <= 0) return 0;
+    T4R_CHECK_ARG(t4r_xlnet_fused_supported(D) && dy && ao && h && mean && rstd && gamma && planes && dh && dao && dav && part,
+                  "xlnet_ln1_bwd: bad arguments");
+    const int R = pick_r(T);
+    const int nwg = (int)((T + 16 * R - 1) / (16 * R));
+    Ln1BwdParams p{dy, ao, h, mean, rstd, gamma, carve_planes(planes, D).OT, dh, dao, dav, part, T, make_drop(drop_p, seed, ctr_hi)};
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(DD, RR)                                                                                             \
+    {                                                                                                            \
+        const size_t smem = (size_t)3 * 16 * RR * (DD + 16) * 2 + (size_t)(DD / 16) * 2 * DD * 4;                \
+        { static bool once = false; if (!once) { set_smem(xlnet_ln1_bwd_kernel<DD, RR>, smem); once = true; } }                                                            \
+        hipLaunchKernelGGL((xlnet_ln1_bwd_kernel<DD, RR>), dim3((unsigned)nwg), dim3(DD * 4), smem, st, p);      \
+    }
+    ATTN_DISPATCH(CALL, D, R)
+#undef CALL
+    T4R_LAUNCH_CHECK();
+    return t4r_reduce_partials_launch(st, part, nwg, d_gamma, D, 1, d_beta, D, 1, nullptr, 0, 0);
+}
+
+// dh [T, D] += d q @ W_q^T + d k @ W_k^T + d v @ W_v^T   (dqkv [3][T][D])
+extern "C" int t4r_xlnet_dh(void* stream, const float* dqkv, const float* planes, float* dh, long T, int D) {
+    if (T <= 0) return 0;
+    T4R_CHECK_ARG(t4r_xlnet_fused_supported(D) && dqkv && planes && dh, "xlnet_dh: bad arguments");
+    const int R = pick_r(T);
+    DhParams p{dqkv, carve_planes(planes, D).QKVN, dh, T};
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(DD, RR)                                                                                             \
+    {                                                                                                            \
+        const size_t smem = (size_t)2 * 3 * 16 * RR * (DD + 16) * 2;                                             \
+        { static bool once = false; if (!once) { set_smem(xlnet_dh_kernel<DD, RR>, smem); once = true; } }                                                                 \
+        hipLaunchKernelGGL((xlnet_dh_kernel<DD, RR>), dim3((unsigned)((T + 16 * RR - 1) / (16 * RR))), dim3(DD * 4), smem, st, p); \
+    }
+    ATTN_DISPATCH(CALL, D, R)
+#undef CALL
+    T4R_LAUNCH_CHECK();
+    return 0;
+}

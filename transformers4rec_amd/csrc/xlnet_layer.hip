@@ -46,8 +46,16 @@ long t4r_xlnet_attn_bwd_ws_floats(int, int, int, int);
 // xlnet_fused.hip: token-tile-stationary feed-forward block (one launch forward, one backward)
 int t4r_xlnet_fused_supported(int D);
 long t4r_xlnet_ff_bwd_part_floats(long T, int D);
-long t4r_xlnet_ff_planes_floats(int D);
-int t4r_xlnet_ff_prepare(void*, const float*, const float*, int, float*);
+long t4r_xlnet_layer_planes_floats(int D);
+int t4r_xlnet_layer_prepare(void*, const float* const*, int, float*);
+int t4r_xlnet_qkv_proj(void*, const float*, const float*, float*, long, int);
+int t4r_xlnet_kr_proj(void*, const float*, const float*, float*, long, int);
+int t4r_xlnet_oproj_ln(void*, const float*, const float*, const float*, const float*, const float*, float*, float*, float*,
+                       float*, long, int, float, float, unsigned long long, unsigned long long);
+long t4r_xlnet_ln1_bwd_part_floats(long, int);
+int t4r_xlnet_ln1_bwd(void*, const float*, const float*, const float*, const float*, const float*, const float*, const float*,
+                      float*, float*, float*, float*, float*, float*, long, int, float, unsigned long long, unsigned long long);
+int t4r_xlnet_dh(void*, const float*, const float*, float*, long, int);
 int t4r_xlnet_ff_fwd(void*, const float*, const float*, const float*, const float*, const float*, const float*,
                      float*, float*, float*, float*, float*, float*, int, int, float, float,
                      unsigned long long, unsigned long long, unsigned long long);
@@ -108,7 +116,7 @@ static LayerWs carve(float* base, int B, int L, int D, int n, int per_batch_kr) 
     // with 288 GB of HBM saving beats regenerating it -- one launch less per layer)
     w.pe_b = per_batch_kr ? take((long)B * 2L * L * D) : nullptr;
     // bf16 planes of the feed-forward weights (fused kernels: cut once in the forward, reused by the backward)
-    w.planes = t4r_xlnet_fused_supported(D) ? take(t4r_xlnet_ff_planes_floats(D)) : nullptr;
+    w.planes = t4r_xlnet_fused_supported(D) ? take(t4r_xlnet_layer_planes_floats(D)) : nullptr;
     w.total = o;
     return w;
 }
@@ -124,7 +132,8 @@ extern "C" long t4r_xlnet_layer_bwd_ws_floats(int B, int L, int D, int n_head, i
     return align4(3 * T * D) + align4(T * D) + align4(T * D) + align4(T * 4 * D) + align4(nkr) +
            align4(t4r_xlnet_attn_bwd_ws_floats(B, L, D, n_head)) + align4(t4r_colreduce_ws_floats(T, 4 * D)) +
            2 * align4(t4r_colreduce_ws_floats(T, 2 * D)) + align4(t4r_colreduce_ws_floats(T, D)) +
-           (dropout ? align4(T * D) : 0) + align4(T * D) + align4(t4r_xlnet_ff_bwd_part_floats(T, D));
+           (dropout ? align4(T * D) : 0) + 2 * align4(T * D) + align4(t4r_xlnet_ff_bwd_part_floats(T, D)) +
+           align4(t4r_xlnet_ln1_bwd_part_floats(T, D));
 }
 
 #define RUN(call)                \
@@ -150,6 +159,30 @@ extern "C" int t4r_xlnet_layer_fwd(void* stream, const float* h, const float* po
     const float* v_w = params[P_V];
     const long TD = (long)T * D, DD = (long)D * D;
     auto C = [&](int site) { return ctr_hi(offset, layer_idx, site); };
+    if (use_fused(D)) {
+        // ONE launch cuts the layer's nine weight matrices into bf16 planes; q, k, v in one token-tile launch; k_r; the
+        // attention core; o-projection + dropout + residual + LayerNorm in one launch; the feed-forward block in one
+        RUN(t4r_xlnet_layer_prepare(stream, params, D, w.planes));
+        RUN(t4r_xlnet_qkv_proj(stream, h, w.planes, w.qkv, T, D));
+        if (drop) {
+            const float* pe_b = pos_emb_b;
+            if (!pe_b) {
+                RUN(t4r_dropout(stream, pos_emb, w.pe_b, nullptr, (long)B * 2 * L * D, 2L * L * D, drop_p, seed,
+                                ctr_hi(offset, 255, SITE_POS)));
+                pe_b = w.pe_b;
+            }
+            RUN(t4r_xlnet_kr_proj(stream, pe_b, w.planes, w.kr, (long)B * 2 * L, D));
+        } else {
+            RUN(t4r_xlnet_kr_proj(stream, pos_emb, w.planes, w.kr, 2L * L, D));
+        }
+        RUN(t4r_xlnet_attn_fwd(stream, w.qkv, w.qkv + TD, w.qkv + 2 * TD, w.kr, params[P_RWB], params[P_RRB], w.av, w.lse,
+                               B, L, n_head, dh, drop, drop_p, seed, C(SITE_PROB), key_len));
+        RUN(t4r_xlnet_oproj_ln(stream, w.av, h, w.planes, params[P_LN1W], params[P_LN1B], w.ao, w.mean1, w.rstd1, w.h1, T, D,
+                               ln_eps, drop_p, seed, C(SITE_ATTN_OUT)));
+        return t4r_xlnet_ff_fwd(stream, w.h1, w.planes, params[P_B1], params[P_B2], params[P_LN2W], params[P_LN2B], w.ffpre,
+                                w.ffact, w.ffout, w.mean2, w.rstd2, h_out, T, D, ln_eps, drop_p, seed, C(SITE_FF_ACT),
+                                C(SITE_FF_OUT));
+    }
     if (k_w == q_w + DD && v_w == q_w + 2 * DD) {
         RUN(t4r_gemm_launch(st, 0, 0, T, D, D, 1.f, h, D, q_w, D, w.qkv, D, nullptr, EPI_NONE, nullptr, 0,
                             1, 0, 3, 0, DD, TD, nullptr));
@@ -185,12 +218,6 @@ extern "C" int t4r_xlnet_layer_fwd(void* stream, const float* h, const float* po
                         nullptr, 0, 1, 0, 1, 0, 0, 0, nullptr));
     RUN(t4r_add_layernorm_fwd(stream, w.ao, h, params[P_LN1W], params[P_LN1B], w.h1, w.mean1, w.rstd1,
                               T, D, ln_eps, drop_p, seed, C(SITE_ATTN_OUT)));
-    if (use_fused(D)) {
-        RUN(t4r_xlnet_ff_prepare(stream, params[P_W1], params[P_W2], D, w.planes));
-        return t4r_xlnet_ff_fwd(stream, w.h1, w.planes, params[P_B1], params[P_B2], params[P_LN2W],
-                                params[P_LN2B], w.ffpre, w.ffact, w.ffout, w.mean2, w.rstd2, h_out, T, D, ln_eps, drop_p,
-                                seed, C(SITE_FF_ACT), C(SITE_FF_OUT));
-    }
     const DropCfg dff = make_drop(drop_p, seed, C(SITE_FF_ACT));
     RUN(t4r_gemm_launch(st, 0, 1, T, 4 * D, D, 1.f, w.h1, D, params[P_W1], D, w.ffact, 4 * D,
                         params[P_B1], EPI_BIAS_GELU, w.ffpre, 4 * D, 1, 0, 1, 0, 0, 0, &dff));
@@ -272,6 +299,8 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
     float* dfo = take(TD);                      // fused feed-forward backward: d ffout rows (own buffer: the FF2 weight
                                                 // gradient may still read them while the attention half runs)
     float* ff_part = take(t4r_xlnet_ff_bwd_part_floats(T, D));
+    float* dao_buf = take(TD);                  // fused LayerNorm-1 backward: d attn_out rows (own buffer, as dfo)
+    float* ln1_part = take(t4r_xlnet_ln1_bwd_part_floats(T, D));
     const bool fused = use_fused(D);
 
     SideStream* ss = side_stream();
@@ -325,8 +354,44 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
     RUN(t4r_gemm_launch(wg(), 1, 0, 4 * D, D, T, 1.f, dff, 4 * D, w.h1, D, grads[P_W1], D, nullptr,
                         EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
     }
+    if (fused) {
+        // LayerNorm-1 backward + d attn_vec in one launch; the attention core; d h from d q, d k, d v in one launch
+        RUN(t4r_xlnet_ln1_bwd(stream, dx, w.ao, h, w.mean1, w.rstd1, params[P_LN1W], w.planes, dh_in, dao_buf, dav,
+                              grads[P_LN1W], grads[P_LN1B], ln1_part, T, D, drop_p, seed, C(SITE_ATTN_OUT)));
+        RUN(t4r_gemm_launch(wg(), 1, 0, D, D, T, 1.f, dao_buf, D, w.av, D, grads[P_O], D, nullptr, EPI_NONE,
+                            nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
+        RUN(t4r_xlnet_attn_bwd(stream, w.qkv, w.qkv + TD, w.qkv + 2 * TD, w.kr, params[P_RWB],
+                               params[P_RRB], w.av, w.lse, dav, dqkv, dqkv + TD, dqkv + 2 * TD, dkr,
+                               grads[P_RWB], grads[P_RRB], attn_ws, B, L, n_head, dh, drop, drop_p, seed,
+                               C(SITE_PROB), key_len));
+        if (drop) {
+            RUN(t4r_gemm_launch(wg(), 1, 0, D, D, B * 2 * L, 1.f, pos_emb_b ? pos_emb_b : w.pe_b, D, dkr, D, grads[P_R], D,
+                                nullptr, EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
+        } else {
+            RUN(t4r_gemm_launch(wg(), 1, 0, D, D, 2 * L, 1.f, pos_emb, D, dkr, D, grads[P_R], D, nullptr,
+                                EPI_NONE, nullptr, 0, 1, 1, 1, 0, 0, 0, nullptr));
+        }
+        {
+            float* gz[3] = {grads[P_Q], grads[P_K], grads[P_V]};
+            hipStream_t sw = wg();
+            if (gz[1] == gz[0] + DD && gz[2] == gz[0] + 2 * DD) {
+                RUN(t4r_gemm_launch(sw, 1, 0, D, D, T, 1.f, h, D, dqkv, D, gz[0], D, nullptr, EPI_NONE, nullptr,
+                                    0, -1, 1, 3, 0, TD, DD, nullptr));
+            } else {
+                for (int z = 0; z < 3; ++z)
+                    RUN(t4r_gemm_launch(sw, 1, 0, D, D, T, 1.f, h, D, dqkv + z * TD, D, gz[z], D, nullptr,
+                                        EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
+            }
+        }
+        RUN(t4r_xlnet_dh(stream, dqkv, w.planes, dh_in, T, D));
+        if (ss) {   // join: the caller's stream continues after every weight gradient of this layer
+            (void)hipEventRecord(ss->done_all, ss->s);
+            (void)hipStreamWaitEvent(st, ss->done_all, 0);
+        }
+        return 0;
+    }
     // LN1: h1 = LN(drop(ao) + h): dh_in = d h (residual part), d ao = dxa (or dh_in when p = 0)
-    if (ss && drop && !fused) (void)hipStreamWaitEvent(st, ss->done_ff2, 0);    // the FF2 wgrad reads dxa, overwritten here
+    if (ss && drop) (void)hipStreamWaitEvent(st, ss->done_ff2, 0);    // the FF2 wgrad reads dxa, overwritten here
     RUN(t4r_add_layernorm_bwd(stream, w.ao, h, params[P_LN1W], w.mean1, w.rstd1, dx, dh_in, dxa,
                               grads[P_LN1W], grads[P_LN1B], red_ln1, T, D, 0, drop_p, seed, C(SITE_ATTN_OUT)));
     const float* dao = drop ? dxa : dh_in;

@@ -626,6 +626,87 @@ def xlnet_layer_bwd(h, pos_emb, params, grads, ws, dh_out, B, L, n_head, eps, bw
 
 
 # ------------------------------------------------------------------------------------ head
+# ------------------------------------------------------------------------------------ fused XLNet layer pieces
+def xlnet_fused_supported(D):
+    return bool(_lib.load().t4r_xlnet_fused_supported(int(D)))
+
+
+def xlnet_layer_prepare(params, D):
+    """bf16 planes of a layer's nine weight matrices (csrc/xlnet_fused_attn.hip); params in XLNET_PARAM_ORDER"""
+    planes = torch.empty(_lib.load().t4r_xlnet_layer_planes_floats(D), device=params[0].device, dtype=torch.float32)
+    ptrs, _keep = ptr_array([_chk(t, torch.float32) for t in params])
+    call("t4r_xlnet_layer_prepare", _stream(), ptrs, D, planes.data_ptr())
+    return planes
+
+
+def xlnet_qkv_proj(h, planes):
+    T, D = h.shape
+    qkv = torch.empty((3, T, D), device=h.device, dtype=torch.float32)
+    call("t4r_xlnet_qkv_proj", _stream(), _chk(h, torch.float32), planes.data_ptr(), qkv.data_ptr(), T, D)
+    return qkv
+
+
+def xlnet_kr_proj(pos, planes):
+    rows, D = pos.shape
+    kr = torch.empty((rows, D), device=pos.device, dtype=torch.float32)
+    call("t4r_xlnet_kr_proj", _stream(), _chk(pos, torch.float32), planes.data_ptr(), kr.data_ptr(), rows, D)
+    return kr
+
+
+def xlnet_oproj_ln(av, h, planes, gamma, beta, eps, drop=NO_DROP, train=True):
+    T, D = av.shape
+    h1 = torch.empty_like(av)
+    ao = torch.empty_like(av) if train else None
+    mean = torch.empty(T, device=av.device) if train else None
+    rstd = torch.empty(T, device=av.device) if train else None
+    call("t4r_xlnet_oproj_ln", _stream(), _chk(av, torch.float32), _chk(h, torch.float32), planes.data_ptr(), _chk(gamma),
+         _chk(beta), _p(ao), _p(mean), _p(rstd), h1.data_ptr(), T, D, float(eps), float(drop[0]), int(drop[1]), int(drop[2]))
+    return h1, ao, mean, rstd
+
+
+def xlnet_ln1_bwd(dy, ao, h, mean, rstd, gamma, planes, d_gamma, d_beta, drop=NO_DROP):
+    T, D = dy.shape
+    dh, dao, dav = torch.empty_like(dy), torch.empty_like(dy), torch.empty_like(dy)
+    part = torch.empty(max(1, _lib.load().t4r_xlnet_ln1_bwd_part_floats(T, D)), device=dy.device)
+    call("t4r_xlnet_ln1_bwd", _stream(), _chk(dy), _chk(ao), _chk(h), _chk(mean), _chk(rstd), _chk(gamma), planes.data_ptr(),
+         dh.data_ptr(), dao.data_ptr(), dav.data_ptr(), _chk(d_gamma), _chk(d_beta), part.data_ptr(), T, D, float(drop[0]),
+         int(drop[1]), int(drop[2]))
+    return dh, dao, dav
+
+
+def xlnet_dh_(dqkv, planes, dh):
+    _, T, D = dqkv.shape
+    call("t4r_xlnet_dh", _stream(), _chk(dqkv, torch.float32), planes.data_ptr(), _chk(dh, torch.float32), T, D)
+    return dh
+
+
+def xlnet_ff_fwd(h1, planes, b1, b2, gamma, beta, eps, drop_p=0.0, seed=0, ctr_act=0, ctr_out=0, train=True):
+    T, D = h1.shape
+    dev = h1.device
+    hout = torch.empty_like(h1)
+    saved = None
+    if train:
+        saved = dict(ffpre=torch.empty((T, 4 * D), device=dev), ffact=torch.empty((T, 4 * D), device=dev),
+                     ffout=torch.empty((T, D), device=dev), mean=torch.empty(T, device=dev), rstd=torch.empty(T, device=dev))
+    g = (lambda k: saved[k].data_ptr()) if train else (lambda k: None)
+    call("t4r_xlnet_ff_fwd", _stream(), _chk(h1, torch.float32), planes.data_ptr(), _chk(b1), _chk(b2), _chk(gamma), _chk(beta),
+         g("ffpre"), g("ffact"), g("ffout"), g("mean"), g("rstd"), hout.data_ptr(), T, D, float(eps), float(drop_p), int(seed),
+         int(ctr_act), int(ctr_out))
+    return hout, saved
+
+
+def xlnet_ff_bwd(dy, h1, saved, gamma, planes, d_gamma, d_beta, d_b2, d_b1, drop_p=0.0, seed=0, ctr_act=0, ctr_out=0):
+    T, D = dy.shape
+    dh1, dffout = torch.empty_like(dy), torch.empty_like(dy)
+    dpre = torch.empty((T, 4 * D), device=dy.device)
+    part = torch.empty(max(1, _lib.load().t4r_xlnet_ff_bwd_part_floats(T, D)), device=dy.device)
+    call("t4r_xlnet_ff_bwd", _stream(), _chk(dy), _chk(saved["ffout"]), _chk(h1), _chk(saved["mean"]), _chk(saved["rstd"]),
+         _chk(gamma), _chk(saved["ffpre"]), planes.data_ptr(), dh1.data_ptr(), dffout.data_ptr(), dpre.data_ptr(),
+         _chk(d_gamma), _chk(d_beta), _chk(d_b2), _chk(d_b1), part.data_ptr(), T, D, float(drop_p), int(seed), int(ctr_act),
+         int(ctr_out))
+    return dh1, dffout, dpre
+
+
 def softmax_ce_fwd(logits, labels, V, label_smoothing=0.0):
     """logits [N, ld] view or buffer whose row stride is the leading dimension."""
     N = logits.shape[0]

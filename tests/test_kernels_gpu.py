@@ -1247,7 +1247,10 @@ def _tok_gemm_epilogue_checks(ops):
     d_new = ops.gemm(A, W, False, True, bias=bias, epilogue=ops.EPI_BIAS_GELU, aux=aux, drop=drop)
     with ops.precision("fp32"):
         d_gen = ops.gemm(A, W, False, True, bias=bias, epilogue=ops.EPI_BIAS_GELU, aux=aux, drop=drop)
-    assert torch.equal(d_new == 0, d_gen == 0) and 0.25 < float((d_new == 0).float().mean()) < 0.35
+    # zeros in the same places -- where the activation itself is not (nearly) zero: gelu(x) underflows to -0.0 around
+    # x = -5.5 (1 + erf reaches 0), and the two kernels' pre-activations differ in the last bits there
+    live = torch.nn.functional.gelu(pre).abs() > 1e-4
+    assert torch.equal((d_new == 0) & live, (d_gen == 0) & live) and 0.25 < float((d_new == 0).float().mean()) < 0.35
     close(d_new, d_gen, atol=3e-5)
     res = torch.randn(M, N, device=DEV, generator=g)
     r_new = ops.gemm(A, W, False, True, bias=bias, epilogue=ops.EPI_BIAS_RESID, aux=res, drop=drop)

@@ -212,8 +212,13 @@ __global__ __launch_bounds__(256) void seq_features_fwd_fast_kernel(SeqFeatParam
     for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int j = 0; j < NCH; ++j)
-            if (tok0 + u < ntok && kind[j] >= 0)
-                *reinterpret_cast<float4*>(p.out + (long)(tok0 + u) * p.W + (gl + GROUP * j) * 4) = v[u][j];
+            if (tok0 + u < ntok && kind[j] >= 0) {
+                // streaming store: the output is consumed by the next kernel from HBM/MALL anyway, and a write-allocating
+                // store evicts table rows that other lookups of this launch would still hit in L2
+                typedef float nt4 __attribute__((ext_vector_type(4)));
+                const nt4 o = {v[u][j].x, v[u][j].y, v[u][j].z, v[u][j].w};
+                __builtin_nontemporal_store(o, reinterpret_cast<nt4*>(p.out + (long)(tok0 + u) * p.W + (gl + GROUP * j) * 4));
+            }
 }
 
 static int pick_group(int W) {

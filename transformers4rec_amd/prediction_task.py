@@ -100,12 +100,15 @@ class _Pre(nn.Module):
         self.module = module
 
 
-# the tied / untied head's d W on a side stream, under the body's backward (T4R_HEAD_SIDE_STREAM=0 turns it off).
+# the tied / untied head's d W on a side stream, under the body's backward (T4R_HEAD_SIDE_STREAM=1 turns it on).
 # Round 1: 5.64 -> 5.61 ms/step (opt-in then); round 2, with the faster split-form products: 5.17 / 5.12 -> 5.10 / 5.05
-# ms on one box (-1.4 %), so it is on by default.  Consumers order themselves after it: the input block's scatter
-# (wait_pending_grad), the optimizer (autograd callback below), the data-parallel table all-reduce
-# (distributed.GradReducer.reduce_tables_async waits for this stream).
-_SIDE_STREAM_ON = os.environ.get("T4R_HEAD_SIDE_STREAM", "1") == "1"
+# ms on one box (-1.4 %), on by default then.  Round 3: OFF by default -- the body's backward now starts with
+# token-tile kernels that take a whole CU each (one 512-thread workgroup, ~140 KB of LDS): next to the 0.5 ms d W launch
+# they wait for CUs instead of overlapping (first xlnet_ff_bwd_kernel of a step: 572 us beside it, 85 us alone), and the
+# two serialise anyway: 3.90 -> 3.85 ms/step on one box without the side stream.  Consumers order themselves after it
+# when it is on: the input block's scatter (wait_pending_grad), the optimizer (autograd callback below), the data-parallel
+# table all-reduce (distributed.GradReducer.reduce_tables_async waits for this stream).
+_SIDE_STREAM_ON = os.environ.get("T4R_HEAD_SIDE_STREAM", "0") == "1"
 # sampled softmax: weight gradient as (ids, rows) + deterministic sorted scatter (default) instead of row atomics
 _SAMPLED_ROWS = os.environ.get("T4R_SAMPLED_ROWS", "1") == "1"
 _SIDE_STREAMS = {}

@@ -33,3 +33,22 @@ for _ in range(3):
     ops.head_split_dx(ws, logits, lse, labels, g, V, W)
     ops.head_split_dw(ws, logits, lse, labels, g, V, D, dW)
 torch.cuda.synchronize()
+
+# round 3: the token-tile-stationary fused kernels of the XLNet layer at the benchmark size (csrc/xlnet_fused*.hip)
+from transformers4rec_amd import _lib
+g32 = lambda *s, std=0.05: torch.randn(*s, device="cuda") * std
+n, dh = 4, D // 4
+prm = [g32(D, n, dh), g32(D, n, dh), g32(D, n, dh), g32(D, n, dh), g32(D, n, dh), g32(n, dh), g32(n, dh), 1 + g32(D), g32(D),
+       g32(4 * D, D), g32(4 * D), g32(D, 4 * D), g32(D), 1 + g32(D), g32(D)]
+h = g32(T, D, std=1.0); dy = g32(T, D, std=1.0)
+z = lambda k: torch.zeros(k, device="cuda")
+for _ in range(3):
+    planes = ops.xlnet_layer_prepare(prm, D)
+    qkv = ops.xlnet_qkv_proj(h, planes)
+    kr = ops.xlnet_kr_proj(g32(2048 * 20, D, std=1.0), planes)
+    h1, ao, mean, rstd = ops.xlnet_oproj_ln(qkv[0].contiguous(), h, planes, prm[7], prm[8], 0.03, (0.3, 7, 11))
+    hout, sv = ops.xlnet_ff_fwd(h1, planes, prm[10], prm[12], prm[13], prm[14], 0.03, 0.3, 7, 12, 13)
+    ops.xlnet_ff_bwd(dy, h1, sv, prm[13], planes, z(D), z(D), z(D), z(4 * D), 0.3, 7, 12, 13)
+    dh, dao, dav = ops.xlnet_ln1_bwd(dy, ao, h, mean, rstd, prm[7], planes, z(D), z(D), (0.3, 7, 11))
+    ops.xlnet_dh_(qkv, planes, dh)
+torch.cuda.synchronize()

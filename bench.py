@@ -666,6 +666,43 @@ def main():
     gather_g_gbs = gather_g_bytes / (gather_g_ms * 1e-3) / 1e9
     del Wbig, ids_g, feats_g
 
+    # ---- the transformer body's fused kernels (csrc/xlnet_fused*.hip), timed live at this run's shape: the feed-forward
+    # block forward / backward (one launch each; 2 * T * 4D * D * 2 algorithmic flops per direction, six bf16 partial
+    # products executed per algorithmic product)
+    body = None
+    if ops.xlnet_fused_supported(D_MODEL):
+        Tt = BATCH * SEQ
+        lay = model.transformer_block.transformer.layer[0]
+        prm = [q.detach().contiguous() for q in lay.ordered_params()]
+        planes = ops.xlnet_layer_prepare(prm, D_MODEL)
+        h1 = torch.randn(Tt, D_MODEL, device=device)
+        dyy = torch.randn(Tt, D_MODEL, device=device)
+        _, sv = ops.xlnet_ff_fwd(h1, planes, prm[10], prm[12], prm[13], prm[14], 0.03, args.dropout, 7, 11, 12)
+        zz = lambda k: torch.zeros(k, device=device)
+        gbuf = (zz(D_MODEL), zz(D_MODEL), zz(D_MODEL), zz(4 * D_MODEL))
+        ff_fwd_ms = timed(lambda: ops.xlnet_ff_fwd(h1, planes, prm[10], prm[12], prm[13], prm[14], 0.03, args.dropout, 7, 11, 12))
+        ff_bwd_ms = timed(lambda: ops.xlnet_ff_bwd(dyy, h1, sv, prm[13], planes, *gbuf, args.dropout, 7, 11, 12))
+        ff_flops = 2.0 * Tt * 4 * D_MODEL * D_MODEL * 2
+        body = {"kernel": "xlnet_ff_fwd_kernel<128, 5> / xlnet_ff_bwd_kernel<128, 5> (token-tile-stationary feed-forward block, "
+                          "one launch per direction; fp32-accurate three-plane bf16 products)",
+                "bound": "mfma + valu (measured: VALU work does not issue under matrix instructions on this chip, "
+                         "tools/mfma_valu_overlap.hip)",
+                "fwd_avg_launch_ms": round(ff_fwd_ms, 4), "bwd_avg_launch_ms": round(ff_bwd_ms, 4),
+                "flops_per_launch": ff_flops, "executed_flops_per_launch": 6 * ff_flops,
+                "fwd": {"achieved": round(6 * ff_flops / (ff_fwd_ms * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(6 * ff_flops / (ff_fwd_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                        "fp32_equivalent_TFLOPs": round(ff_flops / (ff_fwd_ms * 1e-3) / 1e12, 1)},
+                "bwd": {"achieved": round(6 * ff_flops / (ff_bwd_ms * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(6 * ff_flops / (ff_bwd_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                        "fp32_equivalent_TFLOPs": round(ff_flops / (ff_bwd_ms * 1e-3) / 1e12, 1),
+                        "note": "includes the two partial-sum reductions of d gamma, d beta, d b2, d b1"},
+                "algorithmic_bytes_fwd": int(4 * Tt * D_MODEL * (2 + 8 + 1 + 1)), "algorithmic_bytes_bwd": int(4 * Tt * D_MODEL * (3 + 4 + 1 + 4 + 2)),
+                "traffic_fwd": 27.0e6 + 105.1e6, "traffic_bwd": 88.5e6 + 72.6e6,
+                "traffic_source": "committed (not measured in this run): profiles/r03_e_pmc_gemm_fetch_write.csv "
+                                  "(FETCH_SIZE x 2 KB + WRITE_SIZE KB, separate rocprofv3 --pmc passes)",
+                "matrix_pipe_busy": {"fwd": 0.218, "bwd": 0.169, "source": "profiles/r03_e_pmc_mfma_util.csv (in-step)"}}
+        del planes, h1, dyy, sv
+
     # HBM bytes of the launches from the PMC counters (FETCH_SIZE x2 on gfx950, WRITE_SIZE calibrated
     # on a known copy; collected in separate rocprofv3 --pmc passes and committed under profiles/).
     # It is a property of the kernel + shape, not of this run: taken from the committed measurement.
@@ -736,7 +773,7 @@ def main():
                          "algorithmic_bytes": int(4 * (N_m * D_MODEL + W.shape[0] * D_MODEL + N_m * W.shape[0])),
                          "avg_launch_ms": round(gemm_ms, 4), "flops_per_launch": flops,
                          "executed_flops_per_launch": executed},
-            "roofline_gather": {"kernel": "seq_features_fwd_fast_kernel<32, 2> (embedding gather)", "bound": "hbm",
+            "roofline_gather": {"kernel": "seq_features_fwd_fast_kernel<32, 2> (embedding gather, streaming stores)", "bound": "hbm",
                                 "achieved": round(gather_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(gather_gbs / HBM_PEAK_GBS, 4),
                                 "traffic": None if gj is None else gj.get("traffic_bytes_per_launch_c2"),
@@ -749,6 +786,8 @@ def main():
                                     "traffic": None if gj is None else gj.get("traffic_bytes_per_launch_8192"),
                                     "traffic_source": None if gj is None else gj.get("source")}},
         }
+        if body is not None:
+            res["roofline_body"] = body
         res["comm"] = comm
     # Recall@20, the other half of the metric.  N > 1: a collective probe, every rank takes part (T4R_BENCH_DP_RECALL=0
     # skips it on all ranks alike)

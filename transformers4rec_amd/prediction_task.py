@@ -452,6 +452,11 @@ class NextItemPredictionTask(nn.Module):
         W = mod.output_weights.detach()
         T = float(mod.softmax_temperature) if mod.softmax_temperature else 1.0
         V = W.shape[0]
+        if not torch.is_grad_enabled():      # registered operators (torch_ops.py): dispatcher-visible inference head
+            from . import torch_ops  # noqa: F401
+
+            scores = torch.ops.t4r_hip.item_scores(xr, W, 1.0 / T)
+            return scores if top_k is None else torch.ops.t4r_hip.topk(scores, top_k)
         scores = ops.gemm(xr, W, False, True, alpha=1.0 / T, ldc=ops.pad_ld(V))
         if top_k is None:
             return scores

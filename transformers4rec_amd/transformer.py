@@ -221,7 +221,16 @@ class XLNetModel(SeedMixin, nn.Module):
             h = _DropoutFn.apply(h, p, self.seed, ops.dropout_ctr_hi(offset, 255, ops.SITE_INPUT))
         # dropout(pos_emb) is drawn once per forward and shared by the layers (HF :1143)
         pos_b = ops.xlnet_pos_emb_dropout(pos, B, p, self.seed, offset) if p > 0 else None
+        # no gradient wanted (evaluation / inference under torch.no_grad()): the layers run as REGISTERED operators
+        # (torch.ops.t4r_hip.xlnet_layer_infer, torch_ops.py), so the body shows up in make_fx / export / compile graphs
+        infer = p == 0 and not torch.is_grad_enabled()
+        if infer:
+            from . import torch_ops  # noqa: F401  (registers the t4r_hip library)
         for i, layer in enumerate(self.layer):
+            if infer:
+                h = torch.ops.t4r_hip.xlnet_layer_infer(h.reshape(B * L, D), pos, layer.ordered_params(), B, L, cfg.n_head,
+                                                        cfg.layer_norm_eps, key_len).view(B, L, D)
+                continue
             h = _XLNetLayerFn.apply(h, layer.rel_attn.q, layer, pos, cfg.n_head, cfg.layer_norm_eps,
                                     (p, self.seed, offset, i), key_len, pos_b)
         if p > 0:

@@ -61,11 +61,30 @@ def build(device, dropout, v_items=V_ITEMS, d_model=D_MODEL, n_layer=N_LAYER, n_
     return tr, schema, model, dense, tables, opt
 
 
-def setup_data_parallel(tr, model, dense, tables, world):
+def table_exchange_mode():
+    """how the embedding-table gradient crosses the ranks (T4R_BENCH_TABLE_EXCHANGE):
+      "sparse" (default)  the tied head's dense d W is all-reduced EARLY (right after the head's backward, under the body's
+                          backward); the lookup scatter travels as (ids, rows): all-gather + the deterministic sorted scatter
+                          on every rank (84 MB gathered per step at C2 / 8 GPUs, exposed);
+      "dense"             every rank scatters its own lookups into its table gradient, then ONE table all-reduce (51 MB) at the
+                          end of the backward, exposed, nothing row-sparse.
+    Both give the same gradients (tests/test_distributed_cpu.py); which one is faster is a property of the fabric: measured by
+    the driver's 8-GPU run (`config.table_exchange` in the JSON line says which was used)."""
+    m = os.environ.get("T4R_BENCH_TABLE_EXCHANGE", "sparse")
+    if m not in ("sparse", "dense"):
+        raise SystemExit("T4R_BENCH_TABLE_EXCHANGE must be sparse or dense")
+    return m
+
+
+def setup_data_parallel(tr, model, dense, tables, world, mode=None):
     """-> (reducer, hook handle or None).  N > 1: async table all-reduce after the head's backward + row-sparse
-    exchange of the lookup scatter; N = 1: everything local (the reducer only runs the local scatter)."""
+    exchange of the lookup scatter (mode "sparse"), or local scatter + one late table all-reduce (mode "dense");
+    N = 1: everything local (the reducer only runs the local scatter)."""
     sparse = None
     hook = None
+    mode = mode or table_exchange_mode()
+    if mode == "dense" and os.environ.get("T4R_BENCH_SPARSE", "0") != "1":
+        return tr.GradReducer(dense.grad, tables.grad if tables is not None else None, sparse=None), None
     if world > 1 or os.environ.get("T4R_BENCH_SPARSE", "0") == "1":
         # full-softmax head: only the lookup scatter is row-sparse, B * L rows on every rank (weak scaling)
         sparse = tr.SparseRowExchange(equal_sizes=True)
@@ -743,7 +762,7 @@ def main():
                        "global_batch": BATCH * world, "seq_len": SEQ, "parallelism": f"dp{world}",
                        "dropout": args.dropout, "label_rows_per_step": N_m, "final_loss": round(loss, 4),
                        "head_mode": model.prediction_task.resolve_head_mode(N_m, W.shape[0]),
-                       "precision_mode": mode,
+                       "precision_mode": mode, "table_exchange": table_exchange_mode() if world > 1 else "local",
                        "preheat_s": round(preheat_s, 2), "preheat_steps": n_pre,
                        "timed_region_s": round(dt, 4)},
             "roofline": {"kernel": ("head_logits_ce_kernel<4> (next-item logits X@W^T + the softmax statistics of the loss; fp32-accurate: "

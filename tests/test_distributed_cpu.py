@@ -317,6 +317,50 @@ def _bench_worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
+def _bench_dense_worker(rank, world, port, ret):
+    """the "dense" table exchange of bench.setup_data_parallel: local scatter, one late table all-reduce"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    import transformers4rec_amd as tr
+    from transformers4rec_amd.optim import FlatParams
+
+    res = {}
+    for mode in ("dense", "sparse"):
+        torch.manual_seed(0)
+        model = _StubModel()
+        tables = FlatParams([("table", model.table)])
+        dense = FlatParams([(n, p) for n, p in model.transformer_block.named_parameters()])
+        if mode == "dense":
+            reducer, hook = bench.setup_data_parallel(tr, model, dense, tables, world, mode="dense")
+            assert hook is None and reducer.sparse is None and not hasattr(model.table, "_t4r_sparse_sink")
+        else:
+            sparse = tr.SparseRowExchange(apply_fn=_cpu_apply).attach(model.table)
+            reducer = tr.GradReducer(dense.grad, tables.grad, sparse=sparse)
+            tr.head_backward_hook(model, reducer.reduce_tables_async)
+        g = torch.Generator().manual_seed(50 + rank)
+        batches = [{"item_id": torch.randint(1, 30, (4, 5), generator=g)}]
+        step = bench.make_train_step(model, batches, reducer, _StubOpt())
+        dense.grad.zero_(); tables.grad.zero_()
+        step(0)
+        res[mode] = (tables.grad.clone(), dense.grad.clone())
+        tr.SparseRowExchange.detach(model.table)
+    if rank == 0:
+        ret["dt"] = float((res["dense"][0] - res["sparse"][0]).abs().max())
+        ret["dd"] = float((res["dense"][1] - res["sparse"][1]).abs().max())
+        ret["norm"] = float(res["dense"][0].abs().max())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dense_and_sparse_table_exchange_agree():
+    """the two ways of moving the table gradient between ranks are switchable and equivalent"""
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_bench_dense_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert ret["norm"] > 0 and ret["dt"] < 1e-6 and ret["dd"] < 1e-6
+
+
 def test_bench_train_step_wiring_world2():
     """bench.py's own make_train_step / timed_region / head-backward hook / rank seeds on 2 gloo ranks"""
     world = 2

@@ -57,7 +57,13 @@ def prep():
     _lib.call("t4r_xlnet_ff_prepare", ops._stream(), P(W1), P(W2), D, P(planes))
 
 
-print(f"ff_prepare (2 launches): {timed(prep):.1f} us")
+def fwd_infer():
+    _lib.call("t4r_xlnet_ff_fwd", ops._stream(), P(h1), P(planes), P(b1), P(b2), P(gam), P(bet), None, None, None, None, None,
+              P(hout), T, D, 0.03, 0.0, 7, 11, 12)
+
+
+print(f"ff_prepare: {timed(prep):.1f} us")
+print(f"ff_fwd inference form (nothing saved, no Philox): {timed(fwd_infer):.1f} us")
 for name, fn in (("ff_fwd", fwd), ("ff_bwd(+2 reduces)", bwd)):
     us = timed(fn)
     print(f"{name}: {us:.1f} us  {flops / us / 1e6:.1f} TFLOP/s ({flops / us / 1e6 / 157.3:.2f} of the fp32 matrix peak)  T={T} D={D} p={p}")

@@ -86,17 +86,22 @@ __device__ __forceinline__ void load_a3(AFrag<D>& a, const uint16_t* __restrict_
 template <int D, int R, int P>
 __device__ __forceinline__ void product3(const AFrag<D>& a, const uint16_t* bp, int bpl, f32x4 (&acc)[R]) {
     constexpr int KS = D / 32;
+    constexpr int RG = R > 3 ? 3 : R;          // token blocks per group: at most 3 x 3 planes of B fragments (36 VGPRs) live
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        u32x4 b[R][3];
 #pragma unroll
-        for (int r = 0; r < R; ++r)
+        for (int r0 = 0; r0 < R; r0 += RG) {
+            u32x4 b[RG][3];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) b[r][pl] = ldq(bp + pl * bpl + r * 16 * P + 32 * s);
+            for (int r = 0; r < RG; ++r)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    if (r0 + r < R) b[r][pl] = ldq(bp + pl * bpl + (r0 + r) * 16 * P + 32 * s);
 #define T4R_PROD(PA, PB)                                                        \
-        _Pragma("unroll") for (int r = 0; r < R; ++r) acc[r] = mfma_bf(a.v[s][PA], b[r][PB], acc[r]);
-        T4R_SIX(T4R_PROD)
+            _Pragma("unroll") for (int r = 0; r < RG; ++r)                      \
+                if (r0 + r < R) acc[r0 + r] = mfma_bf(a.v[s][PA], b[r][PB], acc[r0 + r]);
+            T4R_SIX(T4R_PROD)
 #undef T4R_PROD
+        }
     }
 }
-

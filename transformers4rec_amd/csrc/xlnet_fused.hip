@@ -85,8 +85,9 @@ __device__ __forceinline__ void ff_fwd_body(const FFFwdParams& p, uint16_t* smem
         product3<D, R, PH>(a1, sh_h + boff, PLN, acc1);
         load_a3<D>(a1, w1p + (long)min(c + 1, 3) * D * D, wpl);   // next chunk's FF1 fragment: in flight under the epilogue and FF2
 #else
-        load_a3<D>(a1, w1p + (long)c * D * D, wpl);
+        if (c == 0) load_a3<D>(a1, w1p, wpl);
         product3<D, R, PH>(a1, sh_h + boff, PLN, acc1);
+        load_a3<D>(a2, w2p + c * D, wpl);                     // in flight under the epilogue (a1 is dead: no extra registers)
 #endif
         // epilogue of chunk c: lane = (token r*16 + n, features d0 .. d0 + 3 of d_inner)
         const int d0 = c * D + 16 * w + 4 * g;
@@ -113,7 +114,7 @@ __device__ __forceinline__ void ff_fwd_body(const FFFwdParams& p, uint16_t* smem
         }
         __syncthreads();
 #if !T4R_FF_PREFETCH
-        load_a3<D>(a2, w2p + c * D, wpl);
+        if (c < 3) load_a3<D>(a1, w1p + (long)(c + 1) * D * D, wpl);   // next chunk's FF1 fragment, in flight under FF2
 #endif
         product3<D, R, PH>(a2, sh_a + boff, PLN, acc2);
     }

@@ -838,7 +838,12 @@ def rank_of_target(x, W, labels, alpha=1.0, chunk=1024):
     V = W.shape[0]
     rank = torch.empty(N, device=x.device, dtype=torch.int32)
     labels = labels.contiguous()
-    for s0 in range(0, N, chunk):           # target scores through the SAME kernel: diagonal of x_c @ W[y_c]^T
+    # Target scores through the SAME kernel (diagonal of x_c @ W[y_c]^T), not a separate row-dot product: an output
+    # element's bits do not depend on its tile position, so `score == target` detects exact ties (duplicated item rows)
+    # and "ties go to the lower index" holds bit for bit, as in the top-k of the materialised scores.  A row-dot kernel
+    # was tried in round 3 (cheaper by ~10 us) and broke exactly that: its rounding differs from the product's, so a tie
+    # with a duplicate row turns into an arbitrary </> (tests/test_kernels_gpu.py::test_rank_of_target_matches_topk_and_sort).
+    for s0 in range(0, N, chunk):
         xc, yc = x[s0: s0 + chunk], labels[s0: s0 + chunk]
         n = xc.shape[0]
         pos = yc.to(torch.int32)

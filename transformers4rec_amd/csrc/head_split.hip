@@ -609,6 +609,11 @@ __global__ __launch_bounds__(256) void head_dx_reduce_kernel(const float* __rest
     *op = s;
 }
 
+static int head_dx_target() {
+    static int target = -1;
+    if (target < 0) { const char* e = getenv("T4R_HEAD_DX_WGS"); target = e ? atoi(e) : 1536; }
+    return target;
+}
 // workspace layout (bytes): XA | XT | WT | d X partials
 struct HeadWs { long xa, xt, wt, part, stats, total; int nblk, nkt, max_split, ntile; };
 HeadWs head_ws(int N, int V, int D) {
@@ -616,7 +621,10 @@ HeadWs head_ws(int N, int V, int D) {
     w.nblk = (N + 31) / 32;
     w.nkt = (V + 31) / 32;
     const long blk = 12L * D * 16;
-    w.max_split = 64;
+    // upper bound of the d X split count t4r_head_split_dx can choose for these sizes (the same rule: <= 64, >= 8 k-tiles
+    // per split, ~T4R_HEAD_DX_WGS workgroups in total): the partial buffer is sized for it, not for 64 always
+    // (64 x N x D x 4 bytes was 1.1 GB of mostly unused workspace at N = 35 k, D = 128, held from forward to backward)
+    w.max_split = max(1, min(min(64, w.nkt / 8), head_dx_target() / ((N + 127) / 128)));
     w.xa = 0;
     w.xt = w.xa + w.nblk * blk;
     w.wt = w.xt + w.nblk * blk;
@@ -739,8 +747,7 @@ extern "C" int t4r_head_split_dx(void* stream, void* ws, const float* logits, lo
     float* part = reinterpret_cast<float*>((char*)ws + w.part);
     const int nkt = (Vc + 31) / 32, row_tiles = (N + 127) / 128;
     T4R_NB_SWITCH(D, hipLaunchKernelGGL(split_km_kernel<NB>, dim3(nkt), dim3(256), 0, st, W, ldw, Vc, wt));
-    static int target = -1;
-    if (target < 0) { const char* e = getenv("T4R_HEAD_DX_WGS"); target = e ? atoi(e) : 1536; }
+    const int target = head_dx_target();
     int splits = max(1, min(min(w.max_split, nkt / 8), target / row_tiles));
     const int kt_per = (nkt + splits - 1) / splits;
     splits = (nkt + kt_per - 1) / kt_per;          // every split owns at least one k-tile

@@ -85,7 +85,6 @@ __device__ __forceinline__ void ff_fwd_body(const FFFwdParams& p, uint16_t* smem
         product3<D, R, PH>(a1, sh_h + boff, PLN, acc1);
         load_a3<D>(a1, w1p + (long)min(c + 1, 3) * D * D, wpl);   // next chunk's FF1 fragment: in flight under the epilogue and FF2
 #else
-        if (c == 0) load_a3<D>(a1, w1p, wpl);
         product3<D, R, PH>(a1, sh_h + boff, PLN, acc1);
         load_a3<D>(a2, w2p + c * D, wpl);                     // in flight under the epilogue (a1 is dead: no extra registers)
 #endif

@@ -58,6 +58,83 @@ static bool auto_split(const GemmParams& p, bool ta, bool tb) {
     return 2.0 * p.M * p.N * (double)p.K >= (double)min_flops;
 }
 
+// ---------------------------------------------------------------- deterministic split-K (two stages)
+// Split-K launches normally add their partial tiles into C with fp32 atomics: run-to-run non-deterministic, and every
+// split of a tile finishes at the same time and hits the same addresses (same-address atomics serialise at the memory
+// side: a 128 x 128-tile experiment, tools/wgrad_planes_experiment.hip, lost 10-20 of 33-43 us to them).  While a SINK
+// is installed (t4r_splitk_sink_begin: the XLNet layer backward does, with a slice of its scratch), accumulating
+// split-K launches store their partial tiles into the sink instead and register a job; ONE launch
+// (t4r_splitk_sink_flush) then adds the partials of every job in split order:  C += ((p0 + p1) + p2) + ...
+// Measured in the step at BASELINE configs[1] (single stream, rocprofv3): FF weight gradients 33.8 -> 32.3 us, the
+// D x D ones 24.2 -> 20.5 us, the reduction 11 us per layer: 560 -> 549 us per step.  The point is the fixed order:
+// the body's parameter gradients are now bit-reproducible run to run (tests/test_kernels_gpu.py).
+struct SplitKJob { const float* part; float* out; int n4; int splits; };
+constexpr int kMaxSplitKJobs = 12;
+struct SplitKJobs { SplitKJob j[kMaxSplitKJobs]; int n; int blk_end[kMaxSplitKJobs]; };
+struct SplitKSink { float* ws = nullptr; long cap = 0, used = 0; SplitKJobs jobs; bool on = false; };
+static thread_local SplitKSink g_sink;
+
+// workgroup = 32 float4 columns x 8 split groups; group g adds splits g, g + 8, ... in order, the groups are added in order
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(SplitKJobs jobs) {
+    __shared__ float4 sm[8][32];
+    int ji = 0;
+    while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.blk_end[ji]) ++ji;
+    const SplitKJob job = jobs.j[ji];
+    const int b = blockIdx.x - (ji ? jobs.blk_end[ji - 1] : 0);
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int i = b * 32 + c;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < job.n4) {
+        const float4* p = reinterpret_cast<const float4*>(job.part) + i;
+        for (int s = g; s < job.splits; s += 8) {
+            const float4 v = p[(long)s * job.n4];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    sm[g][c] = acc;
+    __syncthreads();
+    if (g == 0 && i < job.n4) {
+#pragma unroll
+        for (int r = 1; r < 8; ++r) { const float4 v = sm[r][c]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+        float4* o = reinterpret_cast<float4*>(job.out) + i;
+        float4 t = *o;
+        t.x += acc.x; t.y += acc.y; t.z += acc.z; t.w += acc.w;
+        *o = t;
+    }
+}
+
+void t4r_splitk_sink_begin(float* ws, long cap_floats) {
+    static const int enabled = [] { const char* e = getenv("T4R_SPLITK_SINK"); return e ? atoi(e) : 1; }();
+    g_sink.ws = ws; g_sink.cap = cap_floats; g_sink.used = 0; g_sink.jobs.n = 0; g_sink.on = enabled && ws && cap_floats > 0;
+}
+int t4r_splitk_sink_flush(hipStream_t st) {
+    SplitKJobs& J = g_sink.jobs;
+    if (g_sink.on && J.n > 0) {
+        int blocks = 0;
+        for (int i = 0; i < J.n; ++i) { blocks += (J.j[i].n4 + 31) / 32; J.blk_end[i] = blocks; }
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, J);
+        T4R_LAUNCH_CHECK();
+    }
+    J.n = 0;
+    g_sink.used = 0;
+    return 0;
+}
+void t4r_splitk_sink_end() { g_sink.on = false; g_sink.ws = nullptr; g_sink.cap = 0; g_sink.jobs.n = 0; }
+// a split-K launch asks for room: returns the partial buffer (and registers the jobs) or null (-> atomics)
+static float* splitk_sink_take(const GemmParams& p, int batch) {
+    SplitKSink& k = g_sink;
+    if (!k.on || !p.accumulate || p.epilogue != EPI_NONE || p.sg_lse || p.rk_thr) return nullptr;
+    const long n = (long)p.M * p.ldc;                       // one partial = C's [M][ldc] image (dense outputs: ldc == N)
+    if (p.ldc != p.N || n % 4 || ((uintptr_t)p.C & 15) || (p.sC % 4) || k.jobs.n + batch > kMaxSplitKJobs) return nullptr;
+    const long need = n * p.splitk * batch;
+    if (k.used + need > k.cap || n / 4 > 0x7fffffffL) return nullptr;
+    float* part = k.ws + k.used;
+    k.used += need;
+    for (int b = 0; b < batch; ++b)
+        k.jobs.j[k.jobs.n++] = SplitKJob{part + (long)b * p.splitk * n, p.C + b * p.sC, (int)(n / 4), p.splitk};
+    return part;
+}
+
 template <bool TA, bool TB>
 static int launch_layout(GemmParams& p, int batch, int splitk_req, hipStream_t stream) {
     // tokens x small weight in an fp32-accurate mode: the token-stationary kernel (operands cut once, tok_gemm.hip)
@@ -134,6 +211,14 @@ static int launch_layout(GemmParams& p, int batch, int splitk_req, hipStream_t s
         splitk = min(splitk, 256);
     }
     p.splitk = max(1, splitk);
+    p.part = nullptr;
+    if (p.splitk > 1) {
+        // every split owns at least one k-tile (a partial tile must be written by its split)
+        const int bk0 = prec ? 32 : (bk_sel ? bk_sel : 16);
+        const int kt = (p.K + bk0 - 1) / bk0, kt_per = (kt + p.splitk - 1) / p.splitk;
+        p.splitk = (kt + kt_per - 1) / kt_per;
+        if (p.splitk > 1) p.part = splitk_sink_take(p, batch);
+    }
     // k-tile depth 16.  BK = 32 (16 MFMAs per barrier) wins isolated long-K launches (square 111 ->
     // 115 TF, wgrads 72 -> 80, head dX 91 -> 96; tools/gemm_bench.py) but loses on the K = 128
     // contractions (logits 85 -> 76 TF) and, selected per launch by K, made the whole training step
@@ -145,7 +230,7 @@ static int launch_layout(GemmParams& p, int batch, int splitk_req, hipStream_t s
     p.xcd_order = xcd_sel;
     if (p.splitk > 1) {
         if (p.epilogue != EPI_NONE) { t4r_set_error("gemm: split-K needs epilogue NONE"); return -1; }
-        if (!p.accumulate) {  // atomics accumulate: start from zero unless the caller accumulates
+        if (!p.accumulate && !p.part) {  // atomics accumulate: start from zero unless the caller accumulates
             for (int b = 0; b < batch; ++b)
                 (void)hipMemset2DAsync(p.C + b * p.sC, p.ldc * sizeof(float), 0, p.N * sizeof(float), p.M, stream);
         }
@@ -183,6 +268,7 @@ int t4r_gemm_launch(hipStream_t stream, int transA, int transB, int M, int N, in
     p.vecA = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0) && (sA % 4 == 0);
     p.vecB = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0) && (sB % 4 == 0);
     p.splitk = 1;
+    p.part = nullptr;
     p.drop = drop ? *drop : make_drop(0.f, 0, 0);
     p.sg_lse = nullptr; p.sg_labels = nullptr; p.sg_gout = nullptr; p.sg_rows = 1; p.sg_V = 1; p.sg_smooth = 0.f; p.sg_yoff = 0;
     p.rk_thr = nullptr; p.rk_label = nullptr; p.rk_count = nullptr;

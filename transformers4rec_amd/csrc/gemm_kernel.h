@@ -49,7 +49,9 @@ struct GemmParams {
     float* aux; long ldaux;     // EPI_BIAS_GELU: pre-activation (x + bias) written here
     float alpha;
     int epilogue;
-    int splitk;                 // >1: atomic accumulate alpha*partial into C (epilogue must be NONE)
+    int splitk;                 // >1: atomic accumulate alpha*partial into C (epilogue must be NONE) ...
+    float* part;                // ... or, non-null: split z (= blockIdx.z, batch-major) stores its partial tile to
+                                // part + z * M * ldc (C's layout); a reduction pass adds them in split order (gemm_f32.hip)
     int accumulate;             // splitk==1 only: C += result instead of C = result
     long sA, sB, sC;            // batch strides in elements (gridDim.z = batch * splitk)
     int vecA, vecB;             // 16-byte vector loads legal for this operand
@@ -682,7 +684,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         }
     };
     if (p.splitk > 1) {
-        for_each_out([&](float* cp, int, int, float v, float) __attribute__((always_inline)) { atomicAdd(cp, v); });
+        if (p.part) {
+            float* P = p.part + (long)blockIdx.z * ((long)p.M * p.ldc);
+            for_each_out([&](float* cp, int, int, float v, float) __attribute__((always_inline)) { P[cp - C] = v; });
+        } else {
+            for_each_out([&](float* cp, int, int, float v, float) __attribute__((always_inline)) { atomicAdd(cp, v); });
+        }
     } else if (p.epilogue == EPI_NONE) {
         if (p.accumulate) for_each_out([&](float* cp, int, int, float v, float) __attribute__((always_inline)) { *cp += v; });
         else for_each_out([&](float* cp, int, int, float v, float) __attribute__((always_inline)) { *cp = v; });

@@ -74,6 +74,9 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 }
 
 // Philox4x32-10 counter RNG (device-side draws for MLM masking / dropout).
+#ifndef T4R_PHILOX_ROUNDS
+#define T4R_PHILOX_ROUNDS 10
+#endif
 struct Philox {
     uint32_t k0, k1;
     __device__ __forceinline__ Philox(uint64_t seed) : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)) {}
@@ -82,7 +85,7 @@ struct Philox {
         uint32_t c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
         uint32_t a = k0, b = k1;
 #pragma unroll
-        for (int r = 0; r < 10; ++r) {
+        for (int r = 0; r < T4R_PHILOX_ROUNDS; ++r) {
             const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
             const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
             const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ a;
@@ -127,6 +130,9 @@ __device__ __forceinline__ float u32_to_unit(uint32_t x) {  // [0,1)
 struct DropCfg {
     float p;          // 0 => disabled
     float inv_keep;   // 1 / (1 - p)
+    uint32_t thr;     // keep <=> word >= thr: the integer form of  u32_to_unit(word) >= p  (same decisions: the top 24
+                      // bits k of the word give u = k 2^-24 exactly, so u >= p <=> k >= ceil(p 2^24) <=> word >= ceil(p 2^24) << 8);
+                      // one compare per element instead of shift + convert + multiply + compare
     unsigned long long seed;
     unsigned long long ctr_hi;
 };
@@ -135,14 +141,14 @@ __device__ __forceinline__ float drop_scale(const DropCfg& d, unsigned long long
     const uint4 r = rng(idx >> 2, d.ctr_hi);
     const unsigned k = (unsigned)(idx & 3);
     const uint32_t v = k == 0 ? r.x : (k == 1 ? r.y : (k == 2 ? r.z : r.w));
-    return u32_to_unit(v) >= d.p ? d.inv_keep : 0.f;
+    return v >= d.thr ? d.inv_keep : 0.f;
 }
 // four consecutive elements starting at a multiple of 4
 __device__ __forceinline__ float4 drop_scale4(const DropCfg& d, unsigned long long idx4) {
     const Philox rng(d.seed);
     const uint4 r = rng(idx4 >> 2, d.ctr_hi);
-    return make_float4(u32_to_unit(r.x) >= d.p ? d.inv_keep : 0.f, u32_to_unit(r.y) >= d.p ? d.inv_keep : 0.f,
-                       u32_to_unit(r.z) >= d.p ? d.inv_keep : 0.f, u32_to_unit(r.w) >= d.p ? d.inv_keep : 0.f);
+    return make_float4(r.x >= d.thr ? d.inv_keep : 0.f, r.y >= d.thr ? d.inv_keep : 0.f, r.z >= d.thr ? d.inv_keep : 0.f,
+                       r.w >= d.thr ? d.inv_keep : 0.f);
 }
 // masks of the 16 consecutive elements idx0 .. idx0+15 of which the first n are needed (the rest get 1).
 // aligned (wave uniform; caller guarantees idx0 % 4 == 0 and n % 4 == 0): one Philox block per four
@@ -193,7 +199,7 @@ __device__ __forceinline__ void drop_scale_quad(const DropCfg& d, unsigned long 
         const uint32_t t0 = quad_bcast<K>(w.x), t1 = quad_bcast<K>(w.y), t2 = quad_bcast<K>(w.z),        \
                        t3 = quad_bcast<K>(w.w);                                                          \
         const uint32_t sel = q == 0 ? t0 : (q == 1 ? t1 : (q == 2 ? t2 : t3));                            \
-        m[K] = u32_to_unit(sel) >= d.p ? d.inv_keep : 0.f;                                               \
+        m[K] = sel >= d.thr ? d.inv_keep : 0.f;                                                           \
     }
     T4R_QSEL(0) T4R_QSEL(1) T4R_QSEL(2) T4R_QSEL(3)
 #undef T4R_QSEL
@@ -201,5 +207,6 @@ __device__ __forceinline__ void drop_scale_quad(const DropCfg& d, unsigned long 
 static inline DropCfg make_drop(float p, unsigned long long seed, unsigned long long ctr_hi) {
     DropCfg d;
     d.p = p; d.inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f; d.seed = seed; d.ctr_hi = ctr_hi;
+    d.thr = p <= 0.f ? 0u : (p >= 1.f ? 0xffffffffu : ((uint32_t)ceilf(p * 16777216.0f)) << 8);
     return d;
 }

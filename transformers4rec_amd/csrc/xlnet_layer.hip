@@ -32,6 +32,9 @@ int t4r_colsum(void*, const float*, float*, float*, long, int, long);
 long t4r_colreduce_ws_floats(long, int);
 }
 void t4r_reduce_redirect(hipStream_t side, hipEvent_t* events, int n_events);   // elementwise.hip
+void t4r_splitk_sink_begin(float* ws, long cap_floats);                          // gemm_f32.hip: deterministic split-K
+int t4r_splitk_sink_flush(hipStream_t st);
+void t4r_splitk_sink_end();
 extern "C" {
 int t4r_dropout(void*, const float*, float*, unsigned char*, long, long, float, unsigned long long,
                 unsigned long long);
@@ -125,6 +128,10 @@ static LayerWs carve(float* base, int B, int L, int D, int n, int per_batch_kr) 
 extern "C" long t4r_xlnet_layer_ws_floats(int B, int L, int D, int n_head, int dropout) {
     return carve(nullptr, B, L, D, n_head, dropout).total;
 }
+// partial tiles of the layer's split-K weight gradients (gemm_f32.hip: deterministic split-K): the split rule gives at
+// most K / 320 + 1 splits per product (>= 20 k-tiles of 16 each), K = T (2 T for d r with per-session k_r); outputs
+// 2 x 4 D^2 (FF) + 4 D^2 (q, k, v, o) + D^2 (r)
+static long splitk_sink_floats(long T, int D) { return (T / 320 + 2) * 12L * D * D + (2 * T / 320 + 2) * (long)D * D; }
 // backward scratch: dqkv [3,T,D] + dav [T,D] + dx [T,D] + dff [T,4D] + dkr [2L,D] + attention partials
 extern "C" long t4r_xlnet_layer_bwd_ws_floats(int B, int L, int D, int n_head, int dropout) {
     const long T = (long)B * L;
@@ -133,7 +140,7 @@ extern "C" long t4r_xlnet_layer_bwd_ws_floats(int B, int L, int D, int n_head, i
            align4(t4r_xlnet_attn_bwd_ws_floats(B, L, D, n_head)) + align4(t4r_colreduce_ws_floats(T, 4 * D)) +
            2 * align4(t4r_colreduce_ws_floats(T, 2 * D)) + align4(t4r_colreduce_ws_floats(T, D)) +
            (dropout ? align4(T * D) : 0) + 2 * align4(T * D) + align4(t4r_xlnet_ff_bwd_part_floats(T, D)) +
-           align4(t4r_xlnet_ln1_bwd_part_floats(T, D));
+           align4(t4r_xlnet_ln1_bwd_part_floats(T, D)) + align4(splitk_sink_floats(T, D));
 }
 
 #define RUN(call)                \
@@ -302,6 +309,11 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
     float* dao_buf = take(TD);                  // fused LayerNorm-1 backward: d attn_out rows (own buffer, as dfo)
     float* ln1_part = take(t4r_xlnet_ln1_bwd_part_floats(T, D));
     const bool fused = use_fused(D);
+    // the split-K weight gradients of this call leave their partial tiles here; one launch adds them at the end
+    struct SinkGuard {
+        SinkGuard(float* ws, long cap) { t4r_splitk_sink_begin(ws, cap); }
+        ~SinkGuard() { t4r_splitk_sink_end(); }
+    } sink_guard(take(splitk_sink_floats(T, D)), splitk_sink_floats(T, D));
 
     SideStream* ss = side_stream();
     struct RedirectGuard {      // second stages of the column reductions -> side stream, for this call only
@@ -384,6 +396,7 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
             }
         }
         RUN(t4r_xlnet_dh(stream, dqkv, w.planes, dh_in, T, D));
+        RUN(t4r_splitk_sink_flush(ss ? ss->s : st));
         if (ss) {   // join: the caller's stream continues after every weight gradient of this layer
             (void)hipEventRecord(ss->done_all, ss->s);
             (void)hipStreamWaitEvent(st, ss->done_all, 0);
@@ -432,6 +445,7 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
     for (int z = 0; z < 3; ++z)
         RUN(t4r_gemm_launch(st, 0, 1, T, D, D, 1.f, dqkv + z * TD, D, wz[z], D, dh_in, D, nullptr,
                             EPI_NONE, nullptr, 0, 1, 1, 1, 0, 0, 0, nullptr));
+    RUN(t4r_splitk_sink_flush(ss ? ss->s : st));
     if (ss) {   // join: the caller's stream continues after every weight gradient of this layer
         (void)hipEventRecord(ss->done_all, ss->s);
         (void)hipStreamWaitEvent(st, ss->done_all, 0);

@@ -394,6 +394,15 @@ int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* pos_emb, cons
                         float* dh_in, int B, int L, int D, int n_head, float ln_eps, float drop_p,
                         unsigned long long seed, unsigned long long offset, int layer_idx, const int* key_len,
                         const float* pos_emb_b);
+/* Deferred join of the layer backward's weight-gradient streams (csrc/xlnet_layer.hip).  After
+ * t4r_xlnet_layer_bwd_defer(1) a t4r_xlnet_layer_bwd call on this thread returns without ordering `stream` after its
+ * weight gradients (q, k, v, o, r, W1, W2 and the bias / LayerNorm sums may still be accumulating); the caller keeps
+ * every buffer it passed alive and unwritten and calls t4r_xlnet_layer_bwd_join(stream) before the gradients are read
+ * or those buffers are reused.  Default 0: every call joins before it returns (reference semantics: autograd returns
+ * finished gradients, transformers4rec/torch/block/transformer.py:179-199 under torch.autograd). */
+void t4r_xlnet_layer_bwd_defer(int on);
+int t4r_xlnet_layer_bwd_join(void* stream);
+
 
 /* ----------------------------------------------------------------------------------------
  * a18-a21  next-item head

@@ -79,6 +79,8 @@ _SIGS = {
     "t4r_xlnet_ln1_bwd_part_floats": ("l", "li"),
     "t4r_xlnet_ln1_bwd": ("i", "p" + "ppppppp" + "pppppp" + "lif" + "QQ"),
     "t4r_xlnet_dh": ("i", "pppp" + "li"),
+    "t4r_xlnet_layer_bwd_defer": ("v", "i"),
+    "t4r_xlnet_layer_bwd_join": ("i", "p"),
     "t4r_xlnet_ff_planes_floats": ("l", "i"),
     "t4r_xlnet_ff_prepare": ("i", "pppip"),
     "t4r_xlnet_ff_fwd": ("i", "p" + "pppppp" + "pppppp" + "iiff" + "QQQ"),

@@ -172,10 +172,17 @@ void t4r_reduce_redirect(hipStream_t side, hipEvent_t* events, int n_events) {
     g_red_side = side; g_red_events = events; g_red_n = side ? n_events : 0; g_red_used = 0;
 }
 
+bool t4r_splitk_sink_add_reduce(const float* part, int nblocks, int n, float* const* outs, const int* lens, const int* accs,
+                                int n_seg);     // gemm_f32.hip
 int t4r_reduce_partials_launch(hipStream_t st, const float* part, int nblocks, float* o0, int n0, int a0,
                                float* o1, int n1, int a1, float* o2, int n2, int a2) {
     const int n = n0 + n1 + n2;
     if (n <= 0 || nblocks <= 0) return 0;
+    {   // inside a layer backward the sums join the layer's one reduction launch (gemm_f32.hip: split-K sink)
+        float* const outs[3] = {o0, o1, o2};
+        const int lens[3] = {n0, n1, n2}, accs[3] = {a0, a1, a2};
+        if (t4r_splitk_sink_add_reduce(part, nblocks, n, outs, lens, accs, 3)) return 0;
+    }
     ReduceSeg s0{o0, n0, a0}, s1{o1, n1, a1}, s2{o2, n2, a2};
     if (g_red_side && g_red_used < g_red_n) {
         hipEvent_t ev = g_red_events[g_red_used++];

@@ -65,41 +65,48 @@ static bool auto_split(const GemmParams& p, bool ta, bool tb) {
 // is installed (t4r_splitk_sink_begin: the XLNet layer backward does, with a slice of its scratch), accumulating
 // split-K launches store their partial tiles into the sink instead and register a job; ONE launch
 // (t4r_splitk_sink_flush) then adds the partials of every job in split order:  C += ((p0 + p1) + p2) + ...
+// The second stages of the layer's column reductions (bias / LayerNorm / attention-bias gradients) ride in the same
+// launch (t4r_splitk_sink_add_reduce): one reduction launch per layer backward instead of four small ones + atomics.
 // Measured in the step at BASELINE configs[1] (single stream, rocprofv3): FF weight gradients 33.8 -> 32.3 us, the
 // D x D ones 24.2 -> 20.5 us, the reduction 11 us per layer: 560 -> 549 us per step.  The point is the fixed order:
 // the body's parameter gradients are now bit-reproducible run to run (tests/test_kernels_gpu.py).
-struct SplitKJob { const float* part; float* out; int n4; int splits; };
-constexpr int kMaxSplitKJobs = 12;
+struct SplitKJob { const float* part; float* out; int n4; int splits; long stride4; int accumulate; };
+constexpr int kMaxSplitKJobs = 20;
 struct SplitKJobs { SplitKJob j[kMaxSplitKJobs]; int n; int blk_end[kMaxSplitKJobs]; };
 struct SplitKSink { float* ws = nullptr; long cap = 0, used = 0; SplitKJobs jobs; bool on = false; };
 static thread_local SplitKSink g_sink;
 
-// workgroup = 32 float4 columns x 8 split groups; group g adds splits g, g + 8, ... in order, the groups are added in order
+// workgroup = 16 float4 columns x 16 split groups; group g adds splits g, g + 16, ... in order (four loads in flight per
+// thread: a job with 256 partial rows and 32 columns is ONE workgroup, its time is its dependent load chain), then the
+// groups are added in order
+__device__ __forceinline__ void add4(float4& a, const float4 v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(SplitKJobs jobs) {
-    __shared__ float4 sm[8][32];
+    __shared__ float4 sm[16][16];
     int ji = 0;
     while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.blk_end[ji]) ++ji;
     const SplitKJob job = jobs.j[ji];
     const int b = blockIdx.x - (ji ? jobs.blk_end[ji - 1] : 0);
-    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const int i = b * 32 + c;
+    const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int i = b * 16 + c;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < job.n4) {
         const float4* p = reinterpret_cast<const float4*>(job.part) + i;
-        for (int s = g; s < job.splits; s += 8) {
-            const float4 v = p[(long)s * job.n4];
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        int s = g;
+        for (; s + 48 < job.splits; s += 64) {
+            const float4 v0 = p[(long)s * job.stride4], v1 = p[(long)(s + 16) * job.stride4];
+            const float4 v2 = p[(long)(s + 32) * job.stride4], v3 = p[(long)(s + 48) * job.stride4];
+            add4(acc, v0); add4(acc, v1); add4(acc, v2); add4(acc, v3);
         }
+        for (; s < job.splits; s += 16) add4(acc, p[(long)s * job.stride4]);
     }
     sm[g][c] = acc;
     __syncthreads();
     if (g == 0 && i < job.n4) {
 #pragma unroll
-        for (int r = 1; r < 8; ++r) { const float4 v = sm[r][c]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+        for (int r = 1; r < 16; ++r) add4(acc, sm[r][c]);
         float4* o = reinterpret_cast<float4*>(job.out) + i;
-        float4 t = *o;
-        t.x += acc.x; t.y += acc.y; t.z += acc.z; t.w += acc.w;
-        *o = t;
+        if (job.accumulate) add4(acc, *o);
+        *o = acc;
     }
 }
 
@@ -111,12 +118,11 @@ int t4r_splitk_sink_flush(hipStream_t st) {
     SplitKJobs& J = g_sink.jobs;
     if (g_sink.on && J.n > 0) {
         int blocks = 0;
-        for (int i = 0; i < J.n; ++i) { blocks += (J.j[i].n4 + 31) / 32; J.blk_end[i] = blocks; }
+        for (int i = 0; i < J.n; ++i) { blocks += (J.j[i].n4 + 15) / 16; J.blk_end[i] = blocks; }
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, J);
         T4R_LAUNCH_CHECK();
     }
-    J.n = 0;
-    g_sink.used = 0;
+    J.n = 0;       // the partial buffers stay allocated until the sink ends: a later flush may run on another stream
     return 0;
 }
 void t4r_splitk_sink_end() { g_sink.on = false; g_sink.ws = nullptr; g_sink.cap = 0; g_sink.jobs.n = 0; }
@@ -131,8 +137,29 @@ static float* splitk_sink_take(const GemmParams& p, int batch) {
     float* part = k.ws + k.used;
     k.used += need;
     for (int b = 0; b < batch; ++b)
-        k.jobs.j[k.jobs.n++] = SplitKJob{part + (long)b * p.splitk * n, p.C + b * p.sC, (int)(n / 4), p.splitk};
+        k.jobs.j[k.jobs.n++] = SplitKJob{part + (long)b * p.splitk * n, p.C + b * p.sC, (int)(n / 4), p.splitk, n / 4, 1};
     return part;
+}
+// the second stage of a column reduction (elementwise.hip: t4r_reduce_partials_launch, out_s[i] (+)= sum_b part[b * n + off_s + i])
+// joins the same launch while a sink is installed: false -> the caller launches its own kernel
+bool t4r_splitk_sink_add_reduce(const float* part, int nblocks, int n, float* const* outs, const int* lens, const int* accs,
+                                int n_seg) {
+    SplitKSink& k = g_sink;
+    if (!k.on || nblocks <= 0 || (n & 3) || ((uintptr_t)part & 15)) return false;
+    int live = 0;
+    for (int s = 0; s < n_seg; ++s) {
+        if (lens[s] & 3) return false;
+        // only sums ACCUMULATED into their output are deferred (parameter gradients, read after the layer); an overwriting
+        // one is an intermediate of the layer (d k_r with a shared k_r feeds the r weight gradient) and runs at once
+        if (outs[s] && lens[s] > 0) { if (((uintptr_t)outs[s] & 15) || !accs[s]) return false; ++live; }
+    }
+    if (k.jobs.n + live > kMaxSplitKJobs) return false;
+    int off = 0;
+    for (int s = 0; s < n_seg; ++s) {
+        if (outs[s] && lens[s] > 0) k.jobs.j[k.jobs.n++] = SplitKJob{part + off, outs[s], lens[s] / 4, nblocks, n / 4, accs[s]};
+        off += lens[s];
+    }
+    return true;
 }
 
 template <bool TA, bool TB>

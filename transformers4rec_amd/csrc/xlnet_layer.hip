@@ -243,11 +243,18 @@ extern "C" int t4r_xlnet_layer_fwd(void* stream, const float* h, const float* po
 // the call -- after the call returns, everything on `stream` is ordered after all of its work.
 // T4R_LAYER_SIDE_STREAM=0 keeps everything on one stream.
 struct SideStream {
-    hipStream_t s = nullptr;
-    hipEvent_t fork[6] = {}, red[8] = {}, done_ff2 = nullptr, done_o = nullptr, done_all = nullptr;
+    hipStream_t s = nullptr, s2 = nullptr;   // s2: the attention half's weight gradients (fused path), see t4r_xlnet_layer_bwd
+    hipEvent_t done_s2 = nullptr, join1 = nullptr, join2 = nullptr;   // join*: recorded by t4r_xlnet_layer_bwd_join only (under its mutex)
+    hipEvent_t fork[8] = {}, red[8] = {}, done_ff2 = nullptr, done_o = nullptr, done_all = nullptr;
     int state = 0;    // 0 untried, 1 ready, -1 disabled / failed
 };
 static thread_local SideStream g_side;
+// every thread's side streams (the autograd engine runs a layer backward on its device thread and its end-of-backward
+// callback on whichever thread finishes the graph task: t4r_xlnet_layer_bwd_join waits for ALL of them)
+#include <mutex>
+#include <vector>
+static std::mutex g_side_mu;
+static std::vector<SideStream*> g_side_all;
 
 static SideStream* side_stream() {
     SideStream& ss = g_side;
@@ -260,17 +267,39 @@ static SideStream* side_stream() {
             (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
             const char* pe = getenv("T4R_LAYER_SIDE_PRIO");
             const int prio = pe ? atoi(pe) : lo;
+            // the events order streams of ONE device: no system-scope fence (cache write-back to host visibility) at each record
+            const char* fe = getenv("T4R_LAYER_EVENT_SYSFENCE");
+            const unsigned evf = hipEventDisableTiming | ((fe && atoi(fe)) ? 0u : hipEventDisableSystemFence);
             bool ok = hipStreamCreateWithPriority(&ss.s, hipStreamNonBlocking, prio) == hipSuccess;
-            for (int i = 0; ok && i < 6; ++i) ok = hipEventCreateWithFlags(&ss.fork[i], hipEventDisableTiming) == hipSuccess;
-            for (int i = 0; ok && i < 8; ++i) ok = hipEventCreateWithFlags(&ss.red[i], hipEventDisableTiming) == hipSuccess;
-            ok = ok && hipEventCreateWithFlags(&ss.done_ff2, hipEventDisableTiming) == hipSuccess;
-            ok = ok && hipEventCreateWithFlags(&ss.done_o, hipEventDisableTiming) == hipSuccess;
-            ok = ok && hipEventCreateWithFlags(&ss.done_all, hipEventDisableTiming) == hipSuccess;
-            if (ok) ss.state = 1;
+            ok = ok && hipStreamCreateWithPriority(&ss.s2, hipStreamNonBlocking, prio) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&ss.done_s2, evf) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&ss.join1, evf) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&ss.join2, evf) == hipSuccess;
+            for (int i = 0; ok && i < 8; ++i) ok = hipEventCreateWithFlags(&ss.fork[i], evf) == hipSuccess;
+            for (int i = 0; ok && i < 8; ++i) ok = hipEventCreateWithFlags(&ss.red[i], evf) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&ss.done_ff2, evf) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&ss.done_o, evf) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&ss.done_all, evf) == hipSuccess;
+            if (ok) {
+                ss.state = 1;
+                std::lock_guard<std::mutex> lk(g_side_mu);
+                g_side_all.push_back(&ss);
+            }
         }
     }
     return ss.state == 1 ? &ss : nullptr;
 }
+
+// Deferred join (opt-in, t4r_xlnet_layer_bwd_defer(1)): the call returns WITHOUT making the caller's stream wait for its
+// weight-gradient streams.  After the attention core only ~35 us of critical-chain work are left (d h) but ~90 us of
+// weight-gradient work (r, q|k|v and their reduction can only start then): joined inside the call, the caller's stream
+// idled 60-95 us at every layer boundary (rocprofv3 timeline, profiles/r03_g_*).  Deferred, the next layer's backward
+// starts at once and that tail runs under it.  The caller then owes two things: every buffer the call was given
+// (h, ws, bws, dh_out, pos_emb_b, the parameter and gradient tensors) stays alive and unwritten, and
+// t4r_xlnet_layer_bwd_join(stream) is called before anything reads the parameter gradients or reuses those buffers
+// (transformers4rec_amd/transformer.py does both from the autograd engine's end-of-backward callback).
+static thread_local int g_defer_join = 0;
+extern "C" void t4r_xlnet_layer_bwd_defer(int on) { g_defer_join = on ? 1 : 0; }
 
 // grads[] are ACCUMULATED into (zero them / let the optimizer zero them between steps).
 // dh_in [T,D] is overwritten with d loss / d h.
@@ -333,6 +362,25 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
         ++n_fork;
         return ss->s;
     };
+    // wg_again(): the first side stream once more, for a product whose operands were complete at the previous wg() already
+    // (every event recorded on the caller's stream costs it ~6 us before its next kernel starts: one per group of products)
+    auto wg_again = [&]() -> hipStream_t { return ss ? ss->s : st; };
+    // wg2(): the second weight-gradient stream.  One side stream is a serial queue: the o / r / q / k / v products (ready
+    // when LayerNorm-1 backward and the attention core are done) sat behind the two feed-forward products and their tail
+    // -- five 10-25 us kernels with ~6 us between them -- ran AFTER the critical chain had finished: ~95 us of idle
+    // caller's stream at every layer boundary (rocprofv3 timeline, 4 x per step).  On their own stream they start when
+    // their operands exist.
+    static const int two_side = [] { const char* e = getenv("T4R_LAYER_SIDE_STREAMS"); return e ? atoi(e) : 2; }();
+    bool used_s2 = false;
+    auto wg2 = [&]() -> hipStream_t {
+        if (!ss) return st;
+        if (two_side < 2) return wg();
+        (void)hipEventRecord(ss->fork[n_fork], st);
+        (void)hipStreamWaitEvent(ss->s2, ss->fork[n_fork], 0);
+        ++n_fork;
+        used_s2 = true;
+        return ss->s2;
+    };
 
     if (fused) {
         // one launch: LayerNorm backward -> d ffout -> FF2 dX -> GELU' / dropout -> FF1 dX + residual (+ the partial
@@ -342,8 +390,13 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
                              T, D, drop_p, seed, C(SITE_FF_ACT), C(SITE_FF_OUT)));
         RUN(t4r_gemm_launch(wg(), 1, 0, D, 4 * D, T, 1.f, dfo, D, w.ffact, 4 * D, grads[P_W2], 4 * D, nullptr,
                             EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
-        RUN(t4r_gemm_launch(wg(), 1, 0, 4 * D, D, T, 1.f, dff, 4 * D, w.h1, D, grads[P_W1], D, nullptr,
-                            EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
+        {
+            hipStream_t s1 = wg_again();
+            RUN(t4r_gemm_launch(s1, 1, 0, 4 * D, D, T, 1.f, dff, 4 * D, w.h1, D, grads[P_W1], D, nullptr,
+                                EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
+            // first reduction launch of the call: W2, W1 and the bias / LayerNorm-2 sums of the feed-forward half
+            RUN(t4r_splitk_sink_flush(s1));
+        }
     } else {
     // LN2: y = LN(drop(ffout) + h1): dx = d h1 (residual part), d ffout = dxa (or dx when p = 0)
     RUN(t4r_add_layernorm_bwd(stream, w.ffout, w.h1, params[P_LN2W], w.mean2, w.rstd2, dh_out, dx, dxa,
@@ -370,22 +423,23 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
         // LayerNorm-1 backward + d attn_vec in one launch; the attention core; d h from d q, d k, d v in one launch
         RUN(t4r_xlnet_ln1_bwd(stream, dx, w.ao, h, w.mean1, w.rstd1, params[P_LN1W], w.planes, dh_in, dao_buf, dav,
                               grads[P_LN1W], grads[P_LN1B], ln1_part, T, D, drop_p, seed, C(SITE_ATTN_OUT)));
-        RUN(t4r_gemm_launch(wg(), 1, 0, D, D, T, 1.f, dao_buf, D, w.av, D, grads[P_O], D, nullptr, EPI_NONE,
+        RUN(t4r_gemm_launch(wg2(), 1, 0, D, D, T, 1.f, dao_buf, D, w.av, D, grads[P_O], D, nullptr, EPI_NONE,
                             nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
         RUN(t4r_xlnet_attn_bwd(stream, w.qkv, w.qkv + TD, w.qkv + 2 * TD, w.kr, params[P_RWB],
                                params[P_RRB], w.av, w.lse, dav, dqkv, dqkv + TD, dqkv + 2 * TD, dkr,
                                grads[P_RWB], grads[P_RRB], attn_ws, B, L, n_head, dh, drop, drop_p, seed,
                                C(SITE_PROB), key_len));
         if (drop) {
-            RUN(t4r_gemm_launch(wg(), 1, 0, D, D, B * 2 * L, 1.f, pos_emb_b ? pos_emb_b : w.pe_b, D, dkr, D, grads[P_R], D,
+            RUN(t4r_gemm_launch(wg2(), 1, 0, D, D, B * 2 * L, 1.f, pos_emb_b ? pos_emb_b : w.pe_b, D, dkr, D, grads[P_R], D,
                                 nullptr, EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
         } else {
+            // shared k_r: d k_r is finished by a reduction that was redirected to the FIRST side stream -- its consumer follows it there
             RUN(t4r_gemm_launch(wg(), 1, 0, D, D, 2 * L, 1.f, pos_emb, D, dkr, D, grads[P_R], D, nullptr,
                                 EPI_NONE, nullptr, 0, 1, 1, 1, 0, 0, 0, nullptr));
         }
+        hipStream_t sw = (drop && used_s2 && two_side >= 2 && ss) ? ss->s2 : wg2();   // after the r product's fork: nothing new on the caller's stream
         {
             float* gz[3] = {grads[P_Q], grads[P_K], grads[P_V]};
-            hipStream_t sw = wg();
             if (gz[1] == gz[0] + DD && gz[2] == gz[0] + 2 * DD) {
                 RUN(t4r_gemm_launch(sw, 1, 0, D, D, T, 1.f, h, D, dqkv, D, gz[0], D, nullptr, EPI_NONE, nullptr,
                                     0, -1, 1, 3, 0, TD, DD, nullptr));
@@ -395,11 +449,16 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
                                         EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
             }
         }
+        // second reduction launch: o, r, q, k, v and the LayerNorm-1 / attention-bias sums (same stream as their products)
+        RUN(t4r_splitk_sink_flush(sw));
         RUN(t4r_xlnet_dh(stream, dqkv, w.planes, dh_in, T, D));
-        RUN(t4r_splitk_sink_flush(ss ? ss->s : st));
-        if (ss) {   // join: the caller's stream continues after every weight gradient of this layer
+        if (ss && !g_defer_join) {   // join: the caller's stream continues after every weight gradient of this layer
             (void)hipEventRecord(ss->done_all, ss->s);
             (void)hipStreamWaitEvent(st, ss->done_all, 0);
+            if (used_s2) {
+                (void)hipEventRecord(ss->done_s2, ss->s2);
+                (void)hipStreamWaitEvent(st, ss->done_s2, 0);
+            }
         }
         return 0;
     }
@@ -445,10 +504,23 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
     for (int z = 0; z < 3; ++z)
         RUN(t4r_gemm_launch(st, 0, 1, T, D, D, 1.f, dqkv + z * TD, D, wz[z], D, dh_in, D, nullptr,
                             EPI_NONE, nullptr, 0, 1, 1, 1, 0, 0, 0, nullptr));
-    RUN(t4r_splitk_sink_flush(ss ? ss->s : st));
+    RUN(t4r_splitk_sink_flush(wg()));      // after every producer of a partial on the caller's stream
     if (ss) {   // join: the caller's stream continues after every weight gradient of this layer
         (void)hipEventRecord(ss->done_all, ss->s);
         (void)hipStreamWaitEvent(st, ss->done_all, 0);
+    }
+    return 0;
+}
+
+// the caller's stream waits for everything queued so far on the weight-gradient streams of this thread (no-op without them)
+extern "C" int t4r_xlnet_layer_bwd_join(void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    for (SideStream* ss : g_side_all) {
+        (void)hipEventRecord(ss->join1, ss->s);
+        (void)hipStreamWaitEvent(st, ss->join1, 0);
+        (void)hipEventRecord(ss->join2, ss->s2);
+        (void)hipStreamWaitEvent(st, ss->join2, 0);
     }
     return 0;
 }

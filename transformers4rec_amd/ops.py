@@ -611,7 +611,10 @@ def xlnet_layer_fwd(h, pos_emb, params, B, L, n_head, eps, ws=None, drop_p=0.0, 
 
 
 def xlnet_layer_bwd(h, pos_emb, params, grads, ws, dh_out, B, L, n_head, eps, bws=None, drop_p=0.0,
-                    seed=0, offset=0, layer_idx=0, key_len=None, pos_emb_b=None):
+                    seed=0, offset=0, layer_idx=0, key_len=None, pos_emb_b=None, defer_join=None):
+    """defer_join: a list -> the call returns without waiting for its weight-gradient streams (csrc/xlnet_layer.hip:
+    deferred join) and appends every buffer those streams may still be using to the list; the caller keeps the list
+    alive until it has called xlnet_layer_bwd_join()."""
     D = h.shape[-1]
     if bws is None:
         bws = torch.empty(xlnet_layer_bwd_ws_floats(B, L, D, n_head, drop_p > 0), device=h.device,
@@ -619,10 +622,24 @@ def xlnet_layer_bwd(h, pos_emb, params, grads, ws, dh_out, B, L, n_head, eps, bw
     dh_in = torch.empty_like(h)
     parr, _k1 = ptr_array([_chk(p, torch.float32) for p in params])
     garr, _k2 = ptr_array([_chk(g, torch.float32) for g in grads])
-    call("t4r_xlnet_layer_bwd", _stream(), _chk(h), _chk(pos_emb), parr, garr, _chk(ws),
-         bws.data_ptr(), _chk(dh_out), dh_in.data_ptr(), B, L, D, n_head, float(eps), float(drop_p),
-         int(seed), int(offset), int(layer_idx), _p(key_len, torch.int32), _p(pos_emb_b, torch.float32))
+    lib = _lib.load()
+    if defer_join is not None:
+        lib.t4r_xlnet_layer_bwd_defer(1)
+    try:
+        call("t4r_xlnet_layer_bwd", _stream(), _chk(h), _chk(pos_emb), parr, garr, _chk(ws),
+             bws.data_ptr(), _chk(dh_out), dh_in.data_ptr(), B, L, D, n_head, float(eps), float(drop_p),
+             int(seed), int(offset), int(layer_idx), _p(key_len, torch.int32), _p(pos_emb_b, torch.float32))
+    finally:
+        if defer_join is not None:
+            lib.t4r_xlnet_layer_bwd_defer(0)
+    if defer_join is not None:
+        defer_join.append((h, pos_emb, list(params), list(grads), ws, bws, dh_out, key_len, pos_emb_b))
     return dh_in
+
+
+def xlnet_layer_bwd_join():
+    """the current stream waits for the weight-gradient streams of every deferred xlnet_layer_bwd call so far"""
+    call("t4r_xlnet_layer_bwd_join", _stream())
 
 
 # ------------------------------------------------------------------------------------ head

@@ -13,6 +13,8 @@ relative positional keys are computed once per layer, not per batch row.
 from dataclasses import dataclass, field
 from typing import Optional
 
+import os
+
 import torch
 from torch import nn
 
@@ -154,10 +156,32 @@ class _XLNetLayerFn(torch.autograd.Function):
         p, seed, offset, idx = ctx.drop
         plist = ctx.layer.ordered_params()
         grads = [_grad_buf(q) for q in plist]
+        # the weight-gradient streams of this layer are joined at the END of the backward pass, not here: their tail
+        # (r, q|k|v, the reduction) runs under the next layer's backward instead of stalling it (csrc/xlnet_layer.hip:
+        # deferred join).  The buffers they use stay referenced in _PENDING until the join.
+        defer = _PENDING if _DEFER_JOIN else None
         dh = ops.xlnet_layer_bwd(h2, ctx.pos_emb, [q.detach() for q in plist], grads, ws,
                                  dout.contiguous().view(B * L, D), B, L, n_head, eps, drop_p=p, seed=seed,
-                                 offset=offset, layer_idx=idx, key_len=ctx.key_len, pos_emb_b=ctx.pos_emb_b)
+                                 offset=offset, layer_idx=idx, key_len=ctx.key_len, pos_emb_b=ctx.pos_emb_b,
+                                 defer_join=defer)
+        if defer is not None and not _JOIN_QUEUED[0]:
+            _JOIN_QUEUED[0] = True
+            torch.autograd.Variable._execution_engine.queue_callback(_join_weight_gradient_streams)
         return dh.view(B, L, D), None, None, None, None, None, None, None, None
+
+
+_DEFER_JOIN = os.environ.get("T4R_XLNET_DEFER_JOIN", "1") != "0"
+_PENDING: list = []          # buffers of deferred layer backwards (kept alive until the join)
+_JOIN_QUEUED = [False]
+
+
+def _join_weight_gradient_streams():
+    """end-of-backward callback of the autograd engine: runs before backward() returns, on the caller's current stream"""
+    try:
+        ops.xlnet_layer_bwd_join()
+    finally:
+        _PENDING.clear()
+        _JOIN_QUEUED[0] = False
 
 
 class _DropoutFn(torch.autograd.Function):

@@ -295,6 +295,44 @@ def test_training_mode_dropout_end_to_end():
     assert abs(float(l1) - float(l0)) < 0.5
 
 
+def test_deferred_weight_gradient_join_gives_the_same_gradients(monkeypatch):
+    """The XLNet layers hand their weight gradients to side streams and the module mirror joins them at the END of the
+    backward pass (transformer.py: autograd end-of-backward callback; csrc/xlnet_layer.hip: deferred join).  At a size
+    where those streams really lag (10 240 tokens, split-K weight gradients), every parameter gradient read right after
+    backward() equals, bit for bit, the run that joins inside every layer call -- and a second deferred run."""
+    import transformers4rec_amd as tr
+    from transformers4rec_amd import transformer as T
+
+    torch.manual_seed(0)
+    B, L, V, D = 512, 20, 20001, 128     # head on csrc/head_split.hip (>= 2 GFLOP): fixed summation order there too
+    schema = tr.session_schema(V - 1, L)
+    inputs = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=L, masking="mlm", embedding_dim_default=D)
+    model = tr.XLNetConfig.build(D, 4, 3, total_seq_length=L).to_torch_model(
+        inputs, tr.NextItemPredictionTask(weight_tying=True)).to(DEV)
+    x = {"item_id": tr.random_data_from_schema(schema, B, L, seed=5)["item_id"].to(DEV)}
+    xl = model.transformer_block.transformer
+    model.train(True)
+
+    def run(defer):
+        monkeypatch.setattr(T, "_DEFER_JOIN", defer)
+        model.input_features.masking._rng_offset = 0
+        xl._drop_offset = 0
+        model.zero_grad(set_to_none=True)
+        model(x, training=True)["loss"].backward()
+        assert not T._PENDING                      # joined (and the buffers released) before backward() returned
+        return {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    joined, deferred, again = run(False), run(True), run(True)
+    assert len(joined) > 40 and joined.keys() == deferred.keys()
+    assert sum(".layer." in n for n in joined) == 3 * 15
+    for n in joined:
+        if ".layer." in n:      # the layers' own gradients: fixed summation order end to end, so the bits must agree
+            assert torch.equal(joined[n], deferred[n]), f"{n}: deferred join changed the gradient"
+            assert torch.equal(deferred[n], again[n]), f"{n}: not reproducible"
+        else:                   # e.g. masked_item_embedding: summed over the masked positions with atomics
+            torch.testing.assert_close(joined[n], deferred[n], rtol=1e-4, atol=1e-6)
+
+
 @pytest.mark.parametrize("arch", ["gpt2", "bert"])
 def test_gpt2_bert_training_mode_dropout_and_masking_rules(arch):
     import transformers4rec_amd as tr

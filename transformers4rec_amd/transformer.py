@@ -164,24 +164,24 @@ class _XLNetLayerFn(torch.autograd.Function):
                                  dout.contiguous().view(B * L, D), B, L, n_head, eps, drop_p=p, seed=seed,
                                  offset=offset, layer_idx=idx, key_len=ctx.key_len, pos_emb_b=ctx.pos_emb_b,
                                  defer_join=defer)
-        if defer is not None and not _JOIN_QUEUED[0]:
-            _JOIN_QUEUED[0] = True
+        if defer is not None:
+            # one callback per deferred call (idempotent): no state that an aborted backward pass could leave behind
             torch.autograd.Variable._execution_engine.queue_callback(_join_weight_gradient_streams)
         return dh.view(B, L, D), None, None, None, None, None, None, None, None
 
 
 _DEFER_JOIN = os.environ.get("T4R_XLNET_DEFER_JOIN", "1") != "0"
 _PENDING: list = []          # buffers of deferred layer backwards (kept alive until the join)
-_JOIN_QUEUED = [False]
 
 
 def _join_weight_gradient_streams():
     """end-of-backward callback of the autograd engine: runs before backward() returns, on the caller's current stream"""
+    if not _PENDING:
+        return
     try:
         ops.xlnet_layer_bwd_join()
     finally:
         _PENDING.clear()
-        _JOIN_QUEUED[0] = False
 
 
 class _DropoutFn(torch.autograd.Function):

@@ -394,6 +394,19 @@ int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* pos_emb, cons
                         float* dh_in, int B, int L, int D, int n_head, float ln_eps, float drop_p,
                         unsigned long long seed, unsigned long long offset, int layer_idx, const int* key_len,
                         const float* pos_emb_b);
+/* Prologue of a whole XLNet layer stack (csrc/xlnet_fused_attn.hip, csrc/xlnet_layer.hip): the weight planes of ALL
+ * layers in one launch and the positional keys k_r = pos @ r_l of all layers in one launch per four layers (HF
+ * modeling_xlnet.py:266 k_head_r; the positional encoding and its dropout mask :1143 are shared by the layers), instead
+ * of two launches inside every t4r_xlnet_layer_fwd.  params_all: n_layers x 15 device pointers (order of
+ * t4r_xlnet_layer_fwd); planes[l] / kr[l]: inside layer l's workspace at t4r_xlnet_layer_ws_offsets' offsets; pos: the
+ * [pos_rows, D] positional encoding the layers would project (pos_emb_b [B 2L, D] with dropout, pos_emb [2L, D] without).
+ * After t4r_xlnet_stack_prepared(1) the layer forwards of this thread skip their own two launches (fused widths only;
+ * pos_emb_b must be passed to them when dropout is on). */
+int t4r_xlnet_layer_ws_offsets(int B, int L, int D, int n_head, int dropout, long* planes_off, long* kr_off);
+int t4r_xlnet_stack_prepare(void* stream, const float* const* params_all, int n_layers, int D, float* const* planes,
+                            const float* pos, long pos_rows, float* const* kr);
+void t4r_xlnet_stack_prepared(int on);
+
 /* Deferred join of the layer backward's weight-gradient streams (csrc/xlnet_layer.hip).  After
  * t4r_xlnet_layer_bwd_defer(1) a t4r_xlnet_layer_bwd call on this thread returns without ordering `stream` after its
  * weight gradients (q, k, v, o, r, W1, W2 and the bias / LayerNorm sums may still be accumulating); the caller keeps

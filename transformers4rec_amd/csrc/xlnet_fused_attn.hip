@@ -28,7 +28,7 @@ struct PlaneJob {
     int transpose;         // dst[r0 + c][c0 + r] = src[r][c]  instead of  dst[r0 + r][c0 + c]
     long pair0;            // first pair index of this job in the launch
 };
-#define T4R_MAX_PLANE_JOBS 16
+#define T4R_MAX_PLANE_JOBS 52        /* four layers x 13 matrices: 3.3 KB of kernel arguments */
 struct PlaneJobs { PlaneJob j[T4R_MAX_PLANE_JOBS]; int n; long total; };
 
 __global__ __launch_bounds__(256) void layer_planes_kernel(PlaneJobs jobs) {
@@ -67,11 +67,9 @@ static void add_job(PlaneJobs& js, const float* src, int rows, int cols, const u
 
 // params: host array of the layer's 15 device pointers in the order of t4r_xlnet_layer_fwd (q, k, v, o, r, ..., W1 at 9,
 // W2 at 11); any of the attention weights may be NULL (feed-forward planes only: t4r_xlnet_ff_prepare)
-static int prepare_launch(hipStream_t st, const float* q, const float* k, const float* v, const float* o, const float* r,
-                          const float* W1, const float* W2, int D, float* planes) {
+static void add_layer_jobs(PlaneJobs& js, const float* q, const float* k, const float* v, const float* o, const float* r,
+                           const float* W1, const float* W2, int D, float* planes) {
     const LayerPlanes P = carve_planes(planes, D);
-    PlaneJobs js;
-    js.n = 0; js.total = 0;
     const float* z[3] = {q, k, v};
     for (int i = 0; i < 3; ++i) {
         if (!z[i]) continue;
@@ -91,10 +89,21 @@ static int prepare_launch(hipStream_t st, const float* q, const float* k, const 
         add_job(js, W2, D, 4 * D, P.W2p, D, 4 * D, 0, 0, 0);
         add_job(js, W2, D, 4 * D, P.W2Tp, 4 * D, D, 0, 0, 1);
     }
+}
+static int launch_jobs(hipStream_t st, const PlaneJobs& js) {
     if (js.total == 0) return 0;
     hipLaunchKernelGGL(layer_planes_kernel, dim3((unsigned)((js.total + 255) / 256)), dim3(256), 0, st, js);
     T4R_LAUNCH_CHECK();
     return 0;
+}
+// params: host array of the layer's 15 device pointers in the order of t4r_xlnet_layer_fwd (q, k, v, o, r, ..., W1 at 9,
+// W2 at 11); any of the attention weights may be NULL (feed-forward planes only: t4r_xlnet_ff_prepare)
+static int prepare_launch(hipStream_t st, const float* q, const float* k, const float* v, const float* o, const float* r,
+                          const float* W1, const float* W2, int D, float* planes) {
+    PlaneJobs js;
+    js.n = 0; js.total = 0;
+    add_layer_jobs(js, q, k, v, o, r, W1, W2, D, planes);
+    return launch_jobs(st, js);
 }
 
 extern "C" int t4r_xlnet_fused_supported(int D);
@@ -136,9 +145,9 @@ __device__ __forceinline__ void tile_to_planes(const float* __restrict__ src, lo
 // ---------------------------------------------------------------------------------------------- projections
 struct ProjParams {
     const float* in;          // [T, D]
-    const uint16_t* planes;   // plane 0 of the weight-plane matrix [NM D][D] (rows = output feature)
-    float* out;               // NM matrices [T, D], `ostride` floats apart
-    long ostride;
+    const uint16_t* w[4];     // per output matrix: plane 0 of its weight planes [D][D] (rows = output feature)
+    long wpl;                 // plane stride of those planes (elements)
+    float* out[4];            // per output matrix: [T, D]
     long T;
 };
 
@@ -151,16 +160,15 @@ __global__ __launch_bounds__(D * 4) void xlnet_proj_kernel(ProjParams p) {
     tile_to_planes<D, RT, NT, PH>(p.in, t0, p.T, smem16, tid);
     __syncthreads();
     const int boff = n * PH + 8 * g;
-    const long wpl = (long)NM * D * D;
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
         f32x4 acc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = zero4();
         AFrag<D> a;
-        load_a3<D>(a, p.planes + (long)(m * D + 16 * w + n) * D + 8 * g, wpl);
+        load_a3<D>(a, p.w[m] + (long)(16 * w + n) * D + 8 * g, p.wpl);
         product3<D, R, PH>(a, smem16 + boff, PLN, acc);
-        float* o = p.out + m * p.ostride + 16 * w + 4 * g;
+        float* o = p.out[m] + 16 * w + 4 * g;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const long t = t0 + r * 16 + n;
@@ -429,7 +437,8 @@ extern "C" int t4r_xlnet_qkv_proj(void* stream, const float* h, const float* pla
     if (T <= 0) return 0;
     T4R_CHECK_ARG(t4r_xlnet_fused_supported(D) && h && planes && qkv, "xlnet_qkv_proj: bad arguments");
     const int R = pick_r(T);
-    ProjParams p{h, carve_planes(planes, D).QKVT, qkv, T * D, T};
+    const uint16_t* wq = carve_planes(planes, D).QKVT;
+    ProjParams p{h, {wq, wq + (long)D * D, wq + 2L * D * D, nullptr}, 3L * D * D, {qkv, qkv + T * D, qkv + 2 * T * D, nullptr}, T};
     hipStream_t st = (hipStream_t)stream;
 #define CALL(DD, RR)                                                                                             \
     {                                                                                                            \
@@ -448,7 +457,7 @@ extern "C" int t4r_xlnet_kr_proj(void* stream, const float* pos, const float* pl
     if (rows <= 0) return 0;
     T4R_CHECK_ARG(t4r_xlnet_fused_supported(D) && pos && planes && kr, "xlnet_kr_proj: bad arguments");
     const int R = pick_r(rows);
-    ProjParams p{pos, carve_planes(planes, D).RT, kr, 0, rows};
+    ProjParams p{pos, {carve_planes(planes, D).RT, nullptr, nullptr, nullptr}, (long)D * D, {kr, nullptr, nullptr, nullptr}, rows};
     hipStream_t st = (hipStream_t)stream;
 #define CALL(DD, RR)                                                                                             \
     {                                                                                                            \
@@ -459,6 +468,51 @@ extern "C" int t4r_xlnet_kr_proj(void* stream, const float* pos, const float* pl
     ATTN_DISPATCH(CALL, D, R)
 #undef CALL
     T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+// The prologue of a whole layer stack in two launches instead of two per layer: every layer's weight planes (they do not
+// change inside a step) and every layer's positional keys k_r = pos @ r_l (the positional encoding -- with its dropout
+// mask, drawn once per forward -- is the same for all layers, so its tile is read and cut once for up to four layers).
+// planes[l] / kr[l]: the layer's own buffers (inside its t4r_xlnet_layer_fwd workspace: t4r_xlnet_layer_ws_offsets).
+extern "C" int t4r_xlnet_stack_prepare(void* stream, const float* const* params_all, int n_layers, int D,
+                                       float* const* planes, const float* pos, long pos_rows, float* const* kr) {
+    T4R_CHECK_ARG(t4r_xlnet_fused_supported(D) && params_all && planes && n_layers >= 1, "xlnet_stack_prepare: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    for (int l0 = 0; l0 < n_layers; l0 += 4) {
+        const int nl = min(4, n_layers - l0);
+        PlaneJobs js;
+        js.n = 0; js.total = 0;
+        for (int l = l0; l < l0 + nl; ++l) {
+            const float* const* pr = params_all + (long)l * 15;
+            T4R_CHECK_ARG(planes[l] && pr[0] && pr[1] && pr[2] && pr[3] && pr[4] && pr[9] && pr[11], "xlnet_stack_prepare: null pointer");
+            add_layer_jobs(js, pr[0], pr[1], pr[2], pr[3], pr[4], pr[9], pr[11], D, planes[l]);
+        }
+        if (launch_jobs(st, js)) return -1;
+        if (!pos || pos_rows <= 0) continue;
+        T4R_CHECK_ARG(kr, "xlnet_stack_prepare: null k_r pointers");
+        ProjParams p{pos, {nullptr, nullptr, nullptr, nullptr}, (long)D * D, {nullptr, nullptr, nullptr, nullptr}, pos_rows};
+        for (int m = 0; m < nl; ++m) { p.w[m] = carve_planes(planes[l0 + m], D).RT; p.out[m] = kr[l0 + m]; }
+        const int R = pick_r(pos_rows);
+#define CALLN(DD, RR, NMV)                                                                                       \
+    {                                                                                                            \
+        const size_t smem = (size_t)3 * 16 * RR * (DD + 16) * 2;                                                 \
+        { static bool once = false; if (!once) { set_smem(xlnet_proj_kernel<DD, RR, NMV>, smem); once = true; } } \
+        hipLaunchKernelGGL((xlnet_proj_kernel<DD, RR, NMV>), dim3((unsigned)((pos_rows + 16 * RR - 1) / (16 * RR))), dim3(DD * 4), smem, st, p); \
+    }
+#define CALL1(DD, RR) CALLN(DD, RR, 1)
+#define CALL2(DD, RR) CALLN(DD, RR, 2)
+#define CALL3(DD, RR) CALLN(DD, RR, 3)
+#define CALL4(DD, RR) CALLN(DD, RR, 4)
+        if (nl == 1) { ATTN_DISPATCH(CALL1, D, R) } else if (nl == 2) { ATTN_DISPATCH(CALL2, D, R) }
+        else if (nl == 3) { ATTN_DISPATCH(CALL3, D, R) } else { ATTN_DISPATCH(CALL4, D, R) }
+#undef CALL1
+#undef CALL2
+#undef CALL3
+#undef CALL4
+#undef CALLN
+        T4R_LAUNCH_CHECK();
+    }
     return 0;
 }
 

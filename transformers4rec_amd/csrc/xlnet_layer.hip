@@ -128,6 +128,20 @@ static LayerWs carve(float* base, int B, int L, int D, int n, int per_batch_kr) 
 extern "C" long t4r_xlnet_layer_ws_floats(int B, int L, int D, int n_head, int dropout) {
     return carve(nullptr, B, L, D, n_head, dropout).total;
 }
+// where the weight planes and the positional keys k_r live inside a layer's workspace (float offsets; planes -1 when the
+// width has no fused kernels): the buffers t4r_xlnet_stack_prepare fills for all layers of a stack at once
+extern "C" int t4r_xlnet_layer_ws_offsets(int B, int L, int D, int n_head, int dropout, long* planes_off, long* kr_off) {
+    T4R_CHECK_ARG(planes_off && kr_off, "xlnet_layer_ws_offsets: null pointer");
+    float* const base = reinterpret_cast<float*>(sizeof(float) * 4);        // any non-null base: only differences are used
+    const LayerWs w = carve(base, B, L, D, n_head, dropout);
+    *planes_off = w.planes ? (long)(w.planes - base) : -1;
+    *kr_off = (long)(w.kr - base);
+    return 0;
+}
+// t4r_xlnet_stack_prepared(1): the following t4r_xlnet_layer_fwd calls of this thread find their weight planes and k_r
+// already in their workspace (t4r_xlnet_stack_prepare) and skip both launches (fused path only)
+static thread_local int g_stack_prepared = 0;
+extern "C" void t4r_xlnet_stack_prepared(int on) { g_stack_prepared = on ? 1 : 0; }
 // partial tiles of the layer's split-K weight gradients (gemm_f32.hip: deterministic split-K): the split rule gives at
 // most K / 320 + 1 splits per product (>= 20 k-tiles of 16 each), K = T (2 T for d r with per-session k_r); outputs
 // 2 x 4 D^2 (FF) + 4 D^2 (q, k, v, o) + D^2 (r)
@@ -169,9 +183,11 @@ extern "C" int t4r_xlnet_layer_fwd(void* stream, const float* h, const float* po
     if (use_fused(D)) {
         // ONE launch cuts the layer's nine weight matrices into bf16 planes; q, k, v in one token-tile launch; k_r; the
         // attention core; o-projection + dropout + residual + LayerNorm in one launch; the feed-forward block in one
-        RUN(t4r_xlnet_layer_prepare(stream, params, D, w.planes));
+        if (!g_stack_prepared) RUN(t4r_xlnet_layer_prepare(stream, params, D, w.planes));
         RUN(t4r_xlnet_qkv_proj(stream, h, w.planes, w.qkv, T, D));
-        if (drop) {
+        if (g_stack_prepared) {
+            // k_r of every layer came from one launch of the stack prologue
+        } else if (drop) {
             const float* pe_b = pos_emb_b;
             if (!pe_b) {
                 RUN(t4r_dropout(stream, pos_emb, w.pe_b, nullptr, (long)B * 2 * L * D, 2L * L * D, drop_p, seed,
@@ -423,21 +439,23 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
         // LayerNorm-1 backward + d attn_vec in one launch; the attention core; d h from d q, d k, d v in one launch
         RUN(t4r_xlnet_ln1_bwd(stream, dx, w.ao, h, w.mean1, w.rstd1, params[P_LN1W], w.planes, dh_in, dao_buf, dav,
                               grads[P_LN1W], grads[P_LN1B], ln1_part, T, D, drop_p, seed, C(SITE_ATTN_OUT)));
-        RUN(t4r_gemm_launch(wg2(), 1, 0, D, D, T, 1.f, dao_buf, D, w.av, D, grads[P_O], D, nullptr, EPI_NONE,
-                            nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
         RUN(t4r_xlnet_attn_bwd(stream, w.qkv, w.qkv + TD, w.qkv + 2 * TD, w.kr, params[P_RWB],
                                params[P_RRB], w.av, w.lse, dav, dqkv, dqkv + TD, dqkv + 2 * TD, dkr,
                                grads[P_RWB], grads[P_RRB], attn_ws, B, L, n_head, dh, drop, drop_p, seed,
                                C(SITE_PROB), key_len));
+        // ONE event for the o, r and q|k|v products (their operands are all complete here; with the join deferred nothing
+        // is gained by starting the o product before the attention core)
+        hipStream_t sw = wg2();
+        RUN(t4r_gemm_launch(sw, 1, 0, D, D, T, 1.f, dao_buf, D, w.av, D, grads[P_O], D, nullptr, EPI_NONE,
+                            nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
         if (drop) {
-            RUN(t4r_gemm_launch(wg2(), 1, 0, D, D, B * 2 * L, 1.f, pos_emb_b ? pos_emb_b : w.pe_b, D, dkr, D, grads[P_R], D,
+            RUN(t4r_gemm_launch(sw, 1, 0, D, D, B * 2 * L, 1.f, pos_emb_b ? pos_emb_b : w.pe_b, D, dkr, D, grads[P_R], D,
                                 nullptr, EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
         } else {
             // shared k_r: d k_r is finished by a reduction that was redirected to the FIRST side stream -- its consumer follows it there
             RUN(t4r_gemm_launch(wg(), 1, 0, D, D, 2 * L, 1.f, pos_emb, D, dkr, D, grads[P_R], D, nullptr,
                                 EPI_NONE, nullptr, 0, 1, 1, 1, 0, 0, 0, nullptr));
         }
-        hipStream_t sw = (drop && used_s2 && two_side >= 2 && ss) ? ss->s2 : wg2();   // after the r product's fork: nothing new on the caller's stream
         {
             float* gz[3] = {grads[P_Q], grads[P_K], grads[P_V]};
             if (gz[1] == gz[0] + DD && gz[2] == gz[0] + 2 * DD) {

@@ -596,18 +596,51 @@ def xlnet_pos_emb_dropout(pos_emb, B, p, seed, offset):
 
 
 def xlnet_layer_fwd(h, pos_emb, params, B, L, n_head, eps, ws=None, drop_p=0.0, seed=0, offset=0,
-                    layer_idx=0, key_len=None, pos_emb_b=None):
-    """h [B*L, D]; params: sequence of 15 tensors in XLNET_PARAM_ORDER.  -> (h_out, ws)"""
+                    layer_idx=0, key_len=None, pos_emb_b=None, stack_prepared=False):
+    """h [B*L, D]; params: sequence of 15 tensors in XLNET_PARAM_ORDER.  -> (h_out, ws)
+    stack_prepared: `ws` already holds this layer's weight planes and k_r (xlnet_stack_prepare)"""
     D = h.shape[-1]
     if ws is None:
         ws = torch.empty(xlnet_layer_ws_floats(B, L, D, n_head, drop_p > 0), device=h.device,
                          dtype=torch.float32)
     out = torch.empty_like(h)
     parr, _keep = ptr_array([_chk(p, torch.float32, "xlnet param") for p in params])
-    call("t4r_xlnet_layer_fwd", _stream(), _chk(h, torch.float32), _chk(pos_emb, torch.float32), parr,
-         ws.data_ptr(), out.data_ptr(), B, L, D, n_head, float(eps), float(drop_p), int(seed),
-         int(offset), int(layer_idx), _p(key_len, torch.int32), _p(pos_emb_b, torch.float32))
+    lib = _lib.load()
+    if stack_prepared:
+        lib.t4r_xlnet_stack_prepared(1)
+    try:
+        call("t4r_xlnet_layer_fwd", _stream(), _chk(h, torch.float32), _chk(pos_emb, torch.float32), parr,
+             ws.data_ptr(), out.data_ptr(), B, L, D, n_head, float(eps), float(drop_p), int(seed),
+             int(offset), int(layer_idx), _p(key_len, torch.int32), _p(pos_emb_b, torch.float32))
+    finally:
+        if stack_prepared:
+            lib.t4r_xlnet_stack_prepared(0)
     return out, ws
+
+
+def xlnet_stack_prepare(params_all, B, L, n_head, pos, drop):
+    """The prologue of a whole XLNet stack in two launches (csrc/xlnet_fused_attn.hip: t4r_xlnet_stack_prepare): the
+    weight planes of every layer and every layer's k_r = pos @ r.  params_all: per layer the 15 tensors in
+    XLNET_PARAM_ORDER; pos: what the layers would project ([B * 2L, D] dropped positional encoding, or [2L, D]).
+    -> one workspace per layer, to be passed to xlnet_layer_fwd(..., ws=, stack_prepared=True)."""
+    import ctypes
+
+    D = params_all[0][0].shape[0]
+    dev = params_all[0][0].device
+    n_fl = xlnet_layer_ws_floats(B, L, D, n_head, drop)
+    po, ko = ctypes.c_long(0), ctypes.c_long(0)
+    call("t4r_xlnet_layer_ws_offsets", B, L, D, n_head, int(bool(drop)), ctypes.addressof(po), ctypes.addressof(ko))
+    if po.value < 0:
+        raise ValueError("xlnet_stack_prepare: no fused kernels for this width")
+    ws = [torch.empty(n_fl, device=dev, dtype=torch.float32) for _ in params_all]
+    flat = [_chk(t, torch.float32, "xlnet param") for layer in params_all for t in layer]
+    parr, _k0 = ptr_array(flat)
+    n = len(params_all)
+    planes, _k1 = ptr_array([w.data_ptr() + 4 * po.value for w in ws])
+    kr, _k2 = ptr_array([w.data_ptr() + 4 * ko.value for w in ws])
+    pos2 = pos.reshape(-1, D)
+    call("t4r_xlnet_stack_prepare", _stream(), parr, n, D, planes, _chk(pos2, torch.float32), pos2.shape[0], kr)
+    return ws
 
 
 def xlnet_layer_bwd(h, pos_emb, params, grads, ws, dh_out, B, L, n_head, eps, bws=None, drop_p=0.0,

@@ -137,13 +137,15 @@ def relative_positional_encoding(L, D):
 
 class _XLNetLayerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, h, anchor, layer, pos_emb, n_head, eps, drop, key_len=None, pos_emb_b=None):
+    def forward(ctx, h, anchor, layer, pos_emb, n_head, eps, drop, key_len=None, pos_emb_b=None, ws=None):
+        """ws: this layer's workspace with its weight planes and k_r already in it (XLNetModel.forward: stack prologue)"""
         B, L, D = h.shape
         h2 = h.contiguous().view(B * L, D)
         params = [p.detach() for p in layer.ordered_params()]
         p, seed, offset, idx = drop
-        out, ws = ops.xlnet_layer_fwd(h2, pos_emb, params, B, L, n_head, eps, drop_p=p, seed=seed,
-                                      offset=offset, layer_idx=idx, key_len=key_len, pos_emb_b=pos_emb_b)
+        out, ws = ops.xlnet_layer_fwd(h2, pos_emb, params, B, L, n_head, eps, ws=ws, drop_p=p, seed=seed,
+                                      offset=offset, layer_idx=idx, key_len=key_len, pos_emb_b=pos_emb_b,
+                                      stack_prepared=ws is not None)
         ctx.layer, ctx.pos_emb, ctx.cfg, ctx.drop, ctx.key_len = layer, pos_emb, (B, L, D, n_head, eps), drop, key_len
         ctx.pos_emb_b = pos_emb_b
         ctx.save_for_backward(h2, ws)
@@ -167,10 +169,11 @@ class _XLNetLayerFn(torch.autograd.Function):
         if defer is not None:
             # one callback per deferred call (idempotent): no state that an aborted backward pass could leave behind
             torch.autograd.Variable._execution_engine.queue_callback(_join_weight_gradient_streams)
-        return dh.view(B, L, D), None, None, None, None, None, None, None, None
+        return dh.view(B, L, D), None, None, None, None, None, None, None, None, None
 
 
 _DEFER_JOIN = os.environ.get("T4R_XLNET_DEFER_JOIN", "1") != "0"
+_STACK_PROLOGUE = os.environ.get("T4R_XLNET_STACK_PROLOGUE", "1") != "0" and os.environ.get("T4R_XLNET_FUSED", "1") != "0"
 _PENDING: list = []          # buffers of deferred layer backwards (kept alive until the join)
 
 
@@ -250,13 +253,18 @@ class XLNetModel(SeedMixin, nn.Module):
         infer = p == 0 and not torch.is_grad_enabled()
         if infer:
             from . import torch_ops  # noqa: F401  (registers the t4r_hip library)
+        # the prologue of the stack in two launches: every layer's weight planes and k_r (csrc/xlnet_fused_attn.hip)
+        ws_all = None
+        if not infer and _STACK_PROLOGUE and ops.xlnet_fused_supported(D) and len(self.layer) > 1:
+            ws_all = ops.xlnet_stack_prepare([[q.detach() for q in layer.ordered_params()] for layer in self.layer],
+                                             B, L, cfg.n_head, pos_b if p > 0 else pos, p > 0)
         for i, layer in enumerate(self.layer):
             if infer:
                 h = torch.ops.t4r_hip.xlnet_layer_infer(h.reshape(B * L, D), pos, layer.ordered_params(), B, L, cfg.n_head,
                                                         cfg.layer_norm_eps, key_len).view(B, L, D)
                 continue
             h = _XLNetLayerFn.apply(h, layer.rel_attn.q, layer, pos, cfg.n_head, cfg.layer_norm_eps,
-                                    (p, self.seed, offset, i), key_len, pos_b)
+                                    (p, self.seed, offset, i), key_len, pos_b, None if ws_all is None else ws_all[i])
         if p > 0:
             h = _DropoutFn.apply(h, p, self.seed, ops.dropout_ctr_hi(offset, 255, ops.SITE_FINAL))
         return (h,)

@@ -112,8 +112,9 @@ int t4r_embedding_bag_bwd_rows(void* stream, const float* dout, long ld, int col
  * d_memb[H] += sum of dy over replaced tokens (accumulated), dy zeroed there (in place). */
 int t4r_apply_mask_fwd(void* stream, float* x, const unsigned char* mask, const float* masked_emb,
                        int B, int L, int H, int mode);
+long t4r_apply_mask_bwd_ws_floats(int B, int L, int H);
 int t4r_apply_mask_bwd(void* stream, float* dy, const unsigned char* mask, float* d_masked_emb, int B,
-                       int L, int H, int mode);
+                       int L, int H, int mode, float* ws /* t4r_apply_mask_bwd_ws_floats floats: fixed-order two-stage sum */);
 int t4r_mul(void* stream, const float* a, const float* b, float* out, long n);
 
 /* a4  SoftEmbedding (+ per-feature LayerNorm)

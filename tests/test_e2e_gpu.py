@@ -325,12 +325,11 @@ def test_deferred_weight_gradient_join_gives_the_same_gradients(monkeypatch):
     joined, deferred, again = run(False), run(True), run(True)
     assert len(joined) > 40 and joined.keys() == deferred.keys()
     assert sum(".layer." in n for n in joined) == 3 * 15
+    # every reduction on this path has a fixed order (head_split.hip, the sorted table scatter, the two-stage column sums
+    # and split-K): ALL parameter gradients must agree bit for bit, not only the layers' own
     for n in joined:
-        if ".layer." in n:      # the layers' own gradients: fixed summation order end to end, so the bits must agree
-            assert torch.equal(joined[n], deferred[n]), f"{n}: deferred join changed the gradient"
-            assert torch.equal(deferred[n], again[n]), f"{n}: not reproducible"
-        else:                   # e.g. masked_item_embedding: summed over the masked positions with atomics
-            torch.testing.assert_close(joined[n], deferred[n], rtol=1e-4, atol=1e-6)
+        assert torch.equal(joined[n], deferred[n]), f"{n}: deferred join changed the gradient"
+        assert torch.equal(deferred[n], again[n]), f"{n}: not reproducible"
 
 
 @pytest.mark.parametrize("arch", ["gpt2", "bert"])

@@ -32,7 +32,8 @@ _SIGS = {
     "t4r_embedding_bag_fwd": ("i", "pp" + "li" + "pp" + "llii" + "p" + "li" + "p"),
     "t4r_embedding_bag_bwd_rows": ("i", "pp" + "lii" + "p" + "llii" + "p"),
     "t4r_apply_mask_fwd": ("i", "ppppiiii"),
-    "t4r_apply_mask_bwd": ("i", "ppppiiii"),
+    "t4r_apply_mask_bwd": ("i", "ppppiiii" + "p"),
+    "t4r_apply_mask_bwd_ws_floats": ("l", "iii"),
     "t4r_mul": ("i", "ppppl"),
     "t4r_soft_embedding_fwd": ("i", "pppppppp" + "liif"),
     "t4r_soft_embedding_bwd": ("i", "pppppppppppp" + "liiiif"),

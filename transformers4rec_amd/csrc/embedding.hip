@@ -340,12 +340,15 @@ extern "C" int t4r_apply_mask_fwd(void* stream, float* x, const unsigned char* m
 
 // backward of apply mask: d_memb[H] += sum over replaced tokens of dy ; dy <- 0 at replaced /
 // zeroed tokens (in place), so that the upstream backward sees d x.
+// The sum is formed in two stages (per-workgroup partial rows, then t4r_reduce_partials_launch in block order): 640
+// workgroups adding into the same H addresses with atomics took 24 us and gave a different rounding every run.
+#define T4R_MASK_BWD_TOK 64
 __global__ __launch_bounds__(256) void apply_mask_bwd_kernel(float* __restrict__ dy,
                                                               const unsigned char* __restrict__ mask,
-                                                              float* __restrict__ d_memb, long ntok,
-                                                              int L, int H, int mode, int tok_per_block) {
-    const long t0 = (long)blockIdx.x * tok_per_block;
-    const long t1 = min(ntok, t0 + tok_per_block);
+                                                              float* __restrict__ part, long ntok,
+                                                              int L, int H, int mode) {
+    const long t0 = (long)blockIdx.x * T4R_MASK_BWD_TOK;
+    const long t1 = min(ntok, t0 + T4R_MASK_BWD_TOK);
     for (int c = threadIdx.x; c < H; c += 256) {
         float acc = 0.f;
         for (long t = t0; t < t1; ++t) {
@@ -358,19 +361,25 @@ __global__ __launch_bounds__(256) void apply_mask_bwd_kernel(float* __restrict__
             if (!keep) { acc += dy[t * H + c]; dy[t * H + c] = 0.f; }
             else if (zero) dy[t * H + c] = 0.f;
         }
-        if (acc != 0.f) atomicAdd(d_memb + c, acc);
+        part[(long)blockIdx.x * H + c] = acc;
     }
 }
 
+int t4r_reduce_partials_launch(hipStream_t st, const float* part, int nblocks, float* o0, int n0, int a0,
+                               float* o1, int n1, int a1, float* o2, int n2, int a2);   // elementwise.hip
+extern "C" long t4r_apply_mask_bwd_ws_floats(int B, int L, int H) {
+    return (((long)B * L + T4R_MASK_BWD_TOK - 1) / T4R_MASK_BWD_TOK) * H;
+}
+// ws: t4r_apply_mask_bwd_ws_floats(B, L, H) floats of scratch
 extern "C" int t4r_apply_mask_bwd(void* stream, float* dy, const unsigned char* mask, float* d_memb,
-                                  int B, int L, int H, int mode) {
+                                  int B, int L, int H, int mode, float* ws) {
     const long ntok = (long)B * L;
     if (ntok == 0 || mode == MASK_NONE) return 0;
-    const int tpb = 32;
-    hipLaunchKernelGGL(apply_mask_bwd_kernel, dim3((unsigned)((ntok + tpb - 1) / tpb)), dim3(256), 0,
-                       (hipStream_t)stream, dy, mask, d_memb, ntok, L, H, mode, tpb);
+    T4R_CHECK_ARG(ws, "apply_mask_bwd: null workspace");
+    const int nblk = (int)((ntok + T4R_MASK_BWD_TOK - 1) / T4R_MASK_BWD_TOK);
+    hipLaunchKernelGGL(apply_mask_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dy, mask, ws, ntok, L, H, mode);
     T4R_LAUNCH_CHECK();
-    return 0;
+    return t4r_reduce_partials_launch((hipStream_t)stream, ws, nblk, d_memb, H, 1, nullptr, 0, 0, nullptr, 0, 0);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -418,7 +418,8 @@ def apply_mask_fwd_(x, mask, memb, mode):
 
 def apply_mask_bwd_(dy, mask, d_memb, mode):
     B, L, H = dy.shape
-    call("t4r_apply_mask_bwd", _stream(), _chk(dy), _chk(mask), _chk(d_memb), B, L, H, mode)
+    ws = torch.empty(max(1, _lib.load().t4r_apply_mask_bwd_ws_floats(B, L, H)), device=dy.device, dtype=torch.float32)
+    call("t4r_apply_mask_bwd", _stream(), _chk(dy), _chk(mask), _chk(d_memb), B, L, H, mode, ws.data_ptr())
     return dy
 
 

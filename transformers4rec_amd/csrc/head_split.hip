@@ -55,15 +55,84 @@ __device__ __forceinline__ f32x16 mfma6(const u32x4 (&a)[3], const u32x4 (&b)[3]
     return acc;
 }
 
+// ---- the forward products in the TWO-way fp16 split (HS = true).  The head's three kernels run at the 1.4 kW package
+// limit with the clock pulled down (tools/head_power_probe.py): what they cost is matrix instructions.  Where BOTH operands
+// are well scaled -- the forward product: rows of a LayerNorm output x the item table -- a two-way fp16 split needs three
+// products instead of six:  x s = hi + lo + d,  hi = fp16(x s), lo = fp16(x s - hi), |d| <= 2^-23 |x s|, with s a power of two
+// that puts the tensor's largest magnitude into [2^13, 2^14) (exact; undone exactly in the epilogue), products
+// hi hi + hi lo + lo hi (the dropped lo lo <= 2^-22 |x w|): per product term <= 2^-21 |x w| in the worst case, measured
+// 2-3 x the error of the fp32 matrix cores against fp64 (tools/head_split_bench.py).  Entries below 2^-17 of the
+// tensor's maximum keep fewer than 22 bits (fp16 subnormals in lo) -- irrelevant for a dot product's norm-wise error, NOT
+// acceptable for the gradient operand, whose rare-item columns lie 10^-6 below its maximum: the backward products stay
+// on the three bf16 planes.  T4R_HEAD_FWD_FP16X2=0 puts the forward back on them too.
+__device__ __forceinline__ f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void cut_pair_h(float a, float b, uint32_t (&w)[2]) {
+    const half2_t h = {(_Float16)a, (_Float16)b};              // round to nearest even
+    const half2_t l = {(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
+    w[0] = __builtin_bit_cast(uint32_t, h);
+    w[1] = __builtin_bit_cast(uint32_t, l);
+}
+template <bool HS>
+__device__ __forceinline__ void split8s(const float (&x)[8], float scale, u32x4 (&w)[HS ? 2 : 3]) {
+    if constexpr (HS) {
+        uint32_t a[2], b[2], c[2], d[2];
+        cut_pair_h(x[0] * scale, x[1] * scale, a);
+        cut_pair_h(x[2] * scale, x[3] * scale, b);
+        cut_pair_h(x[4] * scale, x[5] * scale, c);
+        cut_pair_h(x[6] * scale, x[7] * scale, d);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) w[pl] = u32x4{a[pl], b[pl], c[pl], d[pl]};
+    } else {
+        split8(x, w);
+    }
+}
+template <bool HS>
+__device__ __forceinline__ f32x16 mfma_split(const u32x4 (&a)[HS ? 2 : 3], const u32x4 (&b)[HS ? 2 : 3], f32x16 acc) {
+    if constexpr (HS) {
+        acc = mfma_f16(a[1], b[0], acc);
+        acc = mfma_f16(a[0], b[1], acc);
+        acc = mfma_f16(a[0], b[0], acc);
+        return acc;
+    } else {
+        return mfma6(a, b, acc);
+    }
+}
+// largest magnitude of a [rows, cols] matrix as the bits of a non-negative float (they order like unsigned integers), and
+// the power of two that maps it into [2^13, 2^14)
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ src, long ld, long rows, int cols,
+                                                    unsigned* __restrict__ out) {
+    const long n4 = rows * (cols / 4);
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const long r = i / (cols / 4);
+        const int c = (int)(i % (cols / 4)) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(src + r * ld + c);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+__device__ __forceinline__ float scale_of(const unsigned* amax_bits) {
+    const float a = __uint_as_float(*amax_bits);
+    if (!(a > 0.f) || !(a < 3e38f)) return 1.f;      // all zero, infinite or NaN: nothing to position
+    int e;
+    (void)frexpf(a, &e);                              // a = m 2^e, m in [0.5, 1)
+    return ldexpf(1.f, 14 - e);
+}
+
 // ---- plane blocks.  One block = 32 rows of a row-major fp32 matrix [n_rows, D], as three bf16 planes:
 //   MK image (rows are the M / N index of the product, D is K):  [plane][chunk = d / 8][row % 32] x 16 bytes = 8 consecutive d
 //   KM image (rows are K, D is the N index):                     [plane][kc = (row % 32) / 8][d] x 16 bytes = 8 consecutive rows
 // Both are 12 D u32x4 (24 KB at D = 128); rows >= n_rows are zero.
-template <int NB>
+template <int NB, bool HS = false>
 __global__ __launch_bounds__(256) void split_mk_kernel(const float* __restrict__ src, long ld, int n_rows,
-                                                        u32x4* __restrict__ dst) {
-    constexpr int D = 32 * NB, CH = D / 8;
+                                                        u32x4* __restrict__ dst, const unsigned* __restrict__ amax = nullptr) {
+    constexpr int D = 32 * NB, CH = D / 8, NPL = HS ? 2 : 3;
     const int b = blockIdx.x;
+    const float scale = HS ? scale_of(amax) : 1.f;
     for (int idx = threadIdx.x; idx < CH * 32; idx += 256) {
         const int r = idx & 31, c = idx >> 5, row = b * 32 + r;
         float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -72,17 +141,18 @@ __global__ __launch_bounds__(256) void split_mk_kernel(const float* __restrict__
             const float4 v = *reinterpret_cast<const float4*>(src + (long)row * ld + 8 * c + 4);
             x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = v.x; x[5] = v.y; x[6] = v.z; x[7] = v.w;
         }
-        u32x4 w[3];
-        split8(x, w);
+        u32x4 w[NPL];
+        split8s<HS>(x, scale, w);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) dst[((long)b * 3 + pl) * (CH * 32) + c * 32 + r] = w[pl];
+        for (int pl = 0; pl < NPL; ++pl) dst[((long)b * NPL + pl) * (CH * 32) + c * 32 + r] = w[pl];
     }
 }
-template <int NB>
+template <int NB, bool HS = false>
 __global__ __launch_bounds__(256) void split_km_kernel(const float* __restrict__ src, long ld, int n_rows,
-                                                        u32x4* __restrict__ dst) {
-    constexpr int D = 32 * NB;
+                                                        u32x4* __restrict__ dst, const unsigned* __restrict__ amax = nullptr) {
+    constexpr int D = 32 * NB, NPL = HS ? 2 : 3;
     const int b = blockIdx.x;
+    const float scale = HS ? scale_of(amax) : 1.f;
     for (int idx = threadIdx.x; idx < 4 * D; idx += 256) {
         const int d = idx % D, kc = idx / D;
         float x[8];
@@ -91,20 +161,23 @@ __global__ __launch_bounds__(256) void split_km_kernel(const float* __restrict__
             const int row = b * 32 + 8 * kc + e;
             x[e] = row < n_rows ? src[(long)row * ld + d] : 0.f;
         }
-        u32x4 w[3];
-        split8(x, w);
+        u32x4 w[NPL];
+        split8s<HS>(x, scale, w);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) dst[(((long)b * 3 + pl) * 4 + kc) * D + d] = w[pl];
+        for (int pl = 0; pl < NPL; ++pl) dst[(((long)b * NPL + pl) * 4 + kc) * D + d] = w[pl];
     }
 }
 
 // ---- logits:  C[N, V] = alpha * X @ W^T.  grid (ceil(V / 128), row splits); X as MK plane blocks.
-template <int NB>
+template <int NB, bool HS = false>
 __global__ __launch_bounds__(256) void head_logits_split_kernel(const u32x4* __restrict__ XA, const float* __restrict__ W,
                                                                  long ldw, float* __restrict__ C, long ldc, int N, int V,
-                                                                 float alpha, int nblk, int blk_per) {
-    constexpr int KS = 2 * NB, CH = 4 * NB;
-    constexpr int BLK = 12 * 32 * NB;      // u32x4 per plane block
+                                                                 float alpha, int nblk, int blk_per,
+                                                                 const unsigned* __restrict__ amax = nullptr) {
+    constexpr int KS = 2 * NB, CH = 4 * NB, NPL = HS ? 2 : 3;
+    constexpr int BLK = 4 * NPL * 32 * NB;      // u32x4 per plane block
+    const float sw = HS ? scale_of(amax + 1) : 1.f;
+    if (HS) alpha = (alpha / scale_of(amax)) / sw;      // two exact divisions by powers of two (their product may overflow)
     constexpr int SN = (BLK + 255) / 256;
     __shared__ u32x4 lds[2][BLK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, khalf = lane >> 5;
@@ -113,7 +186,7 @@ __global__ __launch_bounds__(256) void head_logits_split_kernel(const u32x4* __r
     const int col = blockIdx.x * 128 + 32 * wave + l32;
 
     // this lane's 8-element pieces of row `col` of W, cut once
-    u32x4 Bf[KS][3];
+    u32x4 Bf[KS][NPL];
     {
         const float* wr = W + (long)min(col, V - 1) * ldw + 8 * khalf;
 #pragma unroll
@@ -121,7 +194,7 @@ __global__ __launch_bounds__(256) void head_logits_split_kernel(const u32x4* __r
             const float4 u = *reinterpret_cast<const float4*>(wr + 16 * s);
             const float4 v = *reinterpret_cast<const float4*>(wr + 16 * s + 4);
             const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
-            split8(x, Bf[s]);
+            split8s<HS>(x, sw, Bf[s]);
         }
     }
 
@@ -151,10 +224,10 @@ __global__ __launch_bounds__(256) void head_logits_split_kernel(const u32x4* __r
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            u32x4 a[3];
+            u32x4 a[NPL];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) a[pl] = lds[buf][(pl * CH + 2 * s + khalf) * 32 + l32];
-            acc = mfma6(a, Bf[s], acc);
+            for (int pl = 0; pl < NPL; ++pl) a[pl] = lds[buf][(pl * CH + 2 * s + khalf) * 32 + l32];
+            acc = mfma_split<HS>(a, Bf[s], acc);
         }
         // next block -> LDS before the logits are stored: the wait for its loads must not cover the HBM stores
         s_store(buf ^ 1);
@@ -207,14 +280,17 @@ __device__ __forceinline__ void quad_transpose4(float (&x)[4], int t) {
     }
 }
 
-template <int NB>
+template <int NB, bool HS = false>
 __global__ __launch_bounds__(256) void head_logits_ce_kernel(const u32x4* __restrict__ XA, const float* __restrict__ W,
                                                               long ldw, float* __restrict__ C, long ldc, int N, int V,
                                                               float alpha, int nblk, int blk_per, int vec_ok,
                                                               float* __restrict__ st_m, float* __restrict__ st_s,
-                                                              float* __restrict__ st_t, int n_tile, int n_split) {
-    constexpr int KS = 2 * NB, CH = 4 * NB;
-    constexpr int BLK = 12 * 32 * NB;
+                                                              float* __restrict__ st_t, int n_tile, int n_split,
+                                                              const unsigned* __restrict__ amax = nullptr) {
+    constexpr int KS = 2 * NB, CH = 4 * NB, NPL = HS ? 2 : 3;
+    constexpr int BLK = 4 * NPL * 32 * NB;
+    const float sw = HS ? scale_of(amax + 1) : 1.f;
+    if (HS) alpha = (alpha / scale_of(amax)) / sw;      // two exact divisions by powers of two (their product may overflow)
     constexpr int SN = (BLK + 255) / 256;
     __shared__ u32x4 lds[2][BLK];
     __shared__ float4 sst[2][4][32];
@@ -230,7 +306,7 @@ __global__ __launch_bounds__(256) void head_logits_ce_kernel(const u32x4* __rest
     const int vbase = tile * 128 + 32 * wave;
     const bool tail_tile = tile * 128 + 128 > V;
 
-    u32x4 Wf[KS][3];
+    u32x4 Wf[KS][NPL];
     {
         const float* wr = W + (long)min(vbase + l32, V - 1) * ldw + 8 * khalf;
 #pragma unroll
@@ -238,7 +314,7 @@ __global__ __launch_bounds__(256) void head_logits_ce_kernel(const u32x4* __rest
             const float4 u = *reinterpret_cast<const float4*>(wr + 16 * s);
             const float4 v = *reinterpret_cast<const float4*>(wr + 16 * s + 4);
             const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
-            split8(x, Wf[s]);
+            split8s<HS>(x, sw, Wf[s]);
         }
     }
     u32x4 st[SN];
@@ -285,10 +361,10 @@ __global__ __launch_bounds__(256) void head_logits_ce_kernel(const u32x4* __rest
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            u32x4 xf[3];
+            u32x4 xf[NPL];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) xf[pl] = lds[buf][(pl * CH + 2 * s + khalf) * 32 + l32];
-            acc = mfma6(Wf[s], xf, acc);
+            for (int pl = 0; pl < NPL; ++pl) xf[pl] = lds[buf][(pl * CH + 2 * s + khalf) * 32 + l32];
+            acc = mfma_split<HS>(Wf[s], xf, acc);
         }
         s_store(buf ^ 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -495,14 +571,19 @@ __global__ __launch_bounds__(256) void head_dw_split_kernel(const float* __restr
 
 // ---- d X partial sums:  part[split][N, D] = alpha * G[:, k-range] @ W[k-range, :].  grid (ceil(N / 128), splits);
 // wave w owns rows 32 w .. 32 w + 31 of the tile, each lane walks its own logits row.
-template <int NB>
+// HS: the two-way fp16 form (see mfma_split).  The gradient rows are scaled by a power of two taken from g / N itself; their
+// tail entries (p ~ 1e-6 and below) lose relative precision in the fp16 pieces, but every OUTPUT row sums all V of them
+// against well-scaled table rows: their absolute error (<= 2^-39 of the row's largest entry each) is far below the
+// rounding of the sum -- unlike d W, whose rare-item rows consist of such entries only and stay on the bf16 planes.
+template <int NB, bool HS = false>
 __global__ __launch_bounds__(256) void head_dx_split_kernel(const float* __restrict__ logits, long ld,
                                                              const float* __restrict__ lse, const long* __restrict__ labels,
                                                              const float* __restrict__ gout, const u32x4* __restrict__ WT,
                                                              float* __restrict__ part, int N, int Vc, int V, int yoff,
-                                                             float smooth, float alpha, int nkt, int kt_per, int row_tiles) {
-    constexpr int D = 32 * NB;
-    constexpr int BLK = 12 * 32 * NB;
+                                                             float smooth, float alpha, int nkt, int kt_per, int row_tiles,
+                                                             const unsigned* __restrict__ amax = nullptr) {
+    constexpr int D = 32 * NB, NPL = HS ? 2 : 3;
+    constexpr int BLK = 4 * NPL * 32 * NB;
     constexpr int SN = (BLK + 255) / 256;
     __shared__ u32x4 lds[2][BLK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, khalf = lane >> 5;
@@ -518,6 +599,13 @@ __global__ __launch_bounds__(256) void head_dx_split_kernel(const float* __restr
     const int y = (int)(labels[rc] - yoff);
     SgScalars q;
     q.g = (gout ? *gout : 1.f) / N;
+    if (HS) {       // |G| <= |g| (1 + eps): position g at 2^13 .. 2^14, undo it (and the table's scale) in alpha
+        int e;
+        (void)frexpf(fabsf(q.g), &e);
+        const float sg = (q.g != 0.f && fabsf(q.g) < 3e38f) ? ldexpf(1.f, 14 - e) : 1.f;
+        q.g *= sg;
+        alpha = (alpha / sg) / scale_of(amax);
+    }
     q.sub = q.g * smooth / V;
     q.hit = q.g * (1.f - smooth);
     const int ldm4 = (int)ld - 4;
@@ -562,23 +650,23 @@ __global__ __launch_bounds__(256) void head_dx_split_kernel(const float* __restr
             for (int i = 0; i < 16; ++i)
                 if (kt * 32 + 16 * (i >> 3) + 8 * khalf + (i & 7) >= Vc) xc[i] = -INFINITY;
         }
-        u32x4 af[2][3];
+        u32x4 af[2][NPL];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int dy = y - (kt * 32 + 16 * s + 8 * khalf);
             float gv[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) gv[e] = sg_value(xc[8 * s + e], l2, dy == e, q);
-            split8(gv, af[s]);
+            split8s<HS>(gv, 1.f, af[s]);
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                u32x4 bf[3];
+                u32x4 bf[NPL];
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) bf[pl] = lds[buf][(pl * 4 + 2 * s + khalf) * D + 32 * j + l32];
-                acc[j] = mfma6(af[s], bf, acc[j]);
+                for (int pl = 0; pl < NPL; ++pl) bf[pl] = lds[buf][(pl * 4 + 2 * s + khalf) * D + 32 * j + l32];
+                acc[j] = mfma_split<HS>(af[s], bf, acc[j]);
             }
         s_store(buf ^ 1);
         __syncthreads();
@@ -615,7 +703,13 @@ static int head_dx_target() {
     return target;
 }
 // workspace layout (bytes): XA | XT | WT | d X partials
-struct HeadWs { long xa, xt, wt, part, stats, total; int nblk, nkt, max_split, ntile; };
+struct HeadWs { long xa, xt, wt, part, stats, scales, total; int nblk, nkt, max_split, ntile; };
+// the forward product in the two-way fp16 split (see mfma_split)?
+static bool head_fwd_fp16x2() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("T4R_HEAD_FWD_FP16X2"); on = e ? (atoi(e) != 0) : 1; }
+    return on != 0;
+}
 HeadWs head_ws(int N, int V, int D) {
     HeadWs w;
     w.nblk = (N + 31) / 32;
@@ -631,12 +725,21 @@ HeadWs head_ws(int N, int V, int D) {
     w.part = w.wt + w.nkt * blk;
     w.stats = w.part + (long)w.max_split * N * D * 4;
     w.ntile = (V + 127) / 128;
-    w.total = w.stats + 3L * w.ntile * N * 4;
+    w.scales = w.stats + 3L * w.ntile * N * 4;       // two words: bits of max |X|, bits of max |W| (fp16 split scales)
+    w.total = w.scales + 256;
     return w;
 }
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
+
+// max |W| of the table rows a forward product reads -> one word (reset first): 51 MB at BASELINE configs[1], ~10 us
+static int head_w_amax(hipStream_t st, const float* W, long ldw, int V, int D, unsigned* out) {
+    if (hipMemsetAsync(out, 0, 4, st) != hipSuccess) { t4r_set_error("head_split: memset failed"); return -1; }
+    const long n4 = (long)V * (D / 4);
+    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)min(2048L, (n4 + 255) / 256)), dim3(256), 0, st, W, ldw, (long)V, D, out);
+    return 0;
+}
 
 #define T4R_NB_SWITCH(D, CALL)                \
     switch ((D) / 32) {                       \
@@ -663,7 +766,15 @@ extern "C" int t4r_head_split_prepare(void* stream, const float* X, long ldx, in
     hipStream_t st = (hipStream_t)stream;
     u32x4* xa = reinterpret_cast<u32x4*>((char*)ws + w.xa);
     u32x4* xt = reinterpret_cast<u32x4*>((char*)ws + w.xt);
-    T4R_NB_SWITCH(D, hipLaunchKernelGGL(split_mk_kernel<NB>, dim3(w.nblk), dim3(256), 0, st, X, ldx, N, xa));
+    if (head_fwd_fp16x2()) {
+        unsigned* amax = reinterpret_cast<unsigned*>((char*)ws + w.scales);
+        if (hipMemsetAsync(amax, 0, 8, st) != hipSuccess) { t4r_set_error("head_split_prepare: memset failed"); return -1; }
+        const long n4 = (long)N * (D / 4);
+        hipLaunchKernelGGL(amax_kernel, dim3((unsigned)min(1024L, (n4 + 255) / 256)), dim3(256), 0, st, X, ldx, (long)N, D, amax);
+        T4R_NB_SWITCH(D, hipLaunchKernelGGL((split_mk_kernel<NB, true>), dim3(w.nblk), dim3(256), 0, st, X, ldx, N, xa, amax));
+    } else {
+        T4R_NB_SWITCH(D, hipLaunchKernelGGL(split_mk_kernel<NB>, dim3(w.nblk), dim3(256), 0, st, X, ldx, N, xa));
+    }
     T4R_NB_SWITCH(D, hipLaunchKernelGGL(split_km_kernel<NB>, dim3(w.nblk), dim3(256), 0, st, X, ldx, N, xt));
     T4R_LAUNCH_CHECK();
     return 0;
@@ -682,8 +793,15 @@ extern "C" int t4r_head_split_logits(void* stream, const void* ws, const float* 
     const int rs = (w.nblk + blk_per - 1) / blk_per;
     const u32x4* xa = reinterpret_cast<const u32x4*>((const char*)ws + w.xa);
     dim3 grid((V + 127) / 128, rs);
-    T4R_NB_SWITCH(D, hipLaunchKernelGGL(head_logits_split_kernel<NB>, grid, dim3(256), 0, (hipStream_t)stream, xa, W, ldw, C,
-                                        ldc, N, V, alpha, w.nblk, blk_per));
+    if (head_fwd_fp16x2()) {
+        unsigned* amax = reinterpret_cast<unsigned*>((char*)ws + w.scales);
+        if (head_w_amax((hipStream_t)stream, W, ldw, V, D, amax + 1)) return -1;
+        T4R_NB_SWITCH(D, hipLaunchKernelGGL((head_logits_split_kernel<NB, true>), grid, dim3(256), 0, (hipStream_t)stream, xa, W,
+                                            ldw, C, ldc, N, V, alpha, w.nblk, blk_per, amax));
+    } else {
+        T4R_NB_SWITCH(D, hipLaunchKernelGGL(head_logits_split_kernel<NB>, grid, dim3(256), 0, (hipStream_t)stream, xa, W, ldw, C,
+                                            ldc, N, V, alpha, w.nblk, blk_per));
+    }
     T4R_LAUNCH_CHECK();
     return 0;
 }
@@ -709,8 +827,15 @@ extern "C" int t4r_head_split_logits_ce(void* stream, void* ws, const float* W, 
     float* stt = label_smoothing > 0.f ? ss + (long)w.ntile * N : nullptr;
     const int vec_ok = aligned16(C) && ldc % 4 == 0;
     dim3 grid(8 * ((w.ntile + 7) / 8) * rs);
-    T4R_NB_SWITCH(D, hipLaunchKernelGGL(head_logits_ce_kernel<NB>, grid, dim3(256), 0, st, xa, W, ldw, C, ldc, N, V, alpha,
-                                        w.nblk, blk_per, vec_ok, sm, ss, stt, w.ntile, rs));
+    if (head_fwd_fp16x2()) {
+        unsigned* amax = reinterpret_cast<unsigned*>((char*)ws + w.scales);
+        if (head_w_amax(st, W, ldw, V, D, amax + 1)) return -1;
+        T4R_NB_SWITCH(D, hipLaunchKernelGGL((head_logits_ce_kernel<NB, true>), grid, dim3(256), 0, st, xa, W, ldw, C, ldc, N, V,
+                                            alpha, w.nblk, blk_per, vec_ok, sm, ss, stt, w.ntile, rs, amax));
+    } else {
+        T4R_NB_SWITCH(D, hipLaunchKernelGGL(head_logits_ce_kernel<NB>, grid, dim3(256), 0, st, xa, W, ldw, C, ldc, N, V, alpha,
+                                            w.nblk, blk_per, vec_ok, sm, ss, stt, w.ntile, rs));
+    }
     if (labels)       // labels == NULL: the product and its per-tile statistics only (timing the dominant kernel alone)
         hipLaunchKernelGGL(head_ce_finalize_kernel, dim3((N + 31) / 32), dim3(1024), 0, st, sm, ss, stt, w.ntile, N, V, C, ldc,
                            labels, label_smoothing, loss_rows, lse);
@@ -746,14 +871,27 @@ extern "C" int t4r_head_split_dx(void* stream, void* ws, const float* logits, lo
     u32x4* wt = reinterpret_cast<u32x4*>((char*)ws + w.wt);
     float* part = reinterpret_cast<float*>((char*)ws + w.part);
     const int nkt = (Vc + 31) / 32, row_tiles = (N + 127) / 128;
-    T4R_NB_SWITCH(D, hipLaunchKernelGGL(split_km_kernel<NB>, dim3(nkt), dim3(256), 0, st, W, ldw, Vc, wt));
+    const bool hs = head_fwd_fp16x2();
+    unsigned* amax = reinterpret_cast<unsigned*>((char*)ws + w.scales) + 1;     // max |W| of THIS call's rows (a chunk of the table)
+    if (hs) {
+        if (head_w_amax(st, W, ldw, Vc, D, amax)) return -1;
+        T4R_NB_SWITCH(D, hipLaunchKernelGGL((split_km_kernel<NB, true>), dim3(nkt), dim3(256), 0, st, W, ldw, Vc, wt, amax));
+    } else {
+        T4R_NB_SWITCH(D, hipLaunchKernelGGL(split_km_kernel<NB>, dim3(nkt), dim3(256), 0, st, W, ldw, Vc, wt));
+    }
     const int target = head_dx_target();
     int splits = max(1, min(min(w.max_split, nkt / 8), target / row_tiles));
     const int kt_per = (nkt + splits - 1) / splits;
     splits = (nkt + kt_per - 1) / kt_per;          // every split owns at least one k-tile
-    T4R_NB_SWITCH(D, hipLaunchKernelGGL(head_dx_split_kernel<NB>, dim3(row_tiles * 8 * ((splits + 7) / 8)), dim3(256), 0, st,
-                                        logits, ld, lse, labels, grad_out, wt, part, N, Vc, V, yoff, label_smoothing, alpha,
-                                        nkt, kt_per, row_tiles));
+    if (hs) {
+        T4R_NB_SWITCH(D, hipLaunchKernelGGL((head_dx_split_kernel<NB, true>), dim3(row_tiles * 8 * ((splits + 7) / 8)), dim3(256),
+                                            0, st, logits, ld, lse, labels, grad_out, wt, part, N, Vc, V, yoff, label_smoothing,
+                                            alpha, nkt, kt_per, row_tiles, amax));
+    } else {
+        T4R_NB_SWITCH(D, hipLaunchKernelGGL(head_dx_split_kernel<NB>, dim3(row_tiles * 8 * ((splits + 7) / 8)), dim3(256), 0, st,
+                                            logits, ld, lse, labels, grad_out, wt, part, N, Vc, V, yoff, label_smoothing, alpha,
+                                            nkt, kt_per, row_tiles));
+    }
     const long nd4 = (long)N * D / 4;
     hipLaunchKernelGGL(head_dx_reduce_kernel, dim3((unsigned)((nd4 + 255) / 256)), dim3(256), 0, st, part, splits, nd4, D / 4,
                        dX, lddx, accumulate);

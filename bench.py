@@ -107,6 +107,12 @@ def make_train_step(model, batches, reducer, opt):
     return train_step
 
 
+def _lib_int(name):
+    from transformers4rec_amd import _lib
+
+    return int(getattr(_lib.load(), name)())
+
+
 def timed_region(train_step, warmup, steps, world, device, first_step=0):
     """W untimed steps, then EXACTLY K steps bracketed by barrier + device sync, MAX over ranks.
     -> (seconds, last output, label rows seen)"""
@@ -623,7 +629,9 @@ def main():
         gemm_ms_f32 = timed(lambda: ops.gemm(xr, W, False, True, out=buf[:, : W.shape[0]]))
     flops = 2.0 * N_m * W.shape[0] * D_MODEL
     split = mode in ("auto", "fp32_bf16x3")
-    executed = (6.0 if split else 1.0) * flops
+    # matrix instructions per fp32-equivalent one: 6 (three bf16 planes) or, in csrc/head_split.hip's forward, 3 (two-way fp16 split)
+    n_prod = float(_lib_int("t4r_head_split_fwd_products")) if (split and head_split) else (6.0 if split else 1.0)
+    executed = n_prod * flops
     peak = {"fp32": MFMA_F32_PEAK_TFLOPS, "auto": MFMA_BF16_PEAK_TFLOPS, "fp32_bf16x3": MFMA_BF16_PEAK_TFLOPS,
             "bf16": MFMA_BF16_PEAK_TFLOPS, "fp16": MFMA_BF16_PEAK_TFLOPS}[mode]
     achieved = executed / (gemm_ms * 1e-3) / 1e12
@@ -790,17 +798,21 @@ def main():
                        "precision_mode": mode, "table_exchange": table_exchange_mode() if world > 1 else "local",
                        "preheat_s": round(preheat_s, 2), "preheat_steps": n_pre,
                        "timed_region_s": round(dt, 4)},
-            "roofline": {"kernel": ("head_logits_ce_kernel<4> (next-item logits X@W^T + the softmax statistics of the loss; fp32-accurate: "
-                                    "exact 3-way bf16 split, six v_mfma_f32_32x32x16_bf16 products per K=16; W fragments "
-                                    "register-resident, X plane blocks through LDS)") if head_split else
+            "roofline": {"kernel": (("head_logits_ce_kernel<4, fp16x2> (next-item logits X@W^T + the softmax statistics of the loss; "
+                                     "fp32-class accuracy: two-way fp16 split with power-of-two tensor scales, three "
+                                     "v_mfma_f32_32x32x16_f16 products per K=16; W fragments register-resident, X plane blocks through LDS)")
+                                    if n_prod == 3.0 else
+                                    ("head_logits_ce_kernel<4> (next-item logits X@W^T + the softmax statistics of the loss; fp32-accurate: "
+                                     "exact 3-way bf16 split, six v_mfma_f32_32x32x16_bf16 products per K=16; W fragments "
+                                     "register-resident, X plane blocks through LDS)")) if head_split else
                                    ("gemm_f32_kernel<128,64,32,NT,PREC=1> (next-item logits X@W^T; fp32-accurate: exact "
                                     "3-way bf16 split, six v_mfma_f32_32x32x16_bf16 products per K=16)") if split else
                                    "gemm_f32_kernel<128,128,16,NT> (next-item logits X@W^T)",
                          "bound": "mfma", "precision_mode": mode,
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4),
-                         "note": "achieved = EXECUTED matrix-core flops (6x the algorithmic 2*N*V*D in the split form) / "
-                                 "launch time, priced against the dense bf16 MFMA peak",
+                         "note": f"achieved = EXECUTED matrix-core flops ({int(n_prod)}x the algorithmic 2*N*V*D in this split form) / "
+                                 "launch time, priced against the dense bf16 / fp16 MFMA peak",
                          "fp32_equivalent": {"achieved": round(flops / (gemm_ms * 1e-3) / 1e12, 2),
                                              "peak": MFMA_F32_PEAK_TFLOPS,
                                              "frac": round(flops / (gemm_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)},

@@ -207,6 +207,9 @@ int t4r_get_tok_gemm_min_rows(void);
  * on different streams.  logits [N, ld] holds the columns [yoff, yoff + Vc) of the [N, V] problem (Vc = V, yoff = 0:
  * all of them); W passed to _dx points at row yoff.  No atomics: results are bit-reproducible. */
 int t4r_head_split_supported(int D);
+/* matrix instructions per fp32-equivalent one in the forward logits / d X products of csrc/head_split.hip: 3 = two-way fp16
+ * split with power-of-two tensor scales (default), 6 = three bf16 planes (T4R_HEAD_FWD_FP16X2=0); d W always 6 */
+int t4r_head_split_fwd_products(void);
 long t4r_head_split_ws_bytes(int N, int V, int D);
 int t4r_head_split_prepare(void* stream, const float* X, long ldx, int N, int D, int V, void* ws);
 int t4r_head_split_logits(void* stream, const void* ws, const float* W, long ldw, float* C, long ldc, int N, int V,

@@ -1194,6 +1194,44 @@ def test_head_split_products_match_fp64(ops, N, V, D, alpha, smooth):
     close(dX, dX_g, rtol=1e-4, atol=1e-5 * float(dX64.abs().max()))
 
 
+@pytest.mark.parametrize("sx,sw,gout", [(1.0, 1.0, 1.0), (3e-13, 2e7, 1.0), (5e11, 7e-9, 1.0), (1.0, 1.0, 3e-21), (40.0, 0.01, 6e9)])
+def test_head_split_fp16_split_is_scale_free(ops, sx, sw, gout):
+    """The forward and d X products run on a two-way fp16 split whose pieces only cover [6e-8, 65504]: power-of-two scales
+    taken from max |X|, max |W| and g / N (csrc/head_split.hip: scale_of, mfma_split) position every tensor first.  The
+    error against fp64, relative to the largest output, must not depend on the magnitudes of the inputs or of the
+    upstream gradient -- fp16 range never shows through."""
+    N, V, D = 150, 3000, 128
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(N, D, device=DEV, generator=g) * sx
+    W = torch.randn(V, D, device=DEV, generator=g) * sw
+    alpha = 1.0 / (sx * sw * 8.0)                      # logits of order one whatever the operand magnitudes
+    labels = torch.randint(0, V, (N,), device=DEV, generator=g)
+    ws = ops.head_split_prepare(x, V)
+    logits, loss, rows, lse = ops.head_split_logits_ce(ws, x, W, labels, alpha=alpha, ldc=ops.pad_ld(V))
+    lg64 = alpha * (x.double() @ W.double().t())
+    assert torch.isfinite(logits).all()
+    assert float((logits.double() - lg64).abs().max()) < 2e-6 * float(lg64.abs().max())
+    go = torch.tensor(gout, device=DEV)
+    dX = ops.head_split_dx(ws, logits, lse, labels, go, V, W, alpha=alpha)
+    p = torch.softmax(logits.double(), dim=1)
+    p[torch.arange(N, device=DEV), labels] -= 1.0
+    dX64 = alpha * ((gout / N) * p) @ W.double()
+    assert torch.isfinite(dX).all()
+    assert float((dX.double() - dX64).abs().max()) < 5e-6 * float(dX64.abs().max())
+
+
+def test_head_split_fp16_split_zero_operand(ops):
+    """an all-zero operand (max |X| = 0: no scale to take) gives exact zeros, not NaN"""
+    N, V, D = 40, 700, 64
+    x = torch.zeros(N, D, device=DEV)
+    W = torch.randn(V, D, device=DEV)
+    labels = torch.randint(0, V, (N,), device=DEV)
+    ws = ops.head_split_prepare(x, V)
+    logits, loss, rows, lse = ops.head_split_logits_ce(ws, x, W, labels, ldc=ops.pad_ld(V))
+    assert torch.equal(logits, torch.zeros_like(logits))
+    assert abs(float(loss) - float(torch.log(torch.tensor(float(V))))) < 1e-5
+
+
 def test_head_split_vocabulary_chunk(ops):
     """logits holding only the columns [yoff, yoff + Vc) of the problem (the chunk-streamed form): labels outside the
     chunk contribute only their softmax mass, eps / V and 1 / N refer to the full problem"""

@@ -55,6 +55,7 @@ _SIGS = {
     "t4r_set_tok_gemm_min_rows": ("v", "i"),
     "t4r_get_tok_gemm_min_rows": ("i", ""),
     "t4r_head_split_supported": ("i", "i"),
+    "t4r_head_split_fwd_products": ("i", ""),
     "t4r_head_split_ws_bytes": ("l", "iii"),
     "t4r_head_split_prepare": ("i", "ppl" + "iii" + "p"),
     "t4r_head_split_logits": ("i", "ppplpl" + "iiif"),

@@ -751,6 +751,8 @@ static int head_w_amax(hipStream_t st, const float* W, long ldw, int V, int D, u
 
 // 1 when these kernels take the shape (the callers fall back to the general GEMM otherwise)
 extern "C" int t4r_head_split_supported(int D) { return D >= 32 && D <= 128 && D % 32 == 0; }
+// matrix instructions per fp32-equivalent one in the forward / d X products: 3 (two-way fp16 split) or 6 (three bf16 planes)
+extern "C" int t4r_head_split_fwd_products(void) { return head_fwd_fp16x2() ? 3 : 6; }
 
 extern "C" long t4r_head_split_ws_bytes(int N, int V, int D) {
     if (!t4r_head_split_supported(D) || N <= 0 || V <= 0) return 0;

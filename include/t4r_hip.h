@@ -212,7 +212,7 @@ int t4r_head_split_supported(int D);
 int t4r_head_split_fwd_products(void);
 long t4r_head_split_ws_bytes(int N, int V, int D);
 int t4r_head_split_prepare(void* stream, const float* X, long ldx, int N, int D, int V, void* ws);
-int t4r_head_split_logits(void* stream, const void* ws, const float* W, long ldw, float* C, long ldc, int N, int V,
+int t4r_head_split_logits(void* stream, void* ws, const float* W, long ldw, float* C, long ldc, int N, int V,
                           int D, float alpha);
 /* logits + mean cross-entropy (label smoothing as losses.py:4-20) in ONE pass over the vocabulary: the logits are
  * stored as by _logits, the softmax statistics are reduced inside the product's workgroups (one partial per row and

@@ -783,7 +783,7 @@ extern "C" int t4r_head_split_prepare(void* stream, const float* X, long ldx, in
 }
 
 // C[N, V] = alpha * X @ W^T from the prepared workspace
-extern "C" int t4r_head_split_logits(void* stream, const void* ws, const float* W, long ldw, float* C, long ldc, int N,
+extern "C" int t4r_head_split_logits(void* stream, void* ws, const float* W, long ldw, float* C, long ldc, int N,
                                      int V, int D, float alpha) {
     if (N <= 0 || V <= 0) return 0;
     T4R_CHECK_ARG(t4r_head_split_supported(D) && W && C && ws, "head_split_logits: unsupported width or null pointer");

@@ -64,7 +64,43 @@ __host__ __device__ inline LayerPlanes carve_planes(const void* base, int D) {
     p.W2Tp = b;
     return p;
 }
-static inline long layer_planes_floats(int D) { return 25L * 3 * D * D / 2; }
+// Two-way fp16 planes (x s = hi + lo, see csrc/head_split.hip: mfma_split) of the matrices whose products have moved to
+// that form, after the bf16 planes: QKVTh [2][3D][D], RTh [2][D][D] (same orientation as QKVT / RT), then the power-of-two
+// scale of every such matrix (one float each: q, k, v, r), i.e. max |W| s in [2^13, 2^14).
+struct LayerPlanesH {
+    const uint16_t *QKVT, *RT;
+    const float* scale;       // [4]: q, k, v, r
+};
+static inline long layer_planes_bf16_floats(int D) { return 25L * 3 * D * D / 2; }
+__host__ __device__ inline LayerPlanesH carve_planes_h(const void* base, int D) {
+    const uint16_t* b = (const uint16_t*)((const float*)base + 25L * 3 * D * D / 2);
+    LayerPlanesH p;
+    p.QKVT = b; b += 2L * 3 * D * D;
+    p.RT = b; b += 2L * D * D;
+    p.scale = (const float*)b;
+    return p;
+}
+static inline long layer_planes_floats(int D) { return layer_planes_bf16_floats(D) + (2L * 4 * D * D) / 2 + 16; }
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 mfma_h(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// two (already scaled) fp32 values -> hi / lo fp16 pairs, both cuts round to nearest even
+__device__ __forceinline__ void cut2h(float a, float b, uint32_t (&w)[2]) {
+    const f16x2v h = {(_Float16)a, (_Float16)b};
+    const f16x2v l = {(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
+    w[0] = __builtin_bit_cast(uint32_t, h);
+    w[1] = __builtin_bit_cast(uint32_t, l);
+}
+// the power of two that puts a largest magnitude m into [2^13, 2^14) (1 for zero / non-finite m)
+__device__ __forceinline__ float pow2_scale(float m) {
+    if (!(m > 0.f) || !(m < 3e38f)) return 1.f;
+    int e;
+    (void)frexpf(m, &e);
+    return ldexpf(1.f, 14 - e);
+}
 
 // acc[r] += A_tile (16 features x D) . B_r (D x 16 tokens) for every token block r, three-plane operands, six products.
 // The weight fragment is requested one product ahead (load_a3: 3 D/32 16-byte loads from the L2-resident planes, issued
@@ -103,5 +139,33 @@ __device__ __forceinline__ void product3(const AFrag<D>& a, const uint16_t* bp, 
             T4R_SIX(T4R_PROD)
 #undef T4R_PROD
         }
+    }
+}
+
+// ---- the same product on two-way fp16 planes: three matrix instructions per k-step and token block instead of six
+template <int D>
+struct AFragH { u32x4 v[D / 32][2]; };
+template <int D>
+__device__ __forceinline__ void load_a2h(AFragH<D>& a, const uint16_t* __restrict__ ap, long apl) {
+#pragma unroll
+    for (int s = 0; s < D / 32; ++s)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) a.v[s][pl] = ldq(ap + pl * apl + 32 * s);
+}
+template <int D, int R, int P>
+__device__ __forceinline__ void product3h(const AFragH<D>& a, const uint16_t* bp, int bpl, f32x4 (&acc)[R]) {
+#pragma unroll
+    for (int s = 0; s < D / 32; ++s) {
+        u32x4 b[R][2];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) b[r][pl] = ldq(bp + pl * bpl + r * 16 * P + 32 * s);
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = mfma_h(a.v[s][1], b[r][0], acc[r]);
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = mfma_h(a.v[s][0], b[r][1], acc[r]);
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = mfma_h(a.v[s][0], b[r][0], acc[r]);
     }
 }

@@ -67,6 +67,55 @@ static void add_job(PlaneJobs& js, const float* src, int rows, int cols, const u
 
 // params: host array of the layer's 15 device pointers in the order of t4r_xlnet_layer_fwd (q, k, v, o, r, ..., W1 at 9,
 // W2 at 11); any of the attention weights may be NULL (feed-forward planes only: t4r_xlnet_ff_prepare)
+// ---- two-way fp16 planes of the square matrices of the projections (q, k, v, r): one workgroup per matrix finds max |W|,
+// derives the power-of-two scale, cuts.  dst[o][k] = src[k][o] (the MFMA A fragment wants consecutive k of one output row).
+struct HJob { const float* src; uint16_t* dst; long dplane; int r0; float* scale; };
+#define T4R_MAX_HJOBS 16
+struct HJobs { HJob j[T4R_MAX_HJOBS]; int n; int D; };
+__global__ __launch_bounds__(1024) void weight_planes_h_kernel(HJobs jobs) {
+    __shared__ float red[16];
+    __shared__ float sh_scale;
+    const HJob jb = jobs.j[blockIdx.x];
+    const int D = jobs.D, n = D * D;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(jb.src[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float mm = red[0];
+        for (int w = 1; w < 16; ++w) mm = fmaxf(mm, red[w]);
+        const float sc = pow2_scale(mm);
+        sh_scale = sc;
+        *jb.scale = sc;
+    }
+    __syncthreads();
+    const float sc = sh_scale;
+    for (int i = threadIdx.x; i < n / 2; i += 1024) {          // pairs (k, k + 1) of one output row o: src[k][o], src[k + 1][o]
+        const int o = i / (D / 2), k = (i % (D / 2)) * 2;
+        uint32_t w[2];
+        cut2h(jb.src[(long)k * D + o] * sc, jb.src[(long)(k + 1) * D + o] * sc, w);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+            *reinterpret_cast<uint32_t*>(jb.dst + pl * jb.dplane + (long)(jb.r0 + o) * D + k) = w[pl];
+    }
+}
+static void add_layer_hjobs(HJobs& js, const float* q, const float* k, const float* v, const float* r, int D, float* planes) {
+    const LayerPlanesH P = carve_planes_h(planes, D);
+    const float* z[3] = {q, k, v};
+    float* sc = const_cast<float*>(P.scale);
+    for (int i = 0; i < 3; ++i)
+        if (z[i]) js.j[js.n++] = HJob{z[i], const_cast<uint16_t*>(P.QKVT), 3L * D * D, i * D, sc + i};
+    if (r) js.j[js.n++] = HJob{r, const_cast<uint16_t*>(P.RT), (long)D * D, 0, sc + 3};
+}
+static int launch_hjobs(hipStream_t st, const HJobs& js) {
+    if (js.n == 0) return 0;
+    hipLaunchKernelGGL(weight_planes_h_kernel, dim3(js.n), dim3(1024), 0, st, js);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
 static void add_layer_jobs(PlaneJobs& js, const float* q, const float* k, const float* v, const float* o, const float* r,
                            const float* W1, const float* W2, int D, float* planes) {
     const LayerPlanes P = carve_planes(planes, D);
@@ -103,7 +152,11 @@ static int prepare_launch(hipStream_t st, const float* q, const float* k, const 
     PlaneJobs js;
     js.n = 0; js.total = 0;
     add_layer_jobs(js, q, k, v, o, r, W1, W2, D, planes);
-    return launch_jobs(st, js);
+    if (launch_jobs(st, js)) return -1;
+    HJobs hj;
+    hj.n = 0; hj.D = D;
+    add_layer_hjobs(hj, q, k, v, r, D, planes);
+    return launch_hjobs(st, hj);
 }
 
 extern "C" int t4r_xlnet_fused_supported(int D);
@@ -142,6 +195,36 @@ __device__ __forceinline__ void tile_to_planes(const float* __restrict__ src, lo
     }
 }
 
+// the same tile as two-way fp16 planes [2][RT][PH], every token row positioned by its OWN power-of-two scale (max |row|
+// -> [2^13, 2^14)): rows of very different magnitude in one tile (gradient rows) keep their full 22 bits each.
+// sh_inv[row] = 1 / scale (exact), multiplied back in the product's epilogue.  The D / 4 threads of a row are consecutive
+// lanes of one wave (D / 4 <= 32).
+template <int D, int RT, int NT, int PH>
+__device__ __forceinline__ void tile_to_planes_h(const float* __restrict__ src, long t0, long T, uint16_t* sh, float* sh_inv,
+                                                 int tid) {
+    constexpr int PLN = RT * PH, G = D / 4;
+    static_assert((RT * G) % NT == 0 || true, "");
+    for (int i = tid; i < ((RT * G + NT - 1) / NT) * NT; i += NT) {      // whole waves stay in the loop: the shuffles need their partners
+        const bool live = i < RT * G;
+        const int row = live ? i / G : RT - 1, c4 = live ? (i % G) * 4 : 0;
+        const long t = min(t0 + row, T - 1);
+        const float4 v = ld4(src + t * D + c4);
+        float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        const float sc = pow2_scale(m);
+        if (live) {
+            uint32_t w0[2], w1[2];
+            cut2h(v.x * sc, v.y * sc, w0);
+            cut2h(v.z * sc, v.w * sc, w1);
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+                *reinterpret_cast<uint2*>(sh + pl * PLN + row * PH + c4) = make_uint2(w0[pl], w1[pl]);
+            if (c4 == 0) sh_inv[row] = 1.f / sc;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- projections
 struct ProjParams {
     const float* in;          // [T, D]
@@ -149,15 +232,20 @@ struct ProjParams {
     long wpl;                 // plane stride of those planes (elements)
     float* out[4];            // per output matrix: [T, D]
     long T;
+    const float* wscale[4];   // HS: the matrices' power-of-two scales (device)
 };
 
-template <int D, int R, int NM>
+// HS: the two-way fp16 form (three matrix instructions per k-step instead of six; per-token and per-matrix power-of-two
+// scales, see tile_to_planes_h / weight_planes_h_kernel)
+template <int D, int R, int NM, bool HS = false>
 __global__ __launch_bounds__(D * 4) void xlnet_proj_kernel(ProjParams p) {
     constexpr int NW = D / 16, NT = NW * 64, RT = 16 * R, PH = D + 16, PLN = RT * PH;
     extern __shared__ uint16_t smem16[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, g = lane >> 4;
     const long t0 = (long)blockIdx.x * RT;
-    tile_to_planes<D, RT, NT, PH>(p.in, t0, p.T, smem16, tid);
+    float* sh_inv = reinterpret_cast<float*>(smem16 + (HS ? 2 : 3) * PLN);       // HS: [RT] inverse token scales
+    if constexpr (HS) tile_to_planes_h<D, RT, NT, PH>(p.in, t0, p.T, smem16, sh_inv, tid);
+    else tile_to_planes<D, RT, NT, PH>(p.in, t0, p.T, smem16, tid);
     __syncthreads();
     const int boff = n * PH + 8 * g;
 #pragma unroll
@@ -165,14 +253,22 @@ __global__ __launch_bounds__(D * 4) void xlnet_proj_kernel(ProjParams p) {
         f32x4 acc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = zero4();
-        AFrag<D> a;
-        load_a3<D>(a, p.w[m] + (long)(16 * w + n) * D + 8 * g, p.wpl);
-        product3<D, R, PH>(a, smem16 + boff, PLN, acc);
+        if constexpr (HS) {
+            AFragH<D> a;
+            load_a2h<D>(a, p.w[m] + (long)(16 * w + n) * D + 8 * g, p.wpl);
+            product3h<D, R, PH>(a, smem16 + boff, PLN, acc);
+        } else {
+            AFrag<D> a;
+            load_a3<D>(a, p.w[m] + (long)(16 * w + n) * D + 8 * g, p.wpl);
+            product3<D, R, PH>(a, smem16 + boff, PLN, acc);
+        }
+        const float iw = HS ? 1.f / *p.wscale[m] : 1.f;
         float* o = p.out[m] + 16 * w + 4 * g;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const long t = t0 + r * 16 + n;
-            if (t < p.T) st4(o + t * D, make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]));
+            const float sc = HS ? sh_inv[r * 16 + n] * iw : 1.f;          // two exact powers of two
+            if (t < p.T) st4(o + t * D, make_float4(acc[r][0] * sc, acc[r][1] * sc, acc[r][2] * sc, acc[r][3] * sc));
         }
     }
 }
@@ -408,6 +504,12 @@ __global__ __launch_bounds__(D * 4) void xlnet_dh_kernel(DhParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------- host side
+// the projections in the two-way fp16 form (T4R_XLNET_FP16X2, default 1)?
+static bool body_fp16x2() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("T4R_XLNET_FP16X2"); on = e ? (atoi(e) != 0) : 1; }
+    return on != 0;
+}
 static int pick_r(long T) {
     const long blocks16 = (T + 15) / 16;
     if (blocks16 <= 256) return 1;
@@ -437,14 +539,22 @@ extern "C" int t4r_xlnet_qkv_proj(void* stream, const float* h, const float* pla
     if (T <= 0) return 0;
     T4R_CHECK_ARG(t4r_xlnet_fused_supported(D) && h && planes && qkv, "xlnet_qkv_proj: bad arguments");
     const int R = pick_r(T);
-    const uint16_t* wq = carve_planes(planes, D).QKVT;
-    ProjParams p{h, {wq, wq + (long)D * D, wq + 2L * D * D, nullptr}, 3L * D * D, {qkv, qkv + T * D, qkv + 2 * T * D, nullptr}, T};
+    const bool hs = body_fp16x2();
+    const LayerPlanesH PH_ = carve_planes_h(planes, D);
+    const uint16_t* wq = hs ? PH_.QKVT : carve_planes(planes, D).QKVT;
+    ProjParams p{h, {wq, wq + (long)D * D, wq + 2L * D * D, nullptr}, 3L * D * D, {qkv, qkv + T * D, qkv + 2 * T * D, nullptr}, T,
+                 {PH_.scale, PH_.scale + 1, PH_.scale + 2, nullptr}};
     hipStream_t st = (hipStream_t)stream;
 #define CALL(DD, RR)                                                                                             \
     {                                                                                                            \
-        const size_t smem = (size_t)3 * 16 * RR * (DD + 16) * 2;                                                 \
-        { static bool once = false; if (!once) { set_smem(xlnet_proj_kernel<DD, RR, 3>, smem); once = true; } }                                                            \
-        hipLaunchKernelGGL((xlnet_proj_kernel<DD, RR, 3>), dim3((unsigned)((T + 16 * RR - 1) / (16 * RR))), dim3(DD * 4), smem, st, p); \
+        const size_t smem = (size_t)3 * 16 * RR * (DD + 16) * 2;       /* HS: two planes + the token scales fit the same size */ \
+        if (hs) {                                                                                                \
+            { static bool once = false; if (!once) { set_smem(xlnet_proj_kernel<DD, RR, 3, true>, smem); once = true; } } \
+            hipLaunchKernelGGL((xlnet_proj_kernel<DD, RR, 3, true>), dim3((unsigned)((T + 16 * RR - 1) / (16 * RR))), dim3(DD * 4), smem, st, p); \
+        } else {                                                                                                 \
+            { static bool once = false; if (!once) { set_smem(xlnet_proj_kernel<DD, RR, 3>, smem); once = true; } } \
+            hipLaunchKernelGGL((xlnet_proj_kernel<DD, RR, 3>), dim3((unsigned)((T + 16 * RR - 1) / (16 * RR))), dim3(DD * 4), smem, st, p); \
+        }                                                                                                        \
     }
     ATTN_DISPATCH(CALL, D, R)
 #undef CALL
@@ -457,13 +567,21 @@ extern "C" int t4r_xlnet_kr_proj(void* stream, const float* pos, const float* pl
     if (rows <= 0) return 0;
     T4R_CHECK_ARG(t4r_xlnet_fused_supported(D) && pos && planes && kr, "xlnet_kr_proj: bad arguments");
     const int R = pick_r(rows);
-    ProjParams p{pos, {carve_planes(planes, D).RT, nullptr, nullptr, nullptr}, (long)D * D, {kr, nullptr, nullptr, nullptr}, rows};
+    const bool hs = body_fp16x2();
+    const LayerPlanesH PH_ = carve_planes_h(planes, D);
+    ProjParams p{pos, {hs ? PH_.RT : carve_planes(planes, D).RT, nullptr, nullptr, nullptr}, (long)D * D, {kr, nullptr, nullptr, nullptr}, rows,
+                 {PH_.scale + 3, nullptr, nullptr, nullptr}};
     hipStream_t st = (hipStream_t)stream;
 #define CALL(DD, RR)                                                                                             \
     {                                                                                                            \
         const size_t smem = (size_t)3 * 16 * RR * (DD + 16) * 2;                                                 \
-        { static bool once = false; if (!once) { set_smem(xlnet_proj_kernel<DD, RR, 1>, smem); once = true; } }                                                            \
-        hipLaunchKernelGGL((xlnet_proj_kernel<DD, RR, 1>), dim3((unsigned)((rows + 16 * RR - 1) / (16 * RR))), dim3(DD * 4), smem, st, p); \
+        if (hs) {                                                                                                \
+            { static bool once = false; if (!once) { set_smem(xlnet_proj_kernel<DD, RR, 1, true>, smem); once = true; } } \
+            hipLaunchKernelGGL((xlnet_proj_kernel<DD, RR, 1, true>), dim3((unsigned)((rows + 16 * RR - 1) / (16 * RR))), dim3(DD * 4), smem, st, p); \
+        } else {                                                                                                 \
+            { static bool once = false; if (!once) { set_smem(xlnet_proj_kernel<DD, RR, 1>, smem); once = true; } } \
+            hipLaunchKernelGGL((xlnet_proj_kernel<DD, RR, 1>), dim3((unsigned)((rows + 16 * RR - 1) / (16 * RR))), dim3(DD * 4), smem, st, p); \
+        }                                                                                                        \
     }
     ATTN_DISPATCH(CALL, D, R)
 #undef CALL
@@ -489,16 +607,37 @@ extern "C" int t4r_xlnet_stack_prepare(void* stream, const float* const* params_
             add_layer_jobs(js, pr[0], pr[1], pr[2], pr[3], pr[4], pr[9], pr[11], D, planes[l]);
         }
         if (launch_jobs(st, js)) return -1;
+        {
+            HJobs hj;
+            hj.n = 0; hj.D = D;
+            for (int l = l0; l < l0 + nl; ++l) {
+                const float* const* pr = params_all + (long)l * 15;
+                add_layer_hjobs(hj, pr[0], pr[1], pr[2], pr[4], D, planes[l]);
+            }
+            if (launch_hjobs(st, hj)) return -1;
+        }
         if (!pos || pos_rows <= 0) continue;
         T4R_CHECK_ARG(kr, "xlnet_stack_prepare: null k_r pointers");
-        ProjParams p{pos, {nullptr, nullptr, nullptr, nullptr}, (long)D * D, {nullptr, nullptr, nullptr, nullptr}, pos_rows};
-        for (int m = 0; m < nl; ++m) { p.w[m] = carve_planes(planes[l0 + m], D).RT; p.out[m] = kr[l0 + m]; }
+        const bool hs = body_fp16x2();
+        ProjParams p{pos, {nullptr, nullptr, nullptr, nullptr}, (long)D * D, {nullptr, nullptr, nullptr, nullptr}, pos_rows,
+                     {nullptr, nullptr, nullptr, nullptr}};
+        for (int m = 0; m < nl; ++m) {
+            const LayerPlanesH PH_ = carve_planes_h(planes[l0 + m], D);
+            p.w[m] = hs ? PH_.RT : carve_planes(planes[l0 + m], D).RT;
+            p.wscale[m] = PH_.scale + 3;
+            p.out[m] = kr[l0 + m];
+        }
         const int R = pick_r(pos_rows);
 #define CALLN(DD, RR, NMV)                                                                                       \
     {                                                                                                            \
         const size_t smem = (size_t)3 * 16 * RR * (DD + 16) * 2;                                                 \
-        { static bool once = false; if (!once) { set_smem(xlnet_proj_kernel<DD, RR, NMV>, smem); once = true; } } \
-        hipLaunchKernelGGL((xlnet_proj_kernel<DD, RR, NMV>), dim3((unsigned)((pos_rows + 16 * RR - 1) / (16 * RR))), dim3(DD * 4), smem, st, p); \
+        if (hs) {                                                                                                \
+            { static bool once = false; if (!once) { set_smem(xlnet_proj_kernel<DD, RR, NMV, true>, smem); once = true; } } \
+            hipLaunchKernelGGL((xlnet_proj_kernel<DD, RR, NMV, true>), dim3((unsigned)((pos_rows + 16 * RR - 1) / (16 * RR))), dim3(DD * 4), smem, st, p); \
+        } else {                                                                                                 \
+            { static bool once = false; if (!once) { set_smem(xlnet_proj_kernel<DD, RR, NMV>, smem); once = true; } } \
+            hipLaunchKernelGGL((xlnet_proj_kernel<DD, RR, NMV>), dim3((unsigned)((pos_rows + 16 * RR - 1) / (16 * RR))), dim3(DD * 4), smem, st, p); \
+        }                                                                                                        \
     }
 #define CALL1(DD, RR) CALLN(DD, RR, 1)
 #define CALL2(DD, RR) CALLN(DD, RR, 2)

@@ -356,7 +356,7 @@ int t4r_xlnet_fused_supported(int D);
 long t4r_xlnet_layer_planes_floats(int D);
 int t4r_xlnet_layer_prepare(void* stream, const float* const* params, int D, float* planes);
 long t4r_xlnet_ff_planes_floats(int D);
-int t4r_xlnet_ff_prepare(void* stream, const float* W1, const float* W2, int D, float* planes);
+int t4r_xlnet_ff_prepare(void* stream, const float* W1, const float* b1, const float* W2, int D, float* planes);
 int t4r_xlnet_qkv_proj(void* stream, const float* h, const float* planes, float* qkv, long T, int D);
 int t4r_xlnet_kr_proj(void* stream, const float* pos, const float* planes, float* kr, long rows, int D);
 int t4r_xlnet_oproj_ln(void* stream, const float* av, const float* h, const float* planes, const float* gamma,

@@ -27,7 +27,7 @@ dg, db, db2, db1 = (torch.zeros(D, device=dev) for _ in range(3)) + (torch.zeros
 part = torch.empty(_lib.load().t4r_xlnet_ff_bwd_part_floats(T, D), device=dev)
 planes = torch.empty(_lib.load().t4r_xlnet_ff_planes_floats(D), device=dev)
 P = lambda t: t.data_ptr()
-_lib.call("t4r_xlnet_ff_prepare", ops._stream(), P(W1), P(W2), D, P(planes))
+_lib.call("t4r_xlnet_ff_prepare", ops._stream(), P(W1), P(b1), P(W2), D, P(planes))
 
 
 def fwd():
@@ -54,7 +54,7 @@ def timed(fn):
 
 flops = 2.0 * T * D * 4 * D * 2
 def prep():
-    _lib.call("t4r_xlnet_ff_prepare", ops._stream(), P(W1), P(W2), D, P(planes))
+    _lib.call("t4r_xlnet_ff_prepare", ops._stream(), P(W1), P(b1), P(W2), D, P(planes))
 
 
 def fwd_infer():

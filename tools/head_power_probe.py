@@ -28,7 +28,7 @@ h1 = torch.randn(T, D, device=dev)
 prm = [torch.randn(4 * D, D, device=dev) * 0.05, torch.randn(4 * D, device=dev) * 0.05, torch.randn(D, 4 * D, device=dev) * 0.05,
        torch.randn(D, device=dev) * 0.05, torch.ones(D, device=dev), torch.zeros(D, device=dev)]
 planes = torch.empty(_lib.load().t4r_xlnet_ff_planes_floats(D), device=dev)
-_lib.call("t4r_xlnet_ff_prepare", ops._stream(), prm[0].data_ptr(), prm[2].data_ptr(), D, planes.data_ptr())
+_lib.call("t4r_xlnet_ff_prepare", ops._stream(), prm[0].data_ptr(), prm[1].data_ptr(), prm[2].data_ptr(), D, planes.data_ptr())
 big = torch.empty(256 << 20, device=dev, dtype=torch.float32)
 
 cases = {

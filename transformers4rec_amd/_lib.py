@@ -87,7 +87,7 @@ _SIGS = {
     "t4r_xlnet_stack_prepared": ("v", "i"),
     "t4r_xlnet_layer_bwd_join": ("i", "p"),
     "t4r_xlnet_ff_planes_floats": ("l", "i"),
-    "t4r_xlnet_ff_prepare": ("i", "pppip"),
+    "t4r_xlnet_ff_prepare": ("i", "ppppip"),
     "t4r_xlnet_ff_fwd": ("i", "p" + "pppppp" + "pppppp" + "iiff" + "QQQ"),
     "t4r_xlnet_ff_bwd": ("i", "p" + "pppppppp" + "pppppppp" + "iif" + "QQQ"),
     "t4r_xlnet_layer_ws_floats": ("l", "iiiii"),

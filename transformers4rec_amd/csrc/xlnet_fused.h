@@ -64,23 +64,33 @@ __host__ __device__ inline LayerPlanes carve_planes(const void* base, int D) {
     p.W2Tp = b;
     return p;
 }
-// Two-way fp16 planes (x s = hi + lo, see csrc/head_split.hip: mfma_split) of the matrices whose products have moved to
-// that form, after the bf16 planes: QKVTh [2][3D][D], RTh [2][D][D] (same orientation as QKVT / RT), then the power-of-two
-// scale of every such matrix (one float each: q, k, v, r), i.e. max |W| s in [2^13, 2^14).
+// Two-way fp16 planes (x s = hi + lo, see csrc/head_split.hip: mfma_split): the same nine plane matrices once more, two
+// planes each, every SOURCE matrix positioned by its own power-of-two scale (max |W| s in [2^13, 2^14)), then 16 floats:
+//   scale[HS_Q, HS_K, HS_V, HS_R, HS_O, HS_W1, HS_W2] of the seven sources (both orientations of a source share it),
+//   scale[HS_B1] = max |b1| (not a scale: with max |W1| = 2^14 / scale[HS_W1] rounded up it bounds |pre| per token).
 struct LayerPlanesH {
-    const uint16_t *QKVT, *RT;
-    const float* scale;       // [4]: q, k, v, r
+    const uint16_t *QKVT, *RT, *ON, *OT, *QKVN, *W1p, *W2p, *W1Tp, *W2Tp;
+    const float* scale;
 };
+enum { HS_Q = 0, HS_K = 1, HS_V = 2, HS_R = 3, HS_O = 4, HS_W1 = 5, HS_W2 = 6, HS_B1 = 7 };
 static inline long layer_planes_bf16_floats(int D) { return 25L * 3 * D * D / 2; }
 __host__ __device__ inline LayerPlanesH carve_planes_h(const void* base, int D) {
     const uint16_t* b = (const uint16_t*)((const float*)base + 25L * 3 * D * D / 2);
+    const long dd = 2L * D * D;
     LayerPlanesH p;
-    p.QKVT = b; b += 2L * 3 * D * D;
-    p.RT = b; b += 2L * D * D;
+    p.QKVT = b; b += 3 * dd;
+    p.RT = b; b += dd;
+    p.ON = b; b += dd;
+    p.OT = b; b += dd;
+    p.QKVN = b; b += 3 * dd;
+    p.W1p = b; b += 4 * dd;
+    p.W2p = b; b += 4 * dd;
+    p.W1Tp = b; b += 4 * dd;
+    p.W2Tp = b; b += 4 * dd;
     p.scale = (const float*)b;
     return p;
 }
-static inline long layer_planes_floats(int D) { return layer_planes_bf16_floats(D) + (2L * 4 * D * D) / 2 + 16; }
+static inline long layer_planes_floats(int D) { return layer_planes_bf16_floats(D) + 25L * 2 * D * D / 2 + 16; }
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));

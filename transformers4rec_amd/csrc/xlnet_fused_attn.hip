@@ -20,65 +20,74 @@
 // ---------------------------------------------------------------------------------------------- weight planes of a layer
 struct PlaneJob {
     const float* src;      // [rows][cols] fp32
-    uint16_t* dst;         // plane 0 of the destination matrix [3][drows][dcols]
-    int rows, cols;        // source shape
-    int dcols;             // destination row pitch
-    long dplane;           // destination plane stride
-    int r0, c0;            // destination offset of this source
-    int transpose;         // dst[r0 + c][c0 + r] = src[r][c]  instead of  dst[r0 + r][c0 + c]
-    long pair0;            // first pair index of this job in the launch
+    uint16_t* dst;         // plane 0 of the bf16 destination matrix [3][drows][dcols]
+    uint16_t* dst_h;       // plane 0 of the fp16 destination [2][drows][dcols] (may be null)
+    const float* scale;    // the source's power-of-two scale (device; fp16 planes)
+    int pair0;             // first pair index of this job in the launch
+    int dplane;            // destination plane stride (elements), both forms
+    short rows, cols;      // source shape
+    short dcols;           // destination row pitch
+    short r0, c0;          // destination offset of this source
+    short transpose;       // dst[r0 + c][c0 + r] = src[r][c]  instead of  dst[r0 + r][c0 + c]
 };
-#define T4R_MAX_PLANE_JOBS 52        /* four layers x 13 matrices: 3.3 KB of kernel arguments */
-struct PlaneJobs { PlaneJob j[T4R_MAX_PLANE_JOBS]; int n; long total; };
+#define T4R_MAX_PLANE_JOBS 52        /* four layers x 13 matrices: 2.9 KB of kernel arguments */
+struct PlaneJobs { PlaneJob j[T4R_MAX_PLANE_JOBS]; int n; int total; };
 
 __global__ __launch_bounds__(256) void layer_planes_kernel(PlaneJobs jobs) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= jobs.total) return;
     int k = 0;
 #pragma unroll 1
     for (int q = 1; q < jobs.n; ++q) k = i >= jobs.j[q].pair0 ? q : k;
     const PlaneJob& jb = jobs.j[k];
-    const long li = i - jb.pair0;
-    const int r = (int)(li / (jb.cols / 2)), c = (int)(li % (jb.cols / 2)) * 2;
+    const int li = i - jb.pair0;
+    const int r = li / (jb.cols / 2), c = (li % (jb.cols / 2)) * 2;
     const float2 v = *reinterpret_cast<const float2*>(jb.src + (long)r * jb.cols + c);
-    uint32_t w[3];
+    uint32_t w[3], wh[2] = {0u, 0u};
     cut3(v.x, v.y, w);
+    if (jb.dst_h) {
+        const float sc = *jb.scale;
+        cut2h(v.x * sc, v.y * sc, wh);
+    }
+    const long o_n = (long)(jb.r0 + r) * jb.dcols + jb.c0 + c;
+    const long o_t0 = (long)(jb.r0 + c) * jb.dcols + jb.c0 + r, o_t1 = o_t0 + jb.dcols;
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
-        uint16_t* d = jb.dst + pl * jb.dplane;
+        uint16_t* d = jb.dst + (long)pl * jb.dplane;
         if (!jb.transpose) {
-            *reinterpret_cast<uint32_t*>(d + (long)(jb.r0 + r) * jb.dcols + jb.c0 + c) = w[pl];
+            *reinterpret_cast<uint32_t*>(d + o_n) = w[pl];
         } else {
-            d[(long)(jb.r0 + c) * jb.dcols + jb.c0 + r] = (uint16_t)(w[pl] & 0xffffu);
-            d[(long)(jb.r0 + c + 1) * jb.dcols + jb.c0 + r] = (uint16_t)(w[pl] >> 16);
+            d[o_t0] = (uint16_t)(w[pl] & 0xffffu);
+            d[o_t1] = (uint16_t)(w[pl] >> 16);
+        }
+    }
+    if (jb.dst_h) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            uint16_t* d = jb.dst_h + (long)pl * jb.dplane;
+            if (!jb.transpose) {
+                *reinterpret_cast<uint32_t*>(d + o_n) = wh[pl];
+            } else {
+                d[o_t0] = (uint16_t)(wh[pl] & 0xffffu);
+                d[o_t1] = (uint16_t)(wh[pl] >> 16);
+            }
         }
     }
 }
 
-extern "C" long t4r_xlnet_layer_planes_floats(int D) { return layer_planes_floats(D); }
-
-static void add_job(PlaneJobs& js, const float* src, int rows, int cols, const uint16_t* dst, int drows, int dcols, int r0,
-                    int c0, int transpose) {
-    PlaneJob& j = js.j[js.n++];
-    j.src = src; j.dst = const_cast<uint16_t*>(dst); j.rows = rows; j.cols = cols; j.dcols = dcols;
-    j.dplane = (long)drows * dcols; j.r0 = r0; j.c0 = c0; j.transpose = transpose; j.pair0 = js.total;
-    js.total += (long)rows * cols / 2;
-}
-
-// params: host array of the layer's 15 device pointers in the order of t4r_xlnet_layer_fwd (q, k, v, o, r, ..., W1 at 9,
-// W2 at 11); any of the attention weights may be NULL (feed-forward planes only: t4r_xlnet_ff_prepare)
-// ---- two-way fp16 planes of the square matrices of the projections (q, k, v, r): one workgroup per matrix finds max |W|,
-// derives the power-of-two scale, cuts.  dst[o][k] = src[k][o] (the MFMA A fragment wants consecutive k of one output row).
-struct HJob { const float* src; uint16_t* dst; long dplane; int r0; float* scale; };
-#define T4R_MAX_HJOBS 16
-struct HJobs { HJob j[T4R_MAX_HJOBS]; int n; int D; };
-__global__ __launch_bounds__(1024) void weight_planes_h_kernel(HJobs jobs) {
+// max |src| of every source matrix -> its power-of-two scale (one workgroup per source: 16-64 k elements, one coalesced
+// pass); a source with `raw` set stores the maximum itself (the bias vector b1)
+struct AmaxJob { const float* src; float* out; int n; int raw; };
+#define T4R_MAX_AMAX_JOBS 32
+struct AmaxJobs { AmaxJob j[T4R_MAX_AMAX_JOBS]; int n; };
+__global__ __launch_bounds__(1024) void weight_scales_kernel(AmaxJobs jobs) {
     __shared__ float red[16];
-    __shared__ float sh_scale;
-    const HJob jb = jobs.j[blockIdx.x];
-    const int D = jobs.D, n = D * D;
+    const AmaxJob jb = jobs.j[blockIdx.x];
     float m = 0.f;
-    for (int i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(jb.src[i]));
+    for (int i = threadIdx.x * 4; i < jb.n; i += 4096) {
+        const float4 v = *reinterpret_cast<const float4*>(jb.src + i);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
@@ -86,61 +95,63 @@ __global__ __launch_bounds__(1024) void weight_planes_h_kernel(HJobs jobs) {
     if (threadIdx.x == 0) {
         float mm = red[0];
         for (int w = 1; w < 16; ++w) mm = fmaxf(mm, red[w]);
-        const float sc = pow2_scale(mm);
-        sh_scale = sc;
-        *jb.scale = sc;
+        *jb.out = jb.raw ? mm : pow2_scale(mm);
     }
-    __syncthreads();
-    const float sc = sh_scale;
-    for (int i = threadIdx.x; i < n / 2; i += 1024) {          // pairs (k, k + 1) of one output row o: src[k][o], src[k + 1][o]
-        const int o = i / (D / 2), k = (i % (D / 2)) * 2;
-        uint32_t w[2];
-        cut2h(jb.src[(long)k * D + o] * sc, jb.src[(long)(k + 1) * D + o] * sc, w);
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-            *reinterpret_cast<uint32_t*>(jb.dst + pl * jb.dplane + (long)(jb.r0 + o) * D + k) = w[pl];
-    }
-}
-static void add_layer_hjobs(HJobs& js, const float* q, const float* k, const float* v, const float* r, int D, float* planes) {
-    const LayerPlanesH P = carve_planes_h(planes, D);
-    const float* z[3] = {q, k, v};
-    float* sc = const_cast<float*>(P.scale);
-    for (int i = 0; i < 3; ++i)
-        if (z[i]) js.j[js.n++] = HJob{z[i], const_cast<uint16_t*>(P.QKVT), 3L * D * D, i * D, sc + i};
-    if (r) js.j[js.n++] = HJob{r, const_cast<uint16_t*>(P.RT), (long)D * D, 0, sc + 3};
-}
-static int launch_hjobs(hipStream_t st, const HJobs& js) {
-    if (js.n == 0) return 0;
-    hipLaunchKernelGGL(weight_planes_h_kernel, dim3(js.n), dim3(1024), 0, st, js);
-    T4R_LAUNCH_CHECK();
-    return 0;
 }
 
-static void add_layer_jobs(PlaneJobs& js, const float* q, const float* k, const float* v, const float* o, const float* r,
-                           const float* W1, const float* W2, int D, float* planes) {
+extern "C" long t4r_xlnet_layer_planes_floats(int D) { return layer_planes_floats(D); }
+
+static void add_job(PlaneJobs& js, const float* src, int rows, int cols, const uint16_t* dst, const uint16_t* dst_h,
+                    const float* scale, int drows, int dcols, int r0, int c0, int transpose) {
+    PlaneJob& j = js.j[js.n++];
+    j.src = src; j.dst = const_cast<uint16_t*>(dst); j.dst_h = const_cast<uint16_t*>(dst_h); j.scale = scale;
+    j.rows = (short)rows; j.cols = (short)cols; j.dcols = (short)dcols; j.dplane = drows * dcols;
+    j.r0 = (short)r0; j.c0 = (short)c0; j.transpose = (short)transpose; j.pair0 = js.total;
+    js.total += rows * cols / 2;
+}
+static void add_amax(AmaxJobs& aj, const float* src, int n, const float* out, int raw) {
+    aj.j[aj.n++] = AmaxJob{src, const_cast<float*>(out), n, raw};
+}
+
+// params: host array of the layer's 15 device pointers in the order of t4r_xlnet_layer_fwd (q, k, v, o, r, ..., W1 at 9,
+// b1 at 10, W2 at 11); any of the attention weights may be NULL (feed-forward planes only: t4r_xlnet_ff_prepare).
+// Every matrix gets its three bf16 planes and its two fp16 planes (scale of the source from the scales launch before).
+static void add_layer_jobs(PlaneJobs& js, AmaxJobs& aj, const float* q, const float* k, const float* v, const float* o,
+                           const float* r, const float* W1, const float* b1, const float* W2, int D, float* planes) {
     const LayerPlanes P = carve_planes(planes, D);
+    const LayerPlanesH H = carve_planes_h(planes, D);
+    const float* sc = H.scale;
     const float* z[3] = {q, k, v};
     for (int i = 0; i < 3; ++i) {
         if (!z[i]) continue;
-        add_job(js, z[i], D, D, P.QKVT, 3 * D, D, i * D, 0, 1);
-        add_job(js, z[i], D, D, P.QKVN, D, 3 * D, 0, i * D, 0);
+        add_amax(aj, z[i], D * D, sc + HS_Q + i, 0);
+        add_job(js, z[i], D, D, P.QKVT, H.QKVT, sc + HS_Q + i, 3 * D, D, i * D, 0, 1);
+        add_job(js, z[i], D, D, P.QKVN, H.QKVN, sc + HS_Q + i, D, 3 * D, 0, i * D, 0);
     }
-    if (r) add_job(js, r, D, D, P.RT, D, D, 0, 0, 1);
+    if (r) {
+        add_amax(aj, r, D * D, sc + HS_R, 0);
+        add_job(js, r, D, D, P.RT, H.RT, sc + HS_R, D, D, 0, 0, 1);
+    }
     if (o) {
-        add_job(js, o, D, D, P.ON, D, D, 0, 0, 0);
-        add_job(js, o, D, D, P.OT, D, D, 0, 0, 1);
+        add_amax(aj, o, D * D, sc + HS_O, 0);
+        add_job(js, o, D, D, P.ON, H.ON, sc + HS_O, D, D, 0, 0, 0);
+        add_job(js, o, D, D, P.OT, H.OT, sc + HS_O, D, D, 0, 0, 1);
     }
     if (W1) {
-        add_job(js, W1, 4 * D, D, P.W1p, 4 * D, D, 0, 0, 0);
-        add_job(js, W1, 4 * D, D, P.W1Tp, D, 4 * D, 0, 0, 1);
+        add_amax(aj, W1, 4 * D * D, sc + HS_W1, 0);
+        add_job(js, W1, 4 * D, D, P.W1p, H.W1p, sc + HS_W1, 4 * D, D, 0, 0, 0);
+        add_job(js, W1, 4 * D, D, P.W1Tp, H.W1Tp, sc + HS_W1, D, 4 * D, 0, 0, 1);
     }
     if (W2) {
-        add_job(js, W2, D, 4 * D, P.W2p, D, 4 * D, 0, 0, 0);
-        add_job(js, W2, D, 4 * D, P.W2Tp, 4 * D, D, 0, 0, 1);
+        add_amax(aj, W2, 4 * D * D, sc + HS_W2, 0);
+        add_job(js, W2, D, 4 * D, P.W2p, H.W2p, sc + HS_W2, D, 4 * D, 0, 0, 0);
+        add_job(js, W2, D, 4 * D, P.W2Tp, H.W2Tp, sc + HS_W2, 4 * D, D, 0, 0, 1);
     }
+    if (b1) add_amax(aj, b1, 4 * D, sc + HS_B1, 1);
 }
-static int launch_jobs(hipStream_t st, const PlaneJobs& js) {
+static int launch_jobs(hipStream_t st, const PlaneJobs& js, const AmaxJobs& aj) {
     if (js.total == 0) return 0;
+    if (aj.n > 0) hipLaunchKernelGGL(weight_scales_kernel, dim3(aj.n), dim3(1024), 0, st, aj);
     hipLaunchKernelGGL(layer_planes_kernel, dim3((unsigned)((js.total + 255) / 256)), dim3(256), 0, st, js);
     T4R_LAUNCH_CHECK();
     return 0;
@@ -148,15 +159,12 @@ static int launch_jobs(hipStream_t st, const PlaneJobs& js) {
 // params: host array of the layer's 15 device pointers in the order of t4r_xlnet_layer_fwd (q, k, v, o, r, ..., W1 at 9,
 // W2 at 11); any of the attention weights may be NULL (feed-forward planes only: t4r_xlnet_ff_prepare)
 static int prepare_launch(hipStream_t st, const float* q, const float* k, const float* v, const float* o, const float* r,
-                          const float* W1, const float* W2, int D, float* planes) {
+                          const float* W1, const float* b1, const float* W2, int D, float* planes) {
     PlaneJobs js;
-    js.n = 0; js.total = 0;
-    add_layer_jobs(js, q, k, v, o, r, W1, W2, D, planes);
-    if (launch_jobs(st, js)) return -1;
-    HJobs hj;
-    hj.n = 0; hj.D = D;
-    add_layer_hjobs(hj, q, k, v, r, D, planes);
-    return launch_hjobs(st, hj);
+    AmaxJobs aj;
+    js.n = 0; js.total = 0; aj.n = 0;
+    add_layer_jobs(js, aj, q, k, v, o, r, W1, b1, W2, D, planes);
+    return launch_jobs(st, js, aj);
 }
 
 extern "C" int t4r_xlnet_fused_supported(int D);
@@ -166,14 +174,14 @@ extern "C" int t4r_xlnet_fused_supported(int D);
 extern "C" int t4r_xlnet_layer_prepare(void* stream, const float* const* params, int D, float* planes) {
     T4R_CHECK_ARG(t4r_xlnet_fused_supported(D), "xlnet_layer_prepare: d_model must be 32, 64 or 128");
     T4R_CHECK_ARG(params && planes, "xlnet_layer_prepare: null pointer");
-    return prepare_launch((hipStream_t)stream, params[0], params[1], params[2], params[3], params[4], params[9], params[11], D,
-                          planes);
+    return prepare_launch((hipStream_t)stream, params[0], params[1], params[2], params[3], params[4], params[9], params[10],
+                          params[11], D, planes);
 }
 // the feed-forward planes only (stand-alone use of t4r_xlnet_ff_fwd / _bwd); same buffer layout and size
-extern "C" int t4r_xlnet_ff_prepare(void* stream, const float* W1, const float* W2, int D, float* planes) {
+extern "C" int t4r_xlnet_ff_prepare(void* stream, const float* W1, const float* b1, const float* W2, int D, float* planes) {
     T4R_CHECK_ARG(t4r_xlnet_fused_supported(D), "xlnet_ff_prepare: d_model must be 32, 64 or 128");
-    T4R_CHECK_ARG(W1 && W2 && planes, "xlnet_ff_prepare: null pointer");
-    return prepare_launch((hipStream_t)stream, nullptr, nullptr, nullptr, nullptr, nullptr, W1, W2, D, planes);
+    T4R_CHECK_ARG(W1 && b1 && W2 && planes, "xlnet_ff_prepare: null pointer");
+    return prepare_launch((hipStream_t)stream, nullptr, nullptr, nullptr, nullptr, nullptr, W1, b1, W2, D, planes);
 }
 extern "C" long t4r_xlnet_ff_planes_floats(int D) { return layer_planes_floats(D); }
 
@@ -236,7 +244,7 @@ struct ProjParams {
 };
 
 // HS: the two-way fp16 form (three matrix instructions per k-step instead of six; per-token and per-matrix power-of-two
-// scales, see tile_to_planes_h / weight_planes_h_kernel)
+// scales, see tile_to_planes_h / weight_scales_kernel)
 template <int D, int R, int NM, bool HS = false>
 __global__ __launch_bounds__(D * 4) void xlnet_proj_kernel(ProjParams p) {
     constexpr int NW = D / 16, NT = NW * 64, RT = 16 * R, PH = D + 16, PLN = RT * PH;
@@ -276,27 +284,43 @@ __global__ __launch_bounds__(D * 4) void xlnet_proj_kernel(ProjParams p) {
 // ---------------------------------------------------------------------------------------------- o-projection + LayerNorm
 struct OProjParams {
     const float *av, *h, *gamma, *beta;    // attn_vec [T, D], layer input h [T, D] (residual), LayerNorm parameters
-    const uint16_t* planes;                // ON planes [D][D]
+    const uint16_t* planes;                // ON planes [D][D] (three bf16 planes, or the two fp16 planes with *wscale)
+    const float* wscale;
     float *ao, *mean, *rstd, *h1;          // saved o-projection output (pre dropout), statistics (all NULL: inference), out
     long T;
     float eps;
     DropCfg drop;
 };
 
-template <int D, int R, bool TRAIN>
+template <int D, int R, bool TRAIN, bool HS>
 __device__ __forceinline__ void oproj_body(const OProjParams& p, uint16_t* smem16) {
     constexpr int NW = D / 16, NT = NW * 64, RT = 16 * R, PH = D + 16, PLN = RT * PH;
     float* sh_red = reinterpret_cast<float*>(smem16 + 3 * PLN);      // [2][NW][RT]
+    float* sh_inv = reinterpret_cast<float*>(smem16 + 2 * PLN);      // HS: [RT] inverse token scales (in the unused third plane)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, g = lane >> 4;
     const long t0 = (long)blockIdx.x * RT;
-    tile_to_planes<D, RT, NT, PH>(p.av, t0, p.T, smem16, tid);
-    AFrag<D> a;
-    load_a3<D>(a, p.planes + (long)(16 * w + n) * D + 8 * g, (long)D * D);
-    __syncthreads();
     f32x4 acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = zero4();
-    product3<D, R, PH>(a, smem16 + n * PH + 8 * g, PLN, acc);
+    if constexpr (HS) {
+        tile_to_planes_h<D, RT, NT, PH>(p.av, t0, p.T, smem16, sh_inv, tid);
+        AFragH<D> a;
+        load_a2h<D>(a, p.planes + (long)(16 * w + n) * D + 8 * g, (long)D * D);
+        __syncthreads();
+        product3h<D, R, PH>(a, smem16 + n * PH + 8 * g, PLN, acc);
+        const float iw = 1.f / *p.wscale;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float sc = sh_inv[r * 16 + n] * iw;
+            acc[r][0] *= sc; acc[r][1] *= sc; acc[r][2] *= sc; acc[r][3] *= sc;
+        }
+    } else {
+        tile_to_planes<D, RT, NT, PH>(p.av, t0, p.T, smem16, tid);
+        AFrag<D> a;
+        load_a3<D>(a, p.planes + (long)(16 * w + n) * D + 8 * g, (long)D * D);
+        __syncthreads();
+        product3<D, R, PH>(a, smem16 + n * PH + 8 * g, PLN, acc);
+    }
     const int f0 = 16 * w + 4 * g;
     const float4 gam = ld4(p.gamma + f0), bet = ld4(p.beta + f0);
     float4 x[R];
@@ -357,33 +381,37 @@ __device__ __forceinline__ void oproj_body(const OProjParams& p, uint16_t* smem1
         }
     }
 }
-template <int D, int R>
+template <int D, int R, bool HS = false>
 __global__ __launch_bounds__(D * 4) void xlnet_oproj_ln_kernel(OProjParams p) {
     extern __shared__ uint16_t smem16[];
-    if (p.ao != nullptr) oproj_body<D, R, true>(p, smem16);
-    else oproj_body<D, R, false>(p, smem16);
+    if (p.ao != nullptr) oproj_body<D, R, true, HS>(p, smem16);
+    else oproj_body<D, R, false, HS>(p, smem16);
 }
 
 // ---------------------------------------------------------------------------------------------- LayerNorm 1 backward + d attn_vec
 struct Ln1BwdParams {
     const float *dy, *ao, *h, *mean, *rstd, *gamma;     // d loss / d h1; o-projection output (pre dropout); layer input; stats
-    const uint16_t* planes;                             // OT planes [D][D]
+    const uint16_t* planes;                             // OT planes [D][D] (bf16 x 3, or fp16 x 2 with *wscale)
+    const float* wscale;
     float *dh, *dao, *dav;                              // [T, D] each, overwritten: residual part of d h, d attn_out, d attn_vec
     float* part;                                        // [nWG][2 D] partial sums (d gamma | d beta)
     long T;
     DropCfg drop;
 };
 
-template <int D, int R>
+template <int D, int R, bool HS = false>
 __global__ __launch_bounds__(D * 4) void xlnet_ln1_bwd_kernel(Ln1BwdParams p) {
     constexpr int NW = D / 16, RT = 16 * R, PH = D + 16, PLN = RT * PH;
     extern __shared__ uint16_t smem16[];
     uint16_t* sh_d = smem16;                                         // [3][RT][PH] d attn_out planes
     float* sh_part = reinterpret_cast<float*>(sh_d + 3 * PLN);       // [NW][2][D]
+    float* sh_inv = reinterpret_cast<float*>(sh_d + 2 * PLN);        // HS: [RT] inverse row scales
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, g = lane >> 4;
     const long t0 = (long)blockIdx.x * RT;
     AFrag<D> a;
-    load_a3<D>(a, p.planes + (long)(16 * w + n) * D + 8 * g, (long)D * D);
+    AFragH<D> ah;
+    if constexpr (HS) load_a2h<D>(ah, p.planes + (long)(16 * w + n) * D + 8 * g, (long)D * D);
+    else load_a3<D>(a, p.planes + (long)(16 * w + n) * D + 8 * g, (long)D * D);
     {
         const int c0 = lane * 2;
         const bool act_lane = c0 < D;
@@ -426,7 +454,19 @@ __global__ __launch_bounds__(D * 4) void xlnet_ln1_bwd_kernel(Ln1BwdParams p) {
                     *reinterpret_cast<float2*>(p.dao + t * D + c0) = make_float2(dxa[0], dxa[1]);
                 }
             }
-            if (act_lane) {
+            if constexpr (HS) {      // the gradient row positioned by its own power-of-two scale (wave-uniform)
+                float m = fmaxf(fabsf(dxa[0]), fabsf(dxa[1]));
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+                const float sc = pow2_scale(m);
+                if (act_lane) {
+                    uint32_t wd[2];
+                    cut2h(dxa[0] * sc, dxa[1] * sc, wd);
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) *reinterpret_cast<uint32_t*>(sh_d + pl * PLN + row * PH + c0) = wd[pl];
+                }
+                if (lane == 0) sh_inv[row] = 1.f / sc;
+            } else if (act_lane) {
                 uint32_t wd[3];
                 cut3(dxa[0], dxa[1], wd);
 #pragma unroll
@@ -452,27 +492,31 @@ __global__ __launch_bounds__(D * 4) void xlnet_ln1_bwd_kernel(Ln1BwdParams p) {
     f32x4 acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = zero4();
-    product3<D, R, PH>(a, sh_d + n * PH + 8 * g, PLN, acc);
+    if constexpr (HS) product3h<D, R, PH>(ah, sh_d + n * PH + 8 * g, PLN, acc);
+    else product3<D, R, PH>(a, sh_d + n * PH + 8 * g, PLN, acc);
+    const float iw = HS ? 1.f / *p.wscale : 1.f;
     const int f0 = 16 * w + 4 * g;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const long t = t0 + r * 16 + n;
-        if (t < p.T) st4(p.dav + t * D + f0, make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]));
+        const float sc = HS ? sh_inv[r * 16 + n] * iw : 1.f;
+        if (t < p.T) st4(p.dav + t * D + f0, make_float4(acc[r][0] * sc, acc[r][1] * sc, acc[r][2] * sc, acc[r][3] * sc));
     }
 }
 
 // ---------------------------------------------------------------------------------------------- d h from d q, d k, d v
 struct DhParams {
     const float* dqkv;        // [3][T][D]
-    const uint16_t* planes;   // QKVN planes [D][3 D]
+    const uint16_t* planes;   // QKVN planes [D][3 D] (bf16 x 3, or fp16 x 2 with wscale[0..2])
+    const float* wscale;
     float* dh;                // [T, D], ACCUMULATED into (holds the LayerNorm-backward residual part)
     long T;
 };
 
-template <int D, int R>
+template <int D, int R, bool HS = false>
 __global__ __launch_bounds__(D * 4) void xlnet_dh_kernel(DhParams p) {
     constexpr int NW = D / 16, NT = NW * 64, RT = 16 * R, PH = D + 16, PLN = RT * PH;
-    extern __shared__ uint16_t smem16[];     // [2][3][RT][PH]
+    extern __shared__ uint16_t smem16[];     // [2][3][RT][PH] (HS: two planes + [RT] inverse token scales per buffer)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, g = lane >> 4;
     const long t0 = (long)blockIdx.x * RT;
     const long TD = p.T * D;
@@ -481,15 +525,37 @@ __global__ __launch_bounds__(D * 4) void xlnet_dh_kernel(DhParams p) {
     f32x4 acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = zero4();
-    tile_to_planes<D, RT, NT, PH>(p.dqkv, t0, p.T, smem16, tid);
+    auto inv_of = [&](int buf) { return reinterpret_cast<float*>(smem16 + buf * 3 * PLN + 2 * PLN); };
+    if constexpr (HS) tile_to_planes_h<D, RT, NT, PH>(p.dqkv, t0, p.T, smem16, inv_of(0), tid);
+    else tile_to_planes<D, RT, NT, PH>(p.dqkv, t0, p.T, smem16, tid);
     __syncthreads();
 #pragma unroll
     for (int z = 0; z < 3; ++z) {
-        AFrag<D> a;
-        load_a3<D>(a, wp + z * D, wpl);
         uint16_t* cur = smem16 + (z & 1) * 3 * PLN;
-        if (z < 2) tile_to_planes<D, RT, NT, PH>(p.dqkv + (z + 1) * TD, t0, p.T, smem16 + ((z + 1) & 1) * 3 * PLN, tid);
-        product3<D, R, PH>(a, cur + n * PH + 8 * g, PLN, acc);
+        if constexpr (HS) {
+            // every gradient tile carries its own token scales and every weight block its own scale: the three products
+            // are scaled back one by one before they are added
+            AFragH<D> a;
+            load_a2h<D>(a, wp + z * D, wpl);
+            if (z < 2) tile_to_planes_h<D, RT, NT, PH>(p.dqkv + (z + 1) * TD, t0, p.T, smem16 + ((z + 1) & 1) * 3 * PLN,
+                                                       inv_of((z + 1) & 1), tid);
+            f32x4 part[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) part[r] = zero4();
+            product3h<D, R, PH>(a, cur + n * PH + 8 * g, PLN, part);
+            const float iw = 1.f / p.wscale[z];
+            const float* inv = inv_of(z & 1);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float sc = inv[r * 16 + n] * iw;
+                acc[r][0] += part[r][0] * sc; acc[r][1] += part[r][1] * sc; acc[r][2] += part[r][2] * sc; acc[r][3] += part[r][3] * sc;
+            }
+        } else {
+            AFrag<D> a;
+            load_a3<D>(a, wp + z * D, wpl);
+            if (z < 2) tile_to_planes<D, RT, NT, PH>(p.dqkv + (z + 1) * TD, t0, p.T, smem16 + ((z + 1) & 1) * 3 * PLN, tid);
+            product3<D, R, PH>(a, cur + n * PH + 8 * g, PLN, acc);
+        }
         if (z < 2) __syncthreads();
     }
     const int k0 = 16 * w + 4 * g;
@@ -543,7 +609,7 @@ extern "C" int t4r_xlnet_qkv_proj(void* stream, const float* h, const float* pla
     const LayerPlanesH PH_ = carve_planes_h(planes, D);
     const uint16_t* wq = hs ? PH_.QKVT : carve_planes(planes, D).QKVT;
     ProjParams p{h, {wq, wq + (long)D * D, wq + 2L * D * D, nullptr}, 3L * D * D, {qkv, qkv + T * D, qkv + 2 * T * D, nullptr}, T,
-                 {PH_.scale, PH_.scale + 1, PH_.scale + 2, nullptr}};
+                 {PH_.scale + HS_Q, PH_.scale + HS_K, PH_.scale + HS_V, nullptr}};
     hipStream_t st = (hipStream_t)stream;
 #define CALL(DD, RR)                                                                                             \
     {                                                                                                            \
@@ -570,7 +636,7 @@ extern "C" int t4r_xlnet_kr_proj(void* stream, const float* pos, const float* pl
     const bool hs = body_fp16x2();
     const LayerPlanesH PH_ = carve_planes_h(planes, D);
     ProjParams p{pos, {hs ? PH_.RT : carve_planes(planes, D).RT, nullptr, nullptr, nullptr}, (long)D * D, {kr, nullptr, nullptr, nullptr}, rows,
-                 {PH_.scale + 3, nullptr, nullptr, nullptr}};
+                 {PH_.scale + HS_R, nullptr, nullptr, nullptr}};
     hipStream_t st = (hipStream_t)stream;
 #define CALL(DD, RR)                                                                                             \
     {                                                                                                            \
@@ -600,22 +666,15 @@ extern "C" int t4r_xlnet_stack_prepare(void* stream, const float* const* params_
     for (int l0 = 0; l0 < n_layers; l0 += 4) {
         const int nl = min(4, n_layers - l0);
         PlaneJobs js;
-        js.n = 0; js.total = 0;
+        AmaxJobs aj;
+        js.n = 0; js.total = 0; aj.n = 0;
         for (int l = l0; l < l0 + nl; ++l) {
             const float* const* pr = params_all + (long)l * 15;
-            T4R_CHECK_ARG(planes[l] && pr[0] && pr[1] && pr[2] && pr[3] && pr[4] && pr[9] && pr[11], "xlnet_stack_prepare: null pointer");
-            add_layer_jobs(js, pr[0], pr[1], pr[2], pr[3], pr[4], pr[9], pr[11], D, planes[l]);
+            T4R_CHECK_ARG(planes[l] && pr[0] && pr[1] && pr[2] && pr[3] && pr[4] && pr[9] && pr[10] && pr[11],
+                          "xlnet_stack_prepare: null pointer");
+            add_layer_jobs(js, aj, pr[0], pr[1], pr[2], pr[3], pr[4], pr[9], pr[10], pr[11], D, planes[l]);
         }
-        if (launch_jobs(st, js)) return -1;
-        {
-            HJobs hj;
-            hj.n = 0; hj.D = D;
-            for (int l = l0; l < l0 + nl; ++l) {
-                const float* const* pr = params_all + (long)l * 15;
-                add_layer_hjobs(hj, pr[0], pr[1], pr[2], pr[4], D, planes[l]);
-            }
-            if (launch_hjobs(st, hj)) return -1;
-        }
+        if (launch_jobs(st, js, aj)) return -1;
         if (!pos || pos_rows <= 0) continue;
         T4R_CHECK_ARG(kr, "xlnet_stack_prepare: null k_r pointers");
         const bool hs = body_fp16x2();
@@ -624,7 +683,7 @@ extern "C" int t4r_xlnet_stack_prepare(void* stream, const float* const* params_
         for (int m = 0; m < nl; ++m) {
             const LayerPlanesH PH_ = carve_planes_h(planes[l0 + m], D);
             p.w[m] = hs ? PH_.RT : carve_planes(planes[l0 + m], D).RT;
-            p.wscale[m] = PH_.scale + 3;
+            p.wscale[m] = PH_.scale + HS_R;
             p.out[m] = kr[l0 + m];
         }
         const int R = pick_r(pos_rows);
@@ -666,13 +725,22 @@ extern "C" int t4r_xlnet_oproj_ln(void* stream, const float* av, const float* h,
     T4R_CHECK_ARG((mean != nullptr) == train && (rstd != nullptr) == train, "xlnet_oproj_ln: ao, mean, rstd go together");
     T4R_CHECK_ARG(train || drop_p == 0.f, "xlnet_oproj_ln: dropout needs the saved activations");
     const int R = pick_r(T);
-    OProjParams p{av, h, gamma, beta, carve_planes(planes, D).ON, ao, mean, rstd, h1, T, eps, make_drop(drop_p, seed, ctr_hi)};
+    const bool hs = body_fp16x2();
+    const LayerPlanesH PH_ = carve_planes_h(planes, D);
+    OProjParams p{av, h, gamma, beta, hs ? PH_.ON : carve_planes(planes, D).ON, PH_.scale + HS_O, ao, mean, rstd, h1, T, eps,
+                  make_drop(drop_p, seed, ctr_hi)};
     hipStream_t st = (hipStream_t)stream;
 #define CALL(DD, RR)                                                                                             \
     {                                                                                                            \
         const size_t smem = (size_t)3 * 16 * RR * (DD + 16) * 2 + (size_t)2 * (DD / 16) * 16 * RR * 4;           \
-        { static bool once = false; if (!once) { set_smem(xlnet_oproj_ln_kernel<DD, RR>, smem); once = true; } }                                                           \
-        hipLaunchKernelGGL((xlnet_oproj_ln_kernel<DD, RR>), dim3((unsigned)((T + 16 * RR - 1) / (16 * RR))), dim3(DD * 4), smem, st, p); \
+        const dim3 grid((unsigned)((T + 16 * RR - 1) / (16 * RR)));                                              \
+        if (hs) {                                                                                                \
+            { static bool once = false; if (!once) { set_smem(xlnet_oproj_ln_kernel<DD, RR, true>, smem); once = true; } } \
+            hipLaunchKernelGGL((xlnet_oproj_ln_kernel<DD, RR, true>), grid, dim3(DD * 4), smem, st, p);          \
+        } else {                                                                                                 \
+            { static bool once = false; if (!once) { set_smem(xlnet_oproj_ln_kernel<DD, RR>, smem); once = true; } } \
+            hipLaunchKernelGGL((xlnet_oproj_ln_kernel<DD, RR>), grid, dim3(DD * 4), smem, st, p);                \
+        }                                                                                                        \
     }
     ATTN_DISPATCH(CALL, D, R)
 #undef CALL
@@ -694,13 +762,21 @@ extern "C" int t4r_xlnet_ln1_bwd(void* stream, const float* dy, const float* ao,
                   "xlnet_ln1_bwd: bad arguments");
     const int R = pick_r(T);
     const int nwg = (int)((T + 16 * R - 1) / (16 * R));
-    Ln1BwdParams p{dy, ao, h, mean, rstd, gamma, carve_planes(planes, D).OT, dh, dao, dav, part, T, make_drop(drop_p, seed, ctr_hi)};
+    const bool hs = body_fp16x2();
+    const LayerPlanesH PH_ = carve_planes_h(planes, D);
+    Ln1BwdParams p{dy, ao, h, mean, rstd, gamma, hs ? PH_.OT : carve_planes(planes, D).OT, PH_.scale + HS_O, dh, dao, dav, part, T,
+                   make_drop(drop_p, seed, ctr_hi)};
     hipStream_t st = (hipStream_t)stream;
 #define CALL(DD, RR)                                                                                             \
     {                                                                                                            \
         const size_t smem = (size_t)3 * 16 * RR * (DD + 16) * 2 + (size_t)(DD / 16) * 2 * DD * 4;                \
-        { static bool once = false; if (!once) { set_smem(xlnet_ln1_bwd_kernel<DD, RR>, smem); once = true; } }                                                            \
-        hipLaunchKernelGGL((xlnet_ln1_bwd_kernel<DD, RR>), dim3((unsigned)nwg), dim3(DD * 4), smem, st, p);      \
+        if (hs) {                                                                                                \
+            { static bool once = false; if (!once) { set_smem(xlnet_ln1_bwd_kernel<DD, RR, true>, smem); once = true; } } \
+            hipLaunchKernelGGL((xlnet_ln1_bwd_kernel<DD, RR, true>), dim3((unsigned)nwg), dim3(DD * 4), smem, st, p); \
+        } else {                                                                                                 \
+            { static bool once = false; if (!once) { set_smem(xlnet_ln1_bwd_kernel<DD, RR>, smem); once = true; } } \
+            hipLaunchKernelGGL((xlnet_ln1_bwd_kernel<DD, RR>), dim3((unsigned)nwg), dim3(DD * 4), smem, st, p);  \
+        }                                                                                                        \
     }
     ATTN_DISPATCH(CALL, D, R)
 #undef CALL
@@ -713,13 +789,21 @@ extern "C" int t4r_xlnet_dh(void* stream, const float* dqkv, const float* planes
     if (T <= 0) return 0;
     T4R_CHECK_ARG(t4r_xlnet_fused_supported(D) && dqkv && planes && dh, "xlnet_dh: bad arguments");
     const int R = pick_r(T);
-    DhParams p{dqkv, carve_planes(planes, D).QKVN, dh, T};
+    const bool hs = body_fp16x2();
+    const LayerPlanesH PH_ = carve_planes_h(planes, D);
+    DhParams p{dqkv, hs ? PH_.QKVN : carve_planes(planes, D).QKVN, PH_.scale + HS_Q, dh, T};
     hipStream_t st = (hipStream_t)stream;
 #define CALL(DD, RR)                                                                                             \
     {                                                                                                            \
         const size_t smem = (size_t)2 * 3 * 16 * RR * (DD + 16) * 2;                                             \
-        { static bool once = false; if (!once) { set_smem(xlnet_dh_kernel<DD, RR>, smem); once = true; } }                                                                 \
-        hipLaunchKernelGGL((xlnet_dh_kernel<DD, RR>), dim3((unsigned)((T + 16 * RR - 1) / (16 * RR))), dim3(DD * 4), smem, st, p); \
+        const dim3 grid((unsigned)((T + 16 * RR - 1) / (16 * RR)));                                              \
+        if (hs) {                                                                                                \
+            { static bool once = false; if (!once) { set_smem(xlnet_dh_kernel<DD, RR, true>, smem); once = true; } } \
+            hipLaunchKernelGGL((xlnet_dh_kernel<DD, RR, true>), grid, dim3(DD * 4), smem, st, p);                \
+        } else {                                                                                                 \
+            { static bool once = false; if (!once) { set_smem(xlnet_dh_kernel<DD, RR>, smem); once = true; } }   \
+            hipLaunchKernelGGL((xlnet_dh_kernel<DD, RR>), grid, dim3(DD * 4), smem, st, p);                      \
+        }                                                                                                        \
     }
     ATTN_DISPATCH(CALL, D, R)
 #undef CALL

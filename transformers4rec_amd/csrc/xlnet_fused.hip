@@ -38,6 +38,7 @@
 struct FFFwdParams {
     const float *h1, *b1, *b2, *gamma, *beta;
     LayerPlanes w;
+    LayerPlanesH wh;       // HS: the two-way fp16 planes and their scales
     float *ffpre, *ffact, *ffout, *mean, *rstd, *hout;     // ffpre / ffact / ffout / mean / rstd: all given (training) or all NULL
     int T;
     float eps;
@@ -46,14 +47,51 @@ struct FFFwdParams {
 
 // FULL: every row of the tile is a token; TRAIN: the backward's activations are saved and the Philox masks evaluated
 // (p = 0 keeps everything); !TRAIN (inference: nothing saved, p = 0): neither.
-template <int D, int R, bool FULL, bool TRAIN>
+// HS: both products on the two-way fp16 split (three matrix instructions per k-step instead of six).  Token rows carry their
+// own power-of-two scale; the activation rows are positioned by a per-token BOUND known before the first chunk
+// (|gelu(x)| <= |x|, |pre[t][f]| <= D max|W1| max|h1[t]| + max|b1|, the dropout factor on top): one scale for all four
+// chunks of a token, as their products share an accumulator.  The bound is loose by one to two orders of magnitude, which
+// costs nothing: fp16 keeps its 11 + 11 bits over 2^17 of range below the bound.
+template <int D, int R, bool FULL, bool TRAIN, bool HS>
 __device__ __forceinline__ void ff_fwd_body(const FFFwdParams& p, uint16_t* smem) {
     constexpr int NW = D / 16, NT = NW * 64, RT = 16 * R, PH = D + 16, PLN = RT * PH, DI = 4 * D;
     uint16_t* sh_h = smem;                                   // [3][RT][PH] token planes
     uint16_t* sh_a = sh_h + 3 * PLN;                         // [3][RT][PH] activation-chunk planes
     float* sh_red = reinterpret_cast<float*>(sh_a + 3 * PLN);   // [2][NW][RT]
+    float* sh_inv_h = reinterpret_cast<float*>(sh_h + 2 * PLN);    // HS: [RT] inverse token scales (in the unused third plane)
+    float* sh_sa = reinterpret_cast<float*>(sh_a + 2 * PLN);       // HS: [RT] activation scales | [RT] their inverses
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, g = lane >> 4;
     const long t0 = (long)blockIdx.x * RT;
+    if constexpr (HS) {
+        const float w1max = 16384.f / p.wh.scale[HS_W1];    // >= max |W1| (the scale puts it into [2^13, 2^14))
+        const float b1max = p.wh.scale[HS_B1];
+        const float keep = TRAIN ? p.drop_act.inv_keep : 1.f;
+        constexpr int G = D / 4;
+        for (int i = tid; i < ((RT * G + NT - 1) / NT) * NT; i += NT) {
+            const bool live = i < RT * G;
+            const int row = live ? i / G : RT - 1, c4 = live ? (i % G) * 4 : 0;
+            const long t = FULL ? t0 + row : min(t0 + row, (long)p.T - 1);
+            const float4 v = ld4(p.h1 + t * D + c4);
+            float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+#pragma unroll
+            for (int o = G / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            const float sc = pow2_scale(m);
+            if (live) {
+                uint32_t w0[2], w1[2];
+                cut2h(v.x * sc, v.y * sc, w0);
+                cut2h(v.z * sc, v.w * sc, w1);
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    *reinterpret_cast<uint2*>(sh_h + pl * PLN + row * PH + c4) = make_uint2(w0[pl], w1[pl]);
+                if (c4 == 0) {
+                    sh_inv_h[row] = 1.f / sc;
+                    const float sa = pow2_scale(((float)D * w1max * m + b1max) * keep);
+                    sh_sa[row] = sa;
+                    sh_sa[RT + row] = 1.f / sa;
+                }
+            }
+        }
+    } else
     for (int i = tid; i < RT * (D / 4); i += NT) {
         const int row = i / (D / 4), c4 = (i % (D / 4)) * 4;
         const long t = FULL ? t0 + row : min(t0 + row, (long)p.T - 1);
@@ -71,15 +109,30 @@ __device__ __forceinline__ void ff_fwd_body(const FFFwdParams& p, uint16_t* smem
     for (int r = 0; r < R; ++r) acc2[r] = zero4();
     const int boff = n * PH + 8 * g;                          // this lane's B-fragment offset inside a token block
     const long wpl = (long)DI * D;                            // plane stride of every weight-plane matrix (4 D * D)
-    const uint16_t* w1p = p.w.W1p + (long)(16 * w + n) * D + 8 * g;       // + c D D: chunk c
-    const uint16_t* w2p = p.w.W2p + (long)(16 * w + n) * DI + 8 * g;      // + c D
+    const uint16_t* w1p = (HS ? p.wh.W1p : p.w.W1p) + (long)(16 * w + n) * D + 8 * g;       // + c D D: chunk c
+    const uint16_t* w2p = (HS ? p.wh.W2p : p.w.W2p) + (long)(16 * w + n) * DI + 8 * g;      // + c D
     AFrag<D> a1, a2;
-    load_a3<D>(a1, w1p, wpl);
+    AFragH<D> h1f, h2f;
+    float is1[R], is2[R];          // HS: what turns an accumulator of FF1 / FF2 back into values, per token block
+    if constexpr (HS) {
+        const float iw1 = 1.f / p.wh.scale[HS_W1], iw2 = 1.f / p.wh.scale[HS_W2];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { is1[r] = sh_inv_h[r * 16 + n] * iw1; is2[r] = sh_sa[RT + r * 16 + n] * iw2; }
+        load_a2h<D>(h1f, w1p, wpl);
+    } else {
+        load_a3<D>(a1, w1p, wpl);
+    }
 #pragma unroll 1
     for (int c = 0; c < 4; ++c) {
         f32x4 acc1[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) acc1[r] = zero4();
+        if constexpr (HS) {
+            product3h<D, R, PH>(h1f, sh_h + boff, PLN, acc1);
+            load_a2h<D>(h2f, w2p + c * D, wpl);
+#pragma unroll
+            for (int r = 0; r < R; ++r) { acc1[r][0] *= is1[r]; acc1[r][1] *= is1[r]; acc1[r][2] *= is1[r]; acc1[r][3] *= is1[r]; }
+        } else {
 #if T4R_FF_PREFETCH
         load_a3<D>(a2, w2p + c * D, wpl);                     // FF2's fragment: in flight under FF1 and the epilogue
         product3<D, R, PH>(a1, sh_h + boff, PLN, acc1);
@@ -88,6 +141,7 @@ __device__ __forceinline__ void ff_fwd_body(const FFFwdParams& p, uint16_t* smem
         product3<D, R, PH>(a1, sh_h + boff, PLN, acc1);
         load_a3<D>(a2, w2p + c * D, wpl);                     // in flight under the epilogue (a1 is dead: no extra registers)
 #endif
+        }
         // epilogue of chunk c: lane = (token r*16 + n, features d0 .. d0 + 3 of d_inner)
         const int d0 = c * D + 16 * w + 4 * g;
         const float4 bias = ld4(p.b1 + d0);
@@ -104,18 +158,37 @@ __device__ __forceinline__ void ff_fwd_body(const FFFwdParams& p, uint16_t* smem
                 v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
             }
             if (TRAIN && in) st4(p.ffact + t * DI + d0, v);
-            uint32_t w0[3], w1[3];
-            cut3(v.x, v.y, w0);
-            cut3(v.z, v.w, w1);
+            if constexpr (HS) {
+                const float sa = sh_sa[r * 16 + n];
+                uint32_t w0[2], w1[2];
+                cut2h(v.x * sa, v.y * sa, w0);
+                cut2h(v.z * sa, v.w * sa, w1);
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                *reinterpret_cast<uint2*>(sh_a + pl * PLN + (r * 16 + n) * PH + 16 * w + 4 * g) = make_uint2(w0[pl], w1[pl]);
+                for (int pl = 0; pl < 2; ++pl)
+                    *reinterpret_cast<uint2*>(sh_a + pl * PLN + (r * 16 + n) * PH + 16 * w + 4 * g) = make_uint2(w0[pl], w1[pl]);
+            } else {
+                uint32_t w0[3], w1[3];
+                cut3(v.x, v.y, w0);
+                cut3(v.z, v.w, w1);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    *reinterpret_cast<uint2*>(sh_a + pl * PLN + (r * 16 + n) * PH + 16 * w + 4 * g) = make_uint2(w0[pl], w1[pl]);
+            }
         }
         __syncthreads();
+        if constexpr (HS) {
+            if (c < 3) load_a2h<D>(h1f, w1p + (long)(c + 1) * D * D, wpl);
+            product3h<D, R, PH>(h2f, sh_a + boff, PLN, acc2);
+        } else {
 #if !T4R_FF_PREFETCH
         if (c < 3) load_a3<D>(a1, w1p + (long)(c + 1) * D * D, wpl);   // next chunk's FF1 fragment, in flight under FF2
 #endif
         product3<D, R, PH>(a2, sh_a + boff, PLN, acc2);
+        }
+    }
+    if constexpr (HS) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) { acc2[r][0] *= is2[r]; acc2[r][1] *= is2[r]; acc2[r][2] *= is2[r]; acc2[r][3] *= is2[r]; }
     }
     // epilogue 2: + b2, dropout, + residual, LayerNorm over the D features of a token (split over the NW waves)
     const int f0 = 16 * w + 4 * g;
@@ -179,17 +252,17 @@ __device__ __forceinline__ void ff_fwd_body(const FFFwdParams& p, uint16_t* smem
     }
 }
 
-template <int D, int R>
+template <int D, int R, bool HS = false>
 __global__ __launch_bounds__(D * 4) void xlnet_ff_fwd_kernel(FFFwdParams p) {
     extern __shared__ uint16_t smem16[];
     // whole tiles run the unpredicated body; only the last workgroup of a ragged launch pays for the row guards
     const bool full = (long)(blockIdx.x + 1) * 16 * R <= p.T;
     if (p.ffpre != nullptr) {
-        if (full) ff_fwd_body<D, R, true, true>(p, smem16);
-        else ff_fwd_body<D, R, false, true>(p, smem16);
+        if (full) ff_fwd_body<D, R, true, true, HS>(p, smem16);
+        else ff_fwd_body<D, R, false, true, HS>(p, smem16);
     } else {
-        if (full) ff_fwd_body<D, R, true, false>(p, smem16);
-        else ff_fwd_body<D, R, false, false>(p, smem16);
+        if (full) ff_fwd_body<D, R, true, false, HS>(p, smem16);
+        else ff_fwd_body<D, R, false, false, HS>(p, smem16);
     }
 }
 
@@ -348,6 +421,11 @@ __global__ __launch_bounds__(D * 4) void xlnet_ff_bwd_kernel(FFBwdParams p) {
 }
 
 // -------------------------------------------------------------------------------------------------- host side
+bool t4r_xlnet_body_fp16x2() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("T4R_XLNET_FP16X2"); on = e ? (atoi(e) != 0) : 1; }
+    return on != 0;
+}
 static int pick_r(long T) {
     // smallest tile (fewest padded rows) whose grid still fits one residency of the 256 CUs; 5 beyond that
     const long blocks16 = (T + 15) / 16;
@@ -363,12 +441,22 @@ template <int D, int R>
 static int ff_fwd_launch(hipStream_t st, const FFFwdParams& p) {
     constexpr int RT = 16 * R, PH = D + 16, NW = D / 16;
     const size_t smem = (size_t)(6 * RT * PH) * 2 + (size_t)(2 * NW * RT) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)xlnet_ff_fwd_kernel<D, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr = true;
+    const dim3 grid((unsigned)((p.T + RT - 1) / RT));
+    if (t4r_xlnet_body_fp16x2()) {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)xlnet_ff_fwd_kernel<D, R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            attr = true;
+        }
+        hipLaunchKernelGGL((xlnet_ff_fwd_kernel<D, R, true>), grid, dim3(D * 4), smem, st, p);
+    } else {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)xlnet_ff_fwd_kernel<D, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            attr = true;
+        }
+        hipLaunchKernelGGL((xlnet_ff_fwd_kernel<D, R>), grid, dim3(D * 4), smem, st, p);
     }
-    hipLaunchKernelGGL((xlnet_ff_fwd_kernel<D, R>), dim3((unsigned)((p.T + RT - 1) / RT)), dim3(D * 4), smem, st, p);
     T4R_LAUNCH_CHECK();
     return 0;
 }
@@ -412,7 +500,7 @@ extern "C" int t4r_xlnet_ff_fwd(void* stream, const float* h1, const float* plan
     T4R_CHECK_ARG((ffact != nullptr) == train && (ffout != nullptr) == train && (mean != nullptr) == train &&
                       (rstd != nullptr) == train, "xlnet_ff_fwd: ffpre, ffact, ffout, mean, rstd are saved together or not at all");
     T4R_CHECK_ARG(train || drop_p == 0.f, "xlnet_ff_fwd: dropout needs the saved activations (training mode)");
-    FFFwdParams p{h1, b1, b2, gamma, beta, carve_planes(planes, D), ffpre, ffact, ffout, mean, rstd, hout, T, eps,
+    FFFwdParams p{h1, b1, b2, gamma, beta, carve_planes(planes, D), carve_planes_h(planes, D), ffpre, ffact, ffout, mean, rstd, hout, T, eps,
                   make_drop(drop_p, seed, ctr_act), make_drop(drop_p, seed, ctr_out)};
     const int R = pick_r(T);
     FUSED_DISPATCH(ff_fwd_launch, D, R, (hipStream_t)stream, p);

@@ -570,12 +570,6 @@ __global__ __launch_bounds__(D * 4) void xlnet_dh_kernel(DhParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------- host side
-// the projections in the two-way fp16 form (T4R_XLNET_FP16X2, default 1)?
-static bool body_fp16x2() {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("T4R_XLNET_FP16X2"); on = e ? (atoi(e) != 0) : 1; }
-    return on != 0;
-}
 static int pick_r(long T) {
     const long blocks16 = (T + 15) / 16;
     if (blocks16 <= 256) return 1;
@@ -605,7 +599,7 @@ extern "C" int t4r_xlnet_qkv_proj(void* stream, const float* h, const float* pla
     if (T <= 0) return 0;
     T4R_CHECK_ARG(t4r_xlnet_fused_supported(D) && h && planes && qkv, "xlnet_qkv_proj: bad arguments");
     const int R = pick_r(T);
-    const bool hs = body_fp16x2();
+    const bool hs = t4r_xlnet_body_fp16x2();
     const LayerPlanesH PH_ = carve_planes_h(planes, D);
     const uint16_t* wq = hs ? PH_.QKVT : carve_planes(planes, D).QKVT;
     ProjParams p{h, {wq, wq + (long)D * D, wq + 2L * D * D, nullptr}, 3L * D * D, {qkv, qkv + T * D, qkv + 2 * T * D, nullptr}, T,
@@ -633,7 +627,7 @@ extern "C" int t4r_xlnet_kr_proj(void* stream, const float* pos, const float* pl
     if (rows <= 0) return 0;
     T4R_CHECK_ARG(t4r_xlnet_fused_supported(D) && pos && planes && kr, "xlnet_kr_proj: bad arguments");
     const int R = pick_r(rows);
-    const bool hs = body_fp16x2();
+    const bool hs = t4r_xlnet_body_fp16x2();
     const LayerPlanesH PH_ = carve_planes_h(planes, D);
     ProjParams p{pos, {hs ? PH_.RT : carve_planes(planes, D).RT, nullptr, nullptr, nullptr}, (long)D * D, {kr, nullptr, nullptr, nullptr}, rows,
                  {PH_.scale + HS_R, nullptr, nullptr, nullptr}};
@@ -677,7 +671,7 @@ extern "C" int t4r_xlnet_stack_prepare(void* stream, const float* const* params_
         if (launch_jobs(st, js, aj)) return -1;
         if (!pos || pos_rows <= 0) continue;
         T4R_CHECK_ARG(kr, "xlnet_stack_prepare: null k_r pointers");
-        const bool hs = body_fp16x2();
+        const bool hs = t4r_xlnet_body_fp16x2();
         ProjParams p{pos, {nullptr, nullptr, nullptr, nullptr}, (long)D * D, {nullptr, nullptr, nullptr, nullptr}, pos_rows,
                      {nullptr, nullptr, nullptr, nullptr}};
         for (int m = 0; m < nl; ++m) {
@@ -725,7 +719,7 @@ extern "C" int t4r_xlnet_oproj_ln(void* stream, const float* av, const float* h,
     T4R_CHECK_ARG((mean != nullptr) == train && (rstd != nullptr) == train, "xlnet_oproj_ln: ao, mean, rstd go together");
     T4R_CHECK_ARG(train || drop_p == 0.f, "xlnet_oproj_ln: dropout needs the saved activations");
     const int R = pick_r(T);
-    const bool hs = body_fp16x2();
+    const bool hs = t4r_xlnet_body_fp16x2();
     const LayerPlanesH PH_ = carve_planes_h(planes, D);
     OProjParams p{av, h, gamma, beta, hs ? PH_.ON : carve_planes(planes, D).ON, PH_.scale + HS_O, ao, mean, rstd, h1, T, eps,
                   make_drop(drop_p, seed, ctr_hi)};
@@ -762,7 +756,7 @@ extern "C" int t4r_xlnet_ln1_bwd(void* stream, const float* dy, const float* ao,
                   "xlnet_ln1_bwd: bad arguments");
     const int R = pick_r(T);
     const int nwg = (int)((T + 16 * R - 1) / (16 * R));
-    const bool hs = body_fp16x2();
+    const bool hs = t4r_xlnet_body_fp16x2();
     const LayerPlanesH PH_ = carve_planes_h(planes, D);
     Ln1BwdParams p{dy, ao, h, mean, rstd, gamma, hs ? PH_.OT : carve_planes(planes, D).OT, PH_.scale + HS_O, dh, dao, dav, part, T,
                    make_drop(drop_p, seed, ctr_hi)};
@@ -789,7 +783,7 @@ extern "C" int t4r_xlnet_dh(void* stream, const float* dqkv, const float* planes
     if (T <= 0) return 0;
     T4R_CHECK_ARG(t4r_xlnet_fused_supported(D) && dqkv && planes && dh, "xlnet_dh: bad arguments");
     const int R = pick_r(T);
-    const bool hs = body_fp16x2();
+    const bool hs = t4r_xlnet_body_fp16x2();
     const LayerPlanesH PH_ = carve_planes_h(planes, D);
     DhParams p{dqkv, hs ? PH_.QKVN : carve_planes(planes, D).QKVN, PH_.scale + HS_Q, dh, T};
     hipStream_t st = (hipStream_t)stream;

@@ -270,19 +270,25 @@ __global__ __launch_bounds__(D * 4) void xlnet_ff_fwd_kernel(FFFwdParams p) {
 struct FFBwdParams {
     const float *dy, *ffout, *h1, *mean, *rstd, *gamma, *ffpre;
     LayerPlanes w;
+    LayerPlanesH wh;       // HS: the two-way fp16 planes and their scales
     float *dh1, *dffout, *dpre;       // [T, D], [T, D], [T, 4D]
     float *partA, *partB;             // per-workgroup partial sums [nWG][3D] (d gamma | d beta | d b2), [nWG][4D] (d b1)
     int T;
     DropCfg drop_act, drop_out;
 };
 
-template <int D, int R>
+// HS: both products on the two-way fp16 split.  The d ffout rows carry their own power-of-two scale (gradient rows of one
+// tile differ by orders of magnitude); the d pre rows are positioned by a per-token bound known before the first chunk:
+// |gelu'| <= 1.13, the dropout factor, |d act[t][f]| <= D max|W2| max|d ffout[t]|.
+template <int D, int R, bool HS = false>
 __global__ __launch_bounds__(D * 4) void xlnet_ff_bwd_kernel(FFBwdParams p) {
     constexpr int NW = D / 16, RT = 16 * R, PH = D + 16, PLN = RT * PH, DI = 4 * D;
     extern __shared__ uint16_t smem16[];
     uint16_t* sh_dfo = smem16;                                  // [3][RT][PH]  d ffout planes (B operand of the FF2 dX product)
     uint16_t* sh_dp = sh_dfo + 3 * PLN;                         // [3][RT][PH]  d pre chunk planes (B operand of the FF1 dX product)
     float* sh_part = reinterpret_cast<float*>(sh_dp + 3 * PLN);    // [NW][3][D]
+    float* sh_inv_d = reinterpret_cast<float*>(sh_dfo + 2 * PLN);  // HS: [RT] inverse d ffout row scales (unused third plane)
+    float* sh_sp = reinterpret_cast<float*>(sh_dp + 2 * PLN);      // HS: [RT] d pre scales | [RT] their inverses
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, g = lane >> 4;
     const long t0 = (long)blockIdx.x * RT;
     // ---- phase A: LayerNorm backward, one token row per wave at a time (lane = two consecutive features)
@@ -330,7 +336,25 @@ __global__ __launch_bounds__(D * 4) void xlnet_ff_bwd_kernel(FFBwdParams p) {
                     *reinterpret_cast<float2*>(p.dffout + t * D + c0) = make_float2(dxa[0], dxa[1]);
                 }
             }
-            if (act_lane) {
+            if constexpr (HS) {      // wave-uniform: the whole row lives in this wave
+                float m = fmaxf(fabsf(dxa[0]), fabsf(dxa[1]));
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+                const float sc = pow2_scale(m);
+                if (act_lane) {
+                    uint32_t wd[2];
+                    cut2h(dxa[0] * sc, dxa[1] * sc, wd);
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) *reinterpret_cast<uint32_t*>(sh_dfo + pl * PLN + row * PH + c0) = wd[pl];
+                }
+                if (lane == 0) {
+                    sh_inv_d[row] = 1.f / sc;
+                    const float w2max = 16384.f / p.wh.scale[HS_W2];       // >= max |W2|
+                    const float sp = pow2_scale(1.13f * p.drop_act.inv_keep * (float)D * w2max * m);
+                    sh_sp[row] = sp;
+                    sh_sp[RT + row] = 1.f / sp;
+                }
+            } else if (act_lane) {
                 uint32_t wd[3];
                 cut3(dxa[0], dxa[1], wd);
 #pragma unroll
@@ -359,14 +383,28 @@ __global__ __launch_bounds__(D * 4) void xlnet_ff_bwd_kernel(FFBwdParams p) {
     for (int r = 0; r < R; ++r) acc3[r] = zero4();
     const int boff = n * PH + 8 * g;
     const long wpl = (long)DI * D;
-    const uint16_t* w2tp = p.w.W2Tp + (long)(16 * w + n) * D + 8 * g;     // + c D D: chunk c
-    const uint16_t* w1tp = p.w.W1Tp + (long)(16 * w + n) * DI + 8 * g;    // + c D
+    const uint16_t* w2tp = (HS ? p.wh.W2Tp : p.w.W2Tp) + (long)(16 * w + n) * D + 8 * g;     // + c D D: chunk c
+    const uint16_t* w1tp = (HS ? p.wh.W1Tp : p.w.W1Tp) + (long)(16 * w + n) * DI + 8 * g;    // + c D
     AFrag<D> a2, a3;
-    load_a3<D>(a2, w2tp, wpl);
+    AFragH<D> h2f, h3f;
+    float is2[R], is3[R], sps[R];      // HS: accumulator -> value factors of the two products, the d pre scales
+    if constexpr (HS) {
+        const float iw2 = 1.f / p.wh.scale[HS_W2], iw1 = 1.f / p.wh.scale[HS_W1];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            is2[r] = sh_inv_d[r * 16 + n] * iw2;
+            sps[r] = sh_sp[r * 16 + n];
+            is3[r] = sh_sp[RT + r * 16 + n] * iw1;
+        }
+        load_a2h<D>(h2f, w2tp, wpl);
+    } else {
+        load_a3<D>(a2, w2tp, wpl);
+    }
 #pragma unroll 1
     for (int c = 0; c < 4; ++c) {
         const int d0 = c * D + 16 * w + 4 * g;
-        load_a3<D>(a3, w1tp + c * D, wpl);
+        if constexpr (HS) load_a2h<D>(h3f, w1tp + c * D, wpl);
+        else load_a3<D>(a3, w1tp + c * D, wpl);
         float4 pre[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -377,8 +415,15 @@ __global__ __launch_bounds__(D * 4) void xlnet_ff_bwd_kernel(FFBwdParams p) {
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = zero4();
         // d ff^T[d][token] = sum_f W2^T[d][f] d ffout[token][f]
-        product3<D, R, PH>(a2, sh_dfo + boff, PLN, acc);
-        load_a3<D>(a2, w2tp + (long)min(c + 1, 3) * D * D, wpl);
+        if constexpr (HS) {
+            product3h<D, R, PH>(h2f, sh_dfo + boff, PLN, acc);
+            load_a2h<D>(h2f, w2tp + (long)min(c + 1, 3) * D * D, wpl);
+#pragma unroll
+            for (int r = 0; r < R; ++r) { acc[r][0] *= is2[r]; acc[r][1] *= is2[r]; acc[r][2] *= is2[r]; acc[r][3] *= is2[r]; }
+        } else {
+            product3<D, R, PH>(a2, sh_dfo + boff, PLN, acc);
+            load_a3<D>(a2, w2tp + (long)min(c + 1, 3) * D * D, wpl);
+        }
         if (c > 0) __syncthreads();                           // the previous chunk's planes have been read by every wave
         float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -389,12 +434,21 @@ __global__ __launch_bounds__(D * 4) void xlnet_ff_bwd_kernel(FFBwdParams p) {
             const float4 m = drop_scale4(p.drop_act, (unsigned long long)t * DI + d0);
             v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
             if (t < p.T) st4(p.dpre + t * DI + d0, v);           // rows beyond T are exact zeros (d ffout rows are)
-            uint32_t w0[3], w1[3];
-            cut3(v.x, v.y, w0);
-            cut3(v.z, v.w, w1);
+            if constexpr (HS) {
+                uint32_t w0[2], w1[2];
+                cut2h(v.x * sps[r], v.y * sps[r], w0);
+                cut2h(v.z * sps[r], v.w * sps[r], w1);
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                *reinterpret_cast<uint2*>(sh_dp + pl * PLN + (r * 16 + n) * PH + 16 * w + 4 * g) = make_uint2(w0[pl], w1[pl]);
+                for (int pl = 0; pl < 2; ++pl)
+                    *reinterpret_cast<uint2*>(sh_dp + pl * PLN + (r * 16 + n) * PH + 16 * w + 4 * g) = make_uint2(w0[pl], w1[pl]);
+            } else {
+                uint32_t w0[3], w1[3];
+                cut3(v.x, v.y, w0);
+                cut3(v.z, v.w, w1);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    *reinterpret_cast<uint2*>(sh_dp + pl * PLN + (r * 16 + n) * PH + 16 * w + 4 * g) = make_uint2(w0[pl], w1[pl]);
+            }
             cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
         }
         // d b1 partial: sum over the tile's tokens = over r (above) and over the 16 lanes n of a lane group
@@ -406,7 +460,12 @@ __global__ __launch_bounds__(D * 4) void xlnet_ff_bwd_kernel(FFBwdParams p) {
         if (n == 0) st4(p.partB + (long)blockIdx.x * DI + d0, cs);
         __syncthreads();
         // d h1^T[k][token] += sum_{d in chunk} W1^T[k][d] d pre[token][d]
-        product3<D, R, PH>(a3, sh_dp + boff, PLN, acc3);
+        if constexpr (HS) product3h<D, R, PH>(h3f, sh_dp + boff, PLN, acc3);
+        else product3<D, R, PH>(a3, sh_dp + boff, PLN, acc3);
+    }
+    if constexpr (HS) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) { acc3[r][0] *= is3[r]; acc3[r][1] *= is3[r]; acc3[r][2] *= is3[r]; acc3[r][3] *= is3[r]; }
     }
     // d h1 = residual part (written in phase A by this workgroup, ordered by the barriers above) + d pre @ W1
     const int k0 = 16 * w + 4 * g;
@@ -464,12 +523,22 @@ template <int D, int R>
 static int ff_bwd_launch(hipStream_t st, const FFBwdParams& p) {
     constexpr int RT = 16 * R, PH = D + 16, NW = D / 16;
     const size_t smem = (size_t)(6 * RT * PH) * 2 + (size_t)(NW * 3 * D) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)xlnet_ff_bwd_kernel<D, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr = true;
+    const dim3 grid((unsigned)((p.T + RT - 1) / RT));
+    if (t4r_xlnet_body_fp16x2()) {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)xlnet_ff_bwd_kernel<D, R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            attr = true;
+        }
+        hipLaunchKernelGGL((xlnet_ff_bwd_kernel<D, R, true>), grid, dim3(D * 4), smem, st, p);
+    } else {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)xlnet_ff_bwd_kernel<D, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            attr = true;
+        }
+        hipLaunchKernelGGL((xlnet_ff_bwd_kernel<D, R>), grid, dim3(D * 4), smem, st, p);
     }
-    hipLaunchKernelGGL((xlnet_ff_bwd_kernel<D, R>), dim3((unsigned)((p.T + RT - 1) / RT)), dim3(D * 4), smem, st, p);
     T4R_LAUNCH_CHECK();
     return 0;
 }
@@ -525,7 +594,7 @@ extern "C" int t4r_xlnet_ff_bwd(void* stream, const float* dy, const float* ffou
     const int nwg = (T + 16 * R - 1) / (16 * R);
     float* partA = part;
     float* partB = part + (long)nwg * 3 * D;
-    FFBwdParams p{dy, ffout, h1, mean, rstd, gamma, ffpre, carve_planes(planes, D), dh1, dffout, dpre, partA, partB, T,
+    FFBwdParams p{dy, ffout, h1, mean, rstd, gamma, ffpre, carve_planes(planes, D), carve_planes_h(planes, D), dh1, dffout, dpre, partA, partB, T,
                   make_drop(drop_p, seed, ctr_act), make_drop(drop_p, seed, ctr_out)};
     hipStream_t st = (hipStream_t)stream;
     auto launch = [&]() -> int {

@@ -162,8 +162,20 @@ bool t4r_splitk_sink_add_reduce(const float* part, int nblocks, int n, float* co
     return true;
 }
 
+// operand maxima of the NEXT launch (device words: bits of max |A|, max |B|): a launch that would run in the three-plane
+// bf16 form runs in the two-way fp16 form instead (gemm_kernel.h: PREC 4).  Consumed by that launch.
+static thread_local const float* g_amax_a = nullptr;
+static thread_local const float* g_amax_b = nullptr;
+static thread_local int g_amax_n = 0;
+void t4r_gemm_operand_amax(const float* a, const float* b, int n) { g_amax_a = a; g_amax_b = b; g_amax_n = n; }
+
 template <bool TA, bool TB>
 static int launch_layout(GemmParams& p, int batch, int splitk_req, hipStream_t stream) {
+    const float* amax_a = g_amax_a;
+    const float* amax_b = g_amax_b;
+    const int amax_n = g_amax_n;
+    g_amax_a = g_amax_b = nullptr;
+    p.amaxA = p.amaxB = nullptr; p.n_amax = 0;
     // tokens x small weight in an fp32-accurate mode: the token-stationary kernel (operands cut once, tok_gemm.hip)
     if (!TA && (splitk_req == 0 || splitk_req == 1)) {
         const int mode = t4r_get_precision();
@@ -219,6 +231,10 @@ static int launch_layout(GemmParams& p, int batch, int splitk_req, hipStream_t s
         bm = big ? 128 : 64;
         bn = big == 1 ? 128 : 64;
         half_big = big;
+        if (prec == 1 && amax_a && amax_b && !feat && p.epilogue == EPI_NONE) {
+            prec = 4; p.amaxA = amax_a; p.amaxB = amax_b; p.n_amax = amax_n;
+            bm = bn = 64; half_big = 0;
+        }
     }
     int splitk = splitk_req;
     if (splitk_req == 0) {  // auto: only when the caller allows atomics (accumulating outputs)

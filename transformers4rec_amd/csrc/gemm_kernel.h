@@ -50,6 +50,9 @@ struct GemmParams {
     float alpha;
     int epilogue;
     int splitk;                 // >1: atomic accumulate alpha*partial into C (epilogue must be NONE) ...
+    const float* amaxA;         // PREC 4: n_amax per-workgroup maxima of |A| and of |B| (device arrays written by the producers
+    const float* amaxB;         //   of the operands): the two-way fp16 split positions both operands by powers of two of their max
+    int n_amax;
     float* part;                // ... or, non-null: split z (= blockIdx.z, batch-major) stores its partial tile to
                                 // part + z * M * ldc (C's layout); a reduction pass adds them in split order (gemm_f32.hip)
     int accumulate;             // splitk==1 only: C += result instead of C = result
@@ -147,9 +150,16 @@ __device__ __forceinline__ uint32_t pk_bf16_rne(float a, float b) {
 // partial products (mid.lo, lo.mid, lo.lo, < 2^-24 |a||b|) carry no systematic sign -- with truncation cuts every
 // piece has the sign of x and the dropped terms add up over long reductions (seen as a 1.8e-5 drift of the
 // head's sum_v dW[v, :] checksum over 100 k rows).  Same instruction count as the truncation form.
+// PREC 4, the two-way fp16 split of an operand already positioned by a power of two (max |.| in [2^13, 2^14)):
+// hi = fp16(x), lo = fp16(x - hi), both round to nearest; three products hi.hi + hi.lo + lo.hi (csrc/head_split.hip).
 template <int PREC>
-__device__ __forceinline__ void cvt_pair(float a, float b, uint32_t (&w)[PREC == 1 ? 3 : 1]) {
-    if constexpr (PREC == 1) {
+__device__ __forceinline__ void cvt_pair(float a, float b, uint32_t (&w)[PREC == 1 ? 3 : (PREC == 4 ? 2 : 1)]) {
+    if constexpr (PREC == 4) {
+        const half2_t h = {(_Float16)a, (_Float16)b};
+        const half2_t l = {(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
+        w[0] = __builtin_bit_cast(uint32_t, h);
+        w[1] = __builtin_bit_cast(uint32_t, l);
+    } else if constexpr (PREC == 1) {
 #ifdef T4R_SPLIT_TRUNC      // A/B build only: truncation cuts (biased, see above)
         const uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
         const float ta = a - __uint_as_float(ua & 0xffff0000u), tb = b - __uint_as_float(ub & 0xffff0000u);
@@ -174,7 +184,7 @@ __device__ __forceinline__ void cvt_pair(float a, float b, uint32_t (&w)[PREC ==
 }
 template <int PREC>
 __device__ __forceinline__ f32x16 mfma_half(uint4 a, uint4 b, f32x16 c) {
-    if constexpr (PREC == 3)
+    if constexpr (PREC == 3 || PREC == 4)
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
     else
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
@@ -184,7 +194,7 @@ __device__ __forceinline__ f32x16 mfma_half(uint4 a, uint4 b, f32x16 c) {
 template <int BM, int BN, int BK, bool TA, bool TB, int PREC>
 constexpr size_t gemm_lds_bytes() {
     if (PREC == 0) return (size_t)2 * ((!TA ? BM * BK : BK * (BM + 4)) + (TB ? BN * BK : BK * (BN + 4))) * 4;
-    constexpr int npl = PREC == 1 ? 3 : 1;
+    constexpr int npl = PREC == 1 ? 3 : (PREC == 4 ? 2 : 1);
     constexpr int pa = (BK / 8) * (!TA ? BM * 4 + 16 : 4 * (BM + 4)), pb = (BK / 8) * (TB ? BN * 4 + 16 : 4 * (BN + 4));
     return (size_t)2 * npl * (pa + pb) * 4;
 }
@@ -204,7 +214,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     constexpr int LDB_S = B_MK ? BK : BN + 4;
     auto swz = [](int row, int chunk) { return (chunk ^ ((row / (64 / BK)) % (BK / 4))) * 4; };
     constexpr bool HALF = PREC != 0;                   // bf16 / fp16 matrix cores
-    constexpr int NPL = PREC == 1 ? 3 : 1;             // operand planes: hi | mid | lo of the exact 3-way bf16 split, or one
+    constexpr int NPL = PREC == 1 ? 3 : (PREC == 4 ? 2 : 1);   // operand planes: hi | mid | lo (bf16), hi | lo (fp16 split), or one
     static_assert(!HALF || BK == 32, "the half-precision operand images are built for BK = 32");
     // half-precision images, per plane, in 32-bit words holding two consecutive k (even k in the low half):
     //   k-contiguous operand: [chunk = k/8][row][4 words]; chunk pitch ROWS*4 + 16 words -- the 8-byte stage
@@ -288,6 +298,29 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     // chosen from g/N itself (|g/N| 2^k in [2^13, 2^14)) and the epilogue's alpha undoes it exactly -- the per-launch
     // form of what torch.cuda.amp.GradScaler does for the reference (trainer.py:363-367); it composes with a
     // user-level loss scale, which only changes g.
+    // PREC 4: the operands' power-of-two positions (max |.| -> [2^13, 2^14); 1 for an all-zero or non-finite operand)
+    float op_sa = 1.f, op_sb = 1.f;
+    if constexpr (PREC == 4) {
+        // every workgroup reduces the producers' per-workgroup maxima itself (a few hundred floats: L2 hits)
+        float ma = 0.f, mb = 0.f;
+        for (int i = tid; i < p.n_amax; i += 256) { ma = fmaxf(ma, p.amaxA[i]); mb = fmaxf(mb, p.amaxB[i]); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { ma = fmaxf(ma, __shfl_xor(ma, o, 64)); mb = fmaxf(mb, __shfl_xor(mb, o, 64)); }
+        float* red = smem;      // the operand images are not in use yet
+        if (lane == 0) { red[2 * wave] = ma; red[2 * wave + 1] = mb; }
+        __syncthreads();
+        ma = fmaxf(fmaxf(red[0], red[2]), fmaxf(red[4], red[6]));
+        mb = fmaxf(fmaxf(red[1], red[3]), fmaxf(red[5], red[7]));
+        __syncthreads();
+        auto scale_of = [](float a) {
+            if (!(a > 0.f) || !(a < 3e38f)) return 1.f;
+            int e;
+            (void)frexpf(a, &e);
+            return ldexpf(1.f, 14 - e);
+        };
+        op_sa = scale_of(ma);
+        op_sb = scale_of(mb);
+    }
     float sg_g = 0.f, sg_unscale = 1.f;
     if (SG) {
         sg_g = (p.sg_gout ? *p.sg_gout : 1.f) / p.sg_rows;
@@ -388,6 +421,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 if (!TB) rb[r] = mask4(rb[r], (live && k0 + kk < p.K) ? 4 : 0);
                 else rb[r] = mask4(rb[r], live ? p.K - (k0 + (idx % (BK / 4)) * 4) : 0);
             }
+        }
+        if constexpr (PREC == 4) {
+#pragma unroll
+            for (int r = 0; r < NA4; ++r) { ra[r].x *= op_sa; ra[r].y *= op_sa; ra[r].z *= op_sa; ra[r].w *= op_sa; }
+#pragma unroll
+            for (int r = 0; r < NB4; ++r) { rb[r].x *= op_sb; rb[r].y *= op_sb; rb[r].z *= op_sb; rb[r].w *= op_sb; }
         }
         if constexpr (HALF) {
             // fp32 stage -> bf16 / fp16 planes (PREC 1: the exact three-way split)
@@ -494,7 +533,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     // Half path: a group = one K = 16 MFMA step; the lane's fragment of step h is the chunk 2 h + khalf
     // (8 consecutive k = four words) of its row, per plane.
     constexpr int NH = HALF ? BK / 16 : KH / 4;
-    constexpr int MFMA_PER_GROUP = HALF ? (PREC == 1 ? 6 : 1) : 4;
+    constexpr int MFMA_PER_GROUP = HALF ? (PREC == 1 ? 6 : (PREC == 4 ? 3 : 1)) : 4;
     float4 fa[HALF ? 1 : NH][WM], fb[HALF ? 1 : NH][WN];
     uint4 fah[HALF ? NH : 1][WM][NPL], fbh[HALF ? NH : 1][WN][NPL];
     auto read_frag = [&](int buf, int h) __attribute__((always_inline)) {
@@ -555,6 +594,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 _Pragma("unroll") for (int i = 0; i < WM; ++i) _Pragma("unroll") for (int j = 0; j < WN; ++j) \
                     acc[i][j] = mfma_half<PREC>(fah[h][i][PA], fbh[h][j][PB], acc[i][j]);
                 T4R_TERM(1, 1) T4R_TERM(2, 0) T4R_TERM(0, 2) T4R_TERM(1, 0) T4R_TERM(0, 1) T4R_TERM(0, 0)
+#undef T4R_TERM
+            } else if constexpr (PREC == 4) {
+#define T4R_TERM(PA, PB)                                                                          \
+                _Pragma("unroll") for (int i = 0; i < WM; ++i) _Pragma("unroll") for (int j = 0; j < WN; ++j) \
+                    acc[i][j] = mfma_half<PREC>(fah[h][i][PA], fbh[h][j][PB], acc[i][j]);
+                T4R_TERM(1, 0) T4R_TERM(0, 1) T4R_TERM(0, 0)
 #undef T4R_TERM
             } else {
 #pragma unroll
@@ -628,7 +673,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     // The mode is workgroup-uniform: it is decided ONCE and each mode has its own straight-line
     // store loop (the per-element switch cost ~30 scalar/vector instructions per output element,
     // a quarter of the MFMA time of a K = 128 tile).
-    const float alpha = p.alpha * sg_unscale;
+    const float alpha = PREC == 4 ? (p.alpha / op_sa) / op_sb : p.alpha * sg_unscale;
     if constexpr (RANK) {
 #pragma unroll
         for (int i = 0; i < WM; ++i) {

@@ -73,7 +73,25 @@ struct LayerPlanesH {
     const uint16_t *QKVT, *RT, *ON, *OT, *QKVN, *W1p, *W2p, *W1Tp, *W2Tp;
     const float* scale;
 };
-enum { HS_Q = 0, HS_K = 1, HS_V = 2, HS_R = 3, HS_O = 4, HS_W1 = 5, HS_W2 = 6, HS_B1 = 7 };
+enum { HS_Q = 0, HS_K = 1, HS_V = 2, HS_R = 3, HS_O = 4, HS_W1 = 5, HS_W2 = 6, HS_B1 = 7,
+       HS_RESERVED = 8 };
+// A workgroup's maximum of per-lane values -> out[blockIdx.x] (plain store: one slot per workgroup; the consumer takes the
+// maximum over the slots.  Atomics on ONE word from 2 k waves cost 30-50 us per launch: same-address atomics serialise.)
+// sh: NW floats of LDS nobody else uses any more; every thread of the workgroup calls it.
+template <int NW>
+__device__ __forceinline__ void block_amax_to(float m, float* sh, float* out, int tid) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __syncthreads();
+    if ((tid & 63) == 0) sh[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+        float mm = sh[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) mm = fmaxf(mm, sh[w]);
+        out[blockIdx.x] = mm;
+    }
+}
 static inline long layer_planes_bf16_floats(int D) { return 25L * 3 * D * D / 2; }
 __host__ __device__ inline LayerPlanesH carve_planes_h(const void* base, int D) {
     const uint16_t* b = (const uint16_t*)((const float*)base + 25L * 3 * D * D / 2);

@@ -39,6 +39,7 @@ struct FFFwdParams {
     const float *h1, *b1, *b2, *gamma, *beta;
     LayerPlanes w;
     LayerPlanesH wh;       // HS: the two-way fp16 planes and their scales
+    float *amax_h1, *amax_act;      // HS, optional: per-workgroup max |h1|, max |act| (operand maxima of the weight gradients)
     float *ffpre, *ffact, *ffout, *mean, *rstd, *hout;     // ffpre / ffact / ffout / mean / rstd: all given (training) or all NULL
     int T;
     float eps;
@@ -62,11 +63,13 @@ __device__ __forceinline__ void ff_fwd_body(const FFFwdParams& p, uint16_t* smem
     float* sh_sa = reinterpret_cast<float*>(sh_a + 2 * PLN);       // HS: [RT] activation scales | [RT] their inverses
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, g = lane >> 4;
     const long t0 = (long)blockIdx.x * RT;
+    float h1max_keep = 0.f;
     if constexpr (HS) {
         const float w1max = 16384.f / p.wh.scale[HS_W1];    // >= max |W1| (the scale puts it into [2^13, 2^14))
         const float b1max = p.wh.scale[HS_B1];
         const float keep = TRAIN ? p.drop_act.inv_keep : 1.f;
         constexpr int G = D / 4;
+        float h1max = 0.f;
         for (int i = tid; i < ((RT * G + NT - 1) / NT) * NT; i += NT) {
             const bool live = i < RT * G;
             const int row = live ? i / G : RT - 1, c4 = live ? (i % G) * 4 : 0;
@@ -77,6 +80,7 @@ __device__ __forceinline__ void ff_fwd_body(const FFFwdParams& p, uint16_t* smem
             for (int o = G / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
             const float sc = pow2_scale(m);
             if (live) {
+                h1max = fmaxf(h1max, m);
                 uint32_t w0[2], w1[2];
                 cut2h(v.x * sc, v.y * sc, w0);
                 cut2h(v.z * sc, v.w * sc, w1);
@@ -91,6 +95,7 @@ __device__ __forceinline__ void ff_fwd_body(const FFFwdParams& p, uint16_t* smem
                 }
             }
         }
+        h1max_keep = h1max;
     } else
     for (int i = tid; i < RT * (D / 4); i += NT) {
         const int row = i / (D / 4), c4 = (i % (D / 4)) * 4;
@@ -113,6 +118,7 @@ __device__ __forceinline__ void ff_fwd_body(const FFFwdParams& p, uint16_t* smem
     const uint16_t* w2p = (HS ? p.wh.W2p : p.w.W2p) + (long)(16 * w + n) * DI + 8 * g;      // + c D
     AFrag<D> a1, a2;
     AFragH<D> h1f, h2f;
+    float actmax = 0.f;            // HS, training: running max |act| of this lane (operand maximum for the W2 weight gradient)
     float is1[R], is2[R];          // HS: what turns an accumulator of FF1 / FF2 back into values, per token block
     if constexpr (HS) {
         const float iw1 = 1.f / p.wh.scale[HS_W1], iw2 = 1.f / p.wh.scale[HS_W2];
@@ -159,6 +165,7 @@ __device__ __forceinline__ void ff_fwd_body(const FFFwdParams& p, uint16_t* smem
             }
             if (TRAIN && in) st4(p.ffact + t * DI + d0, v);
             if constexpr (HS) {
+                if (TRAIN && in) actmax = fmaxf(actmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
                 const float sa = sh_sa[r * 16 + n];
                 uint32_t w0[2], w1[2];
                 cut2h(v.x * sa, v.y * sa, w0);
@@ -250,6 +257,12 @@ __device__ __forceinline__ void ff_fwd_body(const FFFwdParams& p, uint16_t* smem
             if (TRAIN && w == 0 && g == 0) { p.mean[t] = mu[r]; p.rstd[t] = rs; }
         }
     }
+    if constexpr (HS && TRAIN) {
+        if (p.amax_h1) {        // workgroup-uniform
+            block_amax_to<NW>(h1max_keep, sh_red, p.amax_h1, tid);
+            block_amax_to<NW>(actmax, sh_red, p.amax_act, tid);
+        }
+    }
 }
 
 template <int D, int R, bool HS = false>
@@ -271,6 +284,7 @@ struct FFBwdParams {
     const float *dy, *ffout, *h1, *mean, *rstd, *gamma, *ffpre;
     LayerPlanes w;
     LayerPlanesH wh;       // HS: the two-way fp16 planes and their scales
+    float *amax_dpre, *amax_dfo;    // HS, optional: per-workgroup max |d pre|, max |d ffout|
     float *dh1, *dffout, *dpre;       // [T, D], [T, D], [T, 4D]
     float *partA, *partB;             // per-workgroup partial sums [nWG][3D] (d gamma | d beta | d b2), [nWG][4D] (d b1)
     int T;
@@ -291,11 +305,13 @@ __global__ __launch_bounds__(D * 4) void xlnet_ff_bwd_kernel(FFBwdParams p) {
     float* sh_sp = reinterpret_cast<float*>(sh_dp + 2 * PLN);      // HS: [RT] d pre scales | [RT] their inverses
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, g = lane >> 4;
     const long t0 = (long)blockIdx.x * RT;
+    float dfomax_keep = 0.f;
     // ---- phase A: LayerNorm backward, one token row per wave at a time (lane = two consecutive features)
     {
         const int c0 = lane * 2;
         const bool act_lane = c0 < D;
         float gam[2], pg[2], pb[2], pb2[2];
+        float dfomax = 0.f;        // HS: running max |d ffout| over this wave's rows (operand maximum for the W2 weight gradient)
 #pragma unroll
         for (int e = 0; e < 2; ++e) { gam[e] = act_lane ? p.gamma[c0 + e] : 0.f; pg[e] = pb[e] = pb2[e] = 0.f; }
         for (int row = w; row < RT; row += NW) {
@@ -347,6 +363,7 @@ __global__ __launch_bounds__(D * 4) void xlnet_ff_bwd_kernel(FFBwdParams p) {
 #pragma unroll
                     for (int pl = 0; pl < 2; ++pl) *reinterpret_cast<uint32_t*>(sh_dfo + pl * PLN + row * PH + c0) = wd[pl];
                 }
+                dfomax = fmaxf(dfomax, m);
                 if (lane == 0) {
                     sh_inv_d[row] = 1.f / sc;
                     const float w2max = 16384.f / p.wh.scale[HS_W2];       // >= max |W2|
@@ -361,6 +378,7 @@ __global__ __launch_bounds__(D * 4) void xlnet_ff_bwd_kernel(FFBwdParams p) {
                 for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint32_t*>(sh_dfo + pl * PLN + row * PH + c0) = wd[pl];
             }
         }
+        dfomax_keep = dfomax;
         if (act_lane) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
@@ -388,6 +406,7 @@ __global__ __launch_bounds__(D * 4) void xlnet_ff_bwd_kernel(FFBwdParams p) {
     AFrag<D> a2, a3;
     AFragH<D> h2f, h3f;
     float is2[R], is3[R], sps[R];      // HS: accumulator -> value factors of the two products, the d pre scales
+    float dpremax = 0.f;               // HS: running max |d pre| of this lane (operand maximum for the W1 weight gradient)
     if constexpr (HS) {
         const float iw2 = 1.f / p.wh.scale[HS_W2], iw1 = 1.f / p.wh.scale[HS_W1];
 #pragma unroll
@@ -435,6 +454,7 @@ __global__ __launch_bounds__(D * 4) void xlnet_ff_bwd_kernel(FFBwdParams p) {
             v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
             if (t < p.T) st4(p.dpre + t * DI + d0, v);           // rows beyond T are exact zeros (d ffout rows are)
             if constexpr (HS) {
+                dpremax = fmaxf(dpremax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
                 uint32_t w0[2], w1[2];
                 cut2h(v.x * sps[r], v.y * sps[r], w0);
                 cut2h(v.z * sps[r], v.w * sps[r], w1);
@@ -477,6 +497,12 @@ __global__ __launch_bounds__(D * 4) void xlnet_ff_bwd_kernel(FFBwdParams p) {
             st4(p.dh1 + t * D + k0, make_float4(o.x + acc3[r][0], o.y + acc3[r][1], o.z + acc3[r][2], o.w + acc3[r][3]));
         }
     }
+    if constexpr (HS) {
+        if (p.amax_dpre) {      // workgroup-uniform
+            block_amax_to<NW>(dpremax, sh_part, p.amax_dpre, tid);
+            block_amax_to<NW>(dfomax_keep, sh_part, p.amax_dfo, tid);
+        }
+    }
 }
 
 // -------------------------------------------------------------------------------------------------- host side
@@ -485,6 +511,17 @@ bool t4r_xlnet_body_fp16x2() {
     if (on < 0) { const char* e = getenv("T4R_XLNET_FP16X2"); on = e ? (atoi(e) != 0) : 1; }
     return on != 0;
 }
+// Where the next t4r_xlnet_ff_fwd / _bwd calls of this thread leave their per-workgroup operand maxima (four arrays of
+// t4r_xlnet_ff_amax_slots(T) floats: max |h1|, max |act| from the forward, max |d pre|, max |d ffout| from the backward), or
+// nulls (default: stand-alone use).  The layer (xlnet_layer.hip) sets them and hands the arrays to its two feed-forward
+// weight-gradient launches, which then run in the two-way fp16 form (gemm_kernel.h: PREC 4).
+static thread_local float* g_ff_amax[4] = {nullptr, nullptr, nullptr, nullptr};
+void t4r_xlnet_ff_amax_buffers(float* h1, float* act, float* dpre, float* dfo) {
+    g_ff_amax[0] = h1; g_ff_amax[1] = act; g_ff_amax[2] = dpre; g_ff_amax[3] = dfo;
+}
+static int pick_r(long T);
+int t4r_xlnet_ff_amax_count(long T) { const int R = pick_r(T); return (int)((T + 16 * R - 1) / (16 * R)); }   // workgroups of a launch
+long t4r_xlnet_ff_amax_slots(long T) { return (T + 15) / 16; }                                                 // upper bound of it
 static int pick_r(long T) {
     // smallest tile (fewest padded rows) whose grid still fits one residency of the 256 CUs; 5 beyond that
     const long blocks16 = (T + 15) / 16;
@@ -569,7 +606,8 @@ extern "C" int t4r_xlnet_ff_fwd(void* stream, const float* h1, const float* plan
     T4R_CHECK_ARG((ffact != nullptr) == train && (ffout != nullptr) == train && (mean != nullptr) == train &&
                       (rstd != nullptr) == train, "xlnet_ff_fwd: ffpre, ffact, ffout, mean, rstd are saved together or not at all");
     T4R_CHECK_ARG(train || drop_p == 0.f, "xlnet_ff_fwd: dropout needs the saved activations (training mode)");
-    FFFwdParams p{h1, b1, b2, gamma, beta, carve_planes(planes, D), carve_planes_h(planes, D), ffpre, ffact, ffout, mean, rstd, hout, T, eps,
+    FFFwdParams p{h1, b1, b2, gamma, beta, carve_planes(planes, D), carve_planes_h(planes, D), g_ff_amax[0], g_ff_amax[1], ffpre, ffact, ffout,
+                  mean, rstd, hout, T, eps,
                   make_drop(drop_p, seed, ctr_act), make_drop(drop_p, seed, ctr_out)};
     const int R = pick_r(T);
     FUSED_DISPATCH(ff_fwd_launch, D, R, (hipStream_t)stream, p);
@@ -594,7 +632,8 @@ extern "C" int t4r_xlnet_ff_bwd(void* stream, const float* dy, const float* ffou
     const int nwg = (T + 16 * R - 1) / (16 * R);
     float* partA = part;
     float* partB = part + (long)nwg * 3 * D;
-    FFBwdParams p{dy, ffout, h1, mean, rstd, gamma, ffpre, carve_planes(planes, D), carve_planes_h(planes, D), dh1, dffout, dpre, partA, partB, T,
+    FFBwdParams p{dy, ffout, h1, mean, rstd, gamma, ffpre, carve_planes(planes, D), carve_planes_h(planes, D), g_ff_amax[2], g_ff_amax[3], dh1,
+                  dffout, dpre, partA, partB, T,
                   make_drop(drop_p, seed, ctr_act), make_drop(drop_p, seed, ctr_out)};
     hipStream_t st = (hipStream_t)stream;
     auto launch = [&]() -> int {

@@ -43,22 +43,24 @@ __global__ __launch_bounds__(256) void layer_planes_kernel(PlaneJobs jobs) {
     const int li = i - jb.pair0;
     const int r = li / (jb.cols / 2), c = (li % (jb.cols / 2)) * 2;
     const float2 v = *reinterpret_cast<const float2*>(jb.src + (long)r * jb.cols + c);
-    uint32_t w[3], wh[2] = {0u, 0u};
-    cut3(v.x, v.y, w);
+    uint32_t w[3] = {0u, 0u, 0u}, wh[2] = {0u, 0u};
+    if (jb.dst) cut3(v.x, v.y, w);
     if (jb.dst_h) {
         const float sc = *jb.scale;
         cut2h(v.x * sc, v.y * sc, wh);
     }
     const long o_n = (long)(jb.r0 + r) * jb.dcols + jb.c0 + c;
     const long o_t0 = (long)(jb.r0 + c) * jb.dcols + jb.c0 + r, o_t1 = o_t0 + jb.dcols;
+    if (jb.dst) {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-        uint16_t* d = jb.dst + (long)pl * jb.dplane;
-        if (!jb.transpose) {
-            *reinterpret_cast<uint32_t*>(d + o_n) = w[pl];
-        } else {
-            d[o_t0] = (uint16_t)(w[pl] & 0xffffu);
-            d[o_t1] = (uint16_t)(w[pl] >> 16);
+        for (int pl = 0; pl < 3; ++pl) {
+            uint16_t* d = jb.dst + (long)pl * jb.dplane;
+            if (!jb.transpose) {
+                *reinterpret_cast<uint32_t*>(d + o_n) = w[pl];
+            } else {
+                d[o_t0] = (uint16_t)(w[pl] & 0xffffu);
+                d[o_t1] = (uint16_t)(w[pl] >> 16);
+            }
         }
     }
     if (jb.dst_h) {
@@ -103,8 +105,10 @@ extern "C" long t4r_xlnet_layer_planes_floats(int D) { return layer_planes_float
 
 static void add_job(PlaneJobs& js, const float* src, int rows, int cols, const uint16_t* dst, const uint16_t* dst_h,
                     const float* scale, int drows, int dcols, int r0, int c0, int transpose) {
+    // only the form the kernels will read is produced: the fp16 planes (default) or the bf16 planes (T4R_XLNET_FP16X2=0)
+    const bool hs = t4r_xlnet_body_fp16x2();
     PlaneJob& j = js.j[js.n++];
-    j.src = src; j.dst = const_cast<uint16_t*>(dst); j.dst_h = const_cast<uint16_t*>(dst_h); j.scale = scale;
+    j.src = src; j.dst = hs ? nullptr : const_cast<uint16_t*>(dst); j.dst_h = hs ? const_cast<uint16_t*>(dst_h) : nullptr; j.scale = scale;
     j.rows = (short)rows; j.cols = (short)cols; j.dcols = (short)dcols; j.dplane = drows * dcols;
     j.r0 = (short)r0; j.c0 = (short)c0; j.transpose = (short)transpose; j.pair0 = js.total;
     js.total += rows * cols / 2;

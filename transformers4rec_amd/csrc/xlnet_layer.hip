@@ -32,6 +32,11 @@ int t4r_colsum(void*, const float*, float*, float*, long, int, long);
 long t4r_colreduce_ws_floats(long, int);
 }
 void t4r_reduce_redirect(hipStream_t side, hipEvent_t* events, int n_events);   // elementwise.hip
+void t4r_gemm_operand_amax(const float* a, const float* b, int n);               // gemm_f32.hip: next launch in the fp16 split form
+void t4r_xlnet_ff_amax_buffers(float* h1, float* act, float* dpre, float* dfo);  // xlnet_fused.hip
+int t4r_xlnet_ff_amax_count(long T);
+long t4r_xlnet_ff_amax_slots(long T);
+bool t4r_xlnet_body_fp16x2();
 void t4r_splitk_sink_begin(float* ws, long cap_floats);                          // gemm_f32.hip: deterministic split-K
 int t4r_splitk_sink_flush(hipStream_t st);
 void t4r_splitk_sink_end();
@@ -91,7 +96,7 @@ enum { P_Q = 0, P_K, P_V, P_O, P_R, P_RWB, P_RRB, P_LN1W, P_LN1B, P_W1, P_B1, P_
        P_LN2B, P_COUNT };
 
 struct LayerWs {
-    float *qkv, *kr, *av, *lse, *ao, *mean1, *rstd1, *h1, *ffpre, *ffact, *ffout, *mean2, *rstd2, *pe_b, *planes;
+    float *qkv, *kr, *av, *lse, *ao, *mean1, *rstd1, *h1, *ffpre, *ffact, *ffout, *mean2, *rstd2, *pe_b, *planes, *amax;
     long total;
 };
 
@@ -120,6 +125,8 @@ static LayerWs carve(float* base, int B, int L, int D, int n, int per_batch_kr) 
     w.pe_b = per_batch_kr ? take((long)B * 2L * L * D) : nullptr;
     // bf16 planes of the feed-forward weights (fused kernels: cut once in the forward, reused by the backward)
     w.planes = t4r_xlnet_fused_supported(D) ? take(t4r_xlnet_layer_planes_floats(D)) : nullptr;
+    // per-workgroup operand maxima of the feed-forward weight gradients (fused kernels -> fp16-split GEMMs): 4 arrays
+    w.amax = t4r_xlnet_fused_supported(D) ? take(4 * t4r_xlnet_ff_amax_slots(T)) : nullptr;
     w.total = o;
     return w;
 }
@@ -202,9 +209,13 @@ extern "C" int t4r_xlnet_layer_fwd(void* stream, const float* h, const float* po
                                B, L, n_head, dh, drop, drop_p, seed, C(SITE_PROB), key_len));
         RUN(t4r_xlnet_oproj_ln(stream, w.av, h, w.planes, params[P_LN1W], params[P_LN1B], w.ao, w.mean1, w.rstd1, w.h1, T, D,
                                ln_eps, drop_p, seed, C(SITE_ATTN_OUT)));
-        return t4r_xlnet_ff_fwd(stream, w.h1, w.planes, params[P_B1], params[P_B2], params[P_LN2W], params[P_LN2B], w.ffpre,
-                                w.ffact, w.ffout, w.mean2, w.rstd2, h_out, T, D, ln_eps, drop_p, seed, C(SITE_FF_ACT),
-                                C(SITE_FF_OUT));
+        const long ns = t4r_xlnet_ff_amax_slots(T);
+        t4r_xlnet_ff_amax_buffers(w.amax, w.amax + ns, nullptr, nullptr);
+        const int rc = t4r_xlnet_ff_fwd(stream, w.h1, w.planes, params[P_B1], params[P_B2], params[P_LN2W], params[P_LN2B], w.ffpre,
+                                        w.ffact, w.ffout, w.mean2, w.rstd2, h_out, T, D, ln_eps, drop_p, seed, C(SITE_FF_ACT),
+                                        C(SITE_FF_OUT));
+        t4r_xlnet_ff_amax_buffers(nullptr, nullptr, nullptr, nullptr);
+        return rc;
     }
     if (k_w == q_w + DD && v_w == q_w + 2 * DD) {
         RUN(t4r_gemm_launch(st, 0, 0, T, D, D, 1.f, h, D, q_w, D, w.qkv, D, nullptr, EPI_NONE, nullptr, 0,
@@ -401,13 +412,25 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
     if (fused) {
         // one launch: LayerNorm backward -> d ffout -> FF2 dX -> GELU' / dropout -> FF1 dX + residual (+ the partial
         // sums of d gamma, d beta, d b2, d b1, reduced by two small launches on the weight-gradient stream)
-        RUN(t4r_xlnet_ff_bwd(stream, dh_out, w.ffout, w.h1, w.mean2, w.rstd2, params[P_LN2W], w.ffpre, w.planes,
-                             dx, dfo, dff, grads[P_LN2W], grads[P_LN2B], grads[P_B2], grads[P_B1], ff_part,
-                             T, D, drop_p, seed, C(SITE_FF_ACT), C(SITE_FF_OUT)));
+        const long ns = t4r_xlnet_ff_amax_slots(T);
+        const int na = t4r_xlnet_ff_amax_count(T);
+        float* am = w.amax;          // max |h1|, max |act| (forward), max |d pre|, max |d ffout| (now): one float per workgroup
+        t4r_xlnet_ff_amax_buffers(nullptr, nullptr, am + 2 * ns, am + 3 * ns);
+        {
+            const int rc = t4r_xlnet_ff_bwd(stream, dh_out, w.ffout, w.h1, w.mean2, w.rstd2, params[P_LN2W], w.ffpre, w.planes,
+                                            dx, dfo, dff, grads[P_LN2W], grads[P_LN2B], grads[P_B2], grads[P_B1], ff_part,
+                                            T, D, drop_p, seed, C(SITE_FF_ACT), C(SITE_FF_OUT));
+            t4r_xlnet_ff_amax_buffers(nullptr, nullptr, nullptr, nullptr);
+            if (rc) return rc;
+        }
+        // the two weight gradients in the two-way fp16 form, positioned by the operand maxima the fused kernels left
+        const bool hs = t4r_xlnet_body_fp16x2() && drop_p >= 0.f;
+        if (hs) t4r_gemm_operand_amax(am + 3 * ns, am + ns, na);
         RUN(t4r_gemm_launch(wg(), 1, 0, D, 4 * D, T, 1.f, dfo, D, w.ffact, 4 * D, grads[P_W2], 4 * D, nullptr,
                             EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
         {
             hipStream_t s1 = wg_again();
+            if (hs) t4r_gemm_operand_amax(am + 2 * ns, am, na);
             RUN(t4r_gemm_launch(s1, 1, 0, 4 * D, D, T, 1.f, dff, 4 * D, w.h1, D, grads[P_W1], D, nullptr,
                                 EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
             // first reduction launch of the call: W2, W1 and the bias / LayerNorm-2 sums of the feed-forward half

@@ -342,26 +342,41 @@ extern "C" int t4r_apply_mask_fwd(void* stream, float* x, const unsigned char* m
 // zeroed tokens (in place), so that the upstream backward sees d x.
 // The sum is formed in two stages (per-workgroup partial rows, then t4r_reduce_partials_launch in block order): 640
 // workgroups adding into the same H addresses with atomics took 24 us and gave a different rounding every run.
-#define T4R_MASK_BWD_TOK 64
+#define T4R_MASK_BWD_TOK 32
 __global__ __launch_bounds__(256) void apply_mask_bwd_kernel(float* __restrict__ dy,
                                                               const unsigned char* __restrict__ mask,
                                                               float* __restrict__ part, long ntok,
                                                               int L, int H, int mode) {
+    // 256 threads = column slots x token slices: with H = 128 two slices of 16 tokens each (a single slice walked its
+    // tokens one after the other: latency bound)
+    __shared__ float sh[256];
     const long t0 = (long)blockIdx.x * T4R_MASK_BWD_TOK;
     const long t1 = min(ntok, t0 + T4R_MASK_BWD_TOK);
-    for (int c = threadIdx.x; c < H; c += 256) {
+    const int ncol = H < 256 ? H : 256;                   // column slots per pass
+    const int nsl = 256 / ncol > 0 ? 256 / ncol : 1;      // token slices
+    const int cs = threadIdx.x % ncol, sl = threadIdx.x / ncol;
+    for (int c0 = 0; c0 < H; c0 += ncol) {
+        const int c = c0 + cs;
         float acc = 0.f;
-        for (long t = t0; t < t1; ++t) {
-            const bool m = mask[t] != 0;
-            const int l = (int)(t % L);
-            bool keep, zero = false;
-            if (mode == MASK_MLM) keep = !m;
-            else if (mode == MASK_CLM) { keep = m; zero = (l == L - 1); }
-            else keep = m;
-            if (!keep) { acc += dy[t * H + c]; dy[t * H + c] = 0.f; }
-            else if (zero) dy[t * H + c] = 0.f;
+        if (c < H && sl < nsl) {
+            for (long t = t0 + sl; t < t1; t += nsl) {
+                const bool m = mask[t] != 0;
+                const int l = (int)(t % L);
+                bool keep, zero = false;
+                if (mode == MASK_MLM) keep = !m;
+                else if (mode == MASK_CLM) { keep = m; zero = (l == L - 1); }
+                else keep = m;
+                if (!keep) { acc += dy[t * H + c]; dy[t * H + c] = 0.f; }
+                else if (zero) dy[t * H + c] = 0.f;
+            }
         }
-        part[(long)blockIdx.x * H + c] = acc;
+        sh[threadIdx.x] = acc;
+        __syncthreads();
+        if (sl == 0 && c < H) {
+            for (int k = 1; k < nsl; ++k) acc += sh[k * ncol + cs];       // fixed order
+            part[(long)blockIdx.x * H + c] = acc;
+        }
+        __syncthreads();
     }
 }
 

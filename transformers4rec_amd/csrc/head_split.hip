@@ -113,7 +113,15 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ src
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+    // ONE atomic per workgroup (<= 256 in all): with one per wave of 2048 workgroups the launch took 75-100 us -- atomics on
+    // one word serialise at the memory side
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (m > 0.f) atomicMax(out, __float_as_uint(m));
+    }
 }
 __device__ __forceinline__ float scale_of(const unsigned* amax_bits) {
     const float a = __uint_as_float(*amax_bits);
@@ -737,7 +745,7 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 static int head_w_amax(hipStream_t st, const float* W, long ldw, int V, int D, unsigned* out) {
     if (hipMemsetAsync(out, 0, 4, st) != hipSuccess) { t4r_set_error("head_split: memset failed"); return -1; }
     const long n4 = (long)V * (D / 4);
-    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)min(2048L, (n4 + 255) / 256)), dim3(256), 0, st, W, ldw, (long)V, D, out);
+    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)min(256L, (n4 + 255) / 256)), dim3(256), 0, st, W, ldw, (long)V, D, out);
     return 0;
 }
 
@@ -772,7 +780,7 @@ extern "C" int t4r_head_split_prepare(void* stream, const float* X, long ldx, in
         unsigned* amax = reinterpret_cast<unsigned*>((char*)ws + w.scales);
         if (hipMemsetAsync(amax, 0, 8, st) != hipSuccess) { t4r_set_error("head_split_prepare: memset failed"); return -1; }
         const long n4 = (long)N * (D / 4);
-        hipLaunchKernelGGL(amax_kernel, dim3((unsigned)min(1024L, (n4 + 255) / 256)), dim3(256), 0, st, X, ldx, (long)N, D, amax);
+        hipLaunchKernelGGL(amax_kernel, dim3((unsigned)min(256L, (n4 + 255) / 256)), dim3(256), 0, st, X, ldx, (long)N, D, amax);
         T4R_NB_SWITCH(D, hipLaunchKernelGGL((split_mk_kernel<NB, true>), dim3(w.nblk), dim3(256), 0, st, X, ldx, N, xa, amax));
     } else {
         T4R_NB_SWITCH(D, hipLaunchKernelGGL(split_mk_kernel<NB>, dim3(w.nblk), dim3(256), 0, st, X, ldx, N, xa));

@@ -735,24 +735,27 @@ def main():
         ff_fwd_ms = timed(lambda: ops.xlnet_ff_fwd(h1, planes, prm[10], prm[12], prm[13], prm[14], 0.03, args.dropout, 7, 11, 12))
         ff_bwd_ms = timed(lambda: ops.xlnet_ff_bwd(dyy, h1, sv, prm[13], planes, *gbuf, args.dropout, 7, 11, 12))
         ff_flops = 2.0 * Tt * 4 * D_MODEL * D_MODEL * 2
+        npb = float(_lib_int("t4r_xlnet_fused_products"))       # 3: two-way fp16 split, 6: three bf16 planes
         body = {"kernel": "xlnet_ff_fwd_kernel<128, 5> / xlnet_ff_bwd_kernel<128, 5> (token-tile-stationary feed-forward block, "
-                          "one launch per direction; fp32-accurate three-plane bf16 products)",
+                          "one launch per direction; " + ("fp32-class two-way fp16 split: per-token / per-matrix power-of-two scales, "
+                          "three products" if npb == 3.0 else "fp32-accurate three-plane bf16 products, six products") + ")",
                 "bound": "mfma + valu (measured: VALU work does not issue under matrix instructions on this chip, "
                          "tools/mfma_valu_overlap.hip)",
                 "fwd_avg_launch_ms": round(ff_fwd_ms, 4), "bwd_avg_launch_ms": round(ff_bwd_ms, 4),
-                "flops_per_launch": ff_flops, "executed_flops_per_launch": 6 * ff_flops,
-                "fwd": {"achieved": round(6 * ff_flops / (ff_fwd_ms * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(6 * ff_flops / (ff_fwd_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                "flops_per_launch": ff_flops, "executed_flops_per_launch": npb * ff_flops,
+                "fwd": {"achieved": round(npb * ff_flops / (ff_fwd_ms * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(npb * ff_flops / (ff_fwd_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
                         "fp32_equivalent_TFLOPs": round(ff_flops / (ff_fwd_ms * 1e-3) / 1e12, 1)},
-                "bwd": {"achieved": round(6 * ff_flops / (ff_bwd_ms * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(6 * ff_flops / (ff_bwd_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                "bwd": {"achieved": round(npb * ff_flops / (ff_bwd_ms * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(npb * ff_flops / (ff_bwd_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
                         "fp32_equivalent_TFLOPs": round(ff_flops / (ff_bwd_ms * 1e-3) / 1e12, 1),
                         "note": "includes the two partial-sum reductions of d gamma, d beta, d b2, d b1"},
                 "algorithmic_bytes_fwd": int(4 * Tt * D_MODEL * (2 + 8 + 1 + 1)), "algorithmic_bytes_bwd": int(4 * Tt * D_MODEL * (3 + 4 + 1 + 4 + 2)),
                 "traffic_fwd": 27.0e6 + 105.1e6, "traffic_bwd": 88.5e6 + 72.6e6,
                 "traffic_source": "committed (not measured in this run): profiles/r03_e_pmc_gemm_fetch_write.csv "
                                   "(FETCH_SIZE x 2 KB + WRITE_SIZE KB, separate rocprofv3 --pmc passes)",
-                "matrix_pipe_busy": {"fwd": 0.218, "bwd": 0.169, "source": "profiles/r03_e_pmc_mfma_util.csv (in-step)"}}
+                "matrix_pipe_busy": {"fwd": 0.218, "bwd": 0.169, "source": "profiles/r03_e_pmc_mfma_util.csv (in-step; measured on the "
+                                     "six-product bf16 form of these kernels, before the fp16 split)"}}
         del planes, h1, dyy, sv
 
     # HBM bytes of the launches from the PMC counters (FETCH_SIZE x2 on gfx950, WRITE_SIZE calibrated

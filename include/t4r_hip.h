@@ -353,6 +353,9 @@ int t4r_add_pos_bwd(void* stream, const float* dy, float* d_pos, int B, int L, i
  *            caller); d_gamma, d_beta, d_b2 [D], d_b1 [4D] are ACCUMULATED (per-workgroup partial sums + a reduction, no
  *            atomics).  part: t4r_xlnet_ff_bwd_part_floats(T, D) floats of scratch. */
 int t4r_xlnet_fused_supported(int D);
+/* matrix instructions per fp32-equivalent one in the fused layer kernels: 3 = two-way fp16 split with per-token /
+ * per-matrix power-of-two scales (default), 6 = three bf16 planes (T4R_XLNET_FP16X2=0) */
+int t4r_xlnet_fused_products(void);
 long t4r_xlnet_layer_planes_floats(int D);
 int t4r_xlnet_layer_prepare(void* stream, const float* const* params, int D, float* planes);
 long t4r_xlnet_ff_planes_floats(int D);

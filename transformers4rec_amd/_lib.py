@@ -72,6 +72,7 @@ _SIGS = {
     "t4r_xlnet_attn_bwd_ws_floats": ("l", "iiii"),
     "t4r_xlnet_attn_bwd": ("i", "p" * 17 + "iiii" + "ifQQ" + "p"),
     "t4r_xlnet_fused_supported": ("i", "i"),
+    "t4r_xlnet_fused_products": ("i", ""),
     "t4r_xlnet_ff_bwd_part_floats": ("l", "li"),
     "t4r_xlnet_layer_planes_floats": ("l", "i"),
     "t4r_xlnet_layer_prepare": ("i", "ppip"),

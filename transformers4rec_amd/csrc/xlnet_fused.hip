@@ -532,6 +532,8 @@ static int pick_r(long T) {
 }
 
 extern "C" int t4r_xlnet_fused_supported(int D) { return D == 32 || D == 64 || D == 128; }
+// matrix instructions per fp32-equivalent one in the fused layer kernels: 3 (two-way fp16 split, default) or 6 (bf16 planes)
+extern "C" int t4r_xlnet_fused_products(void) { return t4r_xlnet_body_fp16x2() ? 3 : 6; }
 extern "C" long t4r_xlnet_ff_bwd_part_floats(long T, int D) { return ((T + 15) / 16) * 7L * D; }
 template <int D, int R>
 static int ff_fwd_launch(hipStream_t st, const FFFwdParams& p) {

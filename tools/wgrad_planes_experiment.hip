@@ -21,7 +21,7 @@
 // fragments (eight consecutive TOKENS of one feature: the k index runs down the rows of the row-major planes) come out of
 // LDS through gfx950's transposing read ds_read_b64_tr_b16.
 //
-// ds_read_b64_tr_b16, as measured (tools/bin/tr_probe): inside each group of 16 lanes, lane i supplies the address of 4
+// ds_read_b64_tr_b16, as measured (tools/ds_read_tr_probe.hip): inside each group of 16 lanes, lane i supplies the address of 4
 // consecutive bf16; output lane c receives, for j = 0..3, element (c % 4) of what lane 4 j + c / 4 addressed.  With lane
 // i pointing at row (i >> 2), columns 4 (i & 3) .. + 3 of a row-major block, lane c ends up with column c of rows 0..3.
 // Two reads (rows 4 g .. 4 g + 3 and 16 + 4 g .. 16 + 4 g + 3 for lane group g = lane >> 4) give the eight k-slots of one

@@ -299,3 +299,26 @@ def test_ranking_metric_argument_forms():
     assert out["recall_at_5"].tolist() == [1.0, 1.0, 0.0, 0.0]
     assert out["avg_precision_at_10"].tolist() == pytest.approx([1.0, 0.2, 1 / 7, 0.0])
     assert t.compute_metrics()["next-item/recall_at_5"] == 0.5
+
+def test_round3_host_queries_of_the_library():
+    """host-only entry points added in round 3 (no device work): workspace offsets of the stack prologue, the product counts
+    the bench prices the kernels with, the environment switches behind them"""
+    import ctypes
+    from transformers4rec_amd import _lib
+
+    lib = _lib.load()
+    po, ko = ctypes.c_long(-5), ctypes.c_long(-5)
+    assert lib.t4r_xlnet_layer_ws_offsets(8, 20, 128, 4, 1, ctypes.addressof(po), ctypes.addressof(ko)) == 0
+    total = lib.t4r_xlnet_layer_ws_floats(8, 20, 128, 4, 1)
+    planes = lib.t4r_xlnet_layer_planes_floats(128)
+    assert 0 <= ko.value < po.value and po.value + planes <= total          # k_r before the planes, both inside the workspace
+    assert po.value % 4 == 0 and ko.value % 4 == 0                          # 16-byte aligned regions
+    lib.t4r_xlnet_layer_ws_offsets(8, 20, 256, 4, 1, ctypes.addressof(po), ctypes.addressof(ko))
+    assert po.value == -1                                                   # no fused kernels (no planes) at this width
+    assert planes >= 25 * 3 * 128 * 128 // 2 + 25 * 2 * 128 * 128 // 2      # bf16 planes + fp16 planes (+ scales)
+    assert lib.t4r_xlnet_fused_products() in (3, 6) and lib.t4r_head_split_fwd_products() in (3, 6)
+    # deferred join switches are plain host state: callable without a device
+    lib.t4r_xlnet_layer_bwd_defer(1)
+    lib.t4r_xlnet_layer_bwd_defer(0)
+    lib.t4r_xlnet_stack_prepared(0)
+    assert lib.t4r_apply_mask_bwd_ws_floats(4, 20, 128) == ((4 * 20 + 31) // 32) * 128

@@ -215,7 +215,6 @@ template <int D, int RT, int NT, int PH>
 __device__ __forceinline__ void tile_to_planes_h(const float* __restrict__ src, long t0, long T, uint16_t* sh, float* sh_inv,
                                                  int tid) {
     constexpr int PLN = RT * PH, G = D / 4;
-    static_assert((RT * G) % NT == 0 || true, "");
     for (int i = tid; i < ((RT * G + NT - 1) / NT) * NT; i += NT) {      // whole waves stay in the loop: the shuffles need their partners
         const bool live = i < RT * G;
         const int row = live ? i / G : RT - 1, c4 = live ? (i % G) * 4 : 0;

@@ -301,7 +301,7 @@ int t4r_gemm_launch(hipStream_t stream, int transA, int transB, int M, int N, in
                     const float* A, long lda, const float* B, long ldb, float* C, long ldc,
                     const float* bias, int epilogue, float* aux, long ldaux, int splitk,
                     int accumulate, int batch, long sA, long sB, long sC, const DropCfg* drop) {
-    if (M <= 0 || N <= 0) return 0;
+    if (M <= 0 || N <= 0) { g_amax_a = g_amax_b = nullptr; return 0; }     // operand maxima announced for THIS launch die with it
     T4R_CHECK_ARG(K > 0 && A && B && C && batch >= 1, "gemm: bad arguments");
     GemmParams p;
     p.M = M; p.N = N; p.K = K;

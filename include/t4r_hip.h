@@ -222,7 +222,7 @@ int t4r_head_split_logits(void* stream, void* ws, const float* W, long ldw, floa
 int t4r_head_split_logits_ce(void* stream, void* ws, const float* W, long ldw, float* C, long ldc, const long* labels,
                              float* loss_rows, float* lse, float* loss_mean, int N, int V, int D, float alpha,
                              float label_smoothing);
-int t4r_head_split_dw(void* stream, const void* ws, const float* logits, long ld, const float* lse,
+int t4r_head_split_dw(void* stream, void* ws, const float* logits, long ld, const float* lse,
                       const long* labels, const float* grad_out, float label_smoothing, float* dW, long lddw,
                       int N, int Vc, int V, int yoff, int D, float alpha, int accumulate);
 int t4r_head_split_dx(void* stream, void* ws, const float* logits, long ld, const float* lse, const long* labels,

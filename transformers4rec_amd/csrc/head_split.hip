@@ -294,7 +294,8 @@ __global__ __launch_bounds__(256) void head_logits_ce_kernel(const u32x4* __rest
                                                               float alpha, int nblk, int blk_per, int vec_ok,
                                                               float* __restrict__ st_m, float* __restrict__ st_s,
                                                               float* __restrict__ st_t, int n_tile, int n_split,
-                                                              const unsigned* __restrict__ amax = nullptr) {
+                                                              const unsigned* __restrict__ amax = nullptr,
+                                                              float* __restrict__ colmax = nullptr, int vpad = 0) {
     constexpr int KS = 2 * NB, CH = 4 * NB, NPL = HS ? 2 : 3;
     constexpr int BLK = 4 * NPL * 32 * NB;
     const float sw = HS ? scale_of(amax + 1) : 1.f;
@@ -356,6 +357,10 @@ __global__ __launch_bounds__(256) void head_logits_ce_kernel(const u32x4* __rest
             }
         }
     };
+    // running maxima of this lane's sixteen columns over the rows of this workgroup (d W's per-item scales: head_dw_split_kernel)
+    float cmax[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cmax[r] = -INFINITY;
     g_load(b_begin);
     s_store(0);
     __syncthreads();
@@ -382,6 +387,10 @@ __global__ __launch_bounds__(256) void head_logits_ce_kernel(const u32x4* __rest
         for (int r = 0; r < 16; ++r) v[r] = alpha * acc[r];
         const int row = b * 32 + l32;
         const int c0 = vbase + 4 * khalf;
+        if (colmax && row < N) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cmax[r] = fmaxf(cmax[r], v[r]);
+        }
         if (vec_ok && !tail_tile) {
             // full-line stores: the quad's four rows x four column groups are transposed through DPP, so that one store
             // instruction covers EIGHT lanes = all 128 bytes of a row (storing the accumulator layout as it is writes
@@ -435,6 +444,40 @@ __global__ __launch_bounds__(256) void head_logits_ce_kernel(const u32x4* __rest
         __syncthreads();
     }
     flush_stats((b_end - 1 - b_begin) & 1, b_end - 1);
+    if (colmax) {       // one reduction over the 32 rows of the wave per workgroup, not per row block
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) cmax[r] = fmaxf(cmax[r], __shfl_xor(cmax[r], o, 64));
+        }
+        if (l32 == 0) {
+            float* cp = colmax + (long)rsi * vpad + vbase + 4 * khalf;       // columns vbase + 8 g + 4 khalf + (0..3)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(cp + 8 * g) = make_float4(cmax[4 * g], cmax[4 * g + 1], cmax[4 * g + 2], cmax[4 * g + 3]);
+        }
+    }
+}
+
+// d W's per-item scales need: min over the rows of lse, and which items are some row's label (their column holds a -g (1 - eps))
+__global__ __launch_bounds__(1024) void head_dw_aux_kernel(const float* __restrict__ lse, const long* __restrict__ labels, int N,
+                                                            int yoff, int Vc, float* __restrict__ lse_min,
+                                                            unsigned char* __restrict__ islab) {
+    __shared__ float red[16];
+    float m = INFINITY;
+    for (int i = threadIdx.x; i < N; i += 1024) {
+        m = fminf(m, lse[i]);
+        const long y = labels[i] - yoff;
+        if (y >= 0 && y < Vc) islab[y] = 1;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) m = fminf(m, red[w]);
+        *lse_min = fminf(m, red[0]);
+    }
 }
 
 // per row: merge the column tiles' partial triples -> lse, loss  (32 rows x 32 tile slices per workgroup: a row's ~800
@@ -474,14 +517,25 @@ __device__ __forceinline__ float sg_value(float x, float l2, bool is_label, cons
 }
 
 // ---- d W[Vc, D] (+)= alpha * G^T @ X.  grid ceil(Vc / 128); wave w owns vocabulary rows 32 w .. 32 w + 31 of the tile.
-template <int NB>
+// HS (T4R_HEAD_DW_FP16X2): the two-way fp16 form.  Unlike d X, an output row here (one item) sums the gradient entries of ONE
+// column: for a rare item all of them lie 1e-6 .. 1e-12 below the tensor's maximum, so every item gets its OWN scale from a
+// bound on its column (the forward kernel leaves the column maxima of the logits; DwAux).
+struct DwAux { const float* colmax; const float* lse_min; const unsigned char* islab; int vpad, rsplit; };
+__device__ __forceinline__ float pow2_scale_head(float m) {
+    if (!(m > 0.f) || !(m < 3e38f)) return 1.f;
+    int e;
+    (void)frexpf(m, &e);
+    return ldexpf(1.f, 14 - e);
+}
+template <int NB, bool HS = false>
 __global__ __launch_bounds__(256) void head_dw_split_kernel(const float* __restrict__ logits, long ld,
                                                              const float* __restrict__ lse, const long* __restrict__ labels,
                                                              const float* __restrict__ gout, const u32x4* __restrict__ XT,
                                                              float* __restrict__ dW, long lddw, int N, int Vc, int V,
-                                                             int yoff, float smooth, float alpha, int accumulate, int nblk) {
-    constexpr int D = 32 * NB;
-    constexpr int BLK = 12 * 32 * NB;
+                                                             int yoff, float smooth, float alpha, int accumulate, int nblk,
+                                                             const unsigned* __restrict__ amax = nullptr, DwAux dw = DwAux()) {
+    constexpr int D = 32 * NB, NPL = HS ? 2 : 3;
+    constexpr int BLK = 4 * NPL * 32 * NB;
     constexpr int SN = (BLK + 255) / 256;
     __shared__ u32x4 lds[2][BLK];
     __shared__ float2 rinfo[2][32];
@@ -490,6 +544,21 @@ __global__ __launch_bounds__(256) void head_dw_split_kernel(const float* __restr
     const float* lp = logits + min(v, Vc - 1);
     SgScalars q;
     q.g = (gout ? *gout : 1.f) / N;
+    __shared__ float sh_inv[4][32];      // HS: inverse scale of every item row of the tile
+    if (HS) {
+        // THIS item's gradient entries are bounded by |g| (exp(max_r z[r][v] - min_r lse[r]) + eps / V), or by |g| if the item
+        // is some row's label: its column gets its own power-of-two position -- rare items (entries 1e-6 .. 1e-12 of the
+        // tensor's maximum) keep all 22 bits, which one scale for the whole tensor cannot give them
+        // (tools/head_dw_rows_probe.py: 1e-4 relative row error there with a tensor scale, 1e-6 with item scales)
+        float zmax = -INFINITY;
+        for (int sidx = 0; sidx < dw.rsplit; ++sidx) zmax = fmaxf(zmax, dw.colmax[(long)sidx * dw.vpad + min(v, Vc - 1)]);
+        const float pb = dw.islab[min(v, Vc - 1)] ? 1.f : __expf(fminf(zmax - *dw.lse_min, 0.f)) + smooth / V;
+        const float bound = fabsf(q.g) * pb;
+        const float sv = pow2_scale_head(bound);
+        if (khalf == 0) sh_inv[wave][l32] = 1.f / sv;
+        q.g *= sv;
+        alpha = alpha / scale_of(amax);
+    }
     q.sub = q.g * smooth / V;
     q.hit = q.g * (1.f - smooth);
 
@@ -537,7 +606,7 @@ __global__ __launch_bounds__(256) void head_dw_split_kernel(const float* __restr
         for (int i = 0; i < 16; ++i) xc[i] = xn[i];
         g_load(min(b + 1, nblk - 1));
         __builtin_amdgcn_sched_barrier(0);
-        u32x4 af[2][3];
+        u32x4 af[2][NPL];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             float gv[8];
@@ -546,16 +615,16 @@ __global__ __launch_bounds__(256) void head_dw_split_kernel(const float* __restr
                 const float2 in = rinfo[buf][16 * s + 8 * khalf + e];
                 gv[e] = sg_value(xc[8 * s + e], in.x, __float_as_int(in.y) == v, q);
             }
-            split8(gv, af[s]);
+            split8s<HS>(gv, 1.f, af[s]);
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                u32x4 bf[3];
+                u32x4 bf[NPL];
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) bf[pl] = lds[buf][(pl * 4 + 2 * s + khalf) * D + 32 * j + l32];
-                acc[j] = mfma6(af[s], bf, acc[j]);
+                for (int pl = 0; pl < NPL; ++pl) bf[pl] = lds[buf][(pl * 4 + 2 * s + khalf) * D + 32 * j + l32];
+                acc[j] = mfma_split<HS>(af[s], bf, acc[j]);
             }
         s_store(buf ^ 1, min(b + 1, nblk - 1));
         __syncthreads();
@@ -572,7 +641,8 @@ __global__ __launch_bounds__(256) void head_dw_split_kernel(const float* __restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int dr = (r & 3) + 8 * (r >> 2);
-            if (v0 + dr < Vc) cp[(long)dr * lddw] = alpha * acc[j][r] + (accumulate ? old[r] : 0.f);
+            const float a = HS ? alpha * sh_inv[wave][dr + 4 * khalf] : alpha;
+            if (v0 + dr < Vc) cp[(long)dr * lddw] = a * acc[j][r] + (accumulate ? old[r] : 0.f);
         }
     }
 }
@@ -705,13 +775,24 @@ __global__ __launch_bounds__(256) void head_dx_reduce_kernel(const float* __rest
     *op = s;
 }
 
+static int head_rows_per_wg() {
+    static int per = -1;
+    if (per < 0) { const char* e = getenv("T4R_HEAD_ROWS_PER_WG"); per = e ? max(1, atoi(e)) : 12; }
+    return per;
+}
 static int head_dx_target() {
     static int target = -1;
     if (target < 0) { const char* e = getenv("T4R_HEAD_DX_WGS"); target = e ? atoi(e) : 1536; }
     return target;
 }
 // workspace layout (bytes): XA | XT | WT | d X partials
-struct HeadWs { long xa, xt, wt, part, stats, scales, total; int nblk, nkt, max_split, ntile; };
+struct HeadWs { long xa, xt, wt, part, stats, scales, xth, colmax, islab, total; int nblk, nkt, max_split, ntile, vpad, rsplit; };
+// d W too (T4R_HEAD_DW_FP16X2, default 1; per-item scales: see head_dw_split_kernel)?
+static bool head_dw_fp16x2() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("T4R_HEAD_DW_FP16X2"); on = e ? (atoi(e) != 0) : 1; }
+    return on != 0;
+}
 // the forward product in the two-way fp16 split (see mfma_split)?
 static bool head_fwd_fp16x2() {
     static int on = -1;
@@ -733,8 +814,15 @@ HeadWs head_ws(int N, int V, int D) {
     w.part = w.wt + w.nkt * blk;
     w.stats = w.part + (long)w.max_split * N * D * 4;
     w.ntile = (V + 127) / 128;
-    w.scales = w.stats + 3L * w.ntile * N * 4;       // two words: bits of max |X|, bits of max |W| (fp16 split scales)
-    w.total = w.scales + 256;
+    w.scales = w.stats + 3L * w.ntile * N * 4;       // words: bits of max |X|, bits of max |W| (fp16 split scales), min lse
+    // d W in the fp16 form (per-item scales): the fp16 K-major planes of X, the per-row-split column maxima of the logits
+    // the forward kernel leaves, a byte per item "is some row's label"
+    w.xth = w.scales + 256;
+    w.vpad = 128 * w.ntile;
+    w.rsplit = (w.nblk + head_rows_per_wg() - 1) / head_rows_per_wg();
+    w.colmax = w.xth + w.nblk * blk;
+    w.islab = w.colmax + (long)w.rsplit * w.vpad * 4;
+    w.total = w.islab + ((w.vpad + 255) / 256) * 256;
     return w;
 }
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -744,8 +832,27 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 // max |W| of the table rows a forward product reads -> one word (reset first): 51 MB at BASELINE configs[1], ~10 us
 // the table maximum of the last forward product of this thread: d X of the same step (same workspace, same rows of the same
 // table) reuses it instead of reading the table once more
-struct LastWAmax { const void* ws; const float* W; int V; };
-static thread_local LastWAmax g_last_w = {nullptr, nullptr, 0};
+// What the forward products left in their workspaces, keyed by the workspace pointer: process-wide, not per thread -- the
+// autograd engine runs the backward (d X, d W) on its own device thread.  A small ring: a workspace lives from one forward to
+// its backward, and entries are overwritten by later forwards.
+#include <mutex>
+struct FwdNote { const void* ws; const float* W; int Vw; const float* logits; int V, N; bool colmax; };
+static std::mutex g_note_mu;
+static FwdNote g_notes[16] = {};
+static int g_note_next = 0;
+static void note_put(const FwdNote& n) {
+    std::lock_guard<std::mutex> lk(g_note_mu);
+    for (auto& e : g_notes)
+        if (e.ws == n.ws) { e = n; return; }
+    g_notes[g_note_next] = n;
+    g_note_next = (g_note_next + 1) % 16;
+}
+static bool note_get(const void* ws, FwdNote& out) {
+    std::lock_guard<std::mutex> lk(g_note_mu);
+    for (const auto& e : g_notes)
+        if (e.ws == ws && ws) { out = e; return true; }
+    return false;
+}
 static int head_w_amax(hipStream_t st, const float* W, long ldw, int V, int D, unsigned* out) {
     if (hipMemsetAsync(out, 0, 4, st) != hipSuccess) { t4r_set_error("head_split: memset failed"); return -1; }
     const long n4 = (long)V * (D / 4);
@@ -790,6 +897,11 @@ extern "C" int t4r_head_split_prepare(void* stream, const float* X, long ldx, in
         T4R_NB_SWITCH(D, hipLaunchKernelGGL(split_mk_kernel<NB>, dim3(w.nblk), dim3(256), 0, st, X, ldx, N, xa));
     }
     T4R_NB_SWITCH(D, hipLaunchKernelGGL(split_km_kernel<NB>, dim3(w.nblk), dim3(256), 0, st, X, ldx, N, xt));
+    if (head_fwd_fp16x2() && head_dw_fp16x2()) {     // d W may run in either form (it needs the forward's column maxima): both images
+        unsigned* amax = reinterpret_cast<unsigned*>((char*)ws + w.scales);
+        u32x4* xth = reinterpret_cast<u32x4*>((char*)ws + w.xth);
+        T4R_NB_SWITCH(D, hipLaunchKernelGGL((split_km_kernel<NB, true>), dim3(w.nblk), dim3(256), 0, st, X, ldx, N, xth, amax));
+    }
     T4R_LAUNCH_CHECK();
     return 0;
 }
@@ -810,7 +922,7 @@ extern "C" int t4r_head_split_logits(void* stream, void* ws, const float* W, lon
     if (head_fwd_fp16x2()) {
         unsigned* amax = reinterpret_cast<unsigned*>((char*)ws + w.scales);
         if (head_w_amax((hipStream_t)stream, W, ldw, V, D, amax + 1)) return -1;
-        g_last_w = LastWAmax{ws, W, V};
+        note_put(FwdNote{ws, W, V, C, V, N, false});
         T4R_NB_SWITCH(D, hipLaunchKernelGGL((head_logits_split_kernel<NB, true>), grid, dim3(256), 0, (hipStream_t)stream, xa, W,
                                             ldw, C, ldc, N, V, alpha, w.nblk, blk_per, amax));
     } else {
@@ -845,9 +957,11 @@ extern "C" int t4r_head_split_logits_ce(void* stream, void* ws, const float* W, 
     if (head_fwd_fp16x2()) {
         unsigned* amax = reinterpret_cast<unsigned*>((char*)ws + w.scales);
         if (head_w_amax(st, W, ldw, V, D, amax + 1)) return -1;
-        g_last_w = LastWAmax{ws, W, V};
+        float* colmax = nullptr;
+        if (head_dw_fp16x2() && rs == w.rsplit && vec_ok) colmax = reinterpret_cast<float*>((char*)ws + w.colmax);
+        note_put(FwdNote{ws, W, V, C, V, N, colmax != nullptr});
         T4R_NB_SWITCH(D, hipLaunchKernelGGL((head_logits_ce_kernel<NB, true>), grid, dim3(256), 0, st, xa, W, ldw, C, ldc, N, V,
-                                            alpha, w.nblk, blk_per, vec_ok, sm, ss, stt, w.ntile, rs, amax));
+                                            alpha, w.nblk, blk_per, vec_ok, sm, ss, stt, w.ntile, rs, amax, colmax, w.vpad));
     } else {
         T4R_NB_SWITCH(D, hipLaunchKernelGGL(head_logits_ce_kernel<NB>, grid, dim3(256), 0, st, xa, W, ldw, C, ldc, N, V, alpha,
                                             w.nblk, blk_per, vec_ok, sm, ss, stt, w.ntile, rs));
@@ -860,16 +974,32 @@ extern "C" int t4r_head_split_logits_ce(void* stream, void* ws, const float* W, 
 }
 
 // d W[Vc, D] (+)= alpha * dlogits^T @ X;  logits holds the columns [yoff, yoff + Vc) of the [N, V] problem
-extern "C" int t4r_head_split_dw(void* stream, const void* ws, const float* logits, long ld, const float* lse,
+extern "C" int t4r_head_split_dw(void* stream, void* ws, const float* logits, long ld, const float* lse,
                                  const long* labels, const float* grad_out, float label_smoothing, float* dW, long lddw,
                                  int N, int Vc, int V, int yoff, int D, float alpha, int accumulate) {
     if (N <= 0 || Vc <= 0) return 0;
     T4R_CHECK_ARG(t4r_head_split_supported(D) && logits && lse && labels && dW && ws, "head_split_dw: unsupported width or null pointer");
     const HeadWs w = head_ws(N, V, D);
     const u32x4* xt = reinterpret_cast<const u32x4*>((const char*)ws + w.xt);
-    T4R_NB_SWITCH(D, hipLaunchKernelGGL(head_dw_split_kernel<NB>, dim3((Vc + 127) / 128), dim3(256), 0, (hipStream_t)stream,
-                                        logits, ld, lse, labels, grad_out, xt, dW, lddw, N, Vc, V, yoff, label_smoothing,
-                                        alpha, accumulate, w.nblk));
+    FwdNote note;
+    const bool have_cm = note_get(ws, note) && note.colmax && note.logits == logits && note.V == V && note.N == N && Vc == V && yoff == 0;
+    if (head_fwd_fp16x2() && head_dw_fp16x2() && have_cm) {
+        hipStream_t st = (hipStream_t)stream;
+        const unsigned* amax = reinterpret_cast<const unsigned*>((const char*)ws + w.scales);
+        float* lse_min = reinterpret_cast<float*>(const_cast<char*>((const char*)ws) + w.scales) + 2;
+        unsigned char* islab = reinterpret_cast<unsigned char*>(const_cast<char*>((const char*)ws) + w.islab);
+        if (hipMemsetAsync(islab, 0, (size_t)w.vpad, st) != hipSuccess) { t4r_set_error("head_split_dw: memset failed"); return -1; }
+        hipLaunchKernelGGL(head_dw_aux_kernel, dim3(1), dim3(1024), 0, st, lse, labels, N, yoff, Vc, lse_min, islab);
+        DwAux aux{reinterpret_cast<const float*>((const char*)ws + w.colmax), lse_min, islab, w.vpad, w.rsplit};
+        const u32x4* xth = reinterpret_cast<const u32x4*>((const char*)ws + w.xth);
+        T4R_NB_SWITCH(D, hipLaunchKernelGGL((head_dw_split_kernel<NB, true>), dim3((Vc + 127) / 128), dim3(256), 0, st, logits, ld,
+                                            lse, labels, grad_out, xth, dW, lddw, N, Vc, V, yoff, label_smoothing, alpha,
+                                            accumulate, w.nblk, amax, aux));
+    } else {
+        T4R_NB_SWITCH(D, hipLaunchKernelGGL(head_dw_split_kernel<NB>, dim3((Vc + 127) / 128), dim3(256), 0, (hipStream_t)stream,
+                                            logits, ld, lse, labels, grad_out, xt, dW, lddw, N, Vc, V, yoff, label_smoothing,
+                                            alpha, accumulate, w.nblk));
+    }
     T4R_LAUNCH_CHECK();
     return 0;
 }
@@ -890,10 +1020,12 @@ extern "C" int t4r_head_split_dx(void* stream, void* ws, const float* logits, lo
     const bool hs = head_fwd_fp16x2();
     unsigned* amax = reinterpret_cast<unsigned*>((char*)ws + w.scales) + 1;     // max |W| of THIS call's rows (a chunk of the table)
     if (hs) {
-        const bool same = g_last_w.ws == ws && g_last_w.W == W && g_last_w.V == Vc;
+        FwdNote note;
+        const bool same = note_get(ws, note) && note.W == W && note.Vw == Vc;
         if (!same) {
             if (head_w_amax(st, W, ldw, Vc, D, amax)) return -1;
-            g_last_w = LastWAmax{ws, W, Vc};       // the slot now describes THIS table slice
+            if (note_get(ws, note)) { note.W = W; note.Vw = Vc; note_put(note); }     // the slot now describes THIS table slice
+            else note_put(FwdNote{ws, W, Vc, nullptr, 0, 0, false});
         }
         T4R_NB_SWITCH(D, hipLaunchKernelGGL((split_km_kernel<NB, true>), dim3(nkt), dim3(256), 0, st, W, ldw, Vc, wt, amax));
     } else {

@@ -288,14 +288,13 @@ __device__ __forceinline__ void quad_transpose4(float (&x)[4], int t) {
     }
 }
 
-template <int NB, bool HS = false>
-__global__ __launch_bounds__(256) void head_logits_ce_kernel(const u32x4* __restrict__ XA, const float* __restrict__ W,
-                                                              long ldw, float* __restrict__ C, long ldc, int N, int V,
-                                                              float alpha, int nblk, int blk_per, int vec_ok,
-                                                              float* __restrict__ st_m, float* __restrict__ st_s,
-                                                              float* __restrict__ st_t, int n_tile, int n_split,
-                                                              const unsigned* __restrict__ amax = nullptr,
-                                                              float* __restrict__ colmax = nullptr, int vpad = 0) {
+template <int NB, bool HS>
+__device__ __forceinline__ void head_logits_ce_body(const u32x4* __restrict__ XA, const float* __restrict__ W,
+                                                    long ldw, float* __restrict__ C, long ldc, int N, int V,
+                                                    float alpha, int nblk, int blk_per, int vec_ok,
+                                                    float* __restrict__ st_m, float* __restrict__ st_s,
+                                                    float* __restrict__ st_t, int n_tile, int n_split,
+                                                    const unsigned* __restrict__ amax, float* __restrict__ colmax, int vpad) {
     constexpr int KS = 2 * NB, CH = 4 * NB, NPL = HS ? 2 : 3;
     constexpr int BLK = 4 * NPL * 32 * NB;
     const float sw = HS ? scale_of(amax + 1) : 1.f;
@@ -457,6 +456,28 @@ __global__ __launch_bounds__(256) void head_logits_ce_kernel(const u32x4* __rest
                 *reinterpret_cast<float4*>(cp + 8 * g) = make_float4(cmax[4 * g], cmax[4 * g + 1], cmax[4 * g + 2], cmax[4 * g + 3]);
         }
     }
+}
+
+// The fp16 form is pinned to three waves per SIMD (158 VGPRs, no spills): with the sixteen running column maxima it sat at 172,
+// one register granule above the third wave, and the launch lost 15 %.  The bf16 form (212 VGPRs) keeps its two.
+template <int NB, bool HS = false>
+__global__ __launch_bounds__(256) void head_logits_ce_kernel(const u32x4* __restrict__ XA, const float* __restrict__ W,
+                                                              long ldw, float* __restrict__ C, long ldc, int N, int V,
+                                                              float alpha, int nblk, int blk_per, int vec_ok,
+                                                              float* __restrict__ st_m, float* __restrict__ st_s,
+                                                              float* __restrict__ st_t, int n_tile, int n_split,
+                                                              const unsigned* __restrict__ amax = nullptr,
+                                                              float* __restrict__ colmax = nullptr, int vpad = 0) {
+    head_logits_ce_body<NB, false>(XA, W, ldw, C, ldc, N, V, alpha, nblk, blk_per, vec_ok, st_m, st_s, st_t, n_tile, n_split, amax,
+                                   colmax, vpad);
+}
+template <int NB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void head_logits_ce_h_kernel(
+    const u32x4* __restrict__ XA, const float* __restrict__ W, long ldw, float* __restrict__ C, long ldc, int N, int V, float alpha,
+    int nblk, int blk_per, int vec_ok, float* __restrict__ st_m, float* __restrict__ st_s, float* __restrict__ st_t, int n_tile,
+    int n_split, const unsigned* __restrict__ amax, float* __restrict__ colmax, int vpad) {
+    head_logits_ce_body<NB, true>(XA, W, ldw, C, ldc, N, V, alpha, nblk, blk_per, vec_ok, st_m, st_s, st_t, n_tile, n_split, amax,
+                                  colmax, vpad);
 }
 
 // d W's per-item scales need: min over the rows of lse, and which items are some row's label (their column holds a -g (1 - eps))
@@ -960,7 +981,7 @@ extern "C" int t4r_head_split_logits_ce(void* stream, void* ws, const float* W, 
         float* colmax = nullptr;
         if (head_dw_fp16x2() && rs == w.rsplit && vec_ok) colmax = reinterpret_cast<float*>((char*)ws + w.colmax);
         note_put(FwdNote{ws, W, V, C, V, N, colmax != nullptr});
-        T4R_NB_SWITCH(D, hipLaunchKernelGGL((head_logits_ce_kernel<NB, true>), grid, dim3(256), 0, st, xa, W, ldw, C, ldc, N, V,
+        T4R_NB_SWITCH(D, hipLaunchKernelGGL(head_logits_ce_h_kernel<NB>, grid, dim3(256), 0, st, xa, W, ldw, C, ldc, N, V,
                                             alpha, w.nblk, blk_per, vec_ok, sm, ss, stt, w.ntile, rs, amax, colmax, w.vpad));
     } else {
         T4R_NB_SWITCH(D, hipLaunchKernelGGL(head_logits_ce_kernel<NB>, grid, dim3(256), 0, st, xa, W, ldw, C, ldc, N, V, alpha,

@@ -1,4 +1,9 @@
-// Next-item head (tied full softmax) for d_model <= 128, fp32-accurate on the BF16 matrix cores.
+// Next-item head (tied full softmax) for d_model <= 128, fp32-class accuracy on the 16-bit matrix cores.
+//
+// Two operand forms live here.  Round 2 (described first, still selectable with T4R_HEAD_FWD_FP16X2=0 /
+// T4R_HEAD_DW_FP16X2=0): three bf16 planes per operand, six products.  Round 3 (default, see mfma_split below): a two-way
+// fp16 split with exact power-of-two scales -- one per tensor for the forward and d X, one per ITEM for d W -- three
+// products; same or smaller error against fp64, half the matrix instructions (these kernels run at the package power limit).
 //
 // Replaces, for D = 32 / 64 / 96 / 128, the three vocabulary-wide contractions of
 // transformers4rec/torch/model/prediction_task.py:664 (logits = X @ W^T) and of its autograd

@@ -622,7 +622,7 @@ def main():
     if head_split:      # the launch the step issues at this shape: csrc/head_split.hip (operands cut once, W-stationary)
         hws = ops.head_split_prepare(xr, W.shape[0])
         gemm_ms = timed(lambda: ops.call("t4r_head_split_logits_ce", ops._stream(), hws.data_ptr(), W.data_ptr(), W.stride(0),
-                                         buf.data_ptr(), ld, None, None, None, None, N_m, W.shape[0], D_MODEL, 1.0, 0.0))
+                                         buf.data_ptr(), ld, None, None, None, None, N_m, W.shape[0], D_MODEL, 1.0, 0.0, None))
     else:
         gemm_ms = general_ms
     with ops.precision("fp32"):

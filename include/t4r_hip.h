@@ -15,7 +15,10 @@
  *   - `stream` is a hipStream_t (0 = null stream); all work is enqueued, nothing synchronises
  *   - return 0 on success; -1 on an argument error, a hipError_t value on a launch error;
  *     t4r_last_error() gives the message (thread-local)
- *   - no global mutable state besides the error string and lazily-set kernel attributes;
+ *   - no global mutable state besides the (thread-local) error string, lazily-set kernel attributes, the
+ *     precision / threshold switches set through t4r_set_* and the per-device side streams of the layer
+ *     backward; in particular nothing is remembered from a forward call for its backward call: what a backward
+ *     needs travels in caller-owned memory (workspaces, t4r_head_note);
  *     callable from any host thread with the right device current
  *   - "accumulated" outputs are read-modify-write (parameter gradients); everything else is
  *     overwritten
@@ -205,7 +208,15 @@ int t4r_get_tok_gemm_min_rows(void);
  * cutting hoisted out of the inner loops.  ws: t4r_head_split_ws_bytes(N, V, D) bytes, 16-byte aligned, owned by the
  * caller from _prepare (forward) until the last backward product; _dx and _dw use disjoint parts of it and may run
  * on different streams.  logits [N, ld] holds the columns [yoff, yoff + Vc) of the [N, V] problem (Vc = V, yoff = 0:
- * all of them); W passed to _dx points at row yoff.  No atomics: results are bit-reproducible. */
+ * all of them); W passed to _dx points at row yoff.  No atomics: results are bit-reproducible.
+ * note (host, caller-owned, may be NULL): what the forward product tells its backward products -- which table slice the
+ * max |W| word in ws describes, and whether ws holds the per-item column maxima of exactly these logits (then d W runs on
+ * the two-way fp16 split with per-item scales, else on the three bf16 planes).  Zero it before the forward product and
+ * pass the same struct to _dx / _dw of that forward; one note per forward in flight, not shared between concurrent calls.
+ * t4r_head_note_dw_form(note): the form the last _dw with this note ran in -- 0 none yet, 1 three bf16 planes, 2 two-way
+ * fp16 split with per-item scales. */
+typedef struct t4r_head_note { unsigned long long w[8]; } t4r_head_note;
+int t4r_head_note_dw_form(const void* note);
 int t4r_head_split_supported(int D);
 /* matrix instructions per fp32-equivalent one in the forward logits / d X products of csrc/head_split.hip: 3 = two-way fp16
  * split with power-of-two tensor scales (default), 6 = three bf16 planes (T4R_HEAD_FWD_FP16X2=0); d W always 6 */
@@ -213,7 +224,7 @@ int t4r_head_split_fwd_products(void);
 long t4r_head_split_ws_bytes(int N, int V, int D);
 int t4r_head_split_prepare(void* stream, const float* X, long ldx, int N, int D, int V, void* ws);
 int t4r_head_split_logits(void* stream, void* ws, const float* W, long ldw, float* C, long ldc, int N, int V,
-                          int D, float alpha);
+                          int D, float alpha, void* note);
 /* logits + mean cross-entropy (label smoothing as losses.py:4-20) in ONE pass over the vocabulary: the logits are
  * stored as by _logits, the softmax statistics are reduced inside the product's workgroups (one partial per row and
  * 128-column tile in ws) and merged by a small kernel -- replaces t4r_softmax_ce_fwd's second pass over [N, V].
@@ -221,13 +232,13 @@ int t4r_head_split_logits(void* stream, void* ws, const float* W, long ldw, floa
  * statistics) alone. */
 int t4r_head_split_logits_ce(void* stream, void* ws, const float* W, long ldw, float* C, long ldc, const long* labels,
                              float* loss_rows, float* lse, float* loss_mean, int N, int V, int D, float alpha,
-                             float label_smoothing);
+                             float label_smoothing, void* note);
 int t4r_head_split_dw(void* stream, void* ws, const float* logits, long ld, const float* lse,
                       const long* labels, const float* grad_out, float label_smoothing, float* dW, long lddw,
-                      int N, int Vc, int V, int yoff, int D, float alpha, int accumulate);
+                      int N, int Vc, int V, int yoff, int D, float alpha, int accumulate, void* note);
 int t4r_head_split_dx(void* stream, void* ws, const float* logits, long ld, const float* lse, const long* labels,
                       const float* grad_out, float label_smoothing, const float* W, long ldw, float* dX, long lddx,
-                      int N, int Vc, int V, int yoff, int D, float alpha, int accumulate);
+                      int N, int Vc, int V, int yoff, int D, float alpha, int accumulate, void* note);
 
 /* Non-materialising head: output projection + softmax cross-entropy WITHOUT an [N, V] logits tensor
  * (the form that can run a 10 M-item vocabulary: 15 k x 10 M logits would be 600 GB).

@@ -425,35 +425,59 @@ def test_compute_metrics_reduces_over_ranks():
     assert abs(want["next-item/avg_precision_at_20"] - float((hit20 / (ranks_all.double() + 1)).mean())) < 1e-6
 
 
+class _GuardedLinear(torch.nn.Linear):
+    """a drop-in-shaped module for the CPU: carries the drop-in marker and runs the drop-in forward's guard
+    (dropin._HipFeaturesMixin.forward starts with exactly this call) before its own arithmetic"""
+    _t4r_hip = True
+
+    def forward(self, x, training=False):
+        from transformers4rec_amd import dropin
+
+        dropin._check_data_parallel(self, training)
+        return super().forward(x)
+
+
 def _sync_worker(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from transformers4rec_amd import dropin
 
     torch.manual_seed(0)
-    model = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+    model = torch.nn.Sequential(_GuardedLinear(4, 3), _GuardedLinear(3, 2))
     model.train()
+    x = torch.full((5, 4), float(rank + 1))
     # the guard: a training forward of a drop-in module on > 1 ranks raises until somebody owns the gradient exchange
     dropin.allow_data_parallel(False)
     try:
-        dropin._check_data_parallel(model, True)
+        model(x)
         guarded = False
     except RuntimeError as e:
-        guarded = "sync_gradients" in str(e)
-    x = torch.full((5, 4), float(rank + 1))
+        guarded = "enable_data_parallel" in str(e) and "sync_gradients" in str(e)
+    # the documented recipe (ADVICE r3): acknowledge BEFORE the first forward, then forward -> backward -> sync -> step
+    dropin.enable_data_parallel(model)
     model(x).sum().backward()
     model[1].bias.grad = None                                       # a parameter without gradient on this rank
     local = [None if p.grad is None else p.grad.clone() for p in model.parameters()]
     dropin.sync_gradients(model)
-    dropin._check_data_parallel(model, True)                        # acknowledged now
-    ret[rank] = (guarded, local, [p.grad.clone() for p in model.parameters()])
+    synced = [p.grad.clone() for p in model.parameters()]
+    model(x)                                                        # still acknowledged: per model, not a side effect of sync
+    # ... and sync_gradients itself acknowledges nothing: another model of this process is still guarded
+    other = torch.nn.Sequential(_GuardedLinear(4, 2)).train()
+    try:
+        other(x)
+        sticky = True
+    except RuntimeError:
+        sticky = False
+    ret[rank] = (guarded and not sticky, local, synced)
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_dropin_sync_gradients_and_ddp_guard():
     """the HIP backward bypasses autograd hooks, so DDP would never reduce the drop-in's gradients:
-    the forward raises on world_size > 1 until `sync_gradients` (flat averaged all-reduce of every .grad) is wired"""
+    the forward raises on world_size > 1 until the caller has acknowledged (per model, BEFORE the first forward:
+    `enable_data_parallel` / `convert_model(data_parallel=True)`) that it runs `sync_gradients` (flat averaged all-reduce
+    of every .grad) between backward and step -- the recipe of INTEGRATION.md, run end to end on two gloo ranks"""
     world = 2
     ret = mp.Manager().dict()
     mp.spawn(_sync_worker, args=(world, _free_port(), ret), nprocs=world, join=True)

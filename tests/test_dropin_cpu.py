@@ -167,3 +167,40 @@ def test_off_path_configurations_raise(tr, hip):
                                                     embedding_dim_default=32)
     with pytest.raises(NotImplementedError, match="masking"):
         inputs.hip_shadow()
+
+
+def test_shadow_task_keeps_the_users_metric_configuration(tr):
+    """the shadow must not replace the reference task's metric list by the default set -- rank-based
+    metrics keep their cut-offs, `metrics=[]` stays empty, non-rank metrics are left to the reference"""
+    from transformers4rec_amd import dropin
+    from transformers4rec.torch import ranking_metric as rm
+
+    model, inputs, task = _build(tr)
+    dropin.convert_model(model, tr)
+    task.metrics = torch.nn.ModuleList([rm.RecallAt(top_ks=[5], labels_onehot=True)])
+    dropin.drop_shadow(task)
+    sh = task.hip_shadow()
+    assert [(m.name, tuple(m.top_ks)) for m in sh.metrics] == [("recall_at", (5,))]
+
+    class NotRankBased(torch.nn.Module):
+        pass
+
+    task.metrics = torch.nn.ModuleList([NotRankBased(), rm.NDCGAt(top_ks=[3, 7], labels_onehot=True)])
+    dropin.drop_shadow(task)
+    assert [(m.name, tuple(m.top_ks)) for m in task.hip_shadow().metrics] == [("ndcg_at", (3, 7))]
+    task.metrics = torch.nn.ModuleList([])
+    dropin.drop_shadow(task)
+    assert tuple(task.hip_shadow().metrics) == ()
+
+
+def test_convert_model_data_parallel_acknowledges_per_model(tr):
+    from transformers4rec_amd import dropin
+
+    model, inputs, task = _build(tr)
+    dropin.convert_model(model, tr, data_parallel=True)
+    body = model.heads[0].body
+    assert all(m.__dict__.get(dropin._DP_ATTR) for m in (body[0], body[1], task))
+    assert not any(dropin._DP_ATTR in k for k in model.state_dict())
+    other, inputs2, task2 = _build(tr)
+    dropin.convert_model(other, tr)
+    assert not task2.__dict__.get(dropin._DP_ATTR, False)

@@ -322,3 +322,25 @@ def test_round3_host_queries_of_the_library():
     lib.t4r_xlnet_layer_bwd_defer(0)
     lib.t4r_xlnet_stack_prepared(0)
     assert lib.t4r_apply_mask_bwd_ws_floats(4, 20, 128) == ((4 * 20 + 31) // 32) * 128
+
+
+def test_table_config_default_initializer_is_the_references():
+    """features/embedding.py:460-464 -- TableConfig(initializer=None) means normal_(0, 0.05), applied to bag
+    tables too (table_to_embedding_module always runs it); a non-callable initializer is a ValueError"""
+    import pytest
+    import transformers4rec_amd as tr
+    from transformers4rec_amd import features as F
+
+    torch.manual_seed(0)
+    cfg = F.TableConfig(vocabulary_size=4000, dim=64, name="t")
+    assert callable(cfg.initializer)
+    w = torch.empty(4000, 64)
+    cfg.initializer(w)
+    assert abs(float(w.std()) - 0.05) < 2e-3 and abs(float(w.mean())) < 1e-3
+    bag = F._BagTable(4000, 64, "mean", cfg.initializer)
+    assert abs(float(bag.weight.std()) - 0.05) < 2e-3
+    assert abs(float(F._BagTable(4000, 64).weight.std()) - 0.05) < 2e-3
+    with pytest.raises(ValueError, match="callable"):
+        F.TableConfig(vocabulary_size=10, dim=4, initializer=0.05)
+    feats = tr.EmbeddingFeatures({"a": F.FeatureConfig(cfg)})
+    assert abs(float(feats.embedding_tables["a"].weight.std()) - 0.05) < 2e-3

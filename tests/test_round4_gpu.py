@@ -1,0 +1,157 @@
+"""GPU tests of round 4.
+
+  * VERDICT r3 weak #1 / next #1a: the head's weight gradient d W (csrc/head_split.hip; reference chain
+    transformers4rec/torch/model/prediction_task.py:648-671 + CrossEntropyLoss :446 through autograd) checked PER ROW
+    (one row = one item) against fp64 with item norms spread over two decades -- the assertion the norm-wise tests are
+    blind to -- in both kernel forms, with the form that ran asserted through the caller-owned note
+    (include/t4r_hip.h: t4r_head_note, t4r_head_note_dw_form);
+  * the same row-wise check on the item-table gradient of a whole BASELINE configs[1] step, after a few Adam steps and
+    with item norms spread over two decades.
+"""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+BUCKETS = ((1e-1, 1e1), (1e-2, 1e-1), (1e-3, 1e-2), (1e-4, 1e-3), (1e-5, 1e-4), (0.0, 1e-5))
+
+
+def _row_errors(dW, ref):
+    """relative error of every row against ITS OWN largest entry, and the rows' magnitude relative to the largest row"""
+    rmax = ref.abs().amax(dim=1)
+    err = (dW.double() - ref).abs().amax(dim=1) / rmax.clamp_min(1e-300)
+    return err, rmax / rmax.max()
+
+
+def _assert_rowwise(err, rel, tol, what):
+    seen = 0
+    for lo, hi in BUCKETS:
+        m = (rel >= lo) & (rel < hi)
+        n = int(m.sum())
+        if n:
+            seen += 1
+            worst = float(err[m].max())
+            assert worst <= tol, f"{what}: rows with max |row| in [{lo:.0e}, {hi:.0e}) of the largest ({n} rows): " \
+                                 f"relative row error {worst:.2e} > {tol:.0e}"
+    return seen
+
+
+@pytest.mark.parametrize("form", [2, 1])
+def test_head_dw_rows_match_fp64_in_every_magnitude_bucket(form):
+    """N = 2 780 label rows, V = 100 001 items, D = 128 (the shape of BASELINE configs[1]); item norms over two decades,
+    so most items are rare and their gradient rows lie 1e-5 and more below the tensor's largest entry.  form 2: two-way
+    fp16 split with per-item scales (the default when the forward left its column maxima); form 1: three bf16 planes
+    (what runs without a note).  Tolerance: 5e-6 of each ROW's own largest entry."""
+    from transformers4rec_amd import ops
+
+    N, V, D = 2780, 100001, 128
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.randn(N, D, device=DEV, generator=g)
+    W = torch.randn(V, D, device=DEV, generator=g) * (0.05 + 0.45 * torch.rand(V, 1, device=DEV, generator=g) ** 3)
+    labels = torch.randint(0, V, (N,), device=DEV, generator=g)
+    gout = torch.tensor(1.0, device=DEV)
+    ws = ops.head_split_prepare(x, V)
+    logits, _, _, lse = ops.head_split_logits_ce(ws, x, W, labels, ldc=ops.pad_ld(V))
+    p = torch.softmax(logits.double(), dim=1)
+    p[torch.arange(N, device=DEV), labels] -= 1.0
+    ref = (p / N).t() @ x.double()
+    del p
+    if form == 1:      # a fresh (zeroed) note: the backward product knows nothing about the forward
+        ws.t4r_note = (ctypes.c_ulonglong * 8)()
+    assert ops.head_split_dw_form(ws) == 0
+    dW = torch.full((V, D), float("nan"), device=DEV)
+    ops.head_split_dw(ws, logits, lse, labels, gout, V, D, dW, accumulate=False)
+    assert ops.head_split_dw_form(ws) == form, "the d W kernel form that ran is not the one under test"
+    err, rel = _row_errors(dW, ref)
+    assert int((rel < 1e-4).sum()) > V // 4, "the setup must contain many rare-item rows"
+    assert _assert_rowwise(err, rel, 5e-6, f"head d W form {form}") >= 4
+    # accumulate = True adds to what is there, in the same form
+    dW2 = dW.clone()
+    ops.head_split_dw(ws, logits, lse, labels, gout, V, D, dW2, accumulate=True)
+    assert ops.head_split_dw_form(ws) == form
+    err2, _ = _row_errors(dW2 * 0.5, ref)
+    _assert_rowwise(err2, rel, 5e-6, f"head d W form {form} (accumulated)")
+
+
+def test_head_note_is_per_forward_not_process_wide():
+    """more forwards in flight than any ring could hold (gradient accumulation over micro-batches, the chunked head):
+    every backward still finds ITS forward's note -- it travels with the workspace -- and runs the per-item-scale form"""
+    from transformers4rec_amd import ops
+
+    V, D = 20001, 64
+    g = torch.Generator(device=DEV).manual_seed(3)
+    W = torch.randn(V, D, device=DEV, generator=g) * 0.2
+    saved = []
+    for i in range(40):
+        N = 700 + 8 * i
+        x = torch.randn(N, D, device=DEV, generator=g)
+        labels = torch.randint(0, V, (N,), device=DEV, generator=g)
+        ws = ops.head_split_prepare(x, V)
+        logits, _, _, lse = ops.head_split_logits_ce(ws, x, W, labels, ldc=ops.pad_ld(V))
+        saved.append((x, labels, ws, logits, lse))
+    gout = torch.tensor(1.0, device=DEV)
+    for x, labels, ws, logits, lse in saved:
+        dW = torch.empty(V, D, device=DEV)
+        ops.head_split_dw(ws, logits, lse, labels, gout, V, D, dW, accumulate=False)
+        assert ops.head_split_dw_form(ws) == 2
+    x, labels, ws, logits, lse = saved[0]
+    N = x.shape[0]
+    p = torch.softmax(logits.double(), dim=1)
+    p[torch.arange(N, device=DEV), labels] -= 1.0
+    ref = (p / N).t() @ x.double()
+    dW = torch.empty(V, D, device=DEV)
+    ops.head_split_dw(ws, logits, lse, labels, gout, V, D, dW, accumulate=False)
+    err, rel = _row_errors(dW, ref)
+    _assert_rowwise(err, rel, 5e-6, "first of 40 forwards in flight")
+
+
+def test_full_size_table_gradient_rows_after_adam_steps():
+    """BASELINE configs[1] at full size (100 001 x 128 table, 4-layer XLNet, batch 1024 x 20, MLM, tied head, dropout 0):
+    the item table is rescaled so that item norms cover two decades, three Adam steps are taken, then ONE step's table
+    gradient is checked per row.  For items that do not occur in the batch the table gradient IS the head's d W row
+    (the lookup scatter does not touch them): fp64 reference from the step's own logits and head input rows."""
+    import transformers4rec_amd as tr
+
+    torch.manual_seed(0)
+    B, L, V, D = 1024, 20, 100_000, 128
+    schema = tr.session_schema(V, L)
+    inputs = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=L, masking="mlm", embedding_dim_default=D)
+    cfg = tr.XLNetConfig.build(D, 4, 4, total_seq_length=L, dropout=0.0)
+    model = cfg.to_torch_model(inputs, tr.NextItemPredictionTask(weight_tying=True))
+    model.to(DEV)
+    table = model.input_features.item_embedding_table.weight
+    with torch.no_grad():
+        g = torch.Generator(device=DEV).manual_seed(5)
+        table.mul_(1.0 + 99.0 * torch.rand(V + 1, 1, device=DEV, generator=g) ** 3)
+    dense, tables = tr.flatten_model(model)
+    opt = tr.FusedAdam([dense, tables], lr=1e-2)
+    table = model.input_features.item_embedding_table.weight
+    hidden = {}
+    hook = model.transformer_block.register_forward_hook(lambda m, a, out: hidden.__setitem__("h", out.detach()))
+    for step in range(4):
+        data = tr.random_data_from_schema(schema, B, L, seed=20 + step)
+        ids = data["item_id"].to(DEV)
+        out = model({"item_id": ids}, training=True)
+        out["loss"].backward()
+        if step < 3:
+            opt.step()
+    hook.remove()
+    norms = table.detach().norm(dim=1)
+    assert float(norms.max() / norms.min()) > 30.0
+    mask = model.input_features.masking.mask_schema
+    X = hidden["h"][mask].double()                                  # the head's input rows, row-major (b, l) order
+    labels = out["labels"]
+    N = X.shape[0]
+    assert N == labels.shape[0] and N > 2000
+    p = torch.softmax(out["predictions"].detach().double(), dim=1)
+    p[torch.arange(N, device=DEV), labels] -= 1.0
+    ref = (p / N).t() @ X
+    del p
+    absent = torch.ones(V + 1, dtype=torch.bool, device=DEV)
+    absent[ids.flatten()] = False
+    assert int(absent.sum()) > V // 2
+    err, rel = _row_errors(table.grad[absent], ref[absent])
+    assert _assert_rowwise(err, rel, 1e-5, "item-table gradient rows of absent items") >= 2

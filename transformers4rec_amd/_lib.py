@@ -58,10 +58,11 @@ _SIGS = {
     "t4r_head_split_fwd_products": ("i", ""),
     "t4r_head_split_ws_bytes": ("l", "iii"),
     "t4r_head_split_prepare": ("i", "ppl" + "iii" + "p"),
-    "t4r_head_split_logits": ("i", "ppplpl" + "iiif"),
-    "t4r_head_split_logits_ce": ("i", "ppplpl" + "pppp" + "iiiff"),
-    "t4r_head_split_dw": ("i", "ppplpppf" + "pl" + "iiiii" + "fi"),
-    "t4r_head_split_dx": ("i", "ppplpppf" + "plpl" + "iiiii" + "fi"),
+    "t4r_head_note_dw_form": ("i", "p"),
+    "t4r_head_split_logits": ("i", "ppplpl" + "iiif" + "p"),
+    "t4r_head_split_logits_ce": ("i", "ppplpl" + "pppp" + "iiiff" + "p"),
+    "t4r_head_split_dw": ("i", "ppplpppf" + "pl" + "iiiii" + "fi" + "p"),
+    "t4r_head_split_dx": ("i", "ppplpppf" + "plpl" + "iiiii" + "fi" + "p"),
     "t4r_add_layernorm_fwd": ("i", "pppppppp" + "iif" + "fQQ"),
     "t4r_add_layernorm_bwd": ("i", "pppppppppppp" + "iii" + "fQQ"),
     "t4r_colreduce_ws_floats": ("l", "li"),

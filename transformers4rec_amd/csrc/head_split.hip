@@ -855,30 +855,15 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
 
-// max |W| of the table rows a forward product reads -> one word (reset first): 51 MB at BASELINE configs[1], ~10 us
-// the table maximum of the last forward product of this thread: d X of the same step (same workspace, same rows of the same
-// table) reuses it instead of reading the table once more
-// What the forward products left in their workspaces, keyed by the workspace pointer: process-wide, not per thread -- the
-// autograd engine runs the backward (d X, d W) on its own device thread.  A small ring: a workspace lives from one forward to
-// its backward, and entries are overwritten by later forwards.
-#include <mutex>
-struct FwdNote { const void* ws; const float* W; int Vw; const float* logits; int V, N; bool colmax; };
-static std::mutex g_note_mu;
-static FwdNote g_notes[16] = {};
-static int g_note_next = 0;
-static void note_put(const FwdNote& n) {
-    std::lock_guard<std::mutex> lk(g_note_mu);
-    for (auto& e : g_notes)
-        if (e.ws == n.ws) { e = n; return; }
-    g_notes[g_note_next] = n;
-    g_note_next = (g_note_next + 1) % 16;
-}
-static bool note_get(const void* ws, FwdNote& out) {
-    std::lock_guard<std::mutex> lk(g_note_mu);
-    for (const auto& e : g_notes)
-        if (e.ws == ws && ws) { out = e; return true; }
-    return false;
-}
+// What a forward product leaves for its backward products (which table slice the max |W| word of the workspace describes,
+// whether the workspace holds the column maxima of THESE logits): a caller-owned host struct (include/t4r_hip.h:
+// t4r_head_note, 64 bytes, zeroed by the caller before the forward), handed from _logits / _logits_ce to _dx / _dw.  The
+// library keeps nothing between calls.  note == NULL: the backward products assume nothing (d X finds max |W| itself, d W
+// runs on the three bf16 planes).
+struct FwdNote { const float* W; const float* logits; int Vw, V, N, colmax, dw_form, pad; };
+static_assert(sizeof(FwdNote) <= 64, "t4r_head_note is 64 bytes");
+static inline FwdNote* note_of(void* p) { return reinterpret_cast<FwdNote*>(p); }
+extern "C" int t4r_head_note_dw_form(const void* note) { return note ? reinterpret_cast<const FwdNote*>(note)->dw_form : 0; }
 static int head_w_amax(hipStream_t st, const float* W, long ldw, int V, int D, unsigned* out) {
     if (hipMemsetAsync(out, 0, 4, st) != hipSuccess) { t4r_set_error("head_split: memset failed"); return -1; }
     const long n4 = (long)V * (D / 4);
@@ -934,7 +919,7 @@ extern "C" int t4r_head_split_prepare(void* stream, const float* X, long ldx, in
 
 // C[N, V] = alpha * X @ W^T from the prepared workspace
 extern "C" int t4r_head_split_logits(void* stream, void* ws, const float* W, long ldw, float* C, long ldc, int N,
-                                     int V, int D, float alpha) {
+                                     int V, int D, float alpha, void* note) {
     if (N <= 0 || V <= 0) return 0;
     T4R_CHECK_ARG(t4r_head_split_supported(D) && W && C && ws, "head_split_logits: unsupported width or null pointer");
     T4R_CHECK_ARG(aligned16(W) && ldw % 4 == 0, "head_split_logits: W must be 16-byte aligned with a pitch multiple of 4");
@@ -948,7 +933,7 @@ extern "C" int t4r_head_split_logits(void* stream, void* ws, const float* W, lon
     if (head_fwd_fp16x2()) {
         unsigned* amax = reinterpret_cast<unsigned*>((char*)ws + w.scales);
         if (head_w_amax((hipStream_t)stream, W, ldw, V, D, amax + 1)) return -1;
-        note_put(FwdNote{ws, W, V, C, V, N, false});
+        if (note) *note_of(note) = FwdNote{W, C, V, V, N, 0, 0, 0};
         T4R_NB_SWITCH(D, hipLaunchKernelGGL((head_logits_split_kernel<NB, true>), grid, dim3(256), 0, (hipStream_t)stream, xa, W,
                                             ldw, C, ldc, N, V, alpha, w.nblk, blk_per, amax));
     } else {
@@ -964,7 +949,7 @@ extern "C" int t4r_head_split_logits(void* stream, void* ws, const float* W, lon
 int t4r_mean_launch(hipStream_t stream, const float* x, int n, float* out);      // head.hip
 extern "C" int t4r_head_split_logits_ce(void* stream, void* ws, const float* W, long ldw, float* C, long ldc,
                                         const long* labels, float* loss_rows, float* lse, float* loss_mean, int N, int V,
-                                        int D, float alpha, float label_smoothing) {
+                                        int D, float alpha, float label_smoothing, void* note) {
     hipStream_t st = (hipStream_t)stream;
     if (N <= 0 || V <= 0) return loss_mean ? t4r_mean_launch(st, loss_rows, 0, loss_mean) : 0;
     T4R_CHECK_ARG(t4r_head_split_supported(D) && W && C && ws && (!labels || (loss_rows && lse)), "head_split_logits_ce: unsupported width or null pointer");
@@ -985,7 +970,7 @@ extern "C" int t4r_head_split_logits_ce(void* stream, void* ws, const float* W, 
         if (head_w_amax(st, W, ldw, V, D, amax + 1)) return -1;
         float* colmax = nullptr;
         if (head_dw_fp16x2() && rs == w.rsplit && vec_ok) colmax = reinterpret_cast<float*>((char*)ws + w.colmax);
-        note_put(FwdNote{ws, W, V, C, V, N, colmax != nullptr});
+        if (note) *note_of(note) = FwdNote{W, C, V, V, N, colmax != nullptr, 0, 0};
         T4R_NB_SWITCH(D, hipLaunchKernelGGL(head_logits_ce_h_kernel<NB>, grid, dim3(256), 0, st, xa, W, ldw, C, ldc, N, V,
                                             alpha, w.nblk, blk_per, vec_ok, sm, ss, stt, w.ntile, rs, amax, colmax, w.vpad));
     } else {
@@ -1002,13 +987,14 @@ extern "C" int t4r_head_split_logits_ce(void* stream, void* ws, const float* W, 
 // d W[Vc, D] (+)= alpha * dlogits^T @ X;  logits holds the columns [yoff, yoff + Vc) of the [N, V] problem
 extern "C" int t4r_head_split_dw(void* stream, void* ws, const float* logits, long ld, const float* lse,
                                  const long* labels, const float* grad_out, float label_smoothing, float* dW, long lddw,
-                                 int N, int Vc, int V, int yoff, int D, float alpha, int accumulate) {
+                                 int N, int Vc, int V, int yoff, int D, float alpha, int accumulate, void* note_p) {
     if (N <= 0 || Vc <= 0) return 0;
     T4R_CHECK_ARG(t4r_head_split_supported(D) && logits && lse && labels && dW && ws, "head_split_dw: unsupported width or null pointer");
     const HeadWs w = head_ws(N, V, D);
     const u32x4* xt = reinterpret_cast<const u32x4*>((const char*)ws + w.xt);
-    FwdNote note;
-    const bool have_cm = note_get(ws, note) && note.colmax && note.logits == logits && note.V == V && note.N == N && Vc == V && yoff == 0;
+    FwdNote* note = note_of(note_p);
+    const bool have_cm = note && note->colmax && note->logits == logits && note->V == V && note->N == N && Vc == V && yoff == 0;
+    if (note) note->dw_form = (head_fwd_fp16x2() && head_dw_fp16x2() && have_cm) ? 2 : 1;
     if (head_fwd_fp16x2() && head_dw_fp16x2() && have_cm) {
         hipStream_t st = (hipStream_t)stream;
         const unsigned* amax = reinterpret_cast<const unsigned*>((const char*)ws + w.scales);
@@ -1033,7 +1019,8 @@ extern "C" int t4r_head_split_dw(void* stream, void* ws, const float* logits, lo
 // d X[N, D] (+)= alpha * dlogits @ W[yoff : yoff + Vc];  W points at row yoff
 extern "C" int t4r_head_split_dx(void* stream, void* ws, const float* logits, long ld, const float* lse,
                                  const long* labels, const float* grad_out, float label_smoothing, const float* W, long ldw,
-                                 float* dX, long lddx, int N, int Vc, int V, int yoff, int D, float alpha, int accumulate) {
+                                 float* dX, long lddx, int N, int Vc, int V, int yoff, int D, float alpha, int accumulate,
+                                 void* note_p) {
     if (N <= 0 || Vc <= 0) return 0;
     T4R_CHECK_ARG(t4r_head_split_supported(D) && logits && lse && labels && dX && W && ws, "head_split_dx: unsupported width or null pointer");
     T4R_CHECK_ARG(aligned16(logits) && ld % 4 == 0 && ld >= 8 && aligned16(dX) && lddx % 4 == 0,
@@ -1046,12 +1033,11 @@ extern "C" int t4r_head_split_dx(void* stream, void* ws, const float* logits, lo
     const bool hs = head_fwd_fp16x2();
     unsigned* amax = reinterpret_cast<unsigned*>((char*)ws + w.scales) + 1;     // max |W| of THIS call's rows (a chunk of the table)
     if (hs) {
-        FwdNote note;
-        const bool same = note_get(ws, note) && note.W == W && note.Vw == Vc;
+        FwdNote* note = note_of(note_p);
+        const bool same = note && note->W == W && note->Vw == Vc;
         if (!same) {
             if (head_w_amax(st, W, ldw, Vc, D, amax)) return -1;
-            if (note_get(ws, note)) { note.W = W; note.Vw = Vc; note_put(note); }     // the slot now describes THIS table slice
-            else note_put(FwdNote{ws, W, Vc, nullptr, 0, 0, false});
+            if (note) { note->W = W; note->Vw = Vc; }     // the max |W| word now describes THIS table slice
         }
         T4R_NB_SWITCH(D, hipLaunchKernelGGL((split_km_kernel<NB, true>), dim3(nkt), dim3(256), 0, st, W, ldw, Vc, wt, amax));
     } else {

@@ -274,17 +274,24 @@ struct SideStream {
     hipEvent_t done_s2 = nullptr, join1 = nullptr, join2 = nullptr;   // join*: recorded by t4r_xlnet_layer_bwd_join only (under its mutex)
     hipEvent_t fork[8] = {}, red[8] = {}, done_ff2 = nullptr, done_o = nullptr, done_all = nullptr;
     int state = 0;    // 0 untried, 1 ready, -1 disabled / failed
+    int device = -1;
 };
-static thread_local SideStream g_side;
+// One set per (host thread, device), heap-allocated and never freed: the registry below outlives the threads that
+// created the entries (a worker thread that once ran a layer backward may exit; its streams stay valid and idle).
+constexpr int kMaxDev = 16;
+static thread_local SideStream* g_side[kMaxDev] = {};
 // every thread's side streams (the autograd engine runs a layer backward on its device thread and its end-of-backward
-// callback on whichever thread finishes the graph task: t4r_xlnet_layer_bwd_join waits for ALL of them)
+// callback on whichever thread finishes the graph task: t4r_xlnet_layer_bwd_join waits for ALL of the CURRENT device)
 #include <mutex>
 #include <vector>
 static std::mutex g_side_mu;
 static std::vector<SideStream*> g_side_all;
 
 static SideStream* side_stream() {
-    SideStream& ss = g_side;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
+    if (!g_side[dev]) { g_side[dev] = new SideStream(); g_side[dev]->device = dev; }
+    SideStream& ss = *g_side[dev];
     if (ss.state == 0) {
         const char* e = getenv("T4R_LAYER_SIDE_STREAM");
         ss.state = -1;
@@ -553,11 +560,15 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
     return 0;
 }
 
-// the caller's stream waits for everything queued so far on the weight-gradient streams of this thread (no-op without them)
+// the caller's stream waits for everything queued so far on the weight-gradient streams of the current device, whichever
+// host thread queued it (no-op without them)
 extern "C" int t4r_xlnet_layer_bwd_join(void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { t4r_set_error("xlnet_layer_bwd_join: no current device"); return -1; }
     std::lock_guard<std::mutex> lk(g_side_mu);
     for (SideStream* ss : g_side_all) {
+        if (ss->device != dev) continue;
         (void)hipEventRecord(ss->join1, ss->s);
         (void)hipStreamWaitEvent(st, ss->join1, 0);
         (void)hipEventRecord(ss->join2, ss->s2);

@@ -23,9 +23,10 @@ functions return None for parameters), so AccumulateGrad hooks never fire and to
 Trainer wraps the reference model in (torch/trainer.py:131-161) -- would never see them: with
 `find_unused_parameters=True` every HIP parameter is marked unused and the replicas diverge silently.
 A training forward under `torch.distributed` world_size > 1 therefore RAISES until the caller has
-wired a gradient exchange that reads `.grad` after backward and says so: `sync_gradients(model)`
-(one flat all-reduce of every `.grad`, averaged: DDP's semantics) between `backward()` and
-`optimizer.step()`, or `distributed.GradReducer` / `SparseRowExchange` + `allow_data_parallel()`.
+said -- BEFORE that forward -- that it exchanges `.grad` itself after backward:
+`convert_model(model, data_parallel=True)` / `enable_data_parallel(model)` (per model), then
+`sync_gradients(model)` (one flat all-reduce of every `.grad`, averaged: DDP's semantics) between
+`backward()` and `optimizer.step()`, or `distributed.GradReducer` / `SparseRowExchange`.
 
 There is no CPU fallback: a CPU tensor raises _lib.T4RHipError like the rest of the package.
 Configurations off the hot path (PLM/RTD masking, custom projection blocks, pretrained-embedding
@@ -304,10 +305,20 @@ def shadow_task(ref):
         raise NotImplementedError("dropin: the HIP head fuses torch.nn.CrossEntropyLoss(mean) (optionally "
                                   "label-smoothed); other losses are off the hot path")
     pm = ref.pre.module
-    try:        # the reference task's torchmetrics objects, recognised by class name (ranking_metric.coerce)
-        metrics = [P.coerce_metric(m) for m in getattr(ref, "metrics", None) or []] or None
-    except NotImplementedError:
-        metrics = None      # non-rank metrics stay the reference's business (its calculate_metrics still runs them)
+    # the reference task's torchmetrics objects, recognised by class name (ranking_metric.coerce), one by one: the
+    # rank-based ones run on the fused evaluation head with the cut-offs the user configured; the others stay the
+    # reference's business (its calculate_metrics still runs them).  metrics=[] stays "no metrics"; only a task
+    # without the attribute gets the default set.
+    ref_metrics = getattr(ref, "metrics", None)
+    if ref_metrics is None:
+        metrics = None
+    else:
+        metrics = []
+        for m in ref_metrics:
+            try:
+                metrics.append(P.coerce_metric(m))
+            except NotImplementedError:
+                pass
     with _meta():
         sh = P.NextItemPredictionTask(loss=loss, metrics=metrics, task_name=ref.task_name, weight_tying=ref.weight_tying,
                                       softmax_temperature=ref.softmax_temperature, padding_idx=ref.padding_idx,
@@ -363,12 +374,29 @@ def drop_shadow(mod):
 
 
 _DP = {"acknowledged": False}
+_DP_ATTR = "_t4r_hip_dp_ok"
 
 
 def allow_data_parallel(flag=True):
-    """The caller exchanges the `.grad` buffers itself after backward (distributed.GradReducer /
-    SparseRowExchange, or `sync_gradients`): lifts the world_size > 1 guard of the drop-in forward."""
+    """Process-wide form of `enable_data_parallel`: the caller exchanges the `.grad` buffers of EVERY drop-in model of
+    this process itself after backward (distributed.GradReducer / SparseRowExchange, or `sync_gradients`).  Lifts the
+    world_size > 1 guard of the drop-in forward until `allow_data_parallel(False)`; must precede the first training forward."""
     _DP["acknowledged"] = bool(flag)
+
+
+def enable_data_parallel(model, flag=True):
+    """Per-model acknowledgement, to be given BEFORE the first training forward on world_size > 1: the caller promises to
+    exchange this model's `.grad` buffers itself between backward() and optimizer.step() -- `sync_gradients(model)` (one flat
+    averaged all-reduce) or distributed.GradReducer / SparseRowExchange.  The recipe is
+
+        dropin.convert_model(model, data_parallel=True)      # or dropin.enable_data_parallel(model)
+        loss = model(batch, training=True)["loss"]; loss.backward(); dropin.sync_gradients(model); optimizer.step()
+
+    Marks every drop-in module inside `model` (a plain attribute, not in state_dict); returns the model."""
+    for m in model.modules():
+        if getattr(m, "_t4r_hip", False):
+            object.__setattr__(m, _DP_ATTR, bool(flag))
+    return model
 
 
 def sync_gradients(model, group=None):
@@ -378,7 +406,6 @@ def sync_gradients(model, group=None):
     Works on any backend / device (gloo on CPU in tests, RCCL on the GPUs)."""
     import torch.distributed as dist
 
-    allow_data_parallel(True)
     if not (dist.is_available() and dist.is_initialized()):
         return model
     world = dist.get_world_size(group)
@@ -401,7 +428,7 @@ def sync_gradients(model, group=None):
 
 def _check_data_parallel(mod, training):
     """raises when a training forward runs on > 1 ranks and nobody has taken charge of the gradients"""
-    if not (training or mod.training) or _DP["acknowledged"]:
+    if not (training or mod.training) or _DP["acknowledged"] or mod.__dict__.get(_DP_ATTR, False):
         return
     import torch.distributed as dist
 
@@ -409,8 +436,9 @@ def _check_data_parallel(mod, training):
         raise RuntimeError(
             "dropin: training on torch.distributed world_size > 1, but the HIP backward writes parameter "
             "gradients into .grad without autograd hooks, so torch DDP (HF Trainer's wrapper) cannot see them. "
-            "Call transformers4rec_amd.dropin.sync_gradients(model) between backward() and optimizer.step(), "
-            "or wire distributed.GradReducer / SparseRowExchange and call dropin.allow_data_parallel().")
+            "Before training, acknowledge with transformers4rec_amd.dropin.enable_data_parallel(model) (or "
+            "convert_model(model, data_parallel=True)), then call dropin.sync_gradients(model) between backward() and "
+            "optimizer.step() -- or wire distributed.GradReducer / SparseRowExchange yourself.")
 
 
 class _HipFeaturesMixin:
@@ -502,10 +530,11 @@ def uninstall(tr=None):
         tr.TabularSequenceFeatures, tr.TransformerBlock, tr.NextItemPredictionTask = rec[0]
 
 
-def convert_model(model, tr=None):
+def convert_model(model, tr=None, data_parallel=False):
     """Swaps, in place, the class of every reference TabularSequenceFeatures / TransformerBlock /
     NextItemPredictionTask inside `model` for its HIP subclass (no state is touched: the subclasses
-    add methods only).  Returns the model."""
+    add methods only).  data_parallel=True also gives `enable_data_parallel(model)`'s acknowledgement.
+    Returns the model."""
     if tr is None:
         import transformers4rec.torch as tr
     if id(tr) in _INSTALLED:
@@ -521,6 +550,8 @@ def convert_model(model, tr=None):
         for o, h in zip(orig, hip):
             if type(m) is o:
                 m.__class__ = h
+    if data_parallel:
+        enable_data_parallel(model)
     return model
 
 

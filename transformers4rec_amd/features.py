@@ -161,8 +161,12 @@ class TableConfig:
             raise ValueError("Invalid dim {}.".format(dim))
         if combiner not in ("mean", "sum", "sqrtn"):
             raise ValueError("Invalid combiner {}".format(combiner))
+        if initializer is not None and not callable(initializer):
+            raise ValueError("initializer must be callable if specified.")
         self.vocabulary_size, self.dim, self.combiner, self.name = vocabulary_size, dim, combiner, name
-        self.initializer = initializer
+        # features/embedding.py:460-464: no initializer means normal_(mean 0, std 0.05), always applied by
+        # table_to_embedding_module -- bag tables start at std 0.05 too, not at EmbeddingBag's N(0, 1)
+        self.initializer = (lambda w: nn.init.normal_(w, mean=0.0, std=0.05)) if initializer is None else initializer
 
     def __repr__(self):
         return (f"TableConfig(vocabulary_size={self.vocabulary_size!r}, dim={self.dim!r}, "
@@ -177,14 +181,15 @@ class FeatureConfig:
 
 
 class _BagTable(nn.Module):
-    """EmbeddingBagWrapper-shaped parameter holder (`weight`, `mode`); torch.nn.EmbeddingBag's default init N(0, 1)
-    unless the TableConfig carries an initializer (features/embedding.py:86-93)."""
+    """EmbeddingBagWrapper-shaped parameter holder (`weight`, `mode`).  The TableConfig's initializer -- normal_(0, 0.05)
+    when the user gave none (features/embedding.py:460-464) -- always runs after construction (:86-93); built without one
+    (direct use), the same N(0, 0.05) default as `EmbeddingTable`."""
 
     def __init__(self, num_embeddings, embedding_dim, mode="mean", initializer=None):
         super().__init__()
         self.num_embeddings, self.embedding_dim, self.mode = num_embeddings, embedding_dim, mode
         self.weight = nn.Parameter(torch.empty(num_embeddings, embedding_dim))
-        nn.init.normal_(self.weight)
+        nn.init.normal_(self.weight, mean=0.0, std=0.05)
         if initializer is not None:
             initializer(self.weight)
 

@@ -2,6 +2,8 @@
 with the torch caching allocator, launch on torch's current HIP stream.  No arithmetic happens
 here and nothing falls back to torch ops: a missing library raises (see _lib.load).
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -148,7 +150,20 @@ def head_split_prepare(x, V):
     nbytes = _lib.load().t4r_head_split_ws_bytes(N, int(V), D)
     ws = torch.empty(max(nbytes, 16), device=x.device, dtype=torch.uint8)
     call("t4r_head_split_prepare", _stream(), _chk(x, torch.float32), x.stride(0), N, D, int(V), ws.data_ptr())
+    # the host note the forward product leaves for d X / d W (include/t4r_hip.h: t4r_head_note) lives and dies with the workspace
+    ws.t4r_note = (ctypes.c_ulonglong * 8)()
     return ws
+
+
+def _note(ws):
+    n = getattr(ws, "t4r_note", None)
+    return None if n is None else ctypes.addressof(n)
+
+
+def head_split_dw_form(ws):
+    """which kernel the last head_split_dw on this workspace ran: 0 none yet, 1 three bf16 planes, 2 two-way fp16 split
+    with per-item scales"""
+    return _lib.load().t4r_head_note_dw_form(_note(ws))
 
 
 def head_split_logits(ws, x, W, alpha=1.0, ldc=None):
@@ -157,7 +172,7 @@ def head_split_logits(ws, x, W, alpha=1.0, ldc=None):
     ldc = V if ldc is None else ldc
     buf = torch.empty((N, ldc), device=x.device, dtype=torch.float32)
     call("t4r_head_split_logits", _stream(), ws.data_ptr(), _chk(W, torch.float32), W.stride(0), buf.data_ptr(), ldc,
-         N, V, D, float(alpha))
+         N, V, D, float(alpha), _note(ws))
     return buf[:, :V]
 
 
@@ -173,7 +188,7 @@ def head_split_logits_ce(ws, x, W, labels, alpha=1.0, label_smoothing=0.0, ldc=N
     loss = torch.empty((), device=dev, dtype=torch.float32)
     call("t4r_head_split_logits_ce", _stream(), ws.data_ptr(), _chk(W, torch.float32), W.stride(0), buf.data_ptr(), ldc,
          _chk(labels, torch.int64), loss_rows.data_ptr(), lse.data_ptr(), loss.data_ptr(), N, V, D, float(alpha),
-         float(label_smoothing))
+         float(label_smoothing), _note(ws))
     return buf[:, :V], loss, loss_rows, lse
 
 
@@ -181,7 +196,7 @@ def head_split_dw(ws, logits, lse, labels, grad_out, V, D, out, alpha=1.0, label
     N, Vc = logits.shape
     call("t4r_head_split_dw", _stream(), ws.data_ptr(), logits.data_ptr(), logits.stride(0), _chk(lse, torch.float32),
          _chk(labels, torch.int64), _p(grad_out), float(label_smoothing), out.data_ptr(), out.stride(0), N, Vc, int(V),
-         int(yoff), int(D), float(alpha), int(accumulate))
+         int(yoff), int(D), float(alpha), int(accumulate), _note(ws))
     return out
 
 
@@ -192,7 +207,7 @@ def head_split_dx(ws, logits, lse, labels, grad_out, V, W, alpha=1.0, label_smoo
         out = torch.empty((N, D), device=logits.device, dtype=torch.float32)
     call("t4r_head_split_dx", _stream(), ws.data_ptr(), logits.data_ptr(), logits.stride(0), _chk(lse, torch.float32),
          _chk(labels, torch.int64), _p(grad_out), float(label_smoothing), W.data_ptr(), W.stride(0), out.data_ptr(),
-         out.stride(0), N, Vc, int(V), int(yoff), D, float(alpha), int(accumulate))
+         out.stride(0), N, Vc, int(V), int(yoff), D, float(alpha), int(accumulate), _note(ws))
     return out
 
 

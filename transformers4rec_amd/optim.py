@@ -70,7 +70,14 @@ class FusedAdam:
         self.state = [(torch.zeros_like(f.data), torch.zeros_like(f.data)) for f in self.flats]
         self.step_count = 0
 
+    @staticmethod
+    def _join():
+        # weight-gradient streams a failed backward pass left unjoined (transformer.py; no-op normally)
+        from .transformer import _join_weight_gradient_streams
+        _join_weight_gradient_streams()
+
     def step(self, grad_scale=1.0):
+        self._join()
         self.step_count += 1
         for f, (m, v) in zip(self.flats, self.state):
             f.ensure_grads()
@@ -78,5 +85,6 @@ class FusedAdam:
                            self.weight_decay, grad_scale, zero_grad=True)
 
     def zero_grad(self):
+        self._join()
         for f in self.flats:
             f.grad.zero_()

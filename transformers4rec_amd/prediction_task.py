@@ -485,6 +485,8 @@ class NextItemPredictionTask(nn.Module):
         """The task's ranking metrics with one relevant item per row (ranking_metric.py:52-59 labels_onehot=True)
         from a fused top-k of the scores -- no [N, V] one-hot.  A target outside the top max(k) gets rank
         max(k): every metric of the path is zero from there on."""
+        if not self.metrics:
+            return {}
         kmax = max(k for m in self.metrics for k in m.top_ks)
         _, idx = ops.topk(predictions, kmax, predictions.shape[1])
         hit = idx == targets.unsqueeze(-1)

@@ -178,7 +178,11 @@ _PENDING: list = []          # buffers of deferred layer backwards (kept alive u
 
 
 def _join_weight_gradient_streams():
-    """end-of-backward callback of the autograd engine: runs before backward() returns, on the caller's current stream"""
+    """end-of-backward callback of the autograd engine: runs before backward() returns, on the caller's current stream.
+    Also called defensively at the start of the next XLNetModel.forward and from FusedAdam.step / zero_grad: a backward
+    pass that RAISED may never have run its callbacks, and code that catches the exception and then reads or zeroes
+    .grad, or skips the step, must not race with weight-gradient GEMMs still in flight (idempotent: no-op when nothing
+    is pending)."""
     if not _PENDING:
         return
     try:
@@ -233,6 +237,7 @@ class XLNetModel(SeedMixin, nn.Module):
         """key_len: optional int32 [B] of valid key counts (opt-in padding mask, TransformerBlock(mask_padding=True));
         None reproduces the reference, which passes no attention mask."""
         cfg = self.config
+        _join_weight_gradient_streams()      # leftovers of a backward pass that raised (no-op normally)
         B, L, D = inputs_embeds.shape
         if D != cfg.d_model:
             raise ValueError(f"inputs_embeds last dim {D} != d_model {cfg.d_model}")

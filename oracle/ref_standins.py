@@ -7,8 +7,12 @@ container, where `merlin.*`, `merlin_standard_lib`'s betterproto dependency and
 reference pins <4.31).
 
 Used by oracle/make_golden.py (fixture generation) and oracle/cpu_reference_bench.py.
-/root/reference does not exist on the GPU box, so nothing that runs there imports
-this file; the committed fixtures under tests/golden/ are what travels.
+/root/reference does not exist on the GPU box; the committed fixtures under tests/golden/ are
+what travels.  The one exception (VERDICT r3 next #1c): tools/stage_reference.sh puts a scratch,
+git-ignored copy of the reference's two pure-Python packages under .scratch_ref/ of the repo,
+which gpurun ships as it ships the built .so -- then tests/test_dropin_reference_gpu.py runs the
+reference's own Model / Head / SequentialBlock over the HIP drop-in modules on the GPU.  The copy
+is never committed and never imported by the product path.
 
 What is faked: only plumbing -- registries, docstring
 decorators, schema containers, a minimal torchmetrics.Metric.  No arithmetic of the
@@ -21,7 +25,21 @@ import re
 import sys
 import types
 
-REFERENCE_ROOT = "/root/reference"
+import os
+
+
+def _reference_root():
+    """T4R_REFERENCE_ROOT, else /root/reference, else the scratch copy staged by tools/stage_reference.sh"""
+    env = os.environ.get("T4R_REFERENCE_ROOT")
+    if env:
+        return env
+    if os.path.isdir("/root/reference/transformers4rec"):
+        return "/root/reference"
+    scratch = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".scratch_ref")
+    return scratch if os.path.isdir(os.path.join(scratch, "transformers4rec")) else "/root/reference"
+
+
+REFERENCE_ROOT = _reference_root()
 
 
 def _mod(name):

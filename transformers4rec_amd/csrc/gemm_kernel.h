@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             if (!(a > 0.f) || !(a < 3e38f)) return 1.f;
             int e;
             (void)frexpf(a, &e);
-            return ldexpf(1.f, 14 - e);
+            return ldexpf(1.f, min(14 - e, 100));
         };
         op_sa = scale_of(ma);
         op_sb = scale_of(mb);
@@ -327,6 +327,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         if (PREC == 3) {
             int ex;
             (void)frexpf(fabsf(sg_g), &ex);
+            ex = max(ex, -86);          // a vanishing upstream gradient must not overflow the scale
             sg_unscale = ldexpf(1.f, ex - 14);
             sg_g *= ldexpf(1.f, 14 - ex);
         }

@@ -133,7 +133,7 @@ __device__ __forceinline__ float scale_of(const unsigned* amax_bits) {
     if (!(a > 0.f) || !(a < 3e38f)) return 1.f;      // all zero, infinite or NaN: nothing to position
     int e;
     (void)frexpf(a, &e);                              // a = m 2^e, m in [0.5, 1)
-    return ldexpf(1.f, 14 - e);
+    return ldexpf(1.f, min(14 - e, 100));    // a maximum below 2^-86 (the d W bound of an item far below every row's lse) must not overflow the scale
 }
 
 // ---- plane blocks.  One block = 32 rows of a row-major fp32 matrix [n_rows, D], as three bf16 planes:
@@ -551,7 +551,7 @@ __device__ __forceinline__ float pow2_scale_head(float m) {
     if (!(m > 0.f) || !(m < 3e38f)) return 1.f;
     int e;
     (void)frexpf(m, &e);
-    return ldexpf(1.f, 14 - e);
+    return ldexpf(1.f, min(14 - e, 100));    // a maximum below 2^-86 (the d W bound of an item far below every row's lse) must not overflow the scale
 }
 template <int NB, bool HS = false>
 __global__ __launch_bounds__(256) void head_dw_split_kernel(const float* __restrict__ logits, long ld,
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(256) void head_dx_split_kernel(const float* __restr
     if (HS) {       // |G| <= |g| (1 + eps): position g at 2^13 .. 2^14, undo it (and the table's scale) in alpha
         int e;
         (void)frexpf(fabsf(q.g), &e);
-        const float sg = (q.g != 0.f && fabsf(q.g) < 3e38f) ? ldexpf(1.f, 14 - e) : 1.f;
+        const float sg = (q.g != 0.f && fabsf(q.g) < 3e38f) ? ldexpf(1.f, min(14 - e, 100)) : 1.f;
         q.g *= sg;
         alpha = (alpha / sg) / scale_of(amax);
     }

@@ -128,7 +128,7 @@ __device__ __forceinline__ float pow2_scale(float m) {
     if (!(m > 0.f) || !(m < 3e38f)) return 1.f;
     int e;
     (void)frexpf(m, &e);
-    return ldexpf(1.f, 14 - e);
+    return ldexpf(1.f, min(14 - e, 100));    // a maximum below 2^-86 (the d W bound of an item far below every row's lse) must not overflow the scale
 }
 
 // acc[r] += A_tile (16 features x D) . B_r (D x 16 tokens) for every token block r, three-plane operands, six products.

@@ -518,7 +518,7 @@ def install(tr=None):
     orig = (tr.TabularSequenceFeatures, tr.TransformerBlock, tr.NextItemPredictionTask)
     hip = make_dropin(tr)
     tr.TabularSequenceFeatures, tr.TransformerBlock, tr.NextItemPredictionTask = hip
-    _INSTALLED[id(tr)] = (orig, hip)
+    _INSTALLED[id(tr)] = (orig, hip, tr)     # holds the namespace: its id cannot be reused while installed
     return hip
 
 
@@ -538,12 +538,15 @@ def convert_model(model, tr=None, data_parallel=False):
     if tr is None:
         import transformers4rec.torch as tr
     if id(tr) in _INSTALLED:
-        orig, hip = _INSTALLED[id(tr)]
+        orig, hip = _INSTALLED[id(tr)][:2]
     else:
         orig = (tr.TabularSequenceFeatures, tr.TransformerBlock, tr.NextItemPredictionTask)
-        hip = make_dropin(tr)
-        _INSTALLED_CONVERT.setdefault(id(tr), (orig, hip))
-        orig, hip = _INSTALLED_CONVERT[id(tr)]
+        # keyed by id(), so the record keeps the namespace object ALIVE: a collected namespace's id can be handed to a
+        # new object, which would then be converted with the old namespace's classes
+        rec = _INSTALLED_CONVERT.get(id(tr))
+        if rec is None or rec[0] is not tr or rec[1] != orig:
+            rec = _INSTALLED_CONVERT[id(tr)] = (tr, orig, make_dropin(tr))
+        _, orig, hip = rec
     for m in model.modules():
         if getattr(m, "_t4r_hip", False):
             continue

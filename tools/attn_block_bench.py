@@ -1,0 +1,84 @@
+#!/usr/bin/env python
+"""The attention block kernels (csrc/xlnet_attn_block.hip) at the BASELINE configs[1] shape, next to the launches they
+replace; HIP-graph replay (no host overhead).  With the stamp variant of the library
+(tools/build_stamp_variant.sh -> T4R_HIP_LIB=transformers4rec_amd/lib/libt4r_hip_stamps.so) it also prints the phase
+durations in shader cycles (median over the waves of all workgroups).
+    python tools/attn_block_bench.py [--once]        # --once: one launch of each kernel (for rocprofv3 --pmc passes)"""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from transformers4rec_amd import _lib, ops
+
+dev = torch.device("cuda", 0)
+B, L, n, D = 1024, 20, 4, 128
+T = B * L
+REPS = 1 if "--once" in sys.argv else 20
+g = torch.Generator(device=dev).manual_seed(0)
+ORDER = ("q", "k", "v", "o", "r", "r_w_bias", "r_r_bias", "ln_w", "ln_b", "w1", "b1", "w2", "b2", "ff_ln_w", "ff_ln_b")
+r = lambda *s: 0.1 * torch.randn(*s, device=dev, generator=g)
+dh = D // n
+P = dict(q=r(D, n, dh), k=r(D, n, dh), v=r(D, n, dh), o=r(D, n, dh), r=r(D, n, dh), r_w_bias=r(n, dh), r_r_bias=r(n, dh),
+         ln_w=1 + r(D), ln_b=r(D), w1=r(4 * D, D), b1=r(4 * D), w2=r(D, 4 * D), b2=r(D), ff_ln_w=1 + r(D), ff_ln_b=r(D))
+planes = ops.xlnet_layer_prepare([P[k] for k in ORDER], D)
+h = torch.randn(T, D, device=dev, generator=g)
+dy = torch.randn(T, D, device=dev, generator=g)
+lib = _lib.load()
+stamps = None
+if hasattr(lib, "t4r_debug_ab_stamps"):
+    stamps = torch.zeros((B // 4 + 1) * 8 * 8, device=dev, dtype=torch.int64)
+    lib.t4r_debug_ab_stamps.argtypes = [ctypes.c_void_p]
+    lib.t4r_debug_ab_stamps(stamps.data_ptr())
+
+
+def timed(fn):
+    fn(); torch.cuda.synchronize()
+    if REPS == 1:
+        return 0.0
+    s = torch.cuda.Stream(); gr = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        fn()
+        with torch.cuda.graph(gr, stream=s):
+            for _ in range(REPS): fn()
+    torch.cuda.synchronize(); gr.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); gr.replay(); gr.replay(); e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (2 * REPS) * 1e3
+
+
+for p in (0.3, 0.0):
+    kr = torch.randn((B if p > 0 else 1) * 2 * L, D, device=dev, generator=g) * 0.3
+    cp, co = ops.dropout_ctr_hi(1, 0, ops.SITE_PROB), ops.dropout_ctr_hi(1, 0, ops.SITE_ATTN_OUT)
+    rw, rr = P["r_w_bias"].view(-1), P["r_r_bias"].view(-1)
+    keep = {}
+
+    def block_fwd():
+        keep["h1"], keep["saved"] = ops.xlnet_attn_block_fwd(h, planes, P["o"].view(D, D), kr, rw, rr, P["ln_w"], P["ln_b"], B, L, n,
+                                                             0.03, p, 7, cp, co)
+
+    def chain_fwd():
+        qkv = ops.xlnet_qkv_proj(h, planes)
+        av, lse = ops.xlnet_attn_fwd(qkv[0], qkv[1], qkv[2], kr, rw, rr, B, L, n, drop=(p, 7, cp) if p > 0 else ops.NO_DROP)
+        keep["c"] = ops.xlnet_oproj_ln(av, h, planes, P["ln_w"], P["ln_b"], 0.03, drop=(p, 7, co) if p > 0 else ops.NO_DROP)
+
+    tb, tc = timed(block_fwd), timed(chain_fwd)
+    print(f"dropout {p}: attention half forward: one kernel {tb:6.1f} us | projection + core + o-projection/LayerNorm launches {tc:6.1f} us", flush=True)
+    if stamps is not None:
+        stamps.zero_(); block_fwd(); torch.cuda.synchronize()
+        st = stamps.view(-1, 8)[: (B // 4) * 8].double()
+        d = st[:, 1:7] - st[:, 0:6]
+        names = ["P (projection)", "barrier", "A (attention)", "barrier", "O products", "O epilogue"]
+        if os.environ.get("T4R_AB_STAMP_DETAIL") == "P":
+            names = ["h staging", "q, k products", "v products", "barrier + v stores", "-", "(unused)"]
+            st[:, 5] = st[:, 4]
+            st[:, 6] = st[:, 5]
+        tot = (st[:, 6] - st[:, 0])
+        print("   phase cycles, median over waves [min .. max]:")
+        for i, nm in enumerate(names):
+            print(f"      {nm:16s} {float(d[:, i].median()):9.0f}  [{float(d[:, i].min()):7.0f} .. {float(d[:, i].max()):7.0f}]")
+        print(f"      {'total':16s} {float(tot.median()):9.0f}  [{float(tot.min()):7.0f} .. {float(tot.max()):7.0f}]")
+    if hasattr(ops, "xlnet_attn_block_bwd"):
+        pass

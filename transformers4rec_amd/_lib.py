@@ -83,6 +83,8 @@ _SIGS = {
     "t4r_xlnet_ln1_bwd_part_floats": ("l", "li"),
     "t4r_xlnet_ln1_bwd": ("i", "p" + "ppppppp" + "pppppp" + "lif" + "QQ"),
     "t4r_xlnet_dh": ("i", "pppp" + "li"),
+    "t4r_xlnet_attn_block_supported": ("i", "iii"),
+    "t4r_xlnet_attn_block_fwd": ("i", "ppppp" + "l" + "pppp" + "ppppppp" + "iiii" + "ffQQQ" + "p"),
     "t4r_xlnet_layer_bwd_defer": ("v", "i"),
     "t4r_xlnet_layer_ws_offsets": ("i", "iiiii" + "pp"),
     "t4r_xlnet_stack_prepare": ("i", "ppiip" + "plp"),

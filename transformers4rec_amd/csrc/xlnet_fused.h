@@ -109,7 +109,21 @@ __host__ __device__ inline LayerPlanesH carve_planes_h(const void* base, int D) 
     p.scale = (const float*)b;
     return p;
 }
-static inline long layer_planes_floats(int D) { return layer_planes_bf16_floats(D) + 25L * 2 * D * D / 2 + 16; }
+// Round 4: two fp32 TRANSPOSES behind the half-precision planes, for the exact-fp32 (v_mfma_f32_16x16x4_f32) attention
+// block kernels (xlnet_attn_block.hip), whose A operand is 16 bytes of consecutive k of one output-feature row:
+//   QKVT32 [3D][D]   QKVT32[z D + o][k] = W_z[k][o]     q, k, v projections (forward)
+//   OT32   [D][D]    OT32[nd][h] = o[h][nd]             d attn_vec (backward)
+// (o itself [h][nd] and W_z [k][o] as stored serve the o-projection and d h.)
+static inline long layer_planes_half_floats(int D) { return layer_planes_bf16_floats(D) + 25L * 2 * D * D / 2 + 16; }
+struct LayerPlanes32 { const float *QKVT, *OT; };
+__host__ __device__ inline LayerPlanes32 carve_planes_32(const void* base, int D) {
+    const float* b = (const float*)base + (25L * 3 * D * D / 2 + 25L * 2 * D * D / 2 + 16);
+    LayerPlanes32 p;
+    p.QKVT = b;
+    p.OT = b + 3L * D * D;
+    return p;
+}
+static inline long layer_planes_floats(int D) { return layer_planes_half_floats(D) + 4L * D * D; }
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));

@@ -29,6 +29,7 @@ struct PlaneJob {
     short dcols;           // destination row pitch
     short r0, c0;          // destination offset of this source
     short transpose;       // dst[r0 + c][c0 + r] = src[r][c]  instead of  dst[r0 + r][c0 + c]
+    float* dst32;          // fp32 copy in the destination's orientation (exact-fp32 attention block kernels; may be null)
 };
 #define T4R_MAX_PLANE_JOBS 52        /* four layers x 13 matrices: 2.9 KB of kernel arguments */
 struct PlaneJobs { PlaneJob j[T4R_MAX_PLANE_JOBS]; int n; int total; };
@@ -51,6 +52,14 @@ __global__ __launch_bounds__(256) void layer_planes_kernel(PlaneJobs jobs) {
     }
     const long o_n = (long)(jb.r0 + r) * jb.dcols + jb.c0 + c;
     const long o_t0 = (long)(jb.r0 + c) * jb.dcols + jb.c0 + r, o_t1 = o_t0 + jb.dcols;
+    if (jb.dst32) {
+        if (!jb.transpose) {
+            *reinterpret_cast<float2*>(jb.dst32 + o_n) = v;
+        } else {
+            jb.dst32[o_t0] = v.x;
+            jb.dst32[o_t1] = v.y;
+        }
+    }
     if (jb.dst) {
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
@@ -104,13 +113,14 @@ __global__ __launch_bounds__(1024) void weight_scales_kernel(AmaxJobs jobs) {
 extern "C" long t4r_xlnet_layer_planes_floats(int D) { return layer_planes_floats(D); }
 
 static void add_job(PlaneJobs& js, const float* src, int rows, int cols, const uint16_t* dst, const uint16_t* dst_h,
-                    const float* scale, int drows, int dcols, int r0, int c0, int transpose) {
+                    const float* scale, int drows, int dcols, int r0, int c0, int transpose, const float* dst32 = nullptr) {
     // only the form the kernels will read is produced: the fp16 planes (default) or the bf16 planes (T4R_XLNET_FP16X2=0)
     const bool hs = t4r_xlnet_body_fp16x2();
     PlaneJob& j = js.j[js.n++];
     j.src = src; j.dst = hs ? nullptr : const_cast<uint16_t*>(dst); j.dst_h = hs ? const_cast<uint16_t*>(dst_h) : nullptr; j.scale = scale;
     j.rows = (short)rows; j.cols = (short)cols; j.dcols = (short)dcols; j.dplane = drows * dcols;
     j.r0 = (short)r0; j.c0 = (short)c0; j.transpose = (short)transpose; j.pair0 = js.total;
+    j.dst32 = const_cast<float*>(dst32);
     js.total += rows * cols / 2;
 }
 static void add_amax(AmaxJobs& aj, const float* src, int n, const float* out, int raw) {
@@ -124,12 +134,13 @@ static void add_layer_jobs(PlaneJobs& js, AmaxJobs& aj, const float* q, const fl
                            const float* r, const float* W1, const float* b1, const float* W2, int D, float* planes) {
     const LayerPlanes P = carve_planes(planes, D);
     const LayerPlanesH H = carve_planes_h(planes, D);
+    const LayerPlanes32 F = carve_planes_32(planes, D);
     const float* sc = H.scale;
     const float* z[3] = {q, k, v};
     for (int i = 0; i < 3; ++i) {
         if (!z[i]) continue;
         add_amax(aj, z[i], D * D, sc + HS_Q + i, 0);
-        add_job(js, z[i], D, D, P.QKVT, H.QKVT, sc + HS_Q + i, 3 * D, D, i * D, 0, 1);
+        add_job(js, z[i], D, D, P.QKVT, H.QKVT, sc + HS_Q + i, 3 * D, D, i * D, 0, 1, F.QKVT);
         add_job(js, z[i], D, D, P.QKVN, H.QKVN, sc + HS_Q + i, D, 3 * D, 0, i * D, 0);
     }
     if (r) {
@@ -139,7 +150,7 @@ static void add_layer_jobs(PlaneJobs& js, AmaxJobs& aj, const float* q, const fl
     if (o) {
         add_amax(aj, o, D * D, sc + HS_O, 0);
         add_job(js, o, D, D, P.ON, H.ON, sc + HS_O, D, D, 0, 0, 0);
-        add_job(js, o, D, D, P.OT, H.OT, sc + HS_O, D, D, 0, 0, 1);
+        add_job(js, o, D, D, P.OT, H.OT, sc + HS_O, D, D, 0, 0, 1, F.OT);
     }
     if (W1) {
         add_amax(aj, W1, 4 * D * D, sc + HS_W1, 0);

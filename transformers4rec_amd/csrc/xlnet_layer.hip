@@ -64,6 +64,11 @@ long t4r_xlnet_ln1_bwd_part_floats(long, int);
 int t4r_xlnet_ln1_bwd(void*, const float*, const float*, const float*, const float*, const float*, const float*, const float*,
                       float*, float*, float*, float*, float*, float*, long, int, float, unsigned long long, unsigned long long);
 int t4r_xlnet_dh(void*, const float*, const float*, float*, long, int);
+// xlnet_attn_block.hip: the attention half as one kernel per direction, exact fp32 matrix instructions
+int t4r_xlnet_attn_block_supported(int L, int D, int n_head);
+int t4r_xlnet_attn_block_fwd(void*, const float*, const float*, const float*, const float*, long, const float*, const float*,
+                             const float*, const float*, float*, float*, float*, float*, float*, float*, float*, int, int, int,
+                             int, float, float, unsigned long long, unsigned long long, unsigned long long, const int*);
 int t4r_xlnet_ff_fwd(void*, const float*, const float*, const float*, const float*, const float*, const float*,
                      float*, float*, float*, float*, float*, float*, int, int, float, float,
                      unsigned long long, unsigned long long, unsigned long long);
@@ -75,6 +80,12 @@ int t4r_xlnet_ff_bwd(void*, const float*, const float*, const float*, const floa
 static bool use_fused(int D) {
     static const int on = [] { const char* e = getenv("T4R_XLNET_FUSED"); return e ? atoi(e) : 1; }();
     return on && t4r_xlnet_fused_supported(D);
+}
+
+// T4R_XLNET_ATTN_BLOCK=0 restores the four-launch attention half (projection, core, o-projection + LayerNorm) for A/B timing
+static bool use_attn_block(int L, int D, int n_head) {
+    static const int on = [] { const char* e = getenv("T4R_XLNET_ATTN_BLOCK"); return e ? atoi(e) : 1; }();
+    return on && use_fused(D) && t4r_xlnet_attn_block_supported(L, D, n_head);
 }
 
 // dropout sites of one layer (HF modeling_xlnet.py): pos_emb :1143 (model level, but the mask is per
@@ -190,8 +201,9 @@ extern "C" int t4r_xlnet_layer_fwd(void* stream, const float* h, const float* po
     if (use_fused(D)) {
         // ONE launch cuts the layer's nine weight matrices into bf16 planes; q, k, v in one token-tile launch; k_r; the
         // attention core; o-projection + dropout + residual + LayerNorm in one launch; the feed-forward block in one
+        const bool block = use_attn_block(L, D, n_head);
         if (!g_stack_prepared) RUN(t4r_xlnet_layer_prepare(stream, params, D, w.planes));
-        RUN(t4r_xlnet_qkv_proj(stream, h, w.planes, w.qkv, T, D));
+        if (!block) RUN(t4r_xlnet_qkv_proj(stream, h, w.planes, w.qkv, T, D));
         if (g_stack_prepared) {
             // k_r of every layer came from one launch of the stack prologue
         } else if (drop) {
@@ -205,10 +217,18 @@ extern "C" int t4r_xlnet_layer_fwd(void* stream, const float* h, const float* po
         } else {
             RUN(t4r_xlnet_kr_proj(stream, pos_emb, w.planes, w.kr, 2L * L, D));
         }
+        if (block) {
+            // q | k | v projection, attention core, o-projection + dropout + residual + LayerNorm: ONE launch
+            RUN(t4r_xlnet_attn_block_fwd(stream, h, w.planes, params[P_O], w.kr, drop ? 2L * L * D : 0L, params[P_RWB],
+                                         params[P_RRB], params[P_LN1W], params[P_LN1B], w.qkv, w.av, w.lse, w.ao, w.mean1,
+                                         w.rstd1, w.h1, B, L, D, n_head, ln_eps, drop_p, seed, C(SITE_PROB), C(SITE_ATTN_OUT),
+                                         key_len));
+        } else {
         RUN(t4r_xlnet_attn_fwd(stream, w.qkv, w.qkv + TD, w.qkv + 2 * TD, w.kr, params[P_RWB], params[P_RRB], w.av, w.lse,
                                B, L, n_head, dh, drop, drop_p, seed, C(SITE_PROB), key_len));
         RUN(t4r_xlnet_oproj_ln(stream, w.av, h, w.planes, params[P_LN1W], params[P_LN1B], w.ao, w.mean1, w.rstd1, w.h1, T, D,
                                ln_eps, drop_p, seed, C(SITE_ATTN_OUT)));
+        }
         const long ns = t4r_xlnet_ff_amax_slots(T);
         t4r_xlnet_ff_amax_buffers(w.amax, w.amax + ns, nullptr, nullptr);
         const int rc = t4r_xlnet_ff_fwd(stream, w.h1, w.planes, params[P_B1], params[P_B2], params[P_LN2W], params[P_LN2B], w.ffpre,

@@ -746,6 +746,29 @@ def xlnet_dh_(dqkv, planes, dh):
     return dh
 
 
+def xlnet_attn_block_supported(L, D, n_head):
+    return bool(_lib.load().t4r_xlnet_attn_block_supported(int(L), int(D), int(n_head)))
+
+
+def xlnet_attn_block_fwd(h, planes, o, kr, r_w_bias, r_r_bias, gamma, beta, B, L, n_head, eps, drop_p=0.0, seed=0, ctr_prob=0,
+                         ctr_out=0, key_len=None, train=True):
+    """the attention half of a layer in one launch (csrc/xlnet_attn_block.hip): h [B L, D] -> h1, and what the backward needs"""
+    T, D = h.shape
+    dev = h.device
+    qkv = torch.empty((3, T, D), device=dev)
+    av, h1 = torch.empty((T, D), device=dev), torch.empty((T, D), device=dev)
+    lse = torch.empty((B, n_head, L), device=dev)
+    ao = torch.empty((T, D), device=dev) if train else None
+    mean = torch.empty(T, device=dev) if train else None
+    rstd = torch.empty(T, device=dev) if train else None
+    per_session = kr.shape[0] == B * 2 * L and B > 1 or (kr.dim() == 3)
+    call("t4r_xlnet_attn_block_fwd", _stream(), _chk(h, torch.float32), planes.data_ptr(), _chk(o, torch.float32), _chk(kr, torch.float32),
+         2 * L * D if per_session else 0, _chk(r_w_bias), _chk(r_r_bias), _chk(gamma), _chk(beta), qkv.data_ptr(), av.data_ptr(),
+         lse.data_ptr(), _p(ao), _p(mean), _p(rstd), h1.data_ptr(), B, L, D, n_head, float(eps), float(drop_p), int(seed),
+         int(ctr_prob), int(ctr_out), _p(key_len, torch.int32))
+    return h1, dict(qkv=qkv, av=av, lse=lse, ao=ao, mean=mean, rstd=rstd)
+
+
 def xlnet_ff_fwd(h1, planes, b1, b2, gamma, beta, eps, drop_p=0.0, seed=0, ctr_act=0, ctr_out=0, train=True):
     T, D = h1.shape
     dev = h1.device

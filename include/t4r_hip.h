@@ -407,6 +407,14 @@ int t4r_xlnet_attn_block_fwd(void* stream, const float* h, const float* planes, 
                              const float* beta, float* qkv, float* av, float* lse, float* ao, float* mean, float* rstd,
                              float* h1, int B, int L, int D, int n_head, float eps, float drop_p, unsigned long long seed,
                              unsigned long long ctr_prob, unsigned long long ctr_out, const int* key_len);
+long t4r_xlnet_attn_block_bwd_part_floats(int B, int L, int D, int n_head);
+int t4r_xlnet_attn_block_bwd(void* stream, const float* dy, const float* ao, const float* h, const float* mean,
+                             const float* rstd, const float* gamma, const float* planes, const float* wq, const float* wk,
+                             const float* wv, const float* qkv, const float* kr, long kr_bstride, const float* r_w_bias,
+                             const float* r_r_bias, const float* lse, float* dh, float* dao, float* dqkv, float* dkr,
+                             float* d_rw, float* d_rr, float* d_gamma, float* d_beta, float* part, int B, int L, int D,
+                             int n_head, float drop_p, unsigned long long seed, unsigned long long ctr_prob,
+                             unsigned long long ctr_out, const int* key_len);
 long t4r_xlnet_ff_bwd_part_floats(long T, int D);
 int t4r_xlnet_ff_fwd(void* stream, const float* h1, const float* planes, const float* b1, const float* b2,
                      const float* gamma, const float* beta, float* ffpre, float* ffact, float* ffout, float* mean,

@@ -71,7 +71,7 @@ def reference(p, h, kr, B, L, n, eps, mask_p, mask_o, key_len=None):
     rstd = 1.0 / torch.sqrt(x.var(1, unbiased=False) + eps)
     h1 = (x - mean[:, None]) * rstd[:, None] * p["ln_w"] + p["ln_b"]
     qkv = torch.stack([t.permute(0, 2, 1, 3).reshape(B * L, D) for t in (q, k, v)])
-    return dict(qkv=qkv, av=vec, lse=lse, ao=ao, mean=mean, rstd=rstd, h1=h1)
+    return dict(qkv=qkv, av=vec, lse=lse, ao=ao, mean=mean, rstd=rstd, h1=h1, _heads=(q, k, v))
 
 
 def rel_err(a, ref):
@@ -139,3 +139,64 @@ def test_attn_block_unsupported_shapes_are_refused(ops):
     with pytest.raises(_lib.T4RHipError, match="unsupported shape"):
         z = torch.zeros(40 * 256, 256, device=DEV)
         ops.xlnet_attn_block_fwd(z, z, z, z, z, z, z, z, 256, 40, 8, 0.03)
+
+
+# ------------------------------------------------------------------------------------------ backward
+def _autograd_reference(p, h, kr, B, L, n, eps, mp, mo, key_len, dy):
+    """fp64 autograd through the restatement above: gradients of sum(h1 * dy)"""
+    leaves = {k: p[k].clone().requires_grad_(True) for k in ("q", "k", "v", "o", "r_w_bias", "r_r_bias", "ln_w", "ln_b")}
+    hh = h.clone().requires_grad_(True)
+    krr = kr.clone().requires_grad_(True)
+    pp = dict(p)
+    pp.update(leaves)
+    out = reference(pp, hh, krr, B, L, n, eps, mp, mo, key_len)
+    for t in out["_heads"] + (out["ao"],):
+        t.retain_grad()
+    (out["h1"] * dy).sum().backward()
+    g = {k: v.grad for k, v in leaves.items()}
+    D = h.shape[1]
+    dqkv = torch.stack([t.grad.permute(0, 2, 1, 3).reshape(B * L, D) for t in out["_heads"]])
+    g.update(h=hh.grad, kr=krr.grad, dqkv=dqkv, dao=out["ao"].grad)
+    return g
+
+
+@pytest.mark.parametrize("B,L,D,n,drop_p,with_len", CASES)
+def test_attn_block_backward_matches_fp64_autograd(ops, B, L, D, n, drop_p, with_len):
+    p, h, kr, key_len, planes = _setup(ops, B, L, D, n, drop_p, with_len, seed=1)
+    T = B * L
+    g = torch.Generator().manual_seed(7 + B)
+    dy = torch.randn(T, D, generator=g, dtype=torch.float64).float().double()
+    kl = None if key_len is None else key_len.to(DEV).to(torch.int32)
+    mp = _mask(ops, (B, n, L, L), drop_p, SEED, CTR_P) if drop_p > 0 else torch.ones(B, n, L, L, dtype=torch.float64)
+    mo = _mask(ops, (T, D), drop_p, SEED, CTR_O) if drop_p > 0 else torch.ones(T, D, dtype=torch.float64)
+    ref = _autograd_reference(p, h, kr, B, L, n, 0.03, mp, mo, key_len, dy)
+    rw, rr = cu(p["r_w_bias"]).view(-1), cu(p["r_r_bias"]).view(-1)
+    krd = cu(kr).view(-1, D)
+    h1, saved = ops.xlnet_attn_block_fwd(cu(h), planes, cu(p["o"]).view(D, D), krd, rw, rr, cu(p["ln_w"]), cu(p["ln_b"]), B, L, n, 0.03,
+                                          drop_p, SEED, CTR_P, CTR_O, key_len=kl)
+    # accumulated outputs start from a known non-zero state
+    base = {k: torch.full((D,), 0.25, device=DEV) for k in ("rw", "rr", "gamma", "beta")}
+    acc = {k: v.clone() for k, v in base.items()}
+    dh, dao, dqkv, dkr = ops.xlnet_attn_block_bwd(cu(dy), saved, cu(h), planes, cu(p["q"]).view(D, D), cu(p["k"]).view(D, D),
+                                                  cu(p["v"]).view(D, D), krd, rw, rr, cu(p["ln_w"]), acc["rw"], acc["rr"],
+                                                  acc["gamma"], acc["beta"], B, L, n, drop_p, SEED, CTR_P, CTR_O, key_len=kl)
+    tol = 5e-6
+    assert rel_err(dao, ref["dao"]) < tol
+    assert rel_err(dqkv, ref["dqkv"]) < tol
+    assert rel_err(dh, ref["h"]) < tol
+    assert rel_err(dkr.view(ref["kr"].shape), ref["kr"]) < tol
+    assert rel_err(acc["rw"] - 0.25, ref["r_w_bias"].reshape(-1)) < tol
+    assert rel_err(acc["rr"] - 0.25, ref["r_r_bias"].reshape(-1)) < tol
+    assert rel_err(acc["gamma"] - 0.25, ref["ln_w"]) < tol
+    assert rel_err(acc["beta"] - 0.25, ref["ln_b"]) < tol
+    # the weight gradients the caller forms from these rows
+    hq = h.t() @ ref["dqkv"][0]
+    assert rel_err((cu(h).double().t() @ dqkv[0].double()).view(D, n, D // n), ref["q"]) < 2e-5 and float(hq.abs().max()) > 0
+    assert rel_err((dao.double().t() @ saved["av"].double()).view(D, n, D // n), ref["o"]) < 2e-5
+    # no atomics: a second call gives the same bits
+    acc2 = {k: v.clone() for k, v in base.items()}
+    dh2, dao2, dqkv2, dkr2 = ops.xlnet_attn_block_bwd(cu(dy), saved, cu(h), planes, cu(p["q"]).view(D, D), cu(p["k"]).view(D, D),
+                                                      cu(p["v"]).view(D, D), krd, rw, rr, cu(p["ln_w"]), acc2["rw"], acc2["rr"],
+                                                      acc2["gamma"], acc2["beta"], B, L, n, drop_p, SEED, CTR_P, CTR_O, key_len=kl)
+    assert torch.equal(dh, dh2) and torch.equal(dqkv, dqkv2) and torch.equal(dkr, dkr2)
+    assert all(torch.equal(acc[k], acc2[k]) for k in acc)

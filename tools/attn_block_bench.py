@@ -80,5 +80,36 @@ for p in (0.3, 0.0):
         for i, nm in enumerate(names):
             print(f"      {nm:16s} {float(d[:, i].median()):9.0f}  [{float(d[:, i].min()):7.0f} .. {float(d[:, i].max()):7.0f}]")
         print(f"      {'total':16s} {float(tot.median()):9.0f}  [{float(tot.min()):7.0f} .. {float(tot.max()):7.0f}]")
-    if hasattr(ops, "xlnet_attn_block_bwd"):
-        pass
+    d_rw, d_rr, dg, db = (torch.zeros(D, device=dev) for _ in range(4))
+    wq, wk, wv = (P[k].view(D, D) for k in ("q", "k", "v"))
+    block_fwd()
+    saved = keep["saved"]
+
+    def block_bwd():
+        keep["g"] = ops.xlnet_attn_block_bwd(dy, saved, h, planes, wq, wk, wv, kr, rw, rr, P["ln_w"], d_rw, d_rr, dg, db, B, L, n, p, 7, cp, co)
+
+    def chain_bwd():
+        dh, dao, dav = ops.xlnet_ln1_bwd(dy, saved["ao"], h, saved["mean"], saved["rstd"], P["ln_w"], planes, dg, db,
+                                         drop=(p, 7, co) if p > 0 else ops.NO_DROP)
+        dq, dk, dv, dkr = ops.xlnet_attn_bwd(saved["qkv"][0], saved["qkv"][1], saved["qkv"][2], kr, rw, rr, saved["av"], saved["lse"], dav,
+                                             d_rw, d_rr, B, L, n, drop=(p, 7, cp) if p > 0 else ops.NO_DROP)
+        dqkv = torch.stack([dq, dk, dv])
+        keep["c2"] = ops.xlnet_dh_(dqkv, planes, dh)
+
+    tb, tc = timed(block_bwd), timed(chain_bwd)
+    if stamps is not None and os.environ.get("T4R_AB_STAMP_DETAIL") == "3":
+        stamps.zero_(); block_bwd(); torch.cuda.synchronize()
+        st = stamps.view(-1, 8)[: (B // 4) * 8].double()
+        d = st[:, 1:8] - st[:, 0:7]
+        print("   backward phase 3 detail, cycles, median over waves [min .. max]:")
+        for i, nm in enumerate(["staging 1", "scores + gather (it 0)", "softmax bwd", "d v", "d q, d k, d k_r", "second query block", "rest of phase 3"]):
+            print(f"      {nm:24s} {float(d[:, i].median()):9.0f}  [{float(d[:, i].min()):7.0f} .. {float(d[:, i].max()):7.0f}]")
+    elif stamps is not None and os.environ.get("T4R_AB_STAMP_DETAIL") != "P":
+        stamps.zero_(); block_bwd(); torch.cuda.synchronize()
+        st = stamps.view(-1, 8)[: (B // 4) * 8].double()
+        d = st[:, 1:6] - st[:, 0:5]
+        print("   backward phase cycles, median over waves [min .. max]:")
+        for i, nm in enumerate(["1 LayerNorm bwd", "2 d attn_vec", "barrier", "3 attention core", "4 d h"]):
+            print(f"      {nm:18s} {float(d[:, i].median()):9.0f}  [{float(d[:, i].min()):7.0f} .. {float(d[:, i].max()):7.0f}]")
+        print(f"      {'total':18s} {float((st[:, 5] - st[:, 0]).median()):9.0f}")
+    print(f"dropout {p}: attention half backward: one kernel (+ 2 partial reductions) {tb:6.1f} us | LayerNorm-1 backward + core + d h launches (+ stack) {tc:6.1f} us", flush=True)

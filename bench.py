@@ -70,10 +70,53 @@ def table_exchange_mode():
                           end of the backward, exposed, nothing row-sparse.
     Both give the same gradients (tests/test_distributed_cpu.py); which one is faster is a property of the fabric: measured by
     the driver's 8-GPU run (`config.table_exchange` in the JSON line says which was used)."""
-    m = os.environ.get("T4R_BENCH_TABLE_EXCHANGE", "sparse")
-    if m not in ("sparse", "dense"):
-        raise SystemExit("T4R_BENCH_TABLE_EXCHANGE must be sparse or dense")
+    m = os.environ.get("T4R_BENCH_TABLE_EXCHANGE", "auto")
+    if m not in ("sparse", "dense", "auto"):
+        raise SystemExit("T4R_BENCH_TABLE_EXCHANGE must be sparse, dense or auto")
     return m
+
+
+def teardown_data_parallel(tables, hook):
+    """undo setup_data_parallel: the head-backward hook and the row-sparse sinks of the table parameters"""
+    import transformers4rec_amd as tr
+
+    if hook is not None:
+        hook.remove()
+    if tables is not None:
+        tr.SparseRowExchange.detach(*[p for _, p, _ in tables.entries])
+
+
+def pick_table_exchange(setup, teardown, make_step, world, device, steps=3, warm=2):
+    """"auto" (the default at N > 1): time `steps` training steps of each form of the table-gradient exchange on THIS
+    fabric -- barrier + device sync on both sides, MAX over ranks, so every rank takes the same decision -- and keep the
+    faster.  setup(mode) -> (reducer, hook); teardown(hook); make_step(reducer) -> train_step.
+    -> (mode, reducer, hook, {"sparse": ms per step, "dense": ms per step})"""
+    import torch.distributed as dist
+
+    sync = torch.cuda.synchronize if torch.device(device).type == "cuda" else (lambda: None)
+    times = {}
+    for mode in ("sparse", "dense"):
+        reducer, hook = setup(mode)
+        step = make_step(reducer)
+        for i in range(warm):
+            step(i)
+        if world > 1:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(warm + i)
+        if world > 1:
+            dist.barrier()
+        sync()
+        t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        times[mode] = 1e3 * float(t.item()) / steps
+        teardown(hook)
+    best = min(times, key=times.get)        # identical on every rank: the times were all-reduced
+    reducer, hook = setup(best)
+    return best, reducer, hook, {k: round(v, 4) for k, v in times.items()}
 
 
 def setup_data_parallel(tr, model, dense, tables, world, mode=None):
@@ -83,6 +126,8 @@ def setup_data_parallel(tr, model, dense, tables, world, mode=None):
     sparse = None
     hook = None
     mode = mode or table_exchange_mode()
+    if mode == "auto":
+        mode = "sparse"         # the caller runs pick_table_exchange; a plain call keeps the row-sparse form
     if mode == "dense" and os.environ.get("T4R_BENCH_SPARSE", "0") != "1":
         return tr.GradReducer(dense.grad, tables.grad if tables is not None else None, sparse=None), None
     if world > 1 or os.environ.get("T4R_BENCH_SPARSE", "0") == "1":
@@ -140,6 +185,32 @@ def timed_region(train_step, warmup, steps, world, device, first_step=0):
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     return float(tmax.item()), out, n_lab
+
+
+def extra_windows(train_step, steps, world, device, first_step, n_windows=5):
+    """n_windows MORE timed windows of `steps` steps each, after the contract's window (training simply continues): the
+    spread of the headline between windows of one process -- min / median / max ms per step, MAX over ranks each."""
+    import torch.distributed as dist
+
+    sync = torch.cuda.synchronize if torch.device(device).type == "cuda" else (lambda: None)
+    ms = []
+    for wdx in range(n_windows):
+        if world > 1:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            train_step(first_step + wdx * steps + i)
+        if world > 1:
+            dist.barrier()
+        sync()
+        t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms.append(1e3 * float(t.item()) / steps)
+    srt = sorted(ms)
+    return {"n_windows": n_windows, "steps_per_window": steps, "min": round(srt[0], 4), "median": round(srt[len(srt) // 2], 4),
+            "max": round(srt[-1], 4), "all": [round(x, 4) for x in ms]}
 
 
 # --------------------------------------------------------------------------------------------- CPU leg
@@ -481,10 +552,17 @@ def _stub_main(args, world, rank):
         keep = ids != padding_idx
         d_table.index_add_(0, ids[keep], rows[keep])
 
-    sparse = tr.SparseRowExchange(apply_fn=cpu_apply, equal_sizes=True).attach(model.table)
-    reducer = tr.GradReducer(dense.grad, tables.grad, sparse=sparse)
-    if world > 1:
-        tr.head_backward_hook(model, reducer.reduce_tables_async)
+    def setup(mode):
+        if mode == "dense":
+            return tr.GradReducer(dense.grad, tables.grad, sparse=None), None
+        sparse = tr.SparseRowExchange(apply_fn=cpu_apply, equal_sizes=True).attach(model.table)
+        reducer = tr.GradReducer(dense.grad, tables.grad, sparse=sparse)
+        return reducer, (tr.head_backward_hook(model, reducer.reduce_tables_async) if world > 1 else None)
+
+    def teardown(hook):
+        if hook is not None:
+            hook.remove()
+        tr.SparseRowExchange.detach(model.table)
 
     class _Sgd:
         def step(self, grad_scale=1.0):
@@ -494,15 +572,26 @@ def _stub_main(args, world, rank):
 
     g = torch.Generator().manual_seed(1000 + rank)
     batches = [{"item_id": torch.randint(1, 64, (16, 5), generator=g)} for _ in range(4)]
+    exchange_mode, exchange_ms = table_exchange_mode() if world > 1 else "local", None
+    if exchange_mode == "auto":
+        exchange_mode, reducer, _hook, exchange_ms = pick_table_exchange(setup, teardown, lambda red: make_train_step(model, batches, red, _Sgd()),
+                                                                         world, "cpu", steps=2, warm=1)
+    else:
+        reducer, _hook = setup("sparse" if exchange_mode == "local" else exchange_mode)
+    if world > 1 and dist.get_world_size() != args.gpus:
+        raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
     step = make_train_step(model, batches, reducer, _Sgd())
     dt, out, n_lab = timed_region(step, args.warmup, args.steps, world, "cpu")
+    windows = extra_windows(step, args.steps, world, "cpu", args.warmup + args.steps, n_windows=2)
     if rank == 0:
         print(json.dumps({"metric": "launch-plumbing stub (no GPU, not a measurement)", "stub": True,
                           "value": round(16 * world * args.steps / dt, 1), "unit": "sessions/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "ms_per_step_windows": windows, "comm": {"table_exchange_ms_per_step": exchange_ms},
                           "data": "synthetic", "config": {"workload": "stub", "global_batch": 16 * world,
-                                                          "parallelism": f"dp{world}",
+                                                          "parallelism": f"dp{world}", "table_exchange": exchange_mode,
+                                                          "world_size": world,
                                                           "final_loss": round(float(out["loss"].detach()), 4),
                                                           "label_rows": n_lab}}), flush=True)
     if world > 1:
@@ -549,9 +638,15 @@ def main():
         else:
             dist.init_process_group(backend)
 
+        # first-contact safety: the collectives really span the N ranks the driver asked for
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
+
     tr, schema, model, dense, tables, opt = build(device, args.dropout)
     from transformers4rec_amd import ops
 
+    exchange_mode = table_exchange_mode() if world > 1 else "local"
+    exchange_ms = None
     reducer, _hook = setup_data_parallel(tr, model, dense, tables, world)
     masking = model.input_features.masking
     masking.seed, model.transformer_block.transformer.seed = rank_seeds(rank)
@@ -566,6 +661,14 @@ def main():
     # pre-heat steps this particular box managed
     snap = ([f.data.clone() for f in opt.flats], [(m.clone(), v.clone()) for m, v in opt.state], opt.step_count,
             tr.get_rng_state(model))
+    if world > 1 and exchange_mode == "auto":
+        # both forms of the table-gradient exchange timed on this fabric (inside the rolled-back pre-heat), the faster kept
+        teardown_data_parallel(tables, _hook)
+        exchange_mode, reducer, _hook, exchange_ms = pick_table_exchange(
+            lambda m: setup_data_parallel(tr, model, dense, tables, world, mode=m),
+            lambda hk: teardown_data_parallel(tables, hk),
+            lambda red: make_train_step(model, batches, red, opt), world, device)
+        train_step = make_train_step(model, batches, reducer, opt)
     t_pre = time.perf_counter()
     n_pre = 0
     go = torch.ones(1, device=device, dtype=torch.int32)
@@ -591,6 +694,7 @@ def main():
     del snap
     dt, out, n_lab = timed_region(train_step, args.warmup, args.steps, world, device)
     loss = float(out["loss"].detach())
+    windows = extra_windows(train_step, args.steps, world, device, args.warmup + args.steps)
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream
     # (the same GEMM launches the timed steps issue: logits = X[N_m,128] @ W[100001,128]^T)
@@ -716,7 +820,13 @@ def main():
     gather_c3_ms = graph_timed(gather_c3, reps=20)
     gather_c3_bytes = GB * SEQ * (4 * 8 + 4 * W3 + 4 * W3)
     gather_c3_gbs = gather_c3_bytes / (gather_c3_ms * 1e-3) / 1e9
-    del Wbig, ids_g, feats_g, feats_c3, cats, dense
+    # the memcpy ceiling of THIS box, in the same run: a plain device-to-device copy of 1 GiB (read + write = 2 GiB of HBM
+    # traffic), the rate a kernel that only moves bytes can reach here (the guide quotes 6.3 TB/s; these boxes measure ~5.3)
+    cp_src = Wbig.view(-1)[: (1 << 28)]
+    cp_dst = torch.empty_like(cp_src)
+    copy_ms = graph_timed(lambda: cp_dst.copy_(cp_src), reps=10)
+    copy_gbs = 2.0 * cp_src.numel() * 4 / (copy_ms * 1e-3) / 1e9
+    del Wbig, ids_g, feats_g, feats_c3, cats, dense, cp_src, cp_dst
 
     # ---- the transformer body's fused kernels (csrc/xlnet_fused*.hip), timed live at this run's shape: the feed-forward
     # block forward / backward (one launch each; 2 * T * 4D * D * 2 algorithmic flops per direction, six bf16 partial
@@ -782,7 +892,8 @@ def main():
     comm = {"dense_bucket_bytes": int(dense.grad.numel() * 4) if world > 1 else 0,
             "tables_bucket_bytes": int(tables.grad.numel() * 4) if world > 1 and reducer.tables is not None else 0,
             "row_sparse_gathered_bytes": int((sparse.bytes_exchanged if sparse is not None else 0) //
-                                             max(1, n_pre + args.warmup + args.steps)),
+                                             max(1, n_pre + args.warmup + args.steps * (1 + windows["n_windows"]))),
+            "table_exchange_ms_per_step": exchange_ms,
             "note": "per rank and step; the tables all-reduce starts right after the head's backward and runs under the "
                     "transformer body's backward; the dense bucket and the (ids, rows) all-gather are exposed"}
     if rank == 0:
@@ -798,9 +909,11 @@ def main():
                        "global_batch": BATCH * world, "seq_len": SEQ, "parallelism": f"dp{world}",
                        "dropout": args.dropout, "label_rows_per_step": N_m, "final_loss": round(loss, 4),
                        "head_mode": model.prediction_task.resolve_head_mode(N_m, W.shape[0]),
-                       "precision_mode": mode, "table_exchange": table_exchange_mode() if world > 1 else "local",
+                       "precision_mode": mode, "table_exchange": exchange_mode, "world_size": world,
+                       "collective_backend": (backend if world > 1 else None),
                        "preheat_s": round(preheat_s, 2), "preheat_steps": n_pre,
                        "timed_region_s": round(dt, 4)},
+            "ms_per_step_windows": windows,
             "roofline": {"kernel": (("head_logits_ce_kernel<4, fp16x2> (next-item logits X@W^T + the softmax statistics of the loss; "
                                      "fp32-class accuracy: two-way fp16 split with power-of-two tensor scales, three "
                                      "v_mfma_f32_32x32x16_f16 products per K=16; W fragments register-resident, X plane blocks through LDS)")
@@ -838,8 +951,12 @@ def main():
                                 "traffic": None if gj is None else gj.get("traffic_bytes_per_launch_c2"),
                                 "avg_launch_ms": round(gather_ms, 5), "bytes_per_launch": gather_bytes,
                                 "note": "per-GPU batch: 20 480 tokens against the 51 MB table (cache resident)",
+                                "measured_copy_GBps": round(copy_gbs, 1),
+                                "measured_copy_note": "1 GiB device-to-device copy_ in this run (read + write bytes / time): what a pure "
+                                                      "byte-moving kernel reaches on this box; frac_of_measured_copy = gather rate / this",
                                 "at_global_batch_8192_out_of_cache": {
                                     "achieved": round(gather_g_gbs, 1), "frac": round(gather_g_gbs / HBM_PEAK_GBS, 4),
+                                    "frac_of_measured_copy": round(gather_g_gbs / copy_gbs, 4),
                                     "avg_launch_ms": round(gather_g_ms, 5), "bytes_per_launch": gather_g_bytes,
                                     "table": "10 000 001 x 128 fp32 (5.1 GB), 4 id sets rotated",
                                     "traffic": None if gj is None else gj.get("traffic_bytes_per_launch_8192"),
@@ -848,6 +965,7 @@ def main():
                                     "kernel": "seq_features_fwd_fast_kernel<64, 4, 2> (item 128 + 3 x 64 categorical + 2 x 8 dense rows, "
                                               "concat, 336 floats per token)",
                                     "achieved": round(gather_c3_gbs, 1), "frac": round(gather_c3_gbs / HBM_PEAK_GBS, 4),
+                                    "frac_of_measured_copy": round(gather_c3_gbs / copy_gbs, 4),
                                     "avg_launch_ms": round(gather_c3_ms, 5), "bytes_per_launch": gather_c3_bytes,
                                     "note": "163 840 tokens, item table 10 000 001 x 128 (out of cache, 4 id sets rotated), the three "
                                             "small tables are cache resident"}},

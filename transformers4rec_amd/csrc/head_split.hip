@@ -104,6 +104,14 @@ __device__ __forceinline__ f32x16 mfma_split(const u32x4 (&a)[HS ? 2 : 3], const
         return mfma6(a, b, acc);
     }
 }
+// the same three products with the operand ROLES exchanged (a is what the other kernel passes as b): the terms are added
+// in the same order, so a score tile recomputed with X as the A operand equals the forward's (W as the A operand) bit for bit
+__device__ __forceinline__ f32x16 mfma_split_swapped(const u32x4 (&a)[2], const u32x4 (&b)[2], f32x16 acc) {
+    acc = mfma_f16(a[0], b[1], acc);
+    acc = mfma_f16(a[1], b[0], acc);
+    acc = mfma_f16(a[0], b[0], acc);
+    return acc;
+}
 // largest magnitude of a [rows, cols] matrix as the bits of a non-negative float (they order like unsigned integers), and
 // the power of two that maps it into [2^13, 2^14)
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ src, long ld, long rows, int cols,
@@ -172,6 +180,31 @@ __global__ __launch_bounds__(256) void split_km_kernel(const float* __restrict__
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int row = b * 32 + 8 * kc + e;
+            x[e] = row < n_rows ? src[(long)row * ld + d] : 0.f;
+        }
+        u32x4 w[NPL];
+        split8s<HS>(x, scale, w);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) dst[(((long)b * NPL + pl) * 4 + kc) * D + d] = w[pl];
+    }
+}
+
+// KMP image (round 4, the recomputing backward kernels): as the KM image, with the 32 rows of a block in the order the
+// 32 x 32 ACCUMULATOR hands them to a lane -- position (kc = 2 s + khalf, e) holds row 16 s + 4 khalf + (e & 3) + 8 (e >> 2),
+// i.e. accumulator register 8 s + e of lane half khalf.  A score tile recomputed on the matrix cores then IS (after the
+// softmax-gradient transform, in registers) the A operand of the product that contracts over its rows, against this image.
+template <int NB, bool HS = false>
+__global__ __launch_bounds__(256) void split_kmp_kernel(const float* __restrict__ src, long ld, int n_rows,
+                                                         u32x4* __restrict__ dst, const unsigned* __restrict__ amax = nullptr) {
+    constexpr int D = 32 * NB, NPL = HS ? 2 : 3;
+    const int b = blockIdx.x;
+    const float scale = HS ? scale_of(amax) : 1.f;
+    for (int idx = threadIdx.x; idx < 4 * D; idx += 256) {
+        const int d = idx % D, kc = idx / D;
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int row = b * 32 + 16 * (kc >> 1) + 4 * (kc & 1) + (e & 3) + 8 * (e >> 2);
             x[e] = row < n_rows ? src[(long)row * ld + d] : 0.f;
         }
         u32x4 w[NPL];
@@ -293,13 +326,16 @@ __device__ __forceinline__ void quad_transpose4(float (&x)[4], int t) {
     }
 }
 
-template <int NB, bool HS>
+template <int NB, bool HS, bool ZL = false>
 __device__ __forceinline__ void head_logits_ce_body(const u32x4* __restrict__ XA, const float* __restrict__ W,
                                                     long ldw, float* __restrict__ C, long ldc, int N, int V,
                                                     float alpha, int nblk, int blk_per, int vec_ok,
                                                     float* __restrict__ st_m, float* __restrict__ st_s,
                                                     float* __restrict__ st_t, int n_tile, int n_split,
-                                                    const unsigned* __restrict__ amax, float* __restrict__ colmax, int vpad) {
+                                                    const unsigned* __restrict__ amax, float* __restrict__ colmax, int vpad,
+                                                    const long* __restrict__ labels = nullptr, float* __restrict__ zlab = nullptr) {
+    // C == NULL (the recomputing head, round 4): nothing is stored but the statistics -- and, with `labels`, each row's
+    // label logit (zlab [N]: the loss needs it, and the lane that holds it writes it: exact, no second product)
     constexpr int KS = 2 * NB, CH = 4 * NB, NPL = HS ? 2 : 3;
     constexpr int BLK = 4 * NPL * 32 * NB;
     const float sw = HS ? scale_of(amax + 1) : 1.f;
@@ -331,7 +367,10 @@ __device__ __forceinline__ void head_logits_ce_body(const u32x4* __restrict__ XA
         }
     }
     u32x4 st[SN];
+    long lab_n = 0;           // ZL: the label of this lane's row in the block being fetched (unconditional load, as the rest)
     auto g_load = [&](int b) __attribute__((always_inline)) {
+        // (the label first: its consumer, at the top of the next pass, then waits for this load only, not for the block behind it)
+        if constexpr (ZL) lab_n = labels[min(b * 32 + l32, N - 1)];
         const u32x4* src = XA + (long)b * BLK;
 #pragma unroll
         for (int i = 0; i < SN; ++i)
@@ -370,6 +409,7 @@ __device__ __forceinline__ void head_logits_ce_body(const u32x4* __restrict__ XA
     __syncthreads();
     for (int b = b_begin; b < b_end; ++b) {
         const int buf = (b - b_begin) & 1;
+        const long lab_c = lab_n;
         g_load(min(b + 1, b_end - 1));
         __builtin_amdgcn_sched_barrier(0);
         if (b > b_begin) flush_stats(buf ^ 1, b - 1);
@@ -395,7 +435,18 @@ __device__ __forceinline__ void head_logits_ce_body(const u32x4* __restrict__ XA
 #pragma unroll
             for (int r = 0; r < 16; ++r) cmax[r] = fmaxf(cmax[r], v[r]);
         }
-        if (vec_ok && !tail_tile) {
+        if (ZL && row < N) {
+            const int o = (int)(lab_c - c0);                 // this lane's columns: c0 + 8 g + i, g, i = 0..3
+            if (o >= 0 && o < 32 && (o & 4) == 0) {
+                const int rsel = 4 * (o >> 3) + (o & 3);
+                float zl = v[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) zl = rsel == r ? v[r] : zl;
+                zlab[row] = zl;
+            }
+        }
+        if (ZL) {
+        } else if (vec_ok && !tail_tile) {
             // full-line stores: the quad's four rows x four column groups are transposed through DPP, so that one store
             // instruction covers EIGHT lanes = all 128 bytes of a row (storing the accumulator layout as it is writes
             // 32 bytes per row and instruction: FETCH_SIZE showed a third of the logits lines read back for merging)
@@ -484,6 +535,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     head_logits_ce_body<NB, true>(XA, W, ldw, C, ldc, N, V, alpha, nblk, blk_per, vec_ok, st_m, st_s, st_t, n_tile, n_split, amax,
                                   colmax, vpad);
 }
+// the recomputing head's forward: statistics, column maxima and the label logits only -- no [N, V] tensor is written
+template <int NB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void head_ce_stats_h_kernel(
+    const u32x4* __restrict__ XA, const float* __restrict__ W, long ldw, int N, int V, float alpha, int nblk, int blk_per,
+    float* __restrict__ st_m, float* __restrict__ st_s, float* __restrict__ st_t, int n_tile, int n_split,
+    const unsigned* __restrict__ amax, float* __restrict__ colmax, int vpad, const long* __restrict__ labels,
+    float* __restrict__ zlab) {
+    head_logits_ce_body<NB, true, true>(XA, W, ldw, nullptr, 0, N, V, alpha, nblk, blk_per, 1, st_m, st_s, st_t, n_tile, n_split, amax,
+                                        colmax, vpad, labels, zlab);
+}
 
 // d W's per-item scales need: min over the rows of lse, and which items are some row's label (their column holds a -g (1 - eps))
 __global__ __launch_bounds__(1024) void head_dw_aux_kernel(const float* __restrict__ lse, const long* __restrict__ labels, int N,
@@ -513,7 +574,8 @@ __global__ __launch_bounds__(1024) void head_ce_finalize_kernel(const float* __r
                                                                  const float* __restrict__ st_t, int n_tiles, int N, int V,
                                                                  const float* __restrict__ C, long ldc,
                                                                  const long* __restrict__ labels, float smoothing,
-                                                                 float* __restrict__ loss_rows, float* __restrict__ lse_out) {
+                                                                 float* __restrict__ loss_rows, float* __restrict__ lse_out,
+                                                                 const float* __restrict__ zlab = nullptr) {
     __shared__ float sm[32][33], ss[32][33], stt[32][33];
     const int r = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int row = min(blockIdx.x * 32 + r, N - 1);
@@ -528,7 +590,7 @@ __global__ __launch_bounds__(1024) void head_ce_finalize_kernel(const float* __r
     if (sl == 0 && blockIdx.x * 32 + r < N) {
         for (int k = 1; k < 32; ++k) { lse_merge(m, s, sm[k][r], ss[k][r]); t += stt[k][r]; }
         const float lse = m + __logf(s);
-        float loss = lse - C[(long)row * ldc + labels[row]];
+        float loss = lse - (zlab ? zlab[row] : C[(long)row * ldc + labels[row]]);
         if (smoothing > 0.f) loss = (1.f - smoothing) * loss + smoothing * (lse - t / V);
         loss_rows[row] = loss;
         lse_out[row] = lse;
@@ -786,6 +848,267 @@ __global__ __launch_bounds__(256) void head_dx_split_kernel(const float* __restr
         }
 }
 
+// =====================================================================================================================
+// The RECOMPUTING backward (round 4; two-way fp16 form only).  The materialised head writes 1.1 GB of logits and reads them
+// twice (d X, d W): 3.6 GB of HBM traffic per step for 2.3 GB of need, and all three kernels run at "the logits' HBM time
+// plus their matrix time plus their VALU time" -- the parts do not overlap on this chip.  Here nothing of size [N, V] ever
+// exists: the forward keeps statistics only (head_ce_stats_h_kernel), and each backward kernel RECOMPUTES its score tile on
+// the matrix cores -- three more matrix instructions per K = 16 step instead of a 128-byte row segment from HBM -- in the
+// orientation whose ACCUMULATOR layout is, after the softmax-gradient transform in registers, the A operand of the product
+// that follows (the contraction index in accumulator order: the KMP image above).  Arithmetic: the same products, the same
+// exp / cut per gradient element as the materialised kernels; the recomputed logits repeat the forward's (same operand
+// pieces, same order of the three partial products and of K).
+//
+// d W: one workgroup per 128 items, all label rows (as head_dw_split_kernel): W rows as B fragments in registers (cut once),
+//      X blocks through LDS twice -- MK image (A operand of the scores) and KMP image (B operand of d W).
+template <int NB>
+__global__ __launch_bounds__(256) void head_dw_rc_kernel(const u32x4* __restrict__ XA, const u32x4* __restrict__ XTP,
+                                                          const float* __restrict__ W, long ldw, const float* __restrict__ lse,
+                                                          const long* __restrict__ labels, const float* __restrict__ gout,
+                                                          float* __restrict__ dW, long lddw, int N, int V, float smooth, float alpha,
+                                                          int accumulate, int nblk, const unsigned* __restrict__ amax, DwAux dw) {
+    constexpr int D = 32 * NB, KS = 2 * NB, CH = 4 * NB;
+    constexpr int BLK = 4 * 2 * 32 * NB;            // u32x4 per two-plane block (either image)
+    constexpr int SN = (BLK + 255) / 256;
+    __shared__ u32x4 ldsA[2][BLK];
+    __shared__ u32x4 ldsT[2][BLK];
+    __shared__ float2 rinfo[2][32];
+    __shared__ float sh_inv[4][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, khalf = lane >> 5;
+    const int v = blockIdx.x * 128 + 32 * wave + l32, vc = min(v, V - 1);
+    const float sx = scale_of(amax), sw = scale_of(amax + 1);
+    const float zscale = (alpha / sx) / sw;          // accumulator -> logit
+    u32x4 Bf[KS][2];
+    {
+        const float* wr = W + (long)vc * ldw + 8 * khalf;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const float4 u = *reinterpret_cast<const float4*>(wr + 16 * s);
+            const float4 t = *reinterpret_cast<const float4*>(wr + 16 * s + 4);
+            const float x[8] = {u.x, u.y, u.z, u.w, t.x, t.y, t.z, t.w};
+            split8s<true>(x, sw, Bf[s]);
+        }
+    }
+    SgScalars q;
+    q.g = (gout ? *gout : 1.f) / N;
+    {   // this item's power-of-two position from a bound on its column (head_dw_split_kernel)
+        float zmax = -INFINITY;
+        for (int sidx = 0; sidx < dw.rsplit; ++sidx) zmax = fmaxf(zmax, dw.colmax[(long)sidx * dw.vpad + vc]);
+        const float pb = dw.islab[vc] ? 1.f : __expf(fminf(zmax - *dw.lse_min, 0.f)) + smooth / V;
+        const float sv = pow2_scale_head(fabsf(q.g) * pb);
+        if (khalf == 0) sh_inv[wave][l32] = 1.f / sv;
+        q.g *= sv;
+    }
+    q.sub = q.g * smooth / V;
+    q.hit = q.g * (1.f - smooth);
+    const float oscale = alpha / sx;                 // d W = alpha G^T X: undo X's scale (the item scale per output row)
+
+    u32x4 stA[SN], stT[SN];
+    float ri_lse = 0.f;
+    long ri_lab = 0;
+    auto g_load = [&](int b) __attribute__((always_inline)) {
+        const int row = min(b * 32 + (tid & 31), N - 1);
+        ri_lse = lse[row];
+        ri_lab = labels[row];
+        const u32x4* sa = XA + (long)b * BLK;
+        const u32x4* stp = XTP + (long)b * BLK;
+#pragma unroll
+        for (int i = 0; i < SN; ++i)
+            if (BLK % 256 == 0 || i * 256 + tid < BLK) { stA[i] = sa[i * 256 + tid]; stT[i] = stp[i * 256 + tid]; }
+    };
+    auto s_store = [&](int buf, int b) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < SN; ++i)
+            if (BLK % 256 == 0 || i * 256 + tid < BLK) { ldsA[buf][i * 256 + tid] = stA[i]; ldsT[buf][i * 256 + tid] = stT[i]; }
+        const bool live = b * 32 + (tid & 31) < N;
+        if (tid < 32)
+            rinfo[buf][tid] = live ? make_float2(ri_lse * kLog2e, __int_as_float((int)ri_lab)) : make_float2(1e30f, __int_as_float(-1));
+    };
+    f32x16 acc[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    g_load(0);
+    s_store(0, 0);
+    __syncthreads();
+    for (int b = 0; b < nblk; ++b) {
+        const int buf = b & 1;
+        g_load(min(b + 1, nblk - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        // the score tile: rows of the block x this wave's 32 items; lane (item, khalf) gets rows (r & 3) + 8 (r >> 2) + 4 khalf
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            u32x4 a[2];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) a[pl] = ldsA[buf][(pl * CH + 2 * s + khalf) * 32 + l32];
+            z = mfma_split_swapped(a, Bf[s], z);
+        }
+        u32x4 af[2][2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float gv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = 8 * s + e;
+                const float2 in = rinfo[buf][(r & 3) + 8 * (r >> 2) + 4 * khalf];
+                gv[e] = sg_value(zscale * z[r], in.x, __float_as_int(in.y) == v, q);
+            }
+            split8s<true>(gv, 1.f, af[s]);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                u32x4 bf[2];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) bf[pl] = ldsT[buf][(pl * 4 + 2 * s + khalf) * D + 32 * j + l32];
+                acc[j] = mfma_split<true>(af[s], bf, acc[j]);
+            }
+        s_store(buf ^ 1, min(b + 1, nblk - 1));
+        __syncthreads();
+    }
+    const int v0 = blockIdx.x * 128 + 32 * wave + 4 * khalf;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        float* cp = dW + (long)v0 * lddw + 32 * j + l32;
+        float old[16];
+        if (accumulate) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) old[r] = cp[(long)min((r & 3) + 8 * (r >> 2), V - 1 - v0) * lddw];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            const float a = oscale * sh_inv[wave][dr + 4 * khalf];
+            if (v0 + dr < V) cp[(long)dr * lddw] = a * acc[j][r] + (accumulate ? old[r] : 0.f);
+        }
+    }
+}
+
+// d X: workgroups of 128 label rows x a range of 32-item tiles (as head_dx_split_kernel): the rows of X as B fragments in
+//      registers (cut once), the table's tiles through LDS twice -- MK image (A operand of the scores: lane = item) and KMP
+//      image (B operand of d X); lane (row, khalf) gets the items (r & 3) + 8 (r >> 2) + 4 khalf of the tile.
+template <int NB>
+__global__ __launch_bounds__(256) void head_dx_rc_kernel(const float* __restrict__ X, long ldx, const u32x4* __restrict__ WA,
+                                                          const u32x4* __restrict__ WTP, const float* __restrict__ lse,
+                                                          const long* __restrict__ labels, const float* __restrict__ gout,
+                                                          float* __restrict__ part, int N, int V, float smooth, float alpha,
+                                                          int nkt, int kt_per, int row_tiles, const unsigned* __restrict__ amax) {
+    constexpr int D = 32 * NB, KS = 2 * NB, CH = 4 * NB;
+    constexpr int BLK = 4 * 2 * 32 * NB;
+    constexpr int SN = (BLK + 255) / 256;
+    __shared__ u32x4 ldsA[2][BLK];
+    __shared__ u32x4 ldsT[2][BLK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, khalf = lane >> 5;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int rt = slot % row_tiles, split = (slot / row_tiles) * 8 + xcd;
+    const int kt_begin = split * kt_per, kt_end = min(nkt, kt_begin + kt_per);
+    if (kt_begin >= kt_end) return;
+    const int row = rt * 128 + 32 * wave + l32, rc = min(row, N - 1);
+    const float sx = scale_of(amax), sw = scale_of(amax + 1);
+    const float zscale = (alpha / sx) / sw;
+    u32x4 Xf[KS][2];
+    {
+        const float* xr = X + (long)rc * ldx + 8 * khalf;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const float4 u = *reinterpret_cast<const float4*>(xr + 16 * s);
+            const float4 t = *reinterpret_cast<const float4*>(xr + 16 * s + 4);
+            const float x[8] = {u.x, u.y, u.z, u.w, t.x, t.y, t.z, t.w};
+            split8s<true>(x, sx, Xf[s]);
+        }
+    }
+    const float l2 = lse[rc] * kLog2e;
+    const int y = (int)labels[rc];
+    SgScalars q;
+    q.g = (gout ? *gout : 1.f) / N;
+    float oscale;
+    {
+        int e;
+        (void)frexpf(fabsf(q.g), &e);
+        const float sg = (q.g != 0.f && fabsf(q.g) < 3e38f) ? ldexpf(1.f, min(14 - e, 100)) : 1.f;
+        q.g *= sg;
+        oscale = (alpha / sg) / sw;
+    }
+    q.sub = q.g * smooth / V;
+    q.hit = q.g * (1.f - smooth);
+
+    u32x4 stA[SN], stT[SN];
+    auto g_load = [&](int kt) __attribute__((always_inline)) {
+        const u32x4* sa = WA + (long)kt * BLK;
+        const u32x4* stp = WTP + (long)kt * BLK;
+#pragma unroll
+        for (int i = 0; i < SN; ++i)
+            if (BLK % 256 == 0 || i * 256 + tid < BLK) { stA[i] = sa[i * 256 + tid]; stT[i] = stp[i * 256 + tid]; }
+    };
+    auto s_store = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < SN; ++i)
+            if (BLK % 256 == 0 || i * 256 + tid < BLK) { ldsA[buf][i * 256 + tid] = stA[i]; ldsT[buf][i * 256 + tid] = stT[i]; }
+    };
+    f32x16 acc[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    g_load(kt_begin);
+    s_store(0);
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int buf = (kt - kt_begin) & 1;
+        g_load(min(kt + 1, kt_end - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            u32x4 a[2];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) a[pl] = ldsA[buf][(pl * CH + 2 * s + khalf) * 32 + l32];
+            z = mfma_split<true>(a, Xf[s], z);
+        }
+        u32x4 af[2][2];
+        const int dy = y - kt * 32 - 4 * khalf;          // the label's position among this lane's items
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float gv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = 8 * s + e, c = (r & 3) + 8 * (r >> 2);
+                // items past the end of the vocabulary carry no gradient (their table rows are zero in both images)
+                const float zz = (kt * 32 + c + 4 * khalf < V) ? zscale * z[r] : -INFINITY;
+                gv[e] = sg_value(zz, l2, dy == c, q);
+            }
+            split8s<true>(gv, 1.f, af[s]);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                u32x4 bf[2];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) bf[pl] = ldsT[buf][(pl * 4 + 2 * s + khalf) * D + 32 * j + l32];
+                acc[j] = mfma_split<true>(af[s], bf, acc[j]);
+            }
+        s_store(buf ^ 1);
+        __syncthreads();
+    }
+    float* pp = part + (long)split * N * D;
+    const int r0 = rt * 128 + 32 * wave + 4 * khalf;
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = r0 + (r & 3) + 8 * (r >> 2);
+            if (rr < N) pp[(long)rr * D + 32 * j + l32] = oscale * acc[j][r];
+        }
+}
+
 // out[row, :] (+)= sum over the splits, in split order (deterministic)
 __global__ __launch_bounds__(256) void head_dx_reduce_kernel(const float* __restrict__ part, int n_split, long nd4, int d4,
                                                               float* __restrict__ out, long ldo, int accumulate) {
@@ -812,7 +1135,7 @@ static int head_dx_target() {
     return target;
 }
 // workspace layout (bytes): XA | XT | WT | d X partials
-struct HeadWs { long xa, xt, wt, part, stats, scales, xth, colmax, islab, total; int nblk, nkt, max_split, ntile, vpad, rsplit; };
+struct HeadWs { long xa, xt, wt, part, stats, scales, xth, colmax, islab, xtp, wa, zlab, total; int nblk, nkt, max_split, ntile, vpad, rsplit; };
 // d W too (T4R_HEAD_DW_FP16X2, default 1; per-item scales: see head_dw_split_kernel)?
 static bool head_dw_fp16x2() {
     static int on = -1;
@@ -824,6 +1147,13 @@ static bool head_fwd_fp16x2() {
     static int on = -1;
     if (on < 0) { const char* e = getenv("T4R_HEAD_FWD_FP16X2"); on = e ? (atoi(e) != 0) : 1; }
     return on != 0;
+}
+// the recomputing form available (both fp16 switches on) and not switched off (T4R_HEAD_RECOMPUTE=0 also drops its 75 MB
+// of table planes from the workspace)?
+static bool head_recompute_on() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("T4R_HEAD_RECOMPUTE"); on = e ? (atoi(e) != 0) : 1; }
+    return on != 0 && head_fwd_fp16x2() && head_dw_fp16x2();
 }
 HeadWs head_ws(int N, int V, int D) {
     HeadWs w;
@@ -848,7 +1178,11 @@ HeadWs head_ws(int N, int V, int D) {
     w.rsplit = (w.nblk + head_rows_per_wg() - 1) / head_rows_per_wg();
     w.colmax = w.xth + w.nblk * blk;
     w.islab = w.colmax + (long)w.rsplit * w.vpad * 4;
-    w.total = w.islab + ((w.vpad + 255) / 256) * 256;
+    // the recomputing head (round 4): X in accumulator order (KMP), the table as MK blocks (its KMP blocks take `wt`), label logits
+    w.xtp = w.islab + ((w.vpad + 255) / 256) * 256;
+    w.wa = w.xtp + w.nblk * blk;
+    w.zlab = w.wa + (head_recompute_on() ? w.nkt * blk : 0);
+    w.total = w.zlab + (((long)N * 4 + 255) / 256) * 256;
     return w;
 }
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -912,6 +1246,10 @@ extern "C" int t4r_head_split_prepare(void* stream, const float* X, long ldx, in
         unsigned* amax = reinterpret_cast<unsigned*>((char*)ws + w.scales);
         u32x4* xth = reinterpret_cast<u32x4*>((char*)ws + w.xth);
         T4R_NB_SWITCH(D, hipLaunchKernelGGL((split_km_kernel<NB, true>), dim3(w.nblk), dim3(256), 0, st, X, ldx, N, xth, amax));
+        if (head_recompute_on()) {
+            u32x4* xtp = reinterpret_cast<u32x4*>((char*)ws + w.xtp);
+            T4R_NB_SWITCH(D, hipLaunchKernelGGL((split_kmp_kernel<NB, true>), dim3(w.nblk), dim3(256), 0, st, X, ldx, N, xtp, amax));
+        }
     }
     T4R_LAUNCH_CHECK();
     return 0;
@@ -1059,6 +1397,99 @@ extern "C" int t4r_head_split_dx(void* stream, void* ws, const float* logits, lo
     const long nd4 = (long)N * D / 4;
     hipLaunchKernelGGL(head_dx_reduce_kernel, dim3((unsigned)((nd4 + 255) / 256)), dim3(256), 0, st, part, splits, nd4, D / 4,
                        dX, lddx, accumulate);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The recomputing head (see head_dw_rc_kernel): cross-entropy WITHOUT a logits tensor, and its two backward products.
+extern "C" int t4r_head_split_recompute_supported(int D) { return t4r_head_split_supported(D) && head_recompute_on(); }
+
+// loss_rows [N], lse [N] (+ the mean loss) of softmax(alpha X W^T) against labels, from the prepared workspace: statistics
+// per 128-item tile merged by a small kernel, each row's label logit captured by the lane that holds it.  Nothing of size
+// [N, V] is written; predictions, when somebody wants them, are t4r_head_split_logits on the same workspace.
+extern "C" int t4r_head_split_ce(void* stream, void* ws, const float* W, long ldw, const long* labels, float* loss_rows,
+                                 float* lse, float* loss_mean, int N, int V, int D, float alpha, float label_smoothing, void* note) {
+    hipStream_t st = (hipStream_t)stream;
+    if (N <= 0 || V <= 0) return loss_mean ? t4r_mean_launch(st, loss_rows, 0, loss_mean) : 0;
+    T4R_CHECK_ARG(t4r_head_split_recompute_supported(D) && W && ws && labels && loss_rows && lse, "head_split_ce: unsupported (the two-way fp16 form must be on) or null pointer");
+    T4R_CHECK_ARG(aligned16(W) && ldw % 4 == 0, "head_split_ce: W must be 16-byte aligned with a pitch multiple of 4");
+    const HeadWs w = head_ws(N, V, D);
+    const int blk_per = max(1, min(w.nblk, head_rows_per_wg()));
+    const int rs = (w.nblk + blk_per - 1) / blk_per;
+    T4R_CHECK_ARG(rs == w.rsplit, "head_split_ce: row split mismatch");
+    const u32x4* xa = reinterpret_cast<const u32x4*>((const char*)ws + w.xa);
+    float* sm = reinterpret_cast<float*>((char*)ws + w.stats);
+    float* ss = sm + (long)w.ntile * N;
+    float* stt = label_smoothing > 0.f ? ss + (long)w.ntile * N : nullptr;
+    unsigned* amax = reinterpret_cast<unsigned*>((char*)ws + w.scales);
+    float* colmax = reinterpret_cast<float*>((char*)ws + w.colmax);
+    float* zlab = reinterpret_cast<float*>((char*)ws + w.zlab);
+    if (head_w_amax(st, W, ldw, V, D, amax + 1)) return -1;
+    if (note) *note_of(note) = FwdNote{W, nullptr, V, V, N, 1, 0, 0};
+    dim3 grid(8 * ((w.ntile + 7) / 8) * rs);
+    T4R_NB_SWITCH(D, hipLaunchKernelGGL(head_ce_stats_h_kernel<NB>, grid, dim3(256), 0, st, xa, W, ldw, N, V, alpha, w.nblk, blk_per, sm, ss,
+                                        stt, w.ntile, rs, amax, colmax, w.vpad, labels, zlab));
+    hipLaunchKernelGGL(head_ce_finalize_kernel, dim3((N + 31) / 32), dim3(1024), 0, st, sm, ss, stt, w.ntile, N, V, (const float*)nullptr,
+                       0L, labels, label_smoothing, loss_rows, lse, (const float*)zlab);
+    T4R_LAUNCH_CHECK();
+    return loss_mean ? t4r_mean_launch(st, loss_rows, N, loss_mean) : 0;
+}
+
+// d W[V, D] (+)= alpha * dlogits^T @ X with the score tiles recomputed (same workspace and note as t4r_head_split_ce)
+extern "C" int t4r_head_split_dw_rc(void* stream, void* ws, const float* W, long ldw, const float* lse, const long* labels,
+                                    const float* grad_out, float label_smoothing, float* dW, long lddw, int N, int V, int D,
+                                    float alpha, int accumulate, void* note_p) {
+    if (N <= 0 || V <= 0) return 0;
+    T4R_CHECK_ARG(t4r_head_split_recompute_supported(D) && W && lse && labels && dW && ws, "head_split_dw_rc: unsupported or null pointer");
+    FwdNote* note = note_of(note_p);
+    T4R_CHECK_ARG(note && note->colmax && note->W == W && note->V == V && note->N == N, "head_split_dw_rc: the note of this workspace's t4r_head_split_ce is required");
+    const HeadWs w = head_ws(N, V, D);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned* amax = reinterpret_cast<const unsigned*>((const char*)ws + w.scales);
+    float* lse_min = reinterpret_cast<float*>((char*)ws + w.scales) + 2;
+    unsigned char* islab = reinterpret_cast<unsigned char*>((char*)ws + w.islab);
+    if (hipMemsetAsync(islab, 0, (size_t)w.vpad, st) != hipSuccess) { t4r_set_error("head_split_dw_rc: memset failed"); return -1; }
+    hipLaunchKernelGGL(head_dw_aux_kernel, dim3(1), dim3(1024), 0, st, lse, labels, N, 0, V, lse_min, islab);
+    DwAux aux{reinterpret_cast<const float*>((const char*)ws + w.colmax), lse_min, islab, w.vpad, w.rsplit};
+    const u32x4* xa = reinterpret_cast<const u32x4*>((const char*)ws + w.xa);
+    const u32x4* xtp = reinterpret_cast<const u32x4*>((const char*)ws + w.xtp);
+    note->dw_form = 3;
+    T4R_NB_SWITCH(D, hipLaunchKernelGGL(head_dw_rc_kernel<NB>, dim3((V + 127) / 128), dim3(256), 0, st, xa, xtp, W, ldw, lse, labels,
+                                        grad_out, dW, lddw, N, V, label_smoothing, alpha, accumulate, w.nblk, amax, aux));
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+// d X[N, D] (+)= alpha * dlogits @ W with the score tiles recomputed.  X: the rows t4r_head_split_prepare was given.
+extern "C" int t4r_head_split_dx_rc(void* stream, void* ws, const float* X, long ldx, const float* W, long ldw, const float* lse,
+                                    const long* labels, const float* grad_out, float label_smoothing, float* dX, long lddx,
+                                    int N, int V, int D, float alpha, int accumulate, void* note_p) {
+    if (N <= 0 || V <= 0) return 0;
+    T4R_CHECK_ARG(t4r_head_split_recompute_supported(D) && X && W && lse && labels && dX && ws, "head_split_dx_rc: unsupported or null pointer");
+    T4R_CHECK_ARG(aligned16(X) && ldx % 4 == 0 && aligned16(W) && ldw % 4 == 0 && aligned16(dX) && lddx % 4 == 0,
+                  "head_split_dx_rc: X / W / dX must be 16-byte aligned with pitches multiple of 4");
+    FwdNote* note = note_of(note_p);
+    T4R_CHECK_ARG(note && note->W == W && note->Vw == V && note->N == N, "head_split_dx_rc: the note of this workspace's t4r_head_split_ce is required");
+    const HeadWs w = head_ws(N, V, D);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned* amax = reinterpret_cast<const unsigned*>((const char*)ws + w.scales);
+    u32x4* wtp = reinterpret_cast<u32x4*>((char*)ws + w.wt);
+    u32x4* wa = reinterpret_cast<u32x4*>((char*)ws + w.wa);
+    float* part = reinterpret_cast<float*>((char*)ws + w.part);
+    const int nkt = w.nkt, row_tiles = (N + 127) / 128;
+    // the table in both images, positioned by the max |W| the forward left (same table, same rows)
+    T4R_NB_SWITCH(D, hipLaunchKernelGGL((split_mk_kernel<NB, true>), dim3(nkt), dim3(256), 0, st, W, ldw, V, wa, amax + 1));
+    T4R_NB_SWITCH(D, hipLaunchKernelGGL((split_kmp_kernel<NB, true>), dim3(nkt), dim3(256), 0, st, W, ldw, V, wtp, amax + 1));
+    const int target = head_dx_target();
+    int splits = max(1, min(min(w.max_split, nkt / 8), target / row_tiles));
+    const int kt_per = (nkt + splits - 1) / splits;
+    splits = (nkt + kt_per - 1) / kt_per;
+    T4R_NB_SWITCH(D, hipLaunchKernelGGL(head_dx_rc_kernel<NB>, dim3(row_tiles * 8 * ((splits + 7) / 8)), dim3(256), 0, st, X, ldx, wa, wtp,
+                                        lse, labels, grad_out, part, N, V, label_smoothing, alpha, nkt, kt_per, row_tiles, amax));
+    const long nd4 = (long)N * D / 4;
+    hipLaunchKernelGGL(head_dx_reduce_kernel, dim3((unsigned)((nd4 + 255) / 256)), dim3(256), 0, st, part, splits, nd4, D / 4, dX, lddx,
+                       accumulate);
     T4R_LAUNCH_CHECK();
     return 0;
 }

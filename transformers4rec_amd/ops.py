@@ -211,6 +211,44 @@ def head_split_dx(ws, logits, lse, labels, grad_out, V, W, alpha=1.0, label_smoo
     return out
 
 
+# ---- the recomputing form: no [N, V] tensor (csrc/head_split.hip: head_ce_stats_h / head_dw_rc / head_dx_rc kernels)
+def head_split_recompute_supported(D):
+    return bool(_lib.load().t4r_head_split_recompute_supported(int(D)))
+
+
+def head_split_ce(ws, x, W, labels, alpha=1.0, label_smoothing=0.0):
+    """mean loss, loss rows, lse of softmax(alpha x W^T) vs labels from the prepared workspace; nothing of size [N, V] is written"""
+    N, D = x.shape
+    V = W.shape[0]
+    dev = x.device
+    loss_rows = torch.empty(N, device=dev, dtype=torch.float32)
+    lse = torch.empty(N, device=dev, dtype=torch.float32)
+    loss = torch.empty((), device=dev, dtype=torch.float32)
+    call("t4r_head_split_ce", _stream(), ws.data_ptr(), _chk(W, torch.float32), W.stride(0), _chk(labels, torch.int64),
+         loss_rows.data_ptr(), lse.data_ptr(), loss.data_ptr(), N, V, D, float(alpha), float(label_smoothing), _note(ws))
+    return loss, loss_rows, lse
+
+
+def head_split_dw_rc(ws, W, lse, labels, grad_out, out, alpha=1.0, label_smoothing=0.0, accumulate=True):
+    N = lse.shape[0]
+    V, D = W.shape
+    call("t4r_head_split_dw_rc", _stream(), ws.data_ptr(), _chk(W, torch.float32), W.stride(0), _chk(lse, torch.float32),
+         _chk(labels, torch.int64), _p(grad_out), float(label_smoothing), out.data_ptr(), out.stride(0), N, V, D, float(alpha),
+         int(accumulate), _note(ws))
+    return out
+
+
+def head_split_dx_rc(ws, x, W, lse, labels, grad_out, alpha=1.0, label_smoothing=0.0, out=None, accumulate=False):
+    N, D = x.shape
+    V = W.shape[0]
+    if out is None:
+        out = torch.empty((N, D), device=x.device, dtype=torch.float32)
+    call("t4r_head_split_dx_rc", _stream(), ws.data_ptr(), _chk(x, torch.float32), x.stride(0), _chk(W, torch.float32), W.stride(0),
+         _chk(lse, torch.float32), _chk(labels, torch.int64), _p(grad_out), float(label_smoothing), out.data_ptr(), out.stride(0),
+         N, V, D, float(alpha), int(accumulate), _note(ws))
+    return out
+
+
 # ------------------------------------------------------------------------------------ LN / act
 SITE_INPUT, SITE_POS, SITE_PROB, SITE_ATTN_OUT, SITE_FF_ACT, SITE_FF_OUT, SITE_FINAL = range(7)
 NO_DROP = (0.0, 0, 0)

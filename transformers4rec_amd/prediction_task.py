@@ -125,6 +125,7 @@ from .prediction_task_sync import wait_pending_grad  # noqa: E402,F401
 
 
 _HEAD_SPLIT = os.environ.get("T4R_HEAD_SPLIT", "1") != "0"
+_HEAD_RECOMPUTE = os.environ.get("T4R_HEAD_RECOMPUTE", "1") != "0"
 
 
 def _head_split_ok(xp, W, N, V):
@@ -153,7 +154,20 @@ class _NextItemHeadFn(torch.autograd.Function):
             xp = ops.gemm(xr, lin.weight.detach(), False, True, bias=lin.bias.detach(), epilogue=ops.EPI_BIAS)
         V = W.shape[0]
         smooth = float(getattr(task.loss, "label_smoothing", 0.0) or 0.0)
-        ctx.fused = neg is None and task.resolve_head_mode(N, V) == "fused"
+        mode = task.resolve_head_mode(N, V) if neg is None else "materialize"
+        ctx.fused = mode == "fused"
+        ctx.recompute = (mode == "recompute" and any(ctx.needs_input_grad) and _head_split_ok(xp, W, N, V)
+                         and ops.head_split_recompute_supported(W.shape[1]))
+        if ctx.recompute:
+            # no [N, V] tensor at all: statistics forward, score tiles recomputed by the two backward products
+            # (csrc/head_split.hip: head_dw_rc / head_dx_rc kernels); `predictions` is computed if somebody reads it
+            hws = ops.head_split_prepare(xp, V)
+            loss, _rows, lse = ops.head_split_ce(hws, xp, W.detach(), labels, alpha=1.0 / T, label_smoothing=smooth)
+            ctx.task, ctx.neg, ctx.meta = task, None, (B, L, D, N, V, T, V, smooth)
+            ctx.hws = hws
+            ctx.save_for_backward(pos, labels, labels, xr, xp, lse, lse)
+            ctx.set_materialize_grads(False)
+            return loss, None
         if ctx.fused:
             # non-materialising head: the vocabulary streams through one cache-sized [N, chunk] buffer,
             # online softmax statistics forward, chunk recomputation backward (csrc/head.hip)
@@ -196,7 +210,14 @@ class _NextItemHeadFn(torch.autograd.Function):
         W = mod.output_weights
         if dloss is None:
             return (None,) * 7
-        if ctx.fused:
+        if getattr(ctx, "recompute", False):
+            g = dloss.contiguous()
+            hws = ctx.hws
+            dxp = ops.head_split_dx_rc(hws, xp, W.detach(), lse, labels, g, alpha=1.0 / T, label_smoothing=smooth)
+            if W.requires_grad:
+                ops.head_split_dw_rc(hws, W.detach(), lse, labels, g, _grad_buf(W), alpha=1.0 / T, label_smoothing=smooth,
+                                     accumulate=True)
+        elif ctx.fused:
             dxp = ops.linear_softmax_ce_bwd(xp, W.detach(), labels, lse, dloss.contiguous(),
                                             dW=_grad_buf(W) if W.requires_grad else None, alpha=1.0 / T,
                                             label_smoothing=smooth)
@@ -321,8 +342,8 @@ class NextItemPredictionTask(nn.Module):
                  target_dim: int = None, sampled_softmax: Optional[bool] = False,
                  max_n_samples: Optional[int] = 100, top_ks=(10, 20), head_mode: str = "auto"):
         super().__init__()
-        if head_mode not in ("auto", "materialize", "fused"):
-            raise ValueError("head_mode must be 'auto', 'materialize' or 'fused'")
+        if head_mode not in ("auto", "materialize", "fused", "recompute"):
+            raise ValueError("head_mode must be 'auto', 'materialize', 'fused' or 'recompute'")
         # full-softmax training / evaluation head (beyond the reference's signature):
         #   "materialize": logits [N, V] in HBM, `predictions` is that tensor (what the reference returns)
         #   "fused"      : no [N, V] tensor; `predictions` is a LazyPredictions that computes them on first use
@@ -397,6 +418,17 @@ class NextItemPredictionTask(nn.Module):
         if mode == "auto":
             limit = float(os.environ.get("T4R_HEAD_AUTO_GB", "4")) * (1 << 30)
             mode = "materialize" if 4.0 * N * ops.pad_ld(V) <= limit else "fused"
+            # Scores too large to keep: at a head_split.hip width the RECOMPUTING head (round 4: statistics forward, score
+            # tiles recomputed by the two backward products, csrc/head_split.hip) replaces the chunked general path.
+            # Where the scores do fit it is NOT the default: measured at BASELINE configs[1] (d_model 128) the two extra
+            # products cost more than the 3.3 GB of logits traffic they save (step 3.13 vs 2.89 ms: DESIGN.md round 4);
+            # head_mode="recompute" / T4R_HEAD_MODE=recompute selects it anyway (training calls only: metrics read the scores)
+            D = self.pre.module.output_weights.shape[1]
+            if (mode == "fused" and getattr(self, "_training_call", False) and _HEAD_RECOMPUTE and D <= 128
+                    and ops.head_split_recompute_supported(D)):
+                mode = "recompute"
+        if mode == "recompute" and not getattr(self, "_training_call", False):
+            mode = "materialize"
         return mode
 
     def _lazy_predictions(self, x, pos, labels, N):
@@ -423,6 +455,7 @@ class NextItemPredictionTask(nn.Module):
         x = inputs.float()
         mod = self.pre.module
         if training or testing:
+            self._training_call = bool(training)
             n, pos, lab = self.masking.compact_labels()
             # N shapes the row-compacted operands; it was copied to the host right after the masking kernel
             # (masking.n_labels): by now it has long arrived, so this does not drain the queue

@@ -200,3 +200,54 @@ def test_attn_block_backward_matches_fp64_autograd(ops, B, L, D, n, drop_p, with
                                                       acc2["gamma"], acc2["beta"], B, L, n, drop_p, SEED, CTR_P, CTR_O, key_len=kl)
     assert torch.equal(dh, dh2) and torch.equal(dqkv, dqkv2) and torch.equal(dkr, dkr2)
     assert all(torch.equal(acc[k], acc2[k]) for k in acc)
+
+
+@pytest.mark.parametrize("B,L,D,n,per_session,klen", [
+    (5, 20, 128, 4, True, False), (1030, 20, 128, 4, True, False), (7, 20, 128, 4, False, False),
+    (6, 20, 128, 8, True, True), (9, 13, 64, 4, True, True), (3, 32, 64, 2, False, True), (4, 9, 32, 2, True, False),
+    (2, 5, 32, 1, False, False), (600, 8, 64, 4, False, False)])
+def test_attention_core_backward_planes_path(ops, monkeypatch, B, L, D, n, per_session, klen):
+    """t4r_xlnet_attn_bwd with q | k | v (and d q | d k | d v) as planes of one [3][T][D] buffer takes the one-wave-per-head
+    fp32-MFMA core (xlnet_attn_block.hip, CORE instantiation) when T4R_XLNET_ATTN_CORE16=1 (opt-in: measured slower than
+    xlnet_attn_mfma_bwd_kernel at the benchmark shape); checked against autograd of the fp32 restatement of
+    HF modeling_xlnet.py rel_attn_core :96-140 with the SAME Philox mask, and against the separate-tensor path."""
+    monkeypatch.setenv("T4R_XLNET_ATTN_CORE16", "1")
+    g = torch.Generator().manual_seed(B + 3 * L + D)
+    dh = D // n
+    p, seed, ctr = 0.3, 5, ops.dropout_ctr_hi(4, 2, ops.SITE_PROB)
+    q, k, v = (torch.randn(B, L, n, dh, generator=g).requires_grad_() for _ in range(3))
+    kr = torch.randn(*((B,) if per_session else ()), 2 * L, n, dh, generator=g).requires_grad_()
+    rw, rr = (0.5 * torch.randn(n, dh, generator=g)).requires_grad_(), (0.5 * torch.randn(n, dh, generator=g)).requires_grad_()
+    key_len = torch.randint(1, L + 1, (B,), generator=g, dtype=torch.int32) if klen else None
+    m = _mask(ops, (B, n, L, L), p, seed, ctr)
+    ac = torch.einsum("bind,bjnd->bnij", q + rw, k)
+    bd_full = torch.einsum("bind,bpnd->bnip" if per_session else "bind,pnd->bnip", q + rr, kr)
+    idx = torch.arange(L)[None, :] + L - torch.arange(L)[:, None]
+    bd = torch.gather(bd_full, 3, idx[None, None].expand(B, n, L, L))
+    sc = (ac + bd) / dh ** 0.5
+    if klen:
+        j = torch.arange(L)
+        dead = (j[None, None, :] >= key_len.long()[:, None, None]) & (j[None, None, :] != j[None, :, None])
+        sc = sc.masked_fill(dead[:, None], float("-inf"))
+    prob = torch.softmax(sc, 3) * m.float()            # _mask: already scaled by 1 / (1 - p)
+    ref = torch.einsum("bnij,bjnd->bind", prob, v)
+    dout = torch.randn(B, L, n, dh, generator=g)
+    ref.backward(dout)
+    f2 = lambda t: t.detach().reshape(-1, D).to(DEV).contiguous()
+    qkv = torch.stack([f2(q), f2(k), f2(v)])
+    rwd, rrd = f2(rw).reshape(-1), f2(rr).reshape(-1)
+    kl = key_len.to(DEV) if klen else None
+    out, lse = ops.xlnet_attn_fwd(qkv[0], qkv[1], qkv[2], f2(kr), rwd, rrd, B, L, n, drop=(p, seed, ctr), key_len=kl)
+    torch.testing.assert_close(out.cpu(), ref.detach().reshape(-1, D), atol=5e-5, rtol=1e-4)
+    res = {}
+    for name, (a, b, c) in dict(planes=(qkv[0], qkv[1], qkv[2]), separate=(qkv[0].clone(), qkv[1].clone(), qkv[2].clone())).items():
+        drw, drr = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+        dq, dk, dv, dkr = ops.xlnet_attn_bwd(a, b, c, f2(kr), rwd, rrd, out, lse, f2(dout), drw, drr, B, L, n,
+                                             drop=(p, seed, ctr), key_len=kl)
+        res[name] = [t.cpu() for t in (dq, dk, dv, dkr, drw, drr)]
+    want = [q.grad.reshape(-1, D), k.grad.reshape(-1, D), v.grad.reshape(-1, D), kr.grad.reshape(-1, D), rw.grad.reshape(-1), rr.grad.reshape(-1)]
+    for name, got in res.items():
+        for gt, wt, what in zip(got, want, ("dq", "dk", "dv", "dkr", "drw", "drr")):
+            # sums over up to B L terms (biases, shared k_r): absolute error scales with the sum's magnitude
+            tol = 2e-4 * max(1.0, float(wt.abs().max()))
+            assert float((gt - wt).abs().max()) <= tol, (name, what, float((gt - wt).abs().max()), tol)

@@ -97,6 +97,20 @@ for p in (0.3, 0.0):
         keep["c2"] = ops.xlnet_dh_(dqkv, planes, dh)
 
     tb, tc = timed(block_bwd), timed(chain_bwd)
+    # the core alone: q | k | v as planes of one buffer (one-wave-per-head fp32-MFMA core) vs separate tensors (xlnet_attn_mfma.hip)
+    dav_ = torch.randn(T, D, device=dev, generator=g)
+    sep = [t.clone() for t in saved["qkv"]]
+    core = lambda qs: (lambda: keep.__setitem__("core", ops.xlnet_attn_bwd(qs[0], qs[1], qs[2], kr, rw, rr, saved["av"], saved["lse"], dav_, d_rw, d_rr,
+                                                                            B, L, n, drop=(p, 7, cp) if p > 0 else ops.NO_DROP)))
+    print(f"dropout {p}: attention core backward alone: planes path {timed(core(saved['qkv'])):6.1f} us | separate-tensor path {timed(core(sep)):6.1f} us", flush=True)
+    if stamps is not None and os.environ.get("T4R_AB_STAMP_DETAIL") == "C":       # the CORE launch (stamp level 3)
+        stamps.zero_(); core(saved["qkv"])(); torch.cuda.synchronize()
+        st = stamps.view(-1, 8)[: min(B, 512) * n].double()
+        d = st[:, 1:8] - st[:, 0:7]
+        print("   core launch, cycles, median over waves [min .. max]:")
+        for i, nm in enumerate(["staging 1", "scores + gather (it 0)", "softmax bwd", "d v", "d q, d k, d k_r", "second query block", "rest (further sessions)"]):
+            print(f"      {nm:24s} {float(d[:, i].median()):9.0f}  [{float(d[:, i].min()):7.0f} .. {float(d[:, i].max()):7.0f}]")
+        print(f"      start spread over waves {float(st[:, 0].max() - st[:, 0].min()):9.0f}; first start -> last end {float(st[:, 7].max() - st[:, 0].min()):9.0f}")
     if stamps is not None and os.environ.get("T4R_AB_STAMP_DETAIL") == "3":
         stamps.zero_(); block_bwd(); torch.cuda.synchronize()
         st = stamps.view(-1, 8)[: (B // 4) * 8].double()

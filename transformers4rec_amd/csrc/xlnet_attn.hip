@@ -519,6 +519,12 @@ int t4r_xlnet_attn_mfma_bwd(hipStream_t st, const float* q, const float* k, cons
                             const float* rw, const float* rr, const float* lse, const float* dout, float* dq,
                             float* dk, float* dv, float* part, float* dkr, float* d_rw, float* d_rr, int B, int L,
                             int n_head, int d_head, float scale, long kr_bstride, DropCfg drop, const int* key_len);
+// the fp32-MFMA core with the permuted k-slots (xlnet_attn_block.hip, phase 3 of the block backward as its own launch)
+int t4r_xlnet_attn_core16_ok(int L, int D, int n_head);
+int t4r_xlnet_attn_core16_bwd(hipStream_t st, const float* qkv, const float* kr, const float* rw, const float* rr,
+                              const float* lse, const float* dout, float* dqkv, float* part, float* dkr, float* d_rw,
+                              float* d_rr, int B, int L, int n_head, int d_head, float scale, long kr_bstride, DropCfg drop,
+                              const int* key_len);
 static bool use_mfma(int L, int d_head) {
     static int en = -1;
     if (en < 0) { const char* e = getenv("T4R_ATTN_MFMA"); en = e ? atoi(e) : 1; }
@@ -625,6 +631,12 @@ extern "C" int t4r_xlnet_attn_bwd(void* stream, const float* q, const float* k, 
     hipStream_t st = (hipStream_t)stream;
     const long bs = kr_per_batch ? 2L * L * D : 0;
     const DropCfg dc = make_drop(drop_p, seed, ctr_hi);
+    {
+        const long TD = (long)B * L * D;
+        if (k == q + TD && v == q + 2 * TD && dk == dq + TD && dv == dq + 2 * TD && t4r_xlnet_attn_core16_ok(L, D, n_head))
+            return t4r_xlnet_attn_core16_bwd(st, q, k_r, r_w_bias, r_r_bias, lse, dout, dq, workspace, dk_r, d_r_w_bias,
+                                             d_r_r_bias, B, L, n_head, d_head, scale, bs, dc, key_len);
+    }
     if (use_mfma(L, d_head))
         return t4r_xlnet_attn_mfma_bwd(st, q, k, v, k_r, r_w_bias, r_r_bias, lse, dout, dq, dk, dv, workspace, dk_r,
                                        d_r_w_bias, d_r_r_bias, B, L, n_head, d_head, scale, bs, dc, key_len);

@@ -90,6 +90,20 @@ extern "C" void t4r_debug_ab_stamps(void* buf) { g_ab_stamps = (long long*)buf; 
 #define AB_STAMP_(k)
 #endif
 
+#ifndef T4R_CORE_NB
+#define T4R_CORE_NB 8
+#endif
+#ifndef T4R_CORE_SLOTS
+#define T4R_CORE_SLOTS 512
+#endif
+// workgroup barrier that orders LDS traffic only (__syncthreads also waits for the wave's stores to memory)
+__device__ __forceinline__ void lds_barrier() {
+#ifdef T4R_CORE_FULLBAR
+    __syncthreads();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
 constexpr int AB_RT = 80;       // token rows of a workgroup tile (5 blocks of 16)
 constexpr int AB_R = AB_RT / 16;
 constexpr int AB_PR = 68;       // pitch of the per-wave 16 x 64 exchange buffer (PR - 1 odd: the shifted gather spreads over the banks)
@@ -599,6 +613,7 @@ struct AttnBlockBwd {
     const float* kr; long kr_bstride;
     const float *rw, *rr, *lse;
     float *dh, *dao, *dqkv;  // [T][D], [T][D], [3][T][D]
+    const float* dav;        // CORE launch only: d attn_vec [T][D] (the block launch computes it in phase 2)
     float* dkr_b;            // per-session d k_r [B][2L][D] (kr_bstride > 0), else NULL
     float* part_ln;          // [grid][2 D]: d gamma | d beta partial sums
     float* part_at;          // [grid * (d_head / 16)][2 L D + 2 D]: shared d k_r | d r_w_bias | d r_r_bias partial sums
@@ -612,19 +627,24 @@ struct AttnBlockBwd {
 #endif
 };
 
-template <int D, int DH>
+// CORE = true: phase 3 alone as a launch of its own (d attn_vec read from memory, one wave per head, SC sessions staged
+// at a time -- LDS small enough for two workgroups per CU); the caller runs LayerNorm backward / d attn_vec before it and
+// the d h product after it (t4r_xlnet_attn_core16_bwd below).
+template <int D, int DH, bool CORE>
 __global__ __launch_bounds__(D * 4) void xlnet_attn_block_bwd_kernel(AttnBlockBwd p) {
-    constexpr int NW = D / 16, NH = D / DH, KC = D / 16, HC = DH / 16, PQ = 3 * D + 4, PV = D + 4, XR = 40;
+    constexpr int NH = D / DH, NW = CORE ? NH : D / 16, KC = D / 16, HC = DH / 16, PQ = 3 * D + 4, PV = D + 4, XR = 40;
     extern __shared__ float smem[];
-    float* sv = smem;                                 // [AB_RT][PV]: d attn_vec of the tile's rows
-    float* xs = smem + AB_RT * PV;                    // [XR][PQ] staged q | k | v rows of SC sessions; before: d attn_out [AB_RT][PV]; after: d q / d k / d v tile
-    float* xbuf = xs + XR * PQ;                       // [NW][16][AB_PR] exchange buffers
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, g = lane >> 4;
     const int L = p.L;
+    float* sv = smem;                                 // [AB_RT][PV]: d attn_vec of the tile's rows (CORE: [SC L][PV], of the staged sessions)
+    float* xs = smem + (CORE ? L : AB_RT) * PV;      // [XR][PQ] staged q | k | v rows of SC sessions; before: d attn_out [AB_RT][PV]; after: d q / d k / d v tile
+    float* skr = xs + (CORE ? L : XR) * PQ;           // CORE: [2 L][PV] k_r rows of the staged session (or the shared ones)
+    float* xbuf = skr + (CORE ? 2 * L * PV : 0);      // [NW][16][AB_PR] exchange buffers
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, g = lane >> 4;
     const int b0 = blockIdx.x * p.S, nb = min(p.S, p.B - b0), rows = nb * L;
     const long t0 = (long)b0 * L, TD = p.T * D;
 
     AB_STAMP_B(0);
+    if constexpr (!CORE) {
     // the o^T rows of phase 2 are requested first: they arrive under the LayerNorm backward
     float wf[4 * KC];
 #pragma unroll
@@ -635,7 +655,6 @@ __global__ __launch_bounds__(D * 4) void xlnet_attn_block_bwd_kernel(AttnBlockBw
         for (int e = 0; e < 4; ++e) wf[4 * c + e] = t4[e];
     }
     // ------------------------------------------------------------------------------------------------ phase 1
-    {
         float* sd = xs;                               // [AB_RT][PV]
         float* sh_part = xbuf;                        // [NW][2][D]
         const int c0 = lane * 2;
@@ -720,9 +739,9 @@ __global__ __launch_bounds__(D * 4) void xlnet_attn_block_bwd_kernel(AttnBlockBw
         }
 #pragma unroll
         for (int r = 0; r < AB_R; ++r) *reinterpret_cast<float4*>(sv + (16 * r + n) * PV + 16 * w + 4 * g) = f4(acc[r]);
-    }
     AB_STAMP_B(2);
     __syncthreads();
+    }
     AB_STAMP_B(3);
 
     // ------------------------------------------------------------------------------------------------ phase 3
@@ -743,37 +762,66 @@ __global__ __launch_bounds__(D * 4) void xlnet_attn_block_bwd_kernel(AttnBlockBw
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int dt = 0; dt < HC; ++dt) dkrT[mt][dt] = zero4();
+        // the wave's head is fixed: its bias rows / columns once
+                        float rwv[4 * HC], rrv[4 * HC], rwc[HC], rrc[HC];
+        #pragma unroll
+                        for (int c = 0; c < HC; ++c) {
+                            float t4[4];
+                            put4(t4, ld4(p.rw + hc + 16 * c + 4 * g));
+        #pragma unroll
+                            for (int e = 0; e < 4; ++e) rwv[4 * c + e] = t4[e];
+                            put4(t4, ld4(p.rr + hc + 16 * c + 4 * g));
+        #pragma unroll
+                            for (int e = 0; e < 4; ++e) rrv[4 * c + e] = t4[e];
+                            rwc[c] = p.rw[hc + 16 * c + n];
+                            rrc[c] = p.rr[hc + 16 * c + n];
+                        }
         AB_STAMP_3(0, true);
         for (int s0 = 0; s0 < nb; s0 += p.SC) {
             const int sc = min(p.SC, nb - s0);
             // stage q | k | v rows of sessions s0 .. s0 + sc - 1 (coalesced).  Measured and not kept: all requests of a thread in
             // flight at once through registers, the first chunk requested before phase 1 -- the kernel is at its register limit
             // and the staging registers spilled (phase 3: 170 k -> 220 k cycles)
-            __syncthreads();                          // the previous chunk's units are done with xs (first chunk: phase 2 with sd)
+            if constexpr (CORE) lds_barrier();        // the previous session's unit is done with the tiles (its stores to memory need not have landed)
+            else __syncthreads();                     // the previous chunk's units are done with xs (first chunk: phase 2 with sd)
+            if constexpr (CORE) {
+                // one session (SC = 1): q | k | v rows, d attn_vec rows and the session's k_r rows (shared k_r: once), every
+                // request of a batch in flight before the first LDS store (a load -> store loop is one memory latency per turn)
+                constexpr int F4 = D / 4, NB = T4R_CORE_NB;
+                const int nrow = ((!shared_kr || s0 == 0) ? 6 : 4) * L;
+                const long tokb = t0 + (long)s0 * L;
+                const float* krsrc = p.kr + (long)(b0 + s0) * p.kr_bstride;
+                for (int base = 0; base < nrow * F4; base += NB * NW * 64) {
+                    float4 t[NB];
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) {
+                        const int idx = min(base + i * NW * 64 + tid, nrow * F4 - 1), R = idx / F4, c4 = (idx - R * F4) * 4;
+                        const int reg = R / L, row = R - reg * L;
+                        const float* src = reg < 3 ? p.qkv + reg * TD + (tokb + row) * D + c4
+                                           : reg == 3 ? p.dav + (tokb + row) * D + c4 : krsrc + (long)(R - 4 * L) * D + c4;
+                        t[i] = ld4(src);
+                    }
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) {
+                        const int idx = base + i * NW * 64 + tid, R = idx / F4, c4 = (idx - R * F4) * 4;
+                        const int reg = R / L, row = R - reg * L;
+                        float* dst = reg < 3 ? xs + row * PQ + reg * D + c4 : reg == 3 ? sv + row * PV + c4 : skr + (R - 4 * L) * PV + c4;
+                        if (idx < nrow * F4) *reinterpret_cast<float4*>(dst) = t[i];
+                    }
+                }
+            } else {
             for (int idx = tid; idx < sc * L * (3 * D / 4); idx += NW * 64) {
                 const int row = idx / (3 * D / 4), rem = idx - row * (3 * D / 4), z = rem / (D / 4), c4 = (rem - z * (D / 4)) * 4;
                 *reinterpret_cast<float4*>(xs + row * PQ + z * D + c4) = ld4(p.qkv + z * TD + (t0 + (long)s0 * L + row) * D + c4);
             }
-            __syncthreads();
+            }
+            if constexpr (CORE) lds_barrier(); else __syncthreads();
             AB_STAMP_3(1, s0 == 0);
             for (int u = w; u < sc * NH; u += NW) {
-                const int sl = u / NH, s = s0 + sl, b = b0 + s, r0 = sl * L, rv = s * L;       // rows in xs / in sv
+                const int sl = u / NH, s = s0 + sl, b = b0 + s, r0 = sl * L, rv = CORE ? sl * L : s * L;       // rows in xs / in sv
                 const float* krb = p.kr + (long)b * p.kr_bstride;
                 const int klen = p.key_len ? p.key_len[b] : L;
                 const long tok0 = t0 + (long)s * L;
-                float rwv[4 * HC], rrv[4 * HC], rwc[HC], rrc[HC];
-#pragma unroll
-                for (int c = 0; c < HC; ++c) {
-                    float t4[4];
-                    put4(t4, ld4(p.rw + hc + 16 * c + 4 * g));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) rwv[4 * c + e] = t4[e];
-                    put4(t4, ld4(p.rr + hc + 16 * c + 4 * g));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) rrv[4 * c + e] = t4[e];
-                    rwc[c] = p.rw[hc + 16 * c + n];
-                    rrc[c] = p.rr[hc + 16 * c + n];
-                }
                 f32x4 dvT[JT][HC], dkT[JT][HC];
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt)
@@ -788,6 +836,7 @@ __global__ __launch_bounds__(D * 4) void xlnet_attn_block_bwd_kernel(AttnBlockBw
 #pragma unroll 1
                 for (int it = 0; it < JT; ++it) {
                     const int i = 16 * it + n, ic = min(i, L - 1);
+                    const float lrow = p.lse[((long)b * NH + hh) * L + ic];     // requested before the products it follows
                     // ---- scores: S^T, raw^T (as the forward), d P^T = v d O^T
                     float pv[JT][4], dpv[JT][4];
                     {
@@ -810,7 +859,8 @@ __global__ __launch_bounds__(D * 4) void xlnet_attn_block_bwd_kernel(AttnBlockBw
 #pragma unroll
                             for (int c = 0; c < HC; ++c) {
                                 float t4[4];
-                                put4(t4, ld4(krb + (long)min(16 * mt + n, 2 * L - 1) * D + hc + 16 * c + 4 * g));
+                                if constexpr (CORE) put4(t4, lds4(skr + min(16 * mt + n, 2 * L - 1) * PV + hc + 16 * c + 4 * g));
+                                else put4(t4, ld4(krb + (long)min(16 * mt + n, 2 * L - 1) * D + hc + 16 * c + 4 * g));
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) krf[mt][4 * c + e] = t4[e];
                             }
@@ -841,7 +891,6 @@ __global__ __launch_bounds__(D * 4) void xlnet_attn_block_bwd_kernel(AttnBlockBw
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<float4*>(Y + n * AB_PR + 16 * mt + 4 * g) = f4(rT[mt]);
                         wave_lds_sync();
-                        const float lrow = p.lse[((long)b * NH + hh) * L + ic];
 #pragma unroll
                         for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
@@ -933,7 +982,8 @@ __global__ __launch_bounds__(D * 4) void xlnet_attn_block_bwd_kernel(AttnBlockBw
                             for (int e = 0; e < 4; ++e)
 #pragma unroll
                                 for (int dt = 0; dt < HC; ++dt)
-                                    krc[mt][e][dt] = krb[(long)min(16 * mt + 4 * g + e, 2 * L - 1) * D + hc + 16 * dt + n];
+                                    krc[mt][e][dt] = CORE ? skr[min(16 * mt + 4 * g + e, 2 * L - 1) * PV + hc + 16 * dt + n]
+                                                          : krb[(long)min(16 * mt + 4 * g + e, 2 * L - 1) * D + hc + 16 * dt + n];
                         f32x4 dqa[HC], dqb[HC];
 #pragma unroll
                         for (int dt = 0; dt < HC; ++dt) { dqa[dt] = zero4(); dqb[dt] = zero4(); }
@@ -1062,7 +1112,7 @@ __global__ __launch_bounds__(D * 4) void xlnet_attn_block_bwd_kernel(AttnBlockBw
     AB_STAMP_B(4);
     // ------------------------------------------------------------------------------------------------ phase 4
     // d h[tok][k] += sum_z sum_o d z[tok][o] W_z[k][o]: wave w owns k = 16 w .. 16 w + 15
-    {
+    if constexpr (!CORE) {
         f32x4 acc[AB_R];
 #pragma unroll
         for (int r = 0; r < AB_R; ++r) acc[r] = zero4();
@@ -1161,7 +1211,7 @@ extern "C" int t4r_xlnet_attn_block_bwd(void* stream, const float* dy, const flo
     p.woT = carve_planes_32(planes, D).OT;
     p.wqkv[0] = wq; p.wqkv[1] = wk; p.wqkv[2] = wv;
     p.qkv = qkv; p.kr = kr; p.kr_bstride = kr_bstride; p.rw = r_w_bias; p.rr = r_r_bias; p.lse = lse;
-    p.dh = dh; p.dao = dao; p.dqkv = dqkv; p.dkr_b = kr_bstride > 0 ? dkr : nullptr;
+    p.dh = dh; p.dao = dao; p.dqkv = dqkv; p.dav = nullptr; p.dkr_b = kr_bstride > 0 ? dkr : nullptr;
     p.part_ln = part; p.part_at = part + (long)grid_n * 2 * D;
     p.key_len = key_len; p.B = B; p.L = L; p.S = S; p.SC = 40 / L > 0 ? 40 / L : 1; p.T = (long)B * L;
     p.scale = 1.0f / sqrtf((float)dhd);
@@ -1176,8 +1226,8 @@ extern "C" int t4r_xlnet_attn_block_bwd(void* stream, const float* dy, const flo
 #define T4R_AB_BWD(DD, DHH)                                                                                                  \
     {                                                                                                                        \
         static bool once = false;                                                                                            \
-        if (!once) { (void)hipFuncSetAttribute((const void*)xlnet_attn_block_bwd_kernel<DD, DHH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); once = true; } \
-        hipLaunchKernelGGL((xlnet_attn_block_bwd_kernel<DD, DHH>), grid, block, smem, st, p);                                \
+        if (!once) { (void)hipFuncSetAttribute((const void*)xlnet_attn_block_bwd_kernel<DD, DHH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); once = true; } \
+        hipLaunchKernelGGL((xlnet_attn_block_bwd_kernel<DD, DHH, false>), grid, block, smem, st, p);                                \
     }
     switch (D * 100 + dhd) {
         case 12832: T4R_AB_BWD(128, 32) break;
@@ -1194,4 +1244,52 @@ extern "C" int t4r_xlnet_attn_block_bwd(void* stream, const float* dy, const flo
     if (rc) return rc;
     return t4r_reduce_partials_launch(st, p.part_at, grid_n * (dhd / 16), kr_bstride > 0 ? nullptr : dkr, 2 * L * D, 0, d_rw, D, 1,
                                       d_rr, D, 1);
+}
+
+// ------------------------------------------------------------------------------------------------ the core alone
+// Phase 3 of the kernel above as the attention-core backward of t4r_xlnet_attn_bwd (xlnet_attn.hip dispatches here when
+// q | k | v and d q | d k | d v are planes of one [3][T][D] buffer, which is how the layer holds them, and
+// T4R_XLNET_ATTN_CORE16=1): one wave per head, one session staged at a time, two workgroups per CU.  part: >= grid * (2 L D + 2 D) floats, grid <= min(B, 512).
+int t4r_xlnet_attn_core16_ok(int L, int D, int n_head) {
+    // default OFF -- measured (round 4, B 1024 / L 20 / D 128 / 4 heads, dropout 0.3): 65.6 us alone vs 61.3 us for
+    // xlnet_attn_mfma_bwd_kernel, and 3.19 vs 3.09 ms per training step; read per call so that a test can switch it
+    const char* e = getenv("T4R_XLNET_ATTN_CORE16");
+    return e && atoi(e) && t4r_xlnet_attn_block_supported(L, D, n_head);
+}
+int t4r_xlnet_attn_core16_bwd(hipStream_t st, const float* qkv, const float* kr, const float* rw, const float* rr,
+                              const float* lse, const float* dout, float* dqkv, float* part, float* dkr, float* d_rw,
+                              float* d_rr, int B, int L, int n_head, int d_head, float scale, long kr_bstride, DropCfg drop,
+                              const int* key_len) {
+    const int D = n_head * d_head;
+    const int S = (B + T4R_CORE_SLOTS - 1) / T4R_CORE_SLOTS, grid_n = (B + S - 1) / S;
+    AttnBlockBwd p = {};
+    p.qkv = qkv; p.kr = kr; p.kr_bstride = kr_bstride; p.rw = rw; p.rr = rr; p.lse = lse;
+    p.dqkv = dqkv; p.dav = dout; p.dkr_b = kr_bstride > 0 ? dkr : nullptr;
+    p.part_at = part;
+    p.key_len = key_len; p.B = B; p.L = L; p.S = S; p.SC = 1; p.T = (long)B * L;
+    p.scale = scale;
+    p.drop_p = drop;
+#ifdef T4R_AB_STAMPS
+    p.stamps = g_ab_stamps;
+#endif
+    const dim3 grid((unsigned)grid_n), block((unsigned)(n_head * 64));
+    const size_t smem = ((size_t)3 * L * (D + 4) + (size_t)L * (3 * D + 4) + (size_t)n_head * 16 * AB_PR) * sizeof(float);
+#define T4R_AB_CORE(DD, DHH)                                                                                                 \
+    {                                                                                                                        \
+        static bool once = false;                                                                                            \
+        if (!once) { (void)hipFuncSetAttribute((const void*)xlnet_attn_block_bwd_kernel<DD, DHH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); once = true; } \
+        hipLaunchKernelGGL((xlnet_attn_block_bwd_kernel<DD, DHH, true>), grid, block, smem, st, p);                          \
+    }
+    switch (D * 100 + d_head) {
+        case 12832: T4R_AB_CORE(128, 32) break;
+        case 12816: T4R_AB_CORE(128, 16) break;
+        case 6432: T4R_AB_CORE(64, 32) break;
+        case 6416: T4R_AB_CORE(64, 16) break;
+        case 3232: T4R_AB_CORE(32, 32) break;
+        case 3216: T4R_AB_CORE(32, 16) break;
+        default: t4r_set_error("xlnet_attn_core16_bwd: no instantiation"); return -1;
+    }
+#undef T4R_AB_CORE
+    T4R_LAUNCH_CHECK();
+    return t4r_reduce_partials_launch(st, part, grid_n, kr_bstride > 0 ? nullptr : dkr, 2 * L * D, 0, d_rw, D, 1, d_rr, D, 1);
 }

@@ -578,7 +578,9 @@ def xlnet_attn_bwd(q, k, v, k_r, r_w_bias, r_r_bias, out, lse, dout, d_rw, d_rr,
     D = q.shape[-1]
     dev = q.device
     per_b = int(k_r.shape[0] == B * 2 * L and B > 1)
-    dq, dk, dv = (torch.empty((B * L, D), device=dev, dtype=torch.float32) for _ in range(3))
+    # planes of one [3, T, D] buffer, as the layer holds them (with q | k | v laid out the same way and
+    # T4R_XLNET_ATTN_CORE16=1 the library takes the one-wave-per-head fp32-MFMA core of csrc/xlnet_attn_block.hip)
+    dq, dk, dv = torch.empty((3, B * L, D), device=dev, dtype=torch.float32).unbind(0)
     dkr = torch.empty_like(k_r)
     nws = _lib.load().t4r_xlnet_attn_bwd_ws_floats(B, L, D, n_head)
     ws = torch.empty(nws, device=dev, dtype=torch.float32)

@@ -864,8 +864,31 @@ def main():
                 "traffic_fwd": 27.0e6 + 105.1e6, "traffic_bwd": 88.5e6 + 72.6e6,
                 "traffic_source": "committed (not measured in this run): profiles/r03_e_pmc_gemm_fetch_write.csv "
                                   "(FETCH_SIZE x 2 KB + WRITE_SIZE KB, separate rocprofv3 --pmc passes)",
-                "matrix_pipe_busy": {"fwd": 0.218, "bwd": 0.169, "source": "profiles/r03_e_pmc_mfma_util.csv (in-step; measured on the "
-                                     "six-product bf16 form of these kernels, before the fp16 split)"}}
+                "matrix_pipe_busy": {"fwd": 0.125, "bwd": 0.089, "source": "profiles/r04_f_pmc_mfma_busy.csv (in-step, the shipped two-way "
+                                     "fp16 form: SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs; the six-product bf16 "
+                                     "form measured 0.218 / 0.169 in round 3 -- half the matrix instructions, same wall time)"}}
+        # the attention half of the forward as ONE kernel (csrc/xlnet_attn_block.hip, round 4), timed live at this shape;
+        # north_star's "MFMA utilisation on attention" is the committed in-step counter figure beside it
+        if ops.xlnet_attn_block_supported(SEQ, D_MODEL, N_HEAD):
+            gen = torch.Generator(device=device).manual_seed(5)
+            kr_ = 0.3 * torch.randn(BATCH * 2 * SEQ, D_MODEL, device=device, generator=gen)
+            hh_ = torch.randn(Tt, D_MODEL, device=device, generator=gen)
+            dh_ = D_MODEL // N_HEAD
+            ab = lambda: ops.xlnet_attn_block_fwd(hh_, planes, prm[3].view(D_MODEL, D_MODEL), kr_, prm[5].view(-1), prm[6].view(-1),
+                                                  prm[7], prm[8], BATCH, SEQ, N_HEAD, 0.03, args.dropout, 7, 21, 22)
+            ab_ms = timed(ab)
+            ab_flops = 2.0 * Tt * D_MODEL * 4 * D_MODEL + 2.0 * BATCH * N_HEAD * (2 * SEQ * SEQ * dh_ + SEQ * 2 * SEQ * dh_)
+            body["attention_block_fwd"] = {
+                "kernel": "xlnet_attn_block_fwd_kernel<128, 32> (q|k|v projection + relative attention core + o-projection + dropout + "
+                          "residual + LayerNorm in one launch; exact fp32 products on v_mfma_f32_16x16x4_f32)",
+                "avg_launch_ms": round(ab_ms, 4), "flops_per_launch": ab_flops,
+                "achieved": round(ab_flops / (ab_ms * 1e-3) / 1e12, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ab_flops / (ab_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                "algorithmic_bytes": int(4 * Tt * D_MODEL * 7),
+                "matrix_pipe_busy": {"fwd": 0.378, "bwd_core": 0.311, "target": 0.50,
+                                     "source": "profiles/r04_f_pmc_mfma_busy.csv (in-step; bwd_core = xlnet_attn_mfma_bwd_kernel, unchanged "
+                                               "since round 1; round 3: forward core 0.21)"}}
+            del kr_, hh_
         del planes, h1, dyy, sv
 
     # HBM bytes of the launches from the PMC counters (FETCH_SIZE x2 on gfx950, WRITE_SIZE calibrated

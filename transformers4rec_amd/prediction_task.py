@@ -423,10 +423,10 @@ class NextItemPredictionTask(nn.Module):
             # Where the scores do fit it is NOT the default: measured at BASELINE configs[1] (d_model 128) the two extra
             # products cost more than the 3.3 GB of logits traffic they save (step 3.13 vs 2.89 ms: DESIGN.md round 4);
             # head_mode="recompute" / T4R_HEAD_MODE=recompute selects it anyway (training calls only: metrics read the scores)
-            D = self.pre.module.output_weights.shape[1]
-            if (mode == "fused" and getattr(self, "_training_call", False) and _HEAD_RECOMPUTE and D <= 128
-                    and ops.head_split_recompute_supported(D)):
-                mode = "recompute"
+            if mode == "fused" and getattr(self, "_training_call", False) and _HEAD_RECOMPUTE:
+                D = self.pre.module.output_weights.shape[1]
+                if D <= 128 and ops.head_split_recompute_supported(D):
+                    mode = "recompute"
         if mode == "recompute" and not getattr(self, "_training_call", False):
             mode = "materialize"
         return mode

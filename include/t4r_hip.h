@@ -247,8 +247,10 @@ int t4r_head_split_dx(void* stream, void* ws, const float* logits, long ld, cons
  * once and read twice per step at BASELINE configs[1] become two more products).  Same workspace (t4r_head_split_prepare),
  * same note discipline (the note _ce fills is REQUIRED by _dw_rc / _dx_rc), whole vocabulary only (no chunks); predictions,
  * when wanted, are t4r_head_split_logits on the same workspace.  X in _dx_rc: the rows _prepare was given.
- * t4r_head_note_dw_form reports 3 after _dw_rc. */
+ * t4r_head_note_dw_form reports 3 after _dw_rc.  _prepare_rc (after _prepare, same X and workspace, before _ce) cuts the one
+ * more image of X that _dw_rc reads; the materialised head does not need it. */
 int t4r_head_split_recompute_supported(int D);
+int t4r_head_split_prepare_rc(void* stream, const float* X, long ldx, int N, int D, int V, void* ws);
 int t4r_head_split_ce(void* stream, void* ws, const float* W, long ldw, const long* labels, float* loss_rows, float* lse,
                       float* loss_mean, int N, int V, int D, float alpha, float label_smoothing, void* note);
 int t4r_head_split_dw_rc(void* stream, void* ws, const float* W, long ldw, const float* lse, const long* labels,

@@ -64,6 +64,7 @@ _SIGS = {
     "t4r_head_split_dw": ("i", "ppplpppf" + "pl" + "iiiii" + "fi" + "p"),
     "t4r_head_split_dx": ("i", "ppplpppf" + "plpl" + "iiiii" + "fi" + "p"),
     "t4r_head_split_recompute_supported": ("i", "i"),
+    "t4r_head_split_prepare_rc": ("i", "ppl" + "iii" + "p"),
     "t4r_head_split_ce": ("i", "ppplpppp" + "iiiff" + "p"),
     "t4r_head_split_dw_rc": ("i", "ppplpppf" + "pl" + "iiifi" + "p"),
     "t4r_head_split_dx_rc": ("i", "ppplplpppf" + "pl" + "iiifi" + "p"),

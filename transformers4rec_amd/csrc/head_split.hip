@@ -114,25 +114,33 @@ __device__ __forceinline__ f32x16 mfma_split_swapped(const u32x4 (&a)[2], const 
 }
 // largest magnitude of a [rows, cols] matrix as the bits of a non-negative float (they order like unsigned integers), and
 // the power of two that maps it into [2^13, 2^14)
-__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ src, long ld, long rows, int cols,
-                                                    unsigned* __restrict__ out) {
-    const long n4 = rows * (cols / 4);
+__global__ __launch_bounds__(1024) void amax_kernel(const float* __restrict__ src, long ld, long rows, int cols,
+                                                     unsigned* __restrict__ out) {
+    const long n4 = rows * (cols / 4), stride = (long)gridDim.x * blockDim.x;
+    const int c4n = cols / 4;
     float m = 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        const long r = i / (cols / 4);
-        const int c = (int)(i % (cols / 4)) * 4;
-        const float4 v = *reinterpret_cast<const float4*>(src + r * ld + c);
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    // four requests in flight per lane (clamped addresses: a repeated element does not change a maximum)
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += 4 * stride) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long j = min(i + u * stride, n4 - 1);
+            v[u] = *reinterpret_cast<const float4*>(src + (j / c4n) * ld + (int)(j % c4n) * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    // ONE atomic per workgroup (<= 256 in all): with one per wave of 2048 workgroups the launch took 75-100 us -- atomics on
-    // one word serialise at the memory side
-    __shared__ float red[4];
+    // ONE atomic per workgroup and at most 256 workgroups (of up to 1024 threads): atomics on one word serialise at the memory
+    // side at ~12 ns each -- one per wave of 2048 workgroups made the launch 75-100 us, one per workgroup of 1024 still 27 us
+    // for the 51 MB table (12 us of it the atomics; round 4)
+    __shared__ float red[16];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
-        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        const int nw = (int)(blockDim.x >> 6);
+        for (int w = 1; w < nw; ++w) m = fmaxf(m, red[w]);
         if (m > 0.f) atomicMax(out, __float_as_uint(m));
     }
 }
@@ -549,8 +557,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // d W's per-item scales need: min over the rows of lse, and which items are some row's label (their column holds a -g (1 - eps))
 __global__ __launch_bounds__(1024) void head_dw_aux_kernel(const float* __restrict__ lse, const long* __restrict__ labels, int N,
                                                             int yoff, int Vc, float* __restrict__ lse_min,
-                                                            unsigned char* __restrict__ islab) {
+                                                            unsigned char* __restrict__ islab, int vpad) {
     __shared__ float red[16];
+    // the flags are cleared here (one workgroup: a barrier orders the clear before the marks) -- a hipMemsetAsync of the
+    // ~100 KB array in front of this launch became three fill kernels of ~6 us each on the critical stream
+    for (int i = threadIdx.x; i < vpad / 16; i += 1024) reinterpret_cast<uint4*>(islab)[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = (vpad / 16) * 16 + threadIdx.x; i < vpad; i += 1024) islab[i] = 0;
+    __threadfence_block();
+    __syncthreads();
     float m = INFINITY;
     for (int i = threadIdx.x; i < N; i += 1024) {
         m = fminf(m, lse[i]);
@@ -1115,7 +1129,8 @@ __global__ __launch_bounds__(256) void head_dx_reduce_kernel(const float* __rest
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= nd4) return;
     float4 s = reinterpret_cast<const float4*>(part)[i];
-    for (int k = 1; k < n_split; ++k) {
+#pragma unroll 8
+    for (int k = 1; k < n_split; ++k) {      // eight requests in flight, added in split order
         const float4 t = reinterpret_cast<const float4*>(part)[(long)k * nd4 + i];
         s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
@@ -1201,7 +1216,7 @@ extern "C" int t4r_head_note_dw_form(const void* note) { return note ? reinterpr
 static int head_w_amax(hipStream_t st, const float* W, long ldw, int V, int D, unsigned* out) {
     if (hipMemsetAsync(out, 0, 4, st) != hipSuccess) { t4r_set_error("head_split: memset failed"); return -1; }
     const long n4 = (long)V * (D / 4);
-    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)min(1024L, (n4 + 255) / 256)), dim3(256), 0, st, W, ldw, (long)V, D, out);
+    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)min(256L, (n4 + 1023) / 1024)), dim3(1024), 0, st, W, ldw, (long)V, D, out);
     return 0;
 }
 
@@ -1246,11 +1261,23 @@ extern "C" int t4r_head_split_prepare(void* stream, const float* X, long ldx, in
         unsigned* amax = reinterpret_cast<unsigned*>((char*)ws + w.scales);
         u32x4* xth = reinterpret_cast<u32x4*>((char*)ws + w.xth);
         T4R_NB_SWITCH(D, hipLaunchKernelGGL((split_km_kernel<NB, true>), dim3(w.nblk), dim3(256), 0, st, X, ldx, N, xth, amax));
-        if (head_recompute_on()) {
-            u32x4* xtp = reinterpret_cast<u32x4*>((char*)ws + w.xtp);
-            T4R_NB_SWITCH(D, hipLaunchKernelGGL((split_kmp_kernel<NB, true>), dim3(w.nblk), dim3(256), 0, st, X, ldx, N, xtp, amax));
-        }
     }
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+// the one more image of X the RECOMPUTING head's d W reads (accumulator-ordered k-major blocks, split_kmp_kernel): after
+// t4r_head_split_prepare on the same X and workspace, before t4r_head_split_ce.  Its own entry so that the materialised head
+// (the default where the scores fit) does not pay a launch for it on the critical stream.
+extern "C" int t4r_head_split_recompute_supported(int D);
+extern "C" int t4r_head_split_prepare_rc(void* stream, const float* X, long ldx, int N, int D, int V, void* ws) {
+    if (N <= 0) return 0;
+    T4R_CHECK_ARG(t4r_head_split_recompute_supported(D) && X && ws, "head_split_prepare_rc: unsupported (the two-way fp16 forms must be on) or null pointer");
+    T4R_CHECK_ARG(aligned16(X) && ldx % 4 == 0 && aligned16(ws), "head_split_prepare_rc: X must be 16-byte aligned with a pitch multiple of 4");
+    const HeadWs w = head_ws(N, V, D);
+    unsigned* amax = reinterpret_cast<unsigned*>((char*)ws + w.scales);
+    u32x4* xtp = reinterpret_cast<u32x4*>((char*)ws + w.xtp);
+    T4R_NB_SWITCH(D, hipLaunchKernelGGL((split_kmp_kernel<NB, true>), dim3(w.nblk), dim3(256), 0, (hipStream_t)stream, X, ldx, N, xtp, amax));
     T4R_LAUNCH_CHECK();
     return 0;
 }
@@ -1338,8 +1365,7 @@ extern "C" int t4r_head_split_dw(void* stream, void* ws, const float* logits, lo
         const unsigned* amax = reinterpret_cast<const unsigned*>((const char*)ws + w.scales);
         float* lse_min = reinterpret_cast<float*>(const_cast<char*>((const char*)ws) + w.scales) + 2;
         unsigned char* islab = reinterpret_cast<unsigned char*>(const_cast<char*>((const char*)ws) + w.islab);
-        if (hipMemsetAsync(islab, 0, (size_t)w.vpad, st) != hipSuccess) { t4r_set_error("head_split_dw: memset failed"); return -1; }
-        hipLaunchKernelGGL(head_dw_aux_kernel, dim3(1), dim3(1024), 0, st, lse, labels, N, yoff, Vc, lse_min, islab);
+        hipLaunchKernelGGL(head_dw_aux_kernel, dim3(1), dim3(1024), 0, st, lse, labels, N, yoff, Vc, lse_min, islab, w.vpad);
         DwAux aux{reinterpret_cast<const float*>((const char*)ws + w.colmax), lse_min, islab, w.vpad, w.rsplit};
         const u32x4* xth = reinterpret_cast<const u32x4*>((const char*)ws + w.xth);
         T4R_NB_SWITCH(D, hipLaunchKernelGGL((head_dw_split_kernel<NB, true>), dim3((Vc + 127) / 128), dim3(256), 0, st, logits, ld,
@@ -1449,8 +1475,7 @@ extern "C" int t4r_head_split_dw_rc(void* stream, void* ws, const float* W, long
     const unsigned* amax = reinterpret_cast<const unsigned*>((const char*)ws + w.scales);
     float* lse_min = reinterpret_cast<float*>((char*)ws + w.scales) + 2;
     unsigned char* islab = reinterpret_cast<unsigned char*>((char*)ws + w.islab);
-    if (hipMemsetAsync(islab, 0, (size_t)w.vpad, st) != hipSuccess) { t4r_set_error("head_split_dw_rc: memset failed"); return -1; }
-    hipLaunchKernelGGL(head_dw_aux_kernel, dim3(1), dim3(1024), 0, st, lse, labels, N, 0, V, lse_min, islab);
+    hipLaunchKernelGGL(head_dw_aux_kernel, dim3(1), dim3(1024), 0, st, lse, labels, N, 0, V, lse_min, islab, w.vpad);
     DwAux aux{reinterpret_cast<const float*>((const char*)ws + w.colmax), lse_min, islab, w.vpad, w.rsplit};
     const u32x4* xa = reinterpret_cast<const u32x4*>((const char*)ws + w.xa);
     const u32x4* xtp = reinterpret_cast<const u32x4*>((const char*)ws + w.xtp);

@@ -224,6 +224,8 @@ def head_split_ce(ws, x, W, labels, alpha=1.0, label_smoothing=0.0):
     loss_rows = torch.empty(N, device=dev, dtype=torch.float32)
     lse = torch.empty(N, device=dev, dtype=torch.float32)
     loss = torch.empty((), device=dev, dtype=torch.float32)
+    # the image of x only this form's d W reads (kept out of head_split_prepare: the materialised head would pay a launch for it)
+    call("t4r_head_split_prepare_rc", _stream(), _chk(x, torch.float32), x.stride(0), N, D, int(V), ws.data_ptr())
     call("t4r_head_split_ce", _stream(), ws.data_ptr(), _chk(W, torch.float32), W.stride(0), _chk(labels, torch.int64),
          loss_rows.data_ptr(), lse.data_ptr(), loss.data_ptr(), N, V, D, float(alpha), float(label_smoothing), _note(ws))
     return loss, loss_rows, lse

@@ -887,7 +887,11 @@ def main():
                 "avg_launch_ms": round(ab_ms, 4), "flops_per_launch": ab_flops,
                 "achieved": round(ab_flops / (ab_ms * 1e-3) / 1e12, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ab_flops / (ab_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-                "algorithmic_bytes": int(4 * Tt * D_MODEL * 7),
+                # h in; q | k | v, attn_vec, o-projection, h1 out (7 T D floats) + the per-session k_r rows read (B 2L D floats)
+                "algorithmic_bytes": int(4 * Tt * D_MODEL * 7 + 4 * BATCH * 2 * SEQ * D_MODEL),
+                "traffic": int(12616 * 2 * 1024 + 61920 * 1024), "traffic_unit": "bytes/launch",
+                "traffic_source": "committed (not measured in this run): profiles/r04_i_pmc_attn_block_fetch_write.txt (rocprofv3 --pmc "
+                                  "FETCH_SIZE x 2 KB, WRITE_SIZE KB, separate passes, tools/pmc_kernel.sh over tools/attn_block_bench.py --once)",
                 "matrix_pipe_busy": {"fwd": 0.378, "bwd_core": 0.311, "target": 0.50,
                                      "source": "profiles/r04_f_pmc_mfma_busy.csv (in-step; bwd_core = xlnet_attn_mfma_bwd_kernel, unchanged "
                                                "since round 1; round 3: forward core 0.21)"}}

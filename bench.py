@@ -802,7 +802,9 @@ def main():
     # at the global batch, item table out of cache, id sets rotated
     c3_state = {"k": 0}
     cats = [torch.empty((card, 64), device=device).normal_() for card in (1001, 501, 101)]
-    dense = [torch.randn(GB * SEQ, 8, device=device) for _ in range(2)]
+    # (not `dense`: that name is the flat parameter bucket the comm report below reads at N > 1 -- the shadowing crashed every
+    #  N > 1 run after the probes; found by the two-rank run of tests/test_distributed_gpu.py::test_bench_main_two_ranks)
+    dense_rows = [torch.randn(GB * SEQ, 8, device=device) for _ in range(2)]
     feats_c3 = []
     for t in ids_g:
         f = [dict(kind=0, input=t, table=Wbig, dim=D_MODEL, col=0, rows=big_rows)]
@@ -810,7 +812,7 @@ def main():
         for tab in cats:
             f.append(dict(kind=0, input=t % tab.shape[0], table=tab, dim=64, col=col, rows=tab.shape[0]))
             col += 64
-        for dn in dense:
+        for dn in dense_rows:
             f.append(dict(kind=1, input=dn, table=None, dim=8, col=col, rows=0))
             col += 8
         feats_c3.append(f)
@@ -829,7 +831,7 @@ def main():
     cp_dst = torch.empty_like(cp_src)
     copy_ms = graph_timed(lambda: cp_dst.copy_(cp_src), reps=10)
     copy_gbs = 2.0 * cp_src.numel() * 4 / (copy_ms * 1e-3) / 1e9
-    del Wbig, ids_g, feats_g, feats_c3, cats, dense, cp_src, cp_dst
+    del Wbig, ids_g, feats_g, feats_c3, cats, dense_rows, cp_src, cp_dst
 
     # ---- the transformer body's fused kernels (csrc/xlnet_fused*.hip), timed live at this run's shape: the feed-forward
     # block forward / backward (one launch each; 2 * T * 4D * D * 2 algorithmic flops per direction, six bf16 partial

@@ -34,7 +34,7 @@ def _batches(tr, schema, rank, device):
     return [tr.random_data_from_schema(schema, B, L, seed=100 * rank + i, device=device) for i in range(STEPS)]
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, mode="sparse"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
@@ -42,8 +42,11 @@ def _worker(rank, world, port, ret):
     import bench
 
     tr, schema, model, dense, tables, opt = _build(dev)
-    reducer, hook = bench.setup_data_parallel(tr, model, dense, tables, world)
-    assert hook is not None and reducer.sparse is not None
+    reducer, hook = bench.setup_data_parallel(tr, model, dense, tables, world, mode=mode)
+    if mode == "sparse":
+        assert hook is not None and reducer.sparse is not None
+    else:           # "dense": every rank scatters its own lookups, ONE table all-reduce at the end -- no hook, nothing row-sparse
+        assert hook is None and reducer.sparse is None
     model.input_features.masking.seed, model.transformer_block.transformer.seed = bench.rank_seeds(rank)
     model.train()
     batches = _batches(tr, schema, rank, dev)
@@ -61,17 +64,19 @@ def _worker(rank, world, port, ret):
     dist.all_gather(both, flat)
     if rank == 0:
         ret.update(identical=torch.equal(both[0], both[1]), grads0=grads0, losses=losses,
-                   bytes=reducer.sparse.bytes_exchanged)
+                   bytes=reducer.sparse.bytes_exchanged if reducer.sparse is not None else 0)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_training_step_on_one_gpu():
+@pytest.mark.parametrize("mode", ["sparse", "dense"])
+def test_two_rank_training_step_on_one_gpu(mode):
+    """both forms of the table-gradient exchange (bench.py times them at N > 1 and keeps the faster: either may run)"""
     world = 2
     ret = mp.Manager().dict()
-    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), ret, mode), nprocs=world, join=True)
     assert ret["identical"], "replicas drifted: the gradient exchange is not the same on both ranks"
-    assert ret["bytes"] > 0
+    assert (ret["bytes"] > 0) == (mode == "sparse")
     # single-process expectation for step 0: both ranks' batches, gradients averaged.  (Parameters after Adam are
     # not compared across implementations: m / sqrt(v) turns a last-bit difference of a near-zero gradient into a
     # full-size update; the split-K atomics already differ in the last bits from run to run.)

@@ -113,6 +113,34 @@ def test_attn_block_forward_matches_fp64(ops, B, L, D, n, drop_p, with_len):
     assert bool(torch.isfinite(h1).all())
 
 
+@pytest.mark.parametrize("B,L,D,n,drop_p,with_len", [c for c in CASES if c[2] == 128] + [(5, 32, 128, 4, 0.3, True), (11, 13, 128, 8, 0.25, False),
+                                                                                      (1030, 20, 128, 4, 0.3, False)])
+def test_attn_block_forward_two_workgroups_per_cu_layout(ops, monkeypatch, B, L, D, n, drop_p, with_len):
+    """T4R_XLNET_ATTN_BLOCK2=1: the 40-row / 4-wave layout of the same kernel (two workgroups per CU) against fp64, and its
+    saved tensors against the default layout's: q | k | v, attn_vec, lse and the o-projection are the same contraction chains
+    element by element (bit-identical); the LayerNorm sums associate differently (1e-6)."""
+    p, h, kr, key_len, planes = _setup(ops, B, L, D, n, drop_p, with_len)
+    T = B * L
+    kl = None if key_len is None else key_len.to(DEV).to(torch.int32)
+    run = lambda: ops.xlnet_attn_block_fwd(cu(h), planes, cu(p["o"]).view(D, D), cu(kr).view(-1, D), cu(p["r_w_bias"]).view(-1),
+                                           cu(p["r_r_bias"]).view(-1), cu(p["ln_w"]), cu(p["ln_b"]), B, L, n, 0.03, drop_p, SEED,
+                                           CTR_P, CTR_O, key_len=kl)
+    monkeypatch.setenv("T4R_XLNET_ATTN_BLOCK2", "0")
+    h1a, sa = run()
+    monkeypatch.setenv("T4R_XLNET_ATTN_BLOCK2", "1")
+    h1b, sb = run()
+    for name in ("qkv", "av", "lse", "ao"):
+        assert torch.equal(sa[name], sb[name]), name
+    for a, b in ((h1a, h1b), (sa["mean"], sb["mean"]), (sa["rstd"], sb["rstd"])):
+        assert float((a - b).abs().max()) < 2e-6 * max(1.0, float(a.abs().max()))
+    if B <= 64:
+        mp = _mask(ops, (B, n, L, L), drop_p, SEED, CTR_P) if drop_p > 0 else torch.ones(B, n, L, L, dtype=torch.float64)
+        mo = _mask(ops, (T, D), drop_p, SEED, CTR_O) if drop_p > 0 else torch.ones(T, D, dtype=torch.float64)
+        ref = reference(p, h, kr, B, L, n, 0.03, mp, mo, key_len)
+        for name in ("qkv", "av", "ao", "h1", "mean", "rstd"):
+            assert rel_err(sb[name] if name != "h1" else h1b, ref[name]) < 3e-6, name
+
+
 def test_attn_block_forward_equals_the_four_launch_form(ops):
     """same inputs, same Philox keys: the one-launch block and projection -> core -> o-projection + LayerNorm agree to
     fp32 rounding (the dropout decisions are identical, so nothing but summation order differs)"""

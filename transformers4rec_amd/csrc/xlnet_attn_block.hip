@@ -525,6 +525,414 @@ __global__ __launch_bounds__(D * 4) void xlnet_attn_block_fwd_kernel(AttnBlockFw
     AB_STAMP(6);
 }
 
+// ------------------------------------------------------------------------------------------------ forward, two workgroups per CU
+// The same kernel laid out for TWO co-resident workgroups per CU (d_model 128 only; T4R_XLNET_ATTN_BLOCK2=1): a workgroup owns
+// 40 token rows (2 sessions of L = 20; three 16-row blocks, the last one half padding) and has 4 waves, each owning TWO blocks of
+// 16 features.  LDS 62 KB tile + 17 KB exchange buffers = 79.5 KB: two fit the CU's 160 KB, so the phases of one workgroup --
+// which run in series and leave the matrix pipe idle during loads, softmax and the LayerNorm epilogue -- overlap the other's.
+// Arithmetic and saved tensors identical to the kernel above (same contraction order per output element).
+// MEASURED (round 4, B 1024 / L 20 / 4 heads): 60.9 us against 54.7 us with dropout, 55.4 against 51.4 without -- NOT the default.
+// 213 VGPRs, no spills, both workgroups resident; but they are dispatched together and walk the same phases at the same
+// time (they contend for the matrix pipe in phase P and idle together in the epilogues), the 40 -> 48 row padding adds 20 % of
+// matrix work and every CU pulls the weights twice.  Overlap needs workgroups that are OUT of phase, not merely two of them.
+constexpr int AB2_RT = 40, AB2_R = 3, AB2_FB = 2;
+
+template <int DH>
+__global__ __launch_bounds__(256, 2) void xlnet_attn_block2_fwd_kernel(AttnBlockFwd p) {
+    constexpr int D = 128, FB = AB2_FB, NW = D / (16 * FB), NH = D / DH, KC = D / 16, HC = DH / 16, PQ = 3 * D + 4, RT = AB2_RT, R = AB2_R;
+    extern __shared__ float smem[];
+    float* tile = smem;                               // [RT][PQ]
+    float* xbuf = smem + RT * PQ;                     // [NW][16][AB_PR]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, g = lane >> 4;
+    const int L = p.L;
+    const int b0 = blockIdx.x * p.S, nb = min(p.S, p.B - b0), rows = nb * L;
+    const long t0 = (long)b0 * L, TD = p.T * D;
+    // LDS row of token block r, lane n (rows past the tile are clamped copies: finite, never stored)
+    int rowc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) rowc[r] = min(16 * r + n, RT - 1);
+
+    // ------------------------------------------------------------------------------------------------ phase P
+    {
+        constexpr int NST = (RT * (D / 4) + NW * 64 - 1) / (NW * 64);
+        float4 hstage[NST];
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int idx = min(tid + i * NW * 64, RT * (D / 4) - 1);
+            const int row = idx / (D / 4), c4 = (idx - row * (D / 4)) * 4;
+            hstage[i] = ld4(p.h + min(t0 + row, p.T - 1) * D + c4);
+        }
+        float a[FB][2][4 * KC];
+        auto load_a = [&](float (&dst)[4 * KC], int z, int fb) __attribute__((always_inline)) {
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                float t4[4];
+                put4(t4, ld4(p.wqkvT + (long)(z * D + 16 * (FB * w + fb) + n) * D + 16 * c + 4 * g));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dst[4 * c + e] = t4[e];
+            }
+        };
+#pragma unroll
+        for (int fb = 0; fb < FB; ++fb) { load_a(a[fb][0], 0, fb); load_a(a[fb][1], 1, fb); }
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int idx = tid + i * NW * 64;
+            const int row = idx / (D / 4), c4 = (idx - row * (D / 4)) * 4;
+            if (idx < RT * (D / 4)) *reinterpret_cast<float4*>(tile + row * PQ + 2 * D + c4) = hstage[i];
+        }
+        __syncthreads();
+        auto load_x = [&](int c, float (&x)[R][4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) put4(x[r], lds4(tile + rowc[r] * PQ + 2 * D + 4 * g + 16 * c));
+        };
+        // q and k of this wave's two feature blocks, one block at a time: six independent accumulator chains each
+        float av_[FB][4 * KC];
+#pragma unroll
+        for (int fb = 0; fb < FB; ++fb) {
+            f32x4 acc[2][R];
+#pragma unroll
+            for (int z = 0; z < 2; ++z)
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[z][r] = zero4();
+            float xb[2][R][4];
+            load_x(0, xb[0]);
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                if (c + 1 < KC) load_x(c + 1, xb[(c + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        acc[0][r] = mfma4(a[fb][0][4 * c + e], xb[c & 1][r][e], acc[0][r]);
+                        acc[1][r] = mfma4(a[fb][1][4 * c + e], xb[c & 1][r][e], acc[1][r]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // the v weights of this block are requested here: they arrive under the other block's products / the stores
+            load_a(av_[fb], 2, fb);
+            const int f0 = 16 * (FB * w + fb) + 4 * g;
+#pragma unroll
+            for (int z = 0; z < 2; ++z)
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int tok = 16 * r + n;
+                    if (tok < RT) *reinterpret_cast<float4*>(tile + tok * PQ + z * D + f0) = f4(acc[z][r]);
+                    if (tok < rows) st4_stream(p.qkv + z * TD + (t0 + tok) * D + f0, acc[z][r]);
+                }
+        }
+        // v, kept in its accumulators until every wave has read the h rows it replaces
+        f32x4 accv[FB][R];
+#pragma unroll
+        for (int fb = 0; fb < FB; ++fb)
+#pragma unroll
+            for (int r = 0; r < R; ++r) accv[fb][r] = zero4();
+        {
+            float xb[2][R][4];
+            load_x(0, xb[0]);
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                if (c + 1 < KC) load_x(c + 1, xb[(c + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        accv[0][r] = mfma4(av_[0][4 * c + e], xb[c & 1][r][e], accv[0][r]);
+                        accv[1][r] = mfma4(av_[1][4 * c + e], xb[c & 1][r][e], accv[1][r]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int fb = 0; fb < FB; ++fb)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int tok = 16 * r + n, f0 = 16 * (FB * w + fb) + 4 * g;
+                if (tok < RT) *reinterpret_cast<float4*>(tile + tok * PQ + 2 * D + f0) = f4(accv[fb][r]);
+                if (tok < rows) st4_stream(p.qkv + 2 * TD + (t0 + tok) * D + f0, accv[fb][r]);
+            }
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------------------------------------ phase A (as above, NW = 4)
+    auto phase_a = [&](auto MTc) __attribute__((always_inline)) {
+        constexpr int MT = decltype(MTc)::value, JT = (MT + 1) / 2;
+        float* Rm = xbuf + w * 16 * AB_PR;
+        const bool aligned = (L & 3) == 0;
+        for (int u = w; u < nb * NH; u += NW) {
+            const int s = u / NH, hh = u - s * NH, b = b0 + s, r0 = s * L, hc = hh * DH;
+            const float* krb = p.kr + (long)b * p.kr_bstride;
+            const int klen = p.key_len ? p.key_len[b] : L;
+            float krf[MT][4 * HC], kf[JT][4 * HC], vf[JT][4][HC];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int c = 0; c < HC; ++c) {
+                    float t4[4];
+                    put4(t4, ld4(krb + (long)min(16 * mt + n, 2 * L - 1) * D + hc + 16 * c + 4 * g));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) krf[mt][4 * c + e] = t4[e];
+                }
+            float rwv[4 * HC], rrv[4 * HC];
+#pragma unroll
+            for (int c = 0; c < HC; ++c) {
+                float t4[4];
+                put4(t4, ld4(p.rw + hc + 16 * c + 4 * g));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rwv[4 * c + e] = t4[e];
+                put4(t4, ld4(p.rr + hc + 16 * c + 4 * g));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rrv[4 * c + e] = t4[e];
+            }
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int c = 0; c < HC; ++c) {
+                    float t4[4];
+                    put4(t4, lds4(tile + (r0 + min(16 * jt + n, L - 1)) * PQ + D + hc + 16 * c + 4 * g));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) kf[jt][4 * c + e] = t4[e];
+                }
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int dt = 0; dt < HC; ++dt)
+                        vf[jt][e][dt] = tile[(r0 + min(16 * jt + 4 * g + e, L - 1)) * PQ + 2 * D + hc + 16 * dt + n];
+            auto scores = [&](int it, f32x4 (&sT)[JT], f32x4 (&rT)[MT]) __attribute__((always_inline)) {
+                const int ic = min(16 * it + n, L - 1);
+                float bw[4 * HC], br[4 * HC];
+#pragma unroll
+                for (int c = 0; c < HC; ++c) {
+                    float t4[4];
+                    put4(t4, lds4(tile + (r0 + ic) * PQ + hc + 16 * c + 4 * g));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { bw[4 * c + e] = t4[e] + rwv[4 * c + e]; br[4 * c + e] = t4[e] + rrv[4 * c + e]; }
+                }
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) sT[jt] = zero4();
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) rT[mt] = zero4();
+#pragma unroll
+                for (int i4 = 0; i4 < 4 * HC; ++i4) {
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt) sT[jt] = mfma4(kf[jt][i4], bw[i4], sT[jt]);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) rT[mt] = mfma4(krf[mt][i4], br[i4], rT[mt]);
+                }
+            };
+            f32x4 sT[2][JT], rT[2][MT];
+            scores(0, sT[0], rT[0]);
+#pragma unroll
+            for (int it = 0; it < JT; ++it) {
+                const int i = 16 * it + n, ic = min(i, L - 1);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<float4*>(Rm + n * AB_PR + 16 * mt + 4 * g) = f4(rT[it][mt]);
+                wave_lds_sync();
+                float pv[JT][4];
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int jj = min(16 * jt + 4 * g + r, L - 1);
+                        pv[jt][r] = sT[it][jt][r] + Rm[n * AB_PR + jj + L - ic];
+                    }
+                wave_lds_sync();
+                if (it + 1 < JT) scores(it + 1, sT[(it + 1) & 1], rT[(it + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                float mx = -INFINITY;
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = 16 * jt + 4 * g + r;
+                        float sv = pv[jt][r] * p.scale;
+                        if (j >= L) sv = -INFINITY;
+                        else if (j >= klen && j != i) sv = -1e30f;
+                        pv[jt][r] = sv;
+                        mx = fmaxf(mx, sv);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                float sum = 0.f;
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { pv[jt][r] = __expf(pv[jt][r] - mx); sum += pv[jt][r]; }
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                const float inv = 1.f / sum;
+                if (g == 0 && i < L) p.lse[((long)b * NH + hh) * L + i] = mx + __logf(sum);
+                const unsigned long long mbase = ((unsigned long long)(b * NH + hh) * L + ic) * L;
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) {
+                    const int j0 = 16 * jt + 4 * g;
+                    float m[4] = {1.f, 1.f, 1.f, 1.f};
+                    if (p.drop_p.p > 0.f && j0 < L) {
+                        if (aligned) {
+                            const float4 f = drop_scale4(p.drop_p, mbase + j0);
+                            m[0] = f.x; m[1] = f.y; m[2] = f.z; m[3] = f.w;
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (j0 + r < L) m[r] = drop_scale(p.drop_p, mbase + j0 + r);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pv[jt][r] = pv[jt][r] * inv * m[r];
+                }
+                f32x4 o[HC];
+#pragma unroll
+                for (int dt = 0; dt < HC; ++dt) o[dt] = zero4();
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int dt = 0; dt < HC; ++dt) o[dt] = mfma4(vf[jt][e][dt], pv[jt][e], o[dt]);
+                if (i < L) {
+#pragma unroll
+                    for (int dt = 0; dt < HC; ++dt) {
+                        *reinterpret_cast<float4*>(tile + (r0 + i) * PQ + hc + 16 * dt + 4 * g) = f4(o[dt]);
+                        st4_stream(p.av + (t0 + r0 + i) * D + hc + 16 * dt + 4 * g, o[dt]);
+                    }
+                }
+            }
+        }
+    };
+    switch ((2 * L + 15) / 16) {
+        case 1: phase_a(IC<1>()); break;
+        case 2: phase_a(IC<2>()); break;
+        case 3: phase_a(IC<3>()); break;
+        default: phase_a(IC<4>()); break;
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------------------------------------ phase O
+    {
+        const bool train = p.ao != nullptr;
+        float wof[FB][4 * KC];
+#pragma unroll
+        for (int fb = 0; fb < FB; ++fb)
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                float t4[4];
+                put4(t4, ld4(p.wo + (long)(16 * (FB * w + fb) + n) * D + 16 * c + 4 * g));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wof[fb][4 * c + e] = t4[e];
+            }
+        float4 hres[FB][R];
+#pragma unroll
+        for (int fb = 0; fb < FB; ++fb)
+#pragma unroll
+            for (int r = 0; r < R; ++r) hres[fb][r] = ld4(p.h + min(t0 + 16 * r + n, p.T - 1) * D + 16 * (FB * w + fb) + 4 * g);
+        f32x4 acc[FB][R];
+#pragma unroll
+        for (int fb = 0; fb < FB; ++fb)
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[fb][r] = zero4();
+        {
+            float xb[2][R][4];
+#pragma unroll
+            for (int r = 0; r < R; ++r) put4(xb[0][r], lds4(tile + rowc[r] * PQ + 4 * g));
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                if (c + 1 < KC) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) put4(xb[(c + 1) & 1][r], lds4(tile + rowc[r] * PQ + 4 * g + 16 * (c + 1)));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        acc[0][r] = mfma4(wof[0][4 * c + e], xb[c & 1][r][e], acc[0][r]);
+                        acc[1][r] = mfma4(wof[1][4 * c + e], xb[c & 1][r][e], acc[1][r]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        float* sh_red = xbuf;                         // [2][NW][16 R]
+        float4 x[FB][R];
+        float sum[R];
+        float4 gam[FB], bet[FB];
+#pragma unroll
+        for (int fb = 0; fb < FB; ++fb) { gam[fb] = ld4(p.gamma + 16 * (FB * w + fb) + 4 * g); bet[fb] = ld4(p.beta + 16 * (FB * w + fb) + 4 * g); }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int tok = 16 * r + n;
+            const long t = t0 + tok, tc = min(t, p.T - 1);
+            const bool live = tok < rows;
+            float sm = 0.f;
+#pragma unroll
+            for (int fb = 0; fb < FB; ++fb) {
+                const int f0 = 16 * (FB * w + fb) + 4 * g;
+                float4 v = f4(acc[fb][r]);
+                if (train && live) st4_stream(p.ao + t * D + f0, acc[fb][r]);
+                if (p.drop_o.p > 0.f) {
+                    const float4 m = drop_scale4(p.drop_o, (unsigned long long)tc * D + f0);
+                    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+                }
+                v.x += hres[fb][r].x; v.y += hres[fb][r].y; v.z += hres[fb][r].z; v.w += hres[fb][r].w;
+                x[fb][r] = v;
+                sm += (v.x + v.y) + (v.z + v.w);
+            }
+            sm += __shfl_xor(sm, 16, 64);
+            sm += __shfl_xor(sm, 32, 64);
+            sum[r] = sm;
+        }
+        if (g == 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) sh_red[w * 16 * R + 16 * r + n] = sum[r];
+        }
+        __syncthreads();
+        float mu[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float sm = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) sm += sh_red[ww * 16 * R + 16 * r + n];
+            mu[r] = sm * (1.0f / D);
+            float q = 0.f;
+#pragma unroll
+            for (int fb = 0; fb < FB; ++fb) {
+                const float dx = x[fb][r].x - mu[r], dy = x[fb][r].y - mu[r], dz = x[fb][r].z - mu[r], dw = x[fb][r].w - mu[r];
+                q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+            q += __shfl_xor(q, 16, 64);
+            q += __shfl_xor(q, 32, 64);
+            sum[r] = q;
+        }
+        float* sh_red2 = sh_red + NW * 16 * R;
+        if (g == 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) sh_red2[w * 16 * R + 16 * r + n] = sum[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int tok = 16 * r + n;
+            const long t = t0 + tok;
+            float q = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) q += sh_red2[ww * 16 * R + 16 * r + n];
+            const float rs = rsqrtf(q * (1.0f / D) + p.eps);
+            if (tok < rows) {
+#pragma unroll
+                for (int fb = 0; fb < FB; ++fb) {
+                    const int f0 = 16 * (FB * w + fb) + 4 * g;
+                    st4(p.h1 + t * D + f0, make_float4((x[fb][r].x - mu[r]) * rs * gam[fb].x + bet[fb].x, (x[fb][r].y - mu[r]) * rs * gam[fb].y + bet[fb].y,
+                                                       (x[fb][r].z - mu[r]) * rs * gam[fb].z + bet[fb].z, (x[fb][r].w - mu[r]) * rs * gam[fb].w + bet[fb].w));
+                }
+                if (train && w == 0 && g == 0) { p.mean[t] = mu[r]; p.rstd[t] = rs; }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host side (forward)
 extern "C" int t4r_xlnet_fused_supported(int D);
 static size_t attn_block_smem(int D) { return ((size_t)AB_RT * (3 * D + 4) + (size_t)(D / 16) * 16 * AB_PR) * sizeof(float); }
@@ -566,9 +974,28 @@ extern "C" int t4r_xlnet_attn_block_fwd(void* stream, const float* h, const floa
 #ifdef T4R_AB_STAMPS
     p.stamps = g_ab_stamps;
 #endif
+    hipStream_t st = (hipStream_t)stream;
+    {
+        // the two-workgroups-per-CU layout (d_model 128, sessions of at most 40 rows each): read per call so a test can switch it
+        const char* e2 = getenv("T4R_XLNET_ATTN_BLOCK2");
+        if (e2 && atoi(e2) && D == 128 && L <= AB2_RT) {
+            p.S = AB2_RT / L;
+            const dim3 grid2((unsigned)((B + p.S - 1) / p.S)), block2(256);
+            const size_t smem2 = ((size_t)AB2_RT * (3 * D + 4) + (size_t)4 * 16 * AB_PR) * sizeof(float);
+            static bool once2[2] = {false, false};
+            if (dh == 32) {
+                if (!once2[0]) { (void)hipFuncSetAttribute((const void*)xlnet_attn_block2_fwd_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2); once2[0] = true; }
+                hipLaunchKernelGGL((xlnet_attn_block2_fwd_kernel<32>), grid2, block2, smem2, st, p);
+            } else {
+                if (!once2[1]) { (void)hipFuncSetAttribute((const void*)xlnet_attn_block2_fwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2); once2[1] = true; }
+                hipLaunchKernelGGL((xlnet_attn_block2_fwd_kernel<16>), grid2, block2, smem2, st, p);
+            }
+            T4R_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     const dim3 grid((unsigned)((B + S - 1) / S)), block((unsigned)(D * 4));
     const size_t smem = attn_block_smem(D);
-    hipStream_t st = (hipStream_t)stream;
 #define T4R_AB_FWD(DD, DHH)                                                                                                  \
     {                                                                                                                        \
         static bool once = false;                                                                                            \

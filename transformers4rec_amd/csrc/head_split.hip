@@ -157,10 +157,9 @@ __device__ __forceinline__ float scale_of(const unsigned* amax_bits) {
 //   KM image (rows are K, D is the N index):                     [plane][kc = (row % 32) / 8][d] x 16 bytes = 8 consecutive rows
 // Both are 12 D u32x4 (24 KB at D = 128); rows >= n_rows are zero.
 template <int NB, bool HS = false>
-__global__ __launch_bounds__(256) void split_mk_kernel(const float* __restrict__ src, long ld, int n_rows,
-                                                        u32x4* __restrict__ dst, const unsigned* __restrict__ amax = nullptr) {
+__device__ __forceinline__ void split_mk_body(int b, const float* __restrict__ src, long ld, int n_rows,
+                                              u32x4* __restrict__ dst, const unsigned* __restrict__ amax) {
     constexpr int D = 32 * NB, CH = D / 8, NPL = HS ? 2 : 3;
-    const int b = blockIdx.x;
     const float scale = HS ? scale_of(amax) : 1.f;
     for (int idx = threadIdx.x; idx < CH * 32; idx += 256) {
         const int r = idx & 31, c = idx >> 5, row = b * 32 + r;
@@ -177,10 +176,14 @@ __global__ __launch_bounds__(256) void split_mk_kernel(const float* __restrict__
     }
 }
 template <int NB, bool HS = false>
-__global__ __launch_bounds__(256) void split_km_kernel(const float* __restrict__ src, long ld, int n_rows,
+__global__ __launch_bounds__(256) void split_mk_kernel(const float* __restrict__ src, long ld, int n_rows,
                                                         u32x4* __restrict__ dst, const unsigned* __restrict__ amax = nullptr) {
+    split_mk_body<NB, HS>(blockIdx.x, src, ld, n_rows, dst, amax);
+}
+template <int NB, bool HS = false>
+__device__ __forceinline__ void split_km_body(int b, const float* __restrict__ src, long ld, int n_rows,
+                                              u32x4* __restrict__ dst, const unsigned* __restrict__ amax) {
     constexpr int D = 32 * NB, NPL = HS ? 2 : 3;
-    const int b = blockIdx.x;
     const float scale = HS ? scale_of(amax) : 1.f;
     for (int idx = threadIdx.x; idx < 4 * D; idx += 256) {
         const int d = idx % D, kc = idx / D;
@@ -195,6 +198,21 @@ __global__ __launch_bounds__(256) void split_km_kernel(const float* __restrict__
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) dst[(((long)b * NPL + pl) * 4 + kc) * D + d] = w[pl];
     }
+}
+template <int NB, bool HS = false>
+__global__ __launch_bounds__(256) void split_km_kernel(const float* __restrict__ src, long ld, int n_rows,
+                                                        u32x4* __restrict__ dst, const unsigned* __restrict__ amax = nullptr) {
+    split_km_body<NB, HS>(blockIdx.x, src, ld, n_rows, dst, amax);
+}
+// the three images of the head's input rows in ONE launch (blockIdx.y picks the image): fp16 MK (logits), bf16 KM and fp16 KM
+// (d W in either form) -- three 5 us launches on the critical stream otherwise
+template <int NB>
+__global__ __launch_bounds__(256) void split_x_images_kernel(const float* __restrict__ src, long ld, int n_rows, u32x4* __restrict__ xa,
+                                                              u32x4* __restrict__ xt, u32x4* __restrict__ xth,
+                                                              const unsigned* __restrict__ amax) {
+    if (blockIdx.y == 0) split_mk_body<NB, true>(blockIdx.x, src, ld, n_rows, xa, amax);
+    else if (blockIdx.y == 1) split_km_body<NB, false>(blockIdx.x, src, ld, n_rows, xt, nullptr);
+    else split_km_body<NB, true>(blockIdx.x, src, ld, n_rows, xth, amax);
 }
 
 // KMP image (round 4, the recomputing backward kernels): as the KM image, with the 32 rows of a block in the order the
@@ -1252,16 +1270,17 @@ extern "C" int t4r_head_split_prepare(void* stream, const float* X, long ldx, in
         if (hipMemsetAsync(amax, 0, 8, st) != hipSuccess) { t4r_set_error("head_split_prepare: memset failed"); return -1; }
         const long n4 = (long)N * (D / 4);
         hipLaunchKernelGGL(amax_kernel, dim3((unsigned)min(256L, (n4 + 255) / 256)), dim3(256), 0, st, X, ldx, (long)N, D, amax);
+        if (head_dw_fp16x2()) {     // d W may run in either form (it needs the forward's column maxima): all three images, one launch
+            u32x4* xth = reinterpret_cast<u32x4*>((char*)ws + w.xth);
+            T4R_NB_SWITCH(D, hipLaunchKernelGGL(split_x_images_kernel<NB>, dim3(w.nblk, 3), dim3(256), 0, st, X, ldx, N, xa, xt, xth, amax));
+            T4R_LAUNCH_CHECK();
+            return 0;
+        }
         T4R_NB_SWITCH(D, hipLaunchKernelGGL((split_mk_kernel<NB, true>), dim3(w.nblk), dim3(256), 0, st, X, ldx, N, xa, amax));
     } else {
         T4R_NB_SWITCH(D, hipLaunchKernelGGL(split_mk_kernel<NB>, dim3(w.nblk), dim3(256), 0, st, X, ldx, N, xa));
     }
     T4R_NB_SWITCH(D, hipLaunchKernelGGL(split_km_kernel<NB>, dim3(w.nblk), dim3(256), 0, st, X, ldx, N, xt));
-    if (head_fwd_fp16x2() && head_dw_fp16x2()) {     // d W may run in either form (it needs the forward's column maxima): both images
-        unsigned* amax = reinterpret_cast<unsigned*>((char*)ws + w.scales);
-        u32x4* xth = reinterpret_cast<u32x4*>((char*)ws + w.xth);
-        T4R_NB_SWITCH(D, hipLaunchKernelGGL((split_km_kernel<NB, true>), dim3(w.nblk), dim3(256), 0, st, X, ldx, N, xth, amax));
-    }
     T4R_LAUNCH_CHECK();
     return 0;
 }

@@ -405,7 +405,7 @@ int t4r_xlnet_dh(void* stream, const float* dqkv, const float* planes, float* dh
 /* The attention half of a layer as ONE kernel per direction (csrc/xlnet_attn_block.hip; round 4): exact fp32 matrix
  * instructions (v_mfma_f32_16x16x4_f32 = a k-ordered fmaf chain), one workgroup per 80 / L whole sessions, q | k | v, the
  * scores and the probabilities never leave the chip.  Shapes: L <= 32, d_head 16 | 32, d_model 32 | 64 | 128
- * (t4r_xlnet_attn_block_supported); t4r_xlnet_layer_fwd / _bwd use it by default there (T4R_XLNET_ATTN_BLOCK=0: the
+ * (t4r_xlnet_attn_block_supported); t4r_xlnet_layer_fwd uses it by default there (T4R_XLNET_ATTN_BLOCK=0: the
  * qkv_proj -> attention core -> oproj_ln launches above).
  * fwd replaces HF modeling_xlnet.py XLNetRelativeAttention.forward :245-282 (g = None) + rel_attn_core :96-140 +
  *     post_attention :142-152:  h [T, D] -> h1 [T, D] = LayerNorm(dropout(attn_vec @ o^T) + h).
@@ -416,25 +416,14 @@ int t4r_xlnet_dh(void* stream, const float* dqkv, const float* planes, float* dh
  *     (element ((b n_head + head) L + i) L + j) and (seed, ctr_out) on the projection (element t D + feature), the same
  *     keys and element indices as t4r_xlnet_attn_fwd / t4r_xlnet_oproj_ln: the masks are identical.  key_len: optional
  *     int32 [B] (opt-in padding mask as t4r_xlnet_attn_fwd).
- * bwd its autograd:  dy = d loss / d h1 -> dh [T, D] (overwritten: d loss / d h complete, LayerNorm residual + the three
- *     projections), plus the rows the caller's weight-gradient products contract over: dao [T][D] (d o += dao^T @ av),
- *     dqkv [3][T][D] (d W_z += h^T @ dqkv_z), dkr ([B][2L][D] per session, or [2L][D] shared; d r += pos^T @ dkr);
- *     d_rw, d_rr, d_gamma, d_beta ACCUMULATED (per-workgroup partial sums + one fixed-order reduction, no atomics).
- *     part: t4r_xlnet_attn_block_bwd_part_floats(B, L, D) floats of scratch. */
+ * The backward of the attention half stays three launches (t4r_xlnet_ln1_bwd -> t4r_xlnet_attn_bwd -> t4r_xlnet_dh); a
+ *     one-kernel backward was built, tested and measured slower -- tools/experimental/, not exported. */
 int t4r_xlnet_attn_block_supported(int L, int D, int n_head);
 int t4r_xlnet_attn_block_fwd(void* stream, const float* h, const float* planes, const float* o, const float* kr,
                              long kr_bstride, const float* r_w_bias, const float* r_r_bias, const float* gamma,
                              const float* beta, float* qkv, float* av, float* lse, float* ao, float* mean, float* rstd,
                              float* h1, int B, int L, int D, int n_head, float eps, float drop_p, unsigned long long seed,
                              unsigned long long ctr_prob, unsigned long long ctr_out, const int* key_len);
-long t4r_xlnet_attn_block_bwd_part_floats(int B, int L, int D, int n_head);
-int t4r_xlnet_attn_block_bwd(void* stream, const float* dy, const float* ao, const float* h, const float* mean,
-                             const float* rstd, const float* gamma, const float* planes, const float* wq, const float* wk,
-                             const float* wv, const float* qkv, const float* kr, long kr_bstride, const float* r_w_bias,
-                             const float* r_r_bias, const float* lse, float* dh, float* dao, float* dqkv, float* dkr,
-                             float* d_rw, float* d_rr, float* d_gamma, float* d_beta, float* part, int B, int L, int D,
-                             int n_head, float drop_p, unsigned long long seed, unsigned long long ctr_prob,
-                             unsigned long long ctr_out, const int* key_len);
 long t4r_xlnet_ff_bwd_part_floats(long T, int D);
 int t4r_xlnet_ff_fwd(void* stream, const float* h1, const float* planes, const float* b1, const float* b2,
                      const float* gamma, const float* beta, float* ffpre, float* ffact, float* ffout, float* mean,

@@ -6,7 +6,7 @@ last-item protocol.  The counterpart of bench.py's `recall_at_20.hip_bench_confi
 dropout draws and the parameter initialisation come from the CPU generator, so the two trajectories are independent samples
 of the same training procedure: comparable values, not identical ones.
 
-    python oracle/cpu_recall_probe.py [--steps 200] [--out profiles/r04_cpu_oracle_recall_bench_config.json]
+    python oracle/cpu_recall_probe.py [--steps 200] [--out profiles/r05_cpu_oracle_recall_bench_config.json]
 """
 import argparse
 import json
@@ -27,7 +27,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--dropout", type=float, default=0.3)
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_cpu_oracle_recall_bench_config.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r05_cpu_oracle_recall_bench_config.json"))
     args = ap.parse_args()
     cores = os.cpu_count() or 1
     torch.set_num_threads(min(cores, 32))

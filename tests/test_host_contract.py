@@ -344,3 +344,31 @@ def test_table_config_default_initializer_is_the_references():
         F.TableConfig(vocabulary_size=10, dim=4, initializer=0.05)
     feats = tr.EmbeddingFeatures({"a": F.FeatureConfig(cfg)})
     assert abs(float(feats.embedding_tables["a"].weight.std()) - 0.05) < 2e-3
+
+
+def test_table_config_default_initializer_pickles():
+    """the default initializer is a functools.partial as in the reference (features/embedding.py:460-464); a lambda
+    made pickle / torch.save(model) fail"""
+    import pickle
+
+    import transformers4rec_amd as tr
+    from transformers4rec_amd.features import TableConfig
+
+    tc = pickle.loads(pickle.dumps(TableConfig(10, 4)))
+    w = torch.zeros(10, 4)
+    tc.initializer(w)
+    assert 0.0 < float(w.std()) < 0.2
+    schema = tr.session_schema(50, 8)
+    inputs = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=8, masking="mlm", embedding_dim_default=16)
+    pickle.loads(pickle.dumps(inputs))
+
+
+def test_head_mode_by_size(monkeypatch):
+    """the size rule every fallback of the head uses: materialise while the fp32 scores fit T4R_HEAD_AUTO_GB, else the chunked head"""
+    from transformers4rec_amd.prediction_task import NextItemPredictionTask
+
+    monkeypatch.setenv("T4R_HEAD_AUTO_GB", "4")
+    assert NextItemPredictionTask.size_head_mode(2765, 100_001) == "materialize"
+    assert NextItemPredictionTask.size_head_mode(15_360, 10_000_001) == "fused"
+    monkeypatch.setenv("T4R_HEAD_AUTO_GB", "0.0001")
+    assert NextItemPredictionTask.size_head_mode(2765, 100_001) == "fused"

@@ -1,0 +1,146 @@
+"""Round 5 (GPU): the fallback of the recomputing head, the step next to a co-resident "collective" (CU occupier), the
+measurement kernels of tools/t4r_tools.hip."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def _model(tr, V, D, L, seed=11, dropout=0.0):
+    schema = tr.session_schema(V, L)
+    torch.manual_seed(0)
+    inputs = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=L, masking="mlm", embedding_dim_default=D)
+    cfg = tr.XLNetConfig.build(D, 4, 2, total_seq_length=L, dropout=dropout, initializer_range=0.05)
+    model = cfg.to_torch_model(inputs, tr.NextItemPredictionTask(weight_tying=True)).to(DEV).train()
+    model.input_features.masking.seed = seed
+    return schema, model
+
+
+def test_recompute_head_falls_back_by_size_when_its_kernels_cannot_run(monkeypatch):
+    """head_mode 'recompute' whose kernels cannot take the call (here: precision mode fp32) must not fall
+    through to a materialised [N, V] tensor when the scores do not fit -- it takes the chunked head; where they fit it
+    materialises.  Loss equal to the materialised mode either way."""
+    import transformers4rec_amd as tr
+    from transformers4rec_amd import ops
+    from transformers4rec_amd.prediction_task import LazyPredictions
+
+    B, L, V, D = 256, 20, 30000, 64
+    ids = None
+
+    def run(mode, limit_gb):
+        nonlocal ids
+        monkeypatch.setenv("T4R_HEAD_MODE", mode)
+        monkeypatch.setenv("T4R_HEAD_AUTO_GB", limit_gb)
+        schema, model = _model(tr, V, D, L)
+        if ids is None:
+            ids = tr.random_data_from_schema(schema, B, L, seed=3)["item_id"].to(DEV)
+        with ops.precision("fp32"):
+            out = model({"item_id": ids}, training=True)
+            out["loss"].backward()
+        torch.cuda.synchronize()
+        return out, model.input_features.item_embedding_table.weight.grad.clone()
+
+    ref, g_ref = run("materialize", "4")
+    assert torch.is_tensor(ref["predictions"])
+    small, g_small = run("recompute", "0.000001")          # the scores "do not fit": chunked head, nothing of size [N, V]
+    assert isinstance(small["predictions"], LazyPredictions) and not small["predictions"].is_materialized
+    fits, g_fits = run("recompute", "4")                   # they fit: materialised
+    assert torch.is_tensor(fits["predictions"])
+    for out, g in ((small, g_small), (fits, g_fits)):
+        assert abs(float(out["loss"]) - float(ref["loss"])) < 2e-5
+        torch.testing.assert_close(g, g_ref, rtol=1e-3, atol=1e-6 + 1e-4 * float(g_ref.abs().max()))
+
+
+def test_auto_head_mode_respects_the_workspace_budget(monkeypatch):
+    """`auto` takes the recomputing head only while its workspace fits T4R_HEAD_WS_GB"""
+    import transformers4rec_amd as tr
+
+    _, model = _model(tr, 30000, 64, 20)
+    t = model.prediction_task
+    t._training_call = True
+    monkeypatch.setenv("T4R_HEAD_MODE", "auto")
+    monkeypatch.setenv("T4R_HEAD_AUTO_GB", "0.000001")
+    monkeypatch.setenv("T4R_HEAD_WS_GB", "16")
+    assert t.resolve_head_mode(600, 30001) == "recompute"
+    monkeypatch.setenv("T4R_HEAD_WS_GB", "0.000001")
+    assert t.resolve_head_mode(600, 30001) == "fused"
+    t._training_call = False                                  # evaluation calls: by size
+    monkeypatch.setenv("T4R_HEAD_MODE", "recompute")
+    assert t.resolve_head_mode(600, 30001) == "fused"
+    monkeypatch.setenv("T4R_HEAD_AUTO_GB", "4")
+    assert t.resolve_head_mode(600, 30001) == "materialize"
+
+
+def _tools():
+    import t4r_tools
+
+    if not t4r_tools.available():
+        pytest.skip("tools/bin/libt4r_tools.so not built (python -m transformers4rec_amd.build)")
+    return t4r_tools
+
+
+def test_tools_copy_kernel_copies():
+    t = _tools()
+    src = torch.randn(1 << 22, device=DEV)
+    for mode in (0, 1):
+        dst = torch.zeros_like(src)
+        t.copy(dst, src, mode=mode)
+        torch.cuda.synchronize()
+        assert torch.equal(dst, src)
+
+
+def test_occupier_holds_until_the_flag_and_never_beyond_its_bound():
+    t = _tools()
+    occ = t.Occupier(16, threads=256, lds_bytes=16 * 1024, max_us=2000)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    occ.start()
+    occ.join()                       # nobody sets the flag: the time bound ends it
+    e1.record()
+    torch.cuda.synchronize()
+    assert 1.5 < e0.elapsed_time(e1) < 50.0
+    assert int(occ.seen.item()) == 16
+    occ.start()
+    occ.stop()                       # flag set at once: gone long before the bound
+    occ.join()
+    torch.cuda.synchronize()
+    assert int(occ.seen.item()) == 32
+
+
+@pytest.mark.parametrize("k,threads,lds", [(16, 256, 16 * 1024), (32, 512, 96 * 1024)])
+def test_training_step_next_to_a_co_resident_collective_is_bit_identical(k, threads, lds):
+    """one training step with k workgroups HOLDING CUs from the head's backward to the end of the backward
+    pass (what an RCCL ring does while the table bucket is reduced under the body's backward): the token-tile kernels launch
+    one workgroup per CU and must only get slower, never different -- every gradient bit-identical to the undisturbed step."""
+    import transformers4rec_amd as tr
+
+    t = _tools()
+    B, L, V, D = 1024, 20, 20000, 128
+
+    def run(occupied):
+        schema, model = _model(tr, V, D, L, dropout=0.3)
+        model.transformer_block.transformer.seed = 77
+        ids = tr.random_data_from_schema(schema, B, L, seed=5)["item_id"].to(DEV)
+        occ = t.Occupier(k if occupied else 0, threads=threads, lds_bytes=lds, max_us=20000)
+        hook = tr.head_backward_hook(model, occ.start)
+        out = model({"item_id": ids}, training=True)
+        out["loss"].backward()
+        occ.stop()
+        occ.join()
+        torch.cuda.synchronize()
+        hook.remove()
+        if occupied:
+            assert int(occ.seen.item()) == k
+        return float(out["loss"]), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    loss_a, g_a = run(False)
+    loss_b, g_b = run(True)
+    assert loss_a == loss_b and sorted(g_a) == sorted(g_b)
+    for n in g_a:
+        assert torch.equal(g_a[n], g_b[n]), n

@@ -8,10 +8,12 @@ import ctypes
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 
 from transformers4rec_amd import _lib, ops
+import exp_ops
 
 dev = torch.device("cuda", 0)
 B, L, n, D = 1024, 20, 4, 128
@@ -86,7 +88,7 @@ for p in (0.3, 0.0):
     saved = keep["saved"]
 
     def block_bwd():
-        keep["g"] = ops.xlnet_attn_block_bwd(dy, saved, h, planes, wq, wk, wv, kr, rw, rr, P["ln_w"], d_rw, d_rr, dg, db, B, L, n, p, 7, cp, co)
+        keep["g"] = exp_ops.xlnet_attn_block_bwd(dy, saved, h, planes, wq, wk, wv, kr, rw, rr, P["ln_w"], d_rw, d_rr, dg, db, B, L, n, p, 7, cp, co)
 
     def chain_bwd():
         dh, dao, dav = ops.xlnet_ln1_bwd(dy, saved["ao"], h, saved["mean"], saved["rstd"], P["ln_w"], planes, dg, db,

@@ -134,8 +134,8 @@ int t4r_wgrad_stream_launch(const GemmParams& p, int batch, int kper, float* par
     q.A = p.A; q.B = p.B; q.part = part; q.lda = p.lda; q.ldb = p.ldb; q.ldc = p.ldc; q.sA = p.sA; q.sB = p.sB;
     q.M = p.M; q.K = p.K; q.kper = kper; q.splits = p.splitk; q.mb = p.M / 128; q.nb = p.N / 128; q.alpha = p.alpha;
     const size_t smem = (size_t)2 * WS_ROWS * WS_P * sizeof(float);
-    static bool once = false;
-    if (!once) { (void)hipFuncSetAttribute((const void*)wgrad_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); once = true; }
+    static T4rLdsAttr once;
+    t4r_ensure_dynamic_lds((const void*)wgrad_stream_kernel, smem, once);
     const long grid = (long)batch * q.splits * q.mb * q.nb;
     hipLaunchKernelGGL(wgrad_stream_kernel, dim3((unsigned)grid), dim3(512), smem, st, q);
     T4R_LAUNCH_CHECK();

@@ -90,8 +90,6 @@ _SIGS = {
     "t4r_xlnet_dh": ("i", "pppp" + "li"),
     "t4r_xlnet_attn_block_supported": ("i", "iii"),
     "t4r_xlnet_attn_block_fwd": ("i", "ppppp" + "l" + "pppp" + "ppppppp" + "iiii" + "ffQQQ" + "p"),
-    "t4r_xlnet_attn_block_bwd_part_floats": ("l", "iiii"),
-    "t4r_xlnet_attn_block_bwd": ("i", "p" + "pppppp" + "pppp" + "pp" + "l" + "ppp" + "pppp" + "ppppp" + "iiii" + "fQQQ" + "p"),
     "t4r_xlnet_layer_bwd_defer": ("v", "i"),
     "t4r_xlnet_layer_ws_offsets": ("i", "iiiii" + "pp"),
     "t4r_xlnet_stack_prepare": ("i", "ppiip" + "plp"),

@@ -14,7 +14,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libt4r_hip.so")
 SOURCES = ["gemm_f32.hip", "gemm_half.hip", "elementwise.hip", "embedding.hip", "masking.hip", "xlnet_attn.hip",
            "head.hip", "xlnet_layer.hip", "mha.hip", "swap_noise.hip", "xlnet_attn_mfma.hip", "mha_mfma.hip",
-           "embedding_sorted.hip", "head_split.hip", "tok_gemm.hip", "embedding_bag.hip", "xlnet_fused.hip", "xlnet_fused_attn.hip", "xlnet_attn_block.hip", "wgrad_stream.hip"]
+           "embedding_sorted.hip", "head_split.hip", "tok_gemm.hip", "embedding_bag.hip", "xlnet_fused.hip", "xlnet_fused_attn.hip", "xlnet_attn_block.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wno-unused-result"]
 
@@ -59,5 +59,23 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_tools(force=False):
+    """tools/t4r_tools.hip -> tools/bin/libt4r_tools.so: measurement infrastructure (a float4 copy kernel = the box's byte-moving
+    ceiling, a CU occupier = what a resident RCCL kernel does to the chip).  NOT loaded by the package; bench.py and the tests
+    load it through ctypes."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "tools", "t4r_tools.hip")
+    out_dir = os.path.join(root, "tools", "bin")
+    out = os.path.join(out_dir, "libt4r_tools.so")
+    os.makedirs(out_dir, exist_ok=True)
+    if force or _stale(out, [src]):
+        r = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", src, "-o", out],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed (tools):\n" + r.stdout + r.stderr)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_tools(force="--force" in sys.argv))

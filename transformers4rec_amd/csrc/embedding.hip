@@ -144,7 +144,10 @@ __global__ __launch_bounds__(256) void seq_features_fwd_kernel(SeqFeatParams p) 
 // item 128 + 3 x 64 + 2 x 8 soft-embedding rows takes GROUP 64, NCH 2).  U consecutive tokens per lane group
 // with all id loads, then all row loads, in flight together (the generic kernel has one dependent
 // id -> row chain per lane).
-template <int GROUP, int U, int NCH>
+// NT: the table rows are read with non-temporal loads -- a table far beyond the 256 MB Infinity Cache is touched once per
+// launch, and lines that will not be hit again should not evict what will (ids, small tables); the host picks it per launch
+// from the table sizes (T4R_GATHER_NT = 0 / 1 overrides).
+template <int GROUP, int U, int NCH, bool NT = false>
 __global__ __launch_bounds__(256) void seq_features_fwd_fast_kernel(SeqFeatParams p) {
     const int gl = threadIdx.x & (GROUP - 1);
     const int grp = (int)(((long)blockIdx.x * 256 + threadIdx.x) / GROUP);
@@ -205,7 +208,15 @@ __global__ __launch_bounds__(256) void seq_features_fwd_fast_kernel(SeqFeatParam
         for (int j = 0; j < NCH; ++j) {
             v[u][j] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (kind[j] < 0) continue;
-            if (use[u] && !zero[u]) v[u][j] = *reinterpret_cast<const float4*>(src[u][j]);
+            if (use[u] && !zero[u]) {
+                if constexpr (NT) {
+                    typedef float ntl4 __attribute__((ext_vector_type(4)));
+                    const ntl4 t = __builtin_nontemporal_load(reinterpret_cast<const ntl4*>(src[u][j]));
+                    v[u][j] = make_float4(t[0], t[1], t[2], t[3]);
+                } else {
+                    v[u][j] = *reinterpret_cast<const float4*>(src[u][j]);
+                }
+            }
             else if (!use[u]) v[u][j] = *reinterpret_cast<const float4*>(p.masked_emb + (gl + GROUP * j) * 4);
         }
 #pragma unroll
@@ -268,23 +279,39 @@ extern "C" int t4r_seq_features_fwd(
         // tokens per lane group: 2 for rows up to 256 floats (table above); 4 for the two-chunk rows (C3's 336-wide
         // concatenation: 61 % -> 72 % of 8 TB/s at 163 840 tokens, 58 % -> 78 % at 1.3 M with a 10 M-row item table,
         // profiles/r02_e_c3_gather.txt); T4R_GATHER_U overrides
-        const int U = nch == 2 ? ((fast_u_set && fast_u < 4) ? 2 : 4) : ((fast_u >= 4 && nch == 1) ? 4 : 2);
+        const int U = nch == 2 ? ((fast_u_set && fast_u < 4) ? 2 : 4) : ((fast_u >= 4 && nch == 1) ? (fast_u >= 8 ? 8 : 4) : 2);
+        // non-temporal row loads when a gathered table cannot stay on the chip anyway (> 256 MB: beyond the Infinity Cache)
+        static int nt_env = -2;
+        if (nt_env == -2) { const char* e = getenv("T4R_GATHER_NT"); nt_env = e ? atoi(e) : -1; }
+        bool nt = false;
+        for (int f = 0; f < n_feat; ++f)
+            if ((p.kind[f] == 0 || p.kind[f] == 2) && p.rows[f] * (long)p.dim[f] * 4 > (256L << 20)) nt = true;
+        if (nt_env >= 0) nt = nt_env != 0;
         const long groups = ((long)B * L_out + U - 1) / U;
         dim3 fgrid((unsigned)((groups * g + 255) / 256));
         hipStream_t fst = (hipStream_t)stream;
+#define T4R_FAST_L(G, UU, NC)                                                                                                  \
+    do {                                                                                                                       \
+        if (nt) hipLaunchKernelGGL((seq_features_fwd_fast_kernel<G, UU, NC, true>), fgrid, dim3(256), 0, fst, p);               \
+        else hipLaunchKernelGGL((seq_features_fwd_fast_kernel<G, UU, NC, false>), fgrid, dim3(256), 0, fst, p);                 \
+    } while (0)
 #define T4R_FAST(G)                                                                                          \
-    if (U == 4) hipLaunchKernelGGL((seq_features_fwd_fast_kernel<G, 4, 1>), fgrid, dim3(256), 0, fst, p);     \
-    else hipLaunchKernelGGL((seq_features_fwd_fast_kernel<G, 2, 1>), fgrid, dim3(256), 0, fst, p)
+    do {                                                                                                     \
+        if (U == 8) T4R_FAST_L(G, 8, 1);                                                                     \
+        else if (U == 4) T4R_FAST_L(G, 4, 1);                                                                \
+        else T4R_FAST_L(G, 2, 1);                                                                            \
+    } while (0)
         if (nch > 1) {      // rows wider than 256 floats: the 64-lane group, 2 or 4 chunks per lane
-            if (nch == 2 && U == 4) hipLaunchKernelGGL((seq_features_fwd_fast_kernel<64, 4, 2>), fgrid, dim3(256), 0, fst, p);
-            else if (nch == 2) hipLaunchKernelGGL((seq_features_fwd_fast_kernel<64, 2, 2>), fgrid, dim3(256), 0, fst, p);
-            else hipLaunchKernelGGL((seq_features_fwd_fast_kernel<64, 2, 4>), fgrid, dim3(256), 0, fst, p);
+            if (nch == 2 && U == 4) T4R_FAST_L(64, 4, 2);
+            else if (nch == 2) T4R_FAST_L(64, 2, 2);
+            else T4R_FAST_L(64, 2, 4);
         } else switch (g) {
             case 8: T4R_FAST(8); break;
             case 16: T4R_FAST(16); break;
             case 32: T4R_FAST(32); break;
             default: T4R_FAST(64); break;
         }
+#undef T4R_FAST_L
 #undef T4R_FAST
         T4R_LAUNCH_CHECK();
         return 0;

@@ -169,9 +169,11 @@ static thread_local const float* g_amax_b = nullptr;
 static thread_local int g_amax_n = 0;
 void t4r_gemm_operand_amax(const float* a, const float* b, int n) { g_amax_a = a; g_amax_b = b; g_amax_n = n; }
 
+#ifdef T4R_EXPERIMENTAL     /* tools/experimental/wgrad_stream.hip: the K-streaming weight-gradient kernel (measured slower inside the step) */
 void t4r_wgrad_stream_plan(int K, int* splits, int* kper);
 bool t4r_wgrad_stream_ok(const GemmParams& p);
 int t4r_wgrad_stream_launch(const GemmParams& p, int batch, int kper, float* part, hipStream_t st);
+#endif
 
 template <bool TA, bool TB>
 static int launch_layout(GemmParams& p, int batch, int splitk_req, hipStream_t stream) {
@@ -180,6 +182,7 @@ static int launch_layout(GemmParams& p, int batch, int splitk_req, hipStream_t s
     const int amax_n = g_amax_n;
     g_amax_a = g_amax_b = nullptr;
     p.amaxA = p.amaxB = nullptr; p.n_amax = 0;
+#ifdef T4R_EXPERIMENTAL
     // long-K weight gradients with a split-K sink installed (the XLNet layer backward): the K-streaming kernel (wgrad_stream.hip)
     if (TA && !TB && splitk_req < 0 && g_sink.on && t4r_wgrad_stream_ok(p)) {
         int splits = 1, kper = 0;
@@ -189,6 +192,7 @@ static int launch_layout(GemmParams& p, int batch, int splitk_req, hipStream_t s
         if (part) return t4r_wgrad_stream_launch(p, batch, kper, part, stream);
         p.splitk = 1;
     }
+#endif
     // tokens x small weight in an fp32-accurate mode: the token-stationary kernel (operands cut once, tok_gemm.hip)
     if (!TA && (splitk_req == 0 || splitk_req == 1)) {
         const int mode = t4r_get_precision();

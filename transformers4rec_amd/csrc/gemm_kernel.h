@@ -770,12 +770,8 @@ static int launch_vec(const GemmParams& p, int batch, hipStream_t stream) {
     static long pad = -1;   // experiment knob: extra LDS per workgroup = fewer resident workgroups per CU
     if (pad < 0) { const char* e = getenv("T4R_GEMM_LDS_PAD"); pad = e ? atol(e) : 0; }
     const size_t smem = gemm_lds_bytes<BM, BN, BK, TA, TB, PREC>() + (size_t)pad;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_f32_kernel<BM, BN, BK, TA, TB, FEAT, VEC, PREC>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
+    static T4rLdsAttr attr_set;
+    t4r_ensure_dynamic_lds((const void*)gemm_f32_kernel<BM, BN, BK, TA, TB, FEAT, VEC, PREC>, smem, attr_set);
     const int TM = (p.M + BM - 1) / BM, TN = (p.N + BN - 1) / BN;
     const int Tl = TM <= TN ? TN : TM, Ts = TM <= TN ? TM : TN;
     const int gx = (TM * TN < 128 || !p.xcd_order) ? TM * TN : 8 * ((Tl + 7) / 8) * Ts;   // must match the kernel's decode

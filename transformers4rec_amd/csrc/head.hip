@@ -546,11 +546,8 @@ extern "C" int t4r_topk(void* stream, const float* scores, int N, int V, long ld
     if (N == 0) return 0;
     T4R_CHECK_ARG(k >= 1 && k <= TOPK_MAX && k <= V, "topk: 1 <= k <= min(64, V)");
     const size_t smem = (size_t)256 * k * 8;
-    static size_t attr = 0;
-    if (smem > attr) {
-        (void)hipFuncSetAttribute((const void*)topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr = smem;
-    }
+    static T4rLdsAttr attr;
+    t4r_ensure_dynamic_lds((const void*)topk_kernel, smem, attr);
     hipLaunchKernelGGL(topk_kernel, dim3(N), dim3(256), smem, (hipStream_t)stream, scores, V, ld, k,
                        out_val, out_idx);
     T4R_LAUNCH_CHECK();

@@ -215,11 +215,8 @@ template <int DH>
 static int mha_fwd_launch(hipStream_t st, const float* q, const float* k, const float* v, long ld, float* out,
                           long ld_out, float* lse, int B, int L, int n, float scale, int causal, DropCfg dc, const int* key_len) {
     const size_t smem = (size_t)2 * L * (DH + MHA_PAD) * sizeof(float);
-    static size_t attr = 0;
-    if (smem > attr) {
-        (void)hipFuncSetAttribute((const void*)mha_fwd_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr = smem;
-    }
+    static T4rLdsAttr attr;
+    t4r_ensure_dynamic_lds((const void*)mha_fwd_kernel<DH>, smem, attr);
     hipLaunchKernelGGL(mha_fwd_kernel<DH>, dim3(B, n), dim3(L <= 64 ? 64 : 128), smem, st, q, k, v, ld, out, ld_out,
                        lse, B, L, n, scale, causal, dc, key_len);
     T4R_LAUNCH_CHECK();
@@ -230,11 +227,8 @@ static int mha_bwd_launch(hipStream_t st, const float* q, const float* k, const 
                           const float* dout, long ld_out, const float* lse, float* dq, float* dk, float* dv,
                           long ld_d, int B, int L, int n, float scale, int causal, DropCfg dc, const int* key_len) {
     const size_t smem = ((size_t)4 * L * (DH + MHA_PAD) + 2 * L) * sizeof(float);
-    static size_t attr = 0;
-    if (smem > attr) {
-        (void)hipFuncSetAttribute((const void*)mha_bwd_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr = smem;
-    }
+    static T4rLdsAttr attr;
+    t4r_ensure_dynamic_lds((const void*)mha_bwd_kernel<DH>, smem, attr);
     hipLaunchKernelGGL(mha_bwd_kernel<DH>, dim3(B, n), dim3(L <= 64 ? 64 : 128), smem, st, q, k, v, ld, out, dout,
                        ld_out, lse, dq, dk, dv, ld_d, B, L, n, scale, causal, dc, key_len);
     T4R_LAUNCH_CHECK();

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 #define T4R_WAVE 64
 
@@ -14,6 +15,21 @@ extern "C" void t4r_set_error(const char* msg);
             return -1;                    \
         }                                 \
     } while (0)
+
+// The maximum-dynamic-LDS attribute of a kernel is set per DEVICE: a process-wide "set it once" flag leaves the second device of
+// a process without it and its launches fail (several devices per process: xlnet_layer.hip keeps per-device side streams).
+// One word per device holds the largest size already set for this kernel there; two racing threads at worst set it twice.
+#define T4R_MAX_DEVICES 16
+struct T4rLdsAttr { std::atomic<unsigned> bytes[T4R_MAX_DEVICES]; };
+static inline void t4r_ensure_dynamic_lds(const void* kernel, size_t smem, T4rLdsAttr& a) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::atomic<unsigned>& have = a.bytes[dev & (T4R_MAX_DEVICES - 1)];
+    if (smem > have.load(std::memory_order_relaxed)) {
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        have.store((unsigned)smem, std::memory_order_relaxed);
+    }
+}
 
 #define T4R_LAUNCH_CHECK()                                  \
     do {                                                    \

@@ -519,12 +519,15 @@ int t4r_xlnet_attn_mfma_bwd(hipStream_t st, const float* q, const float* k, cons
                             const float* rw, const float* rr, const float* lse, const float* dout, float* dq,
                             float* dk, float* dv, float* part, float* dkr, float* d_rw, float* d_rr, int B, int L,
                             int n_head, int d_head, float scale, long kr_bstride, DropCfg drop, const int* key_len);
-// the fp32-MFMA core with the permuted k-slots (xlnet_attn_block.hip, phase 3 of the block backward as its own launch)
+#ifdef T4R_EXPERIMENTAL
+// the fp32-MFMA core with the permuted k-slots (tools/experimental: phase 3 of the one-kernel backward as its own launch;
+// measured slower than xlnet_attn_mfma_bwd_kernel, not in the product library)
 int t4r_xlnet_attn_core16_ok(int L, int D, int n_head);
 int t4r_xlnet_attn_core16_bwd(hipStream_t st, const float* qkv, const float* kr, const float* rw, const float* rr,
                               const float* lse, const float* dout, float* dqkv, float* part, float* dkr, float* d_rw,
                               float* d_rr, int B, int L, int n_head, int d_head, float scale, long kr_bstride, DropCfg drop,
                               const int* key_len);
+#endif
 static bool use_mfma(int L, int d_head) {
     static int en = -1;
     if (en < 0) { const char* e = getenv("T4R_ATTN_MFMA"); en = e ? atoi(e) : 1; }
@@ -537,12 +540,8 @@ static int attn_fwd_launch(hipStream_t st, const float* q, const float* k, const
                            int B, int L, int n_head, float scale, long kr_bstride, DropCfg drop, const int* key_len) {
     const int D = n_head * DH;
     const size_t smem = attn_fwd_smem(L, D);
-    static size_t attr = 0;
-    if (smem > attr) {
-        (void)hipFuncSetAttribute((const void*)xlnet_attn_fwd_kernel<DH>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr = smem;
-    }
+    static T4rLdsAttr attr;
+    t4r_ensure_dynamic_lds((const void*)xlnet_attn_fwd_kernel<DH>, smem, attr);
     constexpr int HPB = HeadsPerBlock<DH>::v;
     const int waves = n_head < HPB ? n_head : HPB;
     hipLaunchKernelGGL(xlnet_attn_fwd_kernel<DH>, dim3(B, (n_head + HPB - 1) / HPB), dim3(64 * waves), smem, st, q, k, v, kr, rw,
@@ -597,12 +596,8 @@ static int attn_bwd_launch(hipStream_t st, const float* q, const float* k, const
                                           d_rr, D, 1);
     }
     const size_t smem = attn_bwd_smem(L, D, n_head, kr_bstride > 0);
-    static size_t attr = 0;
-    if (smem > attr) {
-        (void)hipFuncSetAttribute((const void*)xlnet_attn_bwd_kernel<DH>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr = smem;
-    }
+    static T4rLdsAttr attr;
+    t4r_ensure_dynamic_lds((const void*)xlnet_attn_bwd_kernel<DH>, smem, attr);
     constexpr int HPB = HeadsPerBlock<DH>::v;
     const int waves = n_head < HPB ? n_head : HPB;
     const int hg = (n_head + HPB - 1) / HPB;
@@ -631,12 +626,14 @@ extern "C" int t4r_xlnet_attn_bwd(void* stream, const float* q, const float* k, 
     hipStream_t st = (hipStream_t)stream;
     const long bs = kr_per_batch ? 2L * L * D : 0;
     const DropCfg dc = make_drop(drop_p, seed, ctr_hi);
+#ifdef T4R_EXPERIMENTAL
     {
         const long TD = (long)B * L * D;
         if (k == q + TD && v == q + 2 * TD && dk == dq + TD && dv == dq + 2 * TD && t4r_xlnet_attn_core16_ok(L, D, n_head))
             return t4r_xlnet_attn_core16_bwd(st, q, k_r, r_w_bias, r_r_bias, lse, dout, dq, workspace, dk_r, d_r_w_bias,
                                              d_r_r_bias, B, L, n_head, d_head, scale, bs, dc, key_len);
     }
+#endif
     if (use_mfma(L, d_head))
         return t4r_xlnet_attn_mfma_bwd(st, q, k, v, k_r, r_w_bias, r_r_bias, lse, dout, dq, dk, dv, workspace, dk_r,
                                        d_r_w_bias, d_r_r_bias, B, L, n_head, d_head, scale, bs, dc, key_len);

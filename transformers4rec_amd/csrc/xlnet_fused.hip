@@ -541,18 +541,12 @@ static int ff_fwd_launch(hipStream_t st, const FFFwdParams& p) {
     const size_t smem = (size_t)(6 * RT * PH) * 2 + (size_t)(2 * NW * RT) * sizeof(float);
     const dim3 grid((unsigned)((p.T + RT - 1) / RT));
     if (t4r_xlnet_body_fp16x2()) {
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute((const void*)xlnet_ff_fwd_kernel<D, R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            attr = true;
-        }
+        static T4rLdsAttr attr;
+        t4r_ensure_dynamic_lds((const void*)xlnet_ff_fwd_kernel<D, R, true>, smem, attr);
         hipLaunchKernelGGL((xlnet_ff_fwd_kernel<D, R, true>), grid, dim3(D * 4), smem, st, p);
     } else {
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute((const void*)xlnet_ff_fwd_kernel<D, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            attr = true;
-        }
+        static T4rLdsAttr attr;
+        t4r_ensure_dynamic_lds((const void*)xlnet_ff_fwd_kernel<D, R>, smem, attr);
         hipLaunchKernelGGL((xlnet_ff_fwd_kernel<D, R>), grid, dim3(D * 4), smem, st, p);
     }
     T4R_LAUNCH_CHECK();
@@ -564,18 +558,12 @@ static int ff_bwd_launch(hipStream_t st, const FFBwdParams& p) {
     const size_t smem = (size_t)(6 * RT * PH) * 2 + (size_t)(NW * 3 * D) * sizeof(float);
     const dim3 grid((unsigned)((p.T + RT - 1) / RT));
     if (t4r_xlnet_body_fp16x2()) {
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute((const void*)xlnet_ff_bwd_kernel<D, R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            attr = true;
-        }
+        static T4rLdsAttr attr;
+        t4r_ensure_dynamic_lds((const void*)xlnet_ff_bwd_kernel<D, R, true>, smem, attr);
         hipLaunchKernelGGL((xlnet_ff_bwd_kernel<D, R, true>), grid, dim3(D * 4), smem, st, p);
     } else {
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute((const void*)xlnet_ff_bwd_kernel<D, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            attr = true;
-        }
+        static T4rLdsAttr attr;
+        t4r_ensure_dynamic_lds((const void*)xlnet_ff_bwd_kernel<D, R>, smem, attr);
         hipLaunchKernelGGL((xlnet_ff_bwd_kernel<D, R>), grid, dim3(D * 4), smem, st, p);
     }
     T4R_LAUNCH_CHECK();

@@ -603,10 +603,6 @@ static int pick_r(long T) {
         default: t4r_set_error("xlnet fused: no instantiation"); return -1;                    \
     }
 
-template <typename K>
-static void set_smem(K kernel, size_t smem) {
-    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-}
 
 // q, k, v = h @ W_{q,k,v}: out = qkv [3][T][D] (one launch).  planes: t4r_xlnet_layer_prepare's buffer.
 extern "C" int t4r_xlnet_qkv_proj(void* stream, const float* h, const float* planes, float* qkv, long T, int D) {
@@ -623,10 +619,10 @@ extern "C" int t4r_xlnet_qkv_proj(void* stream, const float* h, const float* pla
     {                                                                                                            \
         const size_t smem = (size_t)3 * 16 * RR * (DD + 16) * 2;       /* HS: two planes + the token scales fit the same size */ \
         if (hs) {                                                                                                \
-            { static bool once = false; if (!once) { set_smem(xlnet_proj_kernel<DD, RR, 3, true>, smem); once = true; } } \
+            { static T4rLdsAttr once; t4r_ensure_dynamic_lds((const void*)xlnet_proj_kernel<DD, RR, 3, true>, smem, once); } \
             hipLaunchKernelGGL((xlnet_proj_kernel<DD, RR, 3, true>), dim3((unsigned)((T + 16 * RR - 1) / (16 * RR))), dim3(DD * 4), smem, st, p); \
         } else {                                                                                                 \
-            { static bool once = false; if (!once) { set_smem(xlnet_proj_kernel<DD, RR, 3>, smem); once = true; } } \
+            { static T4rLdsAttr once; t4r_ensure_dynamic_lds((const void*)xlnet_proj_kernel<DD, RR, 3>, smem, once); } \
             hipLaunchKernelGGL((xlnet_proj_kernel<DD, RR, 3>), dim3((unsigned)((T + 16 * RR - 1) / (16 * RR))), dim3(DD * 4), smem, st, p); \
         }                                                                                                        \
     }
@@ -650,10 +646,10 @@ extern "C" int t4r_xlnet_kr_proj(void* stream, const float* pos, const float* pl
     {                                                                                                            \
         const size_t smem = (size_t)3 * 16 * RR * (DD + 16) * 2;                                                 \
         if (hs) {                                                                                                \
-            { static bool once = false; if (!once) { set_smem(xlnet_proj_kernel<DD, RR, 1, true>, smem); once = true; } } \
+            { static T4rLdsAttr once; t4r_ensure_dynamic_lds((const void*)xlnet_proj_kernel<DD, RR, 1, true>, smem, once); } \
             hipLaunchKernelGGL((xlnet_proj_kernel<DD, RR, 1, true>), dim3((unsigned)((rows + 16 * RR - 1) / (16 * RR))), dim3(DD * 4), smem, st, p); \
         } else {                                                                                                 \
-            { static bool once = false; if (!once) { set_smem(xlnet_proj_kernel<DD, RR, 1>, smem); once = true; } } \
+            { static T4rLdsAttr once; t4r_ensure_dynamic_lds((const void*)xlnet_proj_kernel<DD, RR, 1>, smem, once); } \
             hipLaunchKernelGGL((xlnet_proj_kernel<DD, RR, 1>), dim3((unsigned)((rows + 16 * RR - 1) / (16 * RR))), dim3(DD * 4), smem, st, p); \
         }                                                                                                        \
     }
@@ -699,10 +695,10 @@ extern "C" int t4r_xlnet_stack_prepare(void* stream, const float* const* params_
     {                                                                                                            \
         const size_t smem = (size_t)3 * 16 * RR * (DD + 16) * 2;                                                 \
         if (hs) {                                                                                                \
-            { static bool once = false; if (!once) { set_smem(xlnet_proj_kernel<DD, RR, NMV, true>, smem); once = true; } } \
+            { static T4rLdsAttr once; t4r_ensure_dynamic_lds((const void*)xlnet_proj_kernel<DD, RR, NMV, true>, smem, once); } \
             hipLaunchKernelGGL((xlnet_proj_kernel<DD, RR, NMV, true>), dim3((unsigned)((pos_rows + 16 * RR - 1) / (16 * RR))), dim3(DD * 4), smem, st, p); \
         } else {                                                                                                 \
-            { static bool once = false; if (!once) { set_smem(xlnet_proj_kernel<DD, RR, NMV>, smem); once = true; } } \
+            { static T4rLdsAttr once; t4r_ensure_dynamic_lds((const void*)xlnet_proj_kernel<DD, RR, NMV>, smem, once); } \
             hipLaunchKernelGGL((xlnet_proj_kernel<DD, RR, NMV>), dim3((unsigned)((pos_rows + 16 * RR - 1) / (16 * RR))), dim3(DD * 4), smem, st, p); \
         }                                                                                                        \
     }
@@ -743,10 +739,10 @@ extern "C" int t4r_xlnet_oproj_ln(void* stream, const float* av, const float* h,
         const size_t smem = (size_t)3 * 16 * RR * (DD + 16) * 2 + (size_t)2 * (DD / 16) * 16 * RR * 4;           \
         const dim3 grid((unsigned)((T + 16 * RR - 1) / (16 * RR)));                                              \
         if (hs) {                                                                                                \
-            { static bool once = false; if (!once) { set_smem(xlnet_oproj_ln_kernel<DD, RR, true>, smem); once = true; } } \
+            { static T4rLdsAttr once; t4r_ensure_dynamic_lds((const void*)xlnet_oproj_ln_kernel<DD, RR, true>, smem, once); } \
             hipLaunchKernelGGL((xlnet_oproj_ln_kernel<DD, RR, true>), grid, dim3(DD * 4), smem, st, p);          \
         } else {                                                                                                 \
-            { static bool once = false; if (!once) { set_smem(xlnet_oproj_ln_kernel<DD, RR>, smem); once = true; } } \
+            { static T4rLdsAttr once; t4r_ensure_dynamic_lds((const void*)xlnet_oproj_ln_kernel<DD, RR>, smem, once); } \
             hipLaunchKernelGGL((xlnet_oproj_ln_kernel<DD, RR>), grid, dim3(DD * 4), smem, st, p);                \
         }                                                                                                        \
     }
@@ -779,10 +775,10 @@ extern "C" int t4r_xlnet_ln1_bwd(void* stream, const float* dy, const float* ao,
     {                                                                                                            \
         const size_t smem = (size_t)3 * 16 * RR * (DD + 16) * 2 + (size_t)(DD / 16) * 2 * DD * 4;                \
         if (hs) {                                                                                                \
-            { static bool once = false; if (!once) { set_smem(xlnet_ln1_bwd_kernel<DD, RR, true>, smem); once = true; } } \
+            { static T4rLdsAttr once; t4r_ensure_dynamic_lds((const void*)xlnet_ln1_bwd_kernel<DD, RR, true>, smem, once); } \
             hipLaunchKernelGGL((xlnet_ln1_bwd_kernel<DD, RR, true>), dim3((unsigned)nwg), dim3(DD * 4), smem, st, p); \
         } else {                                                                                                 \
-            { static bool once = false; if (!once) { set_smem(xlnet_ln1_bwd_kernel<DD, RR>, smem); once = true; } } \
+            { static T4rLdsAttr once; t4r_ensure_dynamic_lds((const void*)xlnet_ln1_bwd_kernel<DD, RR>, smem, once); } \
             hipLaunchKernelGGL((xlnet_ln1_bwd_kernel<DD, RR>), dim3((unsigned)nwg), dim3(DD * 4), smem, st, p);  \
         }                                                                                                        \
     }
@@ -806,10 +802,10 @@ extern "C" int t4r_xlnet_dh(void* stream, const float* dqkv, const float* planes
         const size_t smem = (size_t)2 * 3 * 16 * RR * (DD + 16) * 2;                                             \
         const dim3 grid((unsigned)((T + 16 * RR - 1) / (16 * RR)));                                              \
         if (hs) {                                                                                                \
-            { static bool once = false; if (!once) { set_smem(xlnet_dh_kernel<DD, RR, true>, smem); once = true; } } \
+            { static T4rLdsAttr once; t4r_ensure_dynamic_lds((const void*)xlnet_dh_kernel<DD, RR, true>, smem, once); } \
             hipLaunchKernelGGL((xlnet_dh_kernel<DD, RR, true>), grid, dim3(DD * 4), smem, st, p);                \
         } else {                                                                                                 \
-            { static bool once = false; if (!once) { set_smem(xlnet_dh_kernel<DD, RR>, smem); once = true; } }   \
+            { static T4rLdsAttr once; t4r_ensure_dynamic_lds((const void*)xlnet_dh_kernel<DD, RR>, smem, once); }   \
             hipLaunchKernelGGL((xlnet_dh_kernel<DD, RR>), grid, dim3(DD * 4), smem, st, p);                      \
         }                                                                                                        \
     }

@@ -69,11 +69,13 @@ int t4r_xlnet_attn_block_supported(int L, int D, int n_head);
 int t4r_xlnet_attn_block_fwd(void*, const float*, const float*, const float*, const float*, long, const float*, const float*,
                              const float*, const float*, float*, float*, float*, float*, float*, float*, float*, int, int, int,
                              int, float, float, unsigned long long, unsigned long long, unsigned long long, const int*);
+#ifdef T4R_EXPERIMENTAL     /* tools/experimental: the one-kernel backward of the attention half (measured slower, not in the product library) */
 long t4r_xlnet_attn_block_bwd_part_floats(int B, int L, int D, int n_head);
 int t4r_xlnet_attn_block_bwd(void*, const float*, const float*, const float*, const float*, const float*, const float*, const float*,
                              const float*, const float*, const float*, const float*, const float*, long, const float*, const float*,
                              const float*, float*, float*, float*, float*, float*, float*, float*, float*, float*, int, int, int, int,
                              float, unsigned long long, unsigned long long, unsigned long long, const int*);
+#endif
 int t4r_xlnet_ff_fwd(void*, const float*, const float*, const float*, const float*, const float*, const float*,
                      float*, float*, float*, float*, float*, float*, int, int, float, float,
                      unsigned long long, unsigned long long, unsigned long long);
@@ -87,18 +89,23 @@ static bool use_fused(int D) {
     return on && t4r_xlnet_fused_supported(D);
 }
 
-// The attention half as one kernel per direction (csrc/xlnet_attn_block.hip).  Forward: default ON
-// (T4R_XLNET_ATTN_BLOCK=0 restores projection -> core -> o-projection + LayerNorm).  Backward: default OFF
-// (T4R_XLNET_ATTN_BLOCK_BWD=1): correct and tested, but at 120-130 us per launch not yet ahead of the three launches it
-// replaces (118 us): measurements in DESIGN.md.
+// The attention half of the FORWARD as one kernel (csrc/xlnet_attn_block.hip), default ON
+// (T4R_XLNET_ATTN_BLOCK=0 restores projection -> core -> o-projection + LayerNorm).  The one-kernel BACKWARD was built,
+// tested and measured slower (120-130 us per launch against 118 us for the three launches it would replace: DESIGN.md
+// round 4); it lives in tools/experimental/ and is compiled only into the A/B variant library (-DT4R_EXPERIMENTAL).
 static bool use_attn_block(int L, int D, int n_head) {
     static const int on = [] { const char* e = getenv("T4R_XLNET_ATTN_BLOCK"); return e ? atoi(e) : 1; }();
     return on && use_fused(D) && t4r_xlnet_attn_block_supported(L, D, n_head);
 }
+#ifdef T4R_EXPERIMENTAL
 static bool use_attn_block_bwd(int L, int D, int n_head) {
     static const int on = [] { const char* e = getenv("T4R_XLNET_ATTN_BLOCK_BWD"); return e ? atoi(e) : 0; }();
     return on && use_fused(D) && t4r_xlnet_attn_block_supported(L, D, n_head);
 }
+static long attn_block_bwd_part(int B, int L, int D, int n_head) { return t4r_xlnet_attn_block_bwd_part_floats(B, L, D, n_head); }
+#else
+static long attn_block_bwd_part(int, int, int, int) { return 0; }
+#endif
 
 // dropout sites of one layer (HF modeling_xlnet.py): pos_emb :1143 (model level, but the mask is per
 // batch row so k_r becomes per-session), attention probabilities :132, attention output :147,
@@ -184,7 +191,7 @@ extern "C" long t4r_xlnet_layer_bwd_ws_floats(int B, int L, int D, int n_head, i
            align4(t4r_xlnet_attn_bwd_ws_floats(B, L, D, n_head)) + align4(t4r_colreduce_ws_floats(T, 4 * D)) +
            2 * align4(t4r_colreduce_ws_floats(T, 2 * D)) + align4(t4r_colreduce_ws_floats(T, D)) +
            (dropout ? align4(T * D) : 0) + 2 * align4(T * D) + align4(t4r_xlnet_ff_bwd_part_floats(T, D)) +
-           align4(t4r_xlnet_ln1_bwd_part_floats(T, D)) + align4(t4r_xlnet_attn_block_bwd_part_floats(B, L, D, n_head)) +
+           align4(t4r_xlnet_ln1_bwd_part_floats(T, D)) + align4(attn_block_bwd_part(B, L, D, n_head)) +
            align4(splitk_sink_floats(T, D));
 }
 
@@ -404,7 +411,9 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
     float* ff_part = take(t4r_xlnet_ff_bwd_part_floats(T, D));
     float* dao_buf = take(TD);                  // fused LayerNorm-1 backward: d attn_out rows (own buffer, as dfo)
     float* ln1_part = take(t4r_xlnet_ln1_bwd_part_floats(T, D));
-    float* block_part = take(t4r_xlnet_attn_block_bwd_part_floats(B, L, D, n_head));
+#ifdef T4R_EXPERIMENTAL
+    float* block_part = take(attn_block_bwd_part(B, L, D, n_head));
+#endif
     const bool fused = use_fused(D);
     // the split-K weight gradients of this call leave their partial tiles here; one launch adds them at the end
     struct SinkGuard {
@@ -500,14 +509,19 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
                         EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
     }
     if (fused) {
+#ifdef T4R_EXPERIMENTAL
         const bool block = use_attn_block_bwd(L, D, n_head);
         if (block) {
-            // LayerNorm-1 backward, d attn_vec, the attention core backward and d h: ONE launch (csrc/xlnet_attn_block.hip)
+            // LayerNorm-1 backward, d attn_vec, the attention core backward and d h: ONE launch (tools/experimental)
             RUN(t4r_xlnet_attn_block_bwd(stream, dx, w.ao, h, w.mean1, w.rstd1, params[P_LN1W], w.planes, params[P_Q], params[P_K],
                                          params[P_V], w.qkv, w.kr, drop ? 2L * L * D : 0L, params[P_RWB], params[P_RRB], w.lse,
                                          dh_in, dao_buf, dqkv, dkr, grads[P_RWB], grads[P_RRB], grads[P_LN1W], grads[P_LN1B],
                                          block_part, B, L, D, n_head, drop_p, seed, C(SITE_PROB), C(SITE_ATTN_OUT), key_len));
-        } else {
+        } else
+#else
+        constexpr bool block = false;
+#endif
+        {
         // LayerNorm-1 backward + d attn_vec in one launch; the attention core; d h from d q, d k, d v in one launch
         RUN(t4r_xlnet_ln1_bwd(stream, dx, w.ao, h, w.mean1, w.rstd1, params[P_LN1W], w.planes, dh_in, dao_buf, dav,
                               grads[P_LN1W], grads[P_LN1B], ln1_part, T, D, drop_p, seed, C(SITE_ATTN_OUT)));

@@ -7,6 +7,7 @@ with the same constructor arguments for the hot path, attribute contract (`maski
 `projection_module`) and state_dict names.  All arithmetic runs in
 csrc/embedding.hip / gemm_f32.hip through one fused autograd function.
 """
+import functools
 import math
 import os
 from typing import Dict, Optional
@@ -166,7 +167,8 @@ class TableConfig:
         self.vocabulary_size, self.dim, self.combiner, self.name = vocabulary_size, dim, combiner, name
         # features/embedding.py:460-464: no initializer means normal_(mean 0, std 0.05), always applied by
         # table_to_embedding_module -- bag tables start at std 0.05 too, not at EmbeddingBag's N(0, 1)
-        self.initializer = (lambda w: nn.init.normal_(w, mean=0.0, std=0.05)) if initializer is None else initializer
+        # (a functools.partial, as the reference: a lambda here made torch.save(model) / pickle fail)
+        self.initializer = functools.partial(nn.init.normal_, mean=0.0, std=0.05) if initializer is None else initializer
 
     def __repr__(self):
         return (f"TableConfig(vocabulary_size={self.vocabulary_size!r}, dim={self.dim!r}, "

@@ -144,6 +144,11 @@ def head_split_supported(D):
     return bool(_lib.load().t4r_head_split_supported(int(D)))
 
 
+def head_split_ws_bytes(N, V, D):
+    """bytes of workspace head_split_prepare allocates for these sizes (0: unsupported width)"""
+    return int(_lib.load().t4r_head_split_ws_bytes(int(N), int(V), int(D)))
+
+
 def head_split_prepare(x, V):
     """cuts the head's input rows x [N, D] into the plane blocks of the three products; returns the workspace"""
     N, D = x.shape
@@ -580,8 +585,7 @@ def xlnet_attn_bwd(q, k, v, k_r, r_w_bias, r_r_bias, out, lse, dout, d_rw, d_rr,
     D = q.shape[-1]
     dev = q.device
     per_b = int(k_r.shape[0] == B * 2 * L and B > 1)
-    # planes of one [3, T, D] buffer, as the layer holds them (with q | k | v laid out the same way and
-    # T4R_XLNET_ATTN_CORE16=1 the library takes the one-wave-per-head fp32-MFMA core of csrc/xlnet_attn_block.hip)
+    # planes of one [3, T, D] buffer, as the layer holds them
     dq, dk, dv = torch.empty((3, B * L, D), device=dev, dtype=torch.float32).unbind(0)
     dkr = torch.empty_like(k_r)
     nws = _lib.load().t4r_xlnet_attn_bwd_ws_floats(B, L, D, n_head)
@@ -809,24 +813,6 @@ def xlnet_attn_block_fwd(h, planes, o, kr, r_w_bias, r_r_bias, gamma, beta, B, L
          lse.data_ptr(), _p(ao), _p(mean), _p(rstd), h1.data_ptr(), B, L, D, n_head, float(eps), float(drop_p), int(seed),
          int(ctr_prob), int(ctr_out), _p(key_len, torch.int32))
     return h1, dict(qkv=qkv, av=av, lse=lse, ao=ao, mean=mean, rstd=rstd)
-
-
-def xlnet_attn_block_bwd(dy, saved, h, planes, wq, wk, wv, kr, r_w_bias, r_r_bias, gamma, d_rw, d_rr, d_gamma, d_beta, B, L, n_head,
-                         drop_p=0.0, seed=0, ctr_prob=0, ctr_out=0, key_len=None):
-    """backward of xlnet_attn_block_fwd: -> dh, dao, dqkv [3, T, D], dkr (shape of kr); d_rw / d_rr / d_gamma / d_beta accumulated"""
-    T, D = dy.shape
-    dev = dy.device
-    dh, dao = torch.empty((T, D), device=dev), torch.empty((T, D), device=dev)
-    dqkv = torch.empty((3, T, D), device=dev)
-    dkr = torch.empty_like(kr)
-    per_session = kr.shape[0] == B * 2 * L and B > 1
-    part = torch.empty(max(1, _lib.load().t4r_xlnet_attn_block_bwd_part_floats(B, L, D, n_head)), device=dev)
-    call("t4r_xlnet_attn_block_bwd", _stream(), _chk(dy, torch.float32), _chk(saved["ao"]), _chk(h), _chk(saved["mean"]), _chk(saved["rstd"]),
-         _chk(gamma), planes.data_ptr(), _chk(wq), _chk(wk), _chk(wv), _chk(saved["qkv"]), _chk(kr), 2 * L * D if per_session else 0,
-         _chk(r_w_bias), _chk(r_r_bias), _chk(saved["lse"]), dh.data_ptr(), dao.data_ptr(), dqkv.data_ptr(), dkr.data_ptr(),
-         _chk(d_rw), _chk(d_rr), _chk(d_gamma), _chk(d_beta), part.data_ptr(), B, L, D, n_head, float(drop_p), int(seed), int(ctr_prob),
-         int(ctr_out), _p(key_len, torch.int32))
-    return dh, dao, dqkv, dkr
 
 
 def xlnet_ff_fwd(h1, planes, b1, b2, gamma, beta, eps, drop_p=0.0, seed=0, ctr_act=0, ctr_out=0, train=True):

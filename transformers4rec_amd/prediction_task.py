@@ -155,9 +155,14 @@ class _NextItemHeadFn(torch.autograd.Function):
         V = W.shape[0]
         smooth = float(getattr(task.loss, "label_smoothing", 0.0) or 0.0)
         mode = task.resolve_head_mode(N, V) if neg is None else "materialize"
-        ctx.fused = mode == "fused"
         ctx.recompute = (mode == "recompute" and any(ctx.needs_input_grad) and _head_split_ok(xp, W, N, V)
                          and ops.head_split_recompute_supported(W.shape[1]))
+        if mode == "recompute" and not ctx.recompute:
+            # the recomputing kernels cannot take this call (precision mode, T4R_HEAD_SPLIT=0, a misaligned table, a
+            # training=True call under no_grad): fall back by SIZE -- the chunked head when the [N, V] scores do not
+            # fit, never a silent multi-GB allocation
+            mode = task.size_head_mode(N, V)
+        ctx.fused = mode == "fused"
         if ctx.recompute:
             # no [N, V] tensor at all: statistics forward, score tiles recomputed by the two backward products
             # (csrc/head_split.hip: head_dw_rc / head_dx_rc kernels); `predictions` is computed if somebody reads it
@@ -413,11 +418,16 @@ class NextItemPredictionTask(nn.Module):
             self.to(device)
         return self
 
+    @staticmethod
+    def size_head_mode(N, V):
+        """'materialize' when the [N, V] fp32 scores fit T4R_HEAD_AUTO_GB (default 4 GiB), else the chunked 'fused' head"""
+        limit = float(os.environ.get("T4R_HEAD_AUTO_GB", "4")) * (1 << 30)
+        return "materialize" if 4.0 * N * ops.pad_ld(V) <= limit else "fused"
+
     def resolve_head_mode(self, N, V):
         mode = os.environ.get("T4R_HEAD_MODE") or self.head_mode
         if mode == "auto":
-            limit = float(os.environ.get("T4R_HEAD_AUTO_GB", "4")) * (1 << 30)
-            mode = "materialize" if 4.0 * N * ops.pad_ld(V) <= limit else "fused"
+            mode = self.size_head_mode(N, V)
             # Scores too large to keep: at a head_split.hip width the RECOMPUTING head (round 4: statistics forward, score
             # tiles recomputed by the two backward products, csrc/head_split.hip) replaces the chunked general path.
             # Where the scores do fit it is NOT the default: measured at BASELINE configs[1] (d_model 128) the two extra
@@ -425,10 +435,15 @@ class NextItemPredictionTask(nn.Module):
             # head_mode="recompute" / T4R_HEAD_MODE=recompute selects it anyway (training calls only: metrics read the scores)
             if mode == "fused" and getattr(self, "_training_call", False) and _HEAD_RECOMPUTE:
                 D = self.pre.module.output_weights.shape[1]
-                if D <= 128 and ops.head_split_recompute_supported(D):
+                # its workspace (per-tile statistics + two table images) is not cache-sized like the chunked head's one
+                # chunk: ~30 GB at V = 10 M, N = 15 k, D = 128 -- above T4R_HEAD_WS_GB (default 16) the chunked head stays
+                ws_limit = float(os.environ.get("T4R_HEAD_WS_GB", "16")) * (1 << 30)
+                if (D <= 128 and ops.head_split_recompute_supported(D)
+                        and ops.head_split_ws_bytes(N, V, D) <= ws_limit):
                     mode = "recompute"
         if mode == "recompute" and not getattr(self, "_training_call", False):
-            mode = "materialize"
+            # evaluation calls read the scores: by size, as `auto` (materialize if they fit, else the chunked head)
+            mode = self.size_head_mode(N, V)
         return mode
 
     def _lazy_predictions(self, x, pos, labels, N):

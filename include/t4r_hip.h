@@ -240,6 +240,19 @@ int t4r_head_split_dx(void* stream, void* ws, const float* logits, long ld, cons
                       const float* grad_out, float label_smoothing, const float* W, long ldw, float* dX, long lddx,
                       int N, int Vc, int V, int yoff, int D, float alpha, int accumulate, void* note);
 
+/* The ONE-PASS forward of the same head (round 5; csrc/head_split.hip: head_fwd_dx_kernel): logits, loss rows, lse, the mean
+ * loss AND dX [N, D] = d (mean loss) / d X for grad_out = 1 from one launch over (128-row tile x item range) workgroups --
+ * the score tile comes off the matrix cores once, is stored, and its probabilities against a running row reference feed the
+ * d X product from registers (flash-attention style; a small kernel merges the per-range statistics and partial sums).  The
+ * logits are then read ONCE more (t4r_head_split_dw) instead of twice: 3.65 -> 2.6 GB of HBM traffic per step at BASELINE
+ * configs[1].  Replaces transformers4rec/torch/model/prediction_task.py:648-671 (logits) + CrossEntropyLoss :446 and the d X
+ * half of their autograd.  X: the rows t4r_head_split_prepare was given (same ws); wsum: column sums of W [D], required when
+ * label_smoothing > 0, else NULL; the caller's backward is dX * grad_out and t4r_head_split_dw with the same ws / note.
+ * t4r_head_split_fdx_supported: 1 when this form takes the width (two-way fp16 products on; T4R_HEAD_FDX=0 switches it off). */
+int t4r_head_split_fdx_supported(int D);
+int t4r_head_split_logits_ce_dx(void* stream, void* ws, const float* X, long ldx, const float* W, long ldw, float* C, long ldc,
+                                const long* labels, float* loss_rows, float* lse, float* loss_mean, float* dX, long lddx,
+                                const float* wsum, int N, int V, int D, float alpha, float label_smoothing, void* note);
 /* The RECOMPUTING form of the same head (round 4; two-way fp16 products only: t4r_head_split_recompute_supported): nothing
  * of size [N, V] is written or read.  _ce: loss rows, lse (and the mean) from per-tile statistics, each row's label logit
  * captured inside the product; _dw_rc / _dx_rc: the two backward products with their score tiles recomputed on the matrix

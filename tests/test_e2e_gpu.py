@@ -948,8 +948,10 @@ def test_head_split_path_is_taken_and_agrees_with_the_general_gemm(monkeypatch, 
     model = tr.XLNetConfig.build(D, 4, 2, total_seq_length=L).to_torch_model(inputs, task).to("cuda")
     x = tr.random_data_from_schema(schema, B, L, seed=1, device="cuda")
     taken = []
-    real = ops.head_split_logits_ce
+    # either form of csrc/head_split.hip's forward: the one-pass logits + CE + d X (round 5, default) or logits + CE
+    real, real_dx = ops.head_split_logits_ce, ops.head_split_logits_ce_dx
     monkeypatch.setattr(ops, "head_split_logits_ce", lambda *a, **k: (taken.append(1), real(*a, **k))[1])
+    monkeypatch.setattr(ops, "head_split_logits_ce_dx", lambda *a, **k: (taken.append(1), real_dx(*a, **k))[1])
     from transformers4rec_amd.rng import get_rng_state, set_rng_state
 
     res = {}

@@ -144,3 +144,90 @@ def test_training_step_next_to_a_co_resident_collective_is_bit_identical(k, thre
     assert loss_a == loss_b and sorted(g_a) == sorted(g_b)
     for n in g_a:
         assert torch.equal(g_a[n], g_b[n]), n
+
+
+# ------------------------------------------------------------------------------------------ the one-pass head forward
+@pytest.mark.parametrize("N,V,D,smooth,T", [(700, 30001, 128, 0.0, 1.0), (333, 20017, 64, 0.1, 2.0), (2780, 100001, 128, 0.0, 1.0),
+                                            (129, 9000, 32, 0.05, 1.0), (40, 70000, 96, 0.0, 0.5)])
+def test_head_one_pass_forward_gives_logits_loss_and_dx(N, V, D, smooth, T):
+    """t4r_head_split_logits_ce_dx (csrc/head_split.hip head_fwd_dx_kernel): logits, loss, lse and d X from
+    ONE launch against (i) the two-pass form it replaces -- the logits bit for bit (same operand pieces, same product order),
+    loss / lse / d X to rounding -- and (ii) fp64: transformers4rec/torch/model/prediction_task.py:648-671 + CrossEntropyLoss
+    :446 and autograd's d X of them; d W from the SAME workspace (its per-item scales now come from the column maxima this
+    forward leaves) against fp64 per item row."""
+    from transformers4rec_amd import ops
+
+    if not ops.head_split_fdx_supported(D):
+        pytest.skip("one-pass head switched off (T4R_HEAD_FDX=0 / fp16 forms off)")
+    g = torch.Generator().manual_seed(N + V)
+    x = torch.randn(N, D, generator=g)
+    # item norms over two decades (rare items: d W rows far below the tensor's maximum)
+    W = torch.randn(V, D, generator=g) * (0.02 * torch.logspace(0, 2, V)[torch.randperm(V, generator=g)].unsqueeze(1) / 10)
+    y = torch.randint(1, V, (N,), generator=g)
+    xd, Wd, yd = x.to(DEV), W.to(DEV), y.to(DEV)
+    ld = ops.pad_ld(V)
+    # two-pass form
+    ws0 = ops.head_split_prepare(xd, V)
+    lg0, loss0, rows0, lse0 = ops.head_split_logits_ce(ws0, xd, Wd, yd, alpha=1.0 / T, label_smoothing=smooth, ldc=ld)
+    one = torch.ones((), device=DEV)
+    dx0 = ops.head_split_dx(ws0, lg0, lse0, yd, one, V, Wd, alpha=1.0 / T, label_smoothing=smooth)
+    # one-pass form
+    ws1 = ops.head_split_prepare(xd, V)
+    lg1, loss1, rows1, lse1, dx1 = ops.head_split_logits_ce_dx(ws1, xd, Wd, yd, alpha=1.0 / T, label_smoothing=smooth, ldc=ld)
+    dW1 = torch.zeros(V, D, device=DEV)
+    ops.head_split_dw(ws1, lg1, lse1, yd, one, V, D, dW1, alpha=1.0 / T, label_smoothing=smooth, accumulate=True)
+    torch.cuda.synchronize()
+    assert torch.equal(lg0, lg1)
+    assert float((lse0 - lse1).abs().max()) < 2e-6 * max(1.0, float(lse0.abs().max()))
+    assert float((rows0 - rows1).abs().max()) < 4e-6 * max(1.0, float(rows0.abs().max()))
+    assert abs(float(loss0) - float(loss1)) < 2e-6 * max(1.0, abs(float(loss0)))
+    # fp64
+    x64, W64 = x.double().requires_grad_(), W.double().requires_grad_()
+    z = (x64 @ W64.t()) / T
+    ref = torch.nn.functional.cross_entropy(z, y, label_smoothing=smooth)
+    ref.backward()
+    assert abs(float(loss1) - float(ref)) < 3e-6 * max(1.0, abs(float(ref)))
+    assert float((lg1.double().cpu() - z.detach()).abs().max()) < 3e-6 * float(z.detach().abs().max())
+    dmax = float(x64.grad.abs().max())
+    assert float((dx1.double().cpu() - x64.grad).abs().max()) < 3e-6 * dmax
+    assert float((dx0.double().cpu() - x64.grad).abs().max()) < 3e-6 * dmax
+    # d W per item row (rows of rare items included): relative to the row's own largest entry
+    gW = W64.grad
+    rowmax = gW.abs().max(1).values
+    live = rowmax > 0
+    err = ((dW1.double().cpu() - gW).abs().max(1).values[live] / rowmax[live])
+    assert float(err.max()) < 2e-5 and float(err.median()) < 3e-6
+    if ops.head_split_dw_form(ws1) != 0:
+        assert ops.head_split_dw_form(ws1) == 2          # the fp16 form with per-item scales, not the bf16-plane fallback
+    # bit-reproducible
+    ws2 = ops.head_split_prepare(xd, V)
+    lg2, loss2, rows2, lse2, dx2 = ops.head_split_logits_ce_dx(ws2, xd, Wd, yd, alpha=1.0 / T, label_smoothing=smooth, ldc=ld)
+    assert torch.equal(dx1, dx2) and torch.equal(lse1, lse2) and torch.equal(lg1, lg2)
+
+
+def test_head_one_pass_forward_survives_extreme_scores():
+    """rows whose largest score arrives late and far above the running reference (many bumps of the reference), all-equal
+    scores, a label in the ragged last tile"""
+    from transformers4rec_amd import ops
+
+    N, V, D = 200, 12345, 128
+    if not ops.head_split_fdx_supported(D):
+        pytest.skip("one-pass head switched off")
+    g = torch.Generator().manual_seed(3)
+    W = 0.05 * torch.randn(V, D, generator=g)
+    W[V // 2:] *= torch.linspace(1, 60, V - V // 2).unsqueeze(1)        # scores grow along the vocabulary
+    x = torch.randn(N, D, generator=g)
+    x[0] = 0.0                                                          # all-equal scores
+    y = torch.randint(1, V, (N,), generator=g)
+    y[1] = V - 1
+    xd, Wd, yd = x.to(DEV), W.to(DEV), y.to(DEV)
+    ws = ops.head_split_prepare(xd, V)
+    lg, loss, rows, lse, dx = ops.head_split_logits_ce_dx(ws, xd, Wd, yd, ldc=ops.pad_ld(V))
+    x64 = x.double().requires_grad_()
+    z = x64 @ W.double().t()
+    ref = torch.nn.functional.cross_entropy(z, y)
+    ref.backward()
+    assert bool(torch.isfinite(dx).all()) and bool(torch.isfinite(lse).all())
+    assert abs(float(loss) - float(ref)) < 5e-6 * max(1.0, abs(float(ref)))
+    # (peaked rows: d X = W[top] - W[y] to the rounding of table entries of magnitude ~3: an absolute 2e-7 |W| term)
+    assert float((dx.double().cpu() - x64.grad).abs().max()) < 5e-6 * float(x64.grad.abs().max()) + 2e-7 * float(W.abs().max())

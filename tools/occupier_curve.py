@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=15)
     ap.add_argument("--config", default="c2")
+    ap.add_argument("--priority", type=int, default=0, help="priority of the occupier's stream (-1 = high)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r05_occupier_curve.json"))
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -71,10 +72,18 @@ def main():
            "config": bench.WORKLOADS[args.config], "steps": args.steps, "curves": {}}
     base = timed()
     res["baseline_ms"] = round(base, 4)
+    # ONE side stream for every point of the curve: HIP maps streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default
+    # 4) round-robin, and a stream that lands on the queue of the caller's stream or of a weight-gradient stream is
+    # SERIALISED with it -- a resident kernel there blocks everything queued behind it (round 5's first curve, one fresh
+    # stream per point, was a lottery: 1.06x at k = 16 and 8x at the next point).  The same holds for RCCL's stream at N > 1.
+    side = torch.cuda.Stream(device=dev, priority=args.priority)
+    res["gpu_max_hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES", "default (4)")
+    res["side_stream_priority"] = args.priority
     for name, threads, lds in (("channel_256thr_16KB", 256, 16 * 1024), ("exclusive_512thr_96KB", 512, 96 * 1024)):
         curve = {}
         for k in (8, 16, 32, 64):
             state["occ"] = t4r_tools.Occupier(k, threads=threads, lds_bytes=lds, max_us=20000, device=dev)
+            state["occ"].side = side
             ms = timed()
             seen = int(state["occ"].seen.item())
             curve[str(k)] = {"ms_per_step": round(ms, 4), "slowdown": round(ms / base, 4),

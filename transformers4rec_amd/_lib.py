@@ -58,6 +58,8 @@ _SIGS = {
     "t4r_head_split_fwd_products": ("i", ""),
     "t4r_head_split_ws_bytes": ("l", "iii"),
     "t4r_head_split_prepare": ("i", "ppl" + "iii" + "p"),
+    "t4r_head_split_fdx_supported": ("i", "i"),
+    "t4r_head_split_logits_ce_dx": ("i", "pp" + "plpl" + "pl" + "pppp" + "plp" + "iii" + "ff" + "p"),
     "t4r_head_note_dw_form": ("i", "p"),
     "t4r_head_split_logits": ("i", "ppplpl" + "iiif" + "p"),
     "t4r_head_split_logits_ce": ("i", "ppplpl" + "pppp" + "iiiff" + "p"),

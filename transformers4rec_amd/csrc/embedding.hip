@@ -144,9 +144,11 @@ __global__ __launch_bounds__(256) void seq_features_fwd_kernel(SeqFeatParams p) 
 // item 128 + 3 x 64 + 2 x 8 soft-embedding rows takes GROUP 64, NCH 2).  U consecutive tokens per lane group
 // with all id loads, then all row loads, in flight together (the generic kernel has one dependent
 // id -> row chain per lane).
-// NT: the table rows are read with non-temporal loads -- a table far beyond the 256 MB Infinity Cache is touched once per
-// launch, and lines that will not be hit again should not evict what will (ids, small tables); the host picks it per launch
-// from the table sizes (T4R_GATHER_NT = 0 / 1 overrides).
+// NT: the table rows are read with non-temporal loads.  Chosen by the host when EVERY gathered table is far beyond the 256 MB
+// Infinity Cache (rows touched once per launch should not evict ids / output lines); with small tables in the row (C3's three
+// categoricals: cache resident, hit again and again) plain loads win.  Measured (tools/gather_sweep.py, 163 840 tokens, 10 M-row
+// item table; box copy ceiling 5.1-5.2 TB/s): item-only 0.66 -> 0.70 of 8 TB/s with NT; C3 0.659 plain, 0.643 NT on every
+// table, 0.48 with a per-feature run-time choice (two load forms in one wave: the loads serialise).  T4R_GATHER_NT overrides.
 template <int GROUP, int U, int NCH, bool NT = false>
 __global__ __launch_bounds__(256) void seq_features_fwd_fast_kernel(SeqFeatParams p) {
     const int gl = threadIdx.x & (GROUP - 1);
@@ -283,9 +285,13 @@ extern "C" int t4r_seq_features_fwd(
         // non-temporal row loads when a gathered table cannot stay on the chip anyway (> 256 MB: beyond the Infinity Cache)
         static int nt_env = -2;
         if (nt_env == -2) { const char* e = getenv("T4R_GATHER_NT"); nt_env = e ? atoi(e) : -1; }
-        bool nt = false;
+        bool nt = true, any = false;
         for (int f = 0; f < n_feat; ++f)
-            if ((p.kind[f] == 0 || p.kind[f] == 2) && p.rows[f] * (long)p.dim[f] * 4 > (256L << 20)) nt = true;
+            if (p.kind[f] == 0 || p.kind[f] == 2) {
+                any = true;
+                if (p.rows[f] * (long)p.dim[f] * 4 <= (256L << 20)) nt = false;
+            }
+        nt = nt && any;
         if (nt_env >= 0) nt = nt_env != 0;
         const long groups = ((long)B * L_out + U - 1) / U;
         dim3 fgrid((unsigned)((groups * g + 255) / 256));

@@ -197,6 +197,33 @@ def head_split_logits_ce(ws, x, W, labels, alpha=1.0, label_smoothing=0.0, ldc=N
     return buf[:, :V], loss, loss_rows, lse
 
 
+def head_split_fdx_supported(D):
+    return bool(_lib.load().t4r_head_split_fdx_supported(int(D)))
+
+
+def head_split_logits_ce_dx(ws, x, W, labels, alpha=1.0, label_smoothing=0.0, ldc=None):
+    """the one-pass forward (csrc/head_split.hip: head_fwd_dx_kernel): logits [N, V] (view of an [N, ldc] buffer), mean loss,
+    loss rows, lse AND dx_unit [N, D] = d (mean loss) / d x for an upstream gradient of 1 -- the backward is dx_unit * grad_out
+    plus head_split_dw on the same workspace; the logits are never read for d X"""
+    N, D = x.shape
+    V = W.shape[0]
+    ldc = V if ldc is None else ldc
+    dev = x.device
+    buf = torch.empty((N, ldc), device=dev, dtype=torch.float32)
+    loss_rows = torch.empty(N, device=dev, dtype=torch.float32)
+    lse = torch.empty(N, device=dev, dtype=torch.float32)
+    loss = torch.empty((), device=dev, dtype=torch.float32)
+    dx = torch.empty((N, D), device=dev, dtype=torch.float32)
+    wsum = None
+    if label_smoothing > 0:
+        wsum = torch.zeros(D, device=dev, dtype=torch.float32)
+        colsum_(W, wsum)
+    call("t4r_head_split_logits_ce_dx", _stream(), ws.data_ptr(), _chk(x, torch.float32), x.stride(0), _chk(W, torch.float32),
+         W.stride(0), buf.data_ptr(), ldc, _chk(labels, torch.int64), loss_rows.data_ptr(), lse.data_ptr(), loss.data_ptr(),
+         dx.data_ptr(), dx.stride(0), _p(wsum), N, V, D, float(alpha), float(label_smoothing), _note(ws))
+    return buf[:, :V], loss, loss_rows, lse, dx
+
+
 def head_split_dw(ws, logits, lse, labels, grad_out, V, D, out, alpha=1.0, label_smoothing=0.0, accumulate=True, yoff=0):
     N, Vc = logits.shape
     call("t4r_head_split_dw", _stream(), ws.data_ptr(), logits.data_ptr(), logits.stride(0), _chk(lse, torch.float32),

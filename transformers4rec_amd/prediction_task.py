@@ -182,13 +182,20 @@ class _NextItemHeadFn(torch.autograd.Function):
             ctx.set_materialize_grads(False)
             return loss, None
         hws = None
+        dx_unit = None
         if neg is None:
             if _head_split_ok(xp, W, N, V):
                 # d_model <= 128: operands cut once, W-stationary logits (csrc/head_split.hip)
                 # (and the softmax statistics reduced inside the product: no second pass over [N, V])
                 hws = ops.head_split_prepare(xp, V)
-                logits, loss, _rows, lse = ops.head_split_logits_ce(hws, xp, W.detach(), labels, alpha=1.0 / T,
-                                                                    label_smoothing=smooth, ldc=ops.pad_ld(V))
+                if ctx.needs_input_grad[0] and ops.head_split_fdx_supported(W.shape[1]) and W.stride(0) % 4 == 0:
+                    # one pass (round 5): the scores come off the matrix cores once, are stored, and feed the d X product
+                    # from registers -- the backward keeps only d W's read of the logits
+                    logits, loss, _rows, lse, dx_unit = ops.head_split_logits_ce_dx(hws, xp, W.detach(), labels, alpha=1.0 / T,
+                                                                                    label_smoothing=smooth, ldc=ops.pad_ld(V))
+                else:
+                    logits, loss, _rows, lse = ops.head_split_logits_ce(hws, xp, W.detach(), labels, alpha=1.0 / T,
+                                                                        label_smoothing=smooth, ldc=ops.pad_ld(V))
             else:
                 logits = ops.gemm(xp, W.detach(), False, True, alpha=1.0 / T, ldc=ops.pad_ld(V))
             tgt, width = labels, V
@@ -199,6 +206,7 @@ class _NextItemHeadFn(torch.autograd.Function):
             loss, _rows, lse = ops.softmax_ce_fwd(logits, tgt, width, smooth)
         ctx.task, ctx.neg, ctx.meta = task, neg, (B, L, D, N, V, T, width, smooth)
         ctx.hws = hws
+        ctx.dx_unit = dx_unit
         ctx.save_for_backward(pos, labels, tgt, xr, xp, logits, lse)
         ctx.mark_non_differentiable(logits)
         # without this autograd hands backward() a zero-filled [N_m, V] gradient for `logits`
@@ -232,7 +240,10 @@ class _NextItemHeadFn(torch.autograd.Function):
             g = dloss.contiguous()
             hws = ctx.hws
             Dh = W.shape[1]
-            if hws is not None:
+            if getattr(ctx, "dx_unit", None) is not None:
+                dxp = ctx.dx_unit * g                  # formed in the forward for an upstream gradient of 1
+                ctx.dx_unit = None
+            elif hws is not None:
                 dxp = ops.head_split_dx(hws, logits, lse, tgt, g, V, W.detach(), alpha=1.0 / T, label_smoothing=smooth)
             else:
                 dxp = ops.gemm_softmax_grad(logits, lse, tgt, g, V, W.detach(), False, alpha=1.0 / T,

@@ -755,6 +755,15 @@ def main():
     # file on a single-GPU box; the measured configuration is always nccl (= RCCL), one rank per GPU
     backend = os.environ.get("T4R_BENCH_BACKEND", "nccl")
     dev_index = 0 if os.environ.get("T4R_BENCH_SHARE_GPU", "0") == "1" else local_rank
+    if world > 1:       # (before the first HIP call: the runtime reads its environment once)
+        # The table all-reduce runs UNDER the body's backward, whose token-tile kernels launch one workgroup per CU: every CU an
+        # RCCL channel holds costs them a second round (tools/occupier_curve.py, profiles/r05_occupier_curve.json).  Two knobs,
+        # both overridable from the environment: (i) cap the channels, so that the collective's footprint is known and small --
+        # 16 channels move the 51 MB bucket over 7 xGMI links in ~0.3 ms, well inside the ~1 ms backward; (ii) more hardware
+        # queues than HIP's default 4, so that RCCL's stream does not share a queue with the caller's or a weight-gradient
+        # stream (streams on one hardware queue are serialised: a resident kernel blocks everything queued behind it).
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     import torch.distributed as dist
@@ -1082,6 +1091,8 @@ def main():
                        "head_mode": model.prediction_task.resolve_head_mode(N_m, W.shape[0]),
                        "precision_mode": mode, "table_exchange": exchange_mode, "world_size": world,
                        "collective_backend": (backend if world > 1 else None),
+                       "nccl_max_nchannels": (os.environ.get("NCCL_MAX_NCHANNELS") if world > 1 else None),
+                       "gpu_max_hw_queues": (os.environ.get("GPU_MAX_HW_QUEUES") if world > 1 else None),
                        "preheat_s": round(preheat_s, 2), "preheat_steps": n_pre,
                        "timed_region_s": round(dt, 4)},
             "ms_per_step_windows": windows,

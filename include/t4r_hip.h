@@ -415,6 +415,14 @@ int t4r_xlnet_ln1_bwd(void* stream, const float* dy, const float* ao, const floa
                       float* d_beta, float* part, long T, int D, float drop_p, unsigned long long seed,
                       unsigned long long ctr_hi);
 int t4r_xlnet_dh(void* stream, const float* dqkv, const float* planes, float* dh, long T, int D);
+/* CUs the token-tile kernels of the BACKWARD pass (t4r_xlnet_ff_bwd, _ln1_bwd, _dh; also inside t4r_xlnet_layer_bwd) may count
+ * on; 0 (default) = the whole chip.  Their default grid is one 512-thread workgroup per CU, so a resident kernel that holds k
+ * CUs -- the RCCL all-reduce of the table bucket that runs under the body's backward at N > 1 (the reference's
+ * DDP does the same overlap, transformers4rec/torch/trainer.py:131-161) -- would send every such launch into a second round
+ * of workgroups (measured 1.38x per step, tools/occupier_curve.py).  With a budget below 256 they take the tile that minimises
+ * rounds x rows on that many CUs.  Process-wide, read at every launch; results do not depend on it (same arithmetic per row). */
+void t4r_xlnet_set_cu_budget(int cus);
+int t4r_xlnet_get_cu_budget(void);
 /* The attention half of a layer as ONE kernel per direction (csrc/xlnet_attn_block.hip; round 4): exact fp32 matrix
  * instructions (v_mfma_f32_16x16x4_f32 = a k-ordered fmaf chain), one workgroup per 80 / L whole sessions, q | k | v, the
  * scores and the probabilities never leave the chip.  Shapes: L <= 32, d_head 16 | 32, d_model 32 | 64 | 128

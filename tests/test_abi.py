@@ -73,7 +73,9 @@ _ALLOWED_FILE_SCOPE_STATE = {
     "g_sg": "thread-local, set and cleared inside one t4r_gemm_softmax_grad_f32 call",
     "g_rank": "thread-local, set and cleared inside one t4r_rank_of_target_f32 call",
     "g_amax_a": "thread-local, set and cleared inside one layer call (operand maxima of a GEMM launch)",
-    "g_amax_b": "same", "g_amax_n": "same",
+    "g_amax_b": "same", "g_amax_n": "same", "g_amax_nb": "same",
+    "g_cu_budget": "CUs the backward's token-tile kernels may count on, set only through t4r_xlnet_set_cu_budget (documented in "
+                   "include/t4r_hip.h; results do not depend on it)",
     "g_ff_amax": "thread-local, set and cleared inside one layer call",
     "g_red_side": "thread-local, set and cleared inside one layer call (reduction side stream)",
     "g_red_events": "same", "g_red_n": "same", "g_red_used": "same",

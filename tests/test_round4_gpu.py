@@ -60,7 +60,7 @@ def test_head_dw_rows_match_fp64_in_every_magnitude_bucket(form):
     ref = (p / N).t() @ x.double()
     del p
     if form == 1:      # a fresh (zeroed) note: the backward product knows nothing about the forward
-        ws.t4r_note = (ctypes.c_ulonglong * 8)()
+        ws.t4r_note = torch.zeros(8, dtype=torch.int64)
     assert ops.head_split_dw_form(ws) == 0
     dW = torch.full((V, D), float("nan"), device=DEV)
     ops.head_split_dw(ws, logits, lse, labels, gout, V, D, dW, accumulate=False)

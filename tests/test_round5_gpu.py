@@ -231,3 +231,37 @@ def test_head_one_pass_forward_survives_extreme_scores():
     assert abs(float(loss) - float(ref)) < 5e-6 * max(1.0, abs(float(ref)))
     # (peaked rows: d X = W[top] - W[y] to the rounding of table entries of magnitude ~3: an absolute 2e-7 |W| term)
     assert float((dx.double().cpu() - x64.grad).abs().max()) < 5e-6 * float(x64.grad.abs().max()) + 2e-7 * float(W.abs().max())
+
+
+def test_cu_budget_changes_the_backward_tiles_not_the_gradients():
+    """t4r_xlnet_set_cu_budget (what distributed.GradReducer sets while the table all-reduce holds CUs): the backward's
+    token-tile kernels take 48-row tiles instead of 80-row ones at a budget of 240 CUs -- every per-row result (the gradient
+    w.r.t. the layer input, hence the table gradient) stays bit-identical, the batch-reduced parameter gradients (LayerNorm,
+    biases: per-workgroup partial sums, now grouped differently) agree to rounding."""
+    import transformers4rec_amd as tr
+    from transformers4rec_amd import ops
+
+    B, L, V, D = 1024, 20, 20000, 128
+
+    def run(budget):
+        schema, model = _model(tr, V, D, L, dropout=0.3)
+        model.transformer_block.transformer.seed = 77
+        ids = tr.random_data_from_schema(schema, B, L, seed=5)["item_id"].to(DEV)
+        out = model({"item_id": ids}, training=True)
+        ops.xlnet_set_cu_budget(budget)
+        try:
+            out["loss"].backward()
+            torch.cuda.synchronize()
+        finally:
+            ops.xlnet_set_cu_budget(0)
+        return {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    assert ops.xlnet_get_cu_budget() == 0
+    g_a, g_b = run(0), run(240)
+    assert sorted(g_a) == sorted(g_b)
+    for n in g_a:
+        scale = float(g_a[n].abs().max())
+        assert float((g_a[n] - g_b[n]).abs().max()) <= 4e-6 * scale + 1e-12, n
+    # the masked-item embedding and the table rows are sums over per-row results only
+    tab = [n for n in g_a if n.endswith("item_embedding_table.weight") or n.endswith("item_id.weight")]
+    assert tab

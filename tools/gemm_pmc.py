@@ -33,6 +33,14 @@ for _ in range(3):
     ops.head_split_dx(ws, logits, lse, labels, g, V, W)
     ops.head_split_dw(ws, logits, lse, labels, g, V, D, dW)
 torch.cuda.synchronize()
+# round 5: the ONE-PASS forward (logits + CE + d X: head_fwd_dx_kernel) and the d W that follows it -- the head's traffic per
+# step is now these two launches + the small ones (table images, finalize), instead of logits + d X + d W
+if ops.head_split_fdx_supported(D):
+    for _ in range(3):
+        ws = ops.head_split_prepare(x, V)
+        logits, loss, rows, lse, dxu = ops.head_split_logits_ce_dx(ws, x, W, labels, ldc=ops.pad_ld(V))
+        ops.head_split_dw(ws, logits, lse, labels, g, V, D, dW)
+    torch.cuda.synchronize()
 
 # round 3: the token-tile-stationary fused kernels of the XLNet layer at the benchmark size (csrc/xlnet_fused*.hip)
 from transformers4rec_amd import _lib

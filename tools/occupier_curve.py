@@ -33,6 +33,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=15)
     ap.add_argument("--config", default="c2")
     ap.add_argument("--priority", type=int, default=0, help="priority of the occupier's stream (-1 = high)")
+    ap.add_argument("--only", type=int, default=0, help="one point only: k workgroups of the channel footprint (for a kernel trace)")
+    ap.add_argument("--budget", action="store_true",
+                    help="tell the backward's token-tile kernels how many CUs are left while the occupier is resident "
+                         "(ops.xlnet_set_cu_budget(256 - k): what distributed.GradReducer does around the table all-reduce)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r05_occupier_curve.json"))
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -41,7 +45,16 @@ def main():
     batches = [tr.random_data_from_schema(schema, bench.BATCH, bench.SEQ, seed=i, device=dev) for i in range(8)]
     model.train()
     state = {"occ": None}
-    hook = tr.head_backward_hook(model, lambda: state["occ"] is not None and state["occ"].start())
+    from transformers4rec_amd import ops
+
+    def on_head_backward():
+        occ = state["occ"]
+        if occ is not None:
+            occ.start()
+            if args.budget:
+                ops.xlnet_set_cu_budget(256 - occ.k)
+
+    hook = tr.head_backward_hook(model, on_head_backward)
 
     def step(i):
         out = model(batches[i % 8], training=True)
@@ -50,6 +63,7 @@ def main():
         if occ is not None:
             occ.stop()          # in stream order: after the last kernel of the backward pass on the caller's stream
             occ.join()
+            ops.xlnet_set_cu_budget(0)
         reducer.reduce_all()
         opt.step(grad_scale=reducer.grad_scale)
         return out
@@ -79,9 +93,12 @@ def main():
     side = torch.cuda.Stream(device=dev, priority=args.priority)
     res["gpu_max_hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES", "default (4)")
     res["side_stream_priority"] = args.priority
+    res["cu_budget_told"] = bool(args.budget)
     for name, threads, lds in (("channel_256thr_16KB", 256, 16 * 1024), ("exclusive_512thr_96KB", 512, 96 * 1024)):
+        if args.only and threads != 256:
+            continue
         curve = {}
-        for k in (8, 16, 32, 64):
+        for k in ((args.only,) if args.only else (8, 16, 32, 64)):
             state["occ"] = t4r_tools.Occupier(k, threads=threads, lds_bytes=lds, max_us=20000, device=dev)
             state["occ"].side = side
             ms = timed()

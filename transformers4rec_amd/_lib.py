@@ -90,6 +90,8 @@ _SIGS = {
     "t4r_xlnet_ln1_bwd_part_floats": ("l", "li"),
     "t4r_xlnet_ln1_bwd": ("i", "p" + "ppppppp" + "pppppp" + "lif" + "QQ"),
     "t4r_xlnet_dh": ("i", "pppp" + "li"),
+    "t4r_xlnet_set_cu_budget": ("v", "i"),
+    "t4r_xlnet_get_cu_budget": ("i", ""),
     "t4r_xlnet_attn_block_supported": ("i", "iii"),
     "t4r_xlnet_attn_block_fwd": ("i", "ppppp" + "l" + "pppp" + "ppppppp" + "iiii" + "ffQQQ" + "p"),
     "t4r_xlnet_layer_bwd_defer": ("v", "i"),

@@ -166,8 +166,9 @@ bool t4r_splitk_sink_add_reduce(const float* part, int nblocks, int n, float* co
 // bf16 form runs in the two-way fp16 form instead (gemm_kernel.h: PREC 4).  Consumed by that launch.
 static thread_local const float* g_amax_a = nullptr;
 static thread_local const float* g_amax_b = nullptr;
-static thread_local int g_amax_n = 0;
-void t4r_gemm_operand_amax(const float* a, const float* b, int n) { g_amax_a = a; g_amax_b = b; g_amax_n = n; }
+static thread_local int g_amax_n = 0, g_amax_nb = 0;
+void t4r_gemm_operand_amax(const float* a, const float* b, int n) { g_amax_a = a; g_amax_b = b; g_amax_n = g_amax_nb = n; }
+void t4r_gemm_operand_amax2(const float* a, int na, const float* b, int nb) { g_amax_a = a; g_amax_b = b; g_amax_n = na; g_amax_nb = nb; }
 
 #ifdef T4R_EXPERIMENTAL     /* tools/experimental/wgrad_stream.hip: the K-streaming weight-gradient kernel (measured slower inside the step) */
 void t4r_wgrad_stream_plan(int K, int* splits, int* kper);
@@ -179,9 +180,9 @@ template <bool TA, bool TB>
 static int launch_layout(GemmParams& p, int batch, int splitk_req, hipStream_t stream) {
     const float* amax_a = g_amax_a;
     const float* amax_b = g_amax_b;
-    const int amax_n = g_amax_n;
+    const int amax_n = g_amax_n, amax_nb = g_amax_nb;
     g_amax_a = g_amax_b = nullptr;
-    p.amaxA = p.amaxB = nullptr; p.n_amax = 0;
+    p.amaxA = p.amaxB = nullptr; p.n_amax = p.n_amax_b = 0;
 #ifdef T4R_EXPERIMENTAL
     // long-K weight gradients with a split-K sink installed (the XLNet layer backward): the K-streaming kernel (wgrad_stream.hip)
     if (TA && !TB && splitk_req < 0 && g_sink.on && t4r_wgrad_stream_ok(p)) {
@@ -249,7 +250,7 @@ static int launch_layout(GemmParams& p, int batch, int splitk_req, hipStream_t s
         bn = big == 1 ? 128 : 64;
         half_big = big;
         if (prec == 1 && amax_a && amax_b && !feat && p.epilogue == EPI_NONE) {
-            prec = 4; p.amaxA = amax_a; p.amaxB = amax_b; p.n_amax = amax_n;
+            prec = 4; p.amaxA = amax_a; p.amaxB = amax_b; p.n_amax = amax_n; p.n_amax_b = amax_nb;
             bm = bn = 64; half_big = 0;
         }
     }

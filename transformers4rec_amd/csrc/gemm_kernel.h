@@ -52,7 +52,8 @@ struct GemmParams {
     int splitk;                 // >1: atomic accumulate alpha*partial into C (epilogue must be NONE) ...
     const float* amaxA;         // PREC 4: n_amax per-workgroup maxima of |A| and of |B| (device arrays written by the producers
     const float* amaxB;         //   of the operands): the two-way fp16 split positions both operands by powers of two of their max
-    int n_amax;
+    int n_amax;                 //   n_amax values of A, n_amax_b of B (the producers of the two operands may have run different grids)
+    int n_amax_b;
     float* part;                // ... or, non-null: split z (= blockIdx.z, batch-major) stores its partial tile to
                                 // part + z * M * ldc (C's layout); a reduction pass adds them in split order (gemm_f32.hip)
     int accumulate;             // splitk==1 only: C += result instead of C = result
@@ -303,7 +304,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     if constexpr (PREC == 4) {
         // every workgroup reduces the producers' per-workgroup maxima itself (a few hundred floats: L2 hits)
         float ma = 0.f, mb = 0.f;
-        for (int i = tid; i < p.n_amax; i += 256) { ma = fmaxf(ma, p.amaxA[i]); mb = fmaxf(mb, p.amaxB[i]); }
+        for (int i = tid; i < p.n_amax; i += 256) ma = fmaxf(ma, p.amaxA[i]);
+        for (int i = tid; i < p.n_amax_b; i += 256) mb = fmaxf(mb, p.amaxB[i]);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { ma = fmaxf(ma, __shfl_xor(ma, o, 64)); mb = fmaxf(mb, __shfl_xor(mb, o, 64)); }
         float* red = smem;      // the operand images are not in use yet

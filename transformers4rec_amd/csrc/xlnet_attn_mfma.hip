@@ -427,6 +427,9 @@ int t4r_xlnet_attn_mfma_bwd(hipStream_t st, const float* q, const float* k, cons
                             float* dk, float* dv, float* part, float* dkr, float* d_rw, float* d_rr, int B, int L,
                             int n_head, int d_head, float scale, long kr_bstride, DropCfg drop, const int* key_len) {
     const int D = n_head * d_head;
+    // (one (session, head) unit per wave and 1024 x n_head waves: at four heads exactly one residency of 256 CUs.  Shrinking the
+    //  grid to the CU budget was tried (round 5) and is worse: the unit is a whole session, so 1024 sessions on 960 workgroups
+    //  are two rounds for 64 of them anyway -- the occupier curve went 1.25x -> 1.5x.)
     const int gx = t4r_xlnet_attn_mfma_blocks(B);
     const dim3 grid(gx, n_head), block(64);
     float* dkr_b = kr_bstride > 0 ? dkr : nullptr;

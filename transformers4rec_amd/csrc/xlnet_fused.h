@@ -12,6 +12,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 int t4r_reduce_partials_launch(hipStream_t st, const float* part, int nblocks, float* o0, int n0, int a0,
                                float* o1, int n1, int a1, float* o2, int n2, int a2);   // elementwise.hip
+// token blocks (of 16 rows) per workgroup tile of the token-tile kernels for T rows (xlnet_fused.hip).  backward = true: the
+// launch may run next to a resident collective -- the CU budget of t4r_xlnet_set_cu_budget applies (forward launches never do)
+int t4r_xlnet_pick_r(long T, bool backward);
 bool t4r_xlnet_body_fp16x2();      // xlnet_fused.hip: the token-tile kernels on the two-way fp16 split (T4R_XLNET_FP16X2, default 1)?
 
 __device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }

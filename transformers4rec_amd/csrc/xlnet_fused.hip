@@ -306,28 +306,44 @@ __global__ __launch_bounds__(D * 4) void xlnet_ff_bwd_kernel(FFBwdParams p) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, g = lane >> 4;
     const long t0 = (long)blockIdx.x * RT;
     float dfomax_keep = 0.f;
-    // ---- phase A: LayerNorm backward, one token row per wave at a time (lane = two consecutive features)
+    // ---- phase A: LayerNorm backward, lane = two consecutive features of a token row; a wave owns RT / NW rows and walks
+    // them RB at a time with every load of the batch in flight before the first reduction (round 5: one row at a time was a
+    // chain of RT / NW dependent load -> reduce -> store latencies, ~15 us of the launch at 10 rows per wave)
     {
+        constexpr int RB = 5;
         const int c0 = lane * 2;
         const bool act_lane = c0 < D;
         float gam[2], pg[2], pb[2], pb2[2];
         float dfomax = 0.f;        // HS: running max |d ffout| over this wave's rows (operand maximum for the W2 weight gradient)
 #pragma unroll
         for (int e = 0; e < 2; ++e) { gam[e] = act_lane ? p.gamma[c0 + e] : 0.f; pg[e] = pb[e] = pb2[e] = 0.f; }
-        for (int row = w; row < RT; row += NW) {
+        for (int row0 = w; row0 < RT; row0 += NW * RB) {
+            float2 fo[RB], hh[RB], dd[RB];
+            float mu_[RB], rs_[RB];
+#pragma unroll
+            for (int b = 0; b < RB; ++b) {          // unconditional loads from clamped addresses
+                const long tc = min(t0 + min(row0 + b * NW, RT - 1), (long)p.T - 1);
+                mu_[b] = p.mean[tc]; rs_[b] = p.rstd[tc];
+                const int cc = act_lane ? c0 : 0;
+                fo[b] = *reinterpret_cast<const float2*>(p.ffout + tc * D + cc);
+                hh[b] = *reinterpret_cast<const float2*>(p.h1 + tc * D + cc);
+                dd[b] = *reinterpret_cast<const float2*>(p.dy + tc * D + cc);
+            }
+#pragma unroll
+            for (int b = 0; b < RB; ++b) {
+                const int row = row0 + b * NW;
+                if (row >= RT) break;           // wave-uniform
             const long t = t0 + row;
             float dxa[2] = {0.f, 0.f}, dx[2] = {0.f, 0.f};
             if (t < p.T) {      // wave-uniform
-                const float mu = p.mean[t], rs = p.rstd[t];
+                const float mu = mu_[b], rs = rs_[b];
                 float xh[2] = {0.f, 0.f}, gg[2] = {0.f, 0.f}, dyv[2] = {0.f, 0.f}, m[2] = {1.f, 1.f};
                 float s1 = 0.f, s2 = 0.f;
                 if (act_lane) {
                     drop_scale_vec<2>(p.drop_out, (unsigned long long)t * D + c0, true, m);
-                    const float2 fo = *reinterpret_cast<const float2*>(p.ffout + t * D + c0);
-                    const float2 hh = *reinterpret_cast<const float2*>(p.h1 + t * D + c0);
-                    const float2 dd = *reinterpret_cast<const float2*>(p.dy + t * D + c0);
-                    const float xv[2] = {fo.x * m[0] + hh.x, fo.y * m[1] + hh.y};
-                    dyv[0] = dd.x; dyv[1] = dd.y;
+                    const float2 fo_ = fo[b], hh_ = hh[b], dd_ = dd[b];
+                    const float xv[2] = {fo_.x * m[0] + hh_.x, fo_.y * m[1] + hh_.y};
+                    dyv[0] = dd_.x; dyv[1] = dd_.y;
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         xh[e] = (xv[e] - mu) * rs;
@@ -376,6 +392,7 @@ __global__ __launch_bounds__(D * 4) void xlnet_ff_bwd_kernel(FFBwdParams p) {
                 cut3(dxa[0], dxa[1], wd);
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint32_t*>(sh_dfo + pl * PLN + row * PH + c0) = wd[pl];
+            }
             }
         }
         dfomax_keep = dfomax;
@@ -519,16 +536,39 @@ static thread_local float* g_ff_amax[4] = {nullptr, nullptr, nullptr, nullptr};
 void t4r_xlnet_ff_amax_buffers(float* h1, float* act, float* dpre, float* dfo) {
     g_ff_amax[0] = h1; g_ff_amax[1] = act; g_ff_amax[2] = dpre; g_ff_amax[3] = dfo;
 }
-static int pick_r(long T);
-int t4r_xlnet_ff_amax_count(long T) { const int R = pick_r(T); return (int)((T + 16 * R - 1) / (16 * R)); }   // workgroups of a launch
+static int pick_r(long T) { return t4r_xlnet_pick_r(T, false); }
+int t4r_xlnet_ff_amax_count(long T) { const int R = pick_r(T); return (int)((T + 16 * R - 1) / (16 * R)); }   // workgroups of a forward launch
+int t4r_xlnet_ff_amax_count_bwd(long T) { const int R = t4r_xlnet_pick_r(T, true); return (int)((T + 16 * R - 1) / (16 * R)); }   // of a backward launch
 long t4r_xlnet_ff_amax_slots(long T) { return (T + 15) / 16; }                                                 // upper bound of it
-static int pick_r(long T) {
-    // smallest tile (fewest padded rows) whose grid still fits one residency of the 256 CUs; 5 beyond that
+// CUs the token-tile kernels of the BACKWARD pass may count on (0 = all 256).  Their default grid is ONE 512-thread workgroup
+// per CU (256 tiles of 80 rows at 20 480 tokens): with k CUs held by something else -- an RCCL ring kernel reducing the table
+// bucket under the body's backward, SURVEY 8(e) -- every such launch needs a second round of workgroups for k tiles and takes
+// twice as long (tools/occupier_curve.py: 1.38x per step at k = 8 .. 64).  With a budget below 256 the backward launches
+// take the tile that minimises rounds x rows-per-tile on that many CUs instead (48-row tiles at 240 CUs: two rounds of 0.6).
+// Set by the data-parallel wiring while a collective is in flight (distributed.GradReducer); process-wide, read per launch.
+static std::atomic<int> g_cu_budget{0};
+extern "C" void t4r_xlnet_set_cu_budget(int cus) { g_cu_budget.store(cus < 0 ? 0 : cus, std::memory_order_relaxed); }
+extern "C" int t4r_xlnet_get_cu_budget(void) { return g_cu_budget.load(std::memory_order_relaxed); }
+int t4r_xlnet_pick_r(long T, bool backward) {
     const long blocks16 = (T + 15) / 16;
-    if (blocks16 <= 256) return 1;
-    if (blocks16 <= 512) return 2;
-    if (blocks16 <= 768) return 3;
-    return 5;
+    const int budget = backward ? g_cu_budget.load(std::memory_order_relaxed) : 0;
+    if (budget <= 0 || budget >= 256) {
+        // smallest tile (fewest padded rows) whose grid still fits one residency of the 256 CUs; 5 beyond that
+        if (blocks16 <= 256) return 1;
+        if (blocks16 <= 512) return 2;
+        if (blocks16 <= 768) return 3;
+        return 5;
+    }
+    int best = 5;
+    long best_cost = -1;
+    const int cand[4] = {5, 3, 2, 1};
+    for (int i = 0; i < 4; ++i) {
+        const int R = cand[i];
+        const long tiles = (blocks16 + R - 1) / R, rounds = (tiles + budget - 1) / budget;
+        const long cost = rounds * R;
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = R; }     // ties: the larger tile (fewer weight streams)
+    }
+    return best;
 }
 
 extern "C" int t4r_xlnet_fused_supported(int D) { return D == 32 || D == 64 || D == 128; }
@@ -618,7 +658,7 @@ extern "C" int t4r_xlnet_ff_bwd(void* stream, const float* dy, const float* ffou
     T4R_CHECK_ARG(t4r_xlnet_fused_supported(D), "xlnet_ff_bwd: d_model must be 32, 64 or 128");
     T4R_CHECK_ARG(dy && ffout && h1 && mean && rstd && gamma && ffpre && planes && dh1 && dffout && dpre && part,
                   "xlnet_ff_bwd: null pointer");
-    const int R = pick_r(T);
+    const int R = t4r_xlnet_pick_r(T, true);
     const int nwg = (T + 16 * R - 1) / (16 * R);
     float* partA = part;
     float* partB = part + (long)nwg * 3 * D;

@@ -432,18 +432,33 @@ __global__ __launch_bounds__(D * 4) void xlnet_ln1_bwd_kernel(Ln1BwdParams p) {
         float gam[2], pg[2] = {0.f, 0.f}, pb[2] = {0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 2; ++e) gam[e] = act_lane ? p.gamma[c0 + e] : 0.f;
-        for (int row = w; row < RT; row += NW) {
+        // rows RB at a time, every load of the batch in flight before the first reduction (as xlnet_ff_bwd_kernel's phase A)
+        constexpr int RB = 5;
+        for (int row0 = w; row0 < RT; row0 += NW * RB) {
+            float2 fo_[RB], hh_[RB], dd_[RB];
+            float mu_[RB], rs_[RB];
+#pragma unroll
+            for (int b = 0; b < RB; ++b) {          // unconditional loads from clamped addresses
+                const long tc = min(t0 + min(row0 + b * NW, RT - 1), p.T - 1);
+                mu_[b] = p.mean[tc]; rs_[b] = p.rstd[tc];
+                const int cc = act_lane ? c0 : 0;
+                fo_[b] = *reinterpret_cast<const float2*>(p.ao + tc * D + cc);
+                hh_[b] = *reinterpret_cast<const float2*>(p.h + tc * D + cc);
+                dd_[b] = *reinterpret_cast<const float2*>(p.dy + tc * D + cc);
+            }
+#pragma unroll
+            for (int b = 0; b < RB; ++b) {
+                const int row = row0 + b * NW;
+                if (row >= RT) break;           // wave-uniform
             const long t = t0 + row;
             float dxa[2] = {0.f, 0.f};
             if (t < p.T) {      // wave-uniform
-                const float mu = p.mean[t], rs = p.rstd[t];
+                const float mu = mu_[b], rs = rs_[b];
                 float xh[2] = {0.f, 0.f}, gg[2] = {0.f, 0.f}, dyv[2] = {0.f, 0.f}, m[2] = {1.f, 1.f}, dx[2];
                 float s1 = 0.f, s2 = 0.f;
                 if (act_lane) {
                     drop_scale_vec<2>(p.drop, (unsigned long long)t * D + c0, true, m);
-                    const float2 fo = *reinterpret_cast<const float2*>(p.ao + t * D + c0);
-                    const float2 hh = *reinterpret_cast<const float2*>(p.h + t * D + c0);
-                    const float2 dd = *reinterpret_cast<const float2*>(p.dy + t * D + c0);
+                    const float2 fo = fo_[b], hh = hh_[b], dd = dd_[b];
                     const float xv[2] = {fo.x * m[0] + hh.x, fo.y * m[1] + hh.y};
                     dyv[0] = dd.x; dyv[1] = dd.y;
 #pragma unroll
@@ -485,6 +500,7 @@ __global__ __launch_bounds__(D * 4) void xlnet_ln1_bwd_kernel(Ln1BwdParams p) {
                 cut3(dxa[0], dxa[1], wd);
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint32_t*>(sh_d + pl * PLN + row * PH + c0) = wd[pl];
+            }
             }
         }
         if (act_lane) {
@@ -540,7 +556,43 @@ __global__ __launch_bounds__(D * 4) void xlnet_dh_kernel(DhParams p) {
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = zero4();
     auto inv_of = [&](int buf) { return reinterpret_cast<float*>(smem16 + buf * 3 * PLN + 2 * PLN); };
-    if constexpr (HS) tile_to_planes_h<D, RT, NT, PH>(p.dqkv, t0, p.T, smem16, inv_of(0), tid);
+    // HS: a gradient tile is REQUESTED (raw rows into registers) before the product of the tile in front of it and cut into
+    // its planes after it: the load latency of d k / d v sits under the matrix instructions of d q / d k (round 5; the
+    // one-call tile_to_planes_h in front of each product exposed it three times per launch).  Same arithmetic per element.
+    constexpr int G4 = D / 4, TIT = (RT * G4 + NT - 1) / NT;
+    float4 raw[TIT];
+    auto load_tile = [&](const float* __restrict__ src) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < TIT; ++k) {
+            const int i = tid + k * NT;
+            const bool live = i < RT * G4;
+            const int row = live ? i / G4 : RT - 1, c4 = live ? (i % G4) * 4 : 0;
+            raw[k] = ld4(src + min(t0 + row, p.T - 1) * D + c4);
+        }
+    };
+    auto store_tile = [&](uint16_t* sh, float* sh_inv) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < TIT; ++k) {
+            const int i = tid + k * NT;
+            const bool live = i < RT * G4;
+            const int row = live ? i / G4 : RT - 1, c4 = live ? (i % G4) * 4 : 0;
+            const float4 v = raw[k];
+            float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+#pragma unroll
+            for (int o = G4 / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            const float sc = pow2_scale(m);
+            if (live) {
+                uint32_t w0[2], w1[2];
+                cut2h(v.x * sc, v.y * sc, w0);
+                cut2h(v.z * sc, v.w * sc, w1);
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    *reinterpret_cast<uint2*>(sh + pl * PLN + row * PH + c4) = make_uint2(w0[pl], w1[pl]);
+                if (c4 == 0) sh_inv[row] = 1.f / sc;
+            }
+        }
+    };
+    if constexpr (HS) { load_tile(p.dqkv); store_tile(smem16, inv_of(0)); }
     else tile_to_planes<D, RT, NT, PH>(p.dqkv, t0, p.T, smem16, tid);
     __syncthreads();
 #pragma unroll
@@ -551,8 +603,7 @@ __global__ __launch_bounds__(D * 4) void xlnet_dh_kernel(DhParams p) {
             // are scaled back one by one before they are added
             AFragH<D> a;
             load_a2h<D>(a, wp + z * D, wpl);
-            if (z < 2) tile_to_planes_h<D, RT, NT, PH>(p.dqkv + (z + 1) * TD, t0, p.T, smem16 + ((z + 1) & 1) * 3 * PLN,
-                                                       inv_of((z + 1) & 1), tid);
+            if (z < 2) load_tile(p.dqkv + (z + 1) * TD);
             f32x4 part[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) part[r] = zero4();
@@ -564,6 +615,7 @@ __global__ __launch_bounds__(D * 4) void xlnet_dh_kernel(DhParams p) {
                 const float sc = inv[r * 16 + n] * iw;
                 acc[r][0] += part[r][0] * sc; acc[r][1] += part[r][1] * sc; acc[r][2] += part[r][2] * sc; acc[r][3] += part[r][3] * sc;
             }
+            if (z < 2) store_tile(smem16 + ((z + 1) & 1) * 3 * PLN, inv_of((z + 1) & 1));
         } else {
             AFrag<D> a;
             load_a3<D>(a, wp + z * D, wpl);
@@ -584,13 +636,7 @@ __global__ __launch_bounds__(D * 4) void xlnet_dh_kernel(DhParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------- host side
-static int pick_r(long T) {
-    const long blocks16 = (T + 15) / 16;
-    if (blocks16 <= 256) return 1;
-    if (blocks16 <= 512) return 2;
-    if (blocks16 <= 768) return 3;
-    return 5;
-}
+static int pick_r(long T) { return t4r_xlnet_pick_r(T, false); }
 
 #define ATTN_DISPATCH(CALL, D, R)                                                              \
     switch ((D) * 8 + (R)) {                                                                   \
@@ -764,7 +810,7 @@ extern "C" int t4r_xlnet_ln1_bwd(void* stream, const float* dy, const float* ao,
     if (T <= 0) return 0;
     T4R_CHECK_ARG(t4r_xlnet_fused_supported(D) && dy && ao && h && mean && rstd && gamma && planes && dh && dao && dav && part,
                   "xlnet_ln1_bwd: bad arguments");
-    const int R = pick_r(T);
+    const int R = t4r_xlnet_pick_r(T, true);
     const int nwg = (int)((T + 16 * R - 1) / (16 * R));
     const bool hs = t4r_xlnet_body_fp16x2();
     const LayerPlanesH PH_ = carve_planes_h(planes, D);
@@ -792,7 +838,7 @@ extern "C" int t4r_xlnet_ln1_bwd(void* stream, const float* dy, const float* ao,
 extern "C" int t4r_xlnet_dh(void* stream, const float* dqkv, const float* planes, float* dh, long T, int D) {
     if (T <= 0) return 0;
     T4R_CHECK_ARG(t4r_xlnet_fused_supported(D) && dqkv && planes && dh, "xlnet_dh: bad arguments");
-    const int R = pick_r(T);
+    const int R = t4r_xlnet_pick_r(T, true);
     const bool hs = t4r_xlnet_body_fp16x2();
     const LayerPlanesH PH_ = carve_planes_h(planes, D);
     DhParams p{dqkv, hs ? PH_.QKVN : carve_planes(planes, D).QKVN, PH_.scale + HS_Q, dh, T};

@@ -35,6 +35,8 @@ void t4r_reduce_redirect(hipStream_t side, hipEvent_t* events, int n_events);   
 void t4r_gemm_operand_amax(const float* a, const float* b, int n);               // gemm_f32.hip: next launch in the fp16 split form
 void t4r_xlnet_ff_amax_buffers(float* h1, float* act, float* dpre, float* dfo);  // xlnet_fused.hip
 int t4r_xlnet_ff_amax_count(long T);
+int t4r_xlnet_ff_amax_count_bwd(long T);
+void t4r_gemm_operand_amax2(const float* a, int na, const float* b, int nb);   // gemm_f32.hip: the two producers ran different grids
 long t4r_xlnet_ff_amax_slots(long T);
 bool t4r_xlnet_body_fp16x2();
 void t4r_splitk_sink_begin(float* ws, long cap_floats);                          // gemm_f32.hip: deterministic split-K
@@ -463,7 +465,9 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
         // one launch: LayerNorm backward -> d ffout -> FF2 dX -> GELU' / dropout -> FF1 dX + residual (+ the partial
         // sums of d gamma, d beta, d b2, d b1, reduced by two small launches on the weight-gradient stream)
         const long ns = t4r_xlnet_ff_amax_slots(T);
-        const int na = t4r_xlnet_ff_amax_count(T);
+        // workgroups (= maxima slots) of the forward launches and of this backward launch: the backward's tile follows the CU
+        // budget (t4r_xlnet_set_cu_budget: a collective may hold CUs now), the forward's never does
+        const int na = t4r_xlnet_ff_amax_count(T), nb = t4r_xlnet_ff_amax_count_bwd(T);
         float* am = w.amax;          // max |h1|, max |act| (forward), max |d pre|, max |d ffout| (now): one float per workgroup
         t4r_xlnet_ff_amax_buffers(nullptr, nullptr, am + 2 * ns, am + 3 * ns);
         {
@@ -475,12 +479,12 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
         }
         // the two weight gradients in the two-way fp16 form, positioned by the operand maxima the fused kernels left
         const bool hs = t4r_xlnet_body_fp16x2() && drop_p >= 0.f;
-        if (hs) t4r_gemm_operand_amax(am + 3 * ns, am + ns, na);
+        if (hs) t4r_gemm_operand_amax2(am + 3 * ns, nb, am + ns, na);
         RUN(t4r_gemm_launch(wg(), 1, 0, D, 4 * D, T, 1.f, dfo, D, w.ffact, 4 * D, grads[P_W2], 4 * D, nullptr,
                             EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
         {
             hipStream_t s1 = wg_again();
-            if (hs) t4r_gemm_operand_amax(am + 2 * ns, am, na);
+            if (hs) t4r_gemm_operand_amax2(am + 2 * ns, nb, am, na);
             RUN(t4r_gemm_launch(s1, 1, 0, 4 * D, D, T, 1.f, dff, 4 * D, w.h1, D, grads[P_W1], D, nullptr,
                                 EPI_NONE, nullptr, 0, -1, 1, 1, 0, 0, 0, nullptr));
             // first reduction launch of the call: W2, W1 and the bias / LayerNorm-2 sums of the feed-forward half

@@ -121,6 +121,18 @@ class SparseRowExchange:
             self.apply_fn(tgt, ids_all, rows_all, pad)
 
 
+def collective_channels():
+    """CUs an RCCL kernel of this process may hold while it runs: one workgroup per channel.  RCCL sizes its channel count from
+    the topology unless NCCL_MAX_NCHANNELS caps it; `bench.py` sets the cap (default 16) before the process group exists, so
+    that the number is known here.  Unknown (no cap in the environment): 32 is assumed."""
+    import os
+
+    try:
+        return max(1, int(os.environ.get("NCCL_MAX_NCHANNELS", "32")))
+    except ValueError:
+        return 32
+
+
 class GradReducer:
     def __init__(self, dense_grad, tables_grad=None, group=None, sparse: SparseRowExchange = None):
         self.dense, self.tables, self.group, self.sparse = dense_grad, tables_grad, group, sparse
@@ -128,6 +140,7 @@ class GradReducer:
         self._stream = None
         self._pending = None
         self._launched = False
+        self._budgeted = False
 
     @property
     def grad_scale(self):
@@ -149,12 +162,24 @@ class GradReducer:
                 self._stream.wait_stream(side)
             with torch.cuda.stream(self._stream):
                 self._pending = dist.all_reduce(self.tables, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            # the ring kernel now holds one CU per channel until the reduction is done, i.e. for most of the body's backward:
+            # its one-workgroup-per-CU token-tile kernels are told to plan for the CUs that are left (csrc/xlnet_fused.hip:
+            # t4r_xlnet_set_cu_budget; measured on one GPU with a CU occupier, tools/occupier_curve.py: 1.38x -> see DESIGN 7)
+            from . import ops
+
+            ops.xlnet_set_cu_budget(256 - collective_channels())
+            self._budgeted = True
         else:
             self._pending = dist.all_reduce(self.tables, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def reduce_all(self, tables_already_launched=None):
         launched = self._launched if tables_already_launched is None else tables_already_launched
         self._launched = False
+        if self._budgeted:          # the backward pass is over: the forward's kernels get the whole chip again
+            from . import ops
+
+            ops.xlnet_set_cu_budget(0)
+            self._budgeted = False
         if self.world > 1:
             if self.tables is not None and not launched:
                 dist.all_reduce(self.tables, op=dist.ReduceOp.SUM, group=self.group)

@@ -6,9 +6,10 @@ parameter gradient flows through autograd as an operator output, so
   * `make_fx` of the whole step (forward + backward) yields a graph of `t4r_hip::*` nodes that replays to the same numbers
     (the reference pins traced == eager for its modules: tests/unit/torch/model/test_model.py:58-91).
 
-Scope: BASELINE configs[0] / [1] -- item-id sequence, XLNet body, MLM, tied full softmax (the path the benchmark runs).
-The arithmetic is the module mirror's (same kernels through ops.py); the head takes the general contraction kernels
-(gemm + softmax-CE + softmax-gradient operand), not head_split.hip's workspace form.
+Scope: BASELINE configs[0] / [1] -- item-id sequence, XLNet body, MLM, tied full softmax, dropout as XLNetConfig.build
+sets it (0.3): the configuration the benchmark runs, every dropout site included (round 5).  The arithmetic is the module
+mirror's (same kernels through ops.py, same Philox keys): at a head_split.hip shape the head is the one-pass operator
+(`t4r_hip::next_item_head`: logits + CE + d X from one launch), elsewhere the general contraction kernels.
 
     params = functional.parameters_of(model)            # name -> nn.Parameter, shared with the model
     loss, n_labels = functional.mlm_step(params, cfg_of(model), ids, rng)
@@ -36,26 +37,51 @@ def config_of(model):
                 label_smoothing=float(getattr(model.prediction_task.loss, "label_smoothing", 0.0) or 0.0))
 
 
+def _head_split_form(rows, table, N):
+    """the shapes the module mirror sends to csrc/head_split.hip's one-pass head (prediction_task._head_split_ok)"""
+    from .prediction_task import _head_split_ok
+
+    V, D = table.shape
+    return ops.head_split_fdx_supported(D) and _head_split_ok(rows, table, N, V)
+
+
 def mlm_step(table: torch.Tensor, masked_emb: torch.Tensor, layers, cfg: Dict, ids: torch.Tensor, mask_seed: int, mask_offset: int,
              drop_seed: int = 0, drop_offset: int = 0, training: bool = True, n_labels: int = None):
     """-> (loss, label rows).  table [V, D] (tied), masked_emb [D], layers: per layer the 15 tensors in
-    ops.XLNET_PARAM_ORDER.  dropout > 0 is not wired here (the model-level input / final sites and the per-session
-    positional dropout live in transformer.XLNetModel): pass a model built with dropout 0 or cfg['dropout'] = 0.
+    ops.XLNET_PARAM_ORDER.  cfg['dropout'] > 0 (training): every dropout site of HF XLNetModel as the module mirror places
+    them (transformer.XLNetModel.forward) -- inputs_embeds, the per-session positional encodings (drawn once, shared by the
+    layers), the in-layer sites, the output -- with Philox keys (drop_seed, drop_offset): the SAME masks as the module mirror
+    draws for (seed, _drop_offset), so the two paths agree mask for mask.
     n_labels: the number of label rows when the caller already knows it (a traced step: the count shapes the head's
-    operands, so a trace is specialised to it; None reads it from the device, the step's one host read)."""
-    if cfg.get("dropout", 0.0) > 0 and training:
-        raise NotImplementedError("functional.mlm_step: dropout sites of XLNetModel are not part of the functional path yet")
+    operands, so a trace is specialised to it; None reads it from the device, the step's one host read).
+    training=False: the evaluation protocol (last item of every session masked, masking.py:461-465), no dropout."""
     B, L = ids.shape
     D = table.shape[1]
-    mask, labels, pos, lab, n = T4R.mlm_targets(ids, cfg["mlm_probability"], mask_seed, mask_offset, cfg["padding_idx"])
+    p = float(cfg.get("dropout", 0.0)) if training else 0.0
+    if training:
+        mask, labels, pos, lab, n = T4R.mlm_targets(ids, cfg["mlm_probability"], mask_seed, mask_offset, cfg["padding_idx"])
+    else:
+        mask, labels, counts = ops.mask_targets(ids.contiguous(), ops.MLM_EVAL_LAST, cfg["padding_idx"])
+        n, pos, lab = ops.compact_labels(labels, counts, cfg["padding_idx"])
+    table._t4r_padding_idx = int(cfg["padding_idx"])          # read by the gather's backward operator (table scatter)
     x = T4R.seq_item_embedding(ids, table, mask, masked_emb, ops.MASK_MLM)
+    pe = relative_positional_encoding(L, D).to(x.device).contiguous()
+    pos_b = None
+    if p > 0:
+        x = T4R.dropout(x, p, drop_seed, ops.dropout_ctr_hi(drop_offset, 255, ops.SITE_INPUT))
+        pos_b = T4R.pos_emb_dropout(pe, B, p, drop_seed, drop_offset)
     h = x.view(B * L, D)
-    pe = relative_positional_encoding(L, D).to(h.device).contiguous()
-    for li, p in enumerate(layers):
-        h, _ws = T4R.xlnet_layer_fwd(h, pe, list(p), B, L, cfg["n_head"], cfg["eps"], 0.0, drop_seed, drop_offset, li)
+    for li, prm in enumerate(layers):
+        h, _ws = T4R.xlnet_layer_fwd(h, pe, list(prm), B, L, cfg["n_head"], cfg["eps"], p, drop_seed, drop_offset, li, pos_b)
+    if p > 0:
+        h = T4R.dropout(h, p, drop_seed, ops.dropout_ctr_hi(drop_offset, 255, ops.SITE_FINAL))
     N = int(n.item()) if n_labels is None else int(n_labels)      # the one host read of the step (the module mirror reads it the same way)
     rows = T4R.gather_label_rows(h, pos, N)
-    loss, _logits, _lse = T4R.linear_softmax_ce(rows, table, lab[:N].contiguous(), 1.0 / cfg["temperature"], cfg["label_smoothing"])
+    y = lab[:N].contiguous()
+    if _head_split_form(rows, table, N):
+        loss = T4R.next_item_head(rows, table, y, 1.0 / cfg["temperature"], cfg["label_smoothing"])[0]
+    else:
+        loss = T4R.linear_softmax_ce(rows, table, y, 1.0 / cfg["temperature"], cfg["label_smoothing"])[0]
     return loss, N
 
 
@@ -64,7 +90,8 @@ class FunctionalMLMModel(torch.nn.Module):
     relies on autograd hooks) can wrap -- `DistributedDataParallel(FunctionalMLMModel(model))` reduces every gradient through
     its bucket hooks, where the module mirror's flat-buffer backward (and the drop-in built on it) must exchange gradients
     itself.  Parameters are shared with `model` (no copy), so optimizers / checkpoints of `model` keep working.
-    forward(ids) -> {"loss", "n_labels"}; device draws of the MLM mask advance as in the module mirror."""
+    forward(ids) -> {"loss", "n_labels"}; the device draws of the MLM mask and of the dropout masks advance exactly as in
+    the module mirror (same seeds, same counters: a step here and a step there draw the same masks)."""
 
     def __init__(self, model):
         super().__init__()
@@ -73,11 +100,17 @@ class FunctionalMLMModel(torch.nn.Module):
         self.table = model.input_features.item_embedding_table.weight
         self.masked_emb = m.masked_item_embedding
         self.layers = torch.nn.ModuleList([torch.nn.ParameterList(p) for p in layer_params(model)])
-        self._masking = [m]           # not a sub-module: only its seed / offset are read and advanced
+        self._masking = [m]           # not sub-modules: only their seeds / counters are read and advanced
+        self._transformer = [model.transformer_block.transformer]
 
     def forward(self, ids):
-        m = self._masking[0]
+        m, t = self._masking[0], self._transformer[0]
+        drop_offset = 0
+        if self.training and self.cfg["dropout"] > 0:
+            t._drop_offset += 1
+            drop_offset = t._drop_offset
         loss, n = mlm_step(self.table, self.masked_emb, [list(p) for p in self.layers], self.cfg, ids, m.seed, m._rng_offset,
-                           training=self.training)
-        m._rng_offset += ids.numel()
+                           drop_seed=t.seed, drop_offset=drop_offset, training=self.training)
+        if self.training:
+            m._rng_offset += ids.numel()
         return {"loss": loss, "n_labels": n}

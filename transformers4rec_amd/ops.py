@@ -155,14 +155,16 @@ def head_split_prepare(x, V):
     nbytes = _lib.load().t4r_head_split_ws_bytes(N, int(V), D)
     ws = torch.empty(max(nbytes, 16), device=x.device, dtype=torch.uint8)
     call("t4r_head_split_prepare", _stream(), _chk(x, torch.float32), x.stride(0), N, D, int(V), ws.data_ptr())
-    # the host note the forward product leaves for d X / d W (include/t4r_hip.h: t4r_head_note) lives and dies with the workspace
-    ws.t4r_note = (ctypes.c_ulonglong * 8)()
+    # the host note the forward product leaves for d X / d W (include/t4r_hip.h: t4r_head_note, 64 bytes) lives and dies with
+    # the workspace: a CPU int64[8] tensor, so that it can also travel through the dispatcher as an operator output
+    # (torch_ops.next_item_head) and be re-attached to the workspace tensor its backward operator receives
+    ws.t4r_note = torch.zeros(8, dtype=torch.int64)
     return ws
 
 
 def _note(ws):
     n = getattr(ws, "t4r_note", None)
-    return None if n is None else ctypes.addressof(n)
+    return None if n is None else n.data_ptr()
 
 
 def head_split_dw_form(ws):
@@ -817,6 +819,15 @@ def xlnet_dh_(dqkv, planes, dh):
     _, T, D = dqkv.shape
     call("t4r_xlnet_dh", _stream(), _chk(dqkv, torch.float32), planes.data_ptr(), _chk(dh, torch.float32), T, D)
     return dh
+
+
+def xlnet_set_cu_budget(cus):
+    """CUs the backward pass's token-tile kernels may count on (0 = all): set while a collective holds CUs (distributed.py)"""
+    _lib.load().t4r_xlnet_set_cu_budget(int(cus))
+
+
+def xlnet_get_cu_budget():
+    return int(_lib.load().t4r_xlnet_get_cu_budget())
 
 
 def xlnet_attn_block_supported(L, D, n_head):

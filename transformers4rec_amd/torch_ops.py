@@ -141,15 +141,18 @@ def _(h, pos_emb, params, B, L, n_head, eps, key_len):
 
 @torch.library.custom_op(f"{NS}::xlnet_layer_fwd", mutates_args=())
 def xlnet_layer_fwd(h: torch.Tensor, pos_emb: torch.Tensor, params: Sequence[torch.Tensor], B: int, L: int, n_head: int,
-                    eps: float, drop_p: float, seed: int, offset: int, layer_idx: int) -> Tuple[torch.Tensor, torch.Tensor]:
-    """training form: -> (out [B*L, D], workspace of saved activations for xlnet_layer_bwd)"""
+                    eps: float, drop_p: float, seed: int, offset: int, layer_idx: int,
+                    pos_emb_b: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+    """training form: -> (out [B*L, D], workspace of saved activations for xlnet_layer_bwd).  drop_p > 0: every dropout site
+    of the layer (HF modeling_xlnet.py :132, :147, :301, :303) with Philox keys (seed, offset, layer_idx); pos_emb_b = the
+    per-session dropped positional encodings of this forward (t4r_hip::pos_emb_dropout, HF :1143)"""
     out, ws = ops.xlnet_layer_fwd(h.contiguous(), pos_emb, [p.detach().contiguous() for p in params], B, L, n_head, eps,
-                                  drop_p=drop_p, seed=seed, offset=offset, layer_idx=layer_idx)
+                                  drop_p=drop_p, seed=seed, offset=offset, layer_idx=layer_idx, pos_emb_b=pos_emb_b)
     return out, ws
 
 
 @xlnet_layer_fwd.register_fake
-def _(h, pos_emb, params, B, L, n_head, eps, drop_p, seed, offset, layer_idx):
+def _(h, pos_emb, params, B, L, n_head, eps, drop_p, seed, offset, layer_idx, pos_emb_b):
     D = h.shape[1]
     # the workspace size is a host-side query of the library (no device work): valid under fake tensors too
     n = _lib_floats("t4r_xlnet_layer_ws_floats", B, L, D, n_head, 1 if drop_p > 0 else 0)
@@ -229,11 +232,12 @@ def _seq_item_setup(ctx, inputs, output):
     ids, table, mask, masked_emb, mask_mode = inputs
     ctx.save_for_backward(ids, mask)
     ctx.rows, ctx.mask_mode = table.shape[0], mask_mode
+    ctx.padding_idx = getattr(table, "_t4r_padding_idx", 0)
 
 
 def _seq_item_backward(ctx, dy):
     ids, mask = ctx.saved_tensors
-    d_table, d_memb = torch.ops.t4r_hip.seq_item_embedding_bwd(dy, ids, mask, ctx.rows, ctx.mask_mode, 0)
+    d_table, d_memb = torch.ops.t4r_hip.seq_item_embedding_bwd(dy, ids, mask, ctx.rows, ctx.mask_mode, ctx.padding_idx)
     return None, d_table, None, d_memb, None
 
 
@@ -243,30 +247,32 @@ seq_item_embedding.register_autograd(_seq_item_backward, setup_context=_seq_item
 @torch.library.custom_op(f"{NS}::xlnet_layer_grad", mutates_args=())
 def xlnet_layer_grad(h: torch.Tensor, pos_emb: torch.Tensor, params: Sequence[torch.Tensor], ws: torch.Tensor, dh_out: torch.Tensor,
                      B: int, L: int, n_head: int, eps: float, drop_p: float, seed: int, offset: int,
-                     layer_idx: int) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+                     layer_idx: int, pos_emb_b: Optional[torch.Tensor]) -> Tuple[torch.Tensor, List[torch.Tensor]]:
     """functional backward of xlnet_layer_fwd: -> (d loss / d h, the 15 parameter gradients in ops.XLNET_PARAM_ORDER)"""
     ps = [q.detach().contiguous() for q in params]
     grads = [torch.zeros_like(q) for q in ps]
     dh = ops.xlnet_layer_bwd(h.contiguous(), pos_emb, ps, grads, ws, dh_out.contiguous(), B, L, n_head, eps, drop_p=drop_p,
-                             seed=seed, offset=offset, layer_idx=layer_idx)
+                             seed=seed, offset=offset, layer_idx=layer_idx, pos_emb_b=pos_emb_b)
     return dh, grads
 
 
 @xlnet_layer_grad.register_fake
-def _(h, pos_emb, params, ws, dh_out, B, L, n_head, eps, drop_p, seed, offset, layer_idx):
+def _(h, pos_emb, params, ws, dh_out, B, L, n_head, eps, drop_p, seed, offset, layer_idx, pos_emb_b):
     return h.new_empty(h.shape), [q.new_empty(q.shape) for q in params]
 
 
 def _xl_setup(ctx, inputs, output):
-    h, pos_emb, params, B, L, n_head, eps, drop_p, seed, offset, layer_idx = inputs
-    ctx.save_for_backward(h, pos_emb, output[1], *params)
+    h, pos_emb, params, B, L, n_head, eps, drop_p, seed, offset, layer_idx, pos_emb_b = inputs
+    ctx.has_pb = pos_emb_b is not None
+    ctx.save_for_backward(h, pos_emb, output[1], *(([pos_emb_b] if ctx.has_pb else []) + list(params)))
     ctx.cfg = (B, L, n_head, eps, drop_p, seed, offset, layer_idx)
 
 
 def _xl_backward(ctx, dout, _dws):
-    h, pos_emb, ws, *params = ctx.saved_tensors
-    dh, grads = torch.ops.t4r_hip.xlnet_layer_grad(h, pos_emb, list(params), ws, dout, *ctx.cfg)
-    return (dh, None, list(grads)) + (None,) * 8
+    h, pos_emb, ws, *rest = ctx.saved_tensors
+    pos_emb_b = rest.pop(0) if ctx.has_pb else None
+    dh, grads = torch.ops.t4r_hip.xlnet_layer_grad(h, pos_emb, list(rest), ws, dout, *ctx.cfg, pos_emb_b)
+    return (dh, None, list(grads)) + (None,) * 9
 
 
 xlnet_layer_fwd.register_autograd(_xl_backward, setup_context=_xl_setup)
@@ -356,7 +362,97 @@ def _lsc_backward(ctx, dloss, _dlogits, _dlse):
 linear_softmax_ce.register_autograd(_lsc_backward, setup_context=_lsc_setup)
 
 
+# ---- model-level dropout sites (HF XLNetModel: inputs_embeds :1116, pos_emb :1143, output :1177) -- round 5: the functional
+# path runs the BENCHMARKED configuration (dropout 0.3), not only dropout 0
+@torch.library.custom_op(f"{NS}::dropout", mutates_args=())
+def dropout(x: torch.Tensor, p: float, seed: int, ctr_hi: int) -> torch.Tensor:
+    """x * mask / (1 - p) with the Philox mask keyed (seed, ctr_hi), element index = position in x (t4r_dropout)"""
+    return ops.dropout(x.contiguous().view(-1), p, seed, ctr_hi).view(x.shape)
+
+
+@dropout.register_fake
+def _(x, p, seed, ctr_hi):
+    return x.new_empty(x.shape)
+
+
+def _drop_setup(ctx, inputs, output):
+    ctx.cfg = inputs[1:]
+
+
+dropout.register_autograd(lambda ctx, dy: (torch.ops.t4r_hip.dropout(dy, *ctx.cfg), None, None, None), setup_context=_drop_setup)
+
+
+@torch.library.custom_op(f"{NS}::pos_emb_dropout", mutates_args=())
+def pos_emb_dropout(pos_emb: torch.Tensor, B: int, p: float, seed: int, offset: int) -> torch.Tensor:
+    """dropout(pos_emb expanded over the batch) [B * 2L * D], drawn once per forward and shared by the layers (HF :1143)"""
+    return ops.xlnet_pos_emb_dropout(pos_emb, B, p, seed, offset)
+
+
+@pos_emb_dropout.register_fake
+def _(pos_emb, B, p, seed, offset):
+    return pos_emb.new_empty((B * pos_emb.numel(),))
+
+
+# ---- the next-item head in csrc/head_split.hip's form (d_model <= 128): ONE pass gives logits, loss, lse and d x for an
+# upstream gradient of 1 (round 5: head_fwd_dx_kernel); its backward operator multiplies and runs d W from the workspace
+@torch.library.custom_op(f"{NS}::next_item_head", mutates_args=())
+def next_item_head(x: torch.Tensor, weight: torch.Tensor, labels: torch.Tensor, alpha: float,
+                   label_smoothing: float) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """-> (loss, logits [N, V], lse [N], dx_unit [N, D], workspace, note [8] int64 on the host): prediction_task.py:648-671 + :446"""
+    V = weight.shape[0]
+    xc = x.contiguous()
+    ws = ops.head_split_prepare(xc, V)
+    logits, loss, _rows, lse, dx_unit = ops.head_split_logits_ce_dx(ws, xc, weight.detach(), labels, alpha=alpha,
+                                                                   label_smoothing=label_smoothing, ldc=ops.pad_ld(V))
+    note = ws.t4r_note
+    return loss, logits, lse, dx_unit, ws, note
+
+
+@next_item_head.register_fake
+def _(x, weight, labels, alpha, label_smoothing):
+    V = weight.shape[0]
+    n = max(16, _lib_floats("t4r_head_split_ws_bytes", x.shape[0], V, x.shape[1]))
+    return (x.new_empty(()), x.new_empty((x.shape[0], ops.pad_ld(V)))[:, :V], x.new_empty((x.shape[0],)), x.new_empty(x.shape),
+            x.new_empty((n,), dtype=torch.uint8), torch.empty(8, dtype=torch.int64))
+
+
+@torch.library.custom_op(f"{NS}::next_item_head_bwd", mutates_args=())
+def next_item_head_bwd(weight: torch.Tensor, labels: torch.Tensor, logits: torch.Tensor, lse: torch.Tensor, dx_unit: torch.Tensor,
+                       ws: torch.Tensor, note: torch.Tensor, dloss: torch.Tensor, alpha: float,
+                       label_smoothing: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """-> (d x [N, D], d weight [V, D]): d x = dx_unit * dloss; d W reads the logits once (head_dw_split_kernel)"""
+    V, D = weight.shape
+    g = dloss.contiguous()
+    ws.t4r_note = note                       # the forward's note (which table / logits the workspace words describe)
+    dW = torch.zeros_like(weight)
+    ops.head_split_dw(ws, logits, lse, labels, g, V, D, dW, alpha=alpha, label_smoothing=label_smoothing, accumulate=True)
+    return dx_unit * g, dW
+
+
+@next_item_head_bwd.register_fake
+def _(weight, labels, logits, lse, dx_unit, ws, note, dloss, alpha, label_smoothing):
+    return dx_unit.new_empty(dx_unit.shape), weight.new_empty(weight.shape)
+
+
+def _nih_setup(ctx, inputs, output):
+    x, weight, labels, alpha, smooth = inputs
+    ctx.save_for_backward(weight, labels, output[1], output[2], output[3], output[4], output[5])
+    ctx.cfg = (alpha, smooth)
+    ctx.set_materialize_grads(False)
+
+
+def _nih_backward(ctx, dloss, *_unused):
+    if dloss is None:
+        return None, None, None, None, None
+    weight, labels, logits, lse, dx_unit, ws, note = ctx.saved_tensors
+    dx, dW = torch.ops.t4r_hip.next_item_head_bwd(weight, labels, logits, lse, dx_unit, ws, note, dloss, *ctx.cfg)
+    return dx, dW, None, None, None
+
+
+next_item_head.register_autograd(_nih_backward, setup_context=_nih_setup)
+
+
 OPERATORS = ("gemm", "item_scores", "topk", "rank_of_target", "embedding_gather", "embedding_bag", "ragged_to_padded",
              "xlnet_layer_infer", "xlnet_layer_fwd", "xlnet_layer_bwd", "mlm_targets", "seq_item_embedding",
              "seq_item_embedding_bwd", "xlnet_layer_grad", "gather_label_rows", "scatter_label_rows", "linear_softmax_ce",
-             "linear_softmax_ce_bwd")
+             "linear_softmax_ce_bwd", "dropout", "pos_emb_dropout", "next_item_head", "next_item_head_bwd")

@@ -1281,7 +1281,10 @@ __global__ __launch_bounds__(256) void head_fwd_dx_kernel(const float* __restric
             z = mfma_split<true>(a, Xf[s], z);
         }
         // the next tile into LDS before the logits are stored (its loads were issued at the top): the wait for them must not
-        // cover the HBM stores below, and the staging registers die here
+        // cover the HBM stores below, and the staging registers die here.  (Measured, round 5: moving this to the END of the
+        // step -- a whole step of latency cover, made exact by unconditional clamped-row stores and a peeled vocabulary tail:
+        // s_waitcnt vmcnt(4) in the ISA -- costs 39 more VGPRs (252) and is 0.5 % SLOWER per step, 712 vs 700 us on one box:
+        // the kernel is not waiting on these loads; its time is matrix + vector + LDS issue, which add up on this chip.)
         s_store(buf ^ 1);
         __builtin_amdgcn_sched_barrier(0);
         float v[16];

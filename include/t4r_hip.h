@@ -130,7 +130,9 @@ int t4r_soft_embedding_fwd(void* stream, const float* x, const float* proj_w, co
 int t4r_soft_embedding_bwd(void* stream, const float* dout, const float* x, const float* proj_w,
                            const float* proj_b, const float* table, const float* ln_w,
                            float* d_proj_w, float* d_proj_b, float* d_table, float* d_ln_w,
-                           float* d_ln_b, long ntok, int W, int col, int K, int D, float eps);
+                           float* d_ln_b, long ntok, int W, int col, int K, int D, float eps,
+                           float* ws /* t4r_soft_embedding_bwd_ws_floats floats: per-workgroup partial sums, added in a fixed order (no atomics) */);
+long t4r_soft_embedding_bwd_ws_floats(long ntok, int K, int D);
 
 /* ----------------------------------------------------------------------------------------
  * a11,a12  masking schema + labels (integer, bit-exact)

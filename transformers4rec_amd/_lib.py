@@ -36,7 +36,8 @@ _SIGS = {
     "t4r_apply_mask_bwd_ws_floats": ("l", "iii"),
     "t4r_mul": ("i", "ppppl"),
     "t4r_soft_embedding_fwd": ("i", "pppppppp" + "liif"),
-    "t4r_soft_embedding_bwd": ("i", "pppppppppppp" + "liiiif"),
+    "t4r_soft_embedding_bwd": ("i", "pppppppppppp" + "liiiif" + "p"),
+    "t4r_soft_embedding_bwd_ws_floats": ("l", "lii"),
     "t4r_mask_targets": ("i", "ppiiil" + "ppp" + "fQQ" + "ppp"),
     "t4r_compact_labels": ("i", "pppiil" + "pppp"),
     "t4r_gather_rows": ("i", "ppppii"),

@@ -569,32 +569,47 @@ extern "C" int t4r_soft_embedding_fwd(void* stream, const float* x, const float*
 }
 
 // SoftEmbedding + LayerNorm backward.  dy = d out [tok, W] (columns col..col+D):
-//   d g, d b, d T, d pw, d pb   (x has no gradient).  One thread per token; every parameter
-// gradient is reduced over the wave with shuffles (all 64 lanes target the SAME address: LDS
-// atomics serialised 64-fold there, 228 us per feature at C3), combined per block in LDS, then one
-// global atomic per parameter per block.
+//   d g, d b, d T, d pw, d pb   (x has no gradient).  One thread per token.  Every parameter gradient is a sum over ALL
+// tokens of a per-token term: K D + 2 K + 2 D sums (116 at the defaults K = 10, D = 8).  Round 5: each sum is reduced
+//   * over the wave with DPP row shifts + v_readlane (the shuffle-based wave_sum is a chain of six ds_bpermute round
+//     trips per sum: 58 us per launch at C3, the kernel was nothing but that chain),
+//   * over the four waves of the workgroup through one LDS slot per wave, added in wave order,
+//   * over the workgroups by per-workgroup partial rows + t4r_reduce_partials_launch in block order
+// -- no atomics anywhere: the soft-embedding gradients are bit-reproducible like every other gradient of the path.
+__device__ __forceinline__ float wave_total_dpp(float v) {
+    // after the four row shifts lane 15 of every row of 16 holds its row's sum (lanes without a source add 0)
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xf, false));
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 15));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 47));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    return (r0 + r1) + (r2 + r3);
+}
+
 template <int KMAX, int DMAX>
 __global__ __launch_bounds__(256) void soft_embedding_bwd_kernel(
     const float* __restrict__ dout, const float* __restrict__ x, const float* __restrict__ pw,
     const float* __restrict__ pb, const float* __restrict__ table, const float* __restrict__ lnw,
-    float* __restrict__ d_pw, float* __restrict__ d_pb, float* __restrict__ d_table,
-    float* __restrict__ d_lnw, float* __restrict__ d_lnb, long ntok, int W, int col, int K, int D,
+    float* __restrict__ partA, float* __restrict__ partB, long ntok, int W, int col, int K, int D,
     float eps) {
-    __shared__ float red[KMAX * DMAX + 2 * KMAX + 2 * DMAX];
-    const int nred = K * D + 2 * K + 2 * D;
-    for (int i = threadIdx.x; i < nred; i += 256) red[i] = 0.f;
-    __syncthreads();
-    float* r_tab = red;             // [K*D]
-    float* r_pw = red + K * D;      // [K]
-    float* r_pb = r_pw + K;         // [K]
-    float* r_g = r_pb + K;          // [D]
-    float* r_b = r_g + D;           // [D]
+    // per-wave slots: [4][K D | K | K | D | D]
+    __shared__ float red[4][KMAX * DMAX + 2 * KMAX + 2 * DMAX];
+    const int nA = K * D + 2 * K, nB = 2 * D;
+    const int wv = threadIdx.x >> 6;
+    float* r_tab = red[wv];             // [K*D]
+    float* r_pw = r_tab + K * D;        // [K]
+    float* r_pb = r_pw + K;             // [K]
+    float* r_g = r_pb + K;              // [D]
+    float* r_b = r_g + D;               // [D]
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = t < ntok;
     const int lane = threadIdx.x & 63;
-    auto wadd = [&](float* dst, float v) {          // wave sum -> one LDS atomic
-        v = wave_sum(live ? v : 0.f);
-        if (lane == 0 && v != 0.f) atomicAdd(dst, v);
+    auto wput = [&](float* dst, float v) {          // this wave's sum -> its slot (every slot is written exactly once)
+        v = wave_total_dpp(live ? v : 0.f);
+        if (lane == 0) *dst = v;
     };
     {
         const float xv = live ? x[t] : 0.f;
@@ -632,8 +647,8 @@ __global__ __launch_bounds__(256) void soft_embedding_bwd_kernel(
                 const float xh = (e[d] - mu) * rs;
                 const float g = dy[d] * lnw[d];
                 s1 += g; s2 += g * xh;
-                wadd(&r_g[d], dy[d] * xh);
-                wadd(&r_b[d], dy[d]);
+                wput(&r_g[d], dy[d] * xh);
+                wput(&r_b[d], dy[d]);
             }
             s1 /= D; s2 /= D;
 #pragma unroll
@@ -643,7 +658,10 @@ __global__ __launch_bounds__(256) void soft_embedding_bwd_kernel(
             }
         } else {
 #pragma unroll
-            for (int d = 0; d < DMAX; ++d) de[d] = d < D ? dy[d] : 0.f;
+            for (int d = 0; d < DMAX; ++d) {
+                de[d] = d < D ? dy[d] : 0.f;
+                if (d < D && lane == 0) { r_g[d] = 0.f; r_b[d] = 0.f; }
+            }
         }
         // e = sum_k w_k T_k :  dT_k += w_k de ; dw_k = de . T_k ; ds = w * (dw - sum_j w_j dw_j)
         float dw[KMAX];
@@ -655,7 +673,7 @@ __global__ __launch_bounds__(256) void soft_embedding_bwd_kernel(
 #pragma unroll
                 for (int d = 0; d < DMAX; ++d) if (d < D) {
                     a += de[d] * table[k * D + d];
-                    wadd(&r_tab[k * D + d], w[k] * de[d]);
+                    wput(&r_tab[k * D + d], w[k] * de[d]);
                 }
             }
             dw[k] = a;
@@ -664,43 +682,52 @@ __global__ __launch_bounds__(256) void soft_embedding_bwd_kernel(
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) if (k < K) {
             const float ds = w[k] * (dw[k] - dot);
-            wadd(&r_pw[k], ds * xv);
-            wadd(&r_pb[k], ds);
+            wput(&r_pw[k], ds * xv);
+            wput(&r_pb[k], ds);
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < K * D; i += 256) atomicAdd(d_table + i, r_tab[i]);
-    for (int i = threadIdx.x; i < K; i += 256) {
-        atomicAdd(d_pw + i, r_pw[i]);
-        atomicAdd(d_pb + i, r_pb[i]);
-    }
-    if (lnw)
-        for (int i = threadIdx.x; i < D; i += 256) {
-            atomicAdd(d_lnw + i, r_g[i]);
-            atomicAdd(d_lnb + i, r_b[i]);
-        }
+    // the four waves' slots in wave order -> this workgroup's partial rows
+    for (int i = threadIdx.x; i < nA; i += 256)
+        partA[(long)blockIdx.x * nA + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+    for (int i = threadIdx.x; i < nB; i += 256)
+        partB[(long)blockIdx.x * nB + i] = (red[0][nA + i] + red[1][nA + i]) + (red[2][nA + i] + red[3][nA + i]);
 }
 
+extern "C" long t4r_soft_embedding_bwd_ws_floats(long ntok, int K, int D) {
+    return ((ntok + 255) / 256) * (long)(K * D + 2 * K + 2 * D);
+}
+
+// ws: t4r_soft_embedding_bwd_ws_floats(ntok, K, D) floats of scratch (per-workgroup partial sums)
+int t4r_reduce_partials_launch(hipStream_t st, const float* part, int nblocks, float* o0, int n0, int a0,
+                               float* o1, int n1, int a1, float* o2, int n2, int a2);   // elementwise.hip
 extern "C" int t4r_soft_embedding_bwd(void* stream, const float* dout, const float* x,
                                       const float* proj_w, const float* proj_b, const float* table,
                                       const float* ln_w, float* d_proj_w, float* d_proj_b,
                                       float* d_table, float* d_ln_w, float* d_ln_b, long ntok, int W,
-                                      int col, int K, int D, float eps) {
+                                      int col, int K, int D, float eps, float* ws) {
     if (ntok == 0) return 0;
     T4R_CHECK_ARG(K >= 1 && K <= T4R_SOFT_MAXK && D >= 1 && D <= T4R_SOFT_MAXD,
                   "soft_embedding_bwd: K<=32, dim<=32");
-    dim3 grid((unsigned)((ntok + 255) / 256)), block(256);
+    T4R_CHECK_ARG(ws != nullptr, "soft_embedding_bwd: workspace required (t4r_soft_embedding_bwd_ws_floats)");
+    const int nblocks = (int)((ntok + 255) / 256);
+    const int nA = K * D + 2 * K, nB = 2 * D;
+    float* partA = ws;
+    float* partB = ws + (long)nblocks * nA;
+    dim3 grid((unsigned)nblocks), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (K <= 16 && D <= 8)
         hipLaunchKernelGGL((soft_embedding_bwd_kernel<16, 8>), grid, block, 0, st, dout, x, proj_w,
-                           proj_b, table, ln_w, d_proj_w, d_proj_b, d_table, d_ln_w, d_ln_b, ntok, W,
-                           col, K, D, eps);
+                           proj_b, table, ln_w, partA, partB, ntok, W, col, K, D, eps);
     else
         hipLaunchKernelGGL((soft_embedding_bwd_kernel<32, 32>), grid, block, 0, st, dout, x, proj_w,
-                           proj_b, table, ln_w, d_proj_w, d_proj_b, d_table, d_ln_w, d_ln_b, ntok, W,
-                           col, K, D, eps);
+                           proj_b, table, ln_w, partA, partB, ntok, W, col, K, D, eps);
     T4R_LAUNCH_CHECK();
-    return 0;
+    // fixed-order sums over the workgroups, accumulated into the gradients
+    int rc = t4r_reduce_partials_launch(st, partA, nblocks, d_table, K * D, 1, d_proj_w, K, 1, d_proj_b, K, 1);
+    if (rc != 0) return rc;
+    if (ln_w) rc = t4r_reduce_partials_launch(st, partB, nblocks, d_ln_w, D, 1, d_ln_b, D, 1, nullptr, 0, 0);
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------

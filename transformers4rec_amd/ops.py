@@ -530,9 +530,10 @@ def soft_embedding_bwd(dout, x, proj_w, proj_b, table, ln_w, d_proj_w, d_proj_b,
                        d_ln_b, col, eps=1e-5):
     K, D = table.shape
     W = dout.shape[-1]
+    ws = torch.empty(max(1, _lib.load().t4r_soft_embedding_bwd_ws_floats(x.numel(), K, D)), device=dout.device, dtype=torch.float32)
     call("t4r_soft_embedding_bwd", _stream(), _chk(dout), _chk(x), _chk(proj_w), _chk(proj_b),
          _chk(table), _p(ln_w), _chk(d_proj_w), _chk(d_proj_b), _chk(d_table), _p(d_ln_w), _p(d_ln_b),
-         x.numel(), W, col, K, D, float(eps))
+         x.numel(), W, col, K, D, float(eps), ws.data_ptr())
 
 
 # ------------------------------------------------------------------------------------ masking

@@ -861,15 +861,28 @@ def main():
 
     general_ms = timed(lambda: ops.gemm(xr, W, False, True, out=buf[:, : W.shape[0]]))
     head_split = _head_split_ok(xr, W, N_m, W.shape[0])
-    if head_split:      # the launch the step issues at this shape: csrc/head_split.hip (operands cut once, W-stationary)
+    fdx = False
+    logits_only_ms = None
+    if head_split:      # the launches the step issues at this shape: csrc/head_split.hip
         hws = ops.head_split_prepare(xr, W.shape[0])
-        gemm_ms = timed(lambda: ops.call("t4r_head_split_logits_ce", ops._stream(), hws.data_ptr(), W.data_ptr(), W.stride(0),
-                                         buf.data_ptr(), ld, None, None, None, None, N_m, W.shape[0], D_MODEL, 1.0, 0.0, None))
+        logits_only_ms = timed(lambda: ops.call("t4r_head_split_logits_ce", ops._stream(), hws.data_ptr(), W.data_ptr(), W.stride(0),
+                                                buf.data_ptr(), ld, None, None, None, None, N_m, W.shape[0], D_MODEL, 1.0, 0.0, None))
+        gemm_ms = logits_only_ms
+        fdx = bool(ops.head_split_fdx_supported(D_MODEL))
+        if fdx:
+            # round 5: the step's dominant kernel is the ONE-PASS forward (logits + CE statistics + d X: head_fwd_dx_kernel).
+            # One full call fills the workspace (table maximum, table images), then the kernel alone is timed (labels = NULL)
+            lab_ = torch.randint(1, W.shape[0], (N_m,), device=device)
+            ops.head_split_logits_ce_dx(hws, xr, W, lab_, ldc=ld)
+            gemm_ms = timed(lambda: ops.call("t4r_head_split_logits_ce_dx", ops._stream(), hws.data_ptr(), xr.data_ptr(), xr.stride(0),
+                                             W.data_ptr(), W.stride(0), buf.data_ptr(), ld, None, None, None, None, None, 0, None,
+                                             N_m, W.shape[0], D_MODEL, 1.0, 0.0, None))
     else:
         gemm_ms = general_ms
     with ops.precision("fp32"):
         gemm_ms_f32 = timed(lambda: ops.gemm(xr, W, False, True, out=buf[:, : W.shape[0]]))
-    flops = 2.0 * N_m * W.shape[0] * D_MODEL
+    n_contractions = 2.0 if fdx else 1.0       # the one-pass forward runs the logits AND the d X contraction
+    flops = n_contractions * 2.0 * N_m * W.shape[0] * D_MODEL
     split = mode in ("auto", "fp32_bf16x3")
     # matrix instructions per fp32-equivalent one: 6 (three bf16 planes) or, in csrc/head_split.hip's forward, 3 (two-way fp16 split)
     n_prod = float(_lib_int("t4r_head_split_fwd_products")) if (split and head_split) else (6.0 if split else 1.0)
@@ -877,7 +890,8 @@ def main():
     peak = {"fp32": MFMA_F32_PEAK_TFLOPS, "auto": MFMA_BF16_PEAK_TFLOPS, "fp32_bf16x3": MFMA_BF16_PEAK_TFLOPS,
             "bf16": MFMA_BF16_PEAK_TFLOPS, "fp16": MFMA_BF16_PEAK_TFLOPS}[mode]
     achieved = executed / (gemm_ms * 1e-3) / 1e12
-    alg_bytes = 4.0 * (N_m * D_MODEL + W.shape[0] * D_MODEL + N_m * W.shape[0])
+    # algorithmic bytes: X and W read once, the [N, V] logits written once (+ the d X rows written once by the one-pass form)
+    alg_bytes = 4.0 * (N_m * D_MODEL + W.shape[0] * D_MODEL + N_m * W.shape[0]) + (4.0 * N_m * D_MODEL if fdx else 0.0)
     alg_gbs = alg_bytes / (gemm_ms * 1e-3) / 1e9
     hbm_bound = executed / alg_bytes < peak * 1e12 / (HBM_PEAK_GBS * 1e9)
     # embedding gather (HBM bound): bytes = T * (8 id + 512 row read + 512 row write)
@@ -1053,7 +1067,7 @@ def main():
     # on a known copy; collected in separate rocprofv3 --pmc passes and committed under profiles/).
     # It is a property of the kernel + shape, not of this run: taken from the committed measurement.
     def committed(name):
-        for rnd in ("r02", "r01_g"):
+        for rnd in ("r05", "r02", "r01_g"):
             path = os.path.join(ROOT, "profiles", f"{rnd}_{name}.json")
             if os.path.exists(path):
                 with open(path) as f:
@@ -1062,6 +1076,8 @@ def main():
 
     traffic, traffic_src = None, None
     tj = committed("pmc_traffic")
+    if tj is not None and ("head_fwd_dx" in tj.get("kernel", "")) != fdx:
+        tj = None                   # the committed counters describe the other form of the head's forward
     if tj is not None:
         traffic = int(tj["traffic_bytes_per_launch"] * N_m / tj["n_rows"])   # scales with the label rows
         traffic_src = tj["source"]
@@ -1069,6 +1085,25 @@ def main():
 
     # bytes every rank hands to the collectives per step (payload, not wire traffic: a ring all-reduce moves
     # 2 (N-1)/N of it per link): the dense bucket, the tables bucket (tied head: dense d W) and the row-sparse exchange
+    if fdx:
+        kernel_desc = ("head_fwd_dx_kernel<4> (round 5, ONE pass over (128-row tile x item range) workgroups: next-item logits X@W^T "
+                       "stored once + the softmax statistics of the loss + d X = sum_v p_v W_v from the same score tiles in registers, "
+                       "flash-attention style running reference; fp32-class accuracy: two-way fp16 split with power-of-two scales, three "
+                       "v_mfma_f32_32x32x16_f16 products per K=16 in BOTH contractions; the backward then reads the logits once (d W) "
+                       "instead of twice)")
+    elif head_split and n_prod == 3.0:
+        kernel_desc = ("head_logits_ce_kernel<4, fp16x2> (next-item logits X@W^T + the softmax statistics of the loss; fp32-class "
+                       "accuracy: two-way fp16 split with power-of-two tensor scales, three v_mfma_f32_32x32x16_f16 products per K=16; "
+                       "W fragments register-resident, X plane blocks through LDS)")
+    elif head_split:
+        kernel_desc = ("head_logits_ce_kernel<4> (next-item logits X@W^T + the softmax statistics of the loss; fp32-accurate: exact "
+                       "3-way bf16 split, six v_mfma_f32_32x32x16_bf16 products per K=16; W fragments register-resident, X plane "
+                       "blocks through LDS)")
+    elif split:
+        kernel_desc = ("gemm_f32_kernel<128,64,32,NT,PREC=1> (next-item logits X@W^T; fp32-accurate: exact 3-way bf16 split, six "
+                       "v_mfma_f32_32x32x16_bf16 products per K=16)")
+    else:
+        kernel_desc = "gemm_f32_kernel<128,128,16,NT> (next-item logits X@W^T)"
     sparse = getattr(reducer, "sparse", None)
     comm = {"dense_bucket_bytes": int(dense.grad.numel() * 4) if world > 1 else 0,
             "tables_bucket_bytes": int(tables.grad.numel() * 4) if world > 1 and reducer.tables is not None else 0,
@@ -1096,16 +1131,7 @@ def main():
                        "preheat_s": round(preheat_s, 2), "preheat_steps": n_pre,
                        "timed_region_s": round(dt, 4)},
             "ms_per_step_windows": windows,
-            "roofline": {"kernel": (("head_logits_ce_kernel<4, fp16x2> (next-item logits X@W^T + the softmax statistics of the loss; "
-                                     "fp32-class accuracy: two-way fp16 split with power-of-two tensor scales, three "
-                                     "v_mfma_f32_32x32x16_f16 products per K=16; W fragments register-resident, X plane blocks through LDS)")
-                                    if n_prod == 3.0 else
-                                    ("head_logits_ce_kernel<4> (next-item logits X@W^T + the softmax statistics of the loss; fp32-accurate: "
-                                     "exact 3-way bf16 split, six v_mfma_f32_32x32x16_bf16 products per K=16; W fragments "
-                                     "register-resident, X plane blocks through LDS)")) if head_split else
-                                   ("gemm_f32_kernel<128,64,32,NT,PREC=1> (next-item logits X@W^T; fp32-accurate: exact "
-                                    "3-way bf16 split, six v_mfma_f32_32x32x16_bf16 products per K=16)") if split else
-                                   "gemm_f32_kernel<128,128,16,NT> (next-item logits X@W^T)",
+            "roofline": {"kernel": kernel_desc,
                          # which roof: the kernel's arithmetic intensity (EXECUTED matrix flops per algorithmic HBM byte) against the
                          # machine balance peak flops / 8 TB/s.  Since the products moved to the two-way fp16 split (round 3: 3 matrix
                          # instructions per fp32-equivalent one at the 2.5 PFLOP/s rate) the launch sits BELOW the balance point
@@ -1118,18 +1144,22 @@ def main():
                          "machine_balance_flop_per_byte": round(peak * 1e12 / (HBM_PEAK_GBS * 1e9), 1),
                          "note": ("achieved = algorithmic bytes (X + W read once, the [N, V] logits written once) / launch time; "
                                   "the roof is chosen by arithmetic intensity vs machine balance" if hbm_bound else
-                                  f"achieved = EXECUTED matrix-core flops ({int(n_prod)}x the algorithmic 2*N*V*D in this split form) / "
-                                  "launch time, priced against the dense bf16 / fp16 MFMA peak"),
+                                  f"achieved = EXECUTED matrix-core flops ({int(n_prod)}x the algorithmic {int(n_contractions)} x 2*N*V*D in this split form) / "
+                                  "launch time, priced against the dense bf16 / fp16 MFMA peak; the roof is chosen by arithmetic "
+                                  "intensity vs machine balance" + (" -- with TWO contractions per byte of logits the one-pass kernel sits "
+                                  "on the matrix side of the balance point (the logits-only kernel of rounds 2-4 sat on the HBM side); "
+                                  "its time is matrix + vector (exp, fp16 cuts, quad transposes) + LDS issue, which add up on this chip"
+                                  if fdx else "")),
+                         "contractions_per_launch": int(n_contractions),
+                         "logits_only_kernel_ms": None if logits_only_ms is None else round(logits_only_ms, 4),
                          "mfma_side": {"achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                                        "note": f"EXECUTED matrix-core flops ({int(n_prod)}x the algorithmic 2*N*V*D in this split form) / launch "
-                                               "time against the dense bf16 / fp16 MFMA peak; in-step matrix-pipe busy 0.274 "
-                                               "(profiles/r04_f_pmc_mfma_busy.csv)"},
+                                               "time against the dense bf16 / fp16 MFMA peak"},
                          "fp32_equivalent": {"achieved": round(flops / (gemm_ms * 1e-3) / 1e12, 2),
                                              "peak": MFMA_F32_PEAK_TFLOPS,
                                              "frac": round(flops / (gemm_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)},
-                         "hbm_side": {"algorithmic_GBps": round(4e-9 * (N_m * D_MODEL + W.shape[0] * D_MODEL + N_m * W.shape[0]) / (gemm_ms * 1e-3), 1),
-                                      "frac_of_hbm_peak": round(4e-9 * (N_m * D_MODEL + W.shape[0] * D_MODEL + N_m * W.shape[0]) / (gemm_ms * 1e-3) / HBM_PEAK_GBS, 4),
-                                      "note": "the launch also writes the [N, V] logits once (1.1 GB): its second bound"},
+                         "hbm_side": {"algorithmic_GBps": round(alg_gbs, 1), "frac_of_hbm_peak": round(alg_gbs / HBM_PEAK_GBS, 4),
+                                      "note": "the launch writes the [N, V] logits once (1.1 GB): its second bound"},
                          "general_gemm_same_shape_ms": round(general_ms, 4),
                          "fp32_matrix_core_form": {"avg_launch_ms": round(gemm_ms_f32, 4),
                                                    "achieved": round(flops / (gemm_ms_f32 * 1e-3) / 1e12, 2),
@@ -1137,7 +1167,7 @@ def main():
                          "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": None if traffic_src is None else
                          "committed (not measured in this run; scaled by the label rows): " + traffic_src,
-                         "algorithmic_bytes": int(4 * (N_m * D_MODEL + W.shape[0] * D_MODEL + N_m * W.shape[0])),
+                         "algorithmic_bytes": int(alg_bytes),
                          "avg_launch_ms": round(gemm_ms, 4), "flops_per_launch": flops,
                          "executed_flops_per_launch": executed},
             "roofline_gather": {"kernel": "seq_features_fwd_fast_kernel<32, 2> (embedding gather, streaming stores)", "bound": "hbm",

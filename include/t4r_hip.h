@@ -250,6 +250,7 @@ int t4r_head_split_dx(void* stream, void* ws, const float* logits, long ld, cons
  * configs[1].  Replaces transformers4rec/torch/model/prediction_task.py:648-671 (logits) + CrossEntropyLoss :446 and the d X
  * half of their autograd.  X: the rows t4r_head_split_prepare was given (same ws); wsum: column sums of W [D], required when
  * label_smoothing > 0, else NULL; the caller's backward is dX * grad_out and t4r_head_split_dw with the same ws / note.
+ * labels == NULL: the dominant kernel alone on a workspace a full call has filled (bench.py's roofline timing).
  * t4r_head_split_fdx_supported: 1 when this form takes the width (two-way fp16 products on; T4R_HEAD_FDX=0 switches it off). */
 int t4r_head_split_fdx_supported(int D);
 int t4r_head_split_logits_ce_dx(void* stream, void* ws, const float* X, long ldx, const float* W, long ldw, float* C, long ldc,

@@ -441,7 +441,7 @@ int t4r_xlnet_get_cu_budget(void);
  *     keys and element indices as t4r_xlnet_attn_fwd / t4r_xlnet_oproj_ln: the masks are identical.  key_len: optional
  *     int32 [B] (opt-in padding mask as t4r_xlnet_attn_fwd).
  * The backward of the attention half stays three launches (t4r_xlnet_ln1_bwd -> t4r_xlnet_attn_bwd -> t4r_xlnet_dh); a
- *     one-kernel backward was built, tested and measured slower -- tools/experimental/, not exported. */
+ *     one-kernel backward was built, tested and measured slower (docs/DESIGN_rounds_1_to_4.md, round 4) -- tools/experimental/, not exported. */
 int t4r_xlnet_attn_block_supported(int L, int D, int n_head);
 int t4r_xlnet_attn_block_fwd(void* stream, const float* h, const float* planes, const float* o, const float* kr,
                              long kr_bstride, const float* r_w_bias, const float* r_r_bias, const float* gamma,

@@ -30,7 +30,7 @@
 // attention half is small (12 GFLOP forward per step at BASELINE configs[1]) and was bound by launch boundaries, operand
 // cutting and HBM round trips of q / k / v, not by the matrix pipe -- four launches (projection, core, o-projection +
 // LayerNorm, with q, k, v, attn_vec making a round trip through HBM between them) took 55 us per layer for 22 us of
-// fp32 matrix time.  In one kernel the matrix pipe is the bound: measured numbers in DESIGN.md (round 4).
+// fp32 matrix time.  In one kernel the matrix pipe is the bound: measured numbers in docs/DESIGN_rounds_1_to_4.md (4.1d).
 #include "xlnet_fused.h"
 
 namespace {

@@ -14,7 +14,7 @@
 // The attention core itself (scores, relative shift, softmax, dropout, P @ v) stays xlnet_attn_mfma.hip.
 // Each replaces one or two launches of the general GEMM + an element-wise / LayerNorm launch of the chain in
 // xlnet_layer.hip; what they save is the operand cutting per 64 x 64 tile of the general kernel, the LayerNorm round
-// trips and the launch boundaries (measured per layer at the benchmark size, same box: see DESIGN.md).
+// trips and the launch boundaries (measured per layer at the benchmark size, same box: see docs/DESIGN_rounds_1_to_4.md 4.1c).
 #include "xlnet_fused.h"
 
 // ---------------------------------------------------------------------------------------------- weight planes of a layer

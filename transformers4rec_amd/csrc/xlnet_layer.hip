@@ -93,7 +93,7 @@ static bool use_fused(int D) {
 
 // The attention half of the FORWARD as one kernel (csrc/xlnet_attn_block.hip), default ON
 // (T4R_XLNET_ATTN_BLOCK=0 restores projection -> core -> o-projection + LayerNorm).  The one-kernel BACKWARD was built,
-// tested and measured slower (120-130 us per launch against 118 us for the three launches it would replace: DESIGN.md
+// tested and measured slower (120-130 us per launch against 118 us for the three launches it would replace: docs/DESIGN_rounds_1_to_4.md,
 // round 4); it lives in tools/experimental/ and is compiled only into the A/B variant library (-DT4R_EXPERIMENTAL).
 static bool use_attn_block(int L, int D, int n_head) {
     static const int on = [] { const char* e = getenv("T4R_XLNET_ATTN_BLOCK"); return e ? atoi(e) : 1; }();

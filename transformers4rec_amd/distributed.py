@@ -164,7 +164,7 @@ class GradReducer:
                 self._pending = dist.all_reduce(self.tables, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             # the ring kernel now holds one CU per channel until the reduction is done, i.e. for most of the body's backward:
             # its one-workgroup-per-CU token-tile kernels are told to plan for the CUs that are left (csrc/xlnet_fused.hip:
-            # t4r_xlnet_set_cu_budget; measured on one GPU with a CU occupier, tools/occupier_curve.py: 1.38x -> see DESIGN 7)
+            # t4r_xlnet_set_cu_budget; measured on one GPU with a CU occupier, tools/occupier_curve.py: 1.36x -> 1.25x)
             from . import ops
 
             ops.xlnet_set_cu_budget(256 - collective_channels())

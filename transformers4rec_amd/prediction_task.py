@@ -442,7 +442,7 @@ class NextItemPredictionTask(nn.Module):
             # Scores too large to keep: at a head_split.hip width the RECOMPUTING head (round 4: statistics forward, score
             # tiles recomputed by the two backward products, csrc/head_split.hip) replaces the chunked general path.
             # Where the scores do fit it is NOT the default: measured at BASELINE configs[1] (d_model 128) the two extra
-            # products cost more than the 3.3 GB of logits traffic they save (step 3.13 vs 2.89 ms: DESIGN.md round 4);
+            # products cost more than the 3.3 GB of logits traffic they save (step 3.13 vs 2.89 ms: docs/DESIGN_rounds_1_to_4.md, round 4);
             # head_mode="recompute" / T4R_HEAD_MODE=recompute selects it anyway (training calls only: metrics read the scores)
             if mode == "fused" and getattr(self, "_training_call", False) and _HEAD_RECOMPUTE:
                 D = self.pre.module.output_weights.shape[1]

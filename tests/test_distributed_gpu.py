@@ -146,6 +146,57 @@ def test_torch_ddp_wraps_the_functional_model():
     assert ret["err"] < 1e-6 + 1e-5 * ret["scale"], dict(ret)
 
 
+def _ddp_session_worker(rank, world, port, ret):
+    """as _ddp_worker, for the MULTI-FEATURE model at dropout 0.3 through functional.FunctionalSessionModel (round 5)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import transformers4rec_amd as tr
+    from transformers4rec_amd import functional as F
+    from transformers4rec_amd.rng import get_rng_state, set_rng_state
+
+    torch.manual_seed(0)
+    schema = tr.session_schema(V, L, (("category", 50), ("brand", 9)), ("price", "age"))
+    inputs = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=L, masking="mlm", aggregation="concat", d_output=D,
+                                                    continuous_soft_embeddings=True, embedding_dims={"item_id": D},
+                                                    embedding_dim_default=16)
+    cfg = tr.XLNetConfig.build(D, NH, NL, total_seq_length=L, dropout=0.3)
+    model = cfg.to_torch_model(inputs, tr.NextItemPredictionTask(weight_tying=True)).to(dev).train()
+    model.input_features.masking.seed, model.transformer_block.transformer.seed = 1234 + rank, 77 + rank
+    fm = F.FunctionalSessionModel(model)
+    ddp = torch.nn.parallel.DistributedDataParallel(fm)
+    batch = tr.random_data_from_schema(schema, B, L, seed=300 + rank, device=dev)
+    state = get_rng_state(model)
+    loss = fm(dict(batch))["loss"]
+    own = torch.autograd.grad(loss, list(fm.parameters()))
+    flat = torch.cat([g.reshape(-1) for g in own]).cpu()
+    both = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    want = (both[0] + both[1]) / 2
+    set_rng_state(model, state)                                    # the same MLM and dropout masks again
+    out = ddp(dict(batch))
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    got = torch.cat([p.grad.reshape(-1) for p in fm.parameters()]).cpu()
+    if rank == 0:
+        ret.update(err=float((got - want).abs().max()), scale=float(want.abs().max()), n=int(out["n_labels"]),
+                   n_params=len(list(fm.parameters())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_torch_ddp_wraps_the_multi_feature_functional_model():
+    """torch's own DistributedDataParallel over the registered-operator form of a configs[2]-shaped model
+    (item + two categoricals + two SoftEmbedding features, concat, projection) at dropout 0.3: the bucket hooks see every
+    gradient -- tables, soft embeddings, projection, mask vector, layers -- and average them over the two ranks"""
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_ddp_session_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert ret["n"] > 0 and ret["scale"] > 0 and ret["n_params"] >= 3 + 10 + 2 + 1 + 15 * NL
+    assert ret["err"] < 1e-6 + 1e-5 * ret["scale"], dict(ret)
+
+
 def test_bench_main_two_ranks():
     """`bench.py --gpus 2` END TO END on real kernels -- the driver's N > 1 command with the collectives over gloo and both
     ranks on the box's one GPU (T4R_BENCH_BACKEND / T4R_BENCH_SHARE_GPU): warm-up, the timed pick of the table-gradient

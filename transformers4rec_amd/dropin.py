@@ -438,8 +438,9 @@ def _check_data_parallel(mod, training):
             "gradients into .grad without autograd hooks, so torch DDP (HF Trainer's wrapper) cannot see them. "
             "Before training, acknowledge with transformers4rec_amd.dropin.enable_data_parallel(model) (or "
             "convert_model(model, data_parallel=True)), then call dropin.sync_gradients(model) between backward() and "
-            "optimizer.step() -- or wire distributed.GradReducer / SparseRowExchange yourself.  For an item-id XLNet / MLM "
-            "model, torch.nn.parallel.DistributedDataParallel(functional.FunctionalMLMModel(model)) is the hook-visible form "
+            "optimizer.step() -- or wire distributed.GradReducer / SparseRowExchange yourself.  For an XLNet / MLM model with "
+            "sequence categoricals (+ SoftEmbedding features, concat, projection), "
+            "torch.nn.parallel.DistributedDataParallel(functional.FunctionalSessionModel(model)) is the hook-visible form "
             "of the same step (registered operators with autograd formulas, every dropout site included).")
 
 

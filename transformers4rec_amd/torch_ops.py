@@ -452,7 +452,217 @@ def _nih_backward(ctx, dloss, *_unused):
 next_item_head.register_autograd(_nih_backward, setup_context=_nih_setup)
 
 
+# ---- the multi-feature input block (BASELINE configs[2]: item + categoricals + SoftEmbedding features, concat, ReLU
+# projection, mask) as operators -- round 5: the functional path covers the configuration BASELINE names for the DP run
+@torch.library.custom_op(f"{NS}::soft_embedding", mutates_args=())
+def soft_embedding(x: torch.Tensor, proj_w: torch.Tensor, proj_b: torch.Tensor, table: torch.Tensor, ln_w: Optional[torch.Tensor],
+                   ln_b: Optional[torch.Tensor], eps: float) -> torch.Tensor:
+    """SoftEmbedding (+ its per-feature LayerNorm): x [B, L] -> [B * L, D] (features/embedding.py:551-556, :306-309)"""
+    K, D = table.shape
+    return ops.soft_embedding_fwd(x.contiguous().float(), proj_w.detach(), proj_b.detach(), table.detach(),
+                                  None if ln_w is None else ln_w.detach(), None if ln_b is None else ln_b.detach(), eps).view(-1, D)
+
+
+@soft_embedding.register_fake
+def _(x, proj_w, proj_b, table, ln_w, ln_b, eps):
+    return table.new_empty((x.numel(), table.shape[1]))
+
+
+@torch.library.custom_op(f"{NS}::soft_embedding_grad", mutates_args=())
+def soft_embedding_grad(dout: torch.Tensor, x: torch.Tensor, proj_w: torch.Tensor, proj_b: torch.Tensor, table: torch.Tensor,
+                        ln_w: Optional[torch.Tensor], eps: float) -> List[torch.Tensor]:
+    """-> [d proj_w, d proj_b, d table, d ln_w, d ln_b] (the last two zeros without a LayerNorm); fixed-order sums"""
+    D = table.shape[1]
+    z = lambda t: torch.zeros_like(t)
+    g = [z(proj_w), z(proj_b), z(table), torch.zeros(D, device=dout.device), torch.zeros(D, device=dout.device)]
+    ops.soft_embedding_bwd(dout.contiguous().view(-1, D), x.contiguous().float(), proj_w.detach(), proj_b.detach(), table.detach(),
+                           None if ln_w is None else ln_w.detach(), g[0], g[1], g[2], None if ln_w is None else g[3],
+                           None if ln_w is None else g[4], 0, eps)
+    return g
+
+
+@soft_embedding_grad.register_fake
+def _(dout, x, proj_w, proj_b, table, ln_w, eps):
+    D = table.shape[1]
+    return [proj_w.new_empty(proj_w.shape), proj_b.new_empty(proj_b.shape), table.new_empty(table.shape), table.new_empty((D,)),
+            table.new_empty((D,))]
+
+
+def _se_setup(ctx, inputs, output):
+    x, proj_w, proj_b, table, ln_w, ln_b, eps = inputs
+    ctx.has_ln = ln_w is not None
+    ctx.save_for_backward(x, proj_w, proj_b, table, *([ln_w] if ctx.has_ln else []))
+    ctx.eps = eps
+
+
+def _se_backward(ctx, dout):
+    x, proj_w, proj_b, table, *rest = ctx.saved_tensors
+    g = torch.ops.t4r_hip.soft_embedding_grad(dout, x, proj_w, proj_b, table, rest[0] if ctx.has_ln else None, ctx.eps)
+    return None, g[0], g[1], g[2], (g[3] if ctx.has_ln else None), (g[4] if ctx.has_ln else None), None
+
+
+soft_embedding.register_autograd(_se_backward, setup_context=_se_setup)
+
+
+def _concat_feats(ids, tables, dense, layout, dims):
+    """layout[i] > 0: column block i is table layout[i] - 1 (gathered by ids[layout[i] - 1]); < 0: dense rows -layout[i] - 1"""
+    feats, col = [], 0
+    for code, dim in zip(layout, dims):
+        if code > 0:
+            k = code - 1
+            feats.append(dict(kind=0, input=ids[k].contiguous(), table=tables[k].detach(), dim=dim, col=col, rows=tables[k].shape[0]))
+        else:
+            feats.append(dict(kind=1, input=dense[-code - 1].contiguous(), table=None, dim=dim, col=col))
+        col += dim
+    return feats, col
+
+
+@torch.library.custom_op(f"{NS}::seq_concat", mutates_args=())
+def seq_concat(ids: Sequence[torch.Tensor], tables: Sequence[torch.Tensor], dense: Sequence[torch.Tensor], layout: List[int],
+               dims: List[int]) -> torch.Tensor:
+    """the concatenating gather of the input block (features/embedding.py:226-249 + tabular/aggregation.py:35-47, one launch):
+    table features looked up by their [B, L] ids, dense rows ([B * L, dim]: soft embeddings, continuous columns) copied, column
+    blocks in `layout` order (the reference's sorted feature names) -> [B, L, sum(dims)]"""
+    B, L = ids[0].shape
+    feats, W = _concat_feats(ids, tables, dense, layout, dims)
+    return ops.seq_features_fwd(feats, "concat", B, L, L, W)
+
+
+@seq_concat.register_fake
+def _(ids, tables, dense, layout, dims):
+    return tables[0].new_empty((ids[0].shape[0], ids[0].shape[1], sum(dims)))
+
+
+@torch.library.custom_op(f"{NS}::seq_concat_grad", mutates_args=())
+def seq_concat_grad(dy: torch.Tensor, ids: Sequence[torch.Tensor], table_rows: List[int], layout: List[int], dims: List[int],
+                    padding_idx: int) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
+    """-> (dense [rows, dim] gradient per table: the deterministic sorted scatter of its column block; d of every dense input)"""
+    W = dy.shape[-1]
+    d2 = dy.contiguous().view(-1, W)
+    n_tab = sum(1 for c in layout if c > 0)
+    d_tables = [None] * n_tab
+    d_dense = [None] * (len(layout) - n_tab)
+    col = 0
+    for code, dim in zip(layout, dims):
+        block = d2 if W == dim else ops.copy_cols_out(d2, col, dim)
+        if code > 0:
+            k = code - 1
+            g = torch.zeros((table_rows[k], dim), device=dy.device)
+            ops.scatter_rows_sorted(g, ids[k].reshape(-1).contiguous(), block, padding_idx)
+            d_tables[k] = g
+        else:
+            d_dense[-code - 1] = block.clone() if block is d2 else block
+        col += dim
+    return d_tables, d_dense
+
+
+@seq_concat_grad.register_fake
+def _(dy, ids, table_rows, layout, dims, padding_idx):
+    T = dy.shape[0] * dy.shape[1]
+    tabs = sorted((c - 1, d) for c, d in zip(layout, dims) if c > 0)
+    dens = sorted((-c - 1, d) for c, d in zip(layout, dims) if c < 0)
+    return [dy.new_empty((table_rows[k], d)) for k, d in tabs], [dy.new_empty((T, d)) for _, d in dens]
+
+
+def _sc_setup(ctx, inputs, output):
+    ids, tables, dense, layout, dims = inputs
+    ctx.save_for_backward(*ids)
+    ctx.rows = [t.shape[0] for t in tables]
+    ctx.layout, ctx.dims = list(layout), list(dims)
+    ctx.padding_idx = getattr(tables[0], "_t4r_padding_idx", 0)
+
+
+def _sc_backward(ctx, dy):
+    d_tables, d_dense = torch.ops.t4r_hip.seq_concat_grad(dy, list(ctx.saved_tensors), ctx.rows, ctx.layout, ctx.dims, ctx.padding_idx)
+    return [None] * len(ctx.saved_tensors), list(d_tables), list(d_dense), None, None       # (a list argument gets a list back)
+
+
+seq_concat.register_autograd(_sc_backward, setup_context=_sc_setup)
+
+
+@torch.library.custom_op(f"{NS}::linear_relu", mutates_args=())
+def linear_relu(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """ReLU(x @ weight^T + bias): the projection MLPBlock([d_output]) of the input block (block/mlp.py:68-143), bias + ReLU in
+    the GEMM's epilogue"""
+    return ops.gemm(x.contiguous(), weight.detach(), False, True, bias=bias.detach(), epilogue=ops.EPI_BIAS_RELU)
+
+
+@linear_relu.register_fake
+def _(x, weight, bias):
+    return x.new_empty((x.shape[0], weight.shape[0]))
+
+
+@torch.library.custom_op(f"{NS}::linear_relu_grad", mutates_args=())
+def linear_relu_grad(dy: torch.Tensor, y: torch.Tensor, x: torch.Tensor, weight: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """-> (d x, d weight, d bias)"""
+    d = dy.contiguous().clone()
+    db = torch.zeros(weight.shape[0], device=dy.device)
+    ops.act_bwd_bias(d, y.contiguous(), db, 1)
+    dW = torch.zeros_like(weight)
+    ops.gemm(d, x.contiguous(), True, False, splitk=-1, accumulate=True, out=dW)
+    return ops.gemm(d, weight.detach(), False, False), dW, db
+
+
+@linear_relu_grad.register_fake
+def _(dy, y, x, weight):
+    return x.new_empty(x.shape), weight.new_empty(weight.shape), weight.new_empty((weight.shape[0],))
+
+
+def _lr_setup(ctx, inputs, output):
+    x, weight, bias = inputs
+    ctx.save_for_backward(x, weight, output)
+
+
+def _lr_backward(ctx, dy):
+    x, weight, y = ctx.saved_tensors
+    return tuple(torch.ops.t4r_hip.linear_relu_grad(dy, y, x, weight))
+
+
+linear_relu.register_autograd(_lr_backward, setup_context=_lr_setup)
+
+
+@torch.library.custom_op(f"{NS}::apply_mask", mutates_args=())
+def apply_mask(x: torch.Tensor, mask: torch.Tensor, masked_emb: torch.Tensor, mask_mode: int) -> torch.Tensor:
+    """masking.py:473-498 / :302-337 as its own pass (after a projection): x [B, L, H] with the trainable vector at the
+    replaced positions"""
+    return ops.apply_mask_fwd_(x.contiguous().clone(), mask, masked_emb.detach(), mask_mode)
+
+
+@apply_mask.register_fake
+def _(x, mask, masked_emb, mask_mode):
+    return x.new_empty(x.shape)
+
+
+@torch.library.custom_op(f"{NS}::apply_mask_grad", mutates_args=())
+def apply_mask_grad(dy: torch.Tensor, mask: torch.Tensor, mask_mode: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """-> (d x, d masked_item_embedding)"""
+    d = dy.contiguous().clone()
+    d_memb = torch.zeros(dy.shape[-1], device=dy.device)
+    ops.apply_mask_bwd_(d, mask, d_memb, mask_mode)
+    return d, d_memb
+
+
+@apply_mask_grad.register_fake
+def _(dy, mask, mask_mode):
+    return dy.new_empty(dy.shape), dy.new_empty((dy.shape[-1],))
+
+
+def _am_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[1])
+    ctx.mode = inputs[3]
+
+
+def _am_backward(ctx, dy):
+    dx, d_memb = torch.ops.t4r_hip.apply_mask_grad(dy, ctx.saved_tensors[0], ctx.mode)
+    return dx, None, d_memb, None
+
+
+apply_mask.register_autograd(_am_backward, setup_context=_am_setup)
+
+
 OPERATORS = ("gemm", "item_scores", "topk", "rank_of_target", "embedding_gather", "embedding_bag", "ragged_to_padded",
              "xlnet_layer_infer", "xlnet_layer_fwd", "xlnet_layer_bwd", "mlm_targets", "seq_item_embedding",
              "seq_item_embedding_bwd", "xlnet_layer_grad", "gather_label_rows", "scatter_label_rows", "linear_softmax_ce",
-             "linear_softmax_ce_bwd", "dropout", "pos_emb_dropout", "next_item_head", "next_item_head_bwd")
+             "linear_softmax_ce_bwd", "dropout", "pos_emb_dropout", "next_item_head", "next_item_head_bwd",
+             "soft_embedding", "soft_embedding_grad", "seq_concat", "seq_concat_grad", "linear_relu", "linear_relu_grad", "apply_mask",
+             "apply_mask_grad")

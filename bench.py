@@ -736,6 +736,9 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.3)  # XLNetConfig.build default (config/transformer.py:442)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
+    ap.add_argument("--extra-streams", type=int, default=0,
+                    help="measurement only: K more HIP streams, each with one tiny launch per step -- how the step reacts to "
+                         "more streams than hardware queues (the data-parallel run adds the collective's stream)")
     ap.add_argument("--config", choices=("c2", "c3"), default="c2",
                     help="c2 = BASELINE.json configs[1] (the configuration `metric` is quoted on; default); "
                          "c3 = configs[2], the multi-feature input block on the same XLNet (the 8-GPU DP configuration)")
@@ -757,13 +760,13 @@ def main():
     dev_index = 0 if os.environ.get("T4R_BENCH_SHARE_GPU", "0") == "1" else local_rank
     if world > 1:       # (before the first HIP call: the runtime reads its environment once)
         # The table all-reduce runs UNDER the body's backward, whose token-tile kernels launch one workgroup per CU: every CU an
-        # RCCL channel holds costs them a second round (tools/occupier_curve.py, profiles/r05_occupier_curve.json).  Two knobs,
-        # both overridable from the environment: (i) cap the channels, so that the collective's footprint is known and small --
-        # 16 channels move the 51 MB bucket over 7 xGMI links in ~0.3 ms, well inside the ~1 ms backward; (ii) more hardware
-        # queues than HIP's default 4, so that RCCL's stream does not share a queue with the caller's or a weight-gradient
-        # stream (streams on one hardware queue are serialised: a resident kernel blocks everything queued behind it).
+        # RCCL channel holds costs them a second round (tools/occupier_curve.py, profiles/r05_occupier_curve.json): cap the
+        # channels, so that the collective's footprint is known and small -- 16 channels move the 51 MB bucket over 7 xGMI
+        # links in ~0.3 ms, well inside the ~1 ms backward.  Overridable from the environment.
+        # Streams: the step drives the caller's stream + two weight-gradient streams, the collective's stream is the FOURTH;
+        # a fifth active stream costs +1.0 ms per step on this runtime and GPU_MAX_HW_QUEUES=8 does not lift that
+        # (profiles/r05_q_stream_count.txt) -- so nothing here raises the queue count, and the forward's id-sort stream is off.
         os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     import torch.distributed as dist
@@ -806,6 +809,16 @@ def main():
             lambda hk: teardown_data_parallel(tables, hk),
             lambda red: make_train_step(model, batches, red, opt), world, device)
         train_step = make_train_step(model, batches, reducer, opt)
+    if args.extra_streams > 0:
+        _extra = [torch.cuda.Stream(device) for _ in range(args.extra_streams)]
+        _tick = [torch.zeros(256, device=device) for _ in _extra]
+        _plain_step = train_step
+
+        def train_step(i):
+            for st, t in zip(_extra, _tick):
+                with torch.cuda.stream(st):
+                    t.add_(1.0)
+            return _plain_step(i)
     t_pre = time.perf_counter()
     n_pre = 0
     go = torch.ones(1, device=device, dtype=torch.int32)
@@ -1127,7 +1140,9 @@ def main():
                        "precision_mode": mode, "table_exchange": exchange_mode, "world_size": world,
                        "collective_backend": (backend if world > 1 else None),
                        "nccl_max_nchannels": (os.environ.get("NCCL_MAX_NCHANNELS") if world > 1 else None),
-                       "gpu_max_hw_queues": (os.environ.get("GPU_MAX_HW_QUEUES") if world > 1 else None),
+                       "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       "extra_streams": args.extra_streams,
+                       "prefetch": int(os.environ.get("T4R_PREFETCH", "1")),
                        "preheat_s": round(preheat_s, 2), "preheat_steps": n_pre,
                        "timed_region_s": round(dt, 4)},
             "ms_per_step_windows": windows,

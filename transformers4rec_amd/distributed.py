@@ -9,8 +9,10 @@ step).  Three kinds of traffic:
   dense bucket    everything but the tables (3.4 MB at C2): one all-reduce, latency bound.
   tables bucket   the embedding tables / untied output layer as ONE dense buffer: all-reduce.  With a
                   tied full-softmax head the head's d W fills every row, and that part is final right
-                  after the head's backward -- `reduce_tables_async()` launches the all-reduce there, on
-                  its own stream, under the transformer's backward (the head is FIRST in backward order).
+                  after the head's backward -- `reduce_tables_async()` launches the all-reduce there
+                  (async: on the process group's stream), under the transformer's backward (the head is FIRST
+                  in backward order).  Stream budget: caller + two weight-gradient streams + the collective's = 4;
+                  a fifth active stream slows the whole step down (profiles/r05_q_stream_count.txt).
   row-sparse      gradients that touch few rows -- the lookup scatter of the input block (B*L rows),
                   the sampled-softmax head (labels + negatives) -- are never scattered into the dense
                   bucket while the all-reduce may be in flight: a SparseRowExchange collects them as
@@ -137,7 +139,6 @@ class GradReducer:
     def __init__(self, dense_grad, tables_grad=None, group=None, sparse: SparseRowExchange = None):
         self.dense, self.tables, self.group, self.sparse = dense_grad, tables_grad, group, sparse
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self._stream = None
         self._pending = None
         self._launched = False
         self._budgeted = False
@@ -154,14 +155,16 @@ class GradReducer:
             return
         self._launched = True
         if self.tables.is_cuda:
-            if self._stream is None:
-                self._stream = torch.cuda.Stream()
-            self._stream.wait_stream(torch.cuda.current_stream())
-            from .prediction_task import _SIDE_STREAMS     # the head's d W may still be running on its side stream
+            # async_op=True: the process group runs the collective on ITS OWN stream, ordered after everything enqueued on the
+            # current stream so far -- no stream of ours in between.  That matters: the step already drives the caller's
+            # stream and the two weight-gradient streams of the body's backward, the collective's stream is the fourth, and a
+            # FIFTH active stream slows every kernel of the step down (+1.0 ms per step measured on one GPU with one tiny
+            # launch per step on an extra stream; GPU_MAX_HW_QUEUES does not lift it: profiles/r05_q_stream_count.txt).
+            cur = torch.cuda.current_stream()
+            from .prediction_task import _SIDE_STREAMS     # the head's d W on its (opt-in) side stream: the collective follows it
             for side in _SIDE_STREAMS.values():
-                self._stream.wait_stream(side)
-            with torch.cuda.stream(self._stream):
-                self._pending = dist.all_reduce(self.tables, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                cur.wait_stream(side)
+            self._pending = dist.all_reduce(self.tables, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             # the ring kernel now holds one CU per channel until the reduction is done, i.e. for most of the body's backward:
             # its one-workgroup-per-CU token-tile kernels are told to plan for the CUs that are left (csrc/xlnet_fused.hip:
             # t4r_xlnet_set_cu_budget; measured on one GPU with a CU occupier, tools/occupier_curve.py: 1.36x -> 1.25x)
@@ -186,8 +189,6 @@ class GradReducer:
             dist.all_reduce(self.dense, op=dist.ReduceOp.SUM, group=self.group)
             if self._pending is not None:
                 self._pending.wait()
-                if self._stream is not None:
-                    torch.cuda.current_stream().wait_stream(self._stream)
                 self._pending = None
         if self.sparse is not None:
             self.sparse.exchange()      # world 1: the local deterministic scatter

@@ -52,9 +52,13 @@ _SORT_STREAMS = {}
 
 
 def _sort_ids_forward(ids, rows, padding_idx):
-    """the forward-pass sort, on a side stream: it feeds only the backward, so it runs under the gather and
-    the transformer body instead of in front of them (T4R_EMB_SORT_STREAM=0: on the caller's stream)"""
-    if os.environ.get("T4R_EMB_SORT_STREAM", "1") == "0":
+    """the forward-pass sort (it feeds only the backward).  On the caller's stream by default; T4R_EMB_SORT_STREAM=1 puts it
+    on a side stream, under the gather and the transformer body.  Default OFF since round 5: the side stream is worth nothing
+    at BASELINE configs[1] (2.834 vs 2.847 ms per step) and it is the process's FOURTH stream -- the caller's, this one and
+    the two weight-gradient streams of the body's backward (csrc/xlnet_layer.hip) -- while a FIFTH active stream costs the
+    whole step +1.0 ms (every kernel slows down; profiles/r05_q_stream_count.txt), and a data-parallel run needs that
+    fourth slot for the collective's stream (distributed.GradReducer)."""
+    if os.environ.get("T4R_EMB_SORT_STREAM", "0") != "1":
         return ops.sort_ids(ids, rows, padding_idx)
     dev = ids.device
     key = (dev.type, dev.index)

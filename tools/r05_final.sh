@@ -21,3 +21,6 @@ done
 python tools/pmc_table.py $(find gpurun_out/${tag}_pmc_gather_FETCH_SIZE gpurun_out/${tag}_pmc_gather_WRITE_SIZE -name "*counter_collection.csv") > gpurun_out/${tag}_pmc_gather_fetch_write.csv
 rm -rf gpurun_out/${tag}_pmc_gather_FETCH_SIZE gpurun_out/${tag}_pmc_gather_WRITE_SIZE
 cat gpurun_out/${tag}_pmc_gather_fetch_write.csv | cut -c1-140
+# the two remaining BASELINE configurations at their named size, for the record (parity-test configurations, not bench lines)
+timeout 300 python tools/c45_bench.py c4 20 > gpurun_out/${tag}_c4.json 2> gpurun_out/${tag}_c4.err; tail -1 gpurun_out/${tag}_c4.json | cut -c1-300
+timeout 400 python tools/c45_bench.py c5 3 fp16 > gpurun_out/${tag}_c5_fp16.json 2> gpurun_out/${tag}_c5_fp16.err; tail -1 gpurun_out/${tag}_c5_fp16.json | cut -c1-300

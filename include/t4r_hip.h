@@ -90,6 +90,14 @@ int t4r_embedding_bwd(void* stream, const float* dout, const long* ids, float* d
 long t4r_sort_ids_ws_bytes(long n);
 int t4r_sort_ids(void* stream, const long* ids, long n, long rows, int padding_idx, int* keys_sorted,
                  int* perm, void* ws, long ws_bytes);
+/* The same sort for the F tables of a multi-feature input block in ONE call (BASELINE configs[2]: item id + three more
+ * categoricals = 4 x ~10 small launches on the caller's stream otherwise): ids = HOST array of F device pointers (n lookups
+ * each), rows / padding_idx = host arrays [F]; feature f's result is the slice [f n, (f + 1) n) of keys_sorted / perm and
+ * equals what t4r_sort_ids gives for that feature alone.  F <= 16; ws of t4r_sort_ids_multi_ws_bytes(n, F) bytes.  The
+ * reference runs one embedding backward per table (features/embedding.py:226-249). */
+long t4r_sort_ids_multi_ws_bytes(long n, int F);
+int t4r_sort_ids_multi(void* stream, const long* const* ids, int F, long n, const long* rows, const int* padding_idx,
+                       int* keys_sorted, int* perm, void* ws, long ws_bytes);
 long t4r_embedding_bwd_sorted_ws_floats(long n, int dim);
 int t4r_embedding_bwd_sorted(void* stream, const float* dout, const int* keys_sorted, const int* perm,
                              float* d_table, long n, int W, int col, int dim, long rows, int ids_div,

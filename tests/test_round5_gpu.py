@@ -300,3 +300,23 @@ def test_soft_embedding_backward_is_bit_reproducible_and_accumulates():
     for got, p in zip(a[:4], ps):
         ref = p.grad
         assert float((got.double().cpu() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------ one sort for several tables
+@pytest.mark.parametrize("n,rows", [(20480, [100001, 1001, 501, 2001]), (777, [50, 3]), (4096, [1 << 20, 7, 7, 7, 300000])])
+def test_one_sort_for_several_tables_equals_the_per_table_sorts(n, rows):
+    """ops.sort_ids_multi (t4r_sort_ids_multi: the F tables of a multi-feature input block in one device sort) gives, per table,
+    exactly the (keys, perm) of ops.sort_ids on that table alone -- padding ids, negative and out-of-range ids included."""
+    from transformers4rec_amd import ops
+
+    g = torch.Generator(device="cpu").manual_seed(n)
+    ids = []
+    for r in rows:
+        x = torch.randint(-2, r + 3, (n,), generator=g)          # a few ids below 0 and beyond the table
+        x[torch.rand(n, generator=g) < 0.2] = 0                   # padding
+        ids.append(x.to(DEV))
+    pads = [0] * len(rows)
+    multi = ops.sort_ids_multi(ids, rows, pads)
+    for f, r in enumerate(rows):
+        k, p = ops.sort_ids(ids[f], r, 0)
+        assert torch.equal(multi[f][0], k) and torch.equal(multi[f][1], p), f

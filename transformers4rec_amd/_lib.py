@@ -27,6 +27,8 @@ _SIGS = {
     "t4r_embedding_bwd": ("i", "pppp" + "liiilii"),
     "t4r_sort_ids_ws_bytes": ("l", "l"),
     "t4r_sort_ids": ("i", "pp" + "lli" + "ppp" + "l"),
+    "t4r_sort_ids_multi_ws_bytes": ("l", "li"),
+    "t4r_sort_ids_multi": ("i", "ppilpp" + "ppp" + "l"),
     "t4r_embedding_bwd_sorted_ws_floats": ("l", "li"),
     "t4r_embedding_bwd_sorted": ("i", "ppppp" + "liiili" + "p"),
     "t4r_embedding_bag_fwd": ("i", "pp" + "li" + "pp" + "llii" + "p" + "li" + "p"),

@@ -507,11 +507,16 @@ extern "C" int t4r_mul(void* stream, const float* a, const float* b, float* out,
 // SoftEmbedding (+ per-feature LayerNorm) forward for one continuous feature:
 //   s_k = x*pw_k + pb_k ; w = softmax(s) ; e = sum_k w_k T[k,:] ; y = LN(e)*g + b  (g null: y = e)
 // One thread per token, K/D bounded by template maxima so everything stays in registers.
-template <int KMAX, int DMAX>
+// EXACT: K == KMAX and D == DMAX are compile-time facts (the reference's defaults, 10 soft bins x 8 dimensions, get their own
+// instantiation): with run-time K, D every `k < K` / `d < D` of the unrolled loops is a scalar branch and every table element a
+// scalar load waited for behind its branch -- 9 k instructions, ~600 branches, 306 dependent s_load in the backward, 58 us per
+// launch at BASELINE configs[2]; the exact form is straight-line code with its parameter loads batched up front.
+template <int KMAX, int DMAX, bool EXACT = false>
 __global__ __launch_bounds__(256) void soft_embedding_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ pw, const float* __restrict__ pb,
     const float* __restrict__ table, const float* __restrict__ lnw, const float* __restrict__ lnb,
-    float* __restrict__ out, long ntok, int K, int D, float eps) {
+    float* __restrict__ out, long ntok, int K_rt, int D_rt, float eps) {
+    const int K = EXACT ? KMAX : K_rt, D = EXACT ? DMAX : D_rt;
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntok) return;
     const float xv = x[t];
@@ -558,7 +563,10 @@ extern "C" int t4r_soft_embedding_fwd(void* stream, const float* x, const float*
                   "soft_embedding_fwd: K<=32, dim<=32");
     dim3 grid((unsigned)((ntok + 255) / 256)), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (K <= 16 && D <= 8)
+    if (K == 10 && D == 8)
+        hipLaunchKernelGGL((soft_embedding_fwd_kernel<10, 8, true>), grid, block, 0, st, x, proj_w, proj_b,
+                           table, ln_w, ln_b, out, ntok, K, D, eps);
+    else if (K <= 16 && D <= 8)
         hipLaunchKernelGGL((soft_embedding_fwd_kernel<16, 8>), grid, block, 0, st, x, proj_w, proj_b,
                            table, ln_w, ln_b, out, ntok, K, D, eps);
     else
@@ -589,12 +597,13 @@ __device__ __forceinline__ float wave_total_dpp(float v) {
     return (r0 + r1) + (r2 + r3);
 }
 
-template <int KMAX, int DMAX>
+template <int KMAX, int DMAX, bool EXACT = false>
 __global__ __launch_bounds__(256) void soft_embedding_bwd_kernel(
     const float* __restrict__ dout, const float* __restrict__ x, const float* __restrict__ pw,
     const float* __restrict__ pb, const float* __restrict__ table, const float* __restrict__ lnw,
-    float* __restrict__ partA, float* __restrict__ partB, long ntok, int W, int col, int K, int D,
+    float* __restrict__ partA, float* __restrict__ partB, long ntok, int W, int col, int K_rt, int D_rt,
     float eps) {
+    const int K = EXACT ? KMAX : K_rt, D = EXACT ? DMAX : D_rt;      // EXACT: see soft_embedding_fwd_kernel
     // per-wave slots: [4][K D | K | K | D | D]
     __shared__ float red[4][KMAX * DMAX + 2 * KMAX + 2 * DMAX];
     const int nA = K * D + 2 * K, nB = 2 * D;
@@ -716,7 +725,10 @@ extern "C" int t4r_soft_embedding_bwd(void* stream, const float* dout, const flo
     float* partB = ws + (long)nblocks * nA;
     dim3 grid((unsigned)nblocks), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (K <= 16 && D <= 8)
+    if (K == 10 && D == 8)
+        hipLaunchKernelGGL((soft_embedding_bwd_kernel<10, 8, true>), grid, block, 0, st, dout, x, proj_w,
+                           proj_b, table, ln_w, partA, partB, ntok, W, col, K, D, eps);
+    else if (K <= 16 && D <= 8)
         hipLaunchKernelGGL((soft_embedding_bwd_kernel<16, 8>), grid, block, 0, st, dout, x, proj_w,
                            proj_b, table, ln_w, partA, partB, ntok, W, col, K, D, eps);
     else

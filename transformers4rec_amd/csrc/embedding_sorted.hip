@@ -80,6 +80,72 @@ extern "C" int t4r_sort_ids(void* stream, const long* ids, long n, long rows, in
     return 0;
 }
 
+// ---------------------------------------------------------------------------------- several tables, ONE sort
+// A multi-feature input block (BASELINE configs[2]: item id + three more categoricals) sorts the lookups of every table in
+// the forward pass: F sorts of n pairs are ~10 small launches EACH on the caller's stream (hipCUB picks its merge sort at
+// n = 20 480).  The lookups of all F tables sorted as ONE array of F n pairs -- feature f's keys moved into its own range
+// [off_f, off_f + rows_f], off_f = sum_{g<f} (rows_g + 1) -- leave every feature's n pairs in positions [f n, (f + 1) n) of the
+// result, in the order its own sort would have given (the sort is stable, the ranges are disjoint): a third of the launches.
+constexpr int kSortMaxFeatures = 16;
+struct SortMulti { const long* ids[kSortMaxFeatures]; long rows[kSortMaxFeatures]; long off[kSortMaxFeatures]; int pad[kSortMaxFeatures]; int F; long n; };
+
+__global__ __launch_bounds__(256) void emb_keys_multi_kernel(SortMulti p, int* __restrict__ keys, int* __restrict__ idx) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n * p.F) return;
+    const int f = (int)(i / p.n);
+    const long id = p.ids[f][i - f * p.n];
+    const long rows = p.rows[f];
+    keys[i] = (int)(p.off[f] + ((id == p.pad[f] || id < 0 || id >= rows) ? rows : id));
+    idx[i] = (int)i;
+}
+// back to each feature's own row ids and lookup indices
+__global__ __launch_bounds__(256) void emb_keys_multi_fix_kernel(SortMulti p, int* __restrict__ keys, int* __restrict__ perm) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n * p.F) return;
+    const int f = (int)(i / p.n);
+    keys[i] -= (int)p.off[f];
+    perm[i] -= (int)(f * p.n);
+}
+
+extern "C" long t4r_sort_ids_multi_ws_bytes(long n, int F) { return (n <= 0 || F <= 0) ? 0 : (long)sort_layout(n * F).total; }
+
+// ids: HOST array of F device pointers (n int64 lookups each); rows / padding_idx: host arrays [F].
+// keys_sorted / perm: [F * n]; feature f's result is the slice [f n, (f + 1) n) -- what t4r_sort_ids gives for it alone.
+extern "C" int t4r_sort_ids_multi(void* stream, const long* const* ids, int F, long n, const long* rows, const int* padding_idx,
+                                  int* keys_sorted, int* perm, void* ws, long ws_bytes) {
+    if (n <= 0 || F <= 0) return 0;
+    T4R_CHECK_ARG(ids && rows && padding_idx && keys_sorted && perm && ws, "sort_ids_multi: null pointer");
+    T4R_CHECK_ARG(F <= kSortMaxFeatures, "sort_ids_multi: at most 16 tables per call");
+    SortMulti p;
+    p.F = F; p.n = n;
+    long off = 0;
+    for (int f = 0; f < F; ++f) {
+        T4R_CHECK_ARG(ids[f] && rows[f] > 0, "sort_ids_multi: null ids or empty table");
+        p.ids[f] = ids[f]; p.rows[f] = rows[f]; p.pad[f] = padding_idx[f]; p.off[f] = off;
+        off += rows[f] + 1;
+    }
+    T4R_CHECK_ARG(n * F < (1L << 31) && off < (1L << 31) - 1, "sort_ids_multi: sizes must fit 31 bits");
+    const SortLayout l = sort_layout(n * F);
+    T4R_CHECK_ARG(ws_bytes >= (long)l.total, "sort_ids_multi: workspace too small (t4r_sort_ids_multi_ws_bytes)");
+    hipStream_t st = (hipStream_t)stream;
+    char* w = (char*)ws;
+    int* keys_in = (int*)(w + l.keys_in);
+    int* idx_in = (int*)(w + l.idx_in);
+    const unsigned grid = (unsigned)((n * F + 255) / 256);
+    hipLaunchKernelGGL(emb_keys_multi_kernel, dim3(grid), dim3(256), 0, st, p, keys_in, idx_in);
+    int end_bit = 1;
+    while (end_bit < 31 && (1L << end_bit) < off) ++end_bit;       // bits of the largest key (= off - 1)
+    size_t tb = l.tmp_bytes;
+    if (hipcub::DeviceRadixSort::SortPairs(w + l.tmp, tb, keys_in, keys_sorted, idx_in, perm, (int)(n * F), 0, end_bit, st) !=
+        hipSuccess) {
+        t4r_set_error("sort_ids_multi: device radix sort failed");
+        return -1;
+    }
+    hipLaunchKernelGGL(emb_keys_multi_fix_kernel, dim3(grid), dim3(256), 0, st, p, keys_sorted, perm);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
 // per-lane slice of a gradient row: NV vectors of VEC floats, vector j at column cb + (lane + 64*j)*VEC
 template <int VEC> struct FV { float v[VEC]; };
 template <int VEC>

@@ -77,6 +77,29 @@ def _sort_ids_forward(ids, rows, padding_idx):
     return keys, perm, done
 
 
+_SORT_MULTI = os.environ.get("T4R_EMB_SORT_MULTI", "1") != "0"
+
+
+def _sort_ids_forward_multi(ids_list, rows_list, padding_idx):
+    """_sort_ids_forward for the F tables of one input block at once -> [(keys, perm) or (keys, perm, event)] per table"""
+    pads = [padding_idx] * len(ids_list)
+    if os.environ.get("T4R_EMB_SORT_STREAM", "0") != "1":
+        return ops.sort_ids_multi(ids_list, rows_list, pads)
+    dev = ids_list[0].device
+    key = (dev.type, dev.index)
+    if key not in _SORT_STREAMS:
+        _SORT_STREAMS[key] = torch.cuda.Stream(device=dev)
+    side = _SORT_STREAMS[key]
+    side.wait_stream(torch.cuda.current_stream())
+    for ids in ids_list:
+        ids.record_stream(side)
+    with torch.cuda.stream(side):
+        srt = ops.sort_ids_multi(ids_list, rows_list, pads)
+        done = torch.cuda.Event()
+        done.record(side)
+    return [(k, p, done) for k, p in srt]
+
+
 class EmbeddingTable(nn.Module):
     """nn.Embedding-shaped parameter holder (`weight`, num_embeddings, embedding_dim, padding_idx)."""
 
@@ -515,11 +538,20 @@ class _SeqFeaturesFn(torch.autograd.Function):
         # the sort behind the deterministic table gradient depends on the ids only: done here, in the forward
         ctx.sorted_ids = {}
         if training and _EMB_BWD != "atomic":
+            todo = []
             for name in names:
                 if name in cat.embedding_tables:
                     tab = cat.embedding_tables[name].weight
                     if tab.requires_grad and getattr(tab, "_t4r_sparse_sink", None) is None:
-                        ctx.sorted_ids[name] = _sort_ids_forward(inputs[name].contiguous(), tab.shape[0], cat.padding_idx)
+                        todo.append((name, inputs[name].contiguous(), tab.shape[0]))
+            if len(todo) > 1 and len({t[1].numel() for t in todo}) == 1 and len(todo) <= 16 and _SORT_MULTI:
+                # every table of a multi-feature block in ONE device sort (a third of the launches: ops.sort_ids_multi)
+                srt = _sort_ids_forward_multi([t[1] for t in todo], [t[2] for t in todo], cat.padding_idx)
+                for (name, _i, _r), s_f in zip(todo, srt):
+                    ctx.sorted_ids[name] = s_f
+            else:
+                for name, ids_n, rows_n in todo:
+                    ctx.sorted_ids[name] = _sort_ids_forward(ids_n, rows_n, cat.padding_idx)
         ctx.mask_mode, ctx.mask, ctx.dims, ctx.post_step = mask_mode, mask, (B, L, L_out, W), step
         ctx.agg_out = agg_out if proj is not None else None
         ctx.proj_out = out if proj is not None else None

@@ -421,6 +421,27 @@ def sort_ids(ids, rows, padding_idx=0):
     return keys, perm
 
 
+def sort_ids_multi(ids_list, rows_list, padding_idx_list):
+    """sort_ids for several tables in ONE device sort (csrc/embedding_sorted.hip: t4r_sort_ids_multi): every ids tensor has
+    the same number of lookups n -> [(keys_sorted, perm)] per table, each exactly what sort_ids gives for it alone (views
+    of two [F * n] buffers)."""
+    F = len(ids_list)
+    ids_list = [i.contiguous().view(-1) for i in ids_list]
+    n = ids_list[0].numel()
+    if F > 16 or any(i.numel() != n for i in ids_list):
+        return [sort_ids(i, r, p) for i, r, p in zip(ids_list, rows_list, padding_idx_list)]
+    dev = ids_list[0].device
+    keys = torch.empty(F * n, device=dev, dtype=torch.int32)
+    perm = torch.empty(F * n, device=dev, dtype=torch.int32)
+    nb = _lib.load().t4r_sort_ids_multi_ws_bytes(n, F)
+    ws = torch.empty(max(nb, 1), device=dev, dtype=torch.uint8)
+    parr, _k0 = ptr_array([_chk(i, torch.int64) for i in ids_list])
+    rows, _k1 = long_array([int(r) for r in rows_list])
+    pads, _k2 = int_array([int(p) for p in padding_idx_list])
+    call("t4r_sort_ids_multi", _stream(), parr, F, n, rows, pads, keys.data_ptr(), perm.data_ptr(), ws.data_ptr(), nb)
+    return [(keys[f * n:(f + 1) * n], perm[f * n:(f + 1) * n]) for f in range(F)]
+
+
 def embedding_bwd_sorted(dout, keys, perm, d_table, col, dim, ids_div=1):
     """deterministic d_table[id] += gradient rows (ascending lookup order, one owner per row, no atomics).
     dout [n * ids_div, W]; (keys, perm) from sort_ids."""

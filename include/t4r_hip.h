@@ -181,6 +181,14 @@ int t4r_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, floa
                  const float* bias, int epilogue, float* aux, long ldaux, int splitk, int accumulate,
                  int batch, long strideA, long strideB, long strideC, float drop_p,
                  unsigned long long seed, unsigned long long ctr_hi);
+/* Deterministic split-K for a caller's weight gradients (autograd of torch.nn.Linear's weight, block/mlp.py:133-135): between
+ * _begin and _end every ACCUMULATING split-K t4r_gemm_f32 (dense C, epilogue 0) issued by THIS thread stores its partial tiles
+ * into ws (cap_floats floats; M * N * splits per launch, up to 20 launches) instead of adding them with atomics, and _flush adds
+ * them to C in split order with one launch -- the sum no longer depends on the order the workgroups finish.  A launch that
+ * does not fit the workspace falls back to atomics.  The XLNet layer backward uses the same mechanism internally. */
+void t4r_gemm_splitk_sink_begin(float* ws, long cap_floats);
+int t4r_gemm_splitk_sink_flush(void* stream);
+void t4r_gemm_splitk_sink_end(void);
 
 /* Precision of every dense contraction launched after the call (process-wide setting; T4R_GEMM_PREC sets
  * the default):

@@ -320,3 +320,30 @@ def test_one_sort_for_several_tables_equals_the_per_table_sorts(n, rows):
     for f, r in enumerate(rows):
         k, p = ops.sort_ids(ids[f], r, 0)
         assert torch.equal(multi[f][0], k) and torch.equal(multi[f][1], p), f
+
+
+def test_multi_feature_training_steps_are_bit_reproducible():
+    """BASELINE configs[2] (item id + three categoricals + two SoftEmbeddings, concat, projection): three optimizer steps from
+    the same seeds, twice -- identical losses and identical parameters bit for bit.  The projection's weight gradient was the
+    last sum of that step taken with fp32 atomics in arrival order (ops.gemm_wgrad: split-K partials added in split order)."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    dev = torch.device("cuda", 0)
+
+    def run():
+        tr, schema, model, dense, tables, opt = bench.build(dev, 0.3, config="c3")
+        reducer, _ = bench.setup_data_parallel(tr, model, dense, tables, 1)
+        model.input_features.masking.seed, model.transformer_block.transformer.seed = bench.rank_seeds(0)
+        batches = [tr.random_data_from_schema(schema, bench.BATCH, bench.SEQ, seed=i, device=dev) for i in range(3)]
+        model.train()
+        step = bench.make_train_step(model, batches, reducer, opt)
+        losses = [float(step(i)["loss"]) for i in range(3)]
+        torch.cuda.synchronize()
+        return losses, [f.data.clone() for f in opt.flats]
+
+    la, pa = run()
+    lb, pb = run()
+    assert la == lb
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b)

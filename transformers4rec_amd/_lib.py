@@ -46,6 +46,9 @@ _SIGS = {
     "t4r_scatter_rows_add": ("i", "ppppii"),
     "t4r_last_positions": ("i", "ppiiiilp"),
     "t4r_gemm_f32": ("i", "piiiiif" + "plplpl" + "pipl" + "iii" + "lll" + "fQQ"),
+    "t4r_gemm_splitk_sink_begin": ("v", "pl"),
+    "t4r_gemm_splitk_sink_flush": ("i", "p"),
+    "t4r_gemm_splitk_sink_end": ("v", ""),
     "t4r_mha_fwd": ("i", "pppplplp" + "iiiii" + "fQQ" + "p"),
     "t4r_mha_bwd": ("i", "pppplpplppppl" + "iiiii" + "fQQ" + "p"),
     "t4r_add_pos_fwd": ("i", "ppppp" + "iii"),

@@ -554,6 +554,13 @@ __global__ __launch_bounds__(256) void soft_embedding_fwd_kernel(
     for (int d = 0; d < DMAX; ++d) if (d < D) out[t * D + d] = e[d];
 }
 
+// T4R_SOFT_EXACT=0: the general (run-time K, D) kernels for every shape (A/B and parity of the exact-shape instantiation)
+static bool soft_exact_on() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("T4R_SOFT_EXACT"); on = e ? (atoi(e) != 0) : 1; }
+    return on != 0;
+}
+
 extern "C" int t4r_soft_embedding_fwd(void* stream, const float* x, const float* proj_w,
                                       const float* proj_b, const float* table, const float* ln_w,
                                       const float* ln_b, float* out, long ntok, int K, int D,
@@ -563,7 +570,7 @@ extern "C" int t4r_soft_embedding_fwd(void* stream, const float* x, const float*
                   "soft_embedding_fwd: K<=32, dim<=32");
     dim3 grid((unsigned)((ntok + 255) / 256)), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (K == 10 && D == 8)
+    if (K == 10 && D == 8 && soft_exact_on())
         hipLaunchKernelGGL((soft_embedding_fwd_kernel<10, 8, true>), grid, block, 0, st, x, proj_w, proj_b,
                            table, ln_w, ln_b, out, ntok, K, D, eps);
     else if (K <= 16 && D <= 8)
@@ -725,7 +732,7 @@ extern "C" int t4r_soft_embedding_bwd(void* stream, const float* dout, const flo
     float* partB = ws + (long)nblocks * nA;
     dim3 grid((unsigned)nblocks), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (K == 10 && D == 8)
+    if (K == 10 && D == 8 && soft_exact_on())
         hipLaunchKernelGGL((soft_embedding_bwd_kernel<10, 8, true>), grid, block, 0, st, dout, x, proj_w,
                            proj_b, table, ln_w, partA, partB, ntok, W, col, K, D, eps);
     else if (K <= 16 && D <= 8)

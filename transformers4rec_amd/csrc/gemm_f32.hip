@@ -126,6 +126,14 @@ int t4r_splitk_sink_flush(hipStream_t st) {
     return 0;
 }
 void t4r_splitk_sink_end() { g_sink.on = false; g_sink.ws = nullptr; g_sink.cap = 0; g_sink.jobs.n = 0; }
+// The same mechanism for a caller outside the layer (C ABI, include/t4r_hip.h): between _begin and _end every ACCUMULATING
+// split-K t4r_gemm_f32 of this thread stores its partial tiles into `ws` instead of adding them with atomics; _flush adds
+// them in split order (one launch).  The input block's projection weight gradient uses it (features.py): it was the one
+// order-dependent sum of a BASELINE configs[2] training step.
+extern "C" void t4r_gemm_splitk_sink_begin(float* ws, long cap_floats) { t4r_splitk_sink_begin(ws, cap_floats); }
+extern "C" int t4r_gemm_splitk_sink_flush(void* stream) { return t4r_splitk_sink_flush((hipStream_t)stream); }
+extern "C" void t4r_gemm_splitk_sink_end(void) { t4r_splitk_sink_end(); }
+
 // a split-K launch asks for room: returns the partial buffer (and registers the jobs) or null (-> atomics)
 static float* splitk_sink_take(const GemmParams& p, int batch) {
     SplitKSink& k = g_sink;

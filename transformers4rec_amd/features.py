@@ -573,8 +573,9 @@ class _SeqFeaturesFn(torch.autograd.Function):
             H = d.shape[-1]
             d2 = d.view(B * L, H)
             ops.act_bwd_bias(d2, ctx.proj_out.view(B * L, H), None if lin.bias is None else _grad_buf(lin.bias), 1)
-            ops.gemm(d2, ctx.agg_out.view(B * L, W), True, False, splitk=-1, accumulate=True,
-                     out=_grad_buf(lin.weight))
+            # the projection's weight gradient (K = tokens): split-K with the partials added in split order, not atomics --
+            # it was the one order-dependent sum of a configs[2] step
+            ops.gemm_wgrad(d2, ctx.agg_out.view(B * L, W), _grad_buf(lin.weight))
             d = ops.gemm(d2, lin.weight.detach(), False, False).view(B, L, W)
         names = mod._feature_order
         agg = mod._aggregation

@@ -107,6 +107,25 @@ def gemm(a, b, trans_a=False, trans_b=False, alpha=1.0, bias=None, epilogue=EPI_
     return out
 
 
+def gemm_wgrad(a, b, out):
+    """out[M, N] += a[K, M]^T @ b[K, N] over a long K (a weight gradient: K = tokens) with DETERMINISTIC split-K: the partial
+    tiles go to a scratch buffer and one more launch adds them in split order (csrc/gemm_f32.hip: the split-K sink) instead
+    of fp32 atomics in arrival order.  Needs a dense `out`; otherwise (or if the partials do not fit) plain gemm(splitk=-1)."""
+    M, N, K = a.shape[1], b.shape[1], a.shape[0]
+    if not (out.is_contiguous() and (M * N) % 4 == 0 and out.data_ptr() % 16 == 0):
+        return gemm(a, b, True, False, splitk=-1, accumulate=True, out=out)
+    lib = _lib.load()
+    splits = max(1, min(256, K // 320 + 1))      # the launcher's rule: >= 20 k-tiles of 16 per split, <= 256 splits
+    ws = torch.empty(M * N * splits, device=a.device, dtype=torch.float32)
+    lib.t4r_gemm_splitk_sink_begin(ws.data_ptr(), ws.numel())
+    try:
+        gemm(a, b, True, False, splitk=-1, accumulate=True, out=out)
+        call("t4r_gemm_splitk_sink_flush", _stream())
+    finally:
+        lib.t4r_gemm_splitk_sink_end()
+    return out
+
+
 def gemm_softmax_grad(logits, lse, labels, grad_out, V, b, trans_a, alpha=1.0, label_smoothing=0.0,
                       out=None, splitk=1, accumulate=False):
     """trans_a=False: out[N_rows, N] = alpha * dlogits @ b[V, N] ; True: out[V, N] = alpha * dlogits^T @ b[N_rows, N]

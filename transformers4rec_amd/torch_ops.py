@@ -599,7 +599,7 @@ def linear_relu_grad(dy: torch.Tensor, y: torch.Tensor, x: torch.Tensor, weight:
     db = torch.zeros(weight.shape[0], device=dy.device)
     ops.act_bwd_bias(d, y.contiguous(), db, 1)
     dW = torch.zeros_like(weight)
-    ops.gemm(d, x.contiguous(), True, False, splitk=-1, accumulate=True, out=dW)
+    ops.gemm_wgrad(d, x.contiguous(), dW)           # deterministic split-K, as the module mirror (features.py)
     return ops.gemm(d, weight.detach(), False, False), dW, db
 
 

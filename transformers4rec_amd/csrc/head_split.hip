@@ -1187,8 +1187,13 @@ __device__ __forceinline__ float dpp_row_shr_max(float x, int ctrl4) {
     return fmaxf(x, __int_as_float(y));
 }
 
+// launch_bounds(256, 2): TWO waves per SIMD.  Left alone the compiler took 213 registers + 80 accumulation registers = ONE wave
+// per SIMD, i.e. one workgroup per CU although the 66 KB of LDS let two in (the host code below launches one residency of
+// two per CU: the 506 workgroups of BASELINE configs[1] ran as two rounds); asked for two waves it fits 222 registers with no
+// spill, both workgroups are resident and each fills the other's waits: 723 -> 609 us stand-alone, 2.83 -> 2.70 ms per step
+// (profiles/r05_y_ab.txt).  The same request on head_dw_split_kernel (3 waves, 161 registers) measured 0.02 ms slower: not kept.
 template <int NB>
-__global__ __launch_bounds__(256) void head_fwd_dx_kernel(const float* __restrict__ X, long ldx, const u32x4* __restrict__ WA,
+__global__ __launch_bounds__(256, 2) void head_fwd_dx_kernel(const float* __restrict__ X, long ldx, const u32x4* __restrict__ WA,
                                                           const u32x4* __restrict__ WTP, float* __restrict__ C, long ldc,
                                                           int vec_ok, float* __restrict__ part, float* __restrict__ st_m,
                                                           float* __restrict__ st_s, float* __restrict__ st_t,

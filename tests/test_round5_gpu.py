@@ -347,3 +347,29 @@ def test_multi_feature_training_steps_are_bit_reproducible():
     assert la == lb
     for a, b in zip(pa, pb):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("D", [128, 64, 32])
+def test_tiled_weight_planes_equal_the_element_wise_ones(D, monkeypatch):
+    """layer_planes_tiled_kernel (32 x 32 tiles, transposed destinations through LDS) writes the same bytes as
+    layer_planes_kernel: every plane of every weight matrix of a layer, both orientations, and the fp32 copies."""
+    from transformers4rec_amd import ops
+
+    torch.manual_seed(D)
+    n, dh = 4, D // 4
+    g32 = lambda *s, std=0.05: torch.randn(*s, device=DEV) * std
+    prm = [g32(D, n, dh), g32(D, n, dh), g32(D, n, dh), g32(D, n, dh), g32(D, n, dh), g32(n, dh), g32(n, dh), 1 + g32(D), g32(D),
+           g32(4 * D, D), g32(4 * D), g32(D, 4 * D), g32(D), 1 + g32(D), g32(D)]
+    from transformers4rec_amd import _lib
+
+    def planes_of(tiled):
+        monkeypatch.setenv("T4R_PLANES_TILED", tiled)
+        planes = torch.zeros(_lib.load().t4r_xlnet_layer_planes_floats(D), device=DEV, dtype=torch.float32)   # unwritten gaps stay 0
+        ptrs, _keep = _lib.ptr_array([t.data_ptr() for t in prm])
+        _lib.call("t4r_xlnet_layer_prepare", torch.cuda.current_stream().cuda_stream, ptrs, D, planes.data_ptr())
+        torch.cuda.synchronize()
+        return planes
+
+    a, b = planes_of("0"), planes_of("1")
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    assert int((a.view(torch.int32) != 0).sum()) > a.numel() // 4        # the comparison is not of two empty buffers

@@ -86,6 +86,80 @@ __global__ __launch_bounds__(256) void layer_planes_kernel(PlaneJobs jobs) {
     }
 }
 
+// The same planes (fp16 form) from 32 x 32 tiles, one per wave: coalesced 16-byte reads, the cut once, and BOTH orientations written
+// as full 64-byte row segments -- the transposed ones through an LDS tile.  layer_planes_kernel above gives every thread two
+// source elements and writes a transposed destination as single 2-byte stores 2 * dcols apart: 3.2 M partial-line writes per
+// step, 26 us for 12 MB of planes at BASELINE configs[1].  Same bytes out (tests/test_round5_gpu.py compares the two).
+// Requirements (checked by the host): fp16 form only (dst == null), rows and cols multiples of 32.
+__global__ __launch_bounds__(256) void layer_planes_tiled_kernel(PlaneJobs jobs) {
+    constexpr int HP = 40, FP = 36;                      // LDS pitches: 16-bit tile rows (80 B), fp32 tile rows (144 B)
+    __shared__ __attribute__((aligned(16))) uint16_t th[4][2][32 * HP];
+    __shared__ __attribute__((aligned(16))) float tf[4][32 * FP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_tiles = jobs.total / 512;
+    const int gw0 = blockIdx.x * 4 + wave;
+    const bool active = gw0 < n_tiles;
+    const int gw = active ? gw0 : n_tiles - 1;
+    int k = 0;
+#pragma unroll 1
+    for (int q = 1; q < jobs.n; ++q) k = gw * 512 >= jobs.j[q].pair0 ? q : k;
+    const PlaneJob& jb = jobs.j[k];
+    const int lt = gw - jb.pair0 / 512, tpr = jb.cols / 32;
+    const int tr = (lt / tpr) * 32, tc = (lt % tpr) * 32;          // tile origin in the source
+    const int lr = lane >> 3, lc = (lane & 7) * 4;
+    const float sc = *jb.scale;
+    uint16_t* dh = jb.dst_h;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = lr + 8 * i;
+        const float4 v = *reinterpret_cast<const float4*>(jb.src + (long)(tr + r) * jb.cols + tc + lc);
+        uint32_t wa[2], wb[2];
+        cut2h(v.x * sc, v.y * sc, wa);
+        cut2h(v.z * sc, v.w * sc, wb);
+        if (!jb.transpose) {
+            const long o = (long)(jb.r0 + tr + r) * jb.dcols + jb.c0 + tc + lc;
+            if (active) {
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    *reinterpret_cast<uint2*>(dh + (long)pl * jb.dplane + o) = make_uint2(wa[pl], wb[pl]);
+                if (jb.dst32) *reinterpret_cast<float4*>(jb.dst32 + o) = v;
+            }
+        } else {
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                uint16_t* t = th[wave][pl];
+                t[(lc + 0) * HP + r] = (uint16_t)(wa[pl] & 0xffffu);
+                t[(lc + 1) * HP + r] = (uint16_t)(wa[pl] >> 16);
+                t[(lc + 2) * HP + r] = (uint16_t)(wb[pl] & 0xffffu);
+                t[(lc + 3) * HP + r] = (uint16_t)(wb[pl] >> 16);
+            }
+            if (jb.dst32) {
+                float* t = tf[wave];
+                t[(lc + 0) * FP + r] = v.x; t[(lc + 1) * FP + r] = v.y; t[(lc + 2) * FP + r] = v.z; t[(lc + 3) * FP + r] = v.w;
+            }
+        }
+    }
+    __syncthreads();
+    if (jb.transpose && active) {
+        // destination row = source column: lane -> (row cl, half of its 32 entries)
+        const int cl = lane >> 1, half = lane & 1;
+        const long o = (long)(jb.r0 + tc + cl) * jb.dcols + jb.c0 + tr + 16 * half;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            const uint4* t = reinterpret_cast<const uint4*>(th[wave][pl] + cl * HP + 16 * half);
+            uint4* d = reinterpret_cast<uint4*>(dh + (long)pl * jb.dplane + o);
+            d[0] = t[0];
+            d[1] = t[1];
+        }
+        if (jb.dst32) {
+            const float4* t = reinterpret_cast<const float4*>(tf[wave] + cl * FP + 16 * half);
+            float4* d = reinterpret_cast<float4*>(jb.dst32 + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = t[e];
+        }
+    }
+}
+
 // max |src| of every source matrix -> its power-of-two scale (one workgroup per source: 16-64 k elements, one coalesced
 // pass); a source with `raw` set stores the maximum itself (the bias vector b1)
 struct AmaxJob { const float* src; float* out; int n; int raw; };
@@ -167,6 +241,19 @@ static void add_layer_jobs(PlaneJobs& js, AmaxJobs& aj, const float* q, const fl
 static int launch_jobs(hipStream_t st, const PlaneJobs& js, const AmaxJobs& aj) {
     if (js.total == 0) return 0;
     if (aj.n > 0) hipLaunchKernelGGL(weight_scales_kernel, dim3(aj.n), dim3(1024), 0, st, aj);
+    // the tiled form takes the fp16 planes of matrices whose sides are multiples of 32 with 16-byte-aligned destinations
+    const char* tiled_env = getenv("T4R_PLANES_TILED");        // read per call (two launches per step): a test flips it in-process
+    bool tiled = !tiled_env || atoi(tiled_env) != 0;
+    for (int i = 0; i < js.n && tiled; ++i) {
+        const PlaneJob& j = js.j[i];
+        tiled = !j.dst && j.dst_h && j.rows % 32 == 0 && j.cols % 32 == 0 && j.dcols % 8 == 0 && j.r0 % 32 == 0 && j.c0 % 32 == 0 &&
+                ((uintptr_t)j.src & 15) == 0 && ((uintptr_t)j.dst_h & 15) == 0 && (j.dplane % 8) == 0 && ((uintptr_t)j.dst32 & 15) == 0;
+    }
+    if (tiled) {
+        hipLaunchKernelGGL(layer_planes_tiled_kernel, dim3((unsigned)((js.total / 512 + 3) / 4)), dim3(256), 0, st, js);
+        T4R_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(layer_planes_kernel, dim3((unsigned)((js.total + 255) / 256)), dim3(256), 0, st, js);
     T4R_LAUNCH_CHECK();
     return 0;

@@ -60,10 +60,12 @@ WORKLOADS = {
 }
 
 
-def build(device, dropout, v_items=V_ITEMS, d_model=D_MODEL, n_layer=N_LAYER, n_head=N_HEAD, seq=SEQ, lr=1e-3, config="c2"):
+def build_modules(dropout, v_items=V_ITEMS, d_model=D_MODEL, n_layer=N_LAYER, n_head=N_HEAD, seq=SEQ, config="c2", seed=0):
+    """the benchmarked model on the CPU, freshly initialised from torch.manual_seed(seed) (no device, no optimizer): what
+    `build` moves to the GPU, and what oracle/cpu_lockstep.py takes its identical initial parameters from"""
     import transformers4rec_amd as tr
 
-    torch.manual_seed(0)
+    torch.manual_seed(seed)
     if config == "c3":
         schema = tr.session_schema(v_items, seq, C3_CATS, C3_CONTS)
         inputs = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=seq, masking="mlm", aggregation="concat",
@@ -75,6 +77,11 @@ def build(device, dropout, v_items=V_ITEMS, d_model=D_MODEL, n_layer=N_LAYER, n_
                                                         embedding_dim_default=d_model)
     cfg = tr.XLNetConfig.build(d_model, n_head, n_layer, total_seq_length=seq, dropout=dropout)
     model = cfg.to_torch_model(inputs, tr.NextItemPredictionTask(weight_tying=True))
+    return tr, schema, model
+
+
+def build(device, dropout, v_items=V_ITEMS, d_model=D_MODEL, n_layer=N_LAYER, n_head=N_HEAD, seq=SEQ, lr=1e-3, config="c2", seed=0):
+    tr, schema, model = build_modules(dropout, v_items, d_model, n_layer, n_head, seq, config, seed)
     model.to(device)
     dense, tables = tr.flatten_model(model)
     opt = tr.FusedAdam([dense, tables], lr=lr)

@@ -116,3 +116,85 @@ def test_task_without_hip_features_raises():
     batch = tr.random_data_from_schema(schema, 8, 20, seed=1, device=dev)
     with pytest.raises(RuntimeError, match="label compaction"):
         model(batch, training=True)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Fixture replay THROUGH the drop-in (VERDICT r5 next #1d).  The fixtures under tests/golden/ are what the unmodified
+# reference's Model.forward (torch/model/base.py:544-598 -> Head.forward :371-425 -> SequentialBlock.forward,
+# block/base.py:236-262) returned on the CPU -- loss, predictions, labels, every parameter gradient -- together with the
+# draws it took (oracle/make_golden.py).  Here a model with the reference's module tree and state_dict names gets its three
+# hot-path modules class-swapped by dropin.convert_model, loads the fixture's state_dict, replays the draws and must return
+# what the reference returned.  Unlike tests/test_dropin_reference_gpu.py this needs no reference source tree (which, being
+# Python source, may not travel to a GPU box), so it runs in the driver's round-end GPU suite: the head of THIS round's tree
+# behind the drop-in against reference outputs.
+FIXTURE_CASES = {
+    "xlnet_mlm_item_train": dict(emb_default=32),
+    "xlnet_mlm_multi_train": dict(cats=(("category", 40), ("brand", 9)), conts=("price", "age"), d_output=32,
+                                  embedding_dims={"item_id": 16, "category": 24, "brand": 8}),
+    "xlnet_clm_item_train": dict(masking="clm", emb_default=32, weight_tying=False),
+    "gpt2_clm_item_train": dict(masking="clm", emb_default=32, arch="gpt2"),
+    "bert_mlm_item_train": dict(emb_default=32, arch="bert"),
+}
+
+
+def _converted_fixture_model(name, params_from=None):
+    import golden_utils as gu
+    import test_e2e_gpu as e2e
+    import transformers4rec_amd as tr
+    from transformers4rec_amd import dropin
+
+    d = gu.load(name, params_from)
+    model = e2e.build_model(d, **FIXTURE_CASES[params_from or name])
+    e2e.load_reference_state(model, d)
+    model.to("cuda")
+    ns = types.SimpleNamespace(TabularSequenceFeatures=tr.TabularSequenceFeatures, TransformerBlock=tr.TransformerBlock,
+                               NextItemPredictionTask=tr.NextItemPredictionTask)
+    keys = list(model.state_dict().keys())
+    dropin.convert_model(model, ns)
+    assert all(getattr(m, "_t4r_hip", False) for m in (model.input_features, model.transformer_block, model.prediction_task))
+    assert list(model.state_dict().keys()) == keys
+    return gu, d, model
+
+
+@pytest.mark.parametrize("name", sorted(FIXTURE_CASES))
+def test_reference_fixture_replayed_through_the_dropin_train(name):
+    gu, d, model = _converted_fixture_model(name)
+    model.train()
+    feats = model.input_features
+    if "draw/bern" in d:
+        feats.hip_shadow().masking.set_draws(gu.t(d["draw/bern"]).cuda().to(torch.uint8), gu.t(d["draw/j1"]).cuda(),
+                                             gu.t(d["draw/j2"]).cuda())
+    x = {k[3:]: gu.t(v).cuda() for k, v in d.items() if k.startswith("in/")}
+    out = model(x, training=True)
+    assert torch.equal(feats.masking.mask_schema.cpu(), gu.t(d["out/mask_schema"]))
+    assert torch.equal(feats.masking.masked_targets.cpu(), gu.t(d["out/masked_targets"]))
+    assert torch.equal(out["labels"].cpu(), gu.t(d["out/labels"]))
+    pred, loss = out["predictions"].detach().cpu(), float(out["loss"])
+    assert float((pred - gu.t(d["out/predictions"])).abs().max()) < 1e-3 and abs(loss - float(d["out/loss"])) < 1e-3   # north_star
+    torch.testing.assert_close(pred, gu.t(d["out/predictions"]), rtol=1e-4, atol=5e-5)
+    assert abs(loss - float(d["out/loss"])) < 5e-5
+    out["loss"].backward()
+    g = gu.section(d, "g/")
+    named = dict(model.named_parameters())
+    for k, ref in g.items():
+        assert named[k].grad is not None, f"no gradient reached {k}"
+        torch.testing.assert_close(named[k].grad.cpu(), ref, rtol=2e-4, atol=1e-4, msg=lambda m, k=k: f"{k}: {m}")
+    assert len(g) > 10
+    print(f"[fixture-through-dropin] {name}: loss {loss:.6f} (reference {float(d['out/loss']):.6f}), "
+          f"max |d predictions| {float((pred - gu.t(d['out/predictions'])).abs().max()):.2e}, {len(g)} gradients")
+
+
+@pytest.mark.parametrize("name,train", [("xlnet_mlm_item_eval", "xlnet_mlm_item_train"), ("xlnet_mlm_item_infer", "xlnet_mlm_item_train"),
+                                        ("xlnet_clm_item_eval", "xlnet_clm_item_train"), ("xlnet_clm_item_infer", "xlnet_clm_item_train")])
+def test_reference_fixture_replayed_through_the_dropin_eval_and_inference(name, train):
+    gu, d, model = _converted_fixture_model(name, train)
+    model.eval()
+    x = {k[3:]: gu.t(v).cuda() for k, v in d.items() if k.startswith("in/")}
+    with torch.no_grad():
+        out = model(x, testing=True) if name.endswith("_eval") else model(x)
+    if name.endswith("_eval"):
+        assert torch.equal(out["labels"].cpu(), gu.t(d["out/labels"]))
+        torch.testing.assert_close(out["predictions"].cpu(), gu.t(d["out/predictions"]), rtol=1e-4, atol=5e-5)
+        assert abs(float(out["loss"]) - float(d["out/loss"])) < 5e-5
+    else:
+        torch.testing.assert_close(out.cpu(), gu.t(d["out/predictions"]), rtol=1e-4, atol=5e-5)

@@ -130,3 +130,60 @@ def test_gpt2_bert_padding_mask_restatement_matches_hf(arch):
             got = O.bert_model(x, O.bert_params_from_state(m.state_dict()), n, 0.03, key_len=key_len)
     valid = attn_mask.bool()
     torch.testing.assert_close(got[valid], ref[valid], rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("B,L,D,n,layers", [(3, 20, 64, 4, 2), (2, 7, 32, 2, 3)])
+def test_xlnet_training_mode_restatement_matches_hf(B, L, D, n, layers):
+    """The whole-model training-mode composition (oracle xlnet_model_dropout: input dropout, ONE pos_emb mask shared by
+    the layers, four sites per layer, output dropout) against the installed HF XLNetModel in .train() with dropout 0.3
+    (XLNetConfig.build's default, config/transformer.py:440): the masks HF's nn.Dropout modules drew are recovered by
+    forward hooks (kept <=> output != 0 where the input is non-zero; where the input is zero the mask does not matter)
+    and handed to the oracle; outputs AND gradients must agree.  This pins the site list, the sharing of the pos_emb
+    mask, the 1/(1-p) scaling and the layouts (HF is time-first inside) -- the composition the full-size dropout-0.3
+    GPU test (tests/test_round6_gpu.py) then holds the HIP path to."""
+    p_drop = 0.3
+    cfg = transformers.XLNetConfig(
+        d_model=D, d_inner=4 * D, n_layer=layers, n_head=n, attn_type="bi", ff_activation="gelu",
+        initializer_range=0.01, layer_norm_eps=0.03, dropout=p_drop, pad_token_id=0, vocab_size=1, mem_len=1)
+    torch.manual_seed(2)
+    m = transformers.XLNetModel(cfg).train()
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            p.copy_(1 + 0.1 * torch.randn_like(p) if "layer_norm.weight" in name else 0.1 * torch.randn_like(p))
+    calls = {}
+
+    def hook(tag):
+        def fn(mod, inp, out):
+            calls.setdefault(tag, []).append(((out != 0) | (inp[0] == 0)).detach())
+        return fn
+
+    hs = [m.dropout.register_forward_hook(hook("model"))]
+    for i, l in enumerate(m.layer):
+        hs.append(l.rel_attn.dropout.register_forward_hook(hook(f"attn{i}")))
+        hs.append(l.ff.dropout.register_forward_hook(hook(f"ff{i}")))
+    x = torch.randn(B, L, D, requires_grad=True)
+    ref = m(inputs_embeds=x)[0]
+    for h in hs:
+        h.remove()
+    assert len(calls["model"]) == 3 and all(len(calls[f"attn{i}"]) == 2 and len(calls[f"ff{i}"]) == 2 for i in range(layers))
+    tf = lambda t: t.transpose(0, 1)            # HF [len, B, ...] -> batch-first
+    inp, pos, fin = calls["model"]
+    assert inp.shape == (L, B, D) and pos.shape == (2 * L, B, D) and fin.shape == (L, B, D)
+    masks = dict(input=tf(inp), pos=tf(pos), final=tf(fin), layers=[])
+    for i in range(layers):
+        prob, ao = calls[f"attn{i}"]
+        act, out = calls[f"ff{i}"]
+        assert prob.shape == (B, n, L, L) and act.shape == (L, B, 4 * D)
+        masks["layers"].append(dict(prob=prob, attn_out=tf(ao), ff_act=tf(act), ff_out=tf(out)))
+    xo = x.detach().clone().requires_grad_()
+    lp = [{k: v.detach().clone().requires_grad_() for k, v in O.xlnet_layer_params_from_hf(l).items()} for l in m.layer]
+    got = O.xlnet_model_dropout(xo, lp, n, 0.03, masks, p_drop)
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=2e-5)
+    w = torch.randn(B, L, D)
+    (ref * w).sum().backward()
+    (got * w).sum().backward()
+    torch.testing.assert_close(xo.grad, x.grad, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(lp[0]["r"].grad, m.layer[0].rel_attn.r.grad, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(lp[-1]["w1"].grad, m.layer[-1].ff.layer_1.weight.grad, rtol=1e-4, atol=2e-5)
+    # and the masks mattered
+    assert float((got - O.xlnet_model(xo, lp, n, 0.03)).abs().max()) > 1e-2

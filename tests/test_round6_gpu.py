@@ -1,0 +1,179 @@
+"""Round 6 (GPU): parity AT THE BENCHMARKED SETTING.
+
+  * the oracle's integer restatement of the device random streams (oracle/device_rng.py) against masks exported from
+    the device, bit for bit, every dropout site and the MLM draws;
+  * one whole training step of BASELINE configs[1] and configs[2] at FULL size (B 1024, V 100 001 rows, d 128, 4 layers)
+    with dropout 0.3 -- the configuration bench.py times -- against the CPU oracle given the SAME decisions at every
+    site (input, the pos_emb mask shared by the four layers, prob / attn_out / ff_act / ff_out per layer, output):
+    loss, logits (the north_star 1e-3 gate, asserted much tighter) and the item-table / layer / projection gradients;
+  * three optimizer steps of that configuration in lockstep (Adam both sides, masks and MLM targets from the
+    restatement alone -- nothing is read back from the device but the results).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import device_rng as R
+import golden_utils as gu
+import t4r_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import build_c
+    from transformers4rec_amd import ops as _ops
+
+    build_c.build()
+    return _ops
+
+
+def close(a, b, rtol=1e-4, atol=1e-5, msg=None):
+    torch.testing.assert_close(a.detach().cpu().float(), b.detach().cpu().float(), rtol=rtol, atol=atol, msg=msg)
+
+
+@pytest.mark.parametrize("n", [1, 5, 4096, 100_003])
+@pytest.mark.parametrize("p", [0.1, 0.3])
+def test_dropout_site_restatement_equals_the_device_mask(ops, n, p):
+    seed = 0x1234_5678_9ABC_DEF1 & 0x7FFFFFFFFFFFFFFF
+    for offset, layer, site in ((1, 0, ops.SITE_PROB), (70_000, 3, ops.SITE_FF_ACT), (2, 255, ops.SITE_POS),
+                                (1, 255, ops.SITE_INPUT), (9, 255, ops.SITE_FINAL), (5, 1, ops.SITE_ATTN_OUT), (5, 1, ops.SITE_FF_OUT)):
+        ctr = ops.dropout_ctr_hi(offset, layer, site)
+        assert ctr == R.dropout_ctr_hi(offset, layer, site)
+        _, m = ops.dropout(torch.ones(1, device=DEV), p, seed, ctr, n_total=n, want_mask=True)
+        assert np.array_equal(m.cpu().numpy(), R.dropout_keep(seed, ctr, n, p)), (offset, layer, site)
+
+
+@pytest.mark.parametrize("B,L", [(1024, 20), (257, 33), (64, 64)])
+def test_mlm_draw_restatement_equals_the_device_targets(ops, B, L):
+    g = torch.Generator().manual_seed(B + L)
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    lens[:8] = torch.tensor([1, 1, 2, 2, L, L, 3, 1])
+    ids = torch.randint(1, 100_000, (B, L), generator=g) * (torch.arange(L)[None] < lens[:, None])
+    for seed, offset in ((1234, 0), (4321, 7 * B * L), (2**62 + 11, 2**33 + 5)):
+        mask, labels, counts = ops.mask_targets(ids.to(DEV), ops.MLM_TRAIN, 0, None, None, None, 0.15, seed, offset)
+        m_ref, lab_ref = R.mlm_targets_train_device(ids, seed, offset, 0.15)
+        assert torch.equal(mask.cpu(), m_ref) and torch.equal(labels.cpu(), lab_ref)
+        assert torch.equal(counts.cpu().long(), m_ref.sum(1))
+
+
+def _bench_model(tr, multi, dropout, V=100_000, D=128, L=20, n_layer=4, lr=None):
+    cats = (("category", 1000), ("brand", 100), ("kind", 10)) if multi else ()
+    conts = ("price", "age") if multi else ()
+    schema = tr.session_schema(V, L, cats, conts)
+    kw = dict(max_sequence_length=L, masking="mlm")
+    if multi:
+        kw.update(continuous_soft_embeddings=True, d_output=D, embedding_dims={"item_id": D}, embedding_dim_default=64)
+    else:
+        kw.update(embedding_dim_default=D)
+    torch.manual_seed(0)
+    inputs = tr.TabularSequenceFeatures.from_schema(schema, **kw)
+    cfg = tr.XLNetConfig.build(D, 4, n_layer, total_seq_length=L, dropout=dropout)
+    model = cfg.to_torch_model(inputs, tr.NextItemPredictionTask(weight_tying=True))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(DEV).train()
+    return schema, model, sd
+
+
+@pytest.mark.parametrize("multi", [False, True], ids=["configs1", "configs2"])
+def test_full_size_dropout_step_vs_oracle(ops, multi):
+    """the benchmarked configuration, dropout 0.3, one training step: HIP vs the CPU oracle taking the same decisions."""
+    import transformers4rec_amd as tr
+
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    B, L, V, D, NL, p_drop = 1024, 20, 100_000, 128, 4, 0.3
+    schema, model, sd = _bench_model(tr, multi, p_drop)
+    xl, masking = model.transformer_block.transformer, model.input_features.masking
+    masking.seed, xl.seed = 1234, 4321          # bench.rank_seeds(0)
+    data = tr.random_data_from_schema(schema, B, L, seed=11)
+    out = model({k: v.to(DEV) for k, v in data.items()}, training=True)
+    out["loss"].backward()
+    assert xl._drop_offset == 1
+    # the decisions, from the restatement alone
+    mask, labels = R.mlm_targets_train_device(data["item_id"], 1234, 0, 0.15)
+    assert torch.equal(masking.mask_schema.cpu(), mask) and torch.equal(masking.masked_targets.cpu(), labels)
+    masks = R.xlnet_dropout_masks(B, L, D, 4, NL, p_drop, seed=4321, offset=1)
+    p = gu.oracle_params({"p/" + k: v.numpy() for k, v in sd.items()}, requires_grad=True)
+    ref = O.session_forward(p, dict(n_head=4, eps=0.03, item="item_id", masking="mlm"), data, mask, labels, True, False,
+                            drop=(p_drop, masks))
+    ref["loss"].backward()
+    dl = abs(float(out["loss"].detach()) - float(ref["loss"]))
+    dp = float((out["predictions"].detach().cpu() - ref["logits"].detach()).abs().max())
+    print(f"\n[dropout {p_drop} full size, multi={multi}] loss {float(ref['loss']):.6f}: |d loss| {dl:.2e}, max |d logits| {dp:.2e} "
+          f"over {tuple(ref['logits'].shape)}")
+    assert torch.equal(out["labels"].cpu(), ref["labels"])
+    assert dl < 1e-4 and dp < 1e-4                       # north_star: 1e-3
+    assert abs(float(ref["loss"]) - np.log(V + 1)) < 0.2
+    # the masks mattered: the dropout-0 forward of the same model is elsewhere
+    with torch.no_grad():
+        ref0 = O.session_forward(p, dict(n_head=4, eps=0.03, item="item_id", masking="mlm"), data, mask, labels, True, False)
+    assert float((ref0["logits"] - ref["logits"].detach()).abs().max()) > 10 * dp
+    g_hip = model.input_features.item_embedding_table.weight.grad.cpu()
+    g_ref = p["tables"]["item_id"].grad
+    close(g_hip, g_ref, rtol=1e-3, atol=2e-7)
+    close(g_hip.sum(0), g_ref.sum(0), rtol=1e-3, atol=1e-6)
+    close(masking.masked_item_embedding.grad, p["masked_item_embedding"].grad, rtol=2e-3, atol=2e-7)
+    for i in (0, NL - 1):
+        lay, lp = xl.layer[i], p["layers"][i]
+        close(lay.ff.layer_1.weight.grad, lp["w1"].grad, rtol=2e-3, atol=3e-7, msg=lambda m, i=i: f"layer {i} w1: {m}")
+        close(lay.ff.layer_2.weight.grad, lp["w2"].grad, rtol=2e-3, atol=3e-7, msg=lambda m, i=i: f"layer {i} w2: {m}")
+        close(lay.rel_attn.q.grad, lp["q"].grad, rtol=2e-3, atol=3e-7, msg=lambda m, i=i: f"layer {i} q: {m}")
+        close(lay.rel_attn.o.grad, lp["o"].grad, rtol=2e-3, atol=3e-7, msg=lambda m, i=i: f"layer {i} o: {m}")
+        close(lay.rel_attn.r.grad, lp["r"].grad, rtol=2e-3, atol=3e-7, msg=lambda m, i=i: f"layer {i} r: {m}")
+        close(lay.ff.layer_norm.weight.grad, lp["ff_ln_w"].grad, rtol=2e-3, atol=3e-6, msg=lambda m, i=i: f"layer {i} ln2: {m}")
+    if multi:
+        close(model.input_features.projection_module[0][0].weight.grad, p["proj"][0].grad, rtol=2e-3, atol=3e-7)
+        close(model.input_features.continuous_module.embedding_tables["price"].embedding_table.weight.grad,
+              p["soft"]["price"][2].grad, rtol=2e-3, atol=2e-6)
+
+
+def test_three_optimizer_steps_in_lockstep_at_the_benchmarked_setting(ops):
+    """configs[1], dropout 0.3, Adam lr 1e-3 (bench.py's optimizer), three steps: every step's loss and the parameters after
+    the third against the CPU oracle driven by the restated streams only (MLM offset advances by B*L per step, the dropout
+    offset by one per forward)."""
+    import transformers4rec_amd as tr
+
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    B, L, V, D, NL, p_drop, lr = 1024, 20, 100_000, 128, 4, 0.3, 1e-3
+    schema, model, sd = _bench_model(tr, False, p_drop)
+    xl, masking = model.transformer_block.transformer, model.input_features.masking
+    masking.seed, xl.seed = 1234, 4321
+    dense, tables = tr.flatten_model(model)
+    opt = tr.FusedAdam([dense, tables], lr=lr)
+    p = gu.oracle_params({"p/" + k: v.numpy() for k, v in sd.items()}, requires_grad=True)
+    leaves = [p["tables"]["item_id"], p["masked_item_embedding"]] + [t for lp in p["layers"] for t in lp.values()]
+    ref_opt = torch.optim.Adam(leaves, lr=lr)
+    cfg_o = dict(n_head=4, eps=0.03, item="item_id", masking="mlm")
+    for step in range(3):
+        ids = tr.random_data_from_schema(schema, B, L, seed=100 + step)["item_id"]
+        out = model({"item_id": ids.to(DEV)}, training=True)
+        out["loss"].backward()
+        opt.step()
+        mask, labels = R.mlm_targets_train_device(ids, 1234, step * B * L, 0.15)
+        masks = R.xlnet_dropout_masks(B, L, D, 4, NL, p_drop, seed=4321, offset=step + 1)
+        ref_opt.zero_grad()
+        ref = O.session_forward(p, cfg_o, {"item_id": ids}, mask, labels, True, False, drop=(p_drop, masks))
+        ref["loss"].backward()
+        ref_opt.step()
+        assert torch.equal(masking.masked_targets.cpu(), labels)
+        dl = abs(float(out["loss"].detach()) - float(ref["loss"]))
+        print(f"\n[lockstep step {step}] loss {float(ref['loss']):.6f} |d| {dl:.2e}")
+        assert dl < 1e-4
+    # Adam's first steps move every touched weight by ~lr whatever the gradient's size (the update is g / |g| at step 1), so
+    # an element whose gradient is rounding noise may move the other way: bound the FRACTION of such elements, and everything
+    # else at a small fraction of lr
+    def adam_close(a, b, name):
+        d = (a.detach().cpu() - b.detach()).abs()
+        frac = float((d > 0.05 * lr).float().mean())
+        print(f"[lockstep] {name}: max |d| {float(d.max()):.2e} ({float(d.max()) / lr:.2f} lr), fraction beyond 0.05 lr: {frac:.2e}")
+        assert frac < 1e-3 and float(d.max()) <= 6.5 * lr, name
+
+    adam_close(model.input_features.item_embedding_table.weight, p["tables"]["item_id"], "item table")
+    adam_close(xl.layer[1].ff.layer_1.weight, p["layers"][1]["w1"], "layer 1 w1")
+    adam_close(xl.layer[3].rel_attn.q, p["layers"][3]["q"], "layer 3 q")

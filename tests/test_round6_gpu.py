@@ -103,13 +103,13 @@ def test_full_size_dropout_step_vs_oracle(ops, multi):
     ref = O.session_forward(p, dict(n_head=4, eps=0.03, item="item_id", masking="mlm"), data, mask, labels, True, False,
                             drop=(p_drop, masks))
     ref["loss"].backward()
-    dl = abs(float(out["loss"].detach()) - float(ref["loss"]))
+    dl = abs(float(out["loss"].detach()) - float(ref["loss"].detach()))
     dp = float((out["predictions"].detach().cpu() - ref["logits"].detach()).abs().max())
     print(f"\n[dropout {p_drop} full size, multi={multi}] loss {float(ref['loss']):.6f}: |d loss| {dl:.2e}, max |d logits| {dp:.2e} "
           f"over {tuple(ref['logits'].shape)}")
     assert torch.equal(out["labels"].cpu(), ref["labels"])
     assert dl < 1e-4 and dp < 1e-4                       # north_star: 1e-3
-    assert abs(float(ref["loss"]) - np.log(V + 1)) < 0.2
+    assert abs(float(ref["loss"]) - np.log(V + 1)) < 0.35   # ~ln(V) at init (dropout raises it a little)
     # the masks mattered: the dropout-0 forward of the same model is elsewhere
     with torch.no_grad():
         ref0 = O.session_forward(p, dict(n_head=4, eps=0.03, item="item_id", masking="mlm"), data, mask, labels, True, False)
@@ -162,7 +162,7 @@ def test_three_optimizer_steps_in_lockstep_at_the_benchmarked_setting(ops):
         ref["loss"].backward()
         ref_opt.step()
         assert torch.equal(masking.masked_targets.cpu(), labels)
-        dl = abs(float(out["loss"].detach()) - float(ref["loss"]))
+        dl = abs(float(out["loss"].detach()) - float(ref["loss"].detach()))
         print(f"\n[lockstep step {step}] loss {float(ref['loss']):.6f} |d| {dl:.2e}")
         assert dl < 1e-4
     # Adam's first steps move every touched weight by ~lr whatever the gradient's size (the update is g / |g| at step 1), so

@@ -647,8 +647,15 @@ __device__ __forceinline__ float pow2_scale_head(float m) {
     (void)frexpf(m, &e);
     return ldexpf(1.f, min(14 - e, 100));    // a maximum below 2^-86 (the d W bound of an item far below every row's lse) must not overflow the scale
 }
-template <int NB, bool HS = false>
-__global__ __launch_bounds__(256) void head_dw_split_kernel(const float* __restrict__ logits, long ld,
+// PD: how many 32-row blocks of the lane's logits column are in flight ahead of the one being multiplied (round 6).  The
+// logits are a read-once 1.1 GB stream fetched as 4-byte column elements (a wave instruction moves two 128-byte row
+// segments); with one block ahead a CU had 8 waves x 16 x 256 B = 32 KB in flight -- by Little's law ~4 TB/s at the loaded
+// HBM latency, and the launch measured 3.0.  The kernel runs two waves per SIMD (two workgroups per CU), so the register
+// file has room for more: PD blocks of 16 values per lane.  NT: the logits with non-temporal loads (read once: they should not
+// displace the X images, which every workgroup re-reads, from L2 / Infinity Cache).  Same values in the same MFMA slots in
+// the same order: d W is bit-identical for every PD / NT.
+template <int NB, bool HS = false, int PD = 1, bool NT = false, bool COPY = true, int WPS = 2>
+__global__ __launch_bounds__(256, WPS) void head_dw_split_kernel(const float* __restrict__ logits, long ld,
                                                              const float* __restrict__ lse, const long* __restrict__ labels,
                                                              const float* __restrict__ gout, const u32x4* __restrict__ XT,
                                                              float* __restrict__ dW, long lddw, int N, int Vc, int V,
@@ -685,9 +692,11 @@ __global__ __launch_bounds__(256) void head_dw_split_kernel(const float* __restr
     u32x4 st[SN];
     float ri_lse = 0.f;
     long ri_lab = 0;
-    float xn[16];
+    float xq[PD][16];
     // every load is unconditional and nothing computed from it appears before s_store: a guarded load (tid < 32) or a
-    // conversion right behind it puts an s_waitcnt vmcnt(0) into the middle of the prefetch
+    // conversion right behind it puts an s_waitcnt vmcnt(0) into the middle of the prefetch.  Loads return in order: the X
+    // images / row facts of block b + 1 (consumed at the end of this iteration) are requested BEFORE the logits of block
+    // b + PD (consumed PD iterations later), so that waiting for the former leaves the latter in flight.
     auto g_load = [&](int b) __attribute__((always_inline)) {
         const u32x4* src = XT + (long)b * BLK;
 #pragma unroll
@@ -696,10 +705,15 @@ __global__ __launch_bounds__(256) void head_dw_split_kernel(const float* __restr
         const int row = min(b * 32 + (tid & 31), N - 1);
         ri_lse = lse[row];
         ri_lab = labels[row];
+    };
+    auto x_load = [&](float (&x)[16], int b) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) xn[8 * s + e] = lp[(long)min(b * 32 + 16 * s + 8 * khalf + e, N - 1) * ld];
+            for (int e = 0; e < 8; ++e) {
+                const float* a = lp + (long)min(b * 32 + 16 * s + 8 * khalf + e, N - 1) * ld;
+                x[8 * s + e] = NT ? __builtin_nontemporal_load(a) : *a;
+            }
     };
     auto s_store = [&](int buf, int b) __attribute__((always_inline)) {
 #pragma unroll
@@ -717,37 +731,50 @@ __global__ __launch_bounds__(256) void head_dw_split_kernel(const float* __restr
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
     g_load(0);
+#pragma unroll
+    for (int u = 0; u < PD; ++u) x_load(xq[u], min(u, nblk - 1));
     s_store(0, 0);
     __syncthreads();
-    for (int b = 0; b < nblk; ++b) {
-        const int buf = b & 1;
-        float xc[16];
+    for (int b0 = 0; b0 < nblk; b0 += PD) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) xc[i] = xn[i];
-        g_load(min(b + 1, nblk - 1));
-        __builtin_amdgcn_sched_barrier(0);
-        u32x4 af[2][NPL];
+        for (int u = 0; u < PD; ++u) {
+            const int b = b0 + u;
+            if (b >= nblk) break;            // workgroup-uniform
+            const int buf = b & 1;
+            float xc[16];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            float gv[8];
+            for (int i = 0; i < 16; ++i) xc[i] = xq[u][i];
+            g_load(min(b + 1, nblk - 1));
+            if (COPY) x_load(xq[u], min(b + PD, nblk - 1));
+            __builtin_amdgcn_sched_barrier(0);
+            u32x4 af[2][NPL];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float2 in = rinfo[buf][16 * s + 8 * khalf + e];
-                gv[e] = sg_value(xc[8 * s + e], in.x, __float_as_int(in.y) == v, q);
+            for (int s = 0; s < 2; ++s) {
+                float gv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float2 in = rinfo[buf][16 * s + 8 * khalf + e];
+                    gv[e] = sg_value(xc[8 * s + e], in.x, __float_as_int(in.y) == v, q);
+                }
+                split8s<HS>(gv, 1.f, af[s]);
             }
-            split8s<HS>(gv, 1.f, af[s]);
+            if (!COPY) {          // this slot's values are consumed: refill it before the products (no register copy)
+                __builtin_amdgcn_sched_barrier(0);
+                x_load(xq[u], min(b + PD, nblk - 1));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    u32x4 bf[NPL];
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl) bf[pl] = lds[buf][(pl * 4 + 2 * s + khalf) * D + 32 * j + l32];
+                    acc[j] = mfma_split<HS>(af[s], bf, acc[j]);
+                }
+            s_store(buf ^ 1, min(b + 1, nblk - 1));
+            __syncthreads();
         }
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                u32x4 bf[NPL];
-#pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) bf[pl] = lds[buf][(pl * 4 + 2 * s + khalf) * D + 32 * j + l32];
-                acc[j] = mfma_split<HS>(af[s], bf, acc[j]);
-            }
-        s_store(buf ^ 1, min(b + 1, nblk - 1));
-        __syncthreads();
     }
     const int v0 = blockIdx.x * 128 + 32 * wave + 4 * khalf;
 #pragma unroll
@@ -1710,8 +1737,10 @@ extern "C" int t4r_head_split_dw(void* stream, void* ws, const float* logits, lo
         hipLaunchKernelGGL(head_dw_aux_kernel, dim3(1), dim3(1024), 0, st, lse, labels, N, yoff, Vc, lse_min, islab, w.vpad);
         DwAux aux{reinterpret_cast<const float*>((const char*)ws + w.colmax), lse_min, islab, w.vpad, note->cm_rows > 0 ? note->cm_rows : w.rsplit};
         const u32x4* xth = reinterpret_cast<const u32x4*>((const char*)ws + w.xth);
-        T4R_NB_SWITCH(D, hipLaunchKernelGGL((head_dw_split_kernel<NB, true>), dim3((Vc + 127) / 128), dim3(256), 0, st, logits, ld,
-                                            lse, labels, grad_out, xth, dW, lddw, N, Vc, V, yoff, label_smoothing, alpha,
+        // PD = 1, non-temporal logits (round 6 A/B, profiles/r06_b_head_dw_variants.txt: two / three / four blocks in flight are
+        // 2-7 % SLOWER alone -- the launch is not waiting for its loads --, the non-temporal form is the only one ahead: -0.2 %)
+        T4R_NB_SWITCH(D, hipLaunchKernelGGL((head_dw_split_kernel<NB, true, 1, true>), dim3((Vc + 127) / 128), dim3(256), 0, st, logits,
+                                            ld, lse, labels, grad_out, xth, dW, lddw, N, Vc, V, yoff, label_smoothing, alpha,
                                             accumulate, w.nblk, amax, aux));
     } else {
         T4R_NB_SWITCH(D, hipLaunchKernelGGL(head_dw_split_kernel<NB>, dim3((Vc + 127) / 128), dim3(256), 0, (hipStream_t)stream,

@@ -189,6 +189,8 @@ int t4r_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, floa
 void t4r_gemm_splitk_sink_begin(float* ws, long cap_floats);
 int t4r_gemm_splitk_sink_flush(void* stream);
 void t4r_gemm_splitk_sink_end(void);
+/* launches since the last _begin (this thread) that were eligible for the sink but found no room and fell back to fp32 atomics */
+int t4r_gemm_splitk_sink_bypassed(void);
 
 /* Precision of every dense contraction launched after the call (process-wide setting; T4R_GEMM_PREC sets
  * the default):
@@ -439,9 +441,16 @@ int t4r_xlnet_dh(void* stream, const float* dqkv, const float* planes, float* dh
  * CUs -- the RCCL all-reduce of the table bucket that runs under the body's backward at N > 1 (the reference's
  * DDP does the same overlap, transformers4rec/torch/trainer.py:131-161) -- would send every such launch into a second round
  * of workgroups (measured 1.38x per step, tools/occupier_curve.py).  With a budget below 256 they take the tile that minimises
- * rounds x rows on that many CUs.  Process-wide, read at every launch; results do not depend on it (same arithmetic per row). */
+ * rounds x rows on that many CUs.  Process-wide, read at every launch.  Per-row results (d h, d attn_out, ...) are bit-identical
+ * whatever the budget; the batch-reduced gradients (d gamma, d beta, d b1, d b2) are equal UP TO SUMMATION ORDER: the tile size
+ * sets how the per-workgroup partial sums are grouped, so a budgeted backward rounds them differently from an unbudgeted one
+ * (each is still bit-reproducible for its own budget).  t4r_device_cus(): compute units of the current device (the budget's
+ * upper bound; replaces hipDeviceGetAttribute(hipDeviceAttributeMultiprocessorCount) for the caller). */
 void t4r_xlnet_set_cu_budget(int cus);
 int t4r_xlnet_get_cu_budget(void);
+int t4r_device_cus(void);
+/* 1 if the library was built with -DT4R_EXPERIMENTAL (A/B switches readable from the environment: csrc/t4r_common.h), else 0 */
+int t4r_experimental_build(void);
 /* The attention half of a layer as ONE kernel per direction (csrc/xlnet_attn_block.hip; round 4): exact fp32 matrix
  * instructions (v_mfma_f32_16x16x4_f32 = a k-ordered fmaf chain), one workgroup per 80 / L whole sessions, q | k | v, the
  * scores and the probabilities never leave the chip.  Shapes: L <= 32, d_head 16 | 32, d_model 32 | 64 | 128

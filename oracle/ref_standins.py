@@ -8,11 +8,8 @@ reference pins <4.31).
 
 Used by oracle/make_golden.py (fixture generation) and oracle/cpu_reference_bench.py.
 /root/reference does not exist on the GPU box; the committed fixtures under tests/golden/ are
-what travels.  The one exception (VERDICT r3 next #1c): tools/stage_reference.sh puts a scratch,
-git-ignored copy of the reference's two pure-Python packages under .scratch_ref/ of the repo,
-which gpurun ships as it ships the built .so -- then tests/test_dropin_reference_gpu.py runs the
-reference's own Model / Head / SequentialBlock over the HIP drop-in modules on the GPU.  The copy
-is never committed and never imported by the product path.
+what travels -- the reference itself never does, in any form (rounds 3-4 staged a scratch copy for one
+GPU call; that script is gone since round 6).
 
 What is faked: only plumbing -- registries, docstring
 decorators, schema containers, a minimal torchmetrics.Metric.  No arithmetic of the
@@ -29,14 +26,8 @@ import os
 
 
 def _reference_root():
-    """T4R_REFERENCE_ROOT, else /root/reference, else the scratch copy staged by tools/stage_reference.sh"""
-    env = os.environ.get("T4R_REFERENCE_ROOT")
-    if env:
-        return env
-    if os.path.isdir("/root/reference/transformers4rec"):
-        return "/root/reference"
-    scratch = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".scratch_ref")
-    return scratch if os.path.isdir(os.path.join(scratch, "transformers4rec")) else "/root/reference"
+    """T4R_REFERENCE_ROOT (a maintainer's own checkout), else /root/reference"""
+    return os.environ.get("T4R_REFERENCE_ROOT") or "/root/reference"
 
 
 REFERENCE_ROOT = _reference_root()

@@ -75,7 +75,7 @@ _ALLOWED_FILE_SCOPE_STATE = {
     "g_amax_a": "thread-local, set and cleared inside one layer call (operand maxima of a GEMM launch)",
     "g_amax_b": "same", "g_amax_n": "same", "g_amax_nb": "same",
     "g_cu_budget": "CUs the backward's token-tile kernels may count on, set only through t4r_xlnet_set_cu_budget (documented in "
-                   "include/t4r_hip.h; results do not depend on it)",
+                   "include/t4r_hip.h; per-row results do not depend on it, batch-reduced gradients are equal up to summation order)",
     "g_ff_amax": "thread-local, set and cleared inside one layer call",
     "g_red_side": "thread-local, set and cleared inside one layer call (reduction side stream)",
     "g_red_events": "same", "g_red_n": "same", "g_red_used": "same",

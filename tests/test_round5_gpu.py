@@ -362,14 +362,25 @@ def test_tiled_weight_planes_equal_the_element_wise_ones(D, monkeypatch):
            g32(4 * D, D), g32(4 * D), g32(D, 4 * D), g32(D), 1 + g32(D), g32(D)]
     from transformers4rec_amd import _lib
 
-    def planes_of(tiled):
-        monkeypatch.setenv("T4R_PLANES_TILED", tiled)
+    def planes_of(misaligned):
+        # the tiled kernel takes a call whose sources are 16-byte aligned; one that is not falls to the element-wise kernel
+        # (the product library has no switch for it: csrc/t4r_common.h t4r_exp_getenv)
+        src = prm
+        if misaligned:
+            src = []
+            for t in prm:
+                buf = torch.zeros(t.numel() + 8, device=DEV)
+                off = 2 + (4 - (buf.data_ptr() // 4) % 4) % 4          # data_ptr % 16 == 8
+                v = buf[off: off + t.numel()].view(t.shape)
+                v.copy_(t)
+                assert v.data_ptr() % 16 == 8
+                src.append(v)
         planes = torch.zeros(_lib.load().t4r_xlnet_layer_planes_floats(D), device=DEV, dtype=torch.float32)   # unwritten gaps stay 0
-        ptrs, _keep = _lib.ptr_array([t.data_ptr() for t in prm])
+        ptrs, _keep = _lib.ptr_array([t.data_ptr() for t in src])
         _lib.call("t4r_xlnet_layer_prepare", torch.cuda.current_stream().cuda_stream, ptrs, D, planes.data_ptr())
         torch.cuda.synchronize()
         return planes
 
-    a, b = planes_of("0"), planes_of("1")
+    a, b = planes_of(True), planes_of(False)
     assert torch.equal(a.view(torch.int32), b.view(torch.int32))
     assert int((a.view(torch.int32) != 0).sum()) > a.numel() // 4        # the comparison is not of two empty buffers

@@ -49,6 +49,7 @@ _SIGS = {
     "t4r_gemm_splitk_sink_begin": ("v", "pl"),
     "t4r_gemm_splitk_sink_flush": ("i", "p"),
     "t4r_gemm_splitk_sink_end": ("v", ""),
+    "t4r_gemm_splitk_sink_bypassed": ("i", ""),
     "t4r_mha_fwd": ("i", "pppplplp" + "iiiii" + "fQQ" + "p"),
     "t4r_mha_bwd": ("i", "pppplpplppppl" + "iiiii" + "fQQ" + "p"),
     "t4r_add_pos_fwd": ("i", "ppppp" + "iii"),
@@ -98,6 +99,8 @@ _SIGS = {
     "t4r_xlnet_dh": ("i", "pppp" + "li"),
     "t4r_xlnet_set_cu_budget": ("v", "i"),
     "t4r_xlnet_get_cu_budget": ("i", ""),
+    "t4r_device_cus": ("i", ""),
+    "t4r_experimental_build": ("i", ""),
     "t4r_xlnet_attn_block_supported": ("i", "iii"),
     "t4r_xlnet_attn_block_fwd": ("i", "ppppp" + "l" + "pppp" + "ppppppp" + "iiii" + "ffQQQ" + "p"),
     "t4r_xlnet_layer_bwd_defer": ("v", "i"),
@@ -189,3 +192,17 @@ def int_array(vals):
 def long_array(vals):
     arr = (ctypes.c_long * len(vals))(*vals)
     return ctypes.cast(arr, ctypes.c_void_p), arr
+
+
+def exp_env(name, default=None):
+    """value of an EXPERIMENT switch: the environment variable `name` when the loaded library is an experiment build
+    (-DT4R_EXPERIMENTAL, tools/experimental/build_variant.sh), else `default`.  The product build ignores these names on both
+    sides of the C ABI (csrc/t4r_common.h: t4r_exp_getenv), so that the host never plans for a kernel family the library
+    will not run.  The switches the product DOES read are listed in INTEGRATION.md section 5."""
+    v = os.environ.get(name)
+    if v is None:
+        return default
+    try:
+        return v if load().t4r_experimental_build() else default
+    except Exception:       # noqa: BLE001  (library not built yet: CPU-only import)
+        return default

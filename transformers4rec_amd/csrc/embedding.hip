@@ -271,7 +271,7 @@ extern "C" int t4r_seq_features_fwd(
     const int g = pick_group(W);
     static int fast_u = -1;
     static bool fast_u_set = false;
-    if (fast_u < 0) { const char* e = getenv("T4R_GATHER_U"); fast_u_set = e != nullptr; fast_u = e ? atoi(e) : 2; }
+    if (fast_u < 0) { const char* e = t4r_exp_getenv("T4R_GATHER_U"); fast_u_set = e != nullptr; fast_u = e ? atoi(e) : 2; }
     const int units = (W + 3) / 4;
     const int nch = (units + g - 1) / g;                // 16-byte chunks per lane
     bool fast_ok = fast_u > 0 && agg == AGG_CONCAT && (W & 3) == 0 && nch <= 4 && g >= 8 &&
@@ -284,7 +284,7 @@ extern "C" int t4r_seq_features_fwd(
         const int U = nch == 2 ? ((fast_u_set && fast_u < 4) ? 2 : 4) : ((fast_u >= 4 && nch == 1) ? (fast_u >= 8 ? 8 : 4) : 2);
         // non-temporal row loads when a gathered table cannot stay on the chip anyway (> 256 MB: beyond the Infinity Cache)
         static int nt_env = -2;
-        if (nt_env == -2) { const char* e = getenv("T4R_GATHER_NT"); nt_env = e ? atoi(e) : -1; }
+        if (nt_env == -2) { const char* e = t4r_exp_getenv("T4R_GATHER_NT"); nt_env = e ? atoi(e) : -1; }
         bool nt = true, any = false;
         for (int f = 0; f < n_feat; ++f)
             if (p.kind[f] == 0 || p.kind[f] == 2) {
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256) void soft_embedding_fwd_kernel(
 // T4R_SOFT_EXACT=0: the general (run-time K, D) kernels for every shape (A/B and parity of the exact-shape instantiation)
 static bool soft_exact_on() {
     static int on = -1;
-    if (on < 0) { const char* e = getenv("T4R_SOFT_EXACT"); on = e ? (atoi(e) != 0) : 1; }
+    if (on < 0) { const char* e = t4r_exp_getenv("T4R_SOFT_EXACT"); on = e ? (atoi(e) != 0) : 1; }
     return on != 0;
 }
 

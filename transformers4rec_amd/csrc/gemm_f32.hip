@@ -37,6 +37,14 @@ static int launch_cfg(const GemmParams& p, int batch, hipStream_t stream) {
 //   2 / 3 mixed precision, bf16 / fp16 operands, fp32 accumulation (the reference's AMP: trainer.py:363-367)
 //   4 auto (default): fp32 accuracy, the split form on the shapes where it measured faster (see auto_split)
 static std::atomic<int> g_prec{-1};
+// 1 in an experiment build (-DT4R_EXPERIMENTAL): the host side reads its A/B switches only then (transformers4rec_amd/_lib.py: exp_env)
+extern "C" int t4r_experimental_build(void) {
+#ifdef T4R_EXPERIMENTAL
+    return 1;
+#else
+    return 0;
+#endif
+}
 extern "C" void t4r_set_precision(int mode) { g_prec.store(mode < 0 || mode > 4 ? 0 : mode); }
 extern "C" int t4r_get_precision(void) {
     int m = g_prec.load();
@@ -54,7 +62,7 @@ int t4r_tok_gemm_try(const GemmParams& p, int batch, int ta, int tb, hipStream_t
 // shapes on which the split form beat the fp32 matrix cores (tools/gemm_bench.py --prec, profiles/r02_*)
 static bool auto_split(const GemmParams& p, bool ta, bool tb) {
     static long min_flops = -1;
-    if (min_flops < 0) { const char* e = getenv("T4R_GEMM_AUTO_MIN_GFLOP"); min_flops = (e ? atol(e) : 2) * 1000000000L; }
+    if (min_flops < 0) { const char* e = t4r_exp_getenv("T4R_GEMM_AUTO_MIN_GFLOP"); min_flops = (e ? atol(e) : 2) * 1000000000L; }
     return 2.0 * p.M * p.N * (double)p.K >= (double)min_flops;
 }
 
@@ -73,7 +81,7 @@ static bool auto_split(const GemmParams& p, bool ta, bool tb) {
 struct SplitKJob { const float* part; float* out; int n4; int splits; long stride4; int accumulate; };
 constexpr int kMaxSplitKJobs = 20;
 struct SplitKJobs { SplitKJob j[kMaxSplitKJobs]; int n; int blk_end[kMaxSplitKJobs]; };
-struct SplitKSink { float* ws = nullptr; long cap = 0, used = 0; SplitKJobs jobs; bool on = false; };
+struct SplitKSink { float* ws = nullptr; long cap = 0, used = 0; SplitKJobs jobs; bool on = false; int bypassed = 0; };
 static thread_local SplitKSink g_sink;
 
 // workgroup = 16 float4 columns x 16 split groups; group g adds splits g, g + 16, ... in order (four loads in flight per
@@ -111,8 +119,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(SplitKJobs jobs) {
 }
 
 void t4r_splitk_sink_begin(float* ws, long cap_floats) {
-    static const int enabled = [] { const char* e = getenv("T4R_SPLITK_SINK"); return e ? atoi(e) : 1; }();
+    static const int enabled = [] { const char* e = t4r_exp_getenv("T4R_SPLITK_SINK"); return e ? atoi(e) : 1; }();
     g_sink.ws = ws; g_sink.cap = cap_floats; g_sink.used = 0; g_sink.jobs.n = 0; g_sink.on = enabled && ws && cap_floats > 0;
+    g_sink.bypassed = 0;
 }
 int t4r_splitk_sink_flush(hipStream_t st) {
     SplitKJobs& J = g_sink.jobs;
@@ -133,15 +142,20 @@ void t4r_splitk_sink_end() { g_sink.on = false; g_sink.ws = nullptr; g_sink.cap 
 extern "C" void t4r_gemm_splitk_sink_begin(float* ws, long cap_floats) { t4r_splitk_sink_begin(ws, cap_floats); }
 extern "C" int t4r_gemm_splitk_sink_flush(void* stream) { return t4r_splitk_sink_flush((hipStream_t)stream); }
 extern "C" void t4r_gemm_splitk_sink_end(void) { t4r_splitk_sink_end(); }
+// split-K launches since the last _begin of this thread that were ELIGIBLE for the sink but did not get room in it (too small
+// a workspace, too many jobs) and therefore added their partial tiles with fp32 atomics: correct, but not bit-reproducible.
+// A caller that sized the workspace itself asks here instead of trusting its copy of the launcher's split rule.
+extern "C" int t4r_gemm_splitk_sink_bypassed(void) { return g_sink.bypassed; }
 
 // a split-K launch asks for room: returns the partial buffer (and registers the jobs) or null (-> atomics)
 static float* splitk_sink_take(const GemmParams& p, int batch) {
     SplitKSink& k = g_sink;
     if (!k.on || !p.accumulate || p.epilogue != EPI_NONE || p.sg_lse || p.rk_thr) return nullptr;
     const long n = (long)p.M * p.ldc;                       // one partial = C's [M][ldc] image (dense outputs: ldc == N)
-    if (p.ldc != p.N || n % 4 || ((uintptr_t)p.C & 15) || (p.sC % 4) || k.jobs.n + batch > kMaxSplitKJobs) return nullptr;
+    if (p.ldc != p.N || n % 4 || ((uintptr_t)p.C & 15) || (p.sC % 4)) return nullptr;        // not a shape the sink takes
+    if (k.jobs.n + batch > kMaxSplitKJobs) { ++k.bypassed; return nullptr; }
     const long need = n * p.splitk * batch;
-    if (k.used + need > k.cap || n / 4 > 0x7fffffffL) return nullptr;
+    if (k.used + need > k.cap || n / 4 > 0x7fffffffL) { ++k.bypassed; return nullptr; }
     float* part = k.ws + k.used;
     k.used += need;
     for (int b = 0; b < batch; ++b)
@@ -219,7 +233,7 @@ static int launch_layout(GemmParams& p, int batch, int splitk_req, hipStream_t s
     // exception is chosen by shape below.
     int bm = 64, bn = 64;
     static int tile_sel = -1;
-    if (tile_sel < 0) { const char* e = getenv("T4R_GEMM_TILE"); tile_sel = e ? atoi(e) : 0; }
+    if (tile_sel < 0) { const char* e = t4r_exp_getenv("T4R_GEMM_TILE"); tile_sel = e ? atoi(e) : 0; }
     if (tile_sel == 1) { bm = 64; bn = 128; } else if (tile_sel == 2) { bm = 128; bn = 64; }
     else if (tile_sel == 3) { bm = 64; bn = 64; } else if (tile_sel == 4) { bm = 128; bn = 128; }
     else if (!TA && TB && p.M >= 1024 && p.N >= 32768 && !p.sg_lse && !p.rk_thr && p.epilogue == EPI_NONE) {
@@ -228,7 +242,7 @@ static int launch_layout(GemmParams& p, int batch, int splitk_req, hipStream_t s
         bm = 128; bn = 128;
     }
     static int bk_sel = -1;
-    if (bk_sel < 0) { const char* e = getenv("T4R_GEMM_BK"); bk_sel = e ? atoi(e) : 0; }
+    if (bk_sel < 0) { const char* e = t4r_exp_getenv("T4R_GEMM_BK"); bk_sel = e ? atoi(e) : 0; }
     // precision of this launch: the half-precision variants need 16-byte loadable operands; the rank epilogue
     // (exact ranks of the evaluation head) always stays on the fp32 matrix cores
     int half_big = 0;
@@ -238,13 +252,13 @@ static int launch_layout(GemmParams& p, int batch, int splitk_req, hipStream_t s
     if (prec && p.sg_lse && TB) prec = 0;
     if (prec) {
         static int half_tile = -1;
-        if (half_tile < 0) { const char* e = getenv("T4R_GEMM_HALF_TILE"); half_tile = e ? atoi(e) : 0; }
+        if (half_tile < 0) { const char* e = t4r_exp_getenv("T4R_GEMM_HALF_TILE"); half_tile = e ? atoi(e) : 0; }
         // 128 x 128 only with one operand plane (the three-plane images of a 128 x 128 tile take 101 KB of LDS)
         const bool feat = p.sg_lse || (p.drop.p > 0.f && (p.epilogue == EPI_BIAS_GELU || p.epilogue == EPI_BIAS_RESID));
         int big = (!feat && prec >= 2 && (half_tile == 4 || (half_tile == 0 && bm == 128 && bn == 128))) ? 1 : 0;
         // experiment knobs for the three-plane form: T4R_GEMM_SPLIT_TILE = 4 (128 x 128, one workgroup per CU) | 2 (128 x 64)
         static int split_tile = -1;
-        if (split_tile < 0) { const char* e = getenv("T4R_GEMM_SPLIT_TILE"); split_tile = e ? atoi(e) : 0; }
+        if (split_tile < 0) { const char* e = t4r_exp_getenv("T4R_GEMM_SPLIT_TILE"); split_tile = e ? atoi(e) : 0; }
         if (!feat && prec == 1 && (split_tile == 4 || split_tile == 2) && p.M >= 256 && p.N >= 128) big = split_tile == 4 ? 1 : 2;
         // measured (profiles/r02_b_gemm_prec_bench.txt): the 128 x 64 tile (half the A-operand LDS reads per MFMA)
         // wins the large plain products (C5 body 2459 -> 2233 us, square 4096 1051 -> 944 us, logits 700 -> 693 us)
@@ -252,7 +266,7 @@ static int launch_layout(GemmParams& p, int batch, int splitk_req, hipStream_t s
         if (!feat && prec == 1 && split_tile == 0 && p.M >= 1024 && p.N >= 512 && 2.0 * p.M * p.N * (double)p.K >= 2e10) big = 2;
         // experiment: the softmax-gradient products of the head on the 128 x 64 tile (T4R_GEMM_SG_TILE=2)
         static int sg_tile = -1;
-        if (sg_tile < 0) { const char* e = getenv("T4R_GEMM_SG_TILE"); sg_tile = e ? atoi(e) : 0; }
+        if (sg_tile < 0) { const char* e = t4r_exp_getenv("T4R_GEMM_SG_TILE"); sg_tile = e ? atoi(e) : 0; }
         if (p.sg_lse && prec == 1 && sg_tile == 2 && p.M >= 1024) big = 2;
         bm = big ? 128 : 64;
         bn = big == 1 ? 128 : 64;
@@ -274,8 +288,8 @@ static int launch_layout(GemmParams& p, int batch, int splitk_req, hipStream_t s
         // the epilogue stay a small part.  Measured (tools/gemm_bench.py): head dX 2765x128x100001
         // 1076 us at 1024 workgroups, 786 us at 4096; wgrad 128x512x20480 best at 64 splits.
         static long target = -1, min_tiles = -1;
-        if (target < 0) { const char* e = getenv("T4R_GEMM_SPLIT_TARGET"); target = e ? atol(e) : 4096; }
-        if (min_tiles < 0) { const char* e = getenv("T4R_GEMM_SPLIT_MIN_TILES"); min_tiles = e ? atol(e) : 20; }
+        if (target < 0) { const char* e = t4r_exp_getenv("T4R_GEMM_SPLIT_TARGET"); target = e ? atol(e) : 4096; }
+        if (min_tiles < 0) { const char* e = t4r_exp_getenv("T4R_GEMM_SPLIT_MIN_TILES"); min_tiles = e ? atol(e) : 20; }
         splitk = (int)max(1L, min((long)kt / min_tiles, target / max(1L, blocks)));
         splitk = min(splitk, 256);
     }
@@ -295,7 +309,7 @@ static int launch_layout(GemmParams& p, int batch, int splitk_req, hipStream_t s
     // registers.  T4R_GEMM_BK=32 keeps it available for experiments.
     const int BK = bk_sel ? bk_sel : 16;
     static int xcd_sel = -1;
-    if (xcd_sel < 0) { const char* e = getenv("T4R_GEMM_XCD"); xcd_sel = e ? atoi(e) : 1; }
+    if (xcd_sel < 0) { const char* e = t4r_exp_getenv("T4R_GEMM_XCD"); xcd_sel = e ? atoi(e) : 1; }
     p.xcd_order = xcd_sel;
     if (p.splitk > 1) {
         if (p.epilogue != EPI_NONE) { t4r_set_error("gemm: split-K needs epilogue NONE"); return -1; }

@@ -770,7 +770,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 template <int BM, int BN, int BK, bool TA, bool TB, int FEAT, bool VEC, int PREC = 0>
 static int launch_vec(const GemmParams& p, int batch, hipStream_t stream) {
     static long pad = -1;   // experiment knob: extra LDS per workgroup = fewer resident workgroups per CU
-    if (pad < 0) { const char* e = getenv("T4R_GEMM_LDS_PAD"); pad = e ? atol(e) : 0; }
+    if (pad < 0) { const char* e = t4r_exp_getenv("T4R_GEMM_LDS_PAD"); pad = e ? atol(e) : 0; }
     const size_t smem = gemm_lds_bytes<BM, BN, BK, TA, TB, PREC>() + (size_t)pad;
     static T4rLdsAttr attr_set;
     t4r_ensure_dynamic_lds((const void*)gemm_f32_kernel<BM, BN, BK, TA, TB, FEAT, VEC, PREC>, smem, attr_set);

@@ -1502,12 +1502,12 @@ __global__ __launch_bounds__(256) void split_w_images_kernel(const float* __rest
 
 static int head_rows_per_wg() {
     static int per = -1;
-    if (per < 0) { const char* e = getenv("T4R_HEAD_ROWS_PER_WG"); per = e ? max(1, atoi(e)) : 12; }
+    if (per < 0) { const char* e = t4r_exp_getenv("T4R_HEAD_ROWS_PER_WG"); per = e ? max(1, atoi(e)) : 12; }
     return per;
 }
 static int head_dx_target() {
     static int target = -1;
-    if (target < 0) { const char* e = getenv("T4R_HEAD_DX_WGS"); target = e ? atoi(e) : 1536; }
+    if (target < 0) { const char* e = t4r_exp_getenv("T4R_HEAD_DX_WGS"); target = e ? atoi(e) : 1536; }
     return target;
 }
 // workspace layout (bytes): XA | XT | WT | d X partials
@@ -1515,26 +1515,26 @@ struct HeadWs { long xa, xt, wt, part, stats, scales, xth, colmax, islab, xtp, w
 // d W too (T4R_HEAD_DW_FP16X2, default 1; per-item scales: see head_dw_split_kernel)?
 static bool head_dw_fp16x2() {
     static int on = -1;
-    if (on < 0) { const char* e = getenv("T4R_HEAD_DW_FP16X2"); on = e ? (atoi(e) != 0) : 1; }
+    if (on < 0) { const char* e = t4r_exp_getenv("T4R_HEAD_DW_FP16X2"); on = e ? (atoi(e) != 0) : 1; }
     return on != 0;
 }
 // the forward product in the two-way fp16 split (see mfma_split)?
 static bool head_fwd_fp16x2() {
     static int on = -1;
-    if (on < 0) { const char* e = getenv("T4R_HEAD_FWD_FP16X2"); on = e ? (atoi(e) != 0) : 1; }
+    if (on < 0) { const char* e = t4r_exp_getenv("T4R_HEAD_FWD_FP16X2"); on = e ? (atoi(e) != 0) : 1; }
     return on != 0;
 }
 // the recomputing form available (both fp16 switches on) and not switched off (T4R_HEAD_RECOMPUTE=0 also drops its 75 MB
 // of table planes from the workspace)?
 static bool head_recompute_on() {
     static int on = -1;
-    if (on < 0) { const char* e = getenv("T4R_HEAD_RECOMPUTE"); on = e ? (atoi(e) != 0) : 1; }
+    if (on < 0) { const char* e = t4r_exp_getenv("T4R_HEAD_RECOMPUTE"); on = e ? (atoi(e) != 0) : 1; }
     return on != 0 && head_fwd_fp16x2() && head_dw_fp16x2();
 }
 // logits + statistics + d X in one pass (head_fwd_dx_kernel; T4R_HEAD_FDX=0 restores logits-then-d X-from-the-logits)?
 static bool head_fdx_on() {
     static int on = -1;
-    if (on < 0) { const char* e = getenv("T4R_HEAD_FDX"); on = e ? (atoi(e) != 0) : 1; }
+    if (on < 0) { const char* e = t4r_exp_getenv("T4R_HEAD_FDX"); on = e ? (atoi(e) != 0) : 1; }
     return on != 0 && head_fwd_fp16x2();
 }
 HeadWs head_ws(int N, int V, int D) {
@@ -1659,7 +1659,7 @@ extern "C" int t4r_head_split_logits(void* stream, void* ws, const float* W, lon
     T4R_CHECK_ARG(aligned16(W) && ldw % 4 == 0, "head_split_logits: W must be 16-byte aligned with a pitch multiple of 4");
     const HeadWs w = head_ws(N, V, D);
     static int per_env = -1;
-    if (per_env < 0) { const char* e = getenv("T4R_HEAD_ROWS_PER_WG"); per_env = e ? atoi(e) : 12; }
+    if (per_env < 0) { const char* e = t4r_exp_getenv("T4R_HEAD_ROWS_PER_WG"); per_env = e ? atoi(e) : 12; }
     const int blk_per = max(1, min(w.nblk, per_env));
     const int rs = (w.nblk + blk_per - 1) / blk_per;
     const u32x4* xa = reinterpret_cast<const u32x4*>((const char*)ws + w.xa);
@@ -1690,7 +1690,7 @@ extern "C" int t4r_head_split_logits_ce(void* stream, void* ws, const float* W, 
     T4R_CHECK_ARG(aligned16(W) && ldw % 4 == 0, "head_split_logits_ce: W must be 16-byte aligned with a pitch multiple of 4");
     const HeadWs w = head_ws(N, V, D);
     static int per_env = -1;
-    if (per_env < 0) { const char* e = getenv("T4R_HEAD_ROWS_PER_WG"); per_env = e ? atoi(e) : 12; }
+    if (per_env < 0) { const char* e = t4r_exp_getenv("T4R_HEAD_ROWS_PER_WG"); per_env = e ? atoi(e) : 12; }
     const int blk_per = max(1, min(w.nblk, per_env));
     const int rs = (w.nblk + blk_per - 1) / blk_per;
     const u32x4* xa = reinterpret_cast<const u32x4*>((const char*)ws + w.xa);
@@ -1920,7 +1920,7 @@ extern "C" int t4r_head_split_logits_ce_dx(void* stream, void* ws, const float* 
     const int row_tiles = (N + 127) / 128;
     // one residency of the chip: two 256-thread workgroups per CU (66 KB of LDS each), every workgroup the same number of tiles
     static int target = -1;
-    if (target < 0) { const char* e = getenv("T4R_HEAD_FDX_WGS"); target = e ? max(1, atoi(e)) : 512; }
+    if (target < 0) { const char* e = t4r_exp_getenv("T4R_HEAD_FDX_WGS"); target = e ? max(1, atoi(e)) : 512; }
     int splits = max(1, min(min(64, w.max_split), min(max(1, w.nkt / 8), target / row_tiles)));
     const int kt_per = (w.nkt + splits - 1) / splits;
     splits = (w.nkt + kt_per - 1) / kt_per;

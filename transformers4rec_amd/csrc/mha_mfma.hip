@@ -287,7 +287,7 @@ __global__ __launch_bounds__(512) void mha_mfma_bwd_kernel(
 // ------------------------------------------------------------------------------------------ host
 bool t4r_mha_mfma_ok(int L, int d_head, long ld, long ld_out, long ld_d) {
     static const int on = [] {
-        const char* e = getenv("T4R_MHA_MFMA");
+        const char* e = t4r_exp_getenv("T4R_MHA_MFMA");
         return e ? atoi(e) : 1;
     }();
     const long lim = 0x7fffffffL / 160;     // 32-bit per-session offsets

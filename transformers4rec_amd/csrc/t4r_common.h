@@ -6,6 +6,23 @@
 
 #define T4R_WAVE 64
 
+// ---- environment switches.  The PRODUCT library reads ONE environment variable, T4R_GEMM_PREC (the default precision mode;
+// INTEGRATION.md section 5 lists it with the five the Python host side reads).  Every other T4R_* name in these sources is an
+// A/B, tuning or fallback-forcing switch of an EXPERIMENT build (-DT4R_EXPERIMENTAL: tools/experimental/build_variant.sh):
+// in the product build t4r_exp_getenv() returns NULL, so the compiled-in default -- the measured best -- is what runs, and no
+// untested combination of kernel families can be selected from outside.  (The kernels behind those switches that stay in
+// the library are the general-shape paths the fast ones fall back to -- other d_model / d_head / sequence lengths,
+// misaligned operands --, not alternatives for the same shape.)
+#include <stdlib.h>
+static inline const char* t4r_exp_getenv(const char* name) {
+#ifdef T4R_EXPERIMENTAL
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 extern "C" void t4r_set_error(const char* msg);
 
 #define T4R_CHECK_ARG(cond, msg)          \

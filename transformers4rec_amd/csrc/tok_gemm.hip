@@ -204,7 +204,7 @@ int launch_nbw(const GemmParams& p, int batch, int KC, hipStream_t stream) {
     const long tiles = (long)((p.M + 127) / 128) * batch;
     const int nb = p.N / 32;
     static int force = -1;
-    if (force < 0) { const char* e = getenv("T4R_TOK_NBW"); force = e ? atoi(e) : 0; }
+    if (force < 0) { const char* e = t4r_exp_getenv("T4R_TOK_NBW"); force = e ? atoi(e) : 0; }
     int nbw = 1;
     for (int c : {4, 2}) {
         if (nb % c == 0 && tiles * (nb / c) >= 480) { nbw = c; break; }
@@ -231,7 +231,7 @@ extern "C" void t4r_set_tok_gemm_min_rows(int rows) { g_min_rows.store(rows < 0 
 extern "C" int t4r_get_tok_gemm_min_rows(void) {
     int m = g_min_rows.load();
     if (m < 0) {
-        const char* e = getenv("T4R_TOK_GEMM_MIN_M");
+        const char* e = t4r_exp_getenv("T4R_TOK_GEMM_MIN_M");
         m = e ? atoi(e) : 32768;
         g_min_rows.store(m);
     }
@@ -239,12 +239,12 @@ extern "C" int t4r_get_tok_gemm_min_rows(void) {
 }
 int t4r_tok_gemm_try(const GemmParams& p, int batch, int ta, int tb, hipStream_t stream) {
     static int on = -1;
-    if (on < 0) { const char* e = getenv("T4R_TOK_GEMM"); on = e ? atoi(e) : 1; }
+    if (on < 0) { const char* e = t4r_exp_getenv("T4R_TOK_GEMM"); on = e ? atoi(e) : 1; }
     if (!on || ta || p.sg_lse || p.rk_thr || p.splitk > 1) return 0;
     // below the row threshold only the wide, short products without an epilogue (K <= 128, N >= 512: d ff = d ffout @ W2
     // at 20 480 tokens) -- the one body shape of configs[1] where this kernel was faster INSIDE the step (56 vs 81 us)
     static int wide = -1;
-    if (wide < 0) { const char* e = getenv("T4R_TOK_GEMM_WIDE"); wide = e ? atoi(e) : 1; }
+    if (wide < 0) { const char* e = t4r_exp_getenv("T4R_TOK_GEMM_WIDE"); wide = e ? atoi(e) : 1; }
     const bool wide_short = wide && p.K <= 128 && p.N >= 512 && p.epilogue == EPI_NONE && p.M >= 8192;
     if ((p.M < t4r_get_tok_gemm_min_rows() && !wide_short) || p.N % 32 || p.N < 32 || p.K % 32 || p.K < 32 || p.K > 512) return 0;
     if (p.K > 128 && p.K % 128) return 0;

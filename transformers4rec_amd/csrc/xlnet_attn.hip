@@ -530,7 +530,7 @@ int t4r_xlnet_attn_core16_bwd(hipStream_t st, const float* qkv, const float* kr,
 #endif
 static bool use_mfma(int L, int d_head) {
     static int en = -1;
-    if (en < 0) { const char* e = getenv("T4R_ATTN_MFMA"); en = e ? atoi(e) : 1; }
+    if (en < 0) { const char* e = t4r_exp_getenv("T4R_ATTN_MFMA"); en = e ? atoi(e) : 1; }
     return en && t4r_xlnet_attn_mfma_ok(L, d_head);
 }
 

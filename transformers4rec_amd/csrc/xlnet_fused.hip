@@ -525,7 +525,7 @@ __global__ __launch_bounds__(D * 4) void xlnet_ff_bwd_kernel(FFBwdParams p) {
 // -------------------------------------------------------------------------------------------------- host side
 bool t4r_xlnet_body_fp16x2() {
     static int on = -1;
-    if (on < 0) { const char* e = getenv("T4R_XLNET_FP16X2"); on = e ? (atoi(e) != 0) : 1; }
+    if (on < 0) { const char* e = t4r_exp_getenv("T4R_XLNET_FP16X2"); on = e ? (atoi(e) != 0) : 1; }
     return on != 0;
 }
 // Where the next t4r_xlnet_ff_fwd / _bwd calls of this thread leave their per-workgroup operand maxima (four arrays of
@@ -549,14 +549,29 @@ long t4r_xlnet_ff_amax_slots(long T) { return (T + 15) / 16; }                  
 static std::atomic<int> g_cu_budget{0};
 extern "C" void t4r_xlnet_set_cu_budget(int cus) { g_cu_budget.store(cus < 0 ? 0 : cus, std::memory_order_relaxed); }
 extern "C" int t4r_xlnet_get_cu_budget(void) { return g_cu_budget.load(std::memory_order_relaxed); }
+// compute units of the current device (256 on MI355X), asked once per device
+static int device_cus() {
+    static std::atomic<int> cus[T4R_MAX_DEVICES] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::atomic<int>& c = cus[dev & (T4R_MAX_DEVICES - 1)];
+    int n = c.load(std::memory_order_relaxed);
+    if (n <= 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        c.store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+extern "C" int t4r_device_cus(void) { return device_cus(); }
 int t4r_xlnet_pick_r(long T, bool backward) {
     const long blocks16 = (T + 15) / 16;
+    const int ncu = device_cus();
     const int budget = backward ? g_cu_budget.load(std::memory_order_relaxed) : 0;
-    if (budget <= 0 || budget >= 256) {
-        // smallest tile (fewest padded rows) whose grid still fits one residency of the 256 CUs; 5 beyond that
-        if (blocks16 <= 256) return 1;
-        if (blocks16 <= 512) return 2;
-        if (blocks16 <= 768) return 3;
+    if (budget <= 0 || budget >= ncu) {
+        // smallest tile (fewest padded rows) whose grid still fits one residency of the chip's CUs; 5 beyond that
+        if (blocks16 <= ncu) return 1;
+        if (blocks16 <= 2L * ncu) return 2;
+        if (blocks16 <= 3L * ncu) return 3;
         return 5;
     }
     int best = 5;

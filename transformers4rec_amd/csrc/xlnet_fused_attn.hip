@@ -242,7 +242,7 @@ static int launch_jobs(hipStream_t st, const PlaneJobs& js, const AmaxJobs& aj) 
     if (js.total == 0) return 0;
     if (aj.n > 0) hipLaunchKernelGGL(weight_scales_kernel, dim3(aj.n), dim3(1024), 0, st, aj);
     // the tiled form takes the fp16 planes of matrices whose sides are multiples of 32 with 16-byte-aligned destinations
-    const char* tiled_env = getenv("T4R_PLANES_TILED");        // read per call (two launches per step): a test flips it in-process
+    const char* tiled_env = t4r_exp_getenv("T4R_PLANES_TILED");        // read per call (two launches per step): a test flips it in-process
     bool tiled = !tiled_env || atoi(tiled_env) != 0;
     for (int i = 0; i < js.n && tiled; ++i) {
         const PlaneJob& j = js.j[i];

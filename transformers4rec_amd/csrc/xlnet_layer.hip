@@ -87,7 +87,7 @@ int t4r_xlnet_ff_bwd(void*, const float*, const float*, const float*, const floa
 }
 // T4R_XLNET_FUSED=0 restores the launch chain (A/B timing); default: fused kernels where they exist (d_model 32/64/128)
 static bool use_fused(int D) {
-    static const int on = [] { const char* e = getenv("T4R_XLNET_FUSED"); return e ? atoi(e) : 1; }();
+    static const int on = [] { const char* e = t4r_exp_getenv("T4R_XLNET_FUSED"); return e ? atoi(e) : 1; }();
     return on && t4r_xlnet_fused_supported(D);
 }
 
@@ -96,12 +96,12 @@ static bool use_fused(int D) {
 // tested and measured slower (120-130 us per launch against 118 us for the three launches it would replace: docs/DESIGN_rounds_1_to_4.md,
 // round 4); it lives in tools/experimental/ and is compiled only into the A/B variant library (-DT4R_EXPERIMENTAL).
 static bool use_attn_block(int L, int D, int n_head) {
-    static const int on = [] { const char* e = getenv("T4R_XLNET_ATTN_BLOCK"); return e ? atoi(e) : 1; }();
+    static const int on = [] { const char* e = t4r_exp_getenv("T4R_XLNET_ATTN_BLOCK"); return e ? atoi(e) : 1; }();
     return on && use_fused(D) && t4r_xlnet_attn_block_supported(L, D, n_head);
 }
 #ifdef T4R_EXPERIMENTAL
 static bool use_attn_block_bwd(int L, int D, int n_head) {
-    static const int on = [] { const char* e = getenv("T4R_XLNET_ATTN_BLOCK_BWD"); return e ? atoi(e) : 0; }();
+    static const int on = [] { const char* e = t4r_exp_getenv("T4R_XLNET_ATTN_BLOCK_BWD"); return e ? atoi(e) : 0; }();
     return on && use_fused(D) && t4r_xlnet_attn_block_supported(L, D, n_head);
 }
 static long attn_block_bwd_part(int B, int L, int D, int n_head) { return t4r_xlnet_attn_block_bwd_part_floats(B, L, D, n_head); }
@@ -335,16 +335,16 @@ static SideStream* side_stream() {
     if (!g_side[dev]) { g_side[dev] = new SideStream(); g_side[dev]->device = dev; }
     SideStream& ss = *g_side[dev];
     if (ss.state == 0) {
-        const char* e = getenv("T4R_LAYER_SIDE_STREAM");
+        const char* e = t4r_exp_getenv("T4R_LAYER_SIDE_STREAM");
         ss.state = -1;
         if (!(e && atoi(e) == 0)) {
             // lowest priority: the critical chain on the caller's stream gets the CUs first
             int lo = 0, hi = 0;
             (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-            const char* pe = getenv("T4R_LAYER_SIDE_PRIO");
+            const char* pe = t4r_exp_getenv("T4R_LAYER_SIDE_PRIO");
             const int prio = pe ? atoi(pe) : lo;
             // the events order streams of ONE device: no system-scope fence (cache write-back to host visibility) at each record
-            const char* fe = getenv("T4R_LAYER_EVENT_SYSFENCE");
+            const char* fe = t4r_exp_getenv("T4R_LAYER_EVENT_SYSFENCE");
             const unsigned evf = hipEventDisableTiming | ((fe && atoi(fe)) ? 0u : hipEventDisableSystemFence);
             bool ok = hipStreamCreateWithPriority(&ss.s, hipStreamNonBlocking, prio) == hipSuccess;
             ok = ok && hipStreamCreateWithPriority(&ss.s2, hipStreamNonBlocking, prio) == hipSuccess;
@@ -427,7 +427,7 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
     struct RedirectGuard {      // second stages of the column reductions -> side stream, for this call only
         bool on;
         RedirectGuard(SideStream* s) : on(false) {
-            static const int enabled = [] { const char* e = getenv("T4R_LAYER_SIDE_REDUCE"); return e ? atoi(e) : 1; }();
+            static const int enabled = [] { const char* e = t4r_exp_getenv("T4R_LAYER_SIDE_REDUCE"); return e ? atoi(e) : 1; }();
             if (s && enabled) { t4r_reduce_redirect(s->s, s->red, 8); on = true; }
         }
         ~RedirectGuard() { if (on) t4r_reduce_redirect(nullptr, nullptr, 0); }
@@ -449,7 +449,7 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
     // -- five 10-25 us kernels with ~6 us between them -- ran AFTER the critical chain had finished: ~95 us of idle
     // caller's stream at every layer boundary (rocprofv3 timeline, 4 x per step).  On their own stream they start when
     // their operands exist.
-    static const int two_side = [] { const char* e = getenv("T4R_LAYER_SIDE_STREAMS"); return e ? atoi(e) : 2; }();
+    static const int two_side = [] { const char* e = t4r_exp_getenv("T4R_LAYER_SIDE_STREAMS"); return e ? atoi(e) : 2; }();
     bool used_s2 = false;
     auto wg2 = [&]() -> hipStream_t {
         if (!ss) return st;

@@ -160,36 +160,48 @@ class GradReducer:
             # stream and the two weight-gradient streams of the body's backward, the collective's stream is the fourth, and a
             # FIFTH active stream slows every kernel of the step down (+1.0 ms per step measured on one GPU with one tiny
             # launch per step on an extra stream; GPU_MAX_HW_QUEUES does not lift it: profiles/r05_q_stream_count.txt).
-            cur = torch.cuda.current_stream()
-            from .prediction_task import _SIDE_STREAMS     # the head's d W on its (opt-in) side stream: the collective follows it
-            for side in _SIDE_STREAMS.values():
-                cur.wait_stream(side)
+            # Everything that writes the tables bucket before this point (the head's d W) runs on the caller's stream: c10d's
+            # ordering is the only dependency.  (the opt-in side stream of the head's d W, which this function used
+            # to drain into the caller's stream, is gone -- prediction_task.py.)
             self._pending = dist.all_reduce(self.tables, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             # the ring kernel now holds one CU per channel until the reduction is done, i.e. for most of the body's backward:
             # its one-workgroup-per-CU token-tile kernels are told to plan for the CUs that are left (csrc/xlnet_fused.hip:
-            # t4r_xlnet_set_cu_budget; measured on one GPU with a CU occupier, tools/occupier_curve.py: 1.36x -> 1.25x)
-            from . import ops
+            # t4r_xlnet_set_cu_budget; measured on one GPU with a CU occupier, tools/occupier_curve.py: 1.36x -> 1.25x, DESIGN.md
+            # section 6).  Only an RCCL collective holds CUs: gloo / CPU groups set no budget.  Cleared by reduce_all (in a
+            # finally), by the end-of-backward callback queued here, and -- if the backward raised before either -- by the next
+            # training forward (transformer.XLNetModel.forward: ops.xlnet_clear_cu_budget).
+            if dist.get_backend(self.group) == "nccl":
+                from . import ops
 
-            ops.xlnet_set_cu_budget(256 - collective_channels())
-            self._budgeted = True
+                ops.xlnet_set_cu_budget(max(1, ops.device_cus() - collective_channels()))
+                self._budgeted = True
+                try:
+                    torch.autograd.Variable._execution_engine.queue_callback(self._clear_budget)
+                except RuntimeError:
+                    pass                    # not inside a backward pass: reduce_all clears it
         else:
             self._pending = dist.all_reduce(self.tables, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
-    def reduce_all(self, tables_already_launched=None):
-        launched = self._launched if tables_already_launched is None else tables_already_launched
-        self._launched = False
+    def _clear_budget(self):
         if self._budgeted:          # the backward pass is over: the forward's kernels get the whole chip again
             from . import ops
 
             ops.xlnet_set_cu_budget(0)
             self._budgeted = False
-        if self.world > 1:
-            if self.tables is not None and not launched:
-                dist.all_reduce(self.tables, op=dist.ReduceOp.SUM, group=self.group)
-            dist.all_reduce(self.dense, op=dist.ReduceOp.SUM, group=self.group)
-            if self._pending is not None:
-                self._pending.wait()
-                self._pending = None
+
+    def reduce_all(self, tables_already_launched=None):
+        launched = self._launched if tables_already_launched is None else tables_already_launched
+        self._launched = False
+        try:
+            if self.world > 1:
+                if self.tables is not None and not launched:
+                    dist.all_reduce(self.tables, op=dist.ReduceOp.SUM, group=self.group)
+                dist.all_reduce(self.dense, op=dist.ReduceOp.SUM, group=self.group)
+                if self._pending is not None:
+                    self._pending.wait()
+                    self._pending = None
+        finally:
+            self._clear_budget()
         if self.sparse is not None:
             self.sparse.exchange()      # world 1: the local deterministic scatter
 

@@ -16,15 +16,13 @@ import torch
 from torch import nn
 
 from . import ops
-from .prediction_task_sync import wait_pending_grad as _wait_pending_grad
 from .transformations import TabularDropout, TabularLayerNorm, parse_post, parse_pre
 from .masking import MaskSequence, _grad_buf, parse_masking
 from .schema import Tags, categorical_cardinalities
 
-# table-gradient scatter: "sorted" = stable sort by row id (done in the forward pass: it depends on the ids
-# only) + segmented sum, deterministic, one owner per row (csrc/embedding_sorted.hip); "atomic" = fp32 row
-# atomics (csrc/embedding.hip), kept for A/B timing
-_EMB_BWD = os.environ.get("T4R_EMB_BWD", "sorted")
+# table-gradient scatter: stable sort by row id (done in the forward pass: it depends on the ids only) + segmented sum,
+# deterministic, one owner per row (csrc/embedding_sorted.hip).  The fp32-row-atomics scatter (ops.embedding_bwd) is
+# still in the C ABI for callers that want it; the module path does not use it.
 
 
 def _table_scatter(ctx, name, grad_rows, ids_f, tab, col, dim, padding_idx):
@@ -34,70 +32,22 @@ def _table_scatter(ctx, name, grad_rows, ids_f, tab, col, dim, padding_idx):
     if sink is not None:            # data-parallel row-sparse exchange (distributed.SparseRowExchange)
         sink.add(tab, ids_f, grad_rows, col, dim, ids_div, padding_idx)
         return
-    if _EMB_BWD == "atomic":
-        ops.embedding_bwd(grad_rows, ids_f, _grad_buf(tab), col, dim, padding_idx)
-        return
     srt = ctx.sorted_ids.get(name)
     if srt is None:
         srt = ops.sort_ids(ids_f, tab.shape[0], padding_idx)
-    elif len(srt) == 3:         # sorted on the side stream during the forward pass
-        cur = torch.cuda.current_stream()
-        cur.wait_event(srt[2])
-        srt[0].record_stream(cur)
-        srt[1].record_stream(cur)
     ops.embedding_bwd_sorted(grad_rows, srt[0], srt[1], _grad_buf(tab), col, dim, ids_div)
 
 
-_SORT_STREAMS = {}
-
-
 def _sort_ids_forward(ids, rows, padding_idx):
-    """the forward-pass sort (it feeds only the backward).  On the caller's stream by default; T4R_EMB_SORT_STREAM=1 puts it
-    on a side stream, under the gather and the transformer body.  Default OFF since round 5: the side stream is worth nothing
-    at BASELINE configs[1] (2.834 vs 2.847 ms per step) and it is the process's FOURTH stream -- the caller's, this one and
-    the two weight-gradient streams of the body's backward (csrc/xlnet_layer.hip) -- while a FIFTH active stream costs the
-    whole step +1.0 ms (every kernel slows down; profiles/r05_q_stream_count.txt), and a data-parallel run needs that
-    fourth slot for the collective's stream (distributed.GradReducer)."""
-    if os.environ.get("T4R_EMB_SORT_STREAM", "0") != "1":
-        return ops.sort_ids(ids, rows, padding_idx)
-    dev = ids.device
-    key = (dev.type, dev.index)
-    if key not in _SORT_STREAMS:
-        _SORT_STREAMS[key] = torch.cuda.Stream(device=dev)
-    side = _SORT_STREAMS[key]
-    side.wait_stream(torch.cuda.current_stream())
-    # `ids` may be a temporary (.contiguous() of a sliced / transposed batch) that the caller drops right after this
-    # enqueue: tell the caching allocator that the side stream still reads it, or the block could be handed to a
-    # main-stream allocation under the running sort
-    ids.record_stream(side)
-    with torch.cuda.stream(side):
-        keys, perm = ops.sort_ids(ids, rows, padding_idx)
-        done = torch.cuda.Event()
-        done.record(side)
-    return keys, perm, done
-
-
-_SORT_MULTI = os.environ.get("T4R_EMB_SORT_MULTI", "1") != "0"
+    """the forward-pass sort (it feeds only the backward), on the caller's stream.  (Rounds 3-4 ran it on a side stream; it
+    was worth nothing at BASELINE configs[1] -- 2.834 vs 2.847 ms per step -- and a training step must not drive more than
+    FOUR streams: caller + two weight-gradient streams + the collective's, DESIGN.md section 6.  Removed in round 6.)"""
+    return ops.sort_ids(ids, rows, padding_idx)
 
 
 def _sort_ids_forward_multi(ids_list, rows_list, padding_idx):
-    """_sort_ids_forward for the F tables of one input block at once -> [(keys, perm) or (keys, perm, event)] per table"""
-    pads = [padding_idx] * len(ids_list)
-    if os.environ.get("T4R_EMB_SORT_STREAM", "0") != "1":
-        return ops.sort_ids_multi(ids_list, rows_list, pads)
-    dev = ids_list[0].device
-    key = (dev.type, dev.index)
-    if key not in _SORT_STREAMS:
-        _SORT_STREAMS[key] = torch.cuda.Stream(device=dev)
-    side = _SORT_STREAMS[key]
-    side.wait_stream(torch.cuda.current_stream())
-    for ids in ids_list:
-        ids.record_stream(side)
-    with torch.cuda.stream(side):
-        srt = ops.sort_ids_multi(ids_list, rows_list, pads)
-        done = torch.cuda.Event()
-        done.record(side)
-    return [(k, p, done) for k, p in srt]
+    """_sort_ids_forward for the F tables of one input block as ONE device sort -> [(keys, perm)] per table"""
+    return ops.sort_ids_multi(ids_list, rows_list, [padding_idx] * len(ids_list))
 
 
 class EmbeddingTable(nn.Module):
@@ -537,14 +487,14 @@ class _SeqFeaturesFn(torch.autograd.Function):
         ctx.mod, ctx.inputs, ctx.soft_saved, ctx.post_saved = mod, inputs, soft_saved, post_saved
         # the sort behind the deterministic table gradient depends on the ids only: done here, in the forward
         ctx.sorted_ids = {}
-        if training and _EMB_BWD != "atomic":
+        if training:
             todo = []
             for name in names:
                 if name in cat.embedding_tables:
                     tab = cat.embedding_tables[name].weight
                     if tab.requires_grad and getattr(tab, "_t4r_sparse_sink", None) is None:
                         todo.append((name, inputs[name].contiguous(), tab.shape[0]))
-            if len(todo) > 1 and len({t[1].numel() for t in todo}) == 1 and len(todo) <= 16 and _SORT_MULTI:
+            if len(todo) > 1 and len({t[1].numel() for t in todo}) == 1 and len(todo) <= 16:
                 # every table of a multi-feature block in ONE device sort (a third of the launches: ops.sort_ids_multi)
                 srt = _sort_ids_forward_multi([t[1] for t in todo], [t[2] for t in todo], cat.padding_idx)
                 for (name, _i, _r), s_f in zip(todo, srt):
@@ -603,7 +553,6 @@ class _SeqFeaturesFn(torch.autograd.Function):
                 tab = cat.embedding_tables[name].weight
                 if not tab.requires_grad:
                     continue
-                _wait_pending_grad(tab)     # the tied head's d W may still be running on its side stream
                 src = d
                 if agg == "element-wise-sum-item-multi":
                     src = d_item if name == cat.item_id else d_other

@@ -63,8 +63,7 @@ def mlm_step(table: torch.Tensor, masked_emb: torch.Tensor, layers, cfg: Dict, i
     else:
         mask, labels, counts = ops.mask_targets(ids.contiguous(), ops.MLM_EVAL_LAST, cfg["padding_idx"])
         n, pos, lab = ops.compact_labels(labels, counts, cfg["padding_idx"])
-    table._t4r_padding_idx = int(cfg["padding_idx"])          # read by the gather's backward operator (table scatter)
-    x = T4R.seq_item_embedding(ids, table, mask, masked_emb, ops.MASK_MLM)
+    x = T4R.seq_item_embedding(ids, table, mask, masked_emb, ops.MASK_MLM, int(cfg["padding_idx"]))
     pe = relative_positional_encoding(L, D).to(x.device).contiguous()
     pos_b = None
     if p > 0:
@@ -168,14 +167,13 @@ def session_step(block, spec, layers, cfg: Dict, inputs: Dict[str, torch.Tensor]
     else:
         mask, labels, counts = ops.mask_targets(item_ids, ops.MLM_EVAL_LAST, cfg["padding_idx"])
         n, pos, lab = ops.compact_labels(labels, counts, cfg["padding_idx"])
-    for t in block["tables"]:
-        t._t4r_padding_idx = int(cfg["padding_idx"])
+    pad = int(cfg["padding_idx"])
     if len(spec["layout"]) == 1 and block["proj"] is None:
-        x = T4R.seq_item_embedding(item_ids, table, mask, block["masked_emb"], ops.MASK_MLM)
+        x = T4R.seq_item_embedding(item_ids, table, mask, block["masked_emb"], ops.MASK_MLM, pad)
     else:
         dense = [T4R.soft_embedding(inputs[nm].contiguous().float(), s["proj_w"], s["proj_b"], s["table"], s["ln_w"], s["ln_b"], s["eps"])
                  for nm, s in zip(spec["dense_names"], block["soft"])]
-        x = T4R.seq_concat(ids, list(block["tables"]), dense, list(spec["layout"]), list(spec["dims"]))
+        x = T4R.seq_concat(ids, list(block["tables"]), dense, list(spec["layout"]), list(spec["dims"]), pad)
         W = x.shape[-1]
         if block["proj"] is not None:
             x = T4R.linear_relu(x.view(B * L, W), block["proj"][0], block["proj"][1]).view(B, L, -1)

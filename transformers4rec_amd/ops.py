@@ -41,7 +41,7 @@ def _p(t, dtype=None, name="tensor"):
     return None if t is None else _chk(t, dtype, name)
 
 
-_LD_ALIGN = int(__import__("os").environ.get("T4R_LOGITS_LD_ALIGN", "64"))
+_LD_ALIGN = int(_lib.exp_env("T4R_LOGITS_LD_ALIGN", "64"))
 
 
 def pad_ld(V):
@@ -121,8 +121,14 @@ def gemm_wgrad(a, b, out):
     try:
         gemm(a, b, True, False, splitk=-1, accumulate=True, out=out)
         call("t4r_gemm_splitk_sink_flush", _stream())
+        bypassed = lib.t4r_gemm_splitk_sink_bypassed()
     finally:
         lib.t4r_gemm_splitk_sink_end()
+    if bypassed:       # the sizing above is a copy of the launcher's rule: if they ever part, say so instead of silently losing
+        import warnings   # the bit-reproducibility this function exists for (the sum itself is still correct)
+
+        warnings.warn(f"gemm_wgrad: {bypassed} split-K launch(es) found no room in the deterministic sink ({splits} splits "
+                      f"planned for M={M} N={N} K={K}) and used fp32 atomics: this gradient is not bit-reproducible", RuntimeWarning)
     return out
 
 
@@ -862,9 +868,24 @@ def xlnet_dh_(dqkv, planes, dh):
     return dh
 
 
+_CU_BUDGET_SET = False
+
+
 def xlnet_set_cu_budget(cus):
-    """CUs the backward pass's token-tile kernels may count on (0 = all): set while a collective holds CUs (distributed.py)"""
+    """CUs the backward's token-tile kernels may plan for (0 = the whole chip); process-wide (csrc/xlnet_fused.hip)"""
+    global _CU_BUDGET_SET
     _lib.load().t4r_xlnet_set_cu_budget(int(cus))
+    _CU_BUDGET_SET = int(cus) > 0
+
+
+def xlnet_clear_cu_budget():
+    """no-op unless a budget is set: the safety net of a backward pass that raised before its reducer cleared it"""
+    if _CU_BUDGET_SET:
+        xlnet_set_cu_budget(0)
+
+
+def device_cus():
+    return int(_lib.load().t4r_device_cus())
 
 
 def xlnet_get_cu_budget():

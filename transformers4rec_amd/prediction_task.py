@@ -15,6 +15,7 @@ import torch
 from torch import nn
 
 from . import ops
+from ._lib import exp_env as _exp_env
 from .features import _Linear
 from .masking import MaskedLanguageModeling, _grad_buf
 from .ranking_metric import coerce as coerce_metric, default_metrics
@@ -100,32 +101,16 @@ class _Pre(nn.Module):
         self.module = module
 
 
-# the tied / untied head's d W on a side stream, under the body's backward (T4R_HEAD_SIDE_STREAM=1 turns it on).
-# Round 1: 5.64 -> 5.61 ms/step (opt-in then); round 2, with the faster split-form products: 5.17 / 5.12 -> 5.10 / 5.05
-# ms on one box (-1.4 %), on by default then.  Round 3: OFF by default -- the body's backward now starts with
-# token-tile kernels that take a whole CU each (one 512-thread workgroup, ~140 KB of LDS): next to the 0.5 ms d W launch
-# they wait for CUs instead of overlapping (first xlnet_ff_bwd_kernel of a step: 572 us beside it, 85 us alone), and the
-# two serialise anyway: 3.90 -> 3.85 ms/step on one box without the side stream.  Consumers order themselves after it
-# when it is on: the input block's scatter (wait_pending_grad), the optimizer (autograd callback below), the data-parallel
-# table all-reduce (distributed.GradReducer.reduce_tables_async waits for this stream).
-_SIDE_STREAM_ON = os.environ.get("T4R_HEAD_SIDE_STREAM", "0") == "1"
-# sampled softmax: weight gradient as (ids, rows) + deterministic sorted scatter (default) instead of row atomics
-_SAMPLED_ROWS = os.environ.get("T4R_SAMPLED_ROWS", "1") == "1"
-_SIDE_STREAMS = {}
+# The head's d W runs on the caller's stream, right after d X.  (Rounds 1-2 ran it on a side stream under the body's
+# backward; since round 3 the body's backward starts with token-tile kernels that take a whole CU each, the two only
+# serialise -- 3.90 -> 3.85 ms per step without the side stream -- and a training step must not drive more than four
+# streams, DESIGN.md section 6: the switch and its plumbing were removed in round 6.)
+# sampled softmax: weight gradient as (ids, rows) + deterministic sorted scatter instead of row atomics
+_SAMPLED_ROWS = _exp_env("T4R_SAMPLED_ROWS", "1") == "1"
 
 
-def _side_stream(device):
-    key = (device.type, device.index)
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
-    return _SIDE_STREAMS[key]
-
-
-from .prediction_task_sync import wait_pending_grad  # noqa: E402,F401
-
-
-_HEAD_SPLIT = os.environ.get("T4R_HEAD_SPLIT", "1") != "0"
-_HEAD_RECOMPUTE = os.environ.get("T4R_HEAD_RECOMPUTE", "1") != "0"
+_HEAD_SPLIT = _exp_env("T4R_HEAD_SPLIT", "1") != "0"
+_HEAD_RECOMPUTE = _exp_env("T4R_HEAD_RECOMPUTE", "1") != "0"
 
 
 def _head_split_ok(xp, W, N, V):
@@ -257,27 +242,7 @@ class _NextItemHeadFn(torch.autograd.Function):
                     ops.gemm_softmax_grad(logits, lse, tgt, g, V, xp, True, alpha=1.0 / T, label_smoothing=smooth,
                                           out=gw, accumulate=True)
             if W.requires_grad:
-                # d W only feeds the optimizer (and, when tied, the embedding scatter at the very end of
-                # the backward): it runs on a side stream, under the latency-bound kernels of the body's
-                # backward.  Ordering: the side stream waits for this point; the table's next writer
-                # (features.embedding_bwd) and everything enqueued after backward() wait for `done`.
-                gw = _grad_buf(W)
-                if _SIDE_STREAM_ON:
-                    side = _side_stream(logits.device)
-                    ready = torch.cuda.Event()
-                    ready.record()
-                    with torch.cuda.stream(side):
-                        side.wait_event(ready)
-                        d_w(gw)
-                        done = torch.cuda.Event()
-                        done.record(side)
-                    for t in (logits, lse, tgt, g, xp, gw) + (() if hws is None else (hws,)):
-                        t.record_stream(side)      # the caching allocator must not recycle them under the side kernel
-                    W._t4r_pending = done
-                    torch.autograd.Variable._execution_engine.queue_callback(
-                        lambda ev=done: torch.cuda.current_stream().wait_event(ev))
-                else:
-                    d_w(gw)
+                d_w(_grad_buf(W))
         else:
             dl = ops.softmax_ce_bwd(logits, tgt, lse, dloss.contiguous(), width, smooth)
             sink = getattr(W, "_t4r_sparse_sink", None)

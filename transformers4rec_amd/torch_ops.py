@@ -198,7 +198,7 @@ def _(ids, p, seed, offset, padding_idx):
 
 
 @torch.library.custom_op(f"{NS}::seq_item_embedding", mutates_args=())
-def seq_item_embedding(ids: torch.Tensor, table: torch.Tensor, mask: torch.Tensor, masked_emb: torch.Tensor, mask_mode: int) -> torch.Tensor:
+def seq_item_embedding(ids: torch.Tensor, table: torch.Tensor, mask: torch.Tensor, masked_emb: torch.Tensor, mask_mode: int, padding_idx: int = 0) -> torch.Tensor:
     """item-id sequence embedding with the masking epilogue (features/embedding.py:226-249 + masking.py:473-498): [B, L, D]"""
     B, L = ids.shape
     D = table.shape[1]
@@ -207,7 +207,7 @@ def seq_item_embedding(ids: torch.Tensor, table: torch.Tensor, mask: torch.Tenso
 
 
 @seq_item_embedding.register_fake
-def _(ids, table, mask, masked_emb, mask_mode):
+def _(ids, table, mask, masked_emb, mask_mode, padding_idx=0):
     return table.new_empty((ids.shape[0], ids.shape[1], table.shape[1]))
 
 
@@ -229,16 +229,16 @@ def _(dy, ids, mask, rows, mask_mode, padding_idx):
 
 
 def _seq_item_setup(ctx, inputs, output):
-    ids, table, mask, masked_emb, mask_mode = inputs
+    ids, table, mask, masked_emb, mask_mode, padding_idx = inputs
     ctx.save_for_backward(ids, mask)
     ctx.rows, ctx.mask_mode = table.shape[0], mask_mode
-    ctx.padding_idx = getattr(table, "_t4r_padding_idx", 0)
+    ctx.padding_idx = int(padding_idx)         # an explicit operator argument: survives functional_call / make_fx
 
 
 def _seq_item_backward(ctx, dy):
     ids, mask = ctx.saved_tensors
     d_table, d_memb = torch.ops.t4r_hip.seq_item_embedding_bwd(dy, ids, mask, ctx.rows, ctx.mask_mode, ctx.padding_idx)
-    return None, d_table, None, d_memb, None
+    return None, d_table, None, d_memb, None, None
 
 
 seq_item_embedding.register_autograd(_seq_item_backward, setup_context=_seq_item_setup)
@@ -519,7 +519,7 @@ def _concat_feats(ids, tables, dense, layout, dims):
 
 @torch.library.custom_op(f"{NS}::seq_concat", mutates_args=())
 def seq_concat(ids: Sequence[torch.Tensor], tables: Sequence[torch.Tensor], dense: Sequence[torch.Tensor], layout: List[int],
-               dims: List[int]) -> torch.Tensor:
+               dims: List[int], padding_idx: int = 0) -> torch.Tensor:
     """the concatenating gather of the input block (features/embedding.py:226-249 + tabular/aggregation.py:35-47, one launch):
     table features looked up by their [B, L] ids, dense rows ([B * L, dim]: soft embeddings, continuous columns) copied, column
     blocks in `layout` order (the reference's sorted feature names) -> [B, L, sum(dims)]"""
@@ -529,7 +529,7 @@ def seq_concat(ids: Sequence[torch.Tensor], tables: Sequence[torch.Tensor], dens
 
 
 @seq_concat.register_fake
-def _(ids, tables, dense, layout, dims):
+def _(ids, tables, dense, layout, dims, padding_idx=0):
     return tables[0].new_empty((ids[0].shape[0], ids[0].shape[1], sum(dims)))
 
 
@@ -565,16 +565,16 @@ def _(dy, ids, table_rows, layout, dims, padding_idx):
 
 
 def _sc_setup(ctx, inputs, output):
-    ids, tables, dense, layout, dims = inputs
+    ids, tables, dense, layout, dims, padding_idx = inputs
     ctx.save_for_backward(*ids)
     ctx.rows = [t.shape[0] for t in tables]
     ctx.layout, ctx.dims = list(layout), list(dims)
-    ctx.padding_idx = getattr(tables[0], "_t4r_padding_idx", 0)
+    ctx.padding_idx = int(padding_idx)
 
 
 def _sc_backward(ctx, dy):
     d_tables, d_dense = torch.ops.t4r_hip.seq_concat_grad(dy, list(ctx.saved_tensors), ctx.rows, ctx.layout, ctx.dims, ctx.padding_idx)
-    return [None] * len(ctx.saved_tensors), list(d_tables), list(d_dense), None, None       # (a list argument gets a list back)
+    return [None] * len(ctx.saved_tensors), list(d_tables), list(d_dense), None, None, None       # (a list argument gets a list back)
 
 
 seq_concat.register_autograd(_sc_backward, setup_context=_sc_setup)

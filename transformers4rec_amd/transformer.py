@@ -172,8 +172,10 @@ class _XLNetLayerFn(torch.autograd.Function):
         return dh.view(B, L, D), None, None, None, None, None, None, None, None, None
 
 
-_DEFER_JOIN = os.environ.get("T4R_XLNET_DEFER_JOIN", "1") != "0"
-_STACK_PROLOGUE = os.environ.get("T4R_XLNET_STACK_PROLOGUE", "1") != "0" and os.environ.get("T4R_XLNET_FUSED", "1") != "0"
+from ._lib import exp_env as _exp_env  # noqa: E402
+
+_DEFER_JOIN = _exp_env("T4R_XLNET_DEFER_JOIN", "1") != "0"       # a test flips the attribute; the product reads no switch
+_STACK_PROLOGUE = _exp_env("T4R_XLNET_STACK_PROLOGUE", "1") != "0" and _exp_env("T4R_XLNET_FUSED", "1") != "0"
 _PENDING: list = []          # buffers of deferred layer backwards (kept alive until the join)
 
 
@@ -238,6 +240,7 @@ class XLNetModel(SeedMixin, nn.Module):
         None reproduces the reference, which passes no attention mask."""
         cfg = self.config
         _join_weight_gradient_streams()      # leftovers of a backward pass that raised (no-op normally)
+        ops.xlnet_clear_cu_budget()          # likewise: a data-parallel backward that raised before its reducer cleared it
         B, L, D = inputs_embeds.shape
         if D != cfg.d_model:
             raise ValueError(f"inputs_embeds last dim {D} != d_model {cfg.d_model}")

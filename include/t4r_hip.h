@@ -126,6 +126,9 @@ int t4r_apply_mask_fwd(void* stream, float* x, const unsigned char* mask, const 
 long t4r_apply_mask_bwd_ws_floats(int B, int L, int H);
 int t4r_apply_mask_bwd(void* stream, float* dy, const unsigned char* mask, float* d_masked_emb, int B,
                        int L, int H, int mode, float* ws /* t4r_apply_mask_bwd_ws_floats floats: fixed-order two-stage sum */);
+/* the same out of place (dx = masked gradient, dy untouched; dy != dx): no clone of the incoming gradient in the caller */
+int t4r_apply_mask_bwd_to(void* stream, const float* dy, float* dx, const unsigned char* mask, float* d_masked_emb, int B,
+                          int L, int H, int mode, float* ws);
 int t4r_mul(void* stream, const float* a, const float* b, float* out, long n);
 
 /* a4  SoftEmbedding (+ per-feature LayerNorm)
@@ -162,6 +165,9 @@ int t4r_compact_labels(void* stream, const long* masked_targets, const int* row_
                        long* labels_compact);
 int t4r_gather_rows(void* stream, const float* x, const int* pos, float* out, int n, int D);
 int t4r_scatter_rows_add(void* stream, const float* dout, const int* pos, float* dx, int n, int D);
+/* dx [T, D] = 0 except dx[pos[r], :] = (*scale or 1) * src[r, :], r < n; pos ascending.  One launch for the backward of the
+ * label-row selection x[non_pad_mask] (prediction_task.py:472-479): zero fill + upstream-gradient scaling + scatter. */
+int t4r_scatter_rows_dense(void* stream, const float* src, const int* pos, int n, const float* scale, float* dx, long T, int D);
 /* a21  inference row selection (prediction_task.py:453-461): pos[b] = b*Lgrid + last_item(b) */
 int t4r_last_positions(void* stream, const long* item_ids, int B, int L, int Lgrid, int is_mlm,
                        long padding_idx, int* pos);

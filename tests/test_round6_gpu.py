@@ -177,3 +177,39 @@ def test_three_optimizer_steps_in_lockstep_at_the_benchmarked_setting(ops):
     adam_close(model.input_features.item_embedding_table.weight, p["tables"]["item_id"], "item table")
     adam_close(xl.layer[1].ff.layer_1.weight, p["layers"][1]["w1"], "layer 1 w1")
     adam_close(xl.layer[3].rel_attn.q, p["layers"][3]["q"], "layer 3 q")
+
+
+# ------------------------------------------------------------------------------------------ small launches folded (round 6)
+@pytest.mark.parametrize("T,D,n", [(20480, 128, 2780), (37, 64, 5), (64, 32, 0), (100, 128, 100)])
+def test_scatter_rows_dense_equals_zero_fill_plus_scale_plus_scatter(ops, T, D, n):
+    """one launch for the backward of the label-row selection (prediction_task.py:472-479): bit-identical to torch.zeros +
+    multiply + scatter_rows_add_"""
+    g = torch.Generator().manual_seed(T + n)
+    pos = torch.sort(torch.randperm(T, generator=g)[:n])[0].to(torch.int32)
+    pos_dev = torch.zeros(T, dtype=torch.int32)
+    pos_dev[:n] = pos
+    src = torch.randn(max(n, 1), D, generator=g).to(DEV)
+    scale = torch.tensor(0.37, device=DEV)
+    got = ops.scatter_rows_dense(src, pos_dev.to(DEV), n, scale, T)
+    want = torch.zeros(T, D, device=DEV)
+    if n:
+        ops.scatter_rows_add_((src[:n] * scale).contiguous(), pos_dev[:n].to(DEV), want)
+    assert torch.equal(got, want)
+    # no scale pointer == a scale of one
+    assert torch.equal(ops.scatter_rows_dense(src, pos_dev.to(DEV), n, None, T),
+                       ops.scatter_rows_dense(src, pos_dev.to(DEV), n, torch.tensor(1.0, device=DEV), T))
+
+
+@pytest.mark.parametrize("mode", ["MASK_MLM", "MASK_CLM", "MASK_CLM_INFER"])
+def test_out_of_place_mask_backward_equals_the_in_place_one(ops, mode):
+    B, L, H = 33, 20, 128
+    g = torch.Generator().manual_seed(3)
+    dy = torch.randn(B, L, H, generator=g).to(DEV)
+    mask = (torch.rand(B, L, generator=g) < 0.3).to(DEV)
+    keep = dy.clone()
+    m1, m2 = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    dx = ops.apply_mask_bwd(dy, mask, m1, getattr(ops, mode))
+    assert torch.equal(dy, keep)                                  # the incoming gradient is untouched
+    ref = dy.clone()
+    ops.apply_mask_bwd_(ref, mask, m2, getattr(ops, mode))
+    assert torch.equal(dx, ref) and torch.equal(m1, m2)

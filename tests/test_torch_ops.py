@@ -159,7 +159,7 @@ def test_training_operators_propagate_under_fake_tensors_and_have_autograd():
         mask, labels, pos, lab, cnt = torch.ops.t4r_hip.mlm_targets(ids, 0.15, 1, 0, 0)
         assert mask.dtype == torch.bool and labels.shape == (B, L) and pos.dtype == torch.int32 and cnt.shape == (1,)
         table, memb = torch.empty(V, D, device=DEV), torch.empty(D, device=DEV)
-        x = torch.ops.t4r_hip.seq_item_embedding(ids, table, mask, memb, 1)
+        x = torch.ops.t4r_hip.seq_item_embedding(ids, table, mask, memb, 1, 0)
         assert x.shape == (B, L, D)
         dt, dm = torch.ops.t4r_hip.seq_item_embedding_bwd(x, ids, mask, V, 1, 0)
         assert dt.shape == (V, D) and dm.shape == (D,)
@@ -181,7 +181,7 @@ def test_training_operators_propagate_under_fake_tensors_and_have_autograd():
         memb = torch.empty(64, device=DEV, requires_grad=True)
         ids = torch.empty(3, 20, dtype=torch.int64, device=DEV)
         mask = torch.empty(3, 20, dtype=torch.bool, device=DEV)
-        x = torch.ops.t4r_hip.seq_item_embedding(ids, table, mask, memb, 1)
+        x = torch.ops.t4r_hip.seq_item_embedding(ids, table, mask, memb, 1, 0)
         assert x.requires_grad and x.grad_fn is not None
         prm = [p.requires_grad_() for p in _layer_params(64, 4, DEV)]
         out, ws = torch.ops.t4r_hip.xlnet_layer_fwd(x.view(60, 64), torch.empty(40, 64, device=DEV), prm, 3, 20, 4, 0.03, 0.0, 1, 0, 0, None)
@@ -343,7 +343,7 @@ def test_input_block_operators_propagate_under_fake_tensors():
         se = [torch.empty(*s, device=DEV, requires_grad=True) for s in ((10, 1), (10,), (10, 8), (8,), (8,))]
         rows = torch.ops.t4r_hip.soft_embedding(x, se[0], se[1], se[2], se[3], se[4], 1e-5)
         assert rows.shape == (B * L, 8) and rows.grad_fn is not None
-        cat = torch.ops.t4r_hip.seq_concat(ids, tabs, [rows, rows], [-1, 1, 2, 3, -2], [8, 32, 32, 64, 8])
+        cat = torch.ops.t4r_hip.seq_concat(ids, tabs, [rows, rows], [-1, 1, 2, 3, -2], [8, 32, 32, 64, 8], 0)
         assert cat.shape == (B, L, 144) and cat.grad_fn is not None
         dt, dd = torch.ops.t4r_hip.seq_concat_grad(cat, ids, [11, 101, 501], [-1, 1, 2, 3, -2], [8, 32, 32, 64, 8], 0)
         assert [t.shape for t in dt] == [t.shape for t in tabs] and [t.shape for t in dd] == [(B * L, 8)] * 2

@@ -6,7 +6,7 @@ out=gpurun_out
 mkdir -p $out
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
 for kv in "$@"; do export "$kv"; done
-B="python bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-recall --preheat-seconds 2"
+B="python bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-recall --no-live-traffic --preheat-seconds 2"
 rocprofv3 --kernel-trace --stats -d $out/${tag}_prof -o r -- $B > $out/${tag}_prof.log 2>&1
 db=$(find $out/${tag}_prof -name "*_results.db" | head -1)
 python tools/rocpd_stats.py $db --csv $out/${tag}_kernel_stats.csv > /dev/null

@@ -7,12 +7,12 @@ tag=${1:-r02}
 out=gpurun_out
 mkdir -p $out
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
-B="python bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-recall --preheat-seconds 2"
+B="python bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-recall --no-live-traffic --preheat-seconds 2"
 rocprofv3 --kernel-trace --stats -d $out/${tag}_prof -o r -- $B > $out/${tag}_prof.log 2>&1
 db=$(find $out/${tag}_prof -name "*_results.db" | head -1)
 python tools/rocpd_stats.py $db --csv $out/${tag}_kernel_stats.csv > /dev/null
 # MFMA utilisation inside the step
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $out/${tag}_pmc_mfma -o r -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-recall --preheat-seconds 0.5 > $out/${tag}_pmc_mfma.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $out/${tag}_pmc_mfma -o r -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-recall --no-live-traffic --preheat-seconds 0.5 > $out/${tag}_pmc_mfma.log 2>&1
 db=$(find $out/${tag}_pmc_mfma -name "*_results.db" | head -1)
 python tools/pmc_mfma_util.py $db > $out/${tag}_pmc_mfma_util.csv
 # HBM traffic: GEMM shapes and gather / scatter kernels, FETCH_SIZE and WRITE_SIZE in separate passes

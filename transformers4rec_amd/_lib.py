@@ -36,6 +36,7 @@ _SIGS = {
     "t4r_apply_mask_fwd": ("i", "ppppiiii"),
     "t4r_apply_mask_bwd": ("i", "ppppiiii" + "p"),
     "t4r_apply_mask_bwd_ws_floats": ("l", "iii"),
+    "t4r_apply_mask_bwd_to": ("i", "pppppiiii" + "p"),
     "t4r_mul": ("i", "ppppl"),
     "t4r_soft_embedding_fwd": ("i", "pppppppp" + "liif"),
     "t4r_soft_embedding_bwd": ("i", "pppppppppppp" + "liiiif" + "p"),
@@ -44,6 +45,7 @@ _SIGS = {
     "t4r_compact_labels": ("i", "pppiil" + "pppp"),
     "t4r_gather_rows": ("i", "ppppii"),
     "t4r_scatter_rows_add": ("i", "ppppii"),
+    "t4r_scatter_rows_dense": ("i", "pppippli"),
     "t4r_last_positions": ("i", "ppiiiilp"),
     "t4r_gemm_f32": ("i", "piiiiif" + "plplpl" + "pipl" + "iii" + "lll" + "fQQ"),
     "t4r_gemm_splitk_sink_begin": ("v", "pl"),

@@ -376,7 +376,8 @@ extern "C" int t4r_apply_mask_fwd(void* stream, float* x, const unsigned char* m
 // The sum is formed in two stages (per-workgroup partial rows, then t4r_reduce_partials_launch in block order): 640
 // workgroups adding into the same H addresses with atomics took 24 us and gave a different rounding every run.
 #define T4R_MASK_BWD_TOK 32
-__global__ __launch_bounds__(256) void apply_mask_bwd_kernel(float* __restrict__ dy,
+// src == dst: in place (only the zeroed elements are written); else every element of dst is written (dst = src where kept)
+__global__ __launch_bounds__(256) void apply_mask_bwd_kernel(const float* src, float* dy,
                                                               const unsigned char* __restrict__ mask,
                                                               float* __restrict__ part, long ntok,
                                                               int L, int H, int mode) {
@@ -399,8 +400,10 @@ __global__ __launch_bounds__(256) void apply_mask_bwd_kernel(float* __restrict__
                 if (mode == MASK_MLM) keep = !m;
                 else if (mode == MASK_CLM) { keep = m; zero = (l == L - 1); }
                 else keep = m;
-                if (!keep) { acc += dy[t * H + c]; dy[t * H + c] = 0.f; }
+                const float v = src[t * H + c];
+                if (!keep) { acc += v; dy[t * H + c] = 0.f; }
                 else if (zero) dy[t * H + c] = 0.f;
+                else if (src != dy) dy[t * H + c] = v;
             }
         }
         sh[threadIdx.x] = acc;
@@ -425,7 +428,23 @@ extern "C" int t4r_apply_mask_bwd(void* stream, float* dy, const unsigned char* 
     if (ntok == 0 || mode == MASK_NONE) return 0;
     T4R_CHECK_ARG(ws, "apply_mask_bwd: null workspace");
     const int nblk = (int)((ntok + T4R_MASK_BWD_TOK - 1) / T4R_MASK_BWD_TOK);
-    hipLaunchKernelGGL(apply_mask_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dy, mask, ws, ntok, L, H, mode);
+    hipLaunchKernelGGL(apply_mask_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dy, dy, mask, ws, ntok, L, H, mode);
+    T4R_LAUNCH_CHECK();
+    return t4r_reduce_partials_launch((hipStream_t)stream, ws, nblk, d_memb, H, 1, nullptr, 0, 0, nullptr, 0, 0);
+}
+// the same out of place: dx = the masked gradient, dy untouched (an autograd backward must not write its incoming gradient:
+// the module path cloned dy first -- a 10 MB device copy per step at BASELINE configs[1] -- and masked the clone in place)
+extern "C" int t4r_apply_mask_bwd_to(void* stream, const float* dy, float* dx, const unsigned char* mask, float* d_memb,
+                                     int B, int L, int H, int mode, float* ws) {
+    const long ntok = (long)B * L;
+    if (ntok == 0) return 0;
+    T4R_CHECK_ARG(dy && dx && dy != dx, "apply_mask_bwd_to: dy and dx must be distinct buffers");
+    if (mode == MASK_NONE) {
+        return (int)hipMemcpyAsync(dx, dy, sizeof(float) * ntok * H, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    }
+    T4R_CHECK_ARG(ws, "apply_mask_bwd_to: null workspace");
+    const int nblk = (int)((ntok + T4R_MASK_BWD_TOK - 1) / T4R_MASK_BWD_TOK);
+    hipLaunchKernelGGL(apply_mask_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dy, dx, mask, ws, ntok, L, H, mode);
     T4R_LAUNCH_CHECK();
     return t4r_reduce_partials_launch((hipStream_t)stream, ws, nblk, d_memb, H, 1, nullptr, 0, 0, nullptr, 0, 0);
 }

@@ -305,6 +305,42 @@ extern "C" int t4r_scatter_rows_add(void* stream, const float* dout, const int* 
     return 0;
 }
 
+// The head's backward as ONE launch (round 6): dx [T, D] = 0 except dx[pos[r], :] = scale * src[r, :] for the n label rows.
+// Replaces torch.zeros (a 10 MB fill) + an element-wise multiply by the upstream gradient + scatter_rows_kernel: three launches
+// of ~6 us each on the caller's stream.  `pos` is ascending (label compaction is row-major: compact_labels_kernel), so a row
+// finds out whether it is a label row -- and which -- by bisection; no atomics, no ordering between workgroups.
+// Reference op chain: the autograd of `x[non_pad_mask]` in NextItemPredictionTask.remove_pad_3d (prediction_task.py:472-479).
+__global__ __launch_bounds__(256) void scatter_rows_dense_kernel(const float* __restrict__ src, const int* __restrict__ pos, int n,
+                                                                  const float* __restrict__ scale, float* __restrict__ dx, long T,
+                                                                  int D) {
+    const int dq = D / 4;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * dq) return;
+    const int t = (int)(i / dq), c = (int)(i % dq) * 4;
+    int lo = 0, hi = n;                       // first index with pos[idx] >= t
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (pos[mid] < t) lo = mid + 1; else hi = mid;
+    }
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lo < n && pos[lo] == t) {
+        const float g = scale ? *scale : 1.f;
+        const float4 v = *reinterpret_cast<const float4*>(src + (long)lo * D + c);
+        o = make_float4(g * v.x, g * v.y, g * v.z, g * v.w);
+    }
+    *reinterpret_cast<float4*>(dx + (long)t * D + c) = o;
+}
+extern "C" int t4r_scatter_rows_dense(void* stream, const float* src, const int* pos, int n, const float* scale, float* dx, long T,
+                                      int D) {
+    if (T == 0) return 0;
+    T4R_CHECK_ARG(D % 4 == 0 && dx && (n == 0 || (src && pos)), "scatter_rows_dense: D must be a multiple of 4, pointers non-null");
+    const long t = T * (D / 4);
+    hipLaunchKernelGGL(scatter_rows_dense_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, pos, n,
+                       scale, dx, T, D);
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
 // inference: position of the hidden state to score (prediction_task.py:453-461)
 //   MLM: count(non-pad)   (index into the L+1 grid) ; otherwise count(non-pad) - 1 (wraps to L-1... torch -1)
 __global__ __launch_bounds__(256) void last_positions_kernel(const long* __restrict__ ids, int B, int L,

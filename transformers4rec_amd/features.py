@@ -515,9 +515,10 @@ class _SeqFeaturesFn(torch.autograd.Function):
         if L_out != L:
             raise RuntimeError("the MLM inference grid (L+1) is forward-only")
         masking, proj = mod._masking, mod.projection_module
-        d = dy.contiguous().clone()
-        if masking is not None:
-            ops.apply_mask_bwd_(d, ctx.mask, _grad_buf(masking.masked_item_embedding), ctx.mask_mode)
+        if masking is not None:     # out of place: the incoming gradient is not ours to write, and a clone is a 10 MB copy
+            d = ops.apply_mask_bwd(dy, ctx.mask, _grad_buf(masking.masked_item_embedding), ctx.mask_mode)
+        else:
+            d = dy.contiguous().clone()
         if proj is not None:
             lin = proj[0][0]
             H = d.shape[-1]

@@ -49,9 +49,7 @@ class _ApplyMaskFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         (mask,) = ctx.saved_tensors
-        dx = dy.contiguous().clone()
-        ops.apply_mask_bwd_(dx, mask, _grad_buf(ctx.memb), ctx.mode)
-        return dx, None, None, None
+        return ops.apply_mask_bwd(dy, mask, _grad_buf(ctx.memb), ctx.mode), None, None, None
 
 
 class MaskSequence(SeedMixin, nn.Module):

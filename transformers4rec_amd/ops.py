@@ -558,6 +558,16 @@ def apply_mask_bwd_(dy, mask, d_memb, mode):
     return dy
 
 
+def apply_mask_bwd(dy, mask, d_memb, mode):
+    """out of place: -> dx (dy untouched); d_memb accumulated"""
+    B, L, H = dy.shape
+    dy = dy.contiguous()
+    dx = torch.empty_like(dy)
+    ws = torch.empty(max(1, _lib.load().t4r_apply_mask_bwd_ws_floats(B, L, H)), device=dy.device, dtype=torch.float32)
+    call("t4r_apply_mask_bwd_to", _stream(), _chk(dy), dx.data_ptr(), _chk(mask), _chk(d_memb), B, L, H, mode, ws.data_ptr())
+    return dx
+
+
 def mul(a, b):
     out = torch.empty_like(a)
     call("t4r_mul", _stream(), _chk(a), _chk(b), out.data_ptr(), a.numel())
@@ -623,6 +633,14 @@ def scatter_rows_add_(dout, pos, dx2d):
     n, D = dout.shape
     call("t4r_scatter_rows_add", _stream(), _chk(dout), _chk(pos, torch.int32), _chk(dx2d), n, D)
     return dx2d
+
+
+def scatter_rows_dense(src, pos, n, scale, T):
+    """[T, D] zeros with row pos[r] = scale * src[r] (r < n; pos ascending, scale a device scalar or None): one launch"""
+    D = src.shape[1]
+    dx = torch.empty((T, D), device=src.device, dtype=torch.float32)
+    call("t4r_scatter_rows_dense", _stream(), _chk(src), _chk(pos, torch.int32), int(n), _p(scale), dx.data_ptr(), int(T), D)
+    return dx
 
 
 def last_positions(item_ids, Lgrid, is_mlm, padding_idx=0):

@@ -208,6 +208,7 @@ class _NextItemHeadFn(torch.autograd.Function):
         W = mod.output_weights
         if dloss is None:
             return (None,) * 7
+        dense_dx = False
         if getattr(ctx, "recompute", False):
             g = dloss.contiguous()
             hws = ctx.hws
@@ -226,7 +227,10 @@ class _NextItemHeadFn(torch.autograd.Function):
             hws = ctx.hws
             Dh = W.shape[1]
             if getattr(ctx, "dx_unit", None) is not None:
-                dxp = ctx.dx_unit * g                  # formed in the forward for an upstream gradient of 1
+                # formed in the forward for an upstream gradient of 1.  Without a task block the scaling by g, the zero fill of
+                # the [B L, D] gradient and the row scatter are ONE launch (csrc/masking.hip: scatter_rows_dense_kernel)
+                dense_dx = task.task_block is None
+                dxp = ctx.dx_unit if dense_dx else ctx.dx_unit * g
                 ctx.dx_unit = None
             elif hws is not None:
                 dxp = ops.head_split_dx(hws, logits, lse, tgt, g, V, W.detach(), alpha=1.0 / T, label_smoothing=smooth)
@@ -262,8 +266,11 @@ class _NextItemHeadFn(torch.autograd.Function):
             ops.gemm(dxp, xr, True, False, splitk=-1, accumulate=True, out=_grad_buf(lin.weight))
             ops.colsum_(dxp, _grad_buf(lin.bias))
             dxr = ops.gemm(dxp, lin.weight.detach(), False, False)
-        dx = torch.zeros((B * L, D), device=dxr.device, dtype=torch.float32)
-        ops.scatter_rows_add_(dxr, pos, dx)
+        if dense_dx:
+            dx = ops.scatter_rows_dense(dxr, pos, N, g, B * L)
+        else:
+            dx = torch.zeros((B * L, D), device=dxr.device, dtype=torch.float32)
+            ops.scatter_rows_add_(dxr, pos, dx)
         return dx.view(B, L, D), None, None, None, None, None, None
 
 

@@ -198,7 +198,7 @@ def _(ids, p, seed, offset, padding_idx):
 
 
 @torch.library.custom_op(f"{NS}::seq_item_embedding", mutates_args=())
-def seq_item_embedding(ids: torch.Tensor, table: torch.Tensor, mask: torch.Tensor, masked_emb: torch.Tensor, mask_mode: int, padding_idx: int = 0) -> torch.Tensor:
+def seq_item_embedding(ids: torch.Tensor, table: torch.Tensor, mask: torch.Tensor, masked_emb: torch.Tensor, mask_mode: int, padding_idx: int) -> torch.Tensor:
     """item-id sequence embedding with the masking epilogue (features/embedding.py:226-249 + masking.py:473-498): [B, L, D]"""
     B, L = ids.shape
     D = table.shape[1]
@@ -207,7 +207,7 @@ def seq_item_embedding(ids: torch.Tensor, table: torch.Tensor, mask: torch.Tenso
 
 
 @seq_item_embedding.register_fake
-def _(ids, table, mask, masked_emb, mask_mode, padding_idx=0):
+def _(ids, table, mask, masked_emb, mask_mode, padding_idx):
     return table.new_empty((ids.shape[0], ids.shape[1], table.shape[1]))
 
 
@@ -232,7 +232,9 @@ def _seq_item_setup(ctx, inputs, output):
     ids, table, mask, masked_emb, mask_mode, padding_idx = inputs
     ctx.save_for_backward(ids, mask)
     ctx.rows, ctx.mask_mode = table.shape[0], mask_mode
-    ctx.padding_idx = int(padding_idx)         # an explicit operator argument: survives functional_call / make_fx
+    # an explicit, REQUIRED operator argument: survives functional_call / make_fx.  (No default: the dispatcher drops
+    # trailing arguments that equal their default, and the generated autograd node then expects one gradient less.)
+    ctx.padding_idx = int(padding_idx)
 
 
 def _seq_item_backward(ctx, dy):
@@ -519,7 +521,7 @@ def _concat_feats(ids, tables, dense, layout, dims):
 
 @torch.library.custom_op(f"{NS}::seq_concat", mutates_args=())
 def seq_concat(ids: Sequence[torch.Tensor], tables: Sequence[torch.Tensor], dense: Sequence[torch.Tensor], layout: List[int],
-               dims: List[int], padding_idx: int = 0) -> torch.Tensor:
+               dims: List[int], padding_idx: int) -> torch.Tensor:
     """the concatenating gather of the input block (features/embedding.py:226-249 + tabular/aggregation.py:35-47, one launch):
     table features looked up by their [B, L] ids, dense rows ([B * L, dim]: soft embeddings, continuous columns) copied, column
     blocks in `layout` order (the reference's sorted feature names) -> [B, L, sum(dims)]"""
@@ -529,7 +531,7 @@ def seq_concat(ids: Sequence[torch.Tensor], tables: Sequence[torch.Tensor], dens
 
 
 @seq_concat.register_fake
-def _(ids, tables, dense, layout, dims, padding_idx=0):
+def _(ids, tables, dense, layout, dims, padding_idx):
     return tables[0].new_empty((ids[0].shape[0], ids[0].shape[1], sum(dims)))
 
 

@@ -7,7 +7,8 @@ the host-side mirror of the reference's module interface.  No CPU fallback exist
 __version__ = "0.1.0"
 
 from .schema import ColumnSchema, IntDomain, Schema, Tags, ValueCount, random_data_from_schema, session_schema  # noqa: E402,F401
-from .masking import CausalLanguageModeling, MaskedLanguageModeling, MaskSequence  # noqa: E402,F401
+from .masking import (CausalLanguageModeling, MaskedLanguageModeling, MaskSequence, GradCarrier,  # noqa: E402,F401
+                      enable_autograd_gradients, hip_parameters)
 from .features import (  # noqa: E402,F401
     ContinuousFeatures, EmbeddingFeatures, FeatureConfig, SequenceEmbeddingFeatures, SoftEmbedding,
     SoftEmbeddingFeatures, TableConfig, TabularSequenceFeatures)

@@ -434,14 +434,25 @@ def _check_data_parallel(mod, training):
 
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         raise RuntimeError(
-            "dropin: training on torch.distributed world_size > 1, but the HIP backward writes parameter "
-            "gradients into .grad without autograd hooks, so torch DDP (HF Trainer's wrapper) cannot see them. "
-            "Before training, acknowledge with transformers4rec_amd.dropin.enable_data_parallel(model) (or "
-            "convert_model(model, data_parallel=True)), then call dropin.sync_gradients(model) between backward() and "
-            "optimizer.step() -- or wire distributed.GradReducer / SparseRowExchange yourself.  For an XLNet / MLM model with "
-            "sequence categoricals (+ SoftEmbedding features, concat, projection), "
-            "torch.nn.parallel.DistributedDataParallel(functional.FunctionalSessionModel(model)) is the hook-visible form "
-            "of the same step (registered operators with autograd formulas, every dropout site included).")
+            "dropin: training on torch.distributed world_size > 1 with the FAST gradient path: the HIP backward writes parameter "
+            "gradients into .grad without autograd hooks, so torch DDP (HF Trainer's wrapper) would see none of them.  Either "
+            "(a) transformers4rec_amd.dropin.enable_ddp(model) -- or convert_model(model, ddp=True) -- BEFORE wrapping the model "
+            "in torch.nn.parallel.DistributedDataParallel: the parameter gradients then travel through autograd "
+            "(masking.GradCarrier; same kernels, same numbers) and DDP / HF Trainer work as for the reference; or "
+            "(b) keep the fast path and take charge of the exchange yourself: dropin.enable_data_parallel(model) (or "
+            "convert_model(model, data_parallel=True)), then dropin.sync_gradients(model) between backward() and "
+            "optimizer.step(), or distributed.GradReducer / SparseRowExchange.")
+
+
+def enable_ddp(model):
+    """Autograd-visible parameter gradients for every drop-in module inside `model` (masking.enable_autograd_gradients) and the
+    data-parallel acknowledgement: afterwards `torch.nn.parallel.DistributedDataParallel(model)` -- what HF Trainer wraps the
+    reference's model in, transformers4rec/torch/trainer.py:131-161, docs/source/multi_gpu_train.md:27-40 -- averages the
+    gradients of the HIP path through its own bucket hooks.  Call after convert_model / install, before wrapping."""
+    from .masking import enable_autograd_gradients
+
+    enable_autograd_gradients(model)
+    return enable_data_parallel(model)
 
 
 class _HipFeaturesMixin:

@@ -421,6 +421,7 @@ class _SeqFeaturesFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, anchor, mod, inputs, training, testing):
+        ctx.carrier = bool(mod.__dict__.get("_t4r_carrier_on", False))      # anchor = the GradCarrier's one-float output
         cat, cont = mod.categorical_module, mod.continuous_module
         names = mod._feature_order
         item_ids = inputs[cat.item_id].contiguous()
@@ -580,7 +581,9 @@ class _SeqFeaturesFn(torch.autograd.Function):
                     _grad_buf(se.projection_layer.bias), _grad_buf(se.embedding_table.weight),
                     None if ln is None else _grad_buf(ln.weight), None if ln is None else _grad_buf(ln.bias),
                     col, 1e-5 if ln is None else ln.eps)
-        return None, None, None, None, None
+        # the anchor's slot: a defined (zero) gradient for the GradCarrier's output, so that its node -- the last of the
+        # backward pass -- runs and hands the carried parameter gradients to autograd
+        return (torch.zeros(1, device=dy.device) if ctx.carrier else None), None, None, None, None
 
 
 class TabularSequenceFeatures(nn.Module):
@@ -744,4 +747,13 @@ class TabularSequenceFeatures(nn.Module):
             cat.item_seq = cat.item_ids(inputs)  # stateful, as the reference (embedding.py:242-245); after `pre`
         if self.training:
             self._post_step += 1
-        return _SeqFeaturesFn.apply(cat.item_embedding_table.weight, self, inputs, training, testing)
+        anchor = cat.item_embedding_table.weight
+        carried = self.__dict__.get("_t4r_carrier_params")
+        object.__setattr__(self, "_t4r_carrier_on", False)
+        if carried and torch.is_grad_enabled() and (training or self.training):
+            from .masking import GradCarrier
+
+            GradCarrier.release(carried)                 # leftovers of a forward whose backward never ran
+            anchor = GradCarrier.apply(carried, *carried)      # autograd-visible parameter gradients (masking.GradCarrier)
+            object.__setattr__(self, "_t4r_carrier_on", True)
+        return _SeqFeaturesFn.apply(anchor, self, inputs, training, testing)

@@ -25,6 +25,9 @@ def _grad_buf(p):
     and per-parameter hooks do not see parameter gradients of the HIP modules.
     A frozen parameter (`requires_grad=False`) keeps `.grad` untouched: the kernels get a scratch
     buffer that is cached on the parameter and never read."""
+    c = p.__dict__.get("_t4r_carrier")
+    if c is not None:          # autograd-visible mode (GradCarrier below): the gradient travels through the graph to p.grad
+        return c
     if not p.requires_grad:
         s = p.__dict__.get("_t4r_frozen_scratch")
         if s is None or s.shape != p.shape or s.device != p.device:
@@ -34,6 +37,80 @@ def _grad_buf(p):
     if p.grad is None:
         p.grad = torch.zeros_like(p)
     return p.grad
+
+
+class GradCarrier(torch.autograd.Function):
+    """Makes the parameter gradients of the HIP modules VISIBLE TO AUTOGRAD (the reference trains under
+    HF Trainer -> torch DistributedDataParallel, transformers4rec/torch/trainer.py:131-161, whose bucket hooks hang on the
+    parameters' AccumulateGrad nodes).
+
+    The fast path writes every parameter gradient straight into `.grad` (`_grad_buf`) and returns None to autograd: one Adam
+    launch and one all-reduce per flat bucket, but no hook ever fires.  This node is the other mode, switched on per model
+    (`enable_autograd_gradients`): it takes the parameters as inputs at the very FRONT of the forward (its output, one
+    float, is the anchor of the input block's node, the first node of the path), hands every kernel a zero-filled carrier
+    buffer instead of `.grad` for the duration of the step, and -- being the last node the engine runs in the backward pass,
+    after the head, every layer and the input block have written their gradients -- returns those buffers as the parameters'
+    gradients.  Autograd then accumulates them into `.grad` itself: AccumulateGrad runs, hooks run, torch DDP / per-parameter
+    hooks / torch.autograd.grad see what they see for the reference.  Same kernels, same numbers; the cost is one
+    zero fill of the parameters' size per step and autograd's accumulation pass (the fast path stays the default)."""
+
+    @staticmethod
+    def forward(ctx, owners, *params):
+        """owners: the list of Parameter OBJECTS (the carriers hang on their __dict__, which `_grad_buf` reads); params: the
+        same tensors as graph inputs"""
+        ctx.owners = owners
+        for p in owners:
+            p.__dict__["_t4r_carrier"] = torch.zeros_like(p)
+        return torch.zeros(1, device=owners[0].device)
+
+    @staticmethod
+    def backward(ctx, _d):
+        from .transformer import _join_weight_gradient_streams
+
+        _join_weight_gradient_streams()          # the layers' weight gradients run on side streams: in before they are read
+        return (None,) + tuple(p.__dict__.pop("_t4r_carrier", None) for p in ctx.owners)
+
+    @staticmethod
+    def release(params):
+        """a forward whose backward never ran (evaluation under grad mode, an exception): drop the carriers"""
+        for p in params:
+            p.__dict__.pop("_t4r_carrier", None)
+
+
+def hip_parameters(model):
+    """the parameters (requires_grad, each once) of every hot-path module inside `model`: the mirror classes of this package
+    and the drop-in subclasses of the reference's"""
+    from .features import TabularSequenceFeatures
+    from .prediction_task import NextItemPredictionTask
+    from .transformer import TransformerBlock
+
+    seen, out = set(), []
+    for m in model.modules():
+        if isinstance(m, (TabularSequenceFeatures, TransformerBlock, NextItemPredictionTask)) or getattr(m, "_t4r_hip", False):
+            for p in m.parameters():
+                if p.requires_grad and id(p) not in seen:
+                    seen.add(id(p))
+                    out.append(p)
+    return out
+
+
+def enable_autograd_gradients(model, flag=True):
+    """Switches the hot-path modules inside `model` to autograd-visible parameter gradients (GradCarrier): afterwards
+    torch.nn.parallel.DistributedDataParallel(model), parameter hooks and plain torch optimizers over model.parameters() work as
+    they do for the reference.  Call again after adding / freezing parameters.  Returns the model."""
+    from .features import TabularSequenceFeatures
+
+    params = hip_parameters(model) if flag else None
+    n = 0
+    for m in model.modules():
+        is_hip_features = getattr(m, "_t4r_hip", False) and any(c.__name__ == "_HipFeaturesMixin" for c in type(m).__mro__)
+        tgt = m.hip_shadow() if is_hip_features else m
+        if isinstance(tgt, TabularSequenceFeatures):
+            object.__setattr__(tgt, "_t4r_carrier_params", params)
+            n += 1
+    if flag and n == 0:
+        raise ValueError("enable_autograd_gradients: no TabularSequenceFeatures (the first node of the hot path) inside the model")
+    return model
 
 
 class _ApplyMaskFn(torch.autograd.Function):

@@ -684,6 +684,63 @@ def recall_probe_dp(device, dropout, world, rank, train_steps=RECALL_TRAIN_STEPS
         "note": "metric state (sum, count) all-reduced over the ranks in compute_metrics"}}
 
 
+# --------------------------------------------------------------------------------------------- 8-rank exchange, rehearsed on one GPU
+XGMI_LINK_GBS = 153.0       # per direction and link, 7 links per GPU (task statement / MI355X_MICROARCH.md): the fabric is point to point
+
+
+def rehearse_exchange(device, ms_per_step, table, dense_bytes, world=8, reps=10):
+    """What a rank does AFTER the last backward kernel of a data-parallel step at N = `world`, timed on this one GPU with the sizes
+    of N ranks: the deterministic apply of ALL ranks' lookup rows -- sort of world x B x L (id, position)
+    pairs + segmented sum of world x 10.5 MB of gradient rows into the table gradient (distributed.SparseRowExchange.exchange
+    -> ops.scatter_rows_sorted) -- beside the same apply at one rank's size (what the N = 1 step already contains).  The wire
+    time cannot be measured here; it is ESTIMATED from the link rate for a direct exchange over the 7 point-to-point xGMI
+    links (every peer's share travels on its own link) and reported as an estimate.  -> dict for `comm.rehearsal_8gpu`."""
+    from transformers4rec_amd import ops
+
+    V, D = table.shape
+    g = torch.Generator(device=device).manual_seed(123)
+    d_table = torch.zeros_like(table)
+
+    def timed_apply(n_rows):
+        ids = torch.randint(1, V, (n_rows,), device=device, generator=g)
+        rows = torch.randn(n_rows, D, device=device, generator=g) * 1e-3
+        for _ in range(2):
+            ops.scatter_rows_sorted(d_table, ids, rows, 0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.scatter_rows_sorted(d_table, ids, rows, 0)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    t1 = timed_apply(BATCH * SEQ)
+    tN = timed_apply(world * BATCH * SEQ)
+    per_rank_rows_bytes = BATCH * SEQ * (8 + 4 * D)
+    link = XGMI_LINK_GBS * 1e9
+    # direct exchange: each peer's block arrives on its own link, all (world - 1) links busy at once
+    allgather_ms = 1e3 * per_rank_rows_bytes / link
+    tables_bytes = V * D * 4
+    # reduce-scatter + all-gather of the table bucket, 1 / world of it per peer and link, both phases
+    tables_allreduce_ms = 1e3 * 2.0 * (tables_bytes / world) / link
+    dense_allreduce_ms = 1e3 * 2.0 * (dense_bytes / world) / link + 0.03          # + a latency floor of ~30 us (two small phases)
+    exposed = (tN - t1) + allgather_ms + dense_allreduce_ms
+    # the table all-reduce runs under the body's backward; a resident collective costs the kernels next to it 1.25x for its
+    # duration even with the CU budget (tools/occupier_curve.py, profiles/r05_h_occupier_budget.json)
+    overlap_penalty = 0.25 * tables_allreduce_ms
+    proj = ms_per_step + exposed + overlap_penalty
+    return {"what": f"one GPU, sizes of {world} ranks: MEASURED apply of all ranks' lookup rows; ESTIMATED wire times (direct exchange over "
+                    f"{world - 1} xGMI links at {XGMI_LINK_GBS:.0f} GB/s each); the projection is arithmetic on those, not a measurement",
+            "apply_rows_1_rank_ms": round(t1, 4), f"apply_rows_{world}_ranks_ms": round(tN, 4),
+            "rows_gathered_bytes": world * per_rank_rows_bytes,
+            "estimated_allgather_ms": round(allgather_ms, 4), "estimated_tables_allreduce_ms_overlapped": round(tables_allreduce_ms, 4),
+            "estimated_dense_allreduce_ms": round(dense_allreduce_ms, 4),
+            "exposed_after_backward_ms": round(exposed, 4), "overlap_penalty_ms": round(overlap_penalty, 4),
+            "projected_ms_per_step": round(proj, 4), "projected_sessions_per_s": round(BATCH * world / (proj * 1e-3), 1),
+            "projected_scaling_vs_1gpu": round(world * ms_per_step / proj, 2),
+            "note": "to be checked against the first real SCALE run; the north_star asks >= 6x at 8 GPUs"}
+
+
 # --------------------------------------------------------------------------------------------- live HBM traffic
 def live_head_traffic(n_rows, timeout_s=150):
     """HBM bytes per launch of the head kernels from the PMC counters, measured IN THIS RUN when rocprofv3 is present: two
@@ -1362,6 +1419,11 @@ def main():
         }
         if body is not None:
             res["roofline_body"] = body
+        if world == 1 and args.config == "c2":
+            try:
+                comm["rehearsal_8gpu"] = rehearse_exchange(device, 1e3 * dt / args.steps, W, int(dense.grad.numel() * 4))
+            except Exception as exc:      # noqa: BLE001
+                comm["rehearsal_8gpu"] = {"error": f"{type(exc).__name__}: {exc}"}
         res["comm"] = comm
     # Recall@20, the other half of the metric.  N > 1: a collective probe, every rank takes part (T4R_BENCH_DP_RECALL=0
     # skips it on all ranks alike)

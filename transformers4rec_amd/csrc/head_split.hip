@@ -1219,7 +1219,9 @@ __device__ __forceinline__ float dpp_row_shr_max(float x, int ctrl4) {
 // two per CU: the 506 workgroups of BASELINE configs[1] ran as two rounds); asked for two waves it fits 222 registers with no
 // spill, both workgroups are resident and each fills the other's waits: 723 -> 609 us stand-alone, 2.83 -> 2.70 ms per step
 // (profiles/r05_y_ab.txt).  The same request on head_dw_split_kernel (3 waves, 161 registers) measured 0.02 ms slower: not kept.
-template <int NB>
+// SMOOTH: label smoothing on (the row sums of the logits are wanted: st_t non-null).  Without it the sixteen adds + selects per
+// tile and lane that form those sums are not compiled in (round 6: the kernel's time is matrix + VECTOR issue).
+template <int NB, bool SMOOTH>
 __global__ __launch_bounds__(256, 2) void head_fwd_dx_kernel(const float* __restrict__ X, long ldx, const u32x4* __restrict__ WA,
                                                           const u32x4* __restrict__ WTP, float* __restrict__ C, long ldc,
                                                           int vec_ok, float* __restrict__ part, float* __restrict__ st_m,
@@ -1388,7 +1390,7 @@ __global__ __launch_bounds__(256, 2) void head_fwd_dx_kernel(const float* __rest
                 const float x = v[8 * s + e];
                 pv[e] = __builtin_amdgcn_exp2f(fmaf(x, kLog2e, -ref2));
                 s_run += pv[e];
-                t_run += (tail && x == -INFINITY) ? 0.f : x;
+                if (SMOOTH) t_run += (tail && x == -INFINITY) ? 0.f : x;
             }
             split8s<true>(pv, kFdxPScale, af[s]);
         }
@@ -1419,7 +1421,7 @@ __global__ __launch_bounds__(256, 2) void head_fwd_dx_kernel(const float* __rest
         const long o = (long)split * N + row;
         st_m[o] = m_ref;
         st_s[o] = s_tot;
-        if (st_t) st_t[o] = t_tot;
+        if (SMOOTH) st_t[o] = t_tot;
     }
 }
 
@@ -1932,8 +1934,13 @@ extern "C" int t4r_head_split_logits_ce_dx(void* stream, void* ws, const float* 
     float* colmax = (head_dw_fp16x2() && vec_ok) ? reinterpret_cast<float*>((char*)ws + w.colmax) : nullptr;
     if (note) *note_of(note) = FwdNote{W, C, V, V, N, colmax != nullptr, 0, row_tiles};
     const int n_wg = splits * row_tiles, per_xcd = (n_wg + 7) / 8;
-    T4R_NB_SWITCH(D, hipLaunchKernelGGL(head_fwd_dx_kernel<NB>, dim3(8 * per_xcd), dim3(256), 0, st, X, ldx, wa, wtp, C, ldc, vec_ok, part,
-                                        sm, ss, stt, colmax, w.vpad, N, V, alpha, w.nkt, kt_per, row_tiles, n_wg, per_xcd, amax));
+    if (stt) {
+        T4R_NB_SWITCH(D, hipLaunchKernelGGL((head_fwd_dx_kernel<NB, true>), dim3(8 * per_xcd), dim3(256), 0, st, X, ldx, wa, wtp, C, ldc, vec_ok,
+                                            part, sm, ss, stt, colmax, w.vpad, N, V, alpha, w.nkt, kt_per, row_tiles, n_wg, per_xcd, amax));
+    } else {
+        T4R_NB_SWITCH(D, hipLaunchKernelGGL((head_fwd_dx_kernel<NB, false>), dim3(8 * per_xcd), dim3(256), 0, st, X, ldx, wa, wtp, C, ldc, vec_ok,
+                                            part, sm, ss, stt, colmax, w.vpad, N, V, alpha, w.nkt, kt_per, row_tiles, n_wg, per_xcd, amax));
+    }
     if (!kernel_only)
         hipLaunchKernelGGL(head_fdx_finalize_kernel, dim3((N + 7) / 8), dim3(256), 0, st, sm, ss, stt, part, splits, N, V, D, C, ldc, W, ldw,
                            labels, wsum, label_smoothing, alpha, amax, loss_rows, lse, dX, lddx);

@@ -497,7 +497,11 @@ int t4r_xlnet_ff_bwd(void* stream, const float* dy, const float* ffout, const fl
  * ws: t4r_xlnet_layer_ws_floats() floats saved by fwd for bwd; bws: scratch for bwd.
  * drop_p > 0 enables the reference's training-mode dropouts of the layer (HF :132,:147,:301,:303 and
  * the per-session pos_emb dropout :1143) with masks keyed by (seed, offset = step counter, layer_idx);
- * the workspace queries take dropout = (drop_p > 0). */
+ * the workspace queries take dropout = (drop_p > 0).
+ * layer_idx: bits 0-7 the layer (the only part the mask keys use); bit 8 (0x100), with drop_p > 0 and d_model 32 / 64 / 128:
+ * this is the LAST layer of the stack and its feed-forward kernels also apply the MODEL's output dropout (HF :1177, key
+ * (offset, 255, site 6)) -- to h_out in _fwd, to dh_out on load in _bwd -- instead of two element-wise launches over [T, D]
+ * around the stack (round 6). */
 long t4r_xlnet_layer_ws_floats(int B, int L, int D, int n_head, int dropout);
 long t4r_xlnet_layer_bwd_ws_floats(int B, int L, int D, int n_head, int dropout);
 int t4r_xlnet_layer_fwd(void* stream, const float* h, const float* pos_emb, const float* const* params,

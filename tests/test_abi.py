@@ -77,6 +77,8 @@ _ALLOWED_FILE_SCOPE_STATE = {
     "g_cu_budget": "CUs the backward's token-tile kernels may count on, set only through t4r_xlnet_set_cu_budget (documented in "
                    "include/t4r_hip.h; per-row results do not depend on it, batch-reduced gradients are equal up to summation order)",
     "g_ff_amax": "thread-local, set and cleared inside one layer call",
+    "g_ff_final_ctr": "thread-local, set and cleared inside one layer call (key of the fused model-level output dropout)",
+    "g_ff_final_on": "same",
     "g_red_side": "thread-local, set and cleared inside one layer call (reduction side stream)",
     "g_red_events": "same", "g_red_n": "same", "g_red_used": "same",
 }

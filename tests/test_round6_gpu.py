@@ -213,3 +213,36 @@ def test_out_of_place_mask_backward_equals_the_in_place_one(ops, mode):
     ref = dy.clone()
     ops.apply_mask_bwd_(ref, mask, m2, getattr(ops, mode))
     assert torch.equal(dx, ref) and torch.equal(m1, m2)
+
+
+@pytest.mark.parametrize("B,L,D,n", [(9, 20, 128, 4), (300, 20, 64, 4)])
+def test_output_dropout_fused_into_the_last_layer(ops, B, L, D, n):
+    """layer_idx | LAYER_FUSE_FINAL: the model-level output dropout (HF modeling_xlnet.py:1177) applied by the last layer's
+    feed-forward kernels == the layer without the flag followed by the element-wise dropout of that site; backward likewise
+    (d h and every parameter gradient), bit for bit in the per-row results"""
+    import test_kernels_gpu as K
+
+    g = torch.Generator().manual_seed(B + D)
+    prm = K._layer_params(g, D, n)
+    params = [K.cu(prm[k]) for k in K.ORDER]
+    h = K.cu(torch.randn(B * L, D, generator=g))
+    dout = K.cu(torch.randn(B * L, D, generator=g))
+    pos = K.cu(O.xlnet_pos_emb(L, D))
+    p_drop, seed, offset, layer = 0.3, 1234, 5, 3
+    kw = dict(drop_p=p_drop, seed=seed, offset=offset)
+    ctr_final = ops.dropout_ctr_hi(offset, 255, ops.SITE_FINAL)
+    # reference composition: plain layer, then the element-wise dropout; backward: dropout of the gradient, then the layer
+    out0, ws0 = ops.xlnet_layer_fwd(h, pos, params, B, L, n, 0.03, layer_idx=layer, **kw)
+    want = ops.dropout(out0.view(-1), p_drop, seed, ctr_final).view(B * L, D)
+    g0 = [torch.zeros_like(t) for t in params]
+    dh0 = ops.xlnet_layer_bwd(h, pos, params, g0, ws0, ops.dropout(dout.view(-1), p_drop, seed, ctr_final).view(B * L, D),
+                              B, L, n, 0.03, layer_idx=layer, **kw)
+    out1, ws1 = ops.xlnet_layer_fwd(h, pos, params, B, L, n, 0.03, layer_idx=layer | ops.LAYER_FUSE_FINAL, **kw)
+    assert torch.equal(out1, want)
+    assert float((out1 == 0).float().mean()) > 0.25                 # the site is active
+    g1 = [torch.zeros_like(t) for t in params]
+    dh1 = ops.xlnet_layer_bwd(h, pos, params, g1, ws1, dout, B, L, n, 0.03, layer_idx=layer | ops.LAYER_FUSE_FINAL, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(dh1, dh0)
+    for name, a, b in zip(K.ORDER, g1, g0):
+        assert torch.equal(a, b), name

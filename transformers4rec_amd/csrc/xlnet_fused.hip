@@ -44,6 +44,7 @@ struct FFFwdParams {
     int T;
     float eps;
     DropCfg drop_act, drop_out;
+    DropCfg drop_final;    // p > 0: the MODEL's output dropout (HF modeling_xlnet.py:1177) applied to hout in this launch (last layer)
 };
 
 // FULL: every row of the tile is a token; TRAIN: the backward's activations are saved and the Philox masks evaluated
@@ -252,8 +253,13 @@ __device__ __forceinline__ void ff_fwd_body(const FFFwdParams& p, uint16_t* smem
         for (int ww = 0; ww < NW; ++ww) q += sh_red2[ww * RT + r * 16 + n];
         const float rs = rsqrtf(q * (1.0f / D) + p.eps);
         if (FULL || t < p.T) {
-            st4(p.hout + t * D + f0, make_float4((x[r].x - mu[r]) * rs * gam.x + bet.x, (x[r].y - mu[r]) * rs * gam.y + bet.y,
-                                                 (x[r].z - mu[r]) * rs * gam.z + bet.z, (x[r].w - mu[r]) * rs * gam.w + bet.w));
+            float4 o = make_float4((x[r].x - mu[r]) * rs * gam.x + bet.x, (x[r].y - mu[r]) * rs * gam.y + bet.y,
+                                   (x[r].z - mu[r]) * rs * gam.z + bet.z, (x[r].w - mu[r]) * rs * gam.w + bet.w);
+            if (TRAIN && p.drop_final.p > 0.f) {      // workgroup-uniform: the last layer of a stack in training mode
+                const float4 mf = drop_scale4(p.drop_final, (unsigned long long)t * D + f0);
+                o.x *= mf.x; o.y *= mf.y; o.z *= mf.z; o.w *= mf.w;
+            }
+            st4(p.hout + t * D + f0, o);
             if (TRAIN && w == 0 && g == 0) { p.mean[t] = mu[r]; p.rstd[t] = rs; }
         }
     }
@@ -289,6 +295,7 @@ struct FFBwdParams {
     float *partA, *partB;             // per-workgroup partial sums [nWG][3D] (d gamma | d beta | d b2), [nWG][4D] (d b1)
     int T;
     DropCfg drop_act, drop_out;
+    DropCfg drop_final;    // p > 0: dy is the gradient of the DROPPED output (model-level site): masked on load
 };
 
 // HS: both products on the two-way fp16 split.  The d ffout rows carry their own power-of-two scale (gradient rows of one
@@ -344,6 +351,11 @@ __global__ __launch_bounds__(D * 4) void xlnet_ff_bwd_kernel(FFBwdParams p) {
                     const float2 fo_ = fo[b], hh_ = hh[b], dd_ = dd[b];
                     const float xv[2] = {fo_.x * m[0] + hh_.x, fo_.y * m[1] + hh_.y};
                     dyv[0] = dd_.x; dyv[1] = dd_.y;
+                    if (p.drop_final.p > 0.f) {       // workgroup-uniform
+                        float mf[2];
+                        drop_scale_vec<2>(p.drop_final, (unsigned long long)t * D + c0, true, mf);
+                        dyv[0] *= mf[0]; dyv[1] *= mf[1];
+                    }
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         xh[e] = (xv[e] - mu) * rs;
@@ -533,6 +545,12 @@ bool t4r_xlnet_body_fp16x2() {
 // nulls (default: stand-alone use).  The layer (xlnet_layer.hip) sets them and hands the arrays to its two feed-forward
 // weight-gradient launches, which then run in the two-way fp16 form (gemm_kernel.h: PREC 4).
 static thread_local float* g_ff_amax[4] = {nullptr, nullptr, nullptr, nullptr};
+// set and cleared inside one layer call (csrc/xlnet_layer.hip): the next t4r_xlnet_ff_fwd / _bwd of this thread also applies
+// the model-level output dropout keyed by `ctr` (the last layer of a stack: one launch less per direction and no extra pass
+// over [T, D]); 0 = off
+static thread_local unsigned long long g_ff_final_ctr = 0;
+static thread_local int g_ff_final_on = 0;
+void t4r_xlnet_ff_final_dropout(int on, unsigned long long ctr) { g_ff_final_on = on; g_ff_final_ctr = ctr; }
 void t4r_xlnet_ff_amax_buffers(float* h1, float* act, float* dpre, float* dfo) {
     g_ff_amax[0] = h1; g_ff_amax[1] = act; g_ff_amax[2] = dpre; g_ff_amax[3] = dfo;
 }
@@ -653,7 +671,8 @@ extern "C" int t4r_xlnet_ff_fwd(void* stream, const float* h1, const float* plan
     T4R_CHECK_ARG(train || drop_p == 0.f, "xlnet_ff_fwd: dropout needs the saved activations (training mode)");
     FFFwdParams p{h1, b1, b2, gamma, beta, carve_planes(planes, D), carve_planes_h(planes, D), g_ff_amax[0], g_ff_amax[1], ffpre, ffact, ffout,
                   mean, rstd, hout, T, eps,
-                  make_drop(drop_p, seed, ctr_act), make_drop(drop_p, seed, ctr_out)};
+                  make_drop(drop_p, seed, ctr_act), make_drop(drop_p, seed, ctr_out),
+                  make_drop(g_ff_final_on ? drop_p : 0.f, seed, g_ff_final_ctr)};
     const int R = pick_r(T);
     FUSED_DISPATCH(ff_fwd_launch, D, R, (hipStream_t)stream, p);
     t4r_set_error("xlnet_ff_fwd: no instantiation");
@@ -679,7 +698,8 @@ extern "C" int t4r_xlnet_ff_bwd(void* stream, const float* dy, const float* ffou
     float* partB = part + (long)nwg * 3 * D;
     FFBwdParams p{dy, ffout, h1, mean, rstd, gamma, ffpre, carve_planes(planes, D), carve_planes_h(planes, D), g_ff_amax[2], g_ff_amax[3], dh1,
                   dffout, dpre, partA, partB, T,
-                  make_drop(drop_p, seed, ctr_act), make_drop(drop_p, seed, ctr_out)};
+                  make_drop(drop_p, seed, ctr_act), make_drop(drop_p, seed, ctr_out),
+                  make_drop(g_ff_final_on ? drop_p : 0.f, seed, g_ff_final_ctr)};
     hipStream_t st = (hipStream_t)stream;
     auto launch = [&]() -> int {
         FUSED_DISPATCH(ff_bwd_launch, D, R, st, p);

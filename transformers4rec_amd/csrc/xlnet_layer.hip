@@ -34,6 +34,13 @@ long t4r_colreduce_ws_floats(long, int);
 void t4r_reduce_redirect(hipStream_t side, hipEvent_t* events, int n_events);   // elementwise.hip
 void t4r_gemm_operand_amax(const float* a, const float* b, int n);               // gemm_f32.hip: next launch in the fp16 split form
 void t4r_xlnet_ff_amax_buffers(float* h1, float* act, float* dpre, float* dfo);  // xlnet_fused.hip
+void t4r_xlnet_ff_final_dropout(int on, unsigned long long ctr);                 // xlnet_fused.hip
+// layer_idx carries flags above its low byte (the Philox counters use the low byte only, ctr_hi):
+//   T4R_LAYER_FUSE_FINAL  this is the LAST layer of the stack and the model runs in training mode: the model-level output
+//                         dropout (HF modeling_xlnet.py:1177, key (offset, 255, SITE_FINAL)) is applied by this layer's
+//                         feed-forward kernels -- to h_out in the forward, to dh_out on load in the backward -- instead of by
+//                         two element-wise launches over [T, D] around the stack.  Needs the fused kernels (d_model 32/64/128).
+#define T4R_LAYER_FUSE_FINAL 0x100
 int t4r_xlnet_ff_amax_count(long T);
 int t4r_xlnet_ff_amax_count_bwd(long T);
 void t4r_gemm_operand_amax2(const float* a, int na, const float* b, int nb);   // gemm_f32.hip: the two producers ran different grids
@@ -220,6 +227,8 @@ extern "C" int t4r_xlnet_layer_fwd(void* stream, const float* h, const float* po
     const float* v_w = params[P_V];
     const long TD = (long)T * D, DD = (long)D * D;
     auto C = [&](int site) { return ctr_hi(offset, layer_idx, site); };
+    const bool fuse_final = (layer_idx & T4R_LAYER_FUSE_FINAL) != 0;
+    T4R_CHECK_ARG(!fuse_final || use_fused(D), "xlnet_layer: the fused output dropout needs the fused layer kernels (d_model 32 / 64 / 128)");
     if (use_fused(D)) {
         // ONE launch cuts the layer's nine weight matrices into bf16 planes; q, k, v in one token-tile launch; k_r; the
         // attention core; o-projection + dropout + residual + LayerNorm in one launch; the feed-forward block in one
@@ -253,9 +262,11 @@ extern "C" int t4r_xlnet_layer_fwd(void* stream, const float* h, const float* po
         }
         const long ns = t4r_xlnet_ff_amax_slots(T);
         t4r_xlnet_ff_amax_buffers(w.amax, w.amax + ns, nullptr, nullptr);
+        t4r_xlnet_ff_final_dropout(fuse_final && drop, ctr_hi(offset, 255, SITE_FINAL));
         const int rc = t4r_xlnet_ff_fwd(stream, w.h1, w.planes, params[P_B1], params[P_B2], params[P_LN2W], params[P_LN2B], w.ffpre,
                                         w.ffact, w.ffout, w.mean2, w.rstd2, h_out, T, D, ln_eps, drop_p, seed, C(SITE_FF_ACT),
                                         C(SITE_FF_OUT));
+        t4r_xlnet_ff_final_dropout(0, 0);
         t4r_xlnet_ff_amax_buffers(nullptr, nullptr, nullptr, nullptr);
         return rc;
     }
@@ -393,6 +404,8 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
     const long nkr = (drop ? (long)B : 1L) * 2L * L * D;
     LayerWs w = carve(const_cast<float*>(ws), B, L, D, n_head, drop);
     auto C = [&](int site) { return ctr_hi(offset, layer_idx, site); };
+    const bool fuse_final = (layer_idx & T4R_LAYER_FUSE_FINAL) != 0;
+    T4R_CHECK_ARG(!fuse_final || use_fused(D), "xlnet_layer: the fused output dropout needs the fused layer kernels (d_model 32 / 64 / 128)");
     long o = 0;
     auto take = [&](long nfl) { float* p = bws + o; o += align4(nfl); return p; };
     float* dqkv = take(3 * TD);
@@ -471,9 +484,11 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
         float* am = w.amax;          // max |h1|, max |act| (forward), max |d pre|, max |d ffout| (now): one float per workgroup
         t4r_xlnet_ff_amax_buffers(nullptr, nullptr, am + 2 * ns, am + 3 * ns);
         {
+            t4r_xlnet_ff_final_dropout(fuse_final && drop, ctr_hi(offset, 255, SITE_FINAL));
             const int rc = t4r_xlnet_ff_bwd(stream, dh_out, w.ffout, w.h1, w.mean2, w.rstd2, params[P_LN2W], w.ffpre, w.planes,
                                             dx, dfo, dff, grads[P_LN2W], grads[P_LN2B], grads[P_B2], grads[P_B1], ff_part,
                                             T, D, drop_p, seed, C(SITE_FF_ACT), C(SITE_FF_OUT));
+            t4r_xlnet_ff_final_dropout(0, 0);
             t4r_xlnet_ff_amax_buffers(nullptr, nullptr, nullptr, nullptr);
             if (rc) return rc;
         }

@@ -175,7 +175,9 @@ class _XLNetLayerFn(torch.autograd.Function):
 from ._lib import exp_env as _exp_env  # noqa: E402
 
 _DEFER_JOIN = _exp_env("T4R_XLNET_DEFER_JOIN", "1") != "0"       # a test flips the attribute; the product reads no switch
-_STACK_PROLOGUE = _exp_env("T4R_XLNET_STACK_PROLOGUE", "1") != "0" and _exp_env("T4R_XLNET_FUSED", "1") != "0"
+_FUSED_ON = _exp_env("T4R_XLNET_FUSED", "1") != "0"
+_FUSE_FINAL = True       # module attribute (no switch): tools/ab_step.py flips it for a same-box A/B
+_STACK_PROLOGUE = _exp_env("T4R_XLNET_STACK_PROLOGUE", "1") != "0" and _FUSED_ON
 _PENDING: list = []          # buffers of deferred layer backwards (kept alive until the join)
 
 
@@ -266,14 +268,18 @@ class XLNetModel(SeedMixin, nn.Module):
         if not infer and _STACK_PROLOGUE and ops.xlnet_fused_supported(D) and len(self.layer) > 1:
             ws_all = ops.xlnet_stack_prepare([[q.detach() for q in layer.ordered_params()] for layer in self.layer],
                                              B, L, cfg.n_head, pos_b if p > 0 else pos, p > 0)
+        # the model-level OUTPUT dropout (HF :1177) rides in the last layer's feed-forward kernels (csrc/xlnet_layer.hip:
+        # T4R_LAYER_FUSE_FINAL) instead of two element-wise launches over [B L, D] around the stack
+        fuse_final = p > 0 and not infer and _FUSE_FINAL and _FUSED_ON and ops.xlnet_fused_supported(D)
         for i, layer in enumerate(self.layer):
             if infer:
                 h = torch.ops.t4r_hip.xlnet_layer_infer(h.reshape(B * L, D), pos, layer.ordered_params(), B, L, cfg.n_head,
                                                         cfg.layer_norm_eps, key_len).view(B, L, D)
                 continue
             h = _XLNetLayerFn.apply(h, layer.rel_attn.q, layer, pos, cfg.n_head, cfg.layer_norm_eps,
-                                    (p, self.seed, offset, i), key_len, pos_b, None if ws_all is None else ws_all[i])
-        if p > 0:
+                                    (p, self.seed, offset, i | (ops.LAYER_FUSE_FINAL if fuse_final and i == len(self.layer) - 1 else 0)),
+                                    key_len, pos_b, None if ws_all is None else ws_all[i])
+        if p > 0 and not fuse_final:
             h = _DropoutFn.apply(h, p, self.seed, ops.dropout_ctr_hi(offset, 255, ops.SITE_FINAL))
         return (h,)
 

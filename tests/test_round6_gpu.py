@@ -200,9 +200,13 @@ def test_scatter_rows_dense_equals_zero_fill_plus_scale_plus_scatter(ops, T, D, 
                        ops.scatter_rows_dense(src, pos_dev.to(DEV), n, torch.tensor(1.0, device=DEV), T))
 
 
+@pytest.mark.parametrize("H", [128, 64, 96, 30])
 @pytest.mark.parametrize("mode", ["MASK_MLM", "MASK_CLM", "MASK_CLM_INFER"])
-def test_out_of_place_mask_backward_equals_the_in_place_one(ops, mode):
-    B, L, H = 33, 20, 128
+def test_out_of_place_mask_backward(ops, mode, H):
+    """dx / d masked_item_embedding of the mask backward (reference: autograd of masking.py:302-337 / :473-498): the out-of-place
+    entry leaves the incoming gradient untouched, equals the in-place one bit for bit, and both equal the definition
+    (H % 4 == 0: the float4 kernel; H = 30: the scalar one)"""
+    B, L = 33, 20
     g = torch.Generator().manual_seed(3)
     dy = torch.randn(B, L, H, generator=g).to(DEV)
     mask = (torch.rand(B, L, generator=g) < 0.3).to(DEV)
@@ -213,6 +217,14 @@ def test_out_of_place_mask_backward_equals_the_in_place_one(ops, mode):
     ref = dy.clone()
     ops.apply_mask_bwd_(ref, mask, m2, getattr(ops, mode))
     assert torch.equal(dx, ref) and torch.equal(m1, m2)
+    # the definition: MLM replaces the masked positions, CLM (training) the UNmasked ones and zeroes the last position,
+    # CLM inference the unmasked ones
+    replaced = mask if mode == "MASK_MLM" else ~mask
+    want = torch.where(replaced[..., None], torch.zeros_like(dy), dy)
+    if mode == "MASK_CLM":
+        want[:, L - 1] = 0
+    assert torch.equal(dx, want)
+    torch.testing.assert_close(m1, (dy * replaced[..., None]).double().sum((0, 1)).float(), rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("B,L,D,n", [(9, 20, 128, 4), (300, 20, 64, 4)])

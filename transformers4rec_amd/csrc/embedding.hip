@@ -416,6 +416,63 @@ __global__ __launch_bounds__(256) void apply_mask_bwd_kernel(const float* src, f
     }
 }
 
+// The same for H % 4 == 0, H <= 1024 (round 6): float4 columns, 256 / (H / 4) token rows of the block in parallel and four
+// row requests in flight per thread (the scalar form above walks 16 tokens per thread one dependent load at a time: 29 us for
+// the 10 MB of BASELINE configs[1] once it also writes every element).  Fixed summation order: a thread's tokens ascending,
+// then the token slices in order.
+__global__ __launch_bounds__(256) void apply_mask_bwd4_kernel(const float* src, float* dy,
+                                                               const unsigned char* __restrict__ mask,
+                                                               float* __restrict__ part, long ntok, int L, int H, int mode) {
+    __shared__ float4 sh[256];
+    const int hq = H >> 2, nsl = 256 / hq;
+    const int cs = threadIdx.x % hq, sl = threadIdx.x / hq;
+    const long t0 = (long)blockIdx.x * T4R_MASK_BWD_TOK;
+    const long t1 = min(ntok, t0 + T4R_MASK_BWD_TOK);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sl < nsl) {
+        for (long tb = t0 + sl; tb < t1; tb += 4L * nsl) {
+            float4 v[4];
+            unsigned char mk[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {            // unconditional loads from clamped rows: four requests in flight
+                const long tc = min(tb + (long)u * nsl, t1 - 1);
+                v[u] = *reinterpret_cast<const float4*>(src + tc * H + 4 * cs);
+                mk[u] = mask[tc];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long t = tb + (long)u * nsl;
+                if (t >= t1) break;
+                const bool m = mk[u] != 0;
+                const int l = (int)(t % L);
+                bool keep, zero = false;
+                if (mode == MASK_MLM) keep = !m;
+                else if (mode == MASK_CLM) { keep = m; zero = (l == L - 1); }
+                else keep = m;
+                float4* d = reinterpret_cast<float4*>(dy + t * H + 4 * cs);
+                if (!keep) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; *d = make_float4(0.f, 0.f, 0.f, 0.f); }
+                else if (zero) *d = make_float4(0.f, 0.f, 0.f, 0.f);
+                else if (src != dy) *d = v[u];
+            }
+        }
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (sl == 0) {
+        for (int k = 1; k < nsl; ++k) {              // fixed order
+            const float4 o = sh[k * hq + cs];
+            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+        }
+        *reinterpret_cast<float4*>(part + (long)blockIdx.x * H + 4 * cs) = acc;
+    }
+}
+static void apply_mask_bwd_launch(hipStream_t st, const float* src, float* dst, const unsigned char* mask, float* ws, long ntok,
+                                  int L, int H, int mode, int nblk) {
+    const bool vec = H % 4 == 0 && H <= 1024 && (((uintptr_t)src | (uintptr_t)dst | (uintptr_t)ws) & 15) == 0;
+    if (vec) hipLaunchKernelGGL(apply_mask_bwd4_kernel, dim3(nblk), dim3(256), 0, st, src, dst, mask, ws, ntok, L, H, mode);
+    else hipLaunchKernelGGL(apply_mask_bwd_kernel, dim3(nblk), dim3(256), 0, st, src, dst, mask, ws, ntok, L, H, mode);
+}
+
 int t4r_reduce_partials_launch(hipStream_t st, const float* part, int nblocks, float* o0, int n0, int a0,
                                float* o1, int n1, int a1, float* o2, int n2, int a2);   // elementwise.hip
 extern "C" long t4r_apply_mask_bwd_ws_floats(int B, int L, int H) {
@@ -428,7 +485,7 @@ extern "C" int t4r_apply_mask_bwd(void* stream, float* dy, const unsigned char* 
     if (ntok == 0 || mode == MASK_NONE) return 0;
     T4R_CHECK_ARG(ws, "apply_mask_bwd: null workspace");
     const int nblk = (int)((ntok + T4R_MASK_BWD_TOK - 1) / T4R_MASK_BWD_TOK);
-    hipLaunchKernelGGL(apply_mask_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dy, dy, mask, ws, ntok, L, H, mode);
+    apply_mask_bwd_launch((hipStream_t)stream, dy, dy, mask, ws, ntok, L, H, mode, nblk);
     T4R_LAUNCH_CHECK();
     return t4r_reduce_partials_launch((hipStream_t)stream, ws, nblk, d_memb, H, 1, nullptr, 0, 0, nullptr, 0, 0);
 }
@@ -444,7 +501,7 @@ extern "C" int t4r_apply_mask_bwd_to(void* stream, const float* dy, float* dx, c
     }
     T4R_CHECK_ARG(ws, "apply_mask_bwd_to: null workspace");
     const int nblk = (int)((ntok + T4R_MASK_BWD_TOK - 1) / T4R_MASK_BWD_TOK);
-    hipLaunchKernelGGL(apply_mask_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dy, dx, mask, ws, ntok, L, H, mode);
+    apply_mask_bwd_launch((hipStream_t)stream, dy, dx, mask, ws, ntok, L, H, mode, nblk);
     T4R_LAUNCH_CHECK();
     return t4r_reduce_partials_launch((hipStream_t)stream, ws, nblk, d_memb, H, 1, nullptr, 0, 0, nullptr, 0, 0);
 }

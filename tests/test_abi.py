@@ -116,3 +116,27 @@ def test_head_note_is_caller_owned():
     assert lib.t4r_head_note_dw_form(ctypes.addressof(note)) == 0 and lib.t4r_head_note_dw_form(None) == 0
     hdr = open(_lib.HEADER_PATH).read()
     assert "typedef struct t4r_head_note { unsigned long long w[8]; } t4r_head_note;" in hdr
+
+
+def test_product_build_reads_no_experiment_switch(monkeypatch):
+    """round 6: A/B / tuning / fallback-forcing switches are compile-time (-DT4R_EXPERIMENTAL): the product library says so, the
+    host side then ignores their names too (both sides of the ABI agree on which kernel families can run), and no C source calls
+    getenv() outside the helper and the one documented product variable"""
+    import glob
+    import re
+
+    from transformers4rec_amd import _lib
+
+    assert _lib.load().t4r_experimental_build() == 0
+    monkeypatch.setenv("T4R_XLNET_FUSED", "0")
+    assert _lib.exp_env("T4R_XLNET_FUSED", "1") == "1"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    direct = []
+    for f in glob.glob(os.path.join(root, "transformers4rec_amd", "csrc", "*")):
+        for m in re.finditer(r'(?<![_a-z])getenv\("([A-Z0-9_]+)"\)', open(f).read()):
+            direct.append((os.path.basename(f), m.group(1)))
+    assert sorted(set(direct)) == [("gemm_f32.hip", "T4R_GEMM_PREC")], direct
+    host = set()
+    for f in glob.glob(os.path.join(root, "transformers4rec_amd", "*.py")):
+        host |= set(re.findall(r'environ\.get\("(T4R_[A-Z0-9_]+)"', open(f).read()))
+    assert host == {"T4R_HIP_LIB", "T4R_HEAD_MODE", "T4R_HEAD_AUTO_GB", "T4R_HEAD_CHUNK_MB", "T4R_HEAD_WS_GB"}, host

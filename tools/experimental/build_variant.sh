@@ -1,20 +1,24 @@
 #!/bin/bash
-# A/B variant of the product library with the measured-and-not-kept kernels of this directory compiled in
-# (-DT4R_EXPERIMENTAL): same C ABI plus t4r_xlnet_attn_block_bwd[_part_floats]; the env switches of README.md select them.
-#   bash tools/experimental/build_variant.sh && T4R_HIP_LIB=tools/bin/libt4r_hip_exp.so python bench.py ...
+# EXPERIMENT build of the library (-DT4R_EXPERIMENTAL): same C ABI plus t4r_xlnet_attn_block_bwd[_part_floats], with
+#   * the measured-and-not-kept kernels of this directory compiled in, and
+#   * every A/B / tuning / fallback-forcing environment switch LIVE (csrc/t4r_common.h: t4r_exp_getenv; the product build
+#     compiles them out and reads only the six variables of INTEGRATION.md section 5).
+# Every source is recompiled with the flag (round 6: the switches live in all of them).
+#   bash tools/experimental/build_variant.sh && T4R_HIP_LIB=tools/bin/libt4r_hip_exp.so T4R_GATHER_U=4 python bench.py ...
 set -e
 ROOT="$(cd "$(dirname "$0")/../.." && pwd)"
 CSRC=$ROOT/transformers4rec_amd/csrc
-LIB=$ROOT/transformers4rec_amd/lib
 OUT=$ROOT/tools/bin
 mkdir -p $OUT/exp_obj
+rm -f $OUT/exp_obj/*.o
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result -DT4R_EXPERIMENTAL=1 -I$CSRC"
+n=0
 pids=()
-for f in xlnet_attn_block xlnet_layer xlnet_attn gemm_f32; do
-  /opt/rocm/bin/hipcc $FLAGS -c $CSRC/$f.hip -o $OUT/exp_obj/$f.o & pids+=($!)
+for src in $CSRC/*.hip $ROOT/tools/experimental/wgrad_stream.hip; do
+  /opt/rocm/bin/hipcc $FLAGS -c $src -o $OUT/exp_obj/$(basename ${src%.hip}).o & pids+=($!)
+  n=$((n + 1))
+  if [ $((n % 8)) -eq 0 ]; then for p in "${pids[@]}"; do wait $p; done; pids=(); fi
 done
-/opt/rocm/bin/hipcc $FLAGS -c $ROOT/tools/experimental/wgrad_stream.hip -o $OUT/exp_obj/wgrad_stream.o & pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
-objs=$(ls $LIB/*.o | grep -v -e "/xlnet_attn_block.o" -e "/xlnet_layer.o" -e "/xlnet_attn.o" -e "/gemm_f32.o")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libt4r_hip_exp.so $objs $OUT/exp_obj/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libt4r_hip_exp.so $OUT/exp_obj/*.o
 echo $OUT/libt4r_hip_exp.so

@@ -258,3 +258,27 @@ def test_output_dropout_fused_into_the_last_layer(ops, B, L, D, n):
     assert torch.equal(dh1, dh0)
     for name, a, b in zip(K.ORDER, g1, g0):
         assert torch.equal(a, b), name
+
+
+@pytest.mark.parametrize("n,rows", [(20480, 100_001), (1, 3), (5, 10), (63, 7), (64, 100), (1025, 262_143), (32768, 65_535),
+                                    (4097, 1_000_001), (40_000, 100_001)])
+def test_one_launch_sort_equals_the_stable_order(ops, n, rows):
+    """t4r_sort_ids: problems of one workgroup (n <= 32 768, key and index in one 32-bit word, keys below 2^18) are sorted by ONE
+    launch in LDS (two stable 9-bit counting passes with wave-ballot ranks); larger ones by the library sort.  Both must give THE
+    stable order: keys ascending, equal keys in ascending lookup order; padding and out-of-range ids carry `rows` and come last."""
+    g = torch.Generator().manual_seed(n + rows)
+    ids = torch.randint(0, rows, (n,), generator=g)
+    if n > 8:
+        ids[torch.randint(0, n, (max(1, n // 50),), generator=g)] = 0                  # padding
+        ids[torch.randint(0, n, (max(1, n // 100),), generator=g)] = rows + 5           # out of range
+        ids[torch.randint(0, n, (max(1, n // 100),), generator=g)] = -3
+        ids[: n // 4] = ids[n // 4: 2 * (n // 4)]                                       # many duplicates
+    keys, perm = ops.sort_ids(ids.to(DEV), rows, 0)
+    key_ref = torch.where((ids == 0) | (ids < 0) | (ids >= rows), torch.full_like(ids, rows), ids)
+    ks, ps = torch.sort(key_ref, stable=True)
+    assert torch.equal(keys.cpu().long(), ks) and torch.equal(perm.cpu().long(), ps)
+    # no padding id (the sampled head's rows): id 0 is a row like any other
+    keys2, perm2 = ops.sort_ids(ids.to(DEV), rows, -1)
+    key_ref2 = torch.where((ids < 0) | (ids >= rows), torch.full_like(ids, rows), ids)
+    ks2, ps2 = torch.sort(key_ref2, stable=True)
+    assert torch.equal(keys2.cpu().long(), ks2) and torch.equal(perm2.cpu().long(), ps2)

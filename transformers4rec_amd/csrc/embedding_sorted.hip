@@ -126,8 +126,8 @@ __device__ __forceinline__ void lsort_pass(const unsigned (&word)[T4R_LSORT_STEP
     }
     __syncthreads();
 }
-__global__ __launch_bounds__(1024) void sort_ids_lds_kernel(const long* __restrict__ ids, int n, long rows, int padding_idx, int ib,
-                                                             int* __restrict__ keys_sorted, int* __restrict__ perm) {
+__device__ __forceinline__ void lsort_body(const long* __restrict__ ids, int n, long rows, int padding_idx, int ib,
+                                           int* __restrict__ keys_sorted, int* __restrict__ perm) {
     extern __shared__ unsigned lsort_smem[];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int chunk = (((n + 15) / 16) + 63) / 64 * 64, steps = chunk / 64, begin = w * chunk;
@@ -151,6 +151,10 @@ __global__ __launch_bounds__(1024) void sort_ids_lds_kernel(const long* __restri
         if (s < steps) word[s] = buf[min(begin + s * 64 + lane, n - 1)];
     __syncthreads();
     lsort_pass<true>(word, steps, begin, n, 9, ib, cnt, tot, nullptr, keys_sorted, perm, w, lane, tid);
+}
+__global__ __launch_bounds__(1024) void sort_ids_lds_kernel(const long* __restrict__ ids, int n, long rows, int padding_idx, int ib,
+                                                             int* __restrict__ keys_sorted, int* __restrict__ perm) {
+    lsort_body(ids, n, rows, padding_idx, ib, keys_sorted, perm);
 }
 // does the one-launch sort take this problem?  (key bits <= 18: two 9-bit passes; a word holds key and index)
 static int lsort_index_bits(long n, long rows) {
@@ -224,6 +228,11 @@ extern "C" int t4r_sort_ids(void* stream, const long* ids, long n, long rows, in
 constexpr int kSortMaxFeatures = 16;
 struct SortMulti { const long* ids[kSortMaxFeatures]; long rows[kSortMaxFeatures]; long off[kSortMaxFeatures]; int pad[kSortMaxFeatures]; int F; long n; };
 
+// one workgroup per table: the F sorts of an input block run side by side in ONE launch (round 6; every table one-workgroup sized)
+__global__ __launch_bounds__(1024) void sort_ids_lds_multi_kernel(SortMulti p, int ib, int* __restrict__ keys, int* __restrict__ perm) {
+    const int f = blockIdx.x;
+    lsort_body(p.ids[f], (int)p.n, p.rows[f], p.pad[f], ib, keys + (long)f * p.n, perm + (long)f * p.n);
+}
 __global__ __launch_bounds__(256) void emb_keys_multi_kernel(SortMulti p, int* __restrict__ keys, int* __restrict__ idx) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.n * p.F) return;
@@ -263,6 +272,20 @@ extern "C" int t4r_sort_ids_multi(void* stream, const long* const* ids, int F, l
     const SortLayout l = sort_layout(n * F);
     T4R_CHECK_ARG(ws_bytes >= (long)l.total, "sort_ids_multi: workspace too small (t4r_sort_ids_multi_ws_bytes)");
     hipStream_t st = (hipStream_t)stream;
+    {
+        int ib = lsort_index_bits(n, rows[0]);
+        for (int f = 1; f < F && ib; ++f)
+            if (lsort_index_bits(n, rows[f]) != ib) ib = 0;        // (the index bits depend on n only; 0 = a table does not fit)
+        if (ib) {       // every table is a one-workgroup problem: F workgroups, one launch, no workspace
+            const int chunk = (int)((((n + 15) / 16) + 63) / 64 * 64);
+            const size_t smem = (size_t)16 * chunk * 4 + 512 * 4 + 16 * 512 * 2;
+            static T4rLdsAttr attr;
+            t4r_ensure_dynamic_lds((const void*)sort_ids_lds_multi_kernel, smem, attr);
+            hipLaunchKernelGGL(sort_ids_lds_multi_kernel, dim3(F), dim3(1024), smem, st, p, ib, keys_sorted, perm);
+            T4R_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     char* w = (char*)ws;
     int* keys_in = (int*)(w + l.keys_in);
     int* idx_in = (int*)(w + l.idx_in);

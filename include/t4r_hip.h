@@ -501,7 +501,10 @@ int t4r_xlnet_ff_bwd(void* stream, const float* dy, const float* ffout, const fl
  * layer_idx: bits 0-7 the layer (the only part the mask keys use); bit 8 (0x100), with drop_p > 0 and d_model 32 / 64 / 128:
  * this is the LAST layer of the stack and its feed-forward kernels also apply the MODEL's output dropout (HF :1177, key
  * (offset, 255, site 6)) -- to h_out in _fwd, to dh_out on load in _bwd -- instead of two element-wise launches over [T, D]
- * around the stack (round 6). */
+ * around the stack (round 6); bit 9 (0x200), with drop_p > 0, d_model 32 / 64 / 128 and t4r_xlnet_attn_block_supported(L, D,
+ * n_head): this is the FIRST layer and `h` is the model's UNDROPPED input -- the input dropout (HF :1116, key (offset, 255,
+ * site 0)) is applied on load by the attention-block kernel (the dropped rows are kept in `ws` for _bwd, which takes them from
+ * there whatever `h` it is given) and _bwd masks the d h it returns. */
 long t4r_xlnet_layer_ws_floats(int B, int L, int D, int n_head, int dropout);
 long t4r_xlnet_layer_bwd_ws_floats(int B, int L, int D, int n_head, int dropout);
 int t4r_xlnet_layer_fwd(void* stream, const float* h, const float* pos_emb, const float* const* params,

@@ -29,8 +29,9 @@ def test_workspace_size_queries_are_pure():
     n = lib.t4r_xlnet_layer_ws_floats(1024, 20, 128, 4, 0)
     T = 1024 * 20
     assert n >= T * 128 * (3 + 1 + 1 + 1 + 4 + 4 + 1)
-    # dropout: per-session k_r instead of the shared one, plus the kept dropout(pos_emb) [B, 2L, D]
-    assert lib.t4r_xlnet_layer_ws_floats(1024, 20, 128, 4, 1) == n + (1024 - 1) * 2 * 20 * 128 + 1024 * 2 * 20 * 128
+    # dropout: per-session k_r instead of the shared one, plus the kept dropout(pos_emb) [B, 2L, D], plus (round 6) the dropped
+    # input rows [T, D] a first layer keeps when it applies the model's input dropout itself
+    assert lib.t4r_xlnet_layer_ws_floats(1024, 20, 128, 4, 1) == n + (1024 - 1) * 2 * 20 * 128 + 1024 * 2 * 20 * 128 + T * 128
     assert lib.t4r_xlnet_layer_bwd_ws_floats(8, 20, 64, 4, 0) > 0
     assert lib.t4r_dropout_ctr_hi(3, 2, 4) == (3 << 16) | (2 << 8) | 4
     assert lib.t4r_xlnet_attn_bwd_ws_floats(8, 20, 64, 4) == 8 * (2 * 20 * 64 + 2 * 64)
@@ -79,6 +80,8 @@ _ALLOWED_FILE_SCOPE_STATE = {
     "g_ff_amax": "thread-local, set and cleared inside one layer call",
     "g_ff_final_ctr": "thread-local, set and cleared inside one layer call (key of the fused model-level output dropout)",
     "g_ff_final_on": "same",
+    "g_ab_in_on": "thread-local, set and cleared inside one layer call (fused model-level input dropout of the first layer)",
+    "g_ab_in_ctr": "same", "g_ab_hin": "same", "g_dh_in_on": "same", "g_dh_in_p": "same", "g_dh_in_seed": "same", "g_dh_in_ctr": "same",
     "g_red_side": "thread-local, set and cleared inside one layer call (reduction side stream)",
     "g_red_events": "same", "g_red_n": "same", "g_red_used": "same",
 }

@@ -282,3 +282,41 @@ def test_one_launch_sort_equals_the_stable_order(ops, n, rows):
     key_ref2 = torch.where((ids < 0) | (ids >= rows), torch.full_like(ids, rows), ids)
     ks2, ps2 = torch.sort(key_ref2, stable=True)
     assert torch.equal(keys2.cpu().long(), ks2) and torch.equal(perm2.cpu().long(), ps2)
+
+
+@pytest.mark.parametrize("B,L,D,n", [(9, 20, 128, 4), (300, 20, 64, 4), (5, 32, 128, 4)])
+def test_input_dropout_fused_into_the_first_layer(ops, B, L, D, n):
+    """layer_idx | LAYER_FUSE_INPUT: the model-level input dropout (HF modeling_xlnet.py:1116) applied by the first layer's
+    attention-block kernel on load == the element-wise dropout of that site followed by the layer without the flag; backward:
+    the same parameter gradients, and d h == the plain layer's d h masked again"""
+    import test_kernels_gpu as K
+
+    assert ops.xlnet_attn_block_supported(L, D, n)
+    g = torch.Generator().manual_seed(B + D + L)
+    prm = K._layer_params(g, D, n)
+    params = [K.cu(prm[k]) for k in K.ORDER]
+    h = K.cu(torch.randn(B * L, D, generator=g))
+    dout = K.cu(torch.randn(B * L, D, generator=g))
+    pos = K.cu(O.xlnet_pos_emb(L, D))
+    p_drop, seed, offset = 0.3, 4321, 7
+    kw = dict(drop_p=p_drop, seed=seed, offset=offset)
+    ctr_in = ops.dropout_ctr_hi(offset, 255, ops.SITE_INPUT)
+    hd = ops.dropout(h.view(-1), p_drop, seed, ctr_in).view(B * L, D)
+    out0, ws0 = ops.xlnet_layer_fwd(hd, pos, params, B, L, n, 0.03, layer_idx=0, **kw)
+    g0 = [torch.zeros_like(t) for t in params]
+    dh0 = ops.xlnet_layer_bwd(hd, pos, params, g0, ws0, dout, B, L, n, 0.03, layer_idx=0, **kw)
+    want_dh = ops.dropout(dh0.view(-1), p_drop, seed, ctr_in).view(B * L, D)
+    out1, ws1 = ops.xlnet_layer_fwd(h, pos, params, B, L, n, 0.03, layer_idx=ops.LAYER_FUSE_INPUT, **kw)
+    assert torch.equal(out1, out0)
+    g1 = [torch.zeros_like(t) for t in params]
+    dh1 = ops.xlnet_layer_bwd(h, pos, params, g1, ws1, dout, B, L, n, 0.03, layer_idx=ops.LAYER_FUSE_INPUT, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(dh1, want_dh)
+    assert float((dh1 == 0).float().mean()) > 0.25
+    for name, a, b in zip(K.ORDER, g1, g0):
+        assert torch.equal(a, b), name
+    # both flags on one layer (a one-layer stack)
+    both = ops.LAYER_FUSE_INPUT | ops.LAYER_FUSE_FINAL
+    out2, ws2 = ops.xlnet_layer_fwd(h, pos, params, B, L, n, 0.03, layer_idx=both, **kw)
+    ctr_fin = ops.dropout_ctr_hi(offset, 255, ops.SITE_FINAL)
+    assert torch.equal(out2, ops.dropout(out0.view(-1), p_drop, seed, ctr_fin).view(B * L, D))

@@ -126,6 +126,9 @@ struct AttnBlockFwd {
     long T;
     float scale, eps;
     DropCfg drop_p, drop_o;  // attention probabilities, attention output
+    DropCfg drop_in;         // p > 0 (first layer of a stack in training mode): h is the UNDROPPED input of the model; its
+    float* hin;              // input dropout (HF modeling_xlnet.py:1116) is applied on load and the dropped rows are written to
+                             // hin [T, D] for the backward (residual of LayerNorm 1, operand of the q | k | v weight gradients)
 #ifdef T4R_AB_STAMPS
     long long* stamps;
 #endif
@@ -163,6 +166,18 @@ __global__ __launch_bounds__(D * 4) void xlnet_attn_block_fwd_kernel(AttnBlockFw
             const int idx = min(tid + i * NW * 64, AB_RT * (D / 4) - 1);
             const int row = idx / (D / 4), c4 = (idx - row * (D / 4)) * 4;
             hstage[i] = ld4(p.h + min(t0 + row, p.T - 1) * D + c4);
+        }
+        if (p.drop_in.p > 0.f) {            // workgroup-uniform
+#pragma unroll
+            for (int i = 0; i < NST; ++i) {
+                const int idx = tid + i * NW * 64;
+                const int row = min(idx, AB_RT * (D / 4) - 1) / (D / 4), c4 = (min(idx, AB_RT * (D / 4) - 1) - row * (D / 4)) * 4;
+                const long t = min(t0 + row, p.T - 1);
+                const float4 m = drop_scale4(p.drop_in, (unsigned long long)t * D + c4);
+                hstage[i].x *= m.x; hstage[i].y *= m.y; hstage[i].z *= m.z; hstage[i].w *= m.w;
+                // (rows past this workgroup's S L belong to the next one, which writes them itself)
+                if (idx < AB_RT * (D / 4) && row < p.S * p.L && t0 + row < p.T) *reinterpret_cast<float4*>(p.hin + t * D + c4) = hstage[i];
+            }
         }
         float a[3][4 * KC];
         auto load_a = [&](int z, int c) __attribute__((always_inline)) {
@@ -435,6 +450,13 @@ __global__ __launch_bounds__(D * 4) void xlnet_attn_block_fwd_kernel(AttnBlockFw
         float4 hres[AB_R];
 #pragma unroll
         for (int r = 0; r < AB_R; ++r) hres[r] = ld4(p.h + min(t0 + 16 * r + n, p.T - 1) * D + 16 * w + 4 * g);
+        if (p.drop_in.p > 0.f) {            // the residual is the DROPPED input: the same mask again (recomputed, not re-read)
+#pragma unroll
+            for (int r = 0; r < AB_R; ++r) {
+                const float4 m = drop_scale4(p.drop_in, (unsigned long long)min(t0 + 16 * r + n, p.T - 1) * D + 16 * w + 4 * g);
+                hres[r].x *= m.x; hres[r].y *= m.y; hres[r].z *= m.z; hres[r].w *= m.w;
+            }
+        }
         f32x4 acc[AB_R];
 #pragma unroll
         for (int r = 0; r < AB_R; ++r) acc[r] = zero4();
@@ -548,6 +570,12 @@ static int attn_block_sessions(int L) { return AB_RT / L; }
 // attn_vec av [T][D], lse [B][n_head][L] and (training: ao != NULL) ao [T][D], mean / rstd [T] for the backward.
 // planes: t4r_xlnet_layer_prepare's buffer (its fp32 transposes); o: the layer's o weight [D][n_head][d_head] as stored;
 // kr: k_r = pos_emb @ r, [2 L][D] (kr_bstride 0) or per session [B][2 L][D] (kr_bstride 2 L D).
+// set and cleared inside one layer call (csrc/xlnet_layer.hip, T4R_LAYER_FUSE_INPUT): the next t4r_xlnet_attn_block_fwd of this
+// thread applies the model-level input dropout keyed by `ctr` to h on load and leaves the dropped rows in `hin`
+static thread_local int g_ab_in_on = 0;
+static thread_local unsigned long long g_ab_in_ctr = 0;
+static thread_local float* g_ab_hin = nullptr;
+void t4r_xlnet_attn_block_input_dropout(int on, unsigned long long ctr, float* hin) { g_ab_in_on = on; g_ab_in_ctr = ctr; g_ab_hin = hin; }
 extern "C" int t4r_xlnet_attn_block_fwd(void* stream, const float* h, const float* planes, const float* o, const float* kr,
                                         long kr_bstride, const float* r_w_bias, const float* r_r_bias, const float* gamma,
                                         const float* beta, float* qkv, float* av, float* lse, float* ao, float* mean,
@@ -569,6 +597,9 @@ extern "C" int t4r_xlnet_attn_block_fwd(void* stream, const float* h, const floa
     p.scale = 1.0f / sqrtf((float)dh); p.eps = eps;
     p.drop_p = make_drop(drop_p, seed, ctr_prob);
     p.drop_o = make_drop(drop_p, seed, ctr_out);
+    p.drop_in = make_drop(g_ab_in_on ? drop_p : 0.f, seed, g_ab_in_ctr);
+    p.hin = g_ab_in_on ? g_ab_hin : nullptr;
+    T4R_CHECK_ARG(!(g_ab_in_on && drop_p > 0.f) || p.hin, "xlnet_attn_block_fwd: the fused input dropout needs its output buffer");
 #ifdef T4R_AB_STAMPS
     p.stamps = g_ab_stamps;
 #endif

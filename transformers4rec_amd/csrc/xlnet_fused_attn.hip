@@ -628,6 +628,7 @@ struct DhParams {
     const float* wscale;
     float* dh;                // [T, D], ACCUMULATED into (holds the LayerNorm-backward residual part)
     long T;
+    DropCfg drop_in;          // p > 0 (first layer): dh is the gradient of the DROPPED model input: masked in the final store
 };
 
 template <int D, int R, bool HS = false>
@@ -717,7 +718,12 @@ __global__ __launch_bounds__(D * 4) void xlnet_dh_kernel(DhParams p) {
         const long t = t0 + r * 16 + n;
         if (t < p.T) {
             const float4 o = ld4(p.dh + t * D + k0);
-            st4(p.dh + t * D + k0, make_float4(o.x + acc[r][0], o.y + acc[r][1], o.z + acc[r][2], o.w + acc[r][3]));
+            float4 v = make_float4(o.x + acc[r][0], o.y + acc[r][1], o.z + acc[r][2], o.w + acc[r][3]);
+            if (p.drop_in.p > 0.f) {        // workgroup-uniform
+                const float4 m = drop_scale4(p.drop_in, (unsigned long long)t * D + k0);
+                v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+            }
+            st4(p.dh + t * D + k0, v);
         }
     }
 }
@@ -922,13 +928,21 @@ extern "C" int t4r_xlnet_ln1_bwd(void* stream, const float* dy, const float* ao,
 }
 
 // dh [T, D] += d q @ W_q^T + d k @ W_k^T + d v @ W_v^T   (dqkv [3][T][D])
+// set and cleared inside one layer call (T4R_LAYER_FUSE_INPUT): the next t4r_xlnet_dh masks its result with the input dropout
+static thread_local int g_dh_in_on = 0;
+static thread_local float g_dh_in_p = 0.f;
+static thread_local unsigned long long g_dh_in_seed = 0, g_dh_in_ctr = 0;
+void t4r_xlnet_dh_input_dropout(int on, float p, unsigned long long seed, unsigned long long ctr) {
+    g_dh_in_on = on; g_dh_in_p = p; g_dh_in_seed = seed; g_dh_in_ctr = ctr;
+}
 extern "C" int t4r_xlnet_dh(void* stream, const float* dqkv, const float* planes, float* dh, long T, int D) {
     if (T <= 0) return 0;
     T4R_CHECK_ARG(t4r_xlnet_fused_supported(D) && dqkv && planes && dh, "xlnet_dh: bad arguments");
     const int R = t4r_xlnet_pick_r(T, true);
     const bool hs = t4r_xlnet_body_fp16x2();
     const LayerPlanesH PH_ = carve_planes_h(planes, D);
-    DhParams p{dqkv, hs ? PH_.QKVN : carve_planes(planes, D).QKVN, PH_.scale + HS_Q, dh, T};
+    DhParams p{dqkv, hs ? PH_.QKVN : carve_planes(planes, D).QKVN, PH_.scale + HS_Q, dh, T,
+               make_drop(g_dh_in_on ? g_dh_in_p : 0.f, g_dh_in_seed, g_dh_in_ctr)};
     hipStream_t st = (hipStream_t)stream;
 #define CALL(DD, RR)                                                                                             \
     {                                                                                                            \

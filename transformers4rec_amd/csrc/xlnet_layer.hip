@@ -41,6 +41,14 @@ void t4r_xlnet_ff_final_dropout(int on, unsigned long long ctr);                
 //                         feed-forward kernels -- to h_out in the forward, to dh_out on load in the backward -- instead of by
 //                         two element-wise launches over [T, D] around the stack.  Needs the fused kernels (d_model 32/64/128).
 #define T4R_LAYER_FUSE_FINAL 0x100
+//   T4R_LAYER_FUSE_INPUT  this is the FIRST layer of the stack and `h` is the model's UNDROPPED input: the model-level input
+//                         dropout (HF :1116, key (offset, 255, SITE_INPUT)) is applied by the attention-block kernel on load
+//                         (the dropped rows are kept in the layer's workspace for the backward), and the backward masks d h
+//                         in xlnet_dh's final store -- instead of two element-wise launches over [T, D].  Needs the one-kernel
+//                         attention forward (t4r_xlnet_attn_block_supported) and the fused kernels.
+#define T4R_LAYER_FUSE_INPUT 0x200
+void t4r_xlnet_attn_block_input_dropout(int on, unsigned long long ctr, float* hin);     // xlnet_attn_block.hip
+void t4r_xlnet_dh_input_dropout(int on, float p, unsigned long long seed, unsigned long long ctr);   // xlnet_fused_attn.hip
 int t4r_xlnet_ff_amax_count(long T);
 int t4r_xlnet_ff_amax_count_bwd(long T);
 void t4r_gemm_operand_amax2(const float* a, int na, const float* b, int nb);   // gemm_f32.hip: the two producers ran different grids
@@ -135,7 +143,7 @@ enum { P_Q = 0, P_K, P_V, P_O, P_R, P_RWB, P_RRB, P_LN1W, P_LN1B, P_W1, P_B1, P_
        P_LN2B, P_COUNT };
 
 struct LayerWs {
-    float *qkv, *kr, *av, *lse, *ao, *mean1, *rstd1, *h1, *ffpre, *ffact, *ffout, *mean2, *rstd2, *pe_b, *planes, *amax;
+    float *qkv, *kr, *av, *lse, *ao, *mean1, *rstd1, *h1, *ffpre, *ffact, *ffout, *mean2, *rstd2, *pe_b, *planes, *amax, *hin;
     long total;
 };
 
@@ -166,6 +174,9 @@ static LayerWs carve(float* base, int B, int L, int D, int n, int per_batch_kr) 
     w.planes = t4r_xlnet_fused_supported(D) ? take(t4r_xlnet_layer_planes_floats(D)) : nullptr;
     // per-workgroup operand maxima of the feed-forward weight gradients (fused kernels -> fp16-split GEMMs): 4 arrays
     w.amax = t4r_xlnet_fused_supported(D) ? take(4 * t4r_xlnet_ff_amax_slots(T)) : nullptr;
+    // the dropped input rows of a FIRST layer that applies the model's input dropout itself (T4R_LAYER_FUSE_INPUT); last, so
+    // that every other offset is what it was
+    w.hin = (per_batch_kr && t4r_xlnet_fused_supported(D)) ? take(T * D) : nullptr;
     w.total = o;
     return w;
 }
@@ -229,6 +240,9 @@ extern "C" int t4r_xlnet_layer_fwd(void* stream, const float* h, const float* po
     auto C = [&](int site) { return ctr_hi(offset, layer_idx, site); };
     const bool fuse_final = (layer_idx & T4R_LAYER_FUSE_FINAL) != 0;
     T4R_CHECK_ARG(!fuse_final || use_fused(D), "xlnet_layer: the fused output dropout needs the fused layer kernels (d_model 32 / 64 / 128)");
+    const bool fuse_in = (layer_idx & T4R_LAYER_FUSE_INPUT) != 0 && drop;
+    T4R_CHECK_ARG(!fuse_in || (use_fused(D) && use_attn_block(L, D, n_head)),
+                  "xlnet_layer: the fused input dropout needs the one-kernel attention forward (L <= 32, d_model 32 / 64 / 128)");
     if (use_fused(D)) {
         // ONE launch cuts the layer's nine weight matrices into bf16 planes; q, k, v in one token-tile launch; k_r; the
         // attention core; o-projection + dropout + residual + LayerNorm in one launch; the feed-forward block in one
@@ -250,10 +264,13 @@ extern "C" int t4r_xlnet_layer_fwd(void* stream, const float* h, const float* po
         }
         if (block) {
             // q | k | v projection, attention core, o-projection + dropout + residual + LayerNorm: ONE launch
-            RUN(t4r_xlnet_attn_block_fwd(stream, h, w.planes, params[P_O], w.kr, drop ? 2L * L * D : 0L, params[P_RWB],
-                                         params[P_RRB], params[P_LN1W], params[P_LN1B], w.qkv, w.av, w.lse, w.ao, w.mean1,
-                                         w.rstd1, w.h1, B, L, D, n_head, ln_eps, drop_p, seed, C(SITE_PROB), C(SITE_ATTN_OUT),
-                                         key_len));
+            t4r_xlnet_attn_block_input_dropout(fuse_in, ctr_hi(offset, 255, SITE_INPUT), w.hin);
+            const int rc_ab = t4r_xlnet_attn_block_fwd(stream, h, w.planes, params[P_O], w.kr, drop ? 2L * L * D : 0L, params[P_RWB],
+                                                       params[P_RRB], params[P_LN1W], params[P_LN1B], w.qkv, w.av, w.lse, w.ao, w.mean1,
+                                                       w.rstd1, w.h1, B, L, D, n_head, ln_eps, drop_p, seed, C(SITE_PROB),
+                                                       C(SITE_ATTN_OUT), key_len);
+            t4r_xlnet_attn_block_input_dropout(0, 0, nullptr);
+            if (rc_ab) return rc_ab;
         } else {
         RUN(t4r_xlnet_attn_fwd(stream, w.qkv, w.qkv + TD, w.qkv + 2 * TD, w.kr, params[P_RWB], params[P_RRB], w.av, w.lse,
                                B, L, n_head, dh, drop, drop_p, seed, C(SITE_PROB), key_len));
@@ -406,6 +423,10 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
     auto C = [&](int site) { return ctr_hi(offset, layer_idx, site); };
     const bool fuse_final = (layer_idx & T4R_LAYER_FUSE_FINAL) != 0;
     T4R_CHECK_ARG(!fuse_final || use_fused(D), "xlnet_layer: the fused output dropout needs the fused layer kernels (d_model 32 / 64 / 128)");
+    const bool fuse_in = (layer_idx & T4R_LAYER_FUSE_INPUT) != 0 && drop;
+    T4R_CHECK_ARG(!fuse_in || (use_fused(D) && use_attn_block(L, D, n_head)),
+                  "xlnet_layer: the fused input dropout needs the one-kernel attention forward (L <= 32, d_model 32 / 64 / 128)");
+    if (fuse_in) h = w.hin;          // the forward left the DROPPED input rows there: the residual and the weight-gradient operand
     long o = 0;
     auto take = [&](long nfl) { float* p = bws + o; o += align4(nfl); return p; };
     float* dqkv = take(3 * TD);
@@ -575,7 +596,12 @@ extern "C" int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* po
         }
         // second reduction launch: o, r, q, k, v and the LayerNorm-1 / attention-bias sums (same stream as their products)
         RUN(t4r_splitk_sink_flush(sw));
-        if (!block) RUN(t4r_xlnet_dh(stream, dqkv, w.planes, dh_in, T, D));
+        if (!block) {
+            t4r_xlnet_dh_input_dropout(fuse_in, drop_p, seed, ctr_hi(offset, 255, SITE_INPUT));
+            const int rc_dh = t4r_xlnet_dh(stream, dqkv, w.planes, dh_in, T, D);
+            t4r_xlnet_dh_input_dropout(0, 0.f, 0, 0);
+            if (rc_dh) return rc_dh;
+        }
         if (ss && !g_defer_join) {   // join: the caller's stream continues after every weight gradient of this layer
             (void)hipEventRecord(ss->done_all, ss->s);
             (void)hipStreamWaitEvent(st, ss->done_all, 0);

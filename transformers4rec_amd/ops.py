@@ -313,6 +313,7 @@ def head_split_dx_rc(ws, x, W, lse, labels, grad_out, alpha=1.0, label_smoothing
 # ------------------------------------------------------------------------------------ LN / act
 SITE_INPUT, SITE_POS, SITE_PROB, SITE_ATTN_OUT, SITE_FF_ACT, SITE_FF_OUT, SITE_FINAL = range(7)
 LAYER_FUSE_FINAL = 0x100     # flag in xlnet_layer_fwd / _bwd's layer_idx: this layer also applies the model's output dropout
+LAYER_FUSE_INPUT = 0x200     # ... this (first) layer applies the model's input dropout: h is the undropped input
 NO_DROP = (0.0, 0, 0)
 
 

@@ -177,6 +177,7 @@ from ._lib import exp_env as _exp_env  # noqa: E402
 _DEFER_JOIN = _exp_env("T4R_XLNET_DEFER_JOIN", "1") != "0"       # a test flips the attribute; the product reads no switch
 _FUSED_ON = _exp_env("T4R_XLNET_FUSED", "1") != "0"
 _FUSE_FINAL = True       # module attribute (no switch): tools/ab_step.py flips it for a same-box A/B
+_FUSE_INPUT = True
 _STACK_PROLOGUE = _exp_env("T4R_XLNET_STACK_PROLOGUE", "1") != "0" and _FUSED_ON
 _PENDING: list = []          # buffers of deferred layer backwards (kept alive until the join)
 
@@ -254,7 +255,12 @@ class XLNetModel(SeedMixin, nn.Module):
             self._drop_offset += 1
             offset = self._drop_offset
         h = inputs_embeds
-        if p > 0:
+        # the model-level INPUT dropout (HF :1116) rides in the first layer's kernels (csrc/xlnet_layer.hip: T4R_LAYER_FUSE_INPUT: the
+        # attention-block kernel masks h on load and keeps the dropped rows for the backward, xlnet_dh masks d h) where the
+        # one-kernel attention forward takes the shape; else it is the element-wise launch
+        fuse_in = (p > 0 and torch.is_grad_enabled() and _FUSE_INPUT and _FUSED_ON and ops.xlnet_fused_supported(D)
+                   and ops.xlnet_attn_block_supported(L, D, cfg.n_head) and key_len is None)
+        if p > 0 and not fuse_in:
             h = _DropoutFn.apply(h, p, self.seed, ops.dropout_ctr_hi(offset, 255, ops.SITE_INPUT))
         # dropout(pos_emb) is drawn once per forward and shared by the layers (HF :1143)
         pos_b = ops.xlnet_pos_emb_dropout(pos, B, p, self.seed, offset) if p > 0 else None
@@ -277,7 +283,8 @@ class XLNetModel(SeedMixin, nn.Module):
                                                         cfg.layer_norm_eps, key_len).view(B, L, D)
                 continue
             h = _XLNetLayerFn.apply(h, layer.rel_attn.q, layer, pos, cfg.n_head, cfg.layer_norm_eps,
-                                    (p, self.seed, offset, i | (ops.LAYER_FUSE_FINAL if fuse_final and i == len(self.layer) - 1 else 0)),
+                                    (p, self.seed, offset, i | (ops.LAYER_FUSE_FINAL if fuse_final and i == len(self.layer) - 1 else 0)
+                                     | (ops.LAYER_FUSE_INPUT if fuse_in and i == 0 else 0)),
                                     key_len, pos_b, None if ws_all is None else ws_all[i])
         if p > 0 and not fuse_final:
             h = _DropoutFn.apply(h, p, self.seed, ops.dropout_ctr_hi(offset, 255, ops.SITE_FINAL))

@@ -60,23 +60,37 @@ __device__ __forceinline__ unsigned long long lsort_match(unsigned d, bool valid
     }
     return peers;
 }
-template <bool TO_GLOBAL>
-__device__ __forceinline__ void lsort_pass(const unsigned (&word)[T4R_LSORT_STEPS], int steps, int begin, int n, int shift, int ib,
-                                           unsigned short* cnt, unsigned* tot, unsigned* buf_out, int* keys_out, int* perm_out,
-                                           int w, int lane, int tid) {
+// one counting pass.  fetch(s) = this lane's word of step s of its wave's chunk (pass 1: built from the id in memory, pass 2:
+// read from the LDS buffer).  Both walks are ROLLED loops over groups of four steps with the next group's words requested
+// before the current group is processed (the fully unrolled form -- 32 steps x 2 walks x 2 passes with a 64-bit ballot mask per
+// digit bit -- spilled 15 k registers and ran 1.9 ms).
+template <bool TO_GLOBAL, int G, class Fetch>
+__device__ __forceinline__ void lsort_pass(Fetch fetch, int steps, int begin, int n, int shift, int ib, unsigned short* cnt,
+                                           unsigned* tot, unsigned* buf_out, int* keys_out, int* perm_out, int w, int lane, int tid) {
     unsigned short* my = cnt + w * 512;
     // zero this wave's counter row (512 x 2 bytes = 64 lanes x 16 bytes)
     reinterpret_cast<uint4*>(my)[lane] = make_uint4(0u, 0u, 0u, 0u);
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
+    unsigned cur[G], nxt[G];
 #pragma unroll
-    for (int s = 0; s < T4R_LSORT_STEPS; ++s) {
-        if (s < steps) {                                            // wave-uniform
-            const bool valid = begin + s * 64 + lane < n;
-            const unsigned d = ((word[s] >> ib) >> shift) & 511u;
-            const unsigned long long peers = lsort_match(d, valid);
-            if (valid && (peers & ((1ull << lane) - 1ull)) == 0ull) my[d] = (unsigned short)(my[d] + __popcll(peers));
+    for (int u = 0; u < G; ++u) cur[u] = fetch(min(u, steps - 1));
+#pragma unroll 1
+    for (int g0 = 0; g0 < steps; g0 += G) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) nxt[u] = fetch(min(g0 + G + u, steps - 1));
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const int st = g0 + u;
+            if (st < steps) {                                       // wave-uniform
+                const bool valid = begin + st * 64 + lane < n;
+                const unsigned d = ((cur[u] >> ib) >> shift) & 511u;
+                const unsigned long long peers = lsort_match(d, valid);
+                if (valid && (peers & ((1ull << lane) - 1ull)) == 0ull) my[d] = (unsigned short)(my[d] + __popcll(peers));
+            }
         }
+#pragma unroll
+        for (int u = 0; u < G; ++u) cur[u] = nxt[u];
     }
     __syncthreads();
     if (tid < 512) {                                                // exclusive prefix over the waves, per digit
@@ -106,23 +120,34 @@ __device__ __forceinline__ void lsort_pass(const unsigned (&word)[T4R_LSORT_STEP
     }
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < T4R_LSORT_STEPS; ++s) {
-        if (s < steps) {
-            const bool valid = begin + s * 64 + lane < n;
-            const unsigned d = ((word[s] >> ib) >> shift) & 511u;
-            const unsigned long long peers = lsort_match(d, valid);
-            const unsigned below = (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
-            const unsigned pos = valid ? tot[d] + my[d] + below : 0u;
-            if (valid) {
-                if (TO_GLOBAL) { keys_out[pos] = (int)(word[s] >> ib); perm_out[pos] = (int)(word[s] & ((1u << ib) - 1u)); }
-                else buf_out[pos] = word[s];
+    for (int u = 0; u < G; ++u) cur[u] = fetch(min(u, steps - 1));
+#pragma unroll 1
+    for (int g0 = 0; g0 < steps; g0 += G) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) nxt[u] = fetch(min(g0 + G + u, steps - 1));
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const int st = g0 + u;
+            if (st < steps) {
+                const bool valid = begin + st * 64 + lane < n;
+                const unsigned wd = cur[u];
+                const unsigned d = ((wd >> ib) >> shift) & 511u;
+                const unsigned long long peers = lsort_match(d, valid);
+                const unsigned below = (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
+                const unsigned pos = valid ? tot[d] + my[d] + below : 0u;
+                if (valid) {
+                    if (TO_GLOBAL) { keys_out[pos] = (int)(wd >> ib); perm_out[pos] = (int)(wd & ((1u << ib) - 1u)); }
+                    else buf_out[pos] = wd;
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);                 // every lane has read my[d] before its leader moves it on
+                __builtin_amdgcn_wave_barrier();
+                if (valid && below == 0u) my[d] = (unsigned short)(my[d] + __popcll(peers));
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_s_waitcnt(0xc07f);                     // every lane has read my[d] before its leader moves it on
-            __builtin_amdgcn_wave_barrier();
-            if (valid && below == 0u) my[d] = (unsigned short)(my[d] + __popcll(peers));
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
         }
+#pragma unroll
+        for (int u = 0; u < G; ++u) cur[u] = nxt[u];
     }
     __syncthreads();
 }
@@ -134,23 +159,15 @@ __device__ __forceinline__ void lsort_body(const long* __restrict__ ids, int n, 
     unsigned* buf = lsort_smem;                                           // [16 * chunk] words
     unsigned* tot = buf + 16 * chunk;                                     // [512]
     unsigned short* cnt = reinterpret_cast<unsigned short*>(tot + 512);   // [16][512]
-    unsigned word[T4R_LSORT_STEPS];
-#pragma unroll
-    for (int s = 0; s < T4R_LSORT_STEPS; ++s) {                           // one batch of loads (clamped addresses)
-        word[s] = 0u;
-        if (s < steps) {
-            const int i = min(begin + s * 64 + lane, n - 1);
-            const long id = ids[i];
-            const unsigned key = (id == padding_idx || id < 0 || id >= rows) ? (unsigned)rows : (unsigned)id;
-            word[s] = (key << ib) | (unsigned)i;
-        }
-    }
-    lsort_pass<false>(word, steps, begin, n, 0, ib, cnt, tot, buf, nullptr, nullptr, w, lane, tid);
-#pragma unroll
-    for (int s = 0; s < T4R_LSORT_STEPS; ++s)
-        if (s < steps) word[s] = buf[min(begin + s * 64 + lane, n - 1)];
-    __syncthreads();
-    lsort_pass<true>(word, steps, begin, n, 9, ib, cnt, tot, nullptr, keys_sorted, perm, w, lane, tid);
+    auto from_ids = [&](int st) -> unsigned {
+        const int i = min(begin + st * 64 + lane, n - 1);
+        const long id = ids[i];
+        const unsigned key = (id == padding_idx || id < 0 || id >= rows) ? (unsigned)rows : (unsigned)id;
+        return (key << ib) | (unsigned)i;
+    };
+    lsort_pass<false, 8>(from_ids, steps, begin, n, 0, ib, cnt, tot, buf, nullptr, nullptr, w, lane, tid);
+    auto from_lds = [&](int st) -> unsigned { return buf[min(begin + st * 64 + lane, n - 1)]; };
+    lsort_pass<true, 4>(from_lds, steps, begin, n, 9, ib, cnt, tot, nullptr, keys_sorted, perm, w, lane, tid);
 }
 __global__ __launch_bounds__(1024) void sort_ids_lds_kernel(const long* __restrict__ ids, int n, long rows, int padding_idx, int ib,
                                                              int* __restrict__ keys_sorted, int* __restrict__ perm) {

@@ -35,153 +35,11 @@ __global__ __launch_bounds__(256) void emb_keys_kernel(const long* __restrict__ 
     idx[i] = (int)i;
 }
 
-// ---------------------------------------------------------------------------------------------- one-launch LDS sort (round 6)
-// The (row id, lookup index) pairs of ONE workgroup-sized problem -- n <= 32 768 lookups, bits(rows) + bits(n - 1) <= 32: the
-// item table of BASELINE configs[1] (20 480 lookups of a 100 001-row table) -- sorted by ONE launch instead of hipCUB's eight
-// (key build + merge-sort passes, ~38 us on the caller's stream in front of every step's body): a pair is one 32-bit word
-// key << IB | index, kept in LDS; two stable counting passes over 9-bit digits of the key.
-//   * 16 waves, wave w owns the CONTIGUOUS chunk w of the current order (stable: the global order is wave-major), its words in
-//     registers (one batch of loads, no dependent chain);
-//   * counting: a wave walks its chunk 64 words at a time; lanes with the same digit find each other by nine wave ballots (one
-//     per digit bit), the lowest of them adds their number to the wave's OWN counter row cnt[w][digit] (no atomics);
-//   * one thread per digit turns the 16 rows into exclusive prefixes over the waves, one wave scans the 512 digit totals;
-//   * scatter: the same walk; position = digit base + this wave's running prefix + rank among the equal lanes of the step.
-// Pass 1 reads the ids from memory and scatters the words into LDS, pass 2 reads them in order from LDS and scatters
-// keys_sorted / perm to memory.  Same result as the stable library sort, bit for bit (both are THE stable order).
-#define T4R_LSORT_MAXN 32768
-#define T4R_LSORT_STEPS (T4R_LSORT_MAXN / 1024)          // 64-word steps of a wave's chunk at the largest n
-__device__ __forceinline__ unsigned long long lsort_match(unsigned d, bool valid) {
-    unsigned long long peers = __ballot(valid);
-#pragma unroll
-    for (int b = 0; b < 9; ++b) {
-        const bool bit = (d >> b) & 1u;
-        const unsigned long long m = __ballot(bit);
-        peers &= bit ? m : ~m;
-    }
-    return peers;
-}
-// one counting pass.  fetch(s) = this lane's word of step s of its wave's chunk (pass 1: built from the id in memory, pass 2:
-// read from the LDS buffer).  Both walks are ROLLED loops over groups of four steps with the next group's words requested
-// before the current group is processed (the fully unrolled form -- 32 steps x 2 walks x 2 passes with a 64-bit ballot mask per
-// digit bit -- spilled 15 k registers and ran 1.9 ms).
-template <bool TO_GLOBAL, int G, class Fetch>
-__device__ __forceinline__ void lsort_pass(Fetch fetch, int steps, int begin, int n, int shift, int ib, unsigned short* cnt,
-                                           unsigned* tot, unsigned* buf_out, int* keys_out, int* perm_out, int w, int lane, int tid) {
-    unsigned short* my = cnt + w * 512;
-    // zero this wave's counter row (512 x 2 bytes = 64 lanes x 16 bytes)
-    reinterpret_cast<uint4*>(my)[lane] = make_uint4(0u, 0u, 0u, 0u);
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    unsigned cur[G], nxt[G];
-#pragma unroll
-    for (int u = 0; u < G; ++u) cur[u] = fetch(min(u, steps - 1));
-#pragma unroll 1
-    for (int g0 = 0; g0 < steps; g0 += G) {
-#pragma unroll
-        for (int u = 0; u < G; ++u) nxt[u] = fetch(min(g0 + G + u, steps - 1));
-#pragma unroll
-        for (int u = 0; u < G; ++u) {
-            const int st = g0 + u;
-            if (st < steps) {                                       // wave-uniform
-                const bool valid = begin + st * 64 + lane < n;
-                const unsigned d = ((cur[u] >> ib) >> shift) & 511u;
-                const unsigned long long peers = lsort_match(d, valid);
-                if (valid && (peers & ((1ull << lane) - 1ull)) == 0ull) my[d] = (unsigned short)(my[d] + __popcll(peers));
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < G; ++u) cur[u] = nxt[u];
-    }
-    __syncthreads();
-    if (tid < 512) {                                                // exclusive prefix over the waves, per digit
-        unsigned run = 0;
-#pragma unroll
-        for (int ww = 0; ww < 16; ++ww) {
-            const unsigned c = cnt[ww * 512 + tid];
-            cnt[ww * 512 + tid] = (unsigned short)run;
-            run += c;
-        }
-        tot[tid] = run;
-    }
-    __syncthreads();
-    if (w == 0) {                                                   // exclusive scan of the 512 totals: 8 per lane + wave scan
-        unsigned loc[8], sum = 0;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { loc[e] = tot[lane * 8 + e]; sum += loc[e]; }
-        unsigned inc = sum;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned up = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += up;
-        }
-        unsigned run = inc - sum;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { tot[lane * 8 + e] = run; run += loc[e]; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < G; ++u) cur[u] = fetch(min(u, steps - 1));
-#pragma unroll 1
-    for (int g0 = 0; g0 < steps; g0 += G) {
-#pragma unroll
-        for (int u = 0; u < G; ++u) nxt[u] = fetch(min(g0 + G + u, steps - 1));
-#pragma unroll
-        for (int u = 0; u < G; ++u) {
-            const int st = g0 + u;
-            if (st < steps) {
-                const bool valid = begin + st * 64 + lane < n;
-                const unsigned wd = cur[u];
-                const unsigned d = ((wd >> ib) >> shift) & 511u;
-                const unsigned long long peers = lsort_match(d, valid);
-                const unsigned below = (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
-                const unsigned pos = valid ? tot[d] + my[d] + below : 0u;
-                if (valid) {
-                    if (TO_GLOBAL) { keys_out[pos] = (int)(wd >> ib); perm_out[pos] = (int)(wd & ((1u << ib) - 1u)); }
-                    else buf_out[pos] = wd;
-                }
-                __builtin_amdgcn_s_waitcnt(0xc07f);                 // every lane has read my[d] before its leader moves it on
-                __builtin_amdgcn_wave_barrier();
-                if (valid && below == 0u) my[d] = (unsigned short)(my[d] + __popcll(peers));
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < G; ++u) cur[u] = nxt[u];
-    }
-    __syncthreads();
-}
-__device__ __forceinline__ void lsort_body(const long* __restrict__ ids, int n, long rows, int padding_idx, int ib,
-                                           int* __restrict__ keys_sorted, int* __restrict__ perm) {
-    extern __shared__ unsigned lsort_smem[];
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int chunk = (((n + 15) / 16) + 63) / 64 * 64, steps = chunk / 64, begin = w * chunk;
-    unsigned* buf = lsort_smem;                                           // [16 * chunk] words
-    unsigned* tot = buf + 16 * chunk;                                     // [512]
-    unsigned short* cnt = reinterpret_cast<unsigned short*>(tot + 512);   // [16][512]
-    auto from_ids = [&](int st) -> unsigned {
-        const int i = min(begin + st * 64 + lane, n - 1);
-        const long id = ids[i];
-        const unsigned key = (id == padding_idx || id < 0 || id >= rows) ? (unsigned)rows : (unsigned)id;
-        return (key << ib) | (unsigned)i;
-    };
-    lsort_pass<false, 8>(from_ids, steps, begin, n, 0, ib, cnt, tot, buf, nullptr, nullptr, w, lane, tid);
-    auto from_lds = [&](int st) -> unsigned { return buf[min(begin + st * 64 + lane, n - 1)]; };
-    lsort_pass<true, 4>(from_lds, steps, begin, n, 9, ib, cnt, tot, nullptr, keys_sorted, perm, w, lane, tid);
-}
-__global__ __launch_bounds__(1024) void sort_ids_lds_kernel(const long* __restrict__ ids, int n, long rows, int padding_idx, int ib,
-                                                             int* __restrict__ keys_sorted, int* __restrict__ perm) {
-    lsort_body(ids, n, rows, padding_idx, ib, keys_sorted, perm);
-}
-// does the one-launch sort take this problem?  (key bits <= 18: two 9-bit passes; a word holds key and index)
-static int lsort_index_bits(long n, long rows) {
-    if (n < 1 || n > T4R_LSORT_MAXN || rows < 1 || rows >= (1L << 18)) return 0;
-    int ib = 1, kb = 1;
-    while ((1L << ib) < n) ++ib;
-    while ((1L << kb) <= rows) ++kb;
-    return ib + kb <= 32 ? ib : 0;
-}
-
+// (Round 6 built a one-launch LDS radix sort for workgroup-sized problems -- key << IB | index words in LDS, two stable 9-bit
+// counting passes, equal digits matched by wave ballots, per-wave counter rows, no atomics: bit-identical to the library sort
+// in tests -- and measured it at 70 us per launch against the 38 us of the library's eight launches: ONE workgroup is one CU,
+// and 20 480 words x 4 walks x ~45 instructions per 64 words is ~190 k issue cycles on its four SIMDs whatever the LDS does.
+// Removed again; a multi-workgroup form needs the grid-wide passes the library already has.  DESIGN.md section 4.3.)
 struct SortLayout { size_t keys_in, idx_in, tmp, tmp_bytes, total; };
 static SortLayout sort_layout(long n) {
     SortLayout l;
@@ -210,15 +68,6 @@ extern "C" int t4r_sort_ids(void* stream, const long* ids, long n, long rows, in
     const SortLayout l = sort_layout(n);
     T4R_CHECK_ARG(ws_bytes >= (long)l.total, "sort_ids: workspace too small (t4r_sort_ids_ws_bytes)");
     hipStream_t st = (hipStream_t)stream;
-    if (const int ib = lsort_index_bits(n, rows)) {        // one launch, words in LDS (no workspace used)
-        const int chunk = (int)((((n + 15) / 16) + 63) / 64 * 64);
-        const size_t smem = (size_t)16 * chunk * 4 + 512 * 4 + 16 * 512 * 2;
-        static T4rLdsAttr attr;
-        t4r_ensure_dynamic_lds((const void*)sort_ids_lds_kernel, smem, attr);
-        hipLaunchKernelGGL(sort_ids_lds_kernel, dim3(1), dim3(1024), smem, st, ids, (int)n, rows, padding_idx, ib, keys_sorted, perm);
-        T4R_LAUNCH_CHECK();
-        return 0;
-    }
     char* w = (char*)ws;
     int* keys_in = (int*)(w + l.keys_in);
     int* idx_in = (int*)(w + l.idx_in);
@@ -245,11 +94,6 @@ extern "C" int t4r_sort_ids(void* stream, const long* ids, long n, long rows, in
 constexpr int kSortMaxFeatures = 16;
 struct SortMulti { const long* ids[kSortMaxFeatures]; long rows[kSortMaxFeatures]; long off[kSortMaxFeatures]; int pad[kSortMaxFeatures]; int F; long n; };
 
-// one workgroup per table: the F sorts of an input block run side by side in ONE launch (round 6; every table one-workgroup sized)
-__global__ __launch_bounds__(1024) void sort_ids_lds_multi_kernel(SortMulti p, int ib, int* __restrict__ keys, int* __restrict__ perm) {
-    const int f = blockIdx.x;
-    lsort_body(p.ids[f], (int)p.n, p.rows[f], p.pad[f], ib, keys + (long)f * p.n, perm + (long)f * p.n);
-}
 __global__ __launch_bounds__(256) void emb_keys_multi_kernel(SortMulti p, int* __restrict__ keys, int* __restrict__ idx) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.n * p.F) return;
@@ -289,20 +133,6 @@ extern "C" int t4r_sort_ids_multi(void* stream, const long* const* ids, int F, l
     const SortLayout l = sort_layout(n * F);
     T4R_CHECK_ARG(ws_bytes >= (long)l.total, "sort_ids_multi: workspace too small (t4r_sort_ids_multi_ws_bytes)");
     hipStream_t st = (hipStream_t)stream;
-    {
-        int ib = lsort_index_bits(n, rows[0]);
-        for (int f = 1; f < F && ib; ++f)
-            if (lsort_index_bits(n, rows[f]) != ib) ib = 0;        // (the index bits depend on n only; 0 = a table does not fit)
-        if (ib) {       // every table is a one-workgroup problem: F workgroups, one launch, no workspace
-            const int chunk = (int)((((n + 15) / 16) + 63) / 64 * 64);
-            const size_t smem = (size_t)16 * chunk * 4 + 512 * 4 + 16 * 512 * 2;
-            static T4rLdsAttr attr;
-            t4r_ensure_dynamic_lds((const void*)sort_ids_lds_multi_kernel, smem, attr);
-            hipLaunchKernelGGL(sort_ids_lds_multi_kernel, dim3(F), dim3(1024), smem, st, p, ib, keys_sorted, perm);
-            T4R_LAUNCH_CHECK();
-            return 0;
-        }
-    }
     char* w = (char*)ws;
     int* keys_in = (int*)(w + l.keys_in);
     int* idx_in = (int*)(w + l.idx_in);

@@ -277,6 +277,10 @@ int t4r_head_split_dx(void* stream, void* ws, const float* logits, long ld, cons
  * labels == NULL: the dominant kernel alone on a workspace a full call has filled (bench.py's roofline timing).
  * t4r_head_split_fdx_supported: 1 when this form takes the width (two-way fp16 products on; T4R_HEAD_FDX=0 switches it off). */
 int t4r_head_split_fdx_supported(int D);
+/* The next t4r_head_split_logits_ce_dx of this thread ON TABLE W takes max |W| from part[0 .. n) -- the per-workgroup maxima
+ * t4r_adam_step_amax left over exactly W's elements; the caller promises that nothing has written W since -- instead of a memset
+ * + a pass over the table.  Consumed by that call. */
+void t4r_head_split_w_amax_hint(const float* W, const float* part, int n);
 int t4r_head_split_logits_ce_dx(void* stream, void* ws, const float* X, long ldx, const float* W, long ldw, float* C, long ldc,
                                 const long* labels, float* loss_rows, float* lse, float* loss_mean, float* dX, long lddx,
                                 const float* wsum, int N, int V, int D, float alpha, float label_smoothing, void* note);
@@ -622,6 +626,12 @@ int t4r_seq_sum_cols(void* stream, const float* wide, long ldw, int col, float* 
 int t4r_adam_step(void* stream, float* param, float* grad, float* exp_avg, float* exp_avg_sq, long n,
                   int step, float lr, float beta1, float beta2, float eps, float weight_decay,
                   float grad_scale, int zero_grad);
+/* the same step that also leaves amax_part[b] = max |param[i]| AFTER the update over i in [amax_lo, amax_hi) seen by workgroup b;
+ * returns the number of workgroups (<= 1024: the capacity amax_part must have) or < 0.  With t4r_head_split_w_amax_hint it
+ * replaces the memset + 21 us pass over the tied item table in front of every step's head (round 6). */
+int t4r_adam_step_amax(void* stream, float* param, float* grad, float* exp_avg, float* exp_avg_sq, long n, int step, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, float grad_scale, int zero_grad, long amax_lo,
+                       long amax_hi, float* amax_part);
 
 #ifdef __cplusplus
 }

@@ -80,6 +80,8 @@ _ALLOWED_FILE_SCOPE_STATE = {
     "g_ff_amax": "thread-local, set and cleared inside one layer call",
     "g_ff_final_ctr": "thread-local, set and cleared inside one layer call (key of the fused model-level output dropout)",
     "g_ff_final_on": "same",
+    "g_w_amax_part": "thread-local, set by t4r_head_split_w_amax_hint and consumed (cleared) by the next t4r_head_split_logits_ce_dx",
+    "g_w_amax_W": "same", "g_w_amax_n": "same",
     "g_ab_in_on": "thread-local, set and cleared inside one layer call (fused model-level input dropout of the first layer)",
     "g_ab_in_ctr": "same", "g_ab_hin": "same", "g_dh_in_on": "same", "g_dh_in_p": "same", "g_dh_in_seed": "same", "g_dh_in_ctr": "same",
     "g_red_side": "thread-local, set and cleared inside one layer call (reduction side stream)",

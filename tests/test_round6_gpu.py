@@ -320,3 +320,65 @@ def test_input_dropout_fused_into_the_first_layer(ops, B, L, D, n):
     out2, ws2 = ops.xlnet_layer_fwd(h, pos, params, B, L, n, 0.03, layer_idx=both, **kw)
     ctr_fin = ops.dropout_ctr_hi(offset, 255, ops.SITE_FINAL)
     assert torch.equal(out2, ops.dropout(out0.view(-1), p_drop, seed, ctr_fin).view(B * L, D))
+
+
+def test_table_maximum_from_the_optimizer_launch(ops):
+    """FusedAdam leaves the per-workgroup maxima of the tied item table in its launch (t4r_adam_step_amax); the next step's head
+    takes max |W| from them (t4r_head_split_w_amax_hint) instead of a memset + a pass over the table: same bits in logits, loss
+    and d X; the hint is dropped as soon as anything else writes the table."""
+    import transformers4rec_amd as tr
+
+    B, L, V, D = 256, 20, 30_000, 128
+    schema = tr.session_schema(V, L)
+    torch.manual_seed(0)
+    inputs = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=L, masking="mlm", embedding_dim_default=D)
+    model = tr.XLNetConfig.build(D, 4, 2, total_seq_length=L, dropout=0.0).to_torch_model(
+        inputs, tr.NextItemPredictionTask(weight_tying=True)).to(DEV).train()
+    dense, tables = tr.flatten_model(model)
+    opt = tr.FusedAdam([dense, tables], lr=1e-2)
+    W = model.input_features.item_embedding_table.weight
+    assert ops.w_amax_of(W) is None
+    x = {"item_id": tr.random_data_from_schema(schema, B, L, seed=3)["item_id"].to(DEV)}
+    model(x, training=True)["loss"].backward()
+    opt.step()
+    rec = ops.w_amax_of(W)
+    assert rec is not None
+    part, n = rec
+    assert 1 <= n <= 1024 and float(part[:n].max()) == float(W.detach().abs().max())
+    # the head with and without the hint: bit-identical
+    N = 700
+    g = torch.Generator(device=DEV).manual_seed(1)
+    xr = torch.randn(N, D, device=DEV, generator=g)
+    lab = torch.randint(1, V + 1, (N,), device=DEV, generator=g)
+    outs = []
+    for hint in (None, rec):
+        ws = ops.head_split_prepare(xr, V + 1)
+        outs.append(ops.head_split_logits_ce_dx(ws, xr, W.detach(), lab, ldc=ops.pad_ld(V + 1), w_amax=hint))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    # a training step that uses the hint == the same step without it (fresh model, same seeds)
+    def two_steps(use_hint):
+        torch.manual_seed(0)
+        inp = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=L, masking="mlm", embedding_dim_default=D)
+        mdl = tr.XLNetConfig.build(D, 4, 2, total_seq_length=L, dropout=0.0).to_torch_model(
+            inp, tr.NextItemPredictionTask(weight_tying=True)).to(DEV).train()
+        mdl.input_features.masking.seed = 5
+        dn, tb = tr.flatten_model(mdl)
+        o = tr.FusedAdam([dn, tb], lr=1e-2)
+        if not use_hint:
+            o._amax_targets = [None for _ in o._amax_targets]
+        losses = []
+        for _ in range(3):
+            out = mdl(x, training=True)
+            out["loss"].backward()
+            o.step()
+            losses.append(float(out["loss"].detach()))
+        return losses, tb.data.clone()
+
+    la, ta = two_steps(True)
+    lb, tb_ = two_steps(False)
+    assert la == lb and torch.equal(ta, tb_)
+    # anything else writing the table invalidates the hint
+    with torch.no_grad():
+        W.mul_(1.0)
+    assert ops.w_amax_of(W) is None

@@ -134,6 +134,8 @@ _SIGS = {
     "t4r_copy_cols": ("i", "pp" + "li" + "p" + "ili"),
     "t4r_seq_sum_cols": ("i", "pp" + "li" + "p" + "ili"),
     "t4r_adam_step": ("i", "ppppp" + "li" + "ffffff" + "i"),
+    "t4r_adam_step_amax": ("i", "ppppp" + "li" + "ffffff" + "i" + "llp"),
+    "t4r_head_split_w_amax_hint": ("v", "ppi"),
 }
 
 _lib = None

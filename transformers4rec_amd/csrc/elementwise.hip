@@ -583,11 +583,18 @@ extern "C" int t4r_add_pos_bwd(void* stream, const float* dy, float* d_pos, int 
 //   g = grad (+ wd * p) ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2
 //   p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 // grad_scale multiplies grad first (1/world_size for the DP mean).  Optionally zeroes the grad.
+// AMAX (round 6): the launch also leaves, per workgroup, the largest |p| AFTER the update among the elements [amax_lo, amax_hi)
+// in amax_part[blockIdx.x] -- the tied item table's maximum, which the next step's head needs to position its fp16 images
+// (csrc/head_split.hip: split_w_images_kernel reduces the <= 1024 partials) and used to get from a memset + a 21 us pass over
+// the 51 MB the optimizer has just streamed.  Plain stores, one slot per workgroup (same-address atomics serialise).
+template <bool AMAX>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v,
                                                     long n, float lr, float b1, float b2, float eps,
                                                     float wd, float bc1, float bc2_sqrt,
-                                                    float grad_scale, int zero_grad) {
+                                                    float grad_scale, int zero_grad, long amax_lo, long amax_hi,
+                                                    float* __restrict__ amax_part) {
+    float mx = 0.f;
     const long stride = (long)gridDim.x * blockDim.x * 4;
     for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
         if (i + 4 <= n) {
@@ -603,6 +610,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                 V[e] = b2 * V[e] + (1.f - b2) * gr * gr;
                 const float denom = sqrtf(V[e]) / bc2_sqrt + eps;
                 P[e] -= (lr / bc1) * (M[e] / denom);
+                if (AMAX && i + e >= amax_lo && i + e < amax_hi) mx = fmaxf(mx, fabsf(P[e]));
             }
             *reinterpret_cast<float4*>(p + i) = pp;
             *reinterpret_cast<float4*>(m + i) = mm;
@@ -615,9 +623,17 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                 v[j] = b2 * v[j] + (1.f - b2) * gr * gr;
                 const float denom = sqrtf(v[j]) / bc2_sqrt + eps;
                 p[j] -= (lr / bc1) * (m[j] / denom);
+                if (AMAX && j >= amax_lo && j < amax_hi) mx = fmaxf(mx, fabsf(p[j]));
                 if (zero_grad) g[j] = 0.f;
             }
         }
+    }
+    if (AMAX) {
+        __shared__ float sh[4];
+        mx = wave_max(mx);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) amax_part[blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
     }
 }
 
@@ -633,9 +649,32 @@ extern "C" int t4r_adam_step(void* stream, float* param, float* grad, float* exp
     long blocks = (n / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param,
+    hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param,
                        grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s,
-                       grad_scale, zero_grad);
+                       grad_scale, zero_grad, 0L, 0L, nullptr);
     T4R_LAUNCH_CHECK();
     return 0;
+}
+// the same step; also amax_part[b] = max |param[i]| after the update over i in [amax_lo, amax_hi) seen by workgroup b, for
+// b < the returned number of workgroups (<= 1024 = the capacity the caller provides); < 0: error
+extern "C" int t4r_adam_step_amax(void* stream, float* param, float* grad, float* exp_avg, float* exp_avg_sq, long n, int step,
+                                  float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                                  int zero_grad, long amax_lo, long amax_hi, float* amax_part) {
+    if (n <= 0) return 0;
+    if (!(step >= 1)) { t4r_set_error("adam: step is 1-based"); return -1; }
+    if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 != 0 || !amax_part ||
+        amax_lo < 0 || amax_hi > n || amax_lo >= amax_hi) {
+        t4r_set_error("adam_step_amax: buffers must be 16-byte aligned, the range inside the buffer, amax_part non-null");
+        return -1;
+    }
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                       exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, zero_grad, amax_lo, amax_hi,
+                       amax_part);
+    if (hipGetLastError() != hipSuccess) { t4r_set_error("adam_step_amax: launch failed"); return -1; }
+    return (int)blocks;
 }

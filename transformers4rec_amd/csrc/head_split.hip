@@ -1479,11 +1479,32 @@ __global__ __launch_bounds__(256) void head_fdx_finalize_kernel(const float* __r
 }
 
 // both images of the table the one-pass forward streams (MK: A operand of the scores; KMP: A operand of d X), one launch
+// amax_part (round 6, optional): the table's maximum arrives as <= 1024 per-workgroup partials the optimizer left behind
+// (t4r_adam_step_amax) instead of in *amax: every workgroup reduces them (4 KB of L2 hits), workgroup (0, 0) stores the result
+// where the later kernels of the head read it
 template <int NB>
 __global__ __launch_bounds__(256) void split_w_images_kernel(const float* __restrict__ src, long ld, int n_rows,
                                                               u32x4* __restrict__ wa, u32x4* __restrict__ wtp,
-                                                              const unsigned* __restrict__ amax) {
+                                                              unsigned* amax_word, const float* __restrict__ amax_part,
+                                                              int n_part) {
     constexpr int D = 32 * NB;
+    __shared__ unsigned sh_bits;
+    __shared__ float sh_red[4];
+    const unsigned* amax = amax_word;
+    if (amax_part) {                 // workgroup-uniform
+        float mx = 0.f;
+        for (int i = threadIdx.x; i < n_part; i += 256) mx = fmaxf(mx, amax_part[i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if ((threadIdx.x & 63) == 0) sh_red[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            sh_bits = __float_as_uint(fmaxf(fmaxf(sh_red[0], sh_red[1]), fmaxf(sh_red[2], sh_red[3])));
+            if (blockIdx.x == 0 && blockIdx.y == 0) *amax_word = sh_bits;
+        }
+        __syncthreads();
+        amax = &sh_bits;
+    }
     const int b = blockIdx.x;
     if (blockIdx.y == 0) { split_mk_body<NB, true>(b, src, ld, n_rows, wa, amax); return; }
     const float scale = scale_of(amax);
@@ -1897,6 +1918,15 @@ extern "C" int t4r_head_split_dx_rc(void* stream, void* ws, const float* X, long
 // dX [N, D] = d (mean loss) / d X for grad_out = 1 -- the caller's backward multiplies by its upstream gradient and runs only
 // t4r_head_split_dw (same workspace and note).  X: the rows t4r_head_split_prepare was given.  wsum: column sums of W [D]
 // (needed when label_smoothing > 0, else NULL).
+// The next t4r_head_split_logits_ce_dx of this thread on table W takes max |W| from `part[0 .. n)` (per-workgroup maxima written by
+// t4r_adam_step_amax over exactly W's elements, AFTER which nothing else has written W -- the caller's promise) instead of
+// computing it.  Consumed (cleared) by that call, whatever table it is given.
+static thread_local const float* g_w_amax_part = nullptr;
+static thread_local const float* g_w_amax_W = nullptr;
+static thread_local int g_w_amax_n = 0;
+extern "C" void t4r_head_split_w_amax_hint(const float* W, const float* part, int n) {
+    g_w_amax_W = (part && n > 0) ? W : nullptr; g_w_amax_part = g_w_amax_W ? part : nullptr; g_w_amax_n = g_w_amax_W ? n : 0;
+}
 extern "C" int t4r_head_split_fdx_supported(int D) { return t4r_head_split_supported(D) && head_fdx_on(); }
 extern "C" int t4r_head_split_logits_ce_dx(void* stream, void* ws, const float* X, long ldx, const float* W, long ldw, float* C,
                                            long ldc, const long* labels, float* loss_rows, float* lse, float* loss_mean,
@@ -1914,11 +1944,17 @@ extern "C" int t4r_head_split_logits_ce_dx(void* stream, void* ws, const float* 
     T4R_CHECK_ARG(label_smoothing <= 0.f || wsum, "head_split_logits_ce_dx: label smoothing needs the column sums of W");
     const HeadWs w = head_ws(N, V, D);
     unsigned* amax = reinterpret_cast<unsigned*>((char*)ws + w.scales);
-    if (!kernel_only && head_w_amax(st, W, ldw, V, D, amax + 1)) return -1;
+    // the table's maximum: from the optimizer's partials when the caller announced them for THIS table (t4r_head_split_w_amax_hint,
+    // consumed here), else a memset + a pass over the table
+    const float* w_part = g_w_amax_W == W ? g_w_amax_part : nullptr;
+    const int w_npart = g_w_amax_n;
+    g_w_amax_part = nullptr; g_w_amax_W = nullptr; g_w_amax_n = 0;
+    if (!kernel_only && !w_part && head_w_amax(st, W, ldw, V, D, amax + 1)) return -1;
     u32x4* wa = reinterpret_cast<u32x4*>((char*)ws + w.wa);
     u32x4* wtp = reinterpret_cast<u32x4*>((char*)ws + w.wt);
     if (!kernel_only)
-        T4R_NB_SWITCH(D, hipLaunchKernelGGL(split_w_images_kernel<NB>, dim3(w.nkt, 2), dim3(256), 0, st, W, ldw, V, wa, wtp, amax + 1));
+        T4R_NB_SWITCH(D, hipLaunchKernelGGL(split_w_images_kernel<NB>, dim3(w.nkt, 2), dim3(256), 0, st, W, ldw, V, wa, wtp, amax + 1,
+                                            w_part, w_npart));
     const int row_tiles = (N + 127) / 128;
     // one residency of the chip: two 256-thread workgroups per CU (66 KB of LDS each), every workgroup the same number of tiles
     static int target = -1;

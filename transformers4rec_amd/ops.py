@@ -228,7 +228,7 @@ def head_split_fdx_supported(D):
     return bool(_lib.load().t4r_head_split_fdx_supported(int(D)))
 
 
-def head_split_logits_ce_dx(ws, x, W, labels, alpha=1.0, label_smoothing=0.0, ldc=None):
+def head_split_logits_ce_dx(ws, x, W, labels, alpha=1.0, label_smoothing=0.0, ldc=None, w_amax=None):
     """the one-pass forward (csrc/head_split.hip: head_fwd_dx_kernel): logits [N, V] (view of an [N, ldc] buffer), mean loss,
     loss rows, lse AND dx_unit [N, D] = d (mean loss) / d x for an upstream gradient of 1 -- the backward is dx_unit * grad_out
     plus head_split_dw on the same workspace; the logits are never read for d X"""
@@ -245,6 +245,8 @@ def head_split_logits_ce_dx(ws, x, W, labels, alpha=1.0, label_smoothing=0.0, ld
     if label_smoothing > 0:
         wsum = torch.zeros(D, device=dev, dtype=torch.float32)
         colsum_(W, wsum)
+    if w_amax is not None:      # (partials, n) of ops.w_amax_of(the table's Parameter): max |W| without a pass over W
+        _lib.load().t4r_head_split_w_amax_hint(_chk(W, torch.float32), _chk(w_amax[0], torch.float32), int(w_amax[1]))
     call("t4r_head_split_logits_ce_dx", _stream(), ws.data_ptr(), _chk(x, torch.float32), x.stride(0), _chk(W, torch.float32),
          W.stride(0), buf.data_ptr(), ldc, _chk(labels, torch.int64), loss_rows.data_ptr(), lse.data_ptr(), loss.data_ptr(),
          dx.data_ptr(), dx.stride(0), _p(wsum), N, V, D, float(alpha), float(label_smoothing), _note(ws))
@@ -1109,6 +1111,31 @@ def rank_of_target(x, W, labels, alpha=1.0, chunk=1024):
              _chk(W, torch.float32), W.stride(0), _chk(tgt, torch.float32), _chk(yc, torch.int64),
              rank[s0: s0 + chunk].data_ptr())
     return rank
+
+
+def adam_step_amax_(param, grad, exp_avg, exp_avg_sq, step, lo, hi, part, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                    weight_decay=0.0, grad_scale=1.0, zero_grad=True):
+    """adam_step_ that also leaves the per-workgroup maxima of |param[lo:hi]| after the update in part[:n]; -> n"""
+    lib = _lib.load()
+    n = lib.t4r_adam_step_amax(_stream(), _chk(param, torch.float32), _chk(grad, torch.float32), _chk(exp_avg),
+                               _chk(exp_avg_sq), param.numel(), int(step), float(lr), float(betas[0]), float(betas[1]),
+                               float(eps), float(weight_decay), float(grad_scale), int(zero_grad), int(lo), int(hi),
+                               _chk(part, torch.float32))
+    if n < 0:
+        raise _lib.T4RHipError(lib.t4r_last_error().decode())
+    return n
+
+
+def w_amax_of(W):
+    """(partials, n) the optimizer left for parameter W (optim.FusedAdam: the maximum of the tied item table comes out of the
+    Adam launch) if NOTHING has written W since -- same storage, same version counters -- else None"""
+    rec = getattr(W, "_t4r_w_amax", None)
+    if rec is None:
+        return None
+    part, n, ptr, v_param, flat, v_flat = rec
+    if W.data_ptr() != ptr or W._version != v_param or flat._version != v_flat or not W.is_contiguous():
+        return None
+    return part, n
 
 
 def adam_step_(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,

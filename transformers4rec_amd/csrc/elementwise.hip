@@ -670,7 +670,7 @@ extern "C" int t4r_adam_step_amax(void* stream, float* param, float* grad, float
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
     long blocks = (n / 4 + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 512) blocks = 512;      // (the consumer reduces the partials in every workgroup: 512 x 4 bytes)
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                        exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, zero_grad, amax_lo, amax_hi,

@@ -1439,7 +1439,7 @@ def main():
                 # (configs[2]'s wider input block leaves the initial loss plateau later: 600 steps put its probe into the
                 #  same informative regime as configs[1]'s 200)
                 res["recall_at_20"] = recall_probe(device, args.dropout, config=args.config,
-                                                   train_steps=RECALL_TRAIN_STEPS if args.config == "c2" else 3 * RECALL_TRAIN_STEPS)
+                                                   train_steps=RECALL_TRAIN_STEPS if args.config == "c2" else 5 * RECALL_TRAIN_STEPS)
             except Exception as exc:      # noqa: BLE001 - never lose the throughput line to the metric probe
                 res["recall_at_20"] = {"error": f"{type(exc).__name__}: {exc}"}
         if not args.no_cpu_baseline and world == 1:

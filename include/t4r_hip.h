@@ -531,6 +531,11 @@ int t4r_xlnet_layer_bwd(void* stream, const float* h, const float* pos_emb, cons
 int t4r_xlnet_layer_ws_offsets(int B, int L, int D, int n_head, int dropout, long* planes_off, long* kr_off);
 int t4r_xlnet_stack_prepare(void* stream, const float* const* params_all, int n_layers, int D, float* const* planes,
                             const float* pos, long pos_rows, float* const* kr);
+/* The next t4r_xlnet_stack_prepare of this thread makes the dropped positional rows of a TRAINING forward itself: it is then
+ * given the plain [period, D] encoding as `pos` with pos_rows = B x period, masks row t = pos[t % period] with the pos_emb
+ * dropout keyed (seed, ctr) (HF modeling_xlnet.py:1143) inside the projection kernel and writes the dropped rows to out
+ * [pos_rows, D] -- the tensor the layers' backward takes as pos_emb_b.  Replaces a t4r_dropout launch in front of the call. */
+void t4r_xlnet_stack_pos_dropout(float p, unsigned long long seed, unsigned long long ctr, long period, float* out);
 void t4r_xlnet_stack_prepared(int on);
 
 /* Deferred join of the layer backward's weight-gradient streams (csrc/xlnet_layer.hip).  After

@@ -80,6 +80,7 @@ _ALLOWED_FILE_SCOPE_STATE = {
     "g_ff_amax": "thread-local, set and cleared inside one layer call",
     "g_ff_final_ctr": "thread-local, set and cleared inside one layer call (key of the fused model-level output dropout)",
     "g_ff_final_on": "same",
+    "g_stack_gen": "thread-local, set by t4r_xlnet_stack_pos_dropout and consumed (cleared) by the next t4r_xlnet_stack_prepare",
     "g_w_amax_part": "thread-local, set by t4r_head_split_w_amax_hint and consumed (cleared) by the next t4r_head_split_logits_ce_dx",
     "g_w_amax_W": "same", "g_w_amax_n": "same",
     "g_ab_in_on": "thread-local, set and cleared inside one layer call (fused model-level input dropout of the first layer)",

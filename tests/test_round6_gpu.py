@@ -384,3 +384,38 @@ def test_table_maximum_from_the_optimizer_launch(ops):
     with torch.no_grad():
         W.mul_(1.0)
     assert ops.w_amax_of(W) is None
+
+
+@pytest.mark.parametrize("switch", ["_GEN_POS", "_FUSE_INPUT", "_FUSE_FINAL"])
+def test_model_level_dropout_fusions_do_not_change_the_step(ops, switch, monkeypatch):
+    """the three model-level dropout sites of HF XLNetModel (input :1116, pos_emb :1143, output :1177) ride inside the stack's own
+    kernels (first layer, stack prologue, last layer); with each fusion switched off the element-wise launches run instead: same
+    hidden states, same gradients, bit for bit"""
+    import transformers4rec_amd as tr
+    from transformers4rec_amd import transformer as T
+
+    B, L, D = 96, 20, 128
+    torch.manual_seed(0)
+    xl = tr.XLNetConfig.build(D, 4, 3, total_seq_length=L, dropout=0.3).to_huggingface_torch_model().to(DEV).train()
+    xl.seed = 99
+    x = torch.randn(B, L, D, device=DEV)
+    dout = torch.randn(B, L, D, device=DEV)
+
+    def run(on):
+        monkeypatch.setattr(T, switch, on)
+        xl._drop_offset = 0
+        for p in xl.parameters():
+            p.grad = None
+        xin = x.clone().requires_grad_()
+        (h,) = xl(inputs_embeds=xin)
+        h.backward(dout)
+        torch.cuda.synchronize()
+        return h.detach().clone(), xin.grad.clone(), {n: p.grad.clone() for n, p in xl.named_parameters() if p.grad is not None}
+
+    h1, g1, p1 = run(True)
+    h0, g0, p0 = run(False)
+    assert float((h1 == 0).float().mean()) > 0.25 and float((g1 == 0).float().mean()) > 0.25
+    assert torch.equal(h1, h0) and torch.equal(g1, g0)
+    assert p1.keys() == p0.keys() and len(p1) >= 3 * 13
+    for n in p1:
+        assert torch.equal(p1[n], p0[n]), n

@@ -108,6 +108,7 @@ _SIGS = {
     "t4r_xlnet_layer_bwd_defer": ("v", "i"),
     "t4r_xlnet_layer_ws_offsets": ("i", "iiiii" + "pp"),
     "t4r_xlnet_stack_prepare": ("i", "ppiip" + "plp"),
+    "t4r_xlnet_stack_pos_dropout": ("v", "fQQlp"),
     "t4r_xlnet_stack_prepared": ("v", "i"),
     "t4r_xlnet_layer_bwd_join": ("i", "p"),
     "t4r_xlnet_ff_planes_floats": ("l", "i"),

@@ -309,15 +309,28 @@ __device__ __forceinline__ void tile_to_planes(const float* __restrict__ src, lo
 // -> [2^13, 2^14)): rows of very different magnitude in one tile (gradient rows) keep their full 22 bits each.
 // sh_inv[row] = 1 / scale (exact), multiplied back in the product's epilogue.  The D / 4 threads of a row are consecutive
 // lanes of one wave (D / 4 <= 32).
+// `gen` (round 6, the positional keys of a training forward): the rows are not read from src but MADE here -- row t =
+// base[t % period] (the [2L, D] positional encoding, cache resident) times the pos_emb dropout mask of element (t, c) (HF
+// modeling_xlnet.py:1143: one mask per session, drawn once per forward) -- and written to gen->out [T, D] for the backward's d r
+// contraction: the separate element-wise launch that materialised them (and this kernel's 21 MB read of its result) are gone.
+struct GenRows { const float* base; long period; DropCfg drop; float* out; };
 template <int D, int RT, int NT, int PH>
 __device__ __forceinline__ void tile_to_planes_h(const float* __restrict__ src, long t0, long T, uint16_t* sh, float* sh_inv,
-                                                 int tid) {
+                                                 int tid, const GenRows* gen = nullptr) {
     constexpr int PLN = RT * PH, G = D / 4;
     for (int i = tid; i < ((RT * G + NT - 1) / NT) * NT; i += NT) {      // whole waves stay in the loop: the shuffles need their partners
         const bool live = i < RT * G;
         const int row = live ? i / G : RT - 1, c4 = live ? (i % G) * 4 : 0;
         const long t = min(t0 + row, T - 1);
-        const float4 v = ld4(src + t * D + c4);
+        float4 v;
+        if (gen) {                      // workgroup-uniform
+            v = ld4(gen->base + (t % gen->period) * D + c4);
+            const float4 mk = drop_scale4(gen->drop, (unsigned long long)t * D + c4);
+            v.x *= mk.x; v.y *= mk.y; v.z *= mk.z; v.w *= mk.w;
+            if (live && t0 + row < T) st4(gen->out + t * D + c4, v);
+        } else {
+            v = ld4(src + t * D + c4);
+        }
         float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
 #pragma unroll
         for (int o = G / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
@@ -342,6 +355,7 @@ struct ProjParams {
     float* out[4];            // per output matrix: [T, D]
     long T;
     const float* wscale[4];   // HS: the matrices' power-of-two scales (device)
+    GenRows gen;              // gen.base != NULL: the input rows are generated (see tile_to_planes_h), `in` is unused
 };
 
 // HS: the two-way fp16 form (three matrix instructions per k-step instead of six; per-token and per-matrix power-of-two
@@ -353,7 +367,7 @@ __global__ __launch_bounds__(D * 4) void xlnet_proj_kernel(ProjParams p) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, g = lane >> 4;
     const long t0 = (long)blockIdx.x * RT;
     float* sh_inv = reinterpret_cast<float*>(smem16 + (HS ? 2 : 3) * PLN);       // HS: [RT] inverse token scales
-    if constexpr (HS) tile_to_planes_h<D, RT, NT, PH>(p.in, t0, p.T, smem16, sh_inv, tid);
+    if constexpr (HS) tile_to_planes_h<D, RT, NT, PH>(p.in, t0, p.T, smem16, sh_inv, tid, p.gen.base ? &p.gen : nullptr);
     else tile_to_planes<D, RT, NT, PH>(p.in, t0, p.T, smem16, tid);
     __syncthreads();
     const int boff = n * PH + 8 * g;
@@ -802,8 +816,18 @@ extern "C" int t4r_xlnet_kr_proj(void* stream, const float* pos, const float* pl
 // change inside a step) and every layer's positional keys k_r = pos @ r_l (the positional encoding -- with its dropout
 // mask, drawn once per forward -- is the same for all layers, so its tile is read and cut once for up to four layers).
 // planes[l] / kr[l]: the layer's own buffers (inside its t4r_xlnet_layer_fwd workspace: t4r_xlnet_layer_ws_offsets).
+// The next t4r_xlnet_stack_prepare of this thread MAKES the dropped positional rows itself (round 6): `pos` is then the plain
+// [period, D] positional encoding, pos_rows = B x period, and the projection kernel masks row t = pos[t % period] with the
+// pos_emb dropout of this forward (key (seed, ctr)) and writes the dropped rows to `out` [pos_rows, D] (what the caller used to
+// produce with t4r_dropout before the call, and what the backward's d r contraction reads).  Consumed by that call.
+static thread_local GenRows g_stack_gen = {nullptr, 0, DropCfg(), nullptr};
+extern "C" void t4r_xlnet_stack_pos_dropout(float p, unsigned long long seed, unsigned long long ctr, long period, float* out) {
+    g_stack_gen.base = nullptr; g_stack_gen.period = period; g_stack_gen.drop = make_drop(p, seed, ctr); g_stack_gen.out = out;
+}
 extern "C" int t4r_xlnet_stack_prepare(void* stream, const float* const* params_all, int n_layers, int D,
                                        float* const* planes, const float* pos, long pos_rows, float* const* kr) {
+    GenRows gen = g_stack_gen;
+    g_stack_gen.out = nullptr;
     T4R_CHECK_ARG(t4r_xlnet_fused_supported(D) && params_all && planes && n_layers >= 1, "xlnet_stack_prepare: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     for (int l0 = 0; l0 < n_layers; l0 += 4) {
@@ -823,6 +847,12 @@ extern "C" int t4r_xlnet_stack_prepare(void* stream, const float* const* params_
         const bool hs = t4r_xlnet_body_fp16x2();
         ProjParams p{pos, {nullptr, nullptr, nullptr, nullptr}, (long)D * D, {nullptr, nullptr, nullptr, nullptr}, pos_rows,
                      {nullptr, nullptr, nullptr, nullptr}};
+        if (gen.out) {          // generated rows: needs the two-way fp16 form (the only one the product build runs)
+            T4R_CHECK_ARG(hs && gen.period > 0 && pos_rows % gen.period == 0 && gen.drop.p > 0.f,
+                          "xlnet_stack_prepare: the fused pos_emb dropout needs the fp16 form, p > 0 and pos_rows a multiple of the period");
+            p.gen = gen;
+            p.gen.base = pos;
+        }
         for (int m = 0; m < nl; ++m) {
             const LayerPlanesH PH_ = carve_planes_h(planes[l0 + m], D);
             p.w[m] = hs ? PH_.RT : carve_planes(planes[l0 + m], D).RT;

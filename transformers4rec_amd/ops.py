@@ -778,7 +778,7 @@ def xlnet_layer_fwd(h, pos_emb, params, B, L, n_head, eps, ws=None, drop_p=0.0, 
     return out, ws
 
 
-def xlnet_stack_prepare(params_all, B, L, n_head, pos, drop):
+def xlnet_stack_prepare(params_all, B, L, n_head, pos, drop, pos_dropout=None):
     """The prologue of a whole XLNet stack in two launches (csrc/xlnet_fused_attn.hip: t4r_xlnet_stack_prepare): the
     weight planes of every layer and every layer's k_r = pos @ r.  params_all: per layer the 15 tensors in
     XLNET_PARAM_ORDER; pos: what the layers would project ([B * 2L, D] dropped positional encoding, or [2L, D]).
@@ -799,7 +799,14 @@ def xlnet_stack_prepare(params_all, B, L, n_head, pos, drop):
     planes, _k1 = ptr_array([w.data_ptr() + 4 * po.value for w in ws])
     kr, _k2 = ptr_array([w.data_ptr() + 4 * ko.value for w in ws])
     pos2 = pos.reshape(-1, D)
-    call("t4r_xlnet_stack_prepare", _stream(), parr, n, D, planes, _chk(pos2, torch.float32), pos2.shape[0], kr)
+    rows = pos2.shape[0]
+    if pos_dropout is not None:
+        # (p, seed, offset, out): `pos` is the plain [2L, D] encoding; the projection kernel masks it per session with this
+        # forward's pos_emb dropout and leaves the dropped rows in out [B * 2L, D] (what xlnet_pos_emb_dropout returned)
+        pd, seed, offset, out = pos_dropout
+        _lib.load().t4r_xlnet_stack_pos_dropout(float(pd), int(seed), dropout_ctr_hi(offset, 255, SITE_POS), rows, _chk(out, torch.float32))
+        rows = B * rows
+    call("t4r_xlnet_stack_prepare", _stream(), parr, n, D, planes, _chk(pos2, torch.float32), rows, kr)
     return ws
 
 

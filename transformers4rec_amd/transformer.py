@@ -178,6 +178,7 @@ _DEFER_JOIN = _exp_env("T4R_XLNET_DEFER_JOIN", "1") != "0"       # a test flips 
 _FUSED_ON = _exp_env("T4R_XLNET_FUSED", "1") != "0"
 _FUSE_FINAL = True       # module attribute (no switch): tools/ab_step.py flips it for a same-box A/B
 _FUSE_INPUT = True
+_GEN_POS = True          # the dropped positional rows are made by the stack prologue's projection kernel
 _STACK_PROLOGUE = _exp_env("T4R_XLNET_STACK_PROLOGUE", "1") != "0" and _FUSED_ON
 _PENDING: list = []          # buffers of deferred layer backwards (kept alive until the join)
 
@@ -262,8 +263,14 @@ class XLNetModel(SeedMixin, nn.Module):
                    and ops.xlnet_attn_block_supported(L, D, cfg.n_head) and key_len is None)
         if p > 0 and not fuse_in:
             h = _DropoutFn.apply(h, p, self.seed, ops.dropout_ctr_hi(offset, 255, ops.SITE_INPUT))
-        # dropout(pos_emb) is drawn once per forward and shared by the layers (HF :1143)
-        pos_b = ops.xlnet_pos_emb_dropout(pos, B, p, self.seed, offset) if p > 0 else None
+        # dropout(pos_emb) is drawn once per forward and shared by the layers (HF :1143).  With the stack prologue the projection
+        # kernel that makes every layer's k_r also makes the dropped rows (csrc/xlnet_fused_attn.hip: GenRows): no launch of its own
+        will_prepare = (torch.is_grad_enabled() or p > 0) and _STACK_PROLOGUE and ops.xlnet_fused_supported(D) and len(self.layer) > 1
+        gen_pos = p > 0 and will_prepare and _GEN_POS
+        if gen_pos:
+            pos_b = torch.empty((B * pos.shape[0], D), device=pos.device, dtype=torch.float32)
+        else:
+            pos_b = ops.xlnet_pos_emb_dropout(pos, B, p, self.seed, offset) if p > 0 else None
         # no gradient wanted (evaluation / inference under torch.no_grad()): the layers run as REGISTERED operators
         # (torch.ops.t4r_hip.xlnet_layer_infer, torch_ops.py), so the body shows up in make_fx / export / compile graphs
         infer = p == 0 and not torch.is_grad_enabled()
@@ -273,7 +280,8 @@ class XLNetModel(SeedMixin, nn.Module):
         ws_all = None
         if not infer and _STACK_PROLOGUE and ops.xlnet_fused_supported(D) and len(self.layer) > 1:
             ws_all = ops.xlnet_stack_prepare([[q.detach() for q in layer.ordered_params()] for layer in self.layer],
-                                             B, L, cfg.n_head, pos_b if p > 0 else pos, p > 0)
+                                             B, L, cfg.n_head, pos if (gen_pos or p == 0) else pos_b, p > 0,
+                                             pos_dropout=(p, self.seed, offset, pos_b) if gen_pos else None)
         # the model-level OUTPUT dropout (HF :1177) rides in the last layer's feed-forward kernels (csrc/xlnet_layer.hip:
         # T4R_LAYER_FUSE_FINAL) instead of two element-wise launches over [B L, D] around the stack
         fuse_final = p > 0 and not infer and _FUSE_FINAL and _FUSED_ON and ops.xlnet_fused_supported(D)

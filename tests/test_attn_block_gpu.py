@@ -108,9 +108,11 @@ def test_attn_block_forward_matches_fp64(ops, B, L, D, n, drop_p, with_len):
     mp = _mask(ops, (B, n, L, L), drop_p, SEED, CTR_P) if drop_p > 0 else torch.ones(B, n, L, L, dtype=torch.float64)
     mo = _mask(ops, (T, D), drop_p, SEED, CTR_O) if drop_p > 0 else torch.ones(T, D, dtype=torch.float64)
     ref = reference(p, h, kr, B, L, n, 0.03, mp, mo, key_len)
+    # (round 6: the q | k | v projections run on the two-way fp16 split -- 3-5e-6 of the largest output, like every other large
+    #  contraction of the step; the attention core and the o-projection stay exact fp32)
     for name in ("qkv", "av", "ao", "h1", "mean", "rstd"):
-        assert rel_err(saved[name] if name != "h1" else h1, ref[name]) < 3e-6, name
-    assert float((saved["lse"].double().cpu() - ref["lse"]).abs().max()) < 3e-6 * max(1.0, float(ref["lse"].abs().max()))
+        assert rel_err(saved[name] if name != "h1" else h1, ref[name]) < 6e-6, name
+    assert float((saved["lse"].double().cpu() - ref["lse"]).abs().max()) < 6e-6 * max(1.0, float(ref["lse"].abs().max()))
     assert bool(torch.isfinite(h1).all())
 
 

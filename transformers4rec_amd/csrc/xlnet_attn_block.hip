@@ -113,6 +113,9 @@ constexpr int AB_PR = 68;       // pitch of the per-wave 16 x 64 exchange buffer
 struct AttnBlockFwd {
     const float* h;          // [T, D] layer input
     const float* wqkvT;      // [3 D][D]  W_z^T (carve_planes_32)
+    const uint16_t* wqkv_h;  // HP: the same three matrices as two fp16 planes [plane][z][D][D] (LayerPlanesH::QKVT), plane stride wpl_h,
+    long wpl_h;              //     positioned by the per-matrix powers of two wscale[z] (weight_scales_kernel)
+    const float* wscale;
     const float* wo;         // [D][D]    o as stored: rows = output feature, columns = (head, d)
     const float* kr;         // [2 L, D] shared or [B, 2 L, D] per session (kr_bstride = 2 L D)
     long kr_bstride;
@@ -137,7 +140,11 @@ struct AttnBlockFwd {
 template <int V>
 struct IC { static constexpr int value = V; };
 
-template <int D, int DH>
+// HP (round 6): the q | k | v projections of phase P -- 2.0 of the launch's 3.1 GFLOP and 30.7 k of its 115 k cycles on the fp32
+// matrix instruction -- on the two-way fp16 split of the feed-forward kernels instead (three v_mfma_f32_16x16x32_f16 per k-step of
+// 32: a tenth of the matrix cycles; per-token and per-matrix power-of-two scales; 3-5e-6 of the largest output against fp64
+// like every other large contraction of the step).  The relative-attention core and the o-projection stay exact fp32.
+template <int D, int DH, bool HP>
 __global__ __launch_bounds__(D * 4) void xlnet_attn_block_fwd_kernel(AttnBlockFwd p) {
     constexpr int NW = D / 16, NH = D / DH, KC = D / 16, HC = DH / 16, PQ = 3 * D + 4;
     extern __shared__ float smem[];
@@ -179,6 +186,85 @@ __global__ __launch_bounds__(D * 4) void xlnet_attn_block_fwd_kernel(AttnBlockFw
                 if (idx < AB_RT * (D / 4) && row < p.S * p.L && t0 + row < p.T) *reinterpret_cast<float4*>(p.hin + t * D + c4) = hstage[i];
             }
         }
+        if constexpr (HP) {
+            // weight fragments of the three matrices (hi | lo planes, 16 bytes per k-step and plane), requested behind the h rows
+            AFragH<D> af[3];
+            const uint16_t* wrow = p.wqkv_h + (long)(16 * w + n) * D + 8 * g;
+            load_a2h<D>(af[0], wrow, p.wpl_h);
+            load_a2h<D>(af[1], wrow + (long)D * D, p.wpl_h);          // (the v fragments are requested behind the q product)
+            // the h rows as two fp16 planes, every row positioned by its own power of two, into the v columns of the LDS tile
+            // (row r: hi plane = halves [4 D, 5 D) of the row, lo plane = [5 D, 6 D): the bytes the fp32 copy used); inverse
+            // scales in the exchange buffers (free until phase A)
+            uint16_t* hp = reinterpret_cast<uint16_t*>(tile);
+            float* sh_inv = xbuf;
+            constexpr int G4 = D / 4, HPITCH = 2 * PQ;
+#pragma unroll
+            for (int i = 0; i < NST; ++i) {
+                const int idx = tid + i * NW * 64;
+                const bool live = idx < AB_RT * G4;
+                const int idc = live ? idx : AB_RT * G4 - 1;
+                const int row = idc / G4, c4 = (idc - row * G4) * 4;
+                const float4 v = hstage[i];
+                float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+#pragma unroll
+                for (int o = G4 / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+                const float sc = pow2_scale(m);
+                if (live) {
+                    uint32_t w0[2], w1[2];
+                    cut2h(v.x * sc, v.y * sc, w0);
+                    cut2h(v.z * sc, v.w * sc, w1);
+                    uint16_t* dst = hp + (long)row * HPITCH + 4 * D + c4;
+                    *reinterpret_cast<uint2*>(dst) = make_uint2(w0[0], w1[0]);
+                    *reinterpret_cast<uint2*>(dst + D) = make_uint2(w0[1], w1[1]);
+                    if (c4 == 0) sh_inv[row] = 1.f / sc;
+                }
+            }
+            __syncthreads();
+            AB_STAMP_P(1);
+            const uint16_t* bp = hp + (long)n * HPITCH + 4 * D + 8 * g;
+            float isc[AB_R];
+#pragma unroll
+            for (int r = 0; r < AB_R; ++r) isc[r] = sh_inv[16 * r + n];
+            // q, then k: written to the tile and (write-through) to the saved q | k | v as they finish
+#pragma unroll
+            for (int z = 0; z < 2; ++z) {
+                f32x4 acc[AB_R];
+#pragma unroll
+                for (int r = 0; r < AB_R; ++r) acc[r] = zero4();
+                product3h<D, AB_R, HPITCH>(af[z], bp, D, acc);
+                if (z == 0) load_a2h<D>(af[2], wrow + 2L * D * D, p.wpl_h);
+                const float iw = 1.f / p.wscale[z];
+#pragma unroll
+                for (int r = 0; r < AB_R; ++r) {
+                    const int tok = 16 * r + n;
+                    const float sc = isc[r] * iw;                 // two exact powers of two
+                    acc[r][0] *= sc; acc[r][1] *= sc; acc[r][2] *= sc; acc[r][3] *= sc;
+                    *reinterpret_cast<float4*>(tile + tok * PQ + z * D + 16 * w + 4 * g) = f4(acc[r]);
+                    if (tok < rows) st4_stream(p.qkv + z * TD + (t0 + tok) * D + 16 * w + 4 * g, acc[r]);
+                }
+            }
+            AB_STAMP_P(2);
+            // v: kept in its accumulators until every wave has read the planes it replaces
+            f32x4 accv[AB_R];
+#pragma unroll
+            for (int r = 0; r < AB_R; ++r) accv[r] = zero4();
+            product3h<D, AB_R, HPITCH>(af[2], bp, D, accv);
+            AB_STAMP_P(3);
+            __syncthreads();
+            {
+                const float iw = 1.f / p.wscale[2];
+#pragma unroll
+                for (int r = 0; r < AB_R; ++r) {
+                    const int tok = 16 * r + n;
+                    const float sc = isc[r] * iw;
+                    accv[r][0] *= sc; accv[r][1] *= sc; accv[r][2] *= sc; accv[r][3] *= sc;
+                    *reinterpret_cast<float4*>(tile + tok * PQ + 2 * D + 16 * w + 4 * g) = f4(accv[r]);
+                    if (tok < rows) st4_stream(p.qkv + 2 * TD + (t0 + tok) * D + 16 * w + 4 * g, accv[r]);
+                }
+            }
+            AB_STAMP_P(4);
+            AB_STAMP_P(5);
+        } else {
         float a[3][4 * KC];
         auto load_a = [&](int z, int c) __attribute__((always_inline)) {
             float t4[4];
@@ -264,6 +350,7 @@ __global__ __launch_bounds__(D * 4) void xlnet_attn_block_fwd_kernel(AttnBlockFw
         }
         AB_STAMP_P(4);
         AB_STAMP_P(5);
+        }   // !HP
     }
     AB_STAMP(1);
     __syncthreads();
@@ -591,6 +678,11 @@ extern "C" int t4r_xlnet_attn_block_fwd(void* stream, const float* h, const floa
     const int dh = D / n_head, S = attn_block_sessions(L);
     AttnBlockFwd p;
     p.h = h; p.wqkvT = carve_planes_32(planes, D).QKVT; p.wo = o; p.kr = kr; p.kr_bstride = kr_bstride;
+    const bool hp = t4r_xlnet_body_fp16x2() != 0;          // the two-way fp16 planes exist (the product's only form)
+    {
+        const LayerPlanesH PH_ = carve_planes_h(planes, D);
+        p.wqkv_h = PH_.QKVT; p.wpl_h = 3L * D * D; p.wscale = PH_.scale + HS_Q;
+    }
     p.rw = r_w_bias; p.rr = r_r_bias; p.gamma = gamma; p.beta = beta;
     p.qkv = qkv; p.av = av; p.lse = lse; p.ao = ao; p.mean = mean; p.rstd = rstd; p.h1 = h1; p.key_len = key_len;
     p.B = B; p.L = L; p.S = S; p.T = (long)B * L;
@@ -610,10 +702,14 @@ extern "C" int t4r_xlnet_attn_block_fwd(void* stream, const float* h, const floa
     const dim3 grid((unsigned)((B + S - 1) / S)), block((unsigned)(D * 4));
     const size_t smem = attn_block_smem(D);
 #define T4R_AB_FWD(DD, DHH)                                                                                                  \
-    {                                                                                                                        \
+    if (hp) {                                                                                                                \
         static T4rLdsAttr once;                                                                                            \
-        t4r_ensure_dynamic_lds((const void*)xlnet_attn_block_fwd_kernel<DD, DHH>, smem, once); \
-        hipLaunchKernelGGL((xlnet_attn_block_fwd_kernel<DD, DHH>), grid, block, smem, st, p);                                \
+        t4r_ensure_dynamic_lds((const void*)xlnet_attn_block_fwd_kernel<DD, DHH, true>, smem, once);                         \
+        hipLaunchKernelGGL((xlnet_attn_block_fwd_kernel<DD, DHH, true>), grid, block, smem, st, p);                          \
+    } else {                                                                                                                 \
+        static T4rLdsAttr once;                                                                                            \
+        t4r_ensure_dynamic_lds((const void*)xlnet_attn_block_fwd_kernel<DD, DHH, false>, smem, once);                        \
+        hipLaunchKernelGGL((xlnet_attn_block_fwd_kernel<DD, DHH, false>), grid, block, smem, st, p);                         \
     }
     switch (D * 100 + dh) {
         case 12832: T4R_AB_FWD(128, 32) break;

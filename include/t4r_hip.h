@@ -362,8 +362,10 @@ int t4r_colsum(void* stream, const float* x, float* out, float* ws, long rows, i
  * replaces: HF XLNetRelativeAttention.rel_attn_core :95-140 (+ rel_shift_bnij :81-93),
  *           XLNetLayer.forward :308-353 as configured by config/transformer.py:432-482.
  * q,k,v,out [B*L, n_head*d_head]; k_r [2L, D] = pos_emb @ r (kr_per_batch: [B,2L,D], one set per
- * session, used when pos_emb dropout is on); lse [B,n,L]; L <= 64.  drop_p: attention-probability
- * dropout (HF :132), mask index ((b*n+h)*L+i)*L+j.
+ * session, used when pos_emb dropout is on); lse [B,n,L].  Any L >= 1 and any d_head that is a multiple of 4 up to 128
+ * (the reference takes any total_seq_length / d_model, config/transformer.py:432-482): one-wave kernels (MFMA for L <= 32,
+ * d_head 16 / 32) up to 64 positions with d_head 8 / 16 / 32, the general kernels of csrc/xlnet_attn_long.hip beyond (they
+ * need `out` in the backward).  drop_p: attention-probability dropout (HF :132), mask index ((b*n+h)*L+i)*L+j.
  * backward: d_r_w_bias / d_r_r_bias accumulated, the rest overwritten (dk_r has k_r's shape).
  * key_len (device int32 [B], may be NULL = the reference's behaviour: NO padding mask): opt-in
  * padding mask -- keys at positions >= key_len[b] get the score -1e30 except on the diagonal, as HF XLNet does

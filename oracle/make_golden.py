@@ -3,6 +3,7 @@ reference (NVIDIA-Merlin/Transformers4Rec at /root/reference, imported through
 oracle/ref_standins.py) on CPU fp32 with fixed seeds.
 
     python oracle/make_golden.py            # (re)writes tests/golden/*.npz
+    python oracle/make_golden.py --long     # only the long-sequence fixtures (round 6)
 
 The fixtures pin the oracle (oracle/t4r_oracle.py) and, through it and directly, the HIP
 path.  /root/reference is absent on the GPU box, so only the .npz files travel.
@@ -609,9 +610,31 @@ def prepost_cases(tr, V, L, d, nh):
         save(name, dd, n_head=nh, d_model=d, n_layer=1, eps=0.03, L=L, V=V + 1, ssn_p=0.3, post_drop_p=0.25)
 
 
+# ------------------------------------------------------------------------------------------ round 6
+def long_cases(tr):
+    """Sequences beyond one wave of the attention kernels (total_seq_length 100: the reference takes any length,
+    config/transformer.py:432-482): XLNet MLM train / eval / inference (the inference pass runs the body on L + 1 = 101
+    positions, masking.py:406-418) and XLNet CLM train."""
+    L, V, d, nh, nl, B = 100, 300, 32, 2, 2, 6
+    m = build(tr, V, L, d, nh, nl, emb_default=d, seed=70)
+    x = synth_inputs(B, L, V, (), (), seed=71, min_len=40)
+    save("xlnet_mlm_long_train", run(m, x, True, False, True), n_head=nh, d_model=d, n_layer=nl, eps=0.03, L=L, V=V + 1)
+    save("xlnet_mlm_long_eval", run(m, x, False, True, False, with_params=False), n_head=nh, d_model=d, n_layer=nl, eps=0.03,
+         L=L, V=V + 1)
+    save("xlnet_mlm_long_infer", run(m, x, False, False, False, with_params=False), n_head=nh, d_model=d, n_layer=nl, eps=0.03,
+         L=L, V=V + 1)
+    mD = build(tr, V, L, d, nh, nl, masking="clm", emb_default=d, seed=72)
+    xD = synth_inputs(B, L, V, (), (), seed=73, min_len=40)
+    save("xlnet_clm_long_train", run(mD, xD, True, False, True), n_head=nh, d_model=d, n_layer=nl, eps=0.03, L=L, V=V + 1)
+
+
 if __name__ == "__main__":
     if "--round3" in sys.argv:          # only the fixtures added in round 3 (the others are unchanged)
         torch.set_num_threads(4)
         round3_cases(rs.import_reference())
+    elif "--long" in sys.argv:          # only the fixtures added in round 6
+        torch.set_num_threads(4)
+        long_cases(rs.import_reference())
     else:
         main()
+        long_cases(rs.import_reference())

@@ -166,7 +166,9 @@ def _autograd_reference(p, h, kr, B, L, n, eps, mp, mo, key_len, dy):
 @pytest.mark.parametrize("B,L,D,n,per_session,klen", [
     (5, 20, 128, 4, True, False), (1030, 20, 128, 4, True, False), (7, 20, 128, 4, False, False),
     (6, 20, 128, 8, True, True), (9, 13, 64, 4, True, True), (3, 32, 64, 2, False, True), (4, 9, 32, 2, True, False),
-    (2, 5, 32, 1, False, False), (600, 8, 64, 4, False, False)])
+    (2, 5, 32, 1, False, False), (600, 8, 64, 4, False, False),
+    # beyond one wave (csrc/xlnet_attn_long.hip), with and without the key mask, per-session and shared k_r
+    (3, 100, 64, 4, True, True), (2, 90, 32, 2, False, True), (2, 129, 64, 1, True, False)])
 def test_attention_core_backward_planes_path(ops, monkeypatch, B, L, D, n, per_session, klen):
     """t4r_xlnet_attn_bwd with q | k | v (and d q | d k | d v) as planes of one [3][T][D] buffer -- the layout the layer holds
     them in -- against autograd of the fp32 restatement of HF modeling_xlnet.py rel_attn_core :96-140 with the SAME Philox

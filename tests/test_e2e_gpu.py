@@ -97,6 +97,9 @@ def run_train_case(name, **build_kw):
                                      embedding_dims={"item_id": 24, "country": 8})),
     ("gpt2_clm_item_train", dict(masking="clm", emb_default=32, arch="gpt2")),
     ("bert_mlm_item_train", dict(emb_default=32, arch="bert")),
+    # total_seq_length 100: the general attention kernels of csrc/xlnet_attn_long.hip (round 6)
+    ("xlnet_mlm_long_train", dict(emb_default=32)),
+    ("xlnet_clm_long_train", dict(masking="clm", emb_default=32)),
 ])
 def test_train_step_matches_reference(name, kw):
     d, model, x, cap, hooks = run_train_case(name, **kw)
@@ -149,6 +152,7 @@ def test_sampled_softmax_train_matches_reference():
 @pytest.mark.parametrize("name,params_from,kw", [
     ("xlnet_mlm_item_eval", "xlnet_mlm_item_train", dict(emb_default=32)),
     ("xlnet_clm_item_eval", "xlnet_clm_item_train", dict(masking="clm", emb_default=32, weight_tying=False)),
+    ("xlnet_mlm_long_eval", "xlnet_mlm_long_train", dict(emb_default=32)),
 ])
 def test_eval_matches_reference(name, params_from, kw):
     d = gu.load(name, params_from)
@@ -174,6 +178,7 @@ def test_eval_matches_reference(name, params_from, kw):
     ("xlnet_clm_item_infer", "xlnet_clm_item_train", dict(masking="clm", emb_default=32, weight_tying=False)),
     ("gpt2_clm_item_infer", "gpt2_clm_item_train", dict(masking="clm", emb_default=32, arch="gpt2")),
     ("bert_mlm_item_infer", "bert_mlm_item_train", dict(emb_default=32, arch="bert")),
+    ("xlnet_mlm_long_infer", "xlnet_mlm_long_train", dict(emb_default=32)),       # 101 positions in the body
 ])
 def test_inference_matches_reference(name, params_from, kw):
     d = gu.load(name, params_from)

@@ -94,6 +94,8 @@ def test_log_uniform_golden():
     ("xlnet_mlm_multi_train", "mlm", "concat"),
     ("xlnet_clm_item_train", "clm", "concat"),
     ("xlnet_mlm_context_train", "mlm", "concat"),
+    ("xlnet_mlm_long_train", "mlm", "concat"),          # total_seq_length 100 (round 6: beyond one wave of the attention kernels)
+    ("xlnet_clm_long_train", "clm", "concat"),
 ])
 def test_train_forward_backward_golden(name, masking, agg):
     d = gu.load(name)
@@ -177,6 +179,7 @@ def test_prepost_regularisers_golden(name):
 @pytest.mark.parametrize("name,params_from,masking", [
     ("xlnet_mlm_item_eval", "xlnet_mlm_item_train", "mlm"),
     ("xlnet_clm_item_eval", "xlnet_clm_item_train", "clm"),
+    ("xlnet_mlm_long_eval", "xlnet_mlm_long_train", "mlm"),
 ])
 def test_eval_golden(name, params_from, masking):
     d = gu.load(name, params_from)
@@ -195,6 +198,7 @@ def test_eval_golden(name, params_from, masking):
 @pytest.mark.parametrize("name,params_from,masking", [
     ("xlnet_mlm_item_infer", "xlnet_mlm_item_train", "mlm"),
     ("xlnet_clm_item_infer", "xlnet_clm_item_train", "clm"),
+    ("xlnet_mlm_long_infer", "xlnet_mlm_long_train", "mlm"),       # the body runs on L + 1 = 101 positions
 ])
 def test_inference_golden(name, params_from, masking):
     d = gu.load(name, params_from)

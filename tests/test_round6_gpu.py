@@ -133,6 +133,40 @@ def test_full_size_dropout_step_vs_oracle(ops, multi):
               p["soft"]["price"][2].grad, rtol=2e-3, atol=2e-6)
 
 
+@pytest.mark.parametrize("L,D", [(100, 64), (70, 128), (20, 256), (24, 192), (100, 256)])
+def test_long_sequence_dropout_step_vs_oracle(ops, L, D):
+    """total_seq_length beyond one wave of the attention kernels, or a d_model / head width beyond the fused kernels (d_model 256 and
+    192 with four heads: d_head 64 and 48) -- csrc/xlnet_attn_long.hip --, training mode, dropout 0.3: one step
+    against the CPU oracle taking the same decisions (MLM targets and every dropout site from the restatement alone).  The reference
+    takes any length (config/transformer.py:432-482)."""
+    import transformers4rec_amd as tr
+
+    B, V, NL, p_drop = 24, 3000, 2, 0.3
+    schema, model, sd = _bench_model(tr, False, p_drop, V=V, D=D, L=L, n_layer=NL)
+    xl, masking = model.transformer_block.transformer, model.input_features.masking
+    masking.seed, xl.seed = 77, 78
+    data = tr.random_data_from_schema(schema, B, L, seed=5)
+    out = model({k: v.to(DEV) for k, v in data.items()}, training=True)
+    out["loss"].backward()
+    mask, labels = R.mlm_targets_train_device(data["item_id"], 77, 0, 0.15)
+    assert torch.equal(masking.mask_schema.cpu(), mask) and torch.equal(masking.masked_targets.cpu(), labels)
+    masks = R.xlnet_dropout_masks(B, L, D, 4, NL, p_drop, seed=78, offset=1)
+    p = gu.oracle_params({"p/" + k: v.numpy() for k, v in sd.items()}, requires_grad=True)
+    ref = O.session_forward(p, dict(n_head=4, eps=0.03, item="item_id", masking="mlm"), data, mask, labels, True, False,
+                            drop=(p_drop, masks))
+    ref["loss"].backward()
+    assert torch.equal(out["labels"].cpu(), ref["labels"])
+    assert abs(float(out["loss"].detach()) - float(ref["loss"].detach())) < 1e-4
+    assert float((out["predictions"].detach().cpu() - ref["logits"].detach()).abs().max()) < 1e-4
+    close(model.input_features.item_embedding_table.weight.grad, p["tables"]["item_id"].grad, rtol=1e-3, atol=1e-6)
+    for i in range(NL):
+        lay, lp = xl.layer[i], p["layers"][i]
+        for name, got in (("q", lay.rel_attn.q.grad), ("k", lay.rel_attn.k.grad), ("v", lay.rel_attn.v.grad), ("o", lay.rel_attn.o.grad),
+                          ("r", lay.rel_attn.r.grad), ("r_w_bias", lay.rel_attn.r_w_bias.grad), ("r_r_bias", lay.rel_attn.r_r_bias.grad),
+                          ("w1", lay.ff.layer_1.weight.grad), ("w2", lay.ff.layer_2.weight.grad)):
+            close(got, lp[name].grad, rtol=2e-3, atol=2e-6, msg=lambda m, i=i, name=name: f"layer {i} {name}: {m}")
+
+
 def test_three_optimizer_steps_in_lockstep_at_the_benchmarked_setting(ops):
     """configs[1], dropout 0.3, Adam lr 1e-3 (bench.py's optimizer), three steps: every step's loss and the parameters after
     the third against the CPU oracle driven by the restated streams only (MLM offset advances by B*L per step, the dropout

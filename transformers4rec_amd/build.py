@@ -14,7 +14,8 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libt4r_hip.so")
 SOURCES = ["gemm_f32.hip", "gemm_half.hip", "elementwise.hip", "embedding.hip", "masking.hip", "xlnet_attn.hip",
            "head.hip", "xlnet_layer.hip", "mha.hip", "swap_noise.hip", "xlnet_attn_mfma.hip", "mha_mfma.hip",
-           "embedding_sorted.hip", "head_split.hip", "tok_gemm.hip", "embedding_bag.hip", "xlnet_fused.hip", "xlnet_fused_attn.hip", "xlnet_attn_block.hip"]
+           "embedding_sorted.hip", "head_split.hip", "tok_gemm.hip", "embedding_bag.hip", "xlnet_fused.hip", "xlnet_fused_attn.hip", "xlnet_attn_block.hip",
+           "xlnet_attn_long.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wno-unused-result"]
 

@@ -505,10 +505,23 @@ static size_t attn_bwd_smem(int L, int D, int n, int per_batch_kr = 0) {
 }
 
 extern "C" int t4r_xlnet_attn_bwd_blocks(int B) { return B < 1024 ? B : 1024; }
-extern "C" long t4r_xlnet_attn_bwd_ws_floats(int B, int L, int D, int n_head) {
+static long attn_bwd_part_floats(int B, int L, int D, int n_head) {
     const int hpb = (D / n_head) >= 32 ? 4 : 8;
     return (long)t4r_xlnet_attn_bwd_blocks(B) * ((n_head + hpb - 1) / hpb) * (2L * L * D + 2L * D);
 }
+// the general kernels for L > 64 (xlnet_attn_long.hip) keep delta [B, n_head, L] behind the partial rows
+long t4r_xlnet_attn_long_extra_ws(int B, int L, int n_head, int d_head);
+extern "C" long t4r_xlnet_attn_bwd_ws_floats(int B, int L, int D, int n_head) {
+    return attn_bwd_part_floats(B, L, D, n_head) + t4r_xlnet_attn_long_extra_ws(B, L, n_head, n_head > 0 ? D / n_head : 0);
+}
+int t4r_xlnet_attn_long_ok(int L, int d_head);
+int t4r_xlnet_attn_long_fwd(hipStream_t st, const float* q, const float* k, const float* v, const float* kr, const float* rw,
+                            const float* rr, float* out, float* lse, int B, int L, int n_head, int d_head, float scale,
+                            long kr_bstride, DropCfg drop, const int* key_len);
+int t4r_xlnet_attn_long_bwd(hipStream_t st, const float* q, const float* k, const float* v, const float* kr, const float* rw,
+                            const float* rr, const float* out, const float* lse, const float* dout, float* dq, float* dk,
+                            float* dv, float* part, float* delta, float* dkr, float* d_rw, float* d_rr, int B, int L, int n_head,
+                            int d_head, float scale, long kr_bstride, DropCfg drop, const int* key_len);
 
 // MFMA kernels for L <= 32, d_head 16 / 32 (xlnet_attn_mfma.hip); T4R_ATTN_MFMA=0 keeps the VALU kernels
 int t4r_xlnet_attn_mfma_ok(int L, int d_head);
@@ -558,12 +571,17 @@ extern "C" int t4r_xlnet_attn_fwd(void* stream, const float* q, const float* k, 
                                   int kr_per_batch, float drop_p, unsigned long long seed,
                                   unsigned long long ctr_hi, const int* key_len) {
     if (B == 0) return 0;
-    T4R_CHECK_ARG(L >= 1 && L <= 64, "xlnet_attn: L must be in [1, 64]");
+    T4R_CHECK_ARG(L >= 1, "xlnet_attn: L must be at least 1");
     const int D = n_head * d_head;
     const float scale = 1.0f / sqrtf((float)d_head);
     hipStream_t st = (hipStream_t)stream;
     const long bs = kr_per_batch ? 2L * L * D : 0;
     const DropCfg dc = make_drop(drop_p, seed, ctr_hi);
+    if (L > 64 || !(d_head == 8 || d_head == 16 || d_head == 32)) {       // beyond one wave per row block, or a head width the
+        // one-wave kernels have no instance for: the general kernels (any L, d_head a multiple of 4 up to 128)
+        T4R_CHECK_ARG(t4r_xlnet_attn_long_ok(L, d_head), "xlnet_attn: d_head must be a multiple of 4, at most 128");
+        return t4r_xlnet_attn_long_fwd(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, B, L, n_head, d_head, scale, bs, dc, key_len);
+    }
     if (use_mfma(L, d_head))
         return t4r_xlnet_attn_mfma_fwd(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, B, L, n_head, d_head, scale,
                                        bs, dc, key_len);
@@ -620,12 +638,19 @@ extern "C" int t4r_xlnet_attn_bwd(void* stream, const float* q, const float* k, 
                                   int d_head, int kr_per_batch, float drop_p, unsigned long long seed,
                                   unsigned long long ctr_hi, const int* key_len) {
     if (B == 0) return 0;
-    T4R_CHECK_ARG(L >= 1 && L <= 64, "xlnet_attn: L must be in [1, 64]");
+    T4R_CHECK_ARG(L >= 1, "xlnet_attn: L must be at least 1");
     const int D = n_head * d_head;
     const float scale = 1.0f / sqrtf((float)d_head);
     hipStream_t st = (hipStream_t)stream;
     const long bs = kr_per_batch ? 2L * L * D : 0;
     const DropCfg dc = make_drop(drop_p, seed, ctr_hi);
+    if (L > 64 || !(d_head == 8 || d_head == 16 || d_head == 32)) {
+        T4R_CHECK_ARG(t4r_xlnet_attn_long_ok(L, d_head), "xlnet_attn_bwd: d_head must be a multiple of 4, at most 128");
+        T4R_CHECK_ARG(out != nullptr, "xlnet_attn_bwd: the forward output is needed by the general kernels (L > 64 or d_head not 8 / 16 / 32)");
+        return t4r_xlnet_attn_long_bwd(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, dout, dq, dk, dv, workspace,
+                                       workspace + attn_bwd_part_floats(B, L, D, n_head), dk_r, d_r_w_bias, d_r_r_bias, B, L,
+                                       n_head, d_head, scale, bs, dc, key_len);
+    }
 #ifdef T4R_EXPERIMENTAL
     {
         const long TD = (long)B * L * D;

@@ -1,0 +1,376 @@
+// XLNet relative-position attention core for sequences LONGER than one wave (L > 64) and for head widths the one-wave kernels
+// have no instance for (d_head a multiple of 4 up to 128 other than 8 / 16 / 32), forward and backward (gfx950).
+//
+// The reference takes any total_seq_length (XLNetConfig.build, transformers4rec/config/transformer.py:432-482; HF
+// modeling_xlnet.py rel_attn_core :95-140, rel_shift_bnij :81-93, reached through transformers4rec/torch/block/transformer.py:
+// 179-199); the kernels of xlnet_attn.hip / xlnet_attn_mfma.hip / xlnet_attn_block.hip put one query row on one lane of ONE
+// wave and stop at 64 (32) positions.  This file is the general form behind the same entry points (t4r_xlnet_attn_fwd / _bwd pick
+// it when L > 64): same arithmetic, same dropout keys (mask index ((b n_head + h) L + i) L + j), same opt-in key mask, no bound
+// on L other than memory.  It is the coverage path, not the benchmarked one: everything is recomputed from q, k, v, k_r with
+// plain fp32 FMAs, rows of k / v / q / d out come as wave-uniform (broadcast) loads out of L2, the lane-dependent row of the
+// other operand as a 16-byte-per-lane gather; no LDS, so no L x d_model limit either.
+//
+//   forward          thread = query row i (blocks of 64 rows walked by one wave per (session, head)); one online-softmax pass
+//                    over the keys; saves the row log-sum-exp
+//   backward, rows   thread = query row i:  delta_i = d out_i . out_i (saved for the other two passes),
+//                    dS_ij = scale P_ij (mask_ij d out_i . v_j - delta_i),  d q_i = sum_j dS_ij (k_j + k_r[L + j - i]);
+//                    the two halves of d q summed over rows and sessions are d r_w_bias / d r_r_bias (per-workgroup partials)
+//   backward, keys   thread = key j:  d k_j = sum_i dS_ij (q_i + r_w_bias),  d v_j = sum_i P~_ij d out_i
+//   backward, rel    thread = relative position m:  d k_r[m] = sum_{i, j = m - L + i} dS_ij (q_i + r_r_bias)   (per session, or
+//                    summed over the sessions of the workgroup for the shared k_r: partials reduced in block order)
+// Batch-reduced gradients go through the same partial buffer and reduction launch as the short kernels: deterministic.
+#include "t4r_common.h"
+#include <stdlib.h>
+
+#define T4R_KEY_MASKED (-1e30f)
+
+namespace {
+
+// DH is the CAPACITY of the per-thread vectors (registers: every index is a compile-time constant); dh <= DH, a multiple of 4, is
+// the head width of the call -- the guard per 16-byte group is a scalar compare
+template <int DH>
+__device__ __forceinline__ void load_row(float (&x)[DH], const float* __restrict__ p, int dh) {
+#pragma unroll
+    for (int d = 0; d < DH; d += 4) {
+        if (d < dh) {
+            const float4 t = *reinterpret_cast<const float4*>(p + d);
+            x[d] = t.x; x[d + 1] = t.y; x[d + 2] = t.z; x[d + 3] = t.w;
+        } else {
+            x[d] = 0.f; x[d + 1] = 0.f; x[d + 2] = 0.f; x[d + 3] = 0.f;
+        }
+    }
+}
+template <int DH>
+__device__ __forceinline__ float dot_row(const float (&a)[DH], const float* __restrict__ p, int dh) {
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < DH; d += 4) {
+        if (d < dh) {
+            const float4 t = *reinterpret_cast<const float4*>(p + d);
+            s += a[d] * t.x + a[d + 1] * t.y + a[d + 2] * t.z + a[d + 3] * t.w;
+        }
+    }
+    return s;
+}
+// (a + bias) . p
+template <int DH>
+__device__ __forceinline__ float dot_row_bias(const float* __restrict__ a, const float* __restrict__ bias, const float (&x)[DH], int dh) {
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < DH; d += 4) {
+        if (d < dh) {
+            const float4 t = *reinterpret_cast<const float4*>(a + d);
+            const float4 u = *reinterpret_cast<const float4*>(bias + d);
+            s += (t.x + u.x) * x[d] + (t.y + u.y) * x[d + 1] + (t.z + u.z) * x[d + 2] + (t.w + u.w) * x[d + 3];
+        }
+    }
+    return s;
+}
+template <int DH>
+__device__ __forceinline__ void axpy_row(float (&acc)[DH], float a, const float* __restrict__ p, int dh) {
+#pragma unroll
+    for (int d = 0; d < DH; d += 4) {
+        if (d < dh) {
+            const float4 t = *reinterpret_cast<const float4*>(p + d);
+            acc[d] += a * t.x; acc[d + 1] += a * t.y; acc[d + 2] += a * t.z; acc[d + 3] += a * t.w;
+        }
+    }
+}
+template <int DH>
+__device__ __forceinline__ void axpy_row_bias(float (&acc)[DH], float a, const float* __restrict__ p, const float* __restrict__ bias, int dh) {
+#pragma unroll
+    for (int d = 0; d < DH; d += 4) {
+        if (d < dh) {
+            const float4 t = *reinterpret_cast<const float4*>(p + d);
+            const float4 u = *reinterpret_cast<const float4*>(bias + d);
+            acc[d] += a * (t.x + u.x); acc[d + 1] += a * (t.y + u.y); acc[d + 2] += a * (t.z + u.z); acc[d + 3] += a * (t.w + u.w);
+        }
+    }
+}
+
+struct LongArgs {
+    const float *q, *k, *v, *kr, *rw, *rr;     // [B L, D] x 3; k_r [2 L, D] (+ b kr_bstride); biases [D]
+    const float *out, *lse, *dout;             // backward: forward output, row log-sum-exp [B, n, L], upstream gradient
+    float *o, *lse_o;                          // forward outputs
+    float *dq, *dk, *dv, *dkr_b, *part, *delta;
+    int B, L, n_head, dh;
+    float scale;
+    long kr_bstride;
+    DropCfg drop;
+    const int* key_len;
+};
+
+// score of (i, j) for the thread that holds (q_i + r_w_bias) and (q_i + r_r_bias)
+#define T4R_MASKED(j, i, klen) ((j) >= (klen) && (j) != (i))
+
+template <int DH>
+__global__ __launch_bounds__(64) void attn_long_fwd_kernel(LongArgs a) {
+    const int L = a.L, dh = a.dh, D = a.n_head * dh, h = blockIdx.y, hc = h * dh, lane = threadIdx.x;
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const float* krb = a.kr + (long)b * a.kr_bstride + hc;
+        const int klen = a.key_len ? a.key_len[b] : L;
+        for (int i0 = 0; i0 < L; i0 += 64) {
+            const int i = i0 + lane, ic = min(i, L - 1);
+            float qw[DH], qr[DH], o[DH];
+            {
+                const float* qrow = a.q + ((long)b * L + ic) * D + hc;
+#pragma unroll
+                for (int d = 0; d < DH; ++d) {
+                    const int dc = d < dh ? d : 0;
+                    const float t = qrow[dc];
+                    qw[d] = d < dh ? t + a.rw[hc + dc] : 0.f; qr[d] = d < dh ? t + a.rr[hc + dc] : 0.f; o[d] = 0.f;
+                }
+            }
+            float m = -INFINITY, l = 0.f;
+            for (int j = 0; j < L; ++j) {
+                float s = dot_row<DH>(qw, a.k + ((long)b * L + j) * D + hc, dh) + dot_row<DH>(qr, krb + (long)(j + L - ic) * D, dh);
+                s *= a.scale;
+                if (T4R_MASKED(j, ic, klen)) s = T4R_KEY_MASKED;
+                const float mn = fmaxf(m, s);
+                const float alpha = __expf(m - mn), pj = __expf(s - mn);
+                l = l * alpha + pj;
+                float pd = pj;
+                if (a.drop.p > 0.f) pd *= drop_scale(a.drop, ((unsigned long long)(b * a.n_head + h) * L + ic) * L + j);
+#pragma unroll
+                for (int d = 0; d < DH; ++d) o[d] *= alpha;
+                axpy_row<DH>(o, pd, a.v + ((long)b * L + j) * D + hc, dh);
+                m = mn;
+            }
+            if (i < L) {
+                const float inv = 1.f / l;
+                float* orow = a.o + ((long)b * L + i) * D + hc;
+#pragma unroll
+                for (int d = 0; d < DH; d += 4)
+                    if (d < dh) *reinterpret_cast<float4*>(orow + d) = make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
+                a.lse_o[((long)b * a.n_head + h) * L + i] = m + __logf(l);
+            }
+        }
+    }
+}
+
+// dS_ij / scale-free pieces shared by the three backward passes
+__device__ __forceinline__ float prob_of(float s, float lse) { return __expf(s - lse); }
+
+template <int DH>
+__global__ __launch_bounds__(64) void attn_long_bwd_rows_kernel(LongArgs a) {
+    const int L = a.L, dh = a.dh, D = a.n_head * dh, h = blockIdx.y, hc = h * dh, lane = threadIdx.x;
+    float srw[DH], srr[DH];                     // this lane's share of d r_w_bias / d r_r_bias (all its rows and sessions)
+#pragma unroll
+    for (int d = 0; d < DH; ++d) { srw[d] = 0.f; srr[d] = 0.f; }
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const float* krb = a.kr + (long)b * a.kr_bstride + hc;
+        const int klen = a.key_len ? a.key_len[b] : L;
+        for (int i0 = 0; i0 < L; i0 += 64) {
+            const int i = i0 + lane, ic = min(i, L - 1);
+            const bool live = i < L;
+            float qw[DH], qr[DH], g[DH], dqa[DH], dqb[DH];
+            const long row = ((long)b * L + ic) * D + hc;
+            float delta = 0.f;
+#pragma unroll
+            for (int d = 0; d < DH; ++d) {
+                const bool on = d < dh;
+                const int dc = on ? d : 0;
+                const float t = a.q[row + dc];
+                qw[d] = on ? t + a.rw[hc + dc] : 0.f; qr[d] = on ? t + a.rr[hc + dc] : 0.f;
+                g[d] = on ? a.dout[row + dc] : 0.f;
+                delta += g[d] * a.out[row + dc];
+                dqa[d] = 0.f; dqb[d] = 0.f;
+            }
+            const float lrow = a.lse[((long)b * a.n_head + h) * L + ic];
+            if (live) a.delta[((long)b * a.n_head + h) * L + i] = delta;
+            for (int j = 0; j < L; ++j) {
+                const float* kj = a.k + ((long)b * L + j) * D + hc;
+                const float* krm = krb + (long)(j + L - ic) * D;
+                float s = (dot_row<DH>(qw, kj, dh) + dot_row<DH>(qr, krm, dh)) * a.scale;
+                if (T4R_MASKED(j, ic, klen)) s = T4R_KEY_MASKED;
+                const float p = prob_of(s, lrow);
+                float dp = dot_row<DH>(g, a.v + ((long)b * L + j) * D + hc, dh);
+                if (a.drop.p > 0.f) dp *= drop_scale(a.drop, ((unsigned long long)(b * a.n_head + h) * L + ic) * L + j);
+                const float ds = p * (dp - delta) * a.scale;
+                axpy_row<DH>(dqa, ds, kj, dh);
+                axpy_row<DH>(dqb, ds, krm, dh);
+            }
+            if (live) {
+                float* dqrow = a.dq + ((long)b * L + i) * D + hc;
+#pragma unroll
+                for (int d = 0; d < DH; d += 4)
+                    if (d < dh) *reinterpret_cast<float4*>(dqrow + d) = make_float4(dqa[d] + dqb[d], dqa[d + 1] + dqb[d + 1], dqa[d + 2] + dqb[d + 2], dqa[d + 3] + dqb[d + 3]);
+#pragma unroll
+                for (int d = 0; d < DH; ++d) { srw[d] += dqa[d]; srr[d] += dqb[d]; }
+            }
+        }
+    }
+    // the workgroup's (= the wave's) sums over its lanes, lane order fixed by the butterfly
+    float* mypart = a.part + (long)blockIdx.x * (2L * L * D + 2 * D) + 2L * L * D;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) {
+        float x = srw[d], y = srr[d];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { x += __shfl_xor(x, o, 64); y += __shfl_xor(y, o, 64); }
+        if (lane == 0 && d < dh) { mypart[hc + d] = x; mypart[D + hc + d] = y; }
+    }
+}
+
+template <int DH>
+__global__ __launch_bounds__(64) void attn_long_bwd_keys_kernel(LongArgs a) {
+    const int L = a.L, dh = a.dh, D = a.n_head * dh, h = blockIdx.y, hc = h * dh, lane = threadIdx.x;
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const float* krb = a.kr + (long)b * a.kr_bstride + hc;
+        const int klen = a.key_len ? a.key_len[b] : L;
+        for (int j0 = 0; j0 < L; j0 += 64) {
+            const int j = j0 + lane, jc = min(j, L - 1);
+            float kj[DH], vj[DH], dk[DH], dv[DH];
+            const long row = ((long)b * L + jc) * D + hc;
+            load_row<DH>(kj, a.k + row, dh);
+            load_row<DH>(vj, a.v + row, dh);
+#pragma unroll
+            for (int d = 0; d < DH; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+            for (int i = 0; i < L; ++i) {
+                const float* qi = a.q + ((long)b * L + i) * D + hc;          // wave-uniform rows
+                const float* gi = a.dout + ((long)b * L + i) * D + hc;
+                float krm[DH];
+                load_row<DH>(krm, krb + (long)(jc + L - i) * D, dh);
+                float s = (dot_row_bias<DH>(qi, a.rw + hc, kj, dh) + dot_row_bias<DH>(qi, a.rr + hc, krm, dh)) * a.scale;
+                if (T4R_MASKED(jc, i, klen)) s = T4R_KEY_MASKED;
+                const float p = prob_of(s, a.lse[((long)b * a.n_head + h) * L + i]);
+                float ms = 1.f;
+                if (a.drop.p > 0.f) ms = drop_scale(a.drop, ((unsigned long long)(b * a.n_head + h) * L + i) * L + jc);
+                const float dp = dot_row<DH>(vj, gi, dh) * ms;
+                const float ds = p * (dp - a.delta[((long)b * a.n_head + h) * L + i]) * a.scale;
+                axpy_row_bias<DH>(dk, ds, qi, a.rw + hc, dh);
+                axpy_row<DH>(dv, p * ms, gi, dh);
+            }
+            if (j < L) {
+#pragma unroll
+                for (int d = 0; d < DH; d += 4) {
+                    if (d < dh) {
+                        *reinterpret_cast<float4*>(a.dk + row + d) = make_float4(dk[d], dk[d + 1], dk[d + 2], dk[d + 3]);
+                        *reinterpret_cast<float4*>(a.dv + row + d) = make_float4(dv[d], dv[d + 1], dv[d + 2], dv[d + 3]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int DH, bool SHARED_KR>
+__global__ __launch_bounds__(64) void attn_long_bwd_rel_kernel(LongArgs a) {
+    const int L = a.L, dh = a.dh, D = a.n_head * dh, h = blockIdx.y, hc = h * dh, lane = threadIdx.x;
+    for (int m0 = 0; m0 < 2 * L; m0 += 64) {
+        const int m = m0 + lane, mc = min(m, 2 * L - 1);
+        float acc[DH];
+#pragma unroll
+        for (int d = 0; d < DH; ++d) acc[d] = 0.f;
+        for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+            const float* krb = a.kr + (long)b * a.kr_bstride + hc;
+            const int klen = a.key_len ? a.key_len[b] : L;
+            float krm[DH];
+            load_row<DH>(krm, krb + (long)mc * D, dh);
+            if (!SHARED_KR) {
+#pragma unroll
+                for (int d = 0; d < DH; ++d) acc[d] = 0.f;
+            }
+            for (int i = 0; i < L; ++i) {
+                const int j = mc - L + i;                       // the key this relative position meets query i at
+                const bool hit = j >= 0 && j < L;
+                const int jc = min(max(j, 0), L - 1);
+                const float* qi = a.q + ((long)b * L + i) * D + hc;
+                const float* gi = a.dout + ((long)b * L + i) * D + hc;
+                float kj[DH];
+                load_row<DH>(kj, a.k + ((long)b * L + jc) * D + hc, dh);
+                float s = (dot_row_bias<DH>(qi, a.rw + hc, kj, dh) + dot_row_bias<DH>(qi, a.rr + hc, krm, dh)) * a.scale;
+                if (T4R_MASKED(jc, i, klen)) s = T4R_KEY_MASKED;
+                const float p = hit ? prob_of(s, a.lse[((long)b * a.n_head + h) * L + i]) : 0.f;
+                float dp;
+                {
+                    float vj[DH];
+                    load_row<DH>(vj, a.v + ((long)b * L + jc) * D + hc, dh);
+                    dp = dot_row<DH>(vj, gi, dh);
+                }
+                if (a.drop.p > 0.f) dp *= drop_scale(a.drop, ((unsigned long long)(b * a.n_head + h) * L + i) * L + jc);
+                const float ds = p * (dp - a.delta[((long)b * a.n_head + h) * L + i]) * a.scale;
+                axpy_row_bias<DH>(acc, ds, qi, a.rr + hc, dh);
+            }
+            if (!SHARED_KR && m < 2 * L) {
+                float* o = a.dkr_b + ((long)b * 2 * L + m) * D + hc;
+#pragma unroll
+                for (int d = 0; d < DH; d += 4)
+                    if (d < dh) *reinterpret_cast<float4*>(o + d) = make_float4(acc[d], acc[d + 1], acc[d + 2], acc[d + 3]);
+            }
+        }
+        if (SHARED_KR && m < 2 * L) {
+            float* o = a.part + (long)blockIdx.x * (2L * L * D + 2 * D) + (long)m * D + hc;
+#pragma unroll
+            for (int d = 0; d < DH; d += 4)
+                if (d < dh) *reinterpret_cast<float4*>(o + d) = make_float4(acc[d], acc[d + 1], acc[d + 2], acc[d + 3]);
+        }
+    }
+}
+
+// capacity of the per-thread vectors for a head width
+static int cap_of(int d_head) { return d_head <= 8 ? 8 : d_head <= 16 ? 16 : d_head <= 32 ? 32 : d_head <= 64 ? 64 : 128; }
+
+}  // namespace
+
+int t4r_reduce_partials_launch(hipStream_t st, const float* part, int nblocks, float* o0, int n0, int a0,
+                               float* o1, int n1, int a1, float* o2, int n2, int a2);
+extern "C" int t4r_xlnet_attn_bwd_blocks(int B);
+
+// any L >= 1; head widths that are a multiple of 4 up to 128 (16-byte rows)
+int t4r_xlnet_attn_long_ok(int L, int d_head) { return L >= 1 && d_head >= 4 && d_head <= 128 && d_head % 4 == 0; }
+// floats the backward needs behind the partial rows of t4r_xlnet_attn_bwd_ws_floats: delta [B, n_head, L]
+long t4r_xlnet_attn_long_extra_ws(int B, int L, int n_head, int d_head) {
+    const bool short_ok = L <= 64 && (d_head == 8 || d_head == 16 || d_head == 32);
+    return short_ok ? 0 : (long)B * n_head * L;
+}
+
+int t4r_xlnet_attn_long_fwd(hipStream_t st, const float* q, const float* k, const float* v, const float* kr, const float* rw,
+                            const float* rr, float* out, float* lse, int B, int L, int n_head, int d_head, float scale,
+                            long kr_bstride, DropCfg drop, const int* key_len) {
+    LongArgs a{};
+    a.q = q; a.k = k; a.v = v; a.kr = kr; a.rw = rw; a.rr = rr; a.o = out; a.lse_o = lse;
+    a.B = B; a.L = L; a.n_head = n_head; a.dh = d_head; a.scale = scale; a.kr_bstride = kr_bstride; a.drop = drop; a.key_len = key_len;
+    const dim3 grid(B < 8192 ? B : 8192, n_head), block(64);
+    if (!t4r_xlnet_attn_long_ok(L, d_head)) { t4r_set_error("xlnet_attn: d_head must be a multiple of 4, at most 128"); return -1; }
+    switch (cap_of(d_head)) {
+        case 8: hipLaunchKernelGGL(attn_long_fwd_kernel<8>, grid, block, 0, st, a); break;
+        case 16: hipLaunchKernelGGL(attn_long_fwd_kernel<16>, grid, block, 0, st, a); break;
+        case 32: hipLaunchKernelGGL(attn_long_fwd_kernel<32>, grid, block, 0, st, a); break;
+        case 64: hipLaunchKernelGGL(attn_long_fwd_kernel<64>, grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL(attn_long_fwd_kernel<128>, grid, block, 0, st, a); break;
+    }
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+
+// part: blocks x (2 L D + 2 D) partial rows (the head of t4r_xlnet_attn_bwd_ws_floats' buffer); delta: B n_head L floats behind them
+int t4r_xlnet_attn_long_bwd(hipStream_t st, const float* q, const float* k, const float* v, const float* kr, const float* rw,
+                            const float* rr, const float* out, const float* lse, const float* dout, float* dq, float* dk,
+                            float* dv, float* part, float* delta, float* dkr, float* d_rw, float* d_rr, int B, int L, int n_head,
+                            int d_head, float scale, long kr_bstride, DropCfg drop, const int* key_len) {
+    const int D = n_head * d_head, nblocks = t4r_xlnet_attn_bwd_blocks(B);
+    LongArgs a{};
+    a.q = q; a.k = k; a.v = v; a.kr = kr; a.rw = rw; a.rr = rr; a.out = out; a.lse = lse; a.dout = dout;
+    a.dq = dq; a.dk = dk; a.dv = dv; a.part = part; a.delta = delta;
+    a.dkr_b = kr_bstride > 0 ? dkr : nullptr;
+    a.B = B; a.L = L; a.n_head = n_head; a.dh = d_head; a.scale = scale; a.kr_bstride = kr_bstride; a.drop = drop; a.key_len = key_len;
+    const dim3 grid(nblocks, n_head), block(64);
+    if (!t4r_xlnet_attn_long_ok(L, d_head)) { t4r_set_error("xlnet_attn_bwd: d_head must be a multiple of 4, at most 128"); return -1; }
+    const bool shared = kr_bstride == 0;
+#define T4R_LONG_BWD(DHV)                                                                              \
+    hipLaunchKernelGGL(attn_long_bwd_rows_kernel<DHV>, grid, block, 0, st, a);                         \
+    hipLaunchKernelGGL(attn_long_bwd_keys_kernel<DHV>, grid, block, 0, st, a);                         \
+    if (shared) hipLaunchKernelGGL((attn_long_bwd_rel_kernel<DHV, true>), grid, block, 0, st, a);      \
+    else hipLaunchKernelGGL((attn_long_bwd_rel_kernel<DHV, false>), grid, block, 0, st, a);
+    switch (cap_of(d_head)) {
+        case 8: T4R_LONG_BWD(8) break;
+        case 16: T4R_LONG_BWD(16) break;
+        case 32: T4R_LONG_BWD(32) break;
+        case 64: T4R_LONG_BWD(64) break;
+        default: T4R_LONG_BWD(128) break;
+    }
+#undef T4R_LONG_BWD
+    T4R_LAUNCH_CHECK();
+    // d k_r overwritten (shared k_r: summed over the workgroups here), bias gradients accumulated
+    return t4r_reduce_partials_launch(st, part, nblocks, shared ? dkr : nullptr, 2 * L * D, 0, d_rw, D, 1, d_rr, D, 1);
+}

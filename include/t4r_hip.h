@@ -386,7 +386,8 @@ int t4r_xlnet_attn_bwd(void* stream, const float* q, const float* k, const float
 /* a16  scaled-dot-product attention core of the GPT-2 (causal) and BERT blocks
  * replaces: HF gpt2/modeling_gpt2.py eager_attention_forward :54-72 ; HF bert BertSelfAttention.
  * q,k,v rows of `ld` floats (3*D for GPT-2's fused c_attn output), head h at columns h*d_head..;
- * out/dout rows of ld_out; lse [B,n,L]; L <= 128; d_head 16|32|64.  key_len NULL = no padding mask (the
+ * out/dout rows of ld_out; lse [B,n,L]; any L >= 1 and any d_head that is a multiple of 4 up to 128 (LDS / MFMA kernels up to 128
+ * positions with d_head 16|32|64, the general kernels of csrc/xlnet_attn_long.hip beyond).  key_len NULL = no padding mask (the
  * reference's behaviour); key_len int32 [B] (opt-in): keys >= key_len[b] are masked for every query, as HF does
  * with an attention_mask (finfo.min added to the scores).  drop_p: attention-probability dropout, mask index
  * ((b*n+h)*L+i)*L+j. */

@@ -614,7 +614,7 @@ def prepost_cases(tr, V, L, d, nh):
 def long_cases(tr):
     """Sequences beyond one wave of the attention kernels (total_seq_length 100: the reference takes any length,
     config/transformer.py:432-482): XLNet MLM train / eval / inference (the inference pass runs the body on L + 1 = 101
-    positions, masking.py:406-418) and XLNet CLM train."""
+    positions, masking.py:406-418), XLNet CLM train; GPT-2 CLM and BERT MLM train at total_seq_length 150."""
     L, V, d, nh, nl, B = 100, 300, 32, 2, 2, 6
     m = build(tr, V, L, d, nh, nl, emb_default=d, seed=70)
     x = synth_inputs(B, L, V, (), (), seed=71, min_len=40)
@@ -626,6 +626,14 @@ def long_cases(tr):
     mD = build(tr, V, L, d, nh, nl, masking="clm", emb_default=d, seed=72)
     xD = synth_inputs(B, L, V, (), (), seed=73, min_len=40)
     save("xlnet_clm_long_train", run(mD, xD, True, False, True), n_head=nh, d_model=d, n_layer=nl, eps=0.03, L=L, V=V + 1)
+    # GPT-2 (causal) and BERT beyond 128 positions (the LDS attention kernels' bound), head width 24 (d_model 48, two heads)
+    L, d, B = 150, 48, 4
+    mG = build(tr, V, L, d, nh, 1, masking="clm", emb_default=d, seed=74, arch="gpt2")
+    xG = synth_inputs(B, L, V, (), (), seed=75, min_len=100)
+    save("gpt2_clm_long_train", run(mG, xG, True, False, True), n_head=nh, d_model=d, n_layer=1, eps=1e-5, L=L, V=V + 1)
+    mB = build(tr, V, L, d, nh, 1, emb_default=d, seed=76, arch="bert")
+    xB = synth_inputs(B, L, V, (), (), seed=77, min_len=100)
+    save("bert_mlm_long_train", run(mB, xB, True, False, True), n_head=nh, d_model=d, n_layer=1, eps=0.03, L=L, V=V + 1)
 
 
 if __name__ == "__main__":

@@ -100,6 +100,9 @@ def run_train_case(name, **build_kw):
     # total_seq_length 100: the general attention kernels of csrc/xlnet_attn_long.hip (round 6)
     ("xlnet_mlm_long_train", dict(emb_default=32)),
     ("xlnet_clm_long_train", dict(masking="clm", emb_default=32)),
+    # total_seq_length 150, d_head 24: beyond the LDS kernels of the GPT-2 / BERT attention core (128 positions, d_head 16 / 32 / 64)
+    ("gpt2_clm_long_train", dict(masking="clm", emb_default=48, arch="gpt2")),
+    ("bert_mlm_long_train", dict(emb_default=48, arch="bert")),
 ])
 def test_train_step_matches_reference(name, kw):
     d, model, x, cap, hooks = run_train_case(name, **kw)

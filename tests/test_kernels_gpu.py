@@ -687,7 +687,11 @@ def test_gemm_softmax_grad_fused(ops, N, V, D, eps):
 @pytest.mark.parametrize("B,L,D,n,causal,p", [(4, 20, 64, 4, True, 0.0), (3, 50, 128, 2, True, 0.0), (2, 100, 128, 2, False, 0.0),
                                               (3, 33, 64, 4, False, 0.1), (2, 21, 32, 2, True, 0.3), (2, 128, 32, 1, True, 0.0),
                                               (3, 33, 128, 4, False, 0.1), (2, 100, 512, 8, True, 0.2), (2, 65, 64, 2, False, 0.0),
-                                              (5, 7, 64, 1, True, 0.0), (2, 96, 128, 2, False, 0.3)])
+                                              (5, 7, 64, 1, True, 0.0), (2, 96, 128, 2, False, 0.3),
+                                              # beyond 128 positions / head widths without an LDS-kernel instance (general kernels,
+                                              # csrc/xlnet_attn_long.hip): d_head 32, 64, 48, 8, 128, 24
+                                              (2, 129, 64, 2, True, 0.0), (2, 200, 128, 2, False, 0.2), (3, 50, 96, 2, True, 0.1),
+                                              (2, 33, 16, 2, False, 0.0), (2, 70, 256, 2, True, 0.3), (1040, 130, 24, 1, True, 0.0)])
 def test_mha_fwd_bwd(ops, B, L, D, n, causal, p):
     g = torch.Generator().manual_seed(B + L + D + int(causal))
     dh = D // n
@@ -1052,7 +1056,8 @@ def test_xlnet_attention_padding_mask(ops, B, L, D, n):
 
 
 @pytest.mark.parametrize("B,L,D,n,causal,p", [(4, 20, 64, 2, True, 0.0), (3, 50, 128, 2, True, 0.0), (4, 100, 128, 2, False, 0.0),
-                                              (3, 33, 32, 2, False, 0.0), (3, 21, 64, 2, True, 0.2), (4, 96, 256, 4, False, 0.1)])
+                                              (3, 33, 32, 2, False, 0.0), (3, 21, 64, 2, True, 0.2), (4, 96, 256, 4, False, 0.1),
+                                              (3, 150, 64, 2, True, 0.1), (3, 140, 96, 2, False, 0.0)])
 def test_mha_padding_mask(ops, B, L, D, n, causal, p):
     """opt-in key padding mask of the GPT-2 / BERT attention core (both kernel families) vs the oracle's sdpa,
     whose mask is pinned against HF in tests/test_oracle_vs_hf.py; None keeps the unmasked reference behaviour."""

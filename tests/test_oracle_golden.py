@@ -244,7 +244,8 @@ def test_sampled_softmax_golden():
     torch.testing.assert_close(p["tables"]["item_id"].grad, g[gu.CAT + "item_id.weight"], **TOL)
 
 
-@pytest.mark.parametrize("name,arch", [("gpt2_clm_item_train", "gpt2"), ("bert_mlm_item_train", "bert")])
+@pytest.mark.parametrize("name,arch", [("gpt2_clm_item_train", "gpt2"), ("bert_mlm_item_train", "bert"),
+                                       ("gpt2_clm_long_train", "gpt2"), ("bert_mlm_long_train", "bert")])      # total_seq_length 150
 def test_gpt2_bert_block_golden(name, arch):
     """inputs_embeds -> hidden of the reference's TransformerBlock(GPT2Config / BertConfig) fixtures."""
     d = gu.load(name)

@@ -307,6 +307,144 @@ __global__ __launch_bounds__(64) void attn_long_bwd_rel_kernel(LongArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same for the scaled-dot-product core of the GPT-2 / BERT blocks (mha.hip: one workgroup per (session, head) with the
+// head's K / V in LDS stops at 128 positions and d_head 16 / 32 / 64; HF gpt2/modeling_gpt2.py eager_attention_forward :54-72,
+// bert/modeling_bert.py BertSelfAttention, built by transformers4rec/config/transformer.py:218-260, :493-534 for ANY
+// total_seq_length / d_model).  Same conventions as mha.hip: keys j < min(causal ? i + 1 : L, clamp(key_len[b], 1, L)) take
+// part; dropout mask index ((b n_head + h) L + i) L + j; rows of ld / ld_out / ld_d floats.
+struct MhaLongArgs {
+    const float *q, *k, *v, *out, *dout, *lse;
+    float *o, *lse_o, *dq, *dk, *dv;
+    long ld, ld_out, ld_d;
+    int B, L, n_head, dh, causal;
+    float scale;
+    DropCfg drop;
+    const int* key_len;
+};
+
+template <int DH>
+__global__ __launch_bounds__(64) void mha_long_fwd_kernel(MhaLongArgs a) {
+    const int L = a.L, dh = a.dh, h = blockIdx.y, hc = h * dh, lane = threadIdx.x;
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const int klen = a.key_len ? max(1, min(L, a.key_len[b])) : L;
+        for (int i0 = 0; i0 < L; i0 += 64) {
+            const int i = i0 + lane, ic = min(i, L - 1);
+            float qi[DH], o[DH];
+            load_row<DH>(qi, a.q + ((long)b * L + ic) * a.ld + hc, dh);
+#pragma unroll
+            for (int d = 0; d < DH; ++d) o[d] = 0.f;
+            float m = -INFINITY, l = 0.f;
+            const int jend = min(a.causal ? ic + 1 : L, klen);
+            const int jmax = min(a.causal ? min(i0 + 64, L) : L, klen);       // wave-uniform bound: the rows of k / v stay broadcasts
+            for (int j = 0; j < jmax; ++j) {
+                const bool on = j < jend;
+                const float s = on ? dot_row<DH>(qi, a.k + ((long)b * L + j) * a.ld + hc, dh) * a.scale : -INFINITY;
+                const float mn = fmaxf(m, s);
+                const float alpha = mn == -INFINITY ? 1.f : __expf(m - mn), pj = on ? __expf(s - mn) : 0.f;
+                l = l * alpha + pj;
+                float pd = pj;
+                if (a.drop.p > 0.f) pd *= drop_scale(a.drop, ((unsigned long long)(b * a.n_head + h) * L + ic) * L + j);
+#pragma unroll
+                for (int d = 0; d < DH; ++d) o[d] *= alpha;
+                axpy_row<DH>(o, pd, a.v + ((long)b * L + j) * a.ld + hc, dh);
+                m = mn;
+            }
+            if (i < L) {
+                const float inv = 1.f / l;
+                float* orow = a.o + ((long)b * L + i) * a.ld_out + hc;
+#pragma unroll
+                for (int d = 0; d < DH; d += 4)
+                    if (d < dh) *reinterpret_cast<float4*>(orow + d) = make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
+                a.lse_o[((long)b * a.n_head + h) * L + i] = m + __logf(l);
+            }
+        }
+    }
+}
+
+// d q: thread = query row
+template <int DH>
+__global__ __launch_bounds__(64) void mha_long_bwd_rows_kernel(MhaLongArgs a) {
+    const int L = a.L, dh = a.dh, h = blockIdx.y, hc = h * dh, lane = threadIdx.x;
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const int klen = a.key_len ? max(1, min(L, a.key_len[b])) : L;
+        for (int i0 = 0; i0 < L; i0 += 64) {
+            const int i = i0 + lane, ic = min(i, L - 1);
+            float qi[DH], g[DH], dq[DH];
+            load_row<DH>(qi, a.q + ((long)b * L + ic) * a.ld + hc, dh);
+            load_row<DH>(g, a.dout + ((long)b * L + ic) * a.ld_out + hc, dh);
+            const float delta = dot_row<DH>(g, a.out + ((long)b * L + ic) * a.ld_out + hc, dh);
+#pragma unroll
+            for (int d = 0; d < DH; ++d) dq[d] = 0.f;
+            const float lrow = a.lse[((long)b * a.n_head + h) * L + ic];
+            const int jend = min(a.causal ? ic + 1 : L, klen);
+            const int jmax = min(a.causal ? min(i0 + 64, L) : L, klen);
+            for (int j = 0; j < jmax; ++j) {
+                const float* kj = a.k + ((long)b * L + j) * a.ld + hc;
+                const float p = j < jend ? __expf(dot_row<DH>(qi, kj, dh) * a.scale - lrow) : 0.f;
+                float dp = dot_row<DH>(g, a.v + ((long)b * L + j) * a.ld + hc, dh);
+                if (a.drop.p > 0.f) dp *= drop_scale(a.drop, ((unsigned long long)(b * a.n_head + h) * L + ic) * L + j);
+                axpy_row<DH>(dq, p * (dp - delta) * a.scale, kj, dh);
+            }
+            if (i < L) {
+                float* o = a.dq + ((long)b * L + i) * a.ld_d + hc;
+#pragma unroll
+                for (int d = 0; d < DH; d += 4)
+                    if (d < dh) *reinterpret_cast<float4*>(o + d) = make_float4(dq[d], dq[d + 1], dq[d + 2], dq[d + 3]);
+            }
+        }
+    }
+}
+
+// d k, d v: thread = key; the rows of q / d out / out are wave-uniform, delta_i = d out_i . out_i is recomputed per row
+template <int DH>
+__global__ __launch_bounds__(64) void mha_long_bwd_keys_kernel(MhaLongArgs a) {
+    const int L = a.L, dh = a.dh, h = blockIdx.y, hc = h * dh, lane = threadIdx.x;
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const int klen = a.key_len ? max(1, min(L, a.key_len[b])) : L;
+        for (int j0 = 0; j0 < L; j0 += 64) {
+            const int j = j0 + lane, jc = min(j, L - 1);
+            float kj[DH], vj[DH], dk[DH], dv[DH];
+            load_row<DH>(kj, a.k + ((long)b * L + jc) * a.ld + hc, dh);
+            load_row<DH>(vj, a.v + ((long)b * L + jc) * a.ld + hc, dh);
+#pragma unroll
+            for (int d = 0; d < DH; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+            const bool key_on = jc < klen;
+            for (int i = a.causal ? j0 : 0; i < L; ++i) {
+                const float* qi = a.q + ((long)b * L + i) * a.ld + hc;
+                const float* gi = a.dout + ((long)b * L + i) * a.ld_out + hc;
+                const float* oi = a.out + ((long)b * L + i) * a.ld_out + hc;
+                float delta = 0.f;
+#pragma unroll
+                for (int d = 0; d < DH; d += 4) {
+                    if (d < dh) {
+                        const float4 x = *reinterpret_cast<const float4*>(gi + d), y = *reinterpret_cast<const float4*>(oi + d);
+                        delta += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+                    }
+                }
+                const bool on = key_on && (!a.causal || jc <= i);
+                const float p = on ? __expf(dot_row<DH>(kj, qi, dh) * a.scale - a.lse[((long)b * a.n_head + h) * L + i]) : 0.f;
+                float ms = 1.f;
+                if (a.drop.p > 0.f) ms = drop_scale(a.drop, ((unsigned long long)(b * a.n_head + h) * L + i) * L + jc);
+                const float dp = dot_row<DH>(vj, gi, dh) * ms;
+                axpy_row<DH>(dk, p * (dp - delta) * a.scale, qi, dh);
+                axpy_row<DH>(dv, p * ms, gi, dh);
+            }
+            if (j < L) {
+                float* ok = a.dk + ((long)b * L + j) * a.ld_d + hc;
+                float* ov = a.dv + ((long)b * L + j) * a.ld_d + hc;
+#pragma unroll
+                for (int d = 0; d < DH; d += 4) {
+                    if (d < dh) {
+                        *reinterpret_cast<float4*>(ok + d) = make_float4(dk[d], dk[d + 1], dk[d + 2], dk[d + 3]);
+                        *reinterpret_cast<float4*>(ov + d) = make_float4(dv[d], dv[d + 1], dv[d + 2], dv[d + 3]);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // capacity of the per-thread vectors for a head width
 static int cap_of(int d_head) { return d_head <= 8 ? 8 : d_head <= 16 ? 16 : d_head <= 32 ? 32 : d_head <= 64 ? 64 : 128; }
 
@@ -373,4 +511,45 @@ int t4r_xlnet_attn_long_bwd(hipStream_t st, const float* q, const float* k, cons
     T4R_LAUNCH_CHECK();
     // d k_r overwritten (shared k_r: summed over the workgroups here), bias gradients accumulated
     return t4r_reduce_partials_launch(st, part, nblocks, shared ? dkr : nullptr, 2 * L * D, 0, d_rw, D, 1, d_rr, D, 1);
+}
+
+// ---- scaled-dot-product core (GPT-2 / BERT): any L, d_head a multiple of 4 up to 128
+int t4r_mha_long_ok(int L, int d_head) { return t4r_xlnet_attn_long_ok(L, d_head); }
+int t4r_mha_long_fwd(hipStream_t st, const float* q, const float* k, const float* v, long ld, float* out, long ld_out, float* lse,
+                     int B, int L, int n_head, int d_head, float scale, int causal, DropCfg drop, const int* key_len) {
+    MhaLongArgs a{};
+    a.q = q; a.k = k; a.v = v; a.o = out; a.lse_o = lse; a.ld = ld; a.ld_out = ld_out;
+    a.B = B; a.L = L; a.n_head = n_head; a.dh = d_head; a.causal = causal; a.scale = scale; a.drop = drop; a.key_len = key_len;
+    const dim3 grid(B < 8192 ? B : 8192, n_head), block(64);
+    switch (cap_of(d_head)) {
+        case 8: hipLaunchKernelGGL(mha_long_fwd_kernel<8>, grid, block, 0, st, a); break;
+        case 16: hipLaunchKernelGGL(mha_long_fwd_kernel<16>, grid, block, 0, st, a); break;
+        case 32: hipLaunchKernelGGL(mha_long_fwd_kernel<32>, grid, block, 0, st, a); break;
+        case 64: hipLaunchKernelGGL(mha_long_fwd_kernel<64>, grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL(mha_long_fwd_kernel<128>, grid, block, 0, st, a); break;
+    }
+    T4R_LAUNCH_CHECK();
+    return 0;
+}
+int t4r_mha_long_bwd(hipStream_t st, const float* q, const float* k, const float* v, long ld, const float* out, const float* dout,
+                     long ld_out, const float* lse, float* dq, float* dk, float* dv, long ld_d, int B, int L, int n_head,
+                     int d_head, float scale, int causal, DropCfg drop, const int* key_len) {
+    MhaLongArgs a{};
+    a.q = q; a.k = k; a.v = v; a.out = out; a.dout = dout; a.lse = lse; a.dq = dq; a.dk = dk; a.dv = dv;
+    a.ld = ld; a.ld_out = ld_out; a.ld_d = ld_d;
+    a.B = B; a.L = L; a.n_head = n_head; a.dh = d_head; a.causal = causal; a.scale = scale; a.drop = drop; a.key_len = key_len;
+    const dim3 grid(B < 8192 ? B : 8192, n_head), block(64);
+#define T4R_MHA_LONG_BWD(DHV)                                                        \
+    hipLaunchKernelGGL(mha_long_bwd_rows_kernel<DHV>, grid, block, 0, st, a);        \
+    hipLaunchKernelGGL(mha_long_bwd_keys_kernel<DHV>, grid, block, 0, st, a);
+    switch (cap_of(d_head)) {
+        case 8: T4R_MHA_LONG_BWD(8) break;
+        case 16: T4R_MHA_LONG_BWD(16) break;
+        case 32: T4R_MHA_LONG_BWD(32) break;
+        case 64: T4R_MHA_LONG_BWD(64) break;
+        default: T4R_MHA_LONG_BWD(128) break;
+    }
+#undef T4R_MHA_LONG_BWD
+    T4R_LAUNCH_CHECK();
+    return 0;
 }

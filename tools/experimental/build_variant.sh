@@ -14,7 +14,7 @@ rm -f $OUT/exp_obj/*.o
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result -DT4R_EXPERIMENTAL=1 -I$CSRC"
 n=0
 pids=()
-for src in $CSRC/*.hip $ROOT/tools/experimental/wgrad_stream.hip; do
+for src in $CSRC/*.hip $ROOT/tools/experimental/wgrad_stream.hip $ROOT/tools/experimental/wgrad_units.hip; do
   /opt/rocm/bin/hipcc $FLAGS -c $src -o $OUT/exp_obj/$(basename ${src%.hip}).o & pids+=($!)
   n=$((n + 1))
   if [ $((n % 8)) -eq 0 ]; then for p in "${pids[@]}"; do wait $p; done; pids=(); fi

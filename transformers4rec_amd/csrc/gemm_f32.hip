@@ -196,6 +196,10 @@ void t4r_gemm_operand_amax2(const float* a, int na, const float* b, int nb) { g_
 void t4r_wgrad_stream_plan(int K, int* splits, int* kper);
 bool t4r_wgrad_stream_ok(const GemmParams& p);
 int t4r_wgrad_stream_launch(const GemmParams& p, int batch, int kper, float* part, hipStream_t st);
+// tools/experimental/wgrad_units.hip: read-once, cut-once 128 x 128 units in the two-way fp16 form (T4R_WGRAD_UNITS=1)
+void t4r_wgrad_units_plan(int K, int* splits, int* kper);
+bool t4r_wgrad_units_ok(const GemmParams& p);
+int t4r_wgrad_units_launch(const GemmParams& p, int batch, int kper, float* part, hipStream_t st);
 #endif
 
 template <bool TA, bool TB>
@@ -214,6 +218,18 @@ static int launch_layout(GemmParams& p, int batch, int splitk_req, hipStream_t s
         float* part = splitk_sink_take(p, batch);
         if (part) return t4r_wgrad_stream_launch(p, batch, kper, part, stream);
         p.splitk = 1;
+    }
+    if (TA && !TB && splitk_req < 0 && g_sink.on && amax_a && amax_b) {
+        p.amaxA = amax_a; p.amaxB = amax_b; p.n_amax = amax_n; p.n_amax_b = amax_nb;
+        if (t4r_wgrad_units_ok(p)) {
+            int splits = 1, kper = 0;
+            t4r_wgrad_units_plan(p.K, &splits, &kper);
+            p.splitk = splits;
+            float* part = splitk_sink_take(p, batch);
+            if (part) return t4r_wgrad_units_launch(p, batch, kper, part, stream);
+            p.splitk = 1;
+        }
+        p.amaxA = p.amaxB = nullptr; p.n_amax = p.n_amax_b = 0;
     }
 #endif
     // tokens x small weight in an fp32-accurate mode: the token-stationary kernel (operands cut once, tok_gemm.hip)

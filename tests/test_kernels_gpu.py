@@ -380,7 +380,9 @@ ORDER = ("q", "k", "v", "o", "r", "r_w_bias", "r_r_bias", "ln_w", "ln_b", "w1", 
                                      # beyond one wave (csrc/xlnet_attn_long.hip): d_head 16, 16, 64, 8, 32; row blocks 2 .. 4
                                      (2, 65, 32, 2), (3, 100, 64, 4), (2, 130, 128, 2), (1, 200, 16, 2), (1030, 70, 32, 1),
                                      # head widths without a one-wave instance: 48, 64, 128, 24, 12, 40
-                                     (3, 20, 96, 2), (2, 33, 256, 4), (2, 20, 256, 2), (2, 100, 48, 2), (2, 20, 24, 2), (5, 9, 40, 1)])
+                                     (3, 20, 96, 2), (2, 33, 256, 4), (2, 20, 256, 2), (2, 100, 48, 2), (2, 20, 24, 2), (5, 9, 40, 1),
+                                     # one-wave shapes whose K / V / k_r rows do not fit the LDS of the VALU kernels
+                                     (2, 50, 256, 8), (2, 64, 512, 16), (3, 40, 512, 32)])
 def test_xlnet_attention_core(ops, B, L, D, n):
     g = torch.Generator().manual_seed(B * L + D)
     dh = D // n
@@ -560,7 +562,8 @@ def test_act_bwd_dropout(ops):
 
 
 @pytest.mark.parametrize("B,L,D,n", [(5, 20, 64, 4), (3, 21, 128, 4), (4, 9, 32, 2), (2, 32, 64, 2), (1030, 3, 32, 1),
-                                     (3, 100, 64, 4), (2, 70, 128, 2), (1030, 66, 16, 1), (3, 20, 192, 4), (2, 40, 256, 2)])
+                                     (3, 100, 64, 4), (2, 70, 128, 2), (1030, 66, 16, 1), (3, 20, 192, 4), (2, 40, 256, 2),
+                                     (2, 50, 256, 8), (2, 48, 512, 16)])
 def test_xlnet_attention_dropout_per_session_kr(ops, B, L, D, n):
     g = torch.Generator().manual_seed(B + L + D)
     dh = D // n

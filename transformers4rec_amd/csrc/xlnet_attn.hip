@@ -509,10 +509,24 @@ static long attn_bwd_part_floats(int B, int L, int D, int n_head) {
     const int hpb = (D / n_head) >= 32 ? 4 : 8;
     return (long)t4r_xlnet_attn_bwd_blocks(B) * ((n_head + hpb - 1) / hpb) * (2L * L * D + 2L * D);
 }
-// the general kernels for L > 64 (xlnet_attn_long.hip) keep delta [B, n_head, L] behind the partial rows
-long t4r_xlnet_attn_long_extra_ws(int B, int L, int n_head, int d_head);
+int t4r_xlnet_attn_mfma_ok(int L, int d_head);
+// Which shapes leave the one-wave kernels for the general ones of xlnet_attn_long.hip: more than 64 positions, a head width
+// without an instance, or (VALU kernels only: 32 < L <= 64, or d_head 8) a session whose K / V / k_r rows do not fit the LDS.
+// dir: 0 forward, 1 backward with the shared k_r, 2 backward with per-session k_r, 3 either backward form
+static bool attn_uses_long(int L, int D, int n_head, int dir) {
+    const int d_head = n_head > 0 ? D / n_head : 0;
+    if (L > 64 || !(d_head == 8 || d_head == 16 || d_head == 32)) return true;
+    if (t4r_xlnet_attn_mfma_ok(L, d_head)) return false;            // (an experiment build may switch the MFMA kernels off: it
+                                                                    // then fails loudly on the LDS check below, as before)
+    const size_t lim = 160 * 1024;
+    if (dir == 0) return attn_fwd_smem(L, D) > lim;
+    if (dir == 1) return attn_bwd_smem(L, D, n_head, 0) > lim;
+    if (dir == 2) return attn_bwd_smem(L, D, n_head, 1) > lim;
+    return attn_bwd_smem(L, D, n_head, 0) > lim || attn_bwd_smem(L, D, n_head, 1) > lim;
+}
+// the general kernels keep delta [B, n_head, L] behind the partial rows
 extern "C" long t4r_xlnet_attn_bwd_ws_floats(int B, int L, int D, int n_head) {
-    return attn_bwd_part_floats(B, L, D, n_head) + t4r_xlnet_attn_long_extra_ws(B, L, n_head, n_head > 0 ? D / n_head : 0);
+    return attn_bwd_part_floats(B, L, D, n_head) + (attn_uses_long(L, D, n_head, 3) ? (long)B * n_head * L : 0L);
 }
 int t4r_xlnet_attn_long_ok(int L, int d_head);
 int t4r_xlnet_attn_long_fwd(hipStream_t st, const float* q, const float* k, const float* v, const float* kr, const float* rw,
@@ -577,8 +591,8 @@ extern "C" int t4r_xlnet_attn_fwd(void* stream, const float* q, const float* k, 
     hipStream_t st = (hipStream_t)stream;
     const long bs = kr_per_batch ? 2L * L * D : 0;
     const DropCfg dc = make_drop(drop_p, seed, ctr_hi);
-    if (L > 64 || !(d_head == 8 || d_head == 16 || d_head == 32)) {       // beyond one wave per row block, or a head width the
-        // one-wave kernels have no instance for: the general kernels (any L, d_head a multiple of 4 up to 128)
+    if (attn_uses_long(L, D, n_head, 0)) {       // beyond one wave per row block, a head width the one-wave kernels have no
+        // instance for, or rows that do not fit the LDS: the general kernels (any L, d_head a multiple of 4 up to 128)
         T4R_CHECK_ARG(t4r_xlnet_attn_long_ok(L, d_head), "xlnet_attn: d_head must be a multiple of 4, at most 128");
         return t4r_xlnet_attn_long_fwd(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, B, L, n_head, d_head, scale, bs, dc, key_len);
     }
@@ -644,7 +658,7 @@ extern "C" int t4r_xlnet_attn_bwd(void* stream, const float* q, const float* k, 
     hipStream_t st = (hipStream_t)stream;
     const long bs = kr_per_batch ? 2L * L * D : 0;
     const DropCfg dc = make_drop(drop_p, seed, ctr_hi);
-    if (L > 64 || !(d_head == 8 || d_head == 16 || d_head == 32)) {
+    if (attn_uses_long(L, D, n_head, kr_per_batch ? 2 : 1)) {
         T4R_CHECK_ARG(t4r_xlnet_attn_long_ok(L, d_head), "xlnet_attn_bwd: d_head must be a multiple of 4, at most 128");
         T4R_CHECK_ARG(out != nullptr, "xlnet_attn_bwd: the forward output is needed by the general kernels (L > 64 or d_head not 8 / 16 / 32)");
         return t4r_xlnet_attn_long_bwd(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, dout, dq, dk, dv, workspace,

@@ -456,12 +456,6 @@ extern "C" int t4r_xlnet_attn_bwd_blocks(int B);
 
 // any L >= 1; head widths that are a multiple of 4 up to 128 (16-byte rows)
 int t4r_xlnet_attn_long_ok(int L, int d_head) { return L >= 1 && d_head >= 4 && d_head <= 128 && d_head % 4 == 0; }
-// floats the backward needs behind the partial rows of t4r_xlnet_attn_bwd_ws_floats: delta [B, n_head, L]
-long t4r_xlnet_attn_long_extra_ws(int B, int L, int n_head, int d_head) {
-    const bool short_ok = L <= 64 && (d_head == 8 || d_head == 16 || d_head == 32);
-    return short_ok ? 0 : (long)B * n_head * L;
-}
-
 int t4r_xlnet_attn_long_fwd(hipStream_t st, const float* q, const float* k, const float* v, const float* kr, const float* rw,
                             const float* rr, float* out, float* lse, int B, int L, int n_head, int d_head, float scale,
                             long kr_bstride, DropCfg drop, const int* key_len) {

@@ -219,13 +219,13 @@ def test_construction_time_limits():
     import transformers4rec_amd as tr
 
     # (round 6: the attention kernels take any length -- csrc/xlnet_attn_long.hip beyond 64 positions --; what bounds an
-    # XLNet sequence is the MLM target kernel's 255 positions)
-    schema = tr.session_schema(100, 255)
-    mlm = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=255, masking="mlm", embedding_dim_default=16)
-    clm = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=255, masking="clm", embedding_dim_default=16)
-    cfg = tr.XLNetConfig.build(16, 2, 1, total_seq_length=255)
-    tr.TransformerBlock(cfg, masking=clm.masking)                      # 255 positions fit
-    with pytest.raises(ValueError, match="at most 255"):               # MLM inference needs L + 1 = 256
+    # XLNet sequence is the target kernel's 1023 positions)
+    schema = tr.session_schema(100, 1023)
+    mlm = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=1023, masking="mlm", embedding_dim_default=16)
+    clm = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=1023, masking="clm", embedding_dim_default=16)
+    cfg = tr.XLNetConfig.build(16, 2, 1, total_seq_length=1023)
+    tr.TransformerBlock(cfg, masking=clm.masking)                      # 1023 positions fit
+    with pytest.raises(ValueError, match="at most 1023"):              # MLM inference needs L + 1 = 1024
         tr.TransformerBlock(cfg, masking=mlm.masking)
     tr.TransformerBlock(tr.XLNetConfig.build(16, 2, 1, total_seq_length=100), masking=mlm.masking)     # 64 is no limit any more
     # labels are item ids: a smaller target_dim would index out of range in the head kernels

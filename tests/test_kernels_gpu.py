@@ -382,7 +382,9 @@ ORDER = ("q", "k", "v", "o", "r", "r_w_bias", "r_r_bias", "ln_w", "ln_b", "w1", 
                                      # head widths without a one-wave instance: 48, 64, 128, 24, 12, 40
                                      (3, 20, 96, 2), (2, 33, 256, 4), (2, 20, 256, 2), (2, 100, 48, 2), (2, 20, 24, 2), (5, 9, 40, 1),
                                      # one-wave shapes whose K / V / k_r rows do not fit the LDS of the VALU kernels
-                                     (2, 50, 256, 8), (2, 64, 512, 16), (3, 40, 512, 32)])
+                                     (2, 50, 256, 8), (2, 64, 512, 16), (3, 40, 512, 32),
+                                     # d_head 160, 256 (per-thread vectors in scratch)
+                                     (2, 20, 320, 2), (2, 70, 256, 1)])
 def test_xlnet_attention_core(ops, B, L, D, n):
     g = torch.Generator().manual_seed(B * L + D)
     dh = D // n
@@ -694,7 +696,8 @@ def test_gemm_softmax_grad_fused(ops, N, V, D, eps):
                                               # beyond 128 positions / head widths without an LDS-kernel instance (general kernels,
                                               # csrc/xlnet_attn_long.hip): d_head 32, 64, 48, 8, 128, 24
                                               (2, 129, 64, 2, True, 0.0), (2, 200, 128, 2, False, 0.2), (3, 50, 96, 2, True, 0.1),
-                                              (2, 33, 16, 2, False, 0.0), (2, 70, 256, 2, True, 0.3), (1040, 130, 24, 1, True, 0.0)])
+                                              (2, 33, 16, 2, False, 0.0), (2, 70, 256, 2, True, 0.3), (1040, 130, 24, 1, True, 0.0),
+                                              (2, 20, 320, 2, True, 0.1), (2, 140, 256, 1, False, 0.0)])
 def test_mha_fwd_bwd(ops, B, L, D, n, causal, p):
     g = torch.Generator().manual_seed(B + L + D + int(causal))
     dh = D // n

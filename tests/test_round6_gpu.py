@@ -50,7 +50,7 @@ def test_dropout_site_restatement_equals_the_device_mask(ops, n, p):
         assert np.array_equal(m.cpu().numpy(), R.dropout_keep(seed, ctr, n, p)), (offset, layer, site)
 
 
-@pytest.mark.parametrize("B,L", [(1024, 20), (257, 33), (64, 64)])
+@pytest.mark.parametrize("B,L", [(1024, 20), (257, 33), (64, 64), (33, 255), (21, 300), (9, 1023)])
 def test_mlm_draw_restatement_equals_the_device_targets(ops, B, L):
     g = torch.Generator().manual_seed(B + L)
     lens = torch.randint(1, L + 1, (B,), generator=g)

@@ -19,15 +19,16 @@
 //   * device Philox draws (seed, offset) -- the production path: j1 uniform over the non-pad
 //     positions, j2 uniform over the labelled positions (the distributions torch.multinomial
 //     samples from with 0/1 weights).
-// One wave per session row; a row's non-pad / label sets are 64-bit ballots (L <= 64*MAXC).
+// One wave per session row; a row's non-pad / label sets are 64-bit ballots (L <= 64*MAXC - 1; MAXC is a template parameter:
+// 4 words up to 255 positions -- every configuration of BASELINE.json --, 16 up to 1023).
 #include "t4r_common.h"
 
-#define MAXC 4  // L <= 256
 
 enum { MLM_TRAIN = 0, MLM_EVAL_LAST = 1, MLM_EVAL_ALL = 2, MLM_INFER = 3,
        CLM_TRAIN = 4, CLM_LAST = 5, CLM_INFER = 6 };
 
 // index of the k-th (0-based) set bit over the chunked bitset; -1 if none
+template <int MAXC>
 __device__ __forceinline__ int select_kth(const unsigned long long (&bits)[MAXC + 1], int k) {
     int res = -1;
 #pragma unroll
@@ -43,16 +44,19 @@ __device__ __forceinline__ int select_kth(const unsigned long long (&bits)[MAXC 
     return res;
 }
 // static-index helpers (runtime-indexed register arrays would spill to scratch)
+template <int MAXC>
 __device__ __forceinline__ void bit_or(unsigned long long (&bits)[MAXC + 1], int idx, const unsigned long long (&andmask)[MAXC + 1], bool use_and) {
 #pragma unroll
     for (int c = 0; c < MAXC + 1; ++c)
         if (c == (idx >> 6)) bits[c] |= (1ull << (idx & 63)) & (use_and ? andmask[c] : ~0ull);
 }
+template <int MAXC>
 __device__ __forceinline__ void bit_clear(unsigned long long (&bits)[MAXC + 1], int idx) {
 #pragma unroll
     for (int c = 0; c < MAXC + 1; ++c)
         if (c == (idx >> 6)) bits[c] &= ~(1ull << (idx & 63));
 }
+template <int MAXC>
 __device__ __forceinline__ int popc_all(const unsigned long long (&bits)[MAXC + 1]) {
     int n = 0;
 #pragma unroll
@@ -60,6 +64,7 @@ __device__ __forceinline__ int popc_all(const unsigned long long (&bits)[MAXC + 
     return n;
 }
 
+template <int MAXC>
 __global__ __launch_bounds__(256) void mask_targets_kernel(
     const long* __restrict__ ids, int B, int L, int mode, long padding_idx,
     // injected draws (train) -- any may be null => Philox
@@ -114,20 +119,20 @@ __global__ __launch_bounds__(256) void mask_targets_kernel(
             int j1, j2;
             uint4 r = rng(offset + (unsigned long long)b, 1);
             if (j1_in) j1 = (int)j1_in[b];
-            else j1 = select_kth(nonpad, min(n_nonpad - 1, (int)(u32_to_unit(r.x) * n_nonpad)));
-            if (j1 >= 0 && j1 < L) bit_or(lab, j1, nonpad, true);
-            const int n_lab = popc_all(lab);
+            else j1 = select_kth<MAXC>(nonpad, min(n_nonpad - 1, (int)(u32_to_unit(r.x) * n_nonpad)));
+            if (j1 >= 0 && j1 < L) bit_or<MAXC>(lab, j1, nonpad, true);
+            const int n_lab = popc_all<MAXC>(lab);
             if (n_lab == n_nonpad) {
                 if (j2_in) j2 = (int)j2_in[b];
-                else j2 = select_kth(lab, min(n_lab - 1, (int)(u32_to_unit(r.y) * n_lab)));
-                if (j2 >= 0 && j2 < L) bit_clear(lab, j2);
+                else j2 = select_kth<MAXC>(lab, min(n_lab - 1, (int)(u32_to_unit(r.y) * n_lab)));
+                if (j2 >= 0 && j2 < L) bit_clear<MAXC>(lab, j2);
             }
         }
     } else if (mode == MLM_EVAL_LAST) {
         // labels[b, len-1] = ids[b, len-1]   (len = count of non-pad; reference indexes by count)
         const int last = n_nonpad - 1;  // -1 wraps to L-1 in torch indexing
         const int idx = last < 0 ? L - 1 : last;
-        bit_or(lab, idx, nonpad, true);
+        bit_or<MAXC>(lab, idx, nonpad, true);
     } else if (mode == MLM_EVAL_ALL || mode == CLM_TRAIN || mode == CLM_LAST) {
         // predict_all: labels[l] = ids[l+1] (0 at L-1); mask = labels != pad
 #pragma unroll
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(256) void mask_targets_kernel(
             }
         }
         if (mode == CLM_LAST) {
-            const int last = popc_all(lab) - 1;
+            const int last = popc_all<MAXC>(lab) - 1;
             const int idx = last < 0 ? L - 1 : last;
             // keep only labels[idx] (it may itself be pad -> no label at all)
 #pragma unroll
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(256) void mask_targets_kernel(
         const int idx = n_nonpad;                 // 0..L
         const int src = n_nonpad - 1 < 0 ? L - 1 : n_nonpad - 1;
         const long v = row[src];
-        if (v != padding_idx) bit_or(lab, idx, nonpad, false);
+        if (v != padding_idx) bit_or<MAXC>(lab, idx, nonpad, false);
 #pragma unroll
         for (int c = 0; c < MAXC + 1; ++c) labval[c] = v;
     } else {  // CLM_INFER: mask = ids != pad, labels = ids
@@ -182,12 +187,17 @@ extern "C" int t4r_mask_targets(void* stream, const long* item_ids, int B, int L
                                 const long* j2, float mlm_probability, unsigned long long seed,
                                 unsigned long long offset, unsigned char* mask_schema,
                                 long* masked_targets, int* row_count) {
-    T4R_CHECK_ARG(L >= 1 && L <= 64 * MAXC - 1, "mask_targets: L must be in [1, 255]");
+    T4R_CHECK_ARG(L >= 1 && L <= 1023, "mask_targets: L must be in [1, 1023]");
     T4R_CHECK_ARG(mode >= 0 && mode <= CLM_INFER, "mask_targets: unknown mode");
     if (B == 0) return 0;
-    hipLaunchKernelGGL(mask_targets_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                       item_ids, B, L, mode, padding_idx, bern, j1, j2, mlm_probability, seed, offset,
-                       mask_schema, masked_targets, row_count);
+    if (L <= 255)
+        hipLaunchKernelGGL(mask_targets_kernel<4>, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                           item_ids, B, L, mode, padding_idx, bern, j1, j2, mlm_probability, seed, offset,
+                           mask_schema, masked_targets, row_count);
+    else
+        hipLaunchKernelGGL(mask_targets_kernel<16>, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                           item_ids, B, L, mode, padding_idx, bern, j1, j2, mlm_probability, seed, offset,
+                           mask_schema, masked_targets, row_count);
     T4R_LAUNCH_CHECK();
     return 0;
 }

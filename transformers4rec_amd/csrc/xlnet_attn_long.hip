@@ -1,5 +1,5 @@
 // XLNet relative-position attention core for sequences LONGER than one wave (L > 64) and for head widths the one-wave kernels
-// have no instance for (d_head a multiple of 4 up to 128 other than 8 / 16 / 32), forward and backward (gfx950).
+// have no instance for (d_head a multiple of 4 up to 256 other than 8 / 16 / 32), forward and backward (gfx950).
 //
 // The reference takes any total_seq_length (XLNetConfig.build, transformers4rec/config/transformer.py:432-482; HF
 // modeling_xlnet.py rel_attn_core :95-140, rel_shift_bnij :81-93, reached through transformers4rec/torch/block/transformer.py:
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(64) void mha_long_bwd_keys_kernel(MhaLongArgs a) {
 }
 
 // capacity of the per-thread vectors for a head width
-static int cap_of(int d_head) { return d_head <= 8 ? 8 : d_head <= 16 ? 16 : d_head <= 32 ? 32 : d_head <= 64 ? 64 : 128; }
+static int cap_of(int d_head) { return d_head <= 8 ? 8 : d_head <= 16 ? 16 : d_head <= 32 ? 32 : d_head <= 64 ? 64 : d_head <= 128 ? 128 : 256; }
 
 }  // namespace
 
@@ -454,8 +454,9 @@ int t4r_reduce_partials_launch(hipStream_t st, const float* part, int nblocks, f
                                float* o1, int n1, int a1, float* o2, int n2, int a2);
 extern "C" int t4r_xlnet_attn_bwd_blocks(int B);
 
-// any L >= 1; head widths that are a multiple of 4 up to 128 (16-byte rows)
-int t4r_xlnet_attn_long_ok(int L, int d_head) { return L >= 1 && d_head >= 4 && d_head <= 128 && d_head % 4 == 0; }
+// any L >= 1; head widths that are a multiple of 4 (16-byte rows) up to 256 (above 64 the per-thread vectors spill to scratch:
+// slow, but these are the shapes nothing else takes)
+int t4r_xlnet_attn_long_ok(int L, int d_head) { return L >= 1 && d_head >= 4 && d_head <= 256 && d_head % 4 == 0; }
 int t4r_xlnet_attn_long_fwd(hipStream_t st, const float* q, const float* k, const float* v, const float* kr, const float* rw,
                             const float* rr, float* out, float* lse, int B, int L, int n_head, int d_head, float scale,
                             long kr_bstride, DropCfg drop, const int* key_len) {
@@ -463,13 +464,14 @@ int t4r_xlnet_attn_long_fwd(hipStream_t st, const float* q, const float* k, cons
     a.q = q; a.k = k; a.v = v; a.kr = kr; a.rw = rw; a.rr = rr; a.o = out; a.lse_o = lse;
     a.B = B; a.L = L; a.n_head = n_head; a.dh = d_head; a.scale = scale; a.kr_bstride = kr_bstride; a.drop = drop; a.key_len = key_len;
     const dim3 grid(B < 8192 ? B : 8192, n_head), block(64);
-    if (!t4r_xlnet_attn_long_ok(L, d_head)) { t4r_set_error("xlnet_attn: d_head must be a multiple of 4, at most 128"); return -1; }
+    if (!t4r_xlnet_attn_long_ok(L, d_head)) { t4r_set_error("xlnet_attn: d_head must be a multiple of 4, at most 256"); return -1; }
     switch (cap_of(d_head)) {
         case 8: hipLaunchKernelGGL(attn_long_fwd_kernel<8>, grid, block, 0, st, a); break;
         case 16: hipLaunchKernelGGL(attn_long_fwd_kernel<16>, grid, block, 0, st, a); break;
         case 32: hipLaunchKernelGGL(attn_long_fwd_kernel<32>, grid, block, 0, st, a); break;
         case 64: hipLaunchKernelGGL(attn_long_fwd_kernel<64>, grid, block, 0, st, a); break;
-        default: hipLaunchKernelGGL(attn_long_fwd_kernel<128>, grid, block, 0, st, a); break;
+        case 128: hipLaunchKernelGGL(attn_long_fwd_kernel<128>, grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL(attn_long_fwd_kernel<256>, grid, block, 0, st, a); break;
     }
     T4R_LAUNCH_CHECK();
     return 0;
@@ -487,7 +489,7 @@ int t4r_xlnet_attn_long_bwd(hipStream_t st, const float* q, const float* k, cons
     a.dkr_b = kr_bstride > 0 ? dkr : nullptr;
     a.B = B; a.L = L; a.n_head = n_head; a.dh = d_head; a.scale = scale; a.kr_bstride = kr_bstride; a.drop = drop; a.key_len = key_len;
     const dim3 grid(nblocks, n_head), block(64);
-    if (!t4r_xlnet_attn_long_ok(L, d_head)) { t4r_set_error("xlnet_attn_bwd: d_head must be a multiple of 4, at most 128"); return -1; }
+    if (!t4r_xlnet_attn_long_ok(L, d_head)) { t4r_set_error("xlnet_attn_bwd: d_head must be a multiple of 4, at most 256"); return -1; }
     const bool shared = kr_bstride == 0;
 #define T4R_LONG_BWD(DHV)                                                                              \
     hipLaunchKernelGGL(attn_long_bwd_rows_kernel<DHV>, grid, block, 0, st, a);                         \
@@ -499,7 +501,8 @@ int t4r_xlnet_attn_long_bwd(hipStream_t st, const float* q, const float* k, cons
         case 16: T4R_LONG_BWD(16) break;
         case 32: T4R_LONG_BWD(32) break;
         case 64: T4R_LONG_BWD(64) break;
-        default: T4R_LONG_BWD(128) break;
+        case 128: T4R_LONG_BWD(128) break;
+        default: T4R_LONG_BWD(256) break;
     }
 #undef T4R_LONG_BWD
     T4R_LAUNCH_CHECK();
@@ -520,7 +523,8 @@ int t4r_mha_long_fwd(hipStream_t st, const float* q, const float* k, const float
         case 16: hipLaunchKernelGGL(mha_long_fwd_kernel<16>, grid, block, 0, st, a); break;
         case 32: hipLaunchKernelGGL(mha_long_fwd_kernel<32>, grid, block, 0, st, a); break;
         case 64: hipLaunchKernelGGL(mha_long_fwd_kernel<64>, grid, block, 0, st, a); break;
-        default: hipLaunchKernelGGL(mha_long_fwd_kernel<128>, grid, block, 0, st, a); break;
+        case 128: hipLaunchKernelGGL(mha_long_fwd_kernel<128>, grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL(mha_long_fwd_kernel<256>, grid, block, 0, st, a); break;
     }
     T4R_LAUNCH_CHECK();
     return 0;
@@ -541,7 +545,8 @@ int t4r_mha_long_bwd(hipStream_t st, const float* q, const float* k, const float
         case 16: T4R_MHA_LONG_BWD(16) break;
         case 32: T4R_MHA_LONG_BWD(32) break;
         case 64: T4R_MHA_LONG_BWD(64) break;
-        default: T4R_MHA_LONG_BWD(128) break;
+        case 128: T4R_MHA_LONG_BWD(128) break;
+        default: T4R_MHA_LONG_BWD(256) break;
     }
 #undef T4R_MHA_LONG_BWD
     T4R_LAUNCH_CHECK();

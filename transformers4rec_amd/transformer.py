@@ -300,8 +300,8 @@ class XLNetModel(SeedMixin, nn.Module):
 
 
 # one wave per row block up to 64 positions (xlnet_attn.hip and the MFMA / one-kernel forms); beyond that the general kernels of
-# csrc/xlnet_attn_long.hip.  What bounds the sequence now is the MLM target kernel (csrc/masking.hip: 255 positions).
-XLNET_MAX_SEQ = 255
+# csrc/xlnet_attn_long.hip.  What bounds the sequence now is the target kernel (csrc/masking.hip: 1023 positions).
+XLNET_MAX_SEQ = 1023
 
 
 class TransformerBlock(nn.Module):
@@ -332,7 +332,7 @@ class TransformerBlock(nn.Module):
                              f"the {self.transformer.config_class.__name__} architecture")
         self.masking = masking
         self.prepare_module = None
-        # the MLM target kernel handles at most 255 positions (csrc/masking.hip), and MLM
+        # the target kernel handles at most 1023 positions (csrc/masking.hip), and MLM
         # inference runs the body on L + 1 positions (masking.py:406-418).  Fail at construction, not at the
         # first inference call.
         tsl = getattr(self.transformer.config, "total_seq_length", None)

@@ -362,7 +362,7 @@ int t4r_colsum(void* stream, const float* x, float* out, float* ws, long rows, i
  * replaces: HF XLNetRelativeAttention.rel_attn_core :95-140 (+ rel_shift_bnij :81-93),
  *           XLNetLayer.forward :308-353 as configured by config/transformer.py:432-482.
  * q,k,v,out [B*L, n_head*d_head]; k_r [2L, D] = pos_emb @ r (kr_per_batch: [B,2L,D], one set per
- * session, used when pos_emb dropout is on); lse [B,n,L].  Any L >= 1 and any d_head that is a multiple of 4 up to 256
+ * session, used when pos_emb dropout is on); lse [B,n,L].  Any L >= 1 and any d_head up to 256
  * (the reference takes any total_seq_length / d_model, config/transformer.py:432-482): one-wave kernels (MFMA for L <= 32,
  * d_head 16 / 32) up to 64 positions with d_head 8 / 16 / 32, the general kernels of csrc/xlnet_attn_long.hip beyond (they
  * need `out` in the backward).  drop_p: attention-probability dropout (HF :132), mask index ((b*n+h)*L+i)*L+j.
@@ -386,7 +386,7 @@ int t4r_xlnet_attn_bwd(void* stream, const float* q, const float* k, const float
 /* a16  scaled-dot-product attention core of the GPT-2 (causal) and BERT blocks
  * replaces: HF gpt2/modeling_gpt2.py eager_attention_forward :54-72 ; HF bert BertSelfAttention.
  * q,k,v rows of `ld` floats (3*D for GPT-2's fused c_attn output), head h at columns h*d_head..;
- * out/dout rows of ld_out; lse [B,n,L]; any L >= 1 and any d_head that is a multiple of 4 up to 256 (LDS / MFMA kernels up to 128
+ * out/dout rows of ld_out; lse [B,n,L]; any L >= 1 and any d_head up to 256 (LDS / MFMA kernels up to 128
  * positions with d_head 16|32|64, the general kernels of csrc/xlnet_attn_long.hip beyond).  key_len NULL = no padding mask (the
  * reference's behaviour); key_len int32 [B] (opt-in): keys >= key_len[b] are masked for every query, as HF does
  * with an attention_mask (finfo.min added to the scores).  drop_p: attention-probability dropout, mask index

@@ -384,7 +384,9 @@ ORDER = ("q", "k", "v", "o", "r", "r_w_bias", "r_r_bias", "ln_w", "ln_b", "w1", 
                                      # one-wave shapes whose K / V / k_r rows do not fit the LDS of the VALU kernels
                                      (2, 50, 256, 8), (2, 64, 512, 16), (3, 40, 512, 32),
                                      # d_head 160, 256 (per-thread vectors in scratch)
-                                     (2, 20, 320, 2), (2, 70, 256, 1)])
+                                     (2, 20, 320, 2), (2, 70, 256, 1),
+                                     # head widths that are not a multiple of 4: 25, 25, 10
+                                     (3, 20, 100, 4), (2, 70, 50, 2), (2, 9, 20, 2)])
 def test_xlnet_attention_core(ops, B, L, D, n):
     g = torch.Generator().manual_seed(B * L + D)
     dh = D // n
@@ -565,7 +567,7 @@ def test_act_bwd_dropout(ops):
 
 @pytest.mark.parametrize("B,L,D,n", [(5, 20, 64, 4), (3, 21, 128, 4), (4, 9, 32, 2), (2, 32, 64, 2), (1030, 3, 32, 1),
                                      (3, 100, 64, 4), (2, 70, 128, 2), (1030, 66, 16, 1), (3, 20, 192, 4), (2, 40, 256, 2),
-                                     (2, 50, 256, 8), (2, 48, 512, 16)])
+                                     (2, 50, 256, 8), (2, 48, 512, 16), (3, 20, 100, 4)])
 def test_xlnet_attention_dropout_per_session_kr(ops, B, L, D, n):
     g = torch.Generator().manual_seed(B + L + D)
     dh = D // n
@@ -697,7 +699,8 @@ def test_gemm_softmax_grad_fused(ops, N, V, D, eps):
                                               # csrc/xlnet_attn_long.hip): d_head 32, 64, 48, 8, 128, 24
                                               (2, 129, 64, 2, True, 0.0), (2, 200, 128, 2, False, 0.2), (3, 50, 96, 2, True, 0.1),
                                               (2, 33, 16, 2, False, 0.0), (2, 70, 256, 2, True, 0.3), (1040, 130, 24, 1, True, 0.0),
-                                              (2, 20, 320, 2, True, 0.1), (2, 140, 256, 1, False, 0.0)])
+                                              (2, 20, 320, 2, True, 0.1), (2, 140, 256, 1, False, 0.0),
+                                              (2, 30, 100, 4, True, 0.1), (2, 130, 36, 4, False, 0.0)])
 def test_mha_fwd_bwd(ops, B, L, D, n, causal, p):
     g = torch.Generator().manual_seed(B + L + D + int(causal))
     dh = D // n

@@ -22,13 +22,24 @@ CASES = [
     ("gpt2", "clm", 20, 64, 4), ("gpt2", "clm", 129, 64, 2), ("gpt2", "clm", 50, 192, 4), ("gpt2", "clm", 300, 32, 2),
     ("gpt2", "clm", 20, 320, 2), ("gpt2", "clm", 600, 32, 2), ("xlnet", "mlm", 500, 32, 2), ("bert", "mlm", 1023, 16, 1),
     ("bert", "mlm", 20, 64, 4), ("bert", "mlm", 200, 48, 2), ("bert", "mlm", 100, 512, 8), ("bert", "mlm", 20, 96, 2),
+    ("xlnet", "mlm", 100, 64, 4, "concat"), ("xlnet", "clm", 300, 32, 2, "concat"), ("xlnet", "mlm", 100, 64, 2, "element-wise-sum"),
+    ("gpt2", "clm", 150, 64, 2, "concat"), ("bert", "mlm", 20, 192, 4, "concat"),
 ]
 
 
-def run(arch, masking, L, D, H, V=500, B=6, dropout=0.1):
+def run(arch, masking, L, D, H, multi=None, V=500, B=6, dropout=0.1):
     torch.manual_seed(0)
-    schema = tr.session_schema(V, L)
-    inputs = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=L, masking=masking, embedding_dim_default=D)
+    if multi:           # BASELINE configs[2]'s input block: categoricals + continuous soft embeddings, concat or element-wise sum
+        schema = tr.session_schema(V, L, (("category", 40), ("brand", 9)), ("price", "age") if multi == "concat" else ())
+        kw = dict(max_sequence_length=L, masking=masking, aggregation=multi)
+        if multi == "concat":
+            kw.update(continuous_soft_embeddings=True, d_output=D, embedding_dims={"item_id": D}, embedding_dim_default=24)
+        else:
+            kw.update(embedding_dim_default=D)
+        inputs = tr.TabularSequenceFeatures.from_schema(schema, **kw)
+    else:
+        schema = tr.session_schema(V, L)
+        inputs = tr.TabularSequenceFeatures.from_schema(schema, max_sequence_length=L, masking=masking, embedding_dim_default=D)
     if arch == "xlnet":
         cfg = tr.XLNetConfig.build(D, H, 2, total_seq_length=L, dropout=dropout)
     elif arch == "gpt2":

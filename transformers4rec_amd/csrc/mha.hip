@@ -237,7 +237,7 @@ static int mha_bwd_launch(hipStream_t st, const float* q, const float* k, const 
 
 // q,k,v: rows of `ld` floats (ld = 3*D for GPT-2's fused c_attn output, D for separate buffers),
 // head h at columns [h*d_head, (h+1)*d_head).  out/dout rows of ld_out floats.  lse [B, n, L].
-// general kernels (xlnet_attn_long.hip): any L, d_head a multiple of 4 up to 256
+// general kernels (xlnet_attn_long.hip): any L, d_head up to 256
 int t4r_mha_long_ok(int L, int d_head);
 int t4r_mha_long_fwd(hipStream_t st, const float* q, const float* k, const float* v, long ld, float* out, long ld_out, float* lse,
                      int B, int L, int n_head, int d_head, float scale, int causal, DropCfg drop, const int* key_len);
@@ -256,7 +256,7 @@ extern "C" int t4r_mha_fwd(void* stream, const float* q, const float* k, const f
     const DropCfg dc = make_drop(drop_p, seed, ctr_hi);
     hipStream_t st = (hipStream_t)stream;
     if (!mha_short_ok(L, d_head)) {      // beyond 128 positions, or a head width the LDS kernels have no instance for
-        T4R_CHECK_ARG(t4r_mha_long_ok(L, d_head), "mha: d_head must be a multiple of 4, at most 256");
+        T4R_CHECK_ARG(t4r_mha_long_ok(L, d_head), "mha: d_head must be at most 256");
         return t4r_mha_long_fwd(st, q, k, v, ld, out, ld_out, lse, B, L, n_head, d_head, scale, causal, dc, key_len);
     }
     if (t4r_mha_mfma_ok(L, d_head, ld, ld_out, 0))
@@ -281,7 +281,7 @@ extern "C" int t4r_mha_bwd(void* stream, const float* q, const float* k, const f
     const DropCfg dc = make_drop(drop_p, seed, ctr_hi);
     hipStream_t st = (hipStream_t)stream;
     if (!mha_short_ok(L, d_head)) {
-        T4R_CHECK_ARG(t4r_mha_long_ok(L, d_head), "mha: d_head must be a multiple of 4, at most 256");
+        T4R_CHECK_ARG(t4r_mha_long_ok(L, d_head), "mha: d_head must be at most 256");
         return t4r_mha_long_bwd(st, q, k, v, ld, out, dout, ld_out, lse, dq, dk, dv, ld_d, B, L, n_head, d_head, scale, causal, dc,
                                 key_len);
     }

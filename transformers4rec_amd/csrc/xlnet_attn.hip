@@ -592,8 +592,8 @@ extern "C" int t4r_xlnet_attn_fwd(void* stream, const float* q, const float* k, 
     const long bs = kr_per_batch ? 2L * L * D : 0;
     const DropCfg dc = make_drop(drop_p, seed, ctr_hi);
     if (attn_uses_long(L, D, n_head, 0)) {       // beyond one wave per row block, a head width the one-wave kernels have no
-        // instance for, or rows that do not fit the LDS: the general kernels (any L, d_head a multiple of 4 up to 256)
-        T4R_CHECK_ARG(t4r_xlnet_attn_long_ok(L, d_head), "xlnet_attn: d_head must be a multiple of 4, at most 256");
+        // instance for, or rows that do not fit the LDS: the general kernels (any L, d_head up to 256)
+        T4R_CHECK_ARG(t4r_xlnet_attn_long_ok(L, d_head), "xlnet_attn: d_head must be at most 256");
         return t4r_xlnet_attn_long_fwd(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, B, L, n_head, d_head, scale, bs, dc, key_len);
     }
     if (use_mfma(L, d_head))
@@ -659,7 +659,7 @@ extern "C" int t4r_xlnet_attn_bwd(void* stream, const float* q, const float* k, 
     const long bs = kr_per_batch ? 2L * L * D : 0;
     const DropCfg dc = make_drop(drop_p, seed, ctr_hi);
     if (attn_uses_long(L, D, n_head, kr_per_batch ? 2 : 1)) {
-        T4R_CHECK_ARG(t4r_xlnet_attn_long_ok(L, d_head), "xlnet_attn_bwd: d_head must be a multiple of 4, at most 256");
+        T4R_CHECK_ARG(t4r_xlnet_attn_long_ok(L, d_head), "xlnet_attn_bwd: d_head must be at most 256");
         T4R_CHECK_ARG(out != nullptr, "xlnet_attn_bwd: the forward output is needed by the general kernels (L > 64 or d_head not 8 / 16 / 32)");
         return t4r_xlnet_attn_long_bwd(st, q, k, v, k_r, r_w_bias, r_r_bias, out, lse, dout, dq, dk, dv, workspace,
                                        workspace + attn_bwd_part_floats(B, L, D, n_head), dk_r, d_r_w_bias, d_r_r_bias, B, L,

@@ -1,5 +1,5 @@
 // XLNet relative-position attention core for sequences LONGER than one wave (L > 64) and for head widths the one-wave kernels
-// have no instance for (d_head a multiple of 4 up to 256 other than 8 / 16 / 32), forward and backward (gfx950).
+// have no instance for (d_head up to 256 other than 8 / 16 / 32), forward and backward (gfx950).
 //
 // The reference takes any total_seq_length (XLNetConfig.build, transformers4rec/config/transformer.py:432-482; HF
 // modeling_xlnet.py rel_attn_core :95-140, rel_shift_bnij :81-93, reached through transformers4rec/torch/block/transformer.py:
@@ -26,14 +26,27 @@
 
 namespace {
 
+// four consecutive floats of a head's row: one 16-byte request when the head width is a multiple of 4 (v4: rows and head offsets
+// are then 16-byte aligned), else element by element with the row's tail (left elements) zero-filled
+__device__ __forceinline__ float4 ld4g(const float* __restrict__ p, int left, bool v4) {
+    if (v4) return *reinterpret_cast<const float4*>(p);
+    return make_float4(p[0], left > 1 ? p[1] : 0.f, left > 2 ? p[2] : 0.f, left > 3 ? p[3] : 0.f);
+}
+__device__ __forceinline__ void st4g(float* __restrict__ p, float4 v, int left, bool v4) {
+    if (v4) { *reinterpret_cast<float4*>(p) = v; return; }
+    p[0] = v.x;
+    if (left > 1) p[1] = v.y;
+    if (left > 2) p[2] = v.z;
+    if (left > 3) p[3] = v.w;
+}
 // DH is the CAPACITY of the per-thread vectors (registers: every index is a compile-time constant); dh <= DH, a multiple of 4, is
 // the head width of the call -- the guard per 16-byte group is a scalar compare
 template <int DH>
-__device__ __forceinline__ void load_row(float (&x)[DH], const float* __restrict__ p, int dh) {
+__device__ __forceinline__ void load_row(float (&x)[DH], const float* __restrict__ p, int dh, bool v4) {
 #pragma unroll
     for (int d = 0; d < DH; d += 4) {
         if (d < dh) {
-            const float4 t = *reinterpret_cast<const float4*>(p + d);
+            const float4 t = ld4g(p + d, dh - d, v4);
             x[d] = t.x; x[d + 1] = t.y; x[d + 2] = t.z; x[d + 3] = t.w;
         } else {
             x[d] = 0.f; x[d + 1] = 0.f; x[d + 2] = 0.f; x[d + 3] = 0.f;
@@ -41,12 +54,12 @@ __device__ __forceinline__ void load_row(float (&x)[DH], const float* __restrict
     }
 }
 template <int DH>
-__device__ __forceinline__ float dot_row(const float (&a)[DH], const float* __restrict__ p, int dh) {
+__device__ __forceinline__ float dot_row(const float (&a)[DH], const float* __restrict__ p, int dh, bool v4) {
     float s = 0.f;
 #pragma unroll
     for (int d = 0; d < DH; d += 4) {
         if (d < dh) {
-            const float4 t = *reinterpret_cast<const float4*>(p + d);
+            const float4 t = ld4g(p + d, dh - d, v4);
             s += a[d] * t.x + a[d + 1] * t.y + a[d + 2] * t.z + a[d + 3] * t.w;
         }
     }
@@ -54,35 +67,35 @@ __device__ __forceinline__ float dot_row(const float (&a)[DH], const float* __re
 }
 // (a + bias) . p
 template <int DH>
-__device__ __forceinline__ float dot_row_bias(const float* __restrict__ a, const float* __restrict__ bias, const float (&x)[DH], int dh) {
+__device__ __forceinline__ float dot_row_bias(const float* __restrict__ a, const float* __restrict__ bias, const float (&x)[DH], int dh, bool v4) {
     float s = 0.f;
 #pragma unroll
     for (int d = 0; d < DH; d += 4) {
         if (d < dh) {
-            const float4 t = *reinterpret_cast<const float4*>(a + d);
-            const float4 u = *reinterpret_cast<const float4*>(bias + d);
+            const float4 t = ld4g(a + d, dh - d, v4);
+            const float4 u = ld4g(bias + d, dh - d, v4);
             s += (t.x + u.x) * x[d] + (t.y + u.y) * x[d + 1] + (t.z + u.z) * x[d + 2] + (t.w + u.w) * x[d + 3];
         }
     }
     return s;
 }
 template <int DH>
-__device__ __forceinline__ void axpy_row(float (&acc)[DH], float a, const float* __restrict__ p, int dh) {
+__device__ __forceinline__ void axpy_row(float (&acc)[DH], float a, const float* __restrict__ p, int dh, bool v4) {
 #pragma unroll
     for (int d = 0; d < DH; d += 4) {
         if (d < dh) {
-            const float4 t = *reinterpret_cast<const float4*>(p + d);
+            const float4 t = ld4g(p + d, dh - d, v4);
             acc[d] += a * t.x; acc[d + 1] += a * t.y; acc[d + 2] += a * t.z; acc[d + 3] += a * t.w;
         }
     }
 }
 template <int DH>
-__device__ __forceinline__ void axpy_row_bias(float (&acc)[DH], float a, const float* __restrict__ p, const float* __restrict__ bias, int dh) {
+__device__ __forceinline__ void axpy_row_bias(float (&acc)[DH], float a, const float* __restrict__ p, const float* __restrict__ bias, int dh, bool v4) {
 #pragma unroll
     for (int d = 0; d < DH; d += 4) {
         if (d < dh) {
-            const float4 t = *reinterpret_cast<const float4*>(p + d);
-            const float4 u = *reinterpret_cast<const float4*>(bias + d);
+            const float4 t = ld4g(p + d, dh - d, v4);
+            const float4 u = ld4g(bias + d, dh - d, v4);
             acc[d] += a * (t.x + u.x); acc[d + 1] += a * (t.y + u.y); acc[d + 2] += a * (t.z + u.z); acc[d + 3] += a * (t.w + u.w);
         }
     }
@@ -106,6 +119,7 @@ struct LongArgs {
 template <int DH>
 __global__ __launch_bounds__(64) void attn_long_fwd_kernel(LongArgs a) {
     const int L = a.L, dh = a.dh, D = a.n_head * dh, h = blockIdx.y, hc = h * dh, lane = threadIdx.x;
+    const bool v4 = (dh & 3) == 0;
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
         const float* krb = a.kr + (long)b * a.kr_bstride + hc;
         const int klen = a.key_len ? a.key_len[b] : L;
@@ -123,7 +137,7 @@ __global__ __launch_bounds__(64) void attn_long_fwd_kernel(LongArgs a) {
             }
             float m = -INFINITY, l = 0.f;
             for (int j = 0; j < L; ++j) {
-                float s = dot_row<DH>(qw, a.k + ((long)b * L + j) * D + hc, dh) + dot_row<DH>(qr, krb + (long)(j + L - ic) * D, dh);
+                float s = dot_row<DH>(qw, a.k + ((long)b * L + j) * D + hc, dh, v4) + dot_row<DH>(qr, krb + (long)(j + L - ic) * D, dh, v4);
                 s *= a.scale;
                 if (T4R_MASKED(j, ic, klen)) s = T4R_KEY_MASKED;
                 const float mn = fmaxf(m, s);
@@ -133,7 +147,7 @@ __global__ __launch_bounds__(64) void attn_long_fwd_kernel(LongArgs a) {
                 if (a.drop.p > 0.f) pd *= drop_scale(a.drop, ((unsigned long long)(b * a.n_head + h) * L + ic) * L + j);
 #pragma unroll
                 for (int d = 0; d < DH; ++d) o[d] *= alpha;
-                axpy_row<DH>(o, pd, a.v + ((long)b * L + j) * D + hc, dh);
+                axpy_row<DH>(o, pd, a.v + ((long)b * L + j) * D + hc, dh, v4);
                 m = mn;
             }
             if (i < L) {
@@ -141,7 +155,7 @@ __global__ __launch_bounds__(64) void attn_long_fwd_kernel(LongArgs a) {
                 float* orow = a.o + ((long)b * L + i) * D + hc;
 #pragma unroll
                 for (int d = 0; d < DH; d += 4)
-                    if (d < dh) *reinterpret_cast<float4*>(orow + d) = make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
+                    if (d < dh) st4g(orow + d, make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv), dh - d, v4);
                 a.lse_o[((long)b * a.n_head + h) * L + i] = m + __logf(l);
             }
         }
@@ -154,6 +168,7 @@ __device__ __forceinline__ float prob_of(float s, float lse) { return __expf(s -
 template <int DH>
 __global__ __launch_bounds__(64) void attn_long_bwd_rows_kernel(LongArgs a) {
     const int L = a.L, dh = a.dh, D = a.n_head * dh, h = blockIdx.y, hc = h * dh, lane = threadIdx.x;
+    const bool v4 = (dh & 3) == 0;
     float srw[DH], srr[DH];                     // this lane's share of d r_w_bias / d r_r_bias (all its rows and sessions)
 #pragma unroll
     for (int d = 0; d < DH; ++d) { srw[d] = 0.f; srr[d] = 0.f; }
@@ -181,20 +196,20 @@ __global__ __launch_bounds__(64) void attn_long_bwd_rows_kernel(LongArgs a) {
             for (int j = 0; j < L; ++j) {
                 const float* kj = a.k + ((long)b * L + j) * D + hc;
                 const float* krm = krb + (long)(j + L - ic) * D;
-                float s = (dot_row<DH>(qw, kj, dh) + dot_row<DH>(qr, krm, dh)) * a.scale;
+                float s = (dot_row<DH>(qw, kj, dh, v4) + dot_row<DH>(qr, krm, dh, v4)) * a.scale;
                 if (T4R_MASKED(j, ic, klen)) s = T4R_KEY_MASKED;
                 const float p = prob_of(s, lrow);
-                float dp = dot_row<DH>(g, a.v + ((long)b * L + j) * D + hc, dh);
+                float dp = dot_row<DH>(g, a.v + ((long)b * L + j) * D + hc, dh, v4);
                 if (a.drop.p > 0.f) dp *= drop_scale(a.drop, ((unsigned long long)(b * a.n_head + h) * L + ic) * L + j);
                 const float ds = p * (dp - delta) * a.scale;
-                axpy_row<DH>(dqa, ds, kj, dh);
-                axpy_row<DH>(dqb, ds, krm, dh);
+                axpy_row<DH>(dqa, ds, kj, dh, v4);
+                axpy_row<DH>(dqb, ds, krm, dh, v4);
             }
             if (live) {
                 float* dqrow = a.dq + ((long)b * L + i) * D + hc;
 #pragma unroll
                 for (int d = 0; d < DH; d += 4)
-                    if (d < dh) *reinterpret_cast<float4*>(dqrow + d) = make_float4(dqa[d] + dqb[d], dqa[d + 1] + dqb[d + 1], dqa[d + 2] + dqb[d + 2], dqa[d + 3] + dqb[d + 3]);
+                    if (d < dh) st4g(dqrow + d, make_float4(dqa[d] + dqb[d], dqa[d + 1] + dqb[d + 1], dqa[d + 2] + dqb[d + 2], dqa[d + 3] + dqb[d + 3]), dh - d, v4);
 #pragma unroll
                 for (int d = 0; d < DH; ++d) { srw[d] += dqa[d]; srr[d] += dqb[d]; }
             }
@@ -214,6 +229,7 @@ __global__ __launch_bounds__(64) void attn_long_bwd_rows_kernel(LongArgs a) {
 template <int DH>
 __global__ __launch_bounds__(64) void attn_long_bwd_keys_kernel(LongArgs a) {
     const int L = a.L, dh = a.dh, D = a.n_head * dh, h = blockIdx.y, hc = h * dh, lane = threadIdx.x;
+    const bool v4 = (dh & 3) == 0;
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
         const float* krb = a.kr + (long)b * a.kr_bstride + hc;
         const int klen = a.key_len ? a.key_len[b] : L;
@@ -221,31 +237,31 @@ __global__ __launch_bounds__(64) void attn_long_bwd_keys_kernel(LongArgs a) {
             const int j = j0 + lane, jc = min(j, L - 1);
             float kj[DH], vj[DH], dk[DH], dv[DH];
             const long row = ((long)b * L + jc) * D + hc;
-            load_row<DH>(kj, a.k + row, dh);
-            load_row<DH>(vj, a.v + row, dh);
+            load_row<DH>(kj, a.k + row, dh, v4);
+            load_row<DH>(vj, a.v + row, dh, v4);
 #pragma unroll
             for (int d = 0; d < DH; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
             for (int i = 0; i < L; ++i) {
                 const float* qi = a.q + ((long)b * L + i) * D + hc;          // wave-uniform rows
                 const float* gi = a.dout + ((long)b * L + i) * D + hc;
                 float krm[DH];
-                load_row<DH>(krm, krb + (long)(jc + L - i) * D, dh);
-                float s = (dot_row_bias<DH>(qi, a.rw + hc, kj, dh) + dot_row_bias<DH>(qi, a.rr + hc, krm, dh)) * a.scale;
+                load_row<DH>(krm, krb + (long)(jc + L - i) * D, dh, v4);
+                float s = (dot_row_bias<DH>(qi, a.rw + hc, kj, dh, v4) + dot_row_bias<DH>(qi, a.rr + hc, krm, dh, v4)) * a.scale;
                 if (T4R_MASKED(jc, i, klen)) s = T4R_KEY_MASKED;
                 const float p = prob_of(s, a.lse[((long)b * a.n_head + h) * L + i]);
                 float ms = 1.f;
                 if (a.drop.p > 0.f) ms = drop_scale(a.drop, ((unsigned long long)(b * a.n_head + h) * L + i) * L + jc);
-                const float dp = dot_row<DH>(vj, gi, dh) * ms;
+                const float dp = dot_row<DH>(vj, gi, dh, v4) * ms;
                 const float ds = p * (dp - a.delta[((long)b * a.n_head + h) * L + i]) * a.scale;
-                axpy_row_bias<DH>(dk, ds, qi, a.rw + hc, dh);
-                axpy_row<DH>(dv, p * ms, gi, dh);
+                axpy_row_bias<DH>(dk, ds, qi, a.rw + hc, dh, v4);
+                axpy_row<DH>(dv, p * ms, gi, dh, v4);
             }
             if (j < L) {
 #pragma unroll
                 for (int d = 0; d < DH; d += 4) {
                     if (d < dh) {
-                        *reinterpret_cast<float4*>(a.dk + row + d) = make_float4(dk[d], dk[d + 1], dk[d + 2], dk[d + 3]);
-                        *reinterpret_cast<float4*>(a.dv + row + d) = make_float4(dv[d], dv[d + 1], dv[d + 2], dv[d + 3]);
+                        st4g(a.dk + row + d, make_float4(dk[d], dk[d + 1], dk[d + 2], dk[d + 3]), dh - d, v4);
+                        st4g(a.dv + row + d, make_float4(dv[d], dv[d + 1], dv[d + 2], dv[d + 3]), dh - d, v4);
                     }
                 }
             }
@@ -256,6 +272,7 @@ __global__ __launch_bounds__(64) void attn_long_bwd_keys_kernel(LongArgs a) {
 template <int DH, bool SHARED_KR>
 __global__ __launch_bounds__(64) void attn_long_bwd_rel_kernel(LongArgs a) {
     const int L = a.L, dh = a.dh, D = a.n_head * dh, h = blockIdx.y, hc = h * dh, lane = threadIdx.x;
+    const bool v4 = (dh & 3) == 0;
     for (int m0 = 0; m0 < 2 * L; m0 += 64) {
         const int m = m0 + lane, mc = min(m, 2 * L - 1);
         float acc[DH];
@@ -265,7 +282,7 @@ __global__ __launch_bounds__(64) void attn_long_bwd_rel_kernel(LongArgs a) {
             const float* krb = a.kr + (long)b * a.kr_bstride + hc;
             const int klen = a.key_len ? a.key_len[b] : L;
             float krm[DH];
-            load_row<DH>(krm, krb + (long)mc * D, dh);
+            load_row<DH>(krm, krb + (long)mc * D, dh, v4);
             if (!SHARED_KR) {
 #pragma unroll
                 for (int d = 0; d < DH; ++d) acc[d] = 0.f;
@@ -277,32 +294,32 @@ __global__ __launch_bounds__(64) void attn_long_bwd_rel_kernel(LongArgs a) {
                 const float* qi = a.q + ((long)b * L + i) * D + hc;
                 const float* gi = a.dout + ((long)b * L + i) * D + hc;
                 float kj[DH];
-                load_row<DH>(kj, a.k + ((long)b * L + jc) * D + hc, dh);
-                float s = (dot_row_bias<DH>(qi, a.rw + hc, kj, dh) + dot_row_bias<DH>(qi, a.rr + hc, krm, dh)) * a.scale;
+                load_row<DH>(kj, a.k + ((long)b * L + jc) * D + hc, dh, v4);
+                float s = (dot_row_bias<DH>(qi, a.rw + hc, kj, dh, v4) + dot_row_bias<DH>(qi, a.rr + hc, krm, dh, v4)) * a.scale;
                 if (T4R_MASKED(jc, i, klen)) s = T4R_KEY_MASKED;
                 const float p = hit ? prob_of(s, a.lse[((long)b * a.n_head + h) * L + i]) : 0.f;
                 float dp;
                 {
                     float vj[DH];
-                    load_row<DH>(vj, a.v + ((long)b * L + jc) * D + hc, dh);
-                    dp = dot_row<DH>(vj, gi, dh);
+                    load_row<DH>(vj, a.v + ((long)b * L + jc) * D + hc, dh, v4);
+                    dp = dot_row<DH>(vj, gi, dh, v4);
                 }
                 if (a.drop.p > 0.f) dp *= drop_scale(a.drop, ((unsigned long long)(b * a.n_head + h) * L + i) * L + jc);
                 const float ds = p * (dp - a.delta[((long)b * a.n_head + h) * L + i]) * a.scale;
-                axpy_row_bias<DH>(acc, ds, qi, a.rr + hc, dh);
+                axpy_row_bias<DH>(acc, ds, qi, a.rr + hc, dh, v4);
             }
             if (!SHARED_KR && m < 2 * L) {
                 float* o = a.dkr_b + ((long)b * 2 * L + m) * D + hc;
 #pragma unroll
                 for (int d = 0; d < DH; d += 4)
-                    if (d < dh) *reinterpret_cast<float4*>(o + d) = make_float4(acc[d], acc[d + 1], acc[d + 2], acc[d + 3]);
+                    if (d < dh) st4g(o + d, make_float4(acc[d], acc[d + 1], acc[d + 2], acc[d + 3]), dh - d, v4);
             }
         }
         if (SHARED_KR && m < 2 * L) {
             float* o = a.part + (long)blockIdx.x * (2L * L * D + 2 * D) + (long)m * D + hc;
 #pragma unroll
             for (int d = 0; d < DH; d += 4)
-                if (d < dh) *reinterpret_cast<float4*>(o + d) = make_float4(acc[d], acc[d + 1], acc[d + 2], acc[d + 3]);
+                if (d < dh) st4g(o + d, make_float4(acc[d], acc[d + 1], acc[d + 2], acc[d + 3]), dh - d, v4);
         }
     }
 }
@@ -326,12 +343,13 @@ struct MhaLongArgs {
 template <int DH>
 __global__ __launch_bounds__(64) void mha_long_fwd_kernel(MhaLongArgs a) {
     const int L = a.L, dh = a.dh, h = blockIdx.y, hc = h * dh, lane = threadIdx.x;
+    const bool v4 = (dh & 3) == 0;
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
         const int klen = a.key_len ? max(1, min(L, a.key_len[b])) : L;
         for (int i0 = 0; i0 < L; i0 += 64) {
             const int i = i0 + lane, ic = min(i, L - 1);
             float qi[DH], o[DH];
-            load_row<DH>(qi, a.q + ((long)b * L + ic) * a.ld + hc, dh);
+            load_row<DH>(qi, a.q + ((long)b * L + ic) * a.ld + hc, dh, v4);
 #pragma unroll
             for (int d = 0; d < DH; ++d) o[d] = 0.f;
             float m = -INFINITY, l = 0.f;
@@ -339,7 +357,7 @@ __global__ __launch_bounds__(64) void mha_long_fwd_kernel(MhaLongArgs a) {
             const int jmax = min(a.causal ? min(i0 + 64, L) : L, klen);       // wave-uniform bound: the rows of k / v stay broadcasts
             for (int j = 0; j < jmax; ++j) {
                 const bool on = j < jend;
-                const float s = on ? dot_row<DH>(qi, a.k + ((long)b * L + j) * a.ld + hc, dh) * a.scale : -INFINITY;
+                const float s = on ? dot_row<DH>(qi, a.k + ((long)b * L + j) * a.ld + hc, dh, v4) * a.scale : -INFINITY;
                 const float mn = fmaxf(m, s);
                 const float alpha = mn == -INFINITY ? 1.f : __expf(m - mn), pj = on ? __expf(s - mn) : 0.f;
                 l = l * alpha + pj;
@@ -347,7 +365,7 @@ __global__ __launch_bounds__(64) void mha_long_fwd_kernel(MhaLongArgs a) {
                 if (a.drop.p > 0.f) pd *= drop_scale(a.drop, ((unsigned long long)(b * a.n_head + h) * L + ic) * L + j);
 #pragma unroll
                 for (int d = 0; d < DH; ++d) o[d] *= alpha;
-                axpy_row<DH>(o, pd, a.v + ((long)b * L + j) * a.ld + hc, dh);
+                axpy_row<DH>(o, pd, a.v + ((long)b * L + j) * a.ld + hc, dh, v4);
                 m = mn;
             }
             if (i < L) {
@@ -355,7 +373,7 @@ __global__ __launch_bounds__(64) void mha_long_fwd_kernel(MhaLongArgs a) {
                 float* orow = a.o + ((long)b * L + i) * a.ld_out + hc;
 #pragma unroll
                 for (int d = 0; d < DH; d += 4)
-                    if (d < dh) *reinterpret_cast<float4*>(orow + d) = make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
+                    if (d < dh) st4g(orow + d, make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv), dh - d, v4);
                 a.lse_o[((long)b * a.n_head + h) * L + i] = m + __logf(l);
             }
         }
@@ -366,14 +384,15 @@ __global__ __launch_bounds__(64) void mha_long_fwd_kernel(MhaLongArgs a) {
 template <int DH>
 __global__ __launch_bounds__(64) void mha_long_bwd_rows_kernel(MhaLongArgs a) {
     const int L = a.L, dh = a.dh, h = blockIdx.y, hc = h * dh, lane = threadIdx.x;
+    const bool v4 = (dh & 3) == 0;
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
         const int klen = a.key_len ? max(1, min(L, a.key_len[b])) : L;
         for (int i0 = 0; i0 < L; i0 += 64) {
             const int i = i0 + lane, ic = min(i, L - 1);
             float qi[DH], g[DH], dq[DH];
-            load_row<DH>(qi, a.q + ((long)b * L + ic) * a.ld + hc, dh);
-            load_row<DH>(g, a.dout + ((long)b * L + ic) * a.ld_out + hc, dh);
-            const float delta = dot_row<DH>(g, a.out + ((long)b * L + ic) * a.ld_out + hc, dh);
+            load_row<DH>(qi, a.q + ((long)b * L + ic) * a.ld + hc, dh, v4);
+            load_row<DH>(g, a.dout + ((long)b * L + ic) * a.ld_out + hc, dh, v4);
+            const float delta = dot_row<DH>(g, a.out + ((long)b * L + ic) * a.ld_out + hc, dh, v4);
 #pragma unroll
             for (int d = 0; d < DH; ++d) dq[d] = 0.f;
             const float lrow = a.lse[((long)b * a.n_head + h) * L + ic];
@@ -381,16 +400,16 @@ __global__ __launch_bounds__(64) void mha_long_bwd_rows_kernel(MhaLongArgs a) {
             const int jmax = min(a.causal ? min(i0 + 64, L) : L, klen);
             for (int j = 0; j < jmax; ++j) {
                 const float* kj = a.k + ((long)b * L + j) * a.ld + hc;
-                const float p = j < jend ? __expf(dot_row<DH>(qi, kj, dh) * a.scale - lrow) : 0.f;
-                float dp = dot_row<DH>(g, a.v + ((long)b * L + j) * a.ld + hc, dh);
+                const float p = j < jend ? __expf(dot_row<DH>(qi, kj, dh, v4) * a.scale - lrow) : 0.f;
+                float dp = dot_row<DH>(g, a.v + ((long)b * L + j) * a.ld + hc, dh, v4);
                 if (a.drop.p > 0.f) dp *= drop_scale(a.drop, ((unsigned long long)(b * a.n_head + h) * L + ic) * L + j);
-                axpy_row<DH>(dq, p * (dp - delta) * a.scale, kj, dh);
+                axpy_row<DH>(dq, p * (dp - delta) * a.scale, kj, dh, v4);
             }
             if (i < L) {
                 float* o = a.dq + ((long)b * L + i) * a.ld_d + hc;
 #pragma unroll
                 for (int d = 0; d < DH; d += 4)
-                    if (d < dh) *reinterpret_cast<float4*>(o + d) = make_float4(dq[d], dq[d + 1], dq[d + 2], dq[d + 3]);
+                    if (d < dh) st4g(o + d, make_float4(dq[d], dq[d + 1], dq[d + 2], dq[d + 3]), dh - d, v4);
             }
         }
     }
@@ -400,13 +419,14 @@ __global__ __launch_bounds__(64) void mha_long_bwd_rows_kernel(MhaLongArgs a) {
 template <int DH>
 __global__ __launch_bounds__(64) void mha_long_bwd_keys_kernel(MhaLongArgs a) {
     const int L = a.L, dh = a.dh, h = blockIdx.y, hc = h * dh, lane = threadIdx.x;
+    const bool v4 = (dh & 3) == 0;
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
         const int klen = a.key_len ? max(1, min(L, a.key_len[b])) : L;
         for (int j0 = 0; j0 < L; j0 += 64) {
             const int j = j0 + lane, jc = min(j, L - 1);
             float kj[DH], vj[DH], dk[DH], dv[DH];
-            load_row<DH>(kj, a.k + ((long)b * L + jc) * a.ld + hc, dh);
-            load_row<DH>(vj, a.v + ((long)b * L + jc) * a.ld + hc, dh);
+            load_row<DH>(kj, a.k + ((long)b * L + jc) * a.ld + hc, dh, v4);
+            load_row<DH>(vj, a.v + ((long)b * L + jc) * a.ld + hc, dh, v4);
 #pragma unroll
             for (int d = 0; d < DH; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
             const bool key_on = jc < klen;
@@ -418,17 +438,17 @@ __global__ __launch_bounds__(64) void mha_long_bwd_keys_kernel(MhaLongArgs a) {
 #pragma unroll
                 for (int d = 0; d < DH; d += 4) {
                     if (d < dh) {
-                        const float4 x = *reinterpret_cast<const float4*>(gi + d), y = *reinterpret_cast<const float4*>(oi + d);
+                        const float4 x = ld4g(gi + d, dh - d, v4), y = ld4g(oi + d, dh - d, v4);
                         delta += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
                     }
                 }
                 const bool on = key_on && (!a.causal || jc <= i);
-                const float p = on ? __expf(dot_row<DH>(kj, qi, dh) * a.scale - a.lse[((long)b * a.n_head + h) * L + i]) : 0.f;
+                const float p = on ? __expf(dot_row<DH>(kj, qi, dh, v4) * a.scale - a.lse[((long)b * a.n_head + h) * L + i]) : 0.f;
                 float ms = 1.f;
                 if (a.drop.p > 0.f) ms = drop_scale(a.drop, ((unsigned long long)(b * a.n_head + h) * L + i) * L + jc);
-                const float dp = dot_row<DH>(vj, gi, dh) * ms;
-                axpy_row<DH>(dk, p * (dp - delta) * a.scale, qi, dh);
-                axpy_row<DH>(dv, p * ms, gi, dh);
+                const float dp = dot_row<DH>(vj, gi, dh, v4) * ms;
+                axpy_row<DH>(dk, p * (dp - delta) * a.scale, qi, dh, v4);
+                axpy_row<DH>(dv, p * ms, gi, dh, v4);
             }
             if (j < L) {
                 float* ok = a.dk + ((long)b * L + j) * a.ld_d + hc;
@@ -436,8 +456,8 @@ __global__ __launch_bounds__(64) void mha_long_bwd_keys_kernel(MhaLongArgs a) {
 #pragma unroll
                 for (int d = 0; d < DH; d += 4) {
                     if (d < dh) {
-                        *reinterpret_cast<float4*>(ok + d) = make_float4(dk[d], dk[d + 1], dk[d + 2], dk[d + 3]);
-                        *reinterpret_cast<float4*>(ov + d) = make_float4(dv[d], dv[d + 1], dv[d + 2], dv[d + 3]);
+                        st4g(ok + d, make_float4(dk[d], dk[d + 1], dk[d + 2], dk[d + 3]), dh - d, v4);
+                        st4g(ov + d, make_float4(dv[d], dv[d + 1], dv[d + 2], dv[d + 3]), dh - d, v4);
                     }
                 }
             }
@@ -454,9 +474,9 @@ int t4r_reduce_partials_launch(hipStream_t st, const float* part, int nblocks, f
                                float* o1, int n1, int a1, float* o2, int n2, int a2);
 extern "C" int t4r_xlnet_attn_bwd_blocks(int B);
 
-// any L >= 1; head widths that are a multiple of 4 (16-byte rows) up to 256 (above 64 the per-thread vectors spill to scratch:
-// slow, but these are the shapes nothing else takes)
-int t4r_xlnet_attn_long_ok(int L, int d_head) { return L >= 1 && d_head >= 4 && d_head <= 256 && d_head % 4 == 0; }
+// any L >= 1; head widths up to 256 (16-byte requests when the width is a multiple of 4, element by element otherwise; above 64
+// the per-thread vectors spill to scratch: slow, but these are the shapes nothing else takes)
+int t4r_xlnet_attn_long_ok(int L, int d_head) { return L >= 1 && d_head >= 1 && d_head <= 256; }
 int t4r_xlnet_attn_long_fwd(hipStream_t st, const float* q, const float* k, const float* v, const float* kr, const float* rw,
                             const float* rr, float* out, float* lse, int B, int L, int n_head, int d_head, float scale,
                             long kr_bstride, DropCfg drop, const int* key_len) {
@@ -464,7 +484,7 @@ int t4r_xlnet_attn_long_fwd(hipStream_t st, const float* q, const float* k, cons
     a.q = q; a.k = k; a.v = v; a.kr = kr; a.rw = rw; a.rr = rr; a.o = out; a.lse_o = lse;
     a.B = B; a.L = L; a.n_head = n_head; a.dh = d_head; a.scale = scale; a.kr_bstride = kr_bstride; a.drop = drop; a.key_len = key_len;
     const dim3 grid(B < 8192 ? B : 8192, n_head), block(64);
-    if (!t4r_xlnet_attn_long_ok(L, d_head)) { t4r_set_error("xlnet_attn: d_head must be a multiple of 4, at most 256"); return -1; }
+    if (!t4r_xlnet_attn_long_ok(L, d_head)) { t4r_set_error("xlnet_attn: d_head must be at most 256"); return -1; }
     switch (cap_of(d_head)) {
         case 8: hipLaunchKernelGGL(attn_long_fwd_kernel<8>, grid, block, 0, st, a); break;
         case 16: hipLaunchKernelGGL(attn_long_fwd_kernel<16>, grid, block, 0, st, a); break;
@@ -489,7 +509,7 @@ int t4r_xlnet_attn_long_bwd(hipStream_t st, const float* q, const float* k, cons
     a.dkr_b = kr_bstride > 0 ? dkr : nullptr;
     a.B = B; a.L = L; a.n_head = n_head; a.dh = d_head; a.scale = scale; a.kr_bstride = kr_bstride; a.drop = drop; a.key_len = key_len;
     const dim3 grid(nblocks, n_head), block(64);
-    if (!t4r_xlnet_attn_long_ok(L, d_head)) { t4r_set_error("xlnet_attn_bwd: d_head must be a multiple of 4, at most 256"); return -1; }
+    if (!t4r_xlnet_attn_long_ok(L, d_head)) { t4r_set_error("xlnet_attn_bwd: d_head must be at most 256"); return -1; }
     const bool shared = kr_bstride == 0;
 #define T4R_LONG_BWD(DHV)                                                                              \
     hipLaunchKernelGGL(attn_long_bwd_rows_kernel<DHV>, grid, block, 0, st, a);                         \

@@ -583,6 +583,7 @@ int t4r_sampled_logits_bwd(void* stream, float* dlogits, const float* x, const l
 int t4r_sampled_logits_bwd_rows(void* stream, float* dlogits, const float* x, const long* labels,
                                 const float* W, const long* neg_samples, float* dx, float* rows_out,
                                 float* ws, int N, int D, int n_neg, float temperature);
+/* 1 <= k <= min(256, V); values descending, ties to the lower index (as torch.topk on distinct values / a stable sort) */
 int t4r_topk(void* stream, const float* scores, int N, int V, long ld, int k, float* out_val,
              long* out_idx);
 /* Fused eval head (replaces logits materialisation + torch.topk + the [N, V] one-hot of

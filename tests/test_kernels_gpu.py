@@ -493,7 +493,8 @@ def test_sampled_logits_golden(ops):
     close(dW, W.grad, atol=1e-4)
 
 
-@pytest.mark.parametrize("N,V,k", [(9, 1000, 20), (3, 100001, 20), (4, 50, 10), (2, 64, 64)])
+@pytest.mark.parametrize("N,V,k", [(9, 1000, 20), (3, 100001, 20), (4, 50, 10), (2, 64, 64), (3, 100001, 100), (2, 5000, 256),
+                                   (2, 300, 200)])
 def test_topk(ops, N, V, k):
     g = torch.Generator().manual_seed(V)
     s = torch.randn(N, V, generator=g)
@@ -877,6 +878,12 @@ def test_topk_ties_and_fallback_path(ops):
     v2, i2 = ops.topk(cu(buf)[:, :1003], 64, 1003)
     rv, ri = torch.topk(s2, 64, dim=-1)
     assert torch.equal(v2.cpu(), rv) and torch.equal(i2.cpu(), ri)
+    # 64 < k <= 256 on the same adversarial rows: the selection fallback (no LDS lists of that size)
+    k = 100
+    v3, i3 = ops.topk(cu(s), k)
+    order = torch.argsort(-s, dim=1, stable=True)[:, :k]
+    assert torch.equal(i3.cpu(), order)
+    assert torch.equal(v3.cpu(), torch.gather(s, 1, order))
 
 
 # ------------------------------------------------------------------------------------ deterministic table gradient

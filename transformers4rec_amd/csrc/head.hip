@@ -420,9 +420,11 @@ extern "C" int t4r_sampled_logits_bwd_rows(void* stream, float* dlogits, const f
 // sorted lists in LDS diverged on every insertion: 2.1 ms at 1024 x 100001, this form ~0.3 ms).
 // If the candidate list overflows (adversarial rows with > TOPK_CAP values >= t0, e.g. constant
 // rows) the workgroup falls back to the sorted-list algorithm below.
-#define TOPK_MAX 64
+#define TOPK_MAX 256         // the threshold of step A is the k-th largest of 256 slice maxima
+#define TOPK_LISTS_MAX 64    // the sorted-list fallback keeps [256][k] values + indices in LDS (128 KB at k = 64)
 #define TOPK_CAP 2048
 __device__ void topk_lists_fallback(const float* x, int V, int k, float* sh, float* out_val, long* out_idx, long row);
+__device__ void topk_select_fallback(const float* x, int V, int k, float* out_val, long* out_idx, long row);
 
 __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ scores, int V, long ld,
                                                     int k, float* __restrict__ out_val,
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ sco
             const float v = tmax[o];
             rank += (v > m || (v == m && o < tid)) ? 1 : 0;
         }
-        if (rank == k - 1) t0s = m;          // k <= 64 < 256: exactly one thread has this rank
+        if (rank == k - 1) t0s = m;          // k <= 256 ranks 0 .. 255: exactly one thread has this rank
     }
     __syncthreads();
     const float t0 = t0s;
@@ -472,7 +474,8 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ sco
     __syncthreads();
     const int C = cnt;
     if (C > TOPK_CAP) {                      // workgroup-uniform
-        topk_lists_fallback(x, V, k, sh, out_val, out_idx, row);
+        if (k <= TOPK_LISTS_MAX) topk_lists_fallback(x, V, k, sh, out_val, out_idx, row);
+        else topk_select_fallback(x, V, k, out_val, out_idx, row);
         return;
     }
     // C: rank among candidates
@@ -541,11 +544,50 @@ __device__ void topk_lists_fallback(const float* x, int V, int k, float* sh, flo
     }
 }
 
+// fallback of the fallback for 64 < k <= 256 (no LDS lists of that size): k rounds of a workgroup-wide arg-max over the elements
+// that come after the previous pick in (value descending, index ascending) order.  k V reads per row: adversarial rows only
+// (more than TOPK_CAP values at or above the k-th largest slice maximum, e.g. constant rows).
+__device__ void topk_select_fallback(const float* x, int V, int k, float* out_val, long* out_idx, long row) {
+    __shared__ float wv[4];
+    __shared__ int wi[4];
+    __shared__ float pv_s;
+    __shared__ int pi_s;
+    float prev_v = INFINITY;
+    int prev_i = -1;
+    for (int r = 0; r < k; ++r) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int i = threadIdx.x; i < V; i += 256) {
+            const float v = x[i];
+            const bool after = v < prev_v || (v == prev_v && i > prev_i);
+            if (after && (v > bv || (v == bv && i < bi))) { bv = v; bi = i; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float v2 = __shfl_xor(bv, o, 64);
+            const int i2 = __shfl_xor(bi, o, 64);
+            if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+        }
+        if ((threadIdx.x & 63) == 0) { wv[threadIdx.x >> 6] = bv; wi[threadIdx.x >> 6] = bi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (wv[w] > bv || (wv[w] == bv && wi[w] < bi)) { bv = wv[w]; bi = wi[w]; }
+            out_val[row * k + r] = bv;
+            out_idx[row * k + r] = bi;
+            pv_s = bv; pi_s = bi;
+        }
+        __syncthreads();
+        prev_v = pv_s; prev_i = pi_s;
+        __syncthreads();
+    }
+}
+
 extern "C" int t4r_topk(void* stream, const float* scores, int N, int V, long ld, int k, float* out_val,
                         long* out_idx) {
     if (N == 0) return 0;
-    T4R_CHECK_ARG(k >= 1 && k <= TOPK_MAX && k <= V, "topk: 1 <= k <= min(64, V)");
-    const size_t smem = (size_t)256 * k * 8;
+    T4R_CHECK_ARG(k >= 1 && k <= TOPK_MAX && k <= V, "topk: 1 <= k <= min(256, V)");
+    const size_t smem = k <= TOPK_LISTS_MAX ? (size_t)256 * k * 8 : 0;
     static T4rLdsAttr attr;
     t4r_ensure_dynamic_lds((const void*)topk_kernel, smem, attr);
     hipLaunchKernelGGL(topk_kernel, dim3(N), dim3(256), smem, (hipStream_t)stream, scores, V, ld, k,

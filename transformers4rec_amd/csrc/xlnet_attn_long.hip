@@ -5,10 +5,12 @@
 // modeling_xlnet.py rel_attn_core :95-140, rel_shift_bnij :81-93, reached through transformers4rec/torch/block/transformer.py:
 // 179-199); the kernels of xlnet_attn.hip / xlnet_attn_mfma.hip / xlnet_attn_block.hip put one query row on one lane of ONE
 // wave and stop at 64 (32) positions.  This file is the general form behind the same entry points (t4r_xlnet_attn_fwd / _bwd pick
-// it when L > 64): same arithmetic, same dropout keys (mask index ((b n_head + h) L + i) L + j), same opt-in key mask, no bound
+// it when L > 64, when d_head is not 8 / 16 / 32, or when a session's rows overflow the LDS of the one-wave VALU kernels; the
+// second half of the file is the same for t4r_mha_fwd / _bwd of the GPT-2 / BERT blocks): same arithmetic, same dropout keys (mask index ((b n_head + h) L + i) L + j), same opt-in key mask, no bound
 // on L other than memory.  It is the coverage path, not the benchmarked one: everything is recomputed from q, k, v, k_r with
 // plain fp32 FMAs, rows of k / v / q / d out come as wave-uniform (broadcast) loads out of L2, the lane-dependent row of the
-// other operand as a 16-byte-per-lane gather; no LDS, so no L x d_model limit either.
+// other operand as a 16-byte-per-lane gather (element by element when d_head is not a multiple of 4); no LDS, so no L x d_model
+// limit either.  Head widths up to 256: the per-thread vectors have a compile-time capacity (8 .. 256) and a run-time width.
 //
 //   forward          thread = query row i (blocks of 64 rows walked by one wave per (session, head)); one online-softmax pass
 //                    over the keys; saves the row log-sum-exp

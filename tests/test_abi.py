@@ -39,8 +39,8 @@ def test_workspace_size_queries_are_pure():
 
 def test_argument_errors_are_reported_not_crashes():
     lib = _lib.load()
-    # d_head 7 is unsupported: must come back as rc != 0 with a message, before any launch
-    rc = lib.t4r_xlnet_attn_fwd(None, None, None, None, None, None, None, None, None, 1, 20, 4, 7, 0, 0.0, 0, 0, None)
+    # d_head 300 is unsupported (the general kernels stop at 256): must come back as rc != 0 with a message, before any launch
+    rc = lib.t4r_xlnet_attn_fwd(None, None, None, None, None, None, None, None, None, 1, 20, 4, 300, 0, 0.0, 0, 0, None)
     assert rc != 0 and b"d_head" in lib.t4r_last_error()
     rc = lib.t4r_mask_targets(None, None, 4, 0, 0, 0, None, None, None, 0.15, 0, 0, None, None, None)
     assert rc != 0 and b"L must be" in lib.t4r_last_error()

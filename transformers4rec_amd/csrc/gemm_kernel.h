@@ -156,8 +156,12 @@ __device__ __forceinline__ uint32_t pk_bf16_rne(float a, float b) {
 template <int PREC>
 __device__ __forceinline__ void cvt_pair(float a, float b, uint32_t (&w)[PREC == 1 ? 3 : (PREC == 4 ? 2 : 1)]) {
     if constexpr (PREC == 4) {
-        const half2_t h = {(_Float16)a, (_Float16)b};
-        const half2_t l = {(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
+        // (vector conversions + fma(hi, -1, x): five vector instructions per pair instead of eight, same roundings)
+        typedef float f2v_t __attribute__((ext_vector_type(2)));
+        const f2v_t ab = {a, b};
+        const half2_t h = __builtin_convertvector(ab, half2_t);
+        const f2v_t lab = {__builtin_fmaf((float)h[0], -1.0f, a), __builtin_fmaf((float)h[1], -1.0f, b)};
+        const half2_t l = __builtin_convertvector(lab, half2_t);
         w[0] = __builtin_bit_cast(uint32_t, h);
         w[1] = __builtin_bit_cast(uint32_t, l);
     } else if constexpr (PREC == 1) {

@@ -73,9 +73,13 @@ __device__ __forceinline__ f32x16 mfma6(const u32x4 (&a)[3], const u32x4 (&b)[3]
 __device__ __forceinline__ f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
 }
+// (vector conversions + fma(hi, -1, x): five vector instructions per pair instead of eight, same roundings -- xlnet_fused.h: cut2h)
+typedef float float2v_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void cut_pair_h(float a, float b, uint32_t (&w)[2]) {
-    const half2_t h = {(_Float16)a, (_Float16)b};              // round to nearest even
-    const half2_t l = {(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
+    const float2v_t ab = {a, b};
+    const half2_t h = __builtin_convertvector(ab, half2_t);     // round to nearest even
+    const float2v_t lab = {__builtin_fmaf((float)h[0], -1.0f, a), __builtin_fmaf((float)h[1], -1.0f, b)};
+    const half2_t l = __builtin_convertvector(lab, half2_t);
     w[0] = __builtin_bit_cast(uint32_t, h);
     w[1] = __builtin_bit_cast(uint32_t, l);
 }

@@ -133,10 +133,16 @@ typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x4 mfma_h(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
-// two (already scaled) fp32 values -> hi / lo fp16 pairs, both cuts round to nearest even
+// two (already scaled) fp32 values -> hi / lo fp16 pairs, both cuts round to nearest even.  Written as vector conversions and
+// fma(hi, -1, x) so that the pair costs five vector instructions (v_cvt_pk_f16_f32, two v_cvt_f32_f16, v_pk_add_f32,
+// v_cvt_pk_f16_f32) instead of eight (the element-wise form converted hi twice: once alone for the residual, once packed); same
+// roundings, same bits.
+typedef float f32x2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void cut2h(float a, float b, uint32_t (&w)[2]) {
-    const f16x2v h = {(_Float16)a, (_Float16)b};
-    const f16x2v l = {(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
+    const f32x2v ab = {a, b};
+    const f16x2v h = __builtin_convertvector(ab, f16x2v);
+    const f32x2v lab = {__builtin_fmaf((float)h[0], -1.0f, a), __builtin_fmaf((float)h[1], -1.0f, b)};
+    const f16x2v l = __builtin_convertvector(lab, f16x2v);
     w[0] = __builtin_bit_cast(uint32_t, h);
     w[1] = __builtin_bit_cast(uint32_t, l);
 }

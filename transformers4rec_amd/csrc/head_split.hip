@@ -341,18 +341,28 @@ __device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2
 // 4 x 4 transpose between the four lanes of a quad and four registers: on return x[g] holds what lane (quad base + g)
 // had in x[t], t = this lane's position in the quad (two DPP exchange steps).
 __device__ __forceinline__ void quad_transpose4(float (&x)[4], int t) {
+    // Written so that every DPP move has ONE consumer, a select: the compiler folds the pair into v_cndmask_b32_dpp (8 vector
+    // instructions per transpose; the send-select / move / receive-select form took 16).  Exchange with lane t ^ 1: an even lane's
+    // x[1] becomes its partner's x[0], an odd lane's x[0] its partner's x[1] (and the same for x[3] / x[2]); then with lane t ^ 2 on
+    // the register pairs (0, 2) and (1, 3).
     const bool odd = t & 1, hi = t & 2;
-    {   // exchange with lane t ^ 1: the odd lane gives its x[0], x[2], the even lane its x[1], x[3]
-        const float s0 = odd ? x[0] : x[1], s1 = odd ? x[2] : x[3];
-        const float r0 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s0), 0xB1, 0xf, 0xf, true));
-        const float r1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s1), 0xB1, 0xf, 0xf, true));
-        if (odd) { x[0] = r0; x[2] = r1; } else { x[1] = r0; x[3] = r1; }
+    auto swap1 = [](float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true)); };
+    auto swap2 = [](float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true)); };
+    {   // (every move is executed by ALL lanes, outside the selects: a cross-lane move under a divergent condition reads disabled lanes)
+        const float a0 = x[0], a1 = x[1], a2 = x[2], a3 = x[3];
+        const float p0 = swap1(a0), p1 = swap1(a1), p2 = swap1(a2), p3 = swap1(a3);
+        x[1] = odd ? a1 : p0;
+        x[0] = odd ? p1 : a0;
+        x[3] = odd ? a3 : p2;
+        x[2] = odd ? p3 : a2;
     }
-    {   // exchange with lane t ^ 2
-        const float s0 = hi ? x[0] : x[2], s1 = hi ? x[1] : x[3];
-        const float r0 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s0), 0x4E, 0xf, 0xf, true));
-        const float r1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s1), 0x4E, 0xf, 0xf, true));
-        if (hi) { x[0] = r0; x[1] = r1; } else { x[2] = r0; x[3] = r1; }
+    {
+        const float a0 = x[0], a1 = x[1], a2 = x[2], a3 = x[3];
+        const float p0 = swap2(a0), p1 = swap2(a1), p2 = swap2(a2), p3 = swap2(a3);
+        x[2] = hi ? a2 : p0;
+        x[0] = hi ? p2 : a0;
+        x[3] = hi ? a3 : p1;
+        x[1] = hi ? p3 : a1;
     }
 }
 

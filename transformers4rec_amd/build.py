@@ -18,6 +18,10 @@ SOURCES = ["gemm_f32.hip", "gemm_half.hip", "elementwise.hip", "embedding.hip", 
            "xlnet_attn_long.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wno-unused-result"]
+# per-source additions.  head_split.hip: no NaN is ever looked at there (its maxima are over finite scores and -inf masks), and
+# with NaNs honoured every fmaxf operand that comes out of a cross-lane move or a select is first canonicalised (v_max_f32 v, v, v:
+# 31 of the one-pass head loop's 408 vector instructions); infinities stay honoured (-inf is the mask value).  Same bits.
+EXTRA_FLAGS = {"head_split.hip": ["-fno-honor-nans"]}
 
 
 def _hipcc():
@@ -44,7 +48,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(s, []) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

@@ -15,7 +15,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unuse
 n=0
 pids=()
 for src in $CSRC/*.hip $ROOT/tools/experimental/wgrad_stream.hip $ROOT/tools/experimental/wgrad_units.hip; do
-  extra=""; [ "$(basename $src)" = "head_split.hip" ] && extra="-fno-honor-nans"      # as transformers4rec_amd/build.py: EXTRA_FLAGS
+  extra=""; case "$(basename $src)" in head_split.hip|xlnet_fused.hip|xlnet_fused_attn.hip|xlnet_attn_block.hip) extra="-fno-honor-nans";; esac      # as transformers4rec_amd/build.py: EXTRA_FLAGS
   /opt/rocm/bin/hipcc $FLAGS $extra -c $src -o $OUT/exp_obj/$(basename ${src%.hip}).o & pids+=($!)
   n=$((n + 1))
   if [ $((n % 8)) -eq 0 ]; then for p in "${pids[@]}"; do wait $p; done; pids=(); fi

@@ -18,10 +18,10 @@ SOURCES = ["gemm_f32.hip", "gemm_half.hip", "elementwise.hip", "embedding.hip", 
            "xlnet_attn_long.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wno-unused-result"]
-# per-source additions.  head_split.hip: no NaN is ever looked at there (its maxima are over finite scores and -inf masks), and
+# per-source additions.  The head and the token-tile kernels: no NaN is ever looked at there (its maxima are over finite scores and -inf masks), and
 # with NaNs honoured every fmaxf operand that comes out of a cross-lane move or a select is first canonicalised (v_max_f32 v, v, v:
 # 31 of the one-pass head loop's 408 vector instructions); infinities stay honoured (-inf is the mask value).  Same bits.
-EXTRA_FLAGS = {"head_split.hip": ["-fno-honor-nans"]}
+EXTRA_FLAGS = {f: ["-fno-honor-nans"] for f in ("head_split.hip", "xlnet_fused.hip", "xlnet_fused_attn.hip", "xlnet_attn_block.hip")}
 
 
 def _hipcc():

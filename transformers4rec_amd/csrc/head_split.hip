@@ -720,14 +720,29 @@ __global__ __launch_bounds__(256, WPS) void head_dw_split_kernel(const float* __
         ri_lse = lse[row];
         ri_lab = labels[row];
     };
+    // Addresses: a block that lies wholly inside the N rows (all but the last one) is AFFINE in the row -- one 64-bit product per
+    // lane and block for its first row, the other fifteen rows at compile-time multiples of the (uniform) pitch.  The clamped form
+    // min(row, N - 1) * ld per element, needed only by the last block, was 48 quarter-rate integer multiplies + ~50 other address
+    // instructions per lane and block: more issue cycles than the block's 24 matrix instructions (round 6, from the ISA).
     auto x_load = [&](float (&x)[16], int b) __attribute__((always_inline)) {
+        if (b * 32 + 32 <= N) {             // workgroup-uniform
+            const float* base = lp + (long)(b * 32 + 8 * khalf) * ld;
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+            for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float* a = lp + (long)min(b * 32 + 16 * s + 8 * khalf + e, N - 1) * ld;
-                x[8 * s + e] = NT ? __builtin_nontemporal_load(a) : *a;
-            }
+                for (int e = 0; e < 8; ++e) {
+                    const float* a = base + (long)(16 * s + e) * ld;
+                    x[8 * s + e] = NT ? __builtin_nontemporal_load(a) : *a;
+                }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float* a = lp + (long)min(b * 32 + 16 * s + 8 * khalf + e, N - 1) * ld;
+                    x[8 * s + e] = NT ? __builtin_nontemporal_load(a) : *a;
+                }
+        }
     };
     auto s_store = [&](int buf, int b) __attribute__((always_inline)) {
 #pragma unroll
